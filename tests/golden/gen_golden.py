@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (/root/reference) in this
+container on tiny synthetic clips.  The reference never travels to the GPU box:
+only the .npz files written next to this script do.  No-op when /root/reference
+is absent.
+
+Neither `cv2` nor `ffmpeg` is installed here, so both are replaced by stub
+modules *before* the reference is imported.  The cv2 stub RECORDS every
+cv2.circle call; every numeric step of the reference up to that call
+(densify, pose load/compose/seek/slerp, float32 inverse, transform, crop,
+project, mask, truncation, colour choice, draw order) executes for real.
+What stays unpinned is OpenCV's own arithmetic (circle footprint, remap,
+JPEG decode) -- see DESIGN.md "parity pins".
+
+Fixtures (all small, deterministic, seeded):
+  clip_<tag>.npz   per-clip: static maps, calibration, pose tracks, per-frame
+                   world2chassis/crop/projection outputs, cv2.circle stream
+  pose_seek.npz    seek_by_timestamp edge cases (exact / interpolated / raise)
+  mosaic.npz       VideoGenerator.concate_image layout
+Usage:  python tests/golden/gen_golden.py
+"""
+import json
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+
+
+class _Recorder:
+    def __init__(self):
+        self.calls = []
+
+
+def install_stubs(rec):
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR = 1
+    cv2.INTER_NEAREST = 0
+    cv2.CV_32FC1 = 5
+    cv2.IMREAD_ANYDEPTH = 2
+
+    def circle(img, center, radius, color, thickness):
+        rec.calls.append((int(center[0]), int(center[1]), int(radius),
+                          int(color[0]), int(color[1]), int(color[2]), int(thickness),
+                          type(center[0]).__name__))
+        return img
+
+    def imread(path, flags=None):
+        return np.zeros((900, 1600, 3), np.uint8)
+
+    def initUndistortRectifyMap(K, d, R, newK, size, m1type):
+        return (size, None)
+
+    def remap(img, mapx, mapy, interpolation=None):
+        W, H = mapx
+        return np.zeros((H, W, 3), np.uint8)
+
+    cv2.circle = circle
+    cv2.imread = imread
+    cv2.initUndistortRectifyMap = initUndistortRectifyMap
+    cv2.remap = remap
+    sys.modules["cv2"] = cv2
+    sys.modules["ffmpeg"] = types.ModuleType("ffmpeg")
+
+
+def pack_instances(prefix, instances, out):
+    """list[{"class","points"}] -> flat arrays under out[prefix_*]."""
+    classes = [ins["class"] for ins in instances]
+    counts = np.asarray([ins["points"].shape[0] for ins in instances], np.int64)
+    if len(instances):
+        pts = np.concatenate([np.ascontiguousarray(ins["points"]) for ins in instances], axis=0)
+    else:
+        pts = np.zeros((0, 3))
+    out[prefix + "_classes"] = np.asarray(classes, dtype="U32")
+    out[prefix + "_counts"] = counts
+    out[prefix + "_points"] = pts
+    out[prefix + "_dtype"] = np.asarray(str(pts.dtype))
+
+
+def run_clip(tag, clip_kwargs, mutate=None):
+    from cama_amd.synth import make_clip, DEFAULT_CAMA_CONFIGS
+    rec = _Recorder()
+    install_stubs(rec)
+    for m in [k for k in sys.modules if k == "cama" or k.startswith("cama.")]:
+        del sys.modules[m]
+    sys.path.insert(0, REFERENCE)
+    try:
+        from cama.dataset import ClipManager
+        from cama.dataset_reader import DatasetReader
+        from cama.tools import VideoGenerator
+        import cama as _cama
+        assert _cama.__path__[0].startswith(REFERENCE), _cama.__path__
+        tmp = tempfile.mkdtemp(prefix="golden_")
+        clip = os.path.join(tmp, "clip")
+        make_clip(clip, **clip_kwargs)
+        if mutate is not None:
+            mutate(clip)
+        out = {"clip_kwargs": np.asarray(json.dumps(clip_kwargs)),
+               "mutate": np.asarray(mutate.__name__ if mutate else "")}
+        configs = dict(DEFAULT_CAMA_CONFIGS)
+        cm = ClipManager(configs, clip)
+        # calibration as the reference derived it
+        for c in cm.cm_list:
+            out[f"cal_{c.camera_name}_chassis2camera"] = np.asarray(c.chassis2camera)
+            out[f"cal_{c.camera_name}_K"] = np.asarray(c.K)
+            out[f"cal_{c.camera_name}_K_origin"] = np.asarray(c.K_origin)
+            out[f"cal_{c.camera_name}_wh"] = np.asarray([c.width, c.height, c.width_origin, c.height_origin])
+        datasets = [d for d in ("cama", "nuscenes") if d in cm.instance_maps]
+        out["datasets"] = np.asarray(datasets, dtype="U16")
+        for ds in datasets:
+            pack_instances(f"{ds}_static", cm.instance_maps[ds], out)
+            # pose track exactly as yield_frame builds it (dataset.py:78-87)
+            dr = DatasetReader(clip)
+            pt = cm.get_pt_cama(dr) if ds == "cama" else cm.get_pt_nuscenes(dr)
+            out[f"{ds}_pose_abs"] = np.asarray(pt.absolute_transform)
+            out[f"{ds}_pose_stamps"] = np.asarray(pt.timestamps)
+            stamps = dr.get_sensor_timestamp(configs["camera_main"], sync=True)
+            out[f"{ds}_frame_stamps"] = np.asarray(stamps)
+            w2c = {}
+            for idx in range(1, len(stamps)):
+                try:
+                    c2w = pt.seek_by_timestamp(stamps[idx], t_max_diff=0.5, interpolate=True).astype(np.float32)
+                except RuntimeError:
+                    continue
+                w2c[idx] = np.linalg.inv(c2w)
+            frame_ids = []
+            for image_idx, instance_map in cm.yield_frame(ds):
+                frame_ids.append(image_idx)
+                key = f"{ds}_f{image_idx}"
+                out[key + "_w2c"] = w2c[image_idx]
+                pack_instances(key + "_crop", instance_map, out)
+                maps_2d = cm.project_all_camera(instance_map)
+                rec.calls.clear()
+                for c in cm.cm_list:
+                    pack_instances(f"{key}_{c.camera_name}_vu", maps_2d[c.camera_name], out)
+                    n0 = len(rec.calls)
+                    img = np.zeros((c.height, c.width, 3), np.uint8)
+                    c.render_maps(img, maps_2d[c.camera_name])
+                    calls = rec.calls[n0:]
+                    assert all(k[2] == 2 and k[6] == -1 for k in calls)
+                    assert all(k[7] == "int32" for k in calls), set(k[7] for k in calls)
+                    arr = np.asarray([k[:2] + k[3:6] for k in calls], np.int32).reshape(-1, 5)
+                    out[f"{key}_{c.camera_name}_circles"] = arr   # u, v, b, g, r  in draw order
+            out[f"{ds}_frame_ids"] = np.asarray(frame_ids, np.int64)
+        np.savez_compressed(os.path.join(HERE, f"clip_{tag}.npz"), **out)
+        print(f"clip_{tag}.npz: {len(out)} arrays, datasets={datasets}, "
+              f"frames={ {ds: out[ds + '_frame_ids'].tolist() for ds in datasets} }")
+        shutil.rmtree(tmp)
+    finally:
+        sys.path.remove(REFERENCE)
+        for m in [k for k in sys.modules if k == "cama" or k.startswith("cama.")]:
+            del sys.modules[m]
+
+
+def mutate_pose_gaps(clip):
+    """Create (a) a gap > 0.5 s between two pose rows, (b) a track that ends early,
+    so some frames raise RuntimeError and are skipped (dataset.py:93-96)."""
+    for name in ("scmv_camera_front.txt", "wigo_offset_clip.txt"):
+        p = os.path.join(clip, "odometry", name)
+        rows = np.loadtxt(p)
+        keep = np.ones(len(rows), bool)
+        keep[3] = False            # gap of 1.0 s around frame index 2
+        keep[-3:] = False          # last frames out of range
+        np.savetxt(p, rows[keep])
+
+
+def run_pose_seek():
+    rec = _Recorder()
+    install_stubs(rec)
+    sys.path.insert(0, REFERENCE)
+    try:
+        from cama.pose_transformer import PoseTransformer, SlerpTransform, invT
+        from scipy.spatial.transform import Rotation
+        rng = np.random.default_rng(7)
+        P = 9
+        stamps = 100.0 + np.cumsum(np.r_[0.0, rng.uniform(0.2, 0.45, P - 1)])
+        stamps[5:] += 0.4            # one gap > 0.5 s between rows 4 and 5
+        quat = Rotation.from_rotvec(rng.normal(0, 0.4, (P, 3))).as_quat()
+        xyz = np.cumsum(rng.normal(0, 1.0, (P, 3)), axis=0)
+        tum = np.concatenate([stamps[:, None], xyz, quat], axis=1)
+        ext = np.eye(4)
+        ext[:3, :3] = Rotation.from_rotvec([0.1, -0.2, 0.3]).as_matrix()
+        ext[:3, 3] = [0.5, -0.1, 1.2]
+        out = {"tum": tum, "ext": ext}
+        pt = PoseTransformer()
+        pt.loadarray(tum)
+        out["abs_loaded"] = np.asarray(pt.absolute_transform)
+        out["rel_loaded"] = np.asarray(pt.relative_transform)
+        pt.right_rotate(ext)
+        out["abs_right_rotate"] = np.asarray(pt.absolute_transform)
+        pt2 = PoseTransformer()
+        pt2.loadarray(tum)
+        pt2.normalize2center()
+        out["abs_normalize2center"] = np.asarray(pt2.absolute_transform)
+        out["invT_ext"] = invT(ext)
+        out["slerp_03"] = SlerpTransform(out["abs_loaded"][1], out["abs_loaded"][2], 0.3)
+        queries = [float(stamps[0]), float(stamps[3]), float(stamps[3] + 5e-10), float(stamps[0] - 5e-10),
+                   float(stamps[0] - 1e-3), float(stamps[-1] + 1e-3), float(stamps[-1]),
+                   float((stamps[1] + stamps[2]) / 2), float(stamps[2] + 0.01), float(stamps[4] + 0.1),
+                   float(stamps[6] + 0.123), float(stamps[7] - 1e-7)]
+        res, ok = [], []
+        for q in queries:
+            try:
+                res.append(pt.seek_by_timestamp(q, t_max_diff=0.5, interpolate=True))
+                ok.append(1)
+            except RuntimeError:
+                res.append(np.full((4, 4), np.nan))
+                ok.append(0)
+        out["queries"] = np.asarray(queries)
+        out["seek_ok"] = np.asarray(ok, np.int8)
+        out["seek_result"] = np.asarray(res)
+        res, ok = [], []
+        for q in queries:
+            try:
+                res.append(pt.seek_by_timestamp(q, t_max_diff=0.5, interpolate=False))
+                ok.append(1)
+            except RuntimeError:
+                res.append(np.full((4, 4), np.nan))
+                ok.append(0)
+        out["seek_nearest_ok"] = np.asarray(ok, np.int8)
+        out["seek_nearest_result"] = np.asarray(res)
+        np.savez_compressed(os.path.join(HERE, "pose_seek.npz"), **out)
+        print("pose_seek.npz: ok flags", out["seek_ok"].tolist(), out["seek_nearest_ok"].tolist())
+    finally:
+        sys.path.remove(REFERENCE)
+        for m in [k for k in sys.modules if k == "cama" or k.startswith("cama.")]:
+            del sys.modules[m]
+
+
+def run_mosaic():
+    rec = _Recorder()
+    install_stubs(rec)
+    sys.path.insert(0, REFERENCE)
+    try:
+        from cama.tools import VideoGenerator
+        from cama_amd.synth import CAMERA_NAMES
+        rng = np.random.default_rng(3)
+        H, W = 6, 8
+        imgs = {n: rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for n in CAMERA_NAMES}
+        vg = object.__new__(VideoGenerator)
+        mosaic = VideoGenerator.concate_image(vg, imgs)
+        out = {"mosaic": mosaic}
+        for n in CAMERA_NAMES:
+            out["img_" + n] = imgs[n]
+        np.savez_compressed(os.path.join(HERE, "mosaic.npz"), **out)
+        print("mosaic.npz:", mosaic.shape)
+    finally:
+        sys.path.remove(REFERENCE)
+        for m in [k for k in sys.modules if k == "cama" or k.startswith("cama.")]:
+            del sys.modules[m]
+
+
+def main():
+    if not os.path.isdir(REFERENCE):
+        print("reference not present; golden vectors are committed, nothing to do")
+        return 0
+    sys.path.insert(0, REPO)
+    run_clip("a", dict(n_frames=5, seed=0, n_lines=6, verts_per_line=5, line_len_m=2.0, raster_size=400))
+    run_clip("b_exact", dict(n_frames=4, seed=1, n_lines=4, verts_per_line=4, line_len_m=1.5,
+                             raster_size=300, pose_offset_s=0.0))
+    run_clip("c_gaps", dict(n_frames=8, seed=2, n_lines=4, verts_per_line=3, line_len_m=1.0,
+                            raster_size=300), mutate=mutate_pose_gaps)
+    run_clip("d_nusonly", dict(n_frames=3, seed=3, n_lines=5, verts_per_line=6, line_len_m=1.0,
+                               raster_size=300, with_cama=False))
+    run_clip("e_crop", dict(n_frames=3, seed=4, n_lines=3, verts_per_line=4, line_len_m=14.0,
+                            raster_size=300, with_cama=False))
+    run_pose_seek()
+    run_mosaic()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
