@@ -1,0 +1,198 @@
+/*
+ * oracle/cama_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the per-frame arithmetic of the CAMA
+ * reprojection hot path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (cama_amd/) never does.
+ *
+ * What is restated, and from where:
+ *   oracle_frame_project  <- cama/reproject.py:108-116 (homogeneous transform),
+ *                            :118-131 (inclusive crop box), :187-205 (K, z>0,
+ *                            divide, in-image mask, (v,u) output order);
+ *                            cama/dataset.py:101-112 (world->chassis once, then
+ *                            chassis->camera per camera on the CROPPED points).
+ *   oracle_circle_fill    <- cv2.circle(img,(u,v),r,color,-1) as called at
+ *                            cama/reproject.py:256.  OpenCV is an un-vendored,
+ *                            unpinned dependency (requirements.txt:5) that is
+ *                            not installed on either box: this is a restatement
+ *                            of its published integer midpoint algorithm
+ *                            (imgproc/drawing.cpp, static Circle(), fill branch,
+ *                            taken for thickness<0, LINE_8, shift 0).
+ *                            PARITY UNPINNED for the footprint itself.
+ *   oracle_render_frame   <- cama/reproject.py:246-257 (truncate to int32,
+ *                            sequential draw, last writer wins) + tools.py:22-25
+ *                            (2x3 mosaic).
+ *
+ * Arithmetic contract (pinned against the golden vectors, tests/golden/):
+ * numpy's float64 matmul of a (4,4)/(3,3) matrix with a (4,n)/(3,n) block is,
+ * for n >= 2, a k-ordered FMA chain  acc = m0*p0; acc = fma(m1,p1,acc); ...
+ * (measured in this container against OpenBLAS 0.3.29: 0 mismatches in 4e5
+ * outputs; separate mul/add mismatches in ~30 %).  This file states that chain
+ * explicitly with fma(), so it is deterministic on any host; the HIP kernels
+ * state the same chain with __builtin_fma.  Single-point instances (n == 1) go
+ * through BLAS gemv in the reference and may differ by 1 ulp (documented).
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+/* ---- 3x4 affine rows of a 4x4 row-major matrix applied to (x,y,z,1) ---- */
+static inline void xform_rows(const double *T, double x, double y, double z,
+                              double *ox, double *oy, double *oz)
+{
+    double a;
+    a = T[0] * x;  a = fma(T[1], y, a);  a = fma(T[2], z, a);  a = fma(T[3], 1.0, a);  *ox = a;
+    a = T[4] * x;  a = fma(T[5], y, a);  a = fma(T[6], z, a);  a = fma(T[7], 1.0, a);  *oy = a;
+    a = T[8] * x;  a = fma(T[9], y, a);  a = fma(T[10], z, a); a = fma(T[11], 1.0, a); *oz = a;
+}
+
+static inline void k_rows(const double *K, double x, double y, double z,
+                          double *o0, double *o1, double *o2)
+{
+    double a;
+    a = K[0] * x; a = fma(K[1], y, a); a = fma(K[2], z, a); *o0 = a;
+    a = K[3] * x; a = fma(K[4], y, a); a = fma(K[5], z, a); *o1 = a;
+    a = K[6] * x; a = fma(K[7], y, a); a = fma(K[8], z, a); *o2 = a;
+}
+
+/*
+ * One frame.  xyz: N x 3 map-frame points, float (is_f64 == 0) or double.
+ * w2c: 4x4 row-major doubles (the float32 inverse, promoted exactly).
+ * c2cam: C x 16, K: C x 9 doubles.  crop: xmin,xmax,ymin,ymax,zmin,zmax.
+ * Outputs (any may be NULL): chassis N x 3, crop_mask N,
+ * vu C x N x 2 (v first), vis C x N.  Entries of vu where vis==0 are left
+ * untouched except that they are written when the point passed the crop
+ * (values may be inf/nan exactly like the reference's intermediate).
+ */
+void oracle_frame_project(const void *xyz, int is_f64, int64_t N,
+                          const double *w2c, const double *crop,
+                          const double *c2cam, const double *K, int C,
+                          int W, int H,
+                          double *chassis, uint8_t *crop_mask,
+                          double *vu, uint8_t *vis)
+{
+    for (int64_t i = 0; i < N; i++) {
+        double x, y, z;
+        if (is_f64) {
+            const double *p = (const double *)xyz + 3 * i;
+            x = p[0]; y = p[1]; z = p[2];
+        } else {
+            const float *p = (const float *)xyz + 3 * i;
+            x = p[0]; y = p[1]; z = p[2];
+        }
+        double cx, cy, cz;
+        xform_rows(w2c, x, y, z, &cx, &cy, &cz);
+        if (chassis) { chassis[3 * i] = cx; chassis[3 * i + 1] = cy; chassis[3 * i + 2] = cz; }
+        int in = (cx >= crop[0]) & (cx <= crop[1]) & (cy >= crop[2]) & (cy <= crop[3]) &
+                 (cz >= crop[4]) & (cz <= crop[5]);
+        if (crop_mask) crop_mask[i] = (uint8_t)in;
+        for (int c = 0; c < C; c++) {
+            uint8_t ok = 0;
+            if (in) {
+                double px, py, pz, h0, h1, h2;
+                xform_rows(c2cam + 16 * c, cx, cy, cz, &px, &py, &pz);
+                k_rows(K + 9 * c, px, py, pz, &h0, &h1, &h2);
+                double u = h0 / h2, v = h1 / h2, w = h2 / h2;
+                ok = (uint8_t)((h2 > 0) & (w > 0) & (u >= 0) & (u < (double)W) & (v >= 0) & (v < (double)H));
+                if (vu) { vu[((int64_t)c * N + i) * 2] = v; vu[((int64_t)c * N + i) * 2 + 1] = u; }
+            }
+            if (vis) vis[(int64_t)c * N + i] = ok;
+        }
+    }
+}
+
+/* Generic single-transform helper (reproject.py:108-116) for API-level checks. */
+void oracle_transform(const double *xyz, int64_t N, const double *T, double *out)
+{
+    for (int64_t i = 0; i < N; i++)
+        xform_rows(T, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], out + 3 * i, out + 3 * i + 1, out + 3 * i + 2);
+}
+
+/* ---- OpenCV-style filled circle on an H x W x 3 uint8 image with row stride `step` bytes ---- */
+static inline void hline(uint8_t *row, int x0, int x1, const uint8_t *bgr)
+{
+    for (int x = x0; x <= x1; x++) { row[3 * x] = bgr[0]; row[3 * x + 1] = bgr[1]; row[3 * x + 2] = bgr[2]; }
+}
+
+void oracle_circle_fill(uint8_t *img, int H, int W, int64_t step, int cx, int cy, int radius,
+                        int b, int g, int r)
+{
+    const uint8_t bgr[3] = {(uint8_t)b, (uint8_t)g, (uint8_t)r};
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    int inside = cx >= radius && cx < W - radius && cy >= radius && cy < H - radius;
+    while (dx >= dy) {
+        int mask;
+        int y11 = cy - dy, y12 = cy + dy, y21 = cy - dx, y22 = cy + dx;
+        int x11 = cx - dx, x12 = cx + dx, x21 = cx - dy, x22 = cx + dy;
+        if (inside) {
+            hline(img + (int64_t)y11 * step, x11, x12, bgr);
+            hline(img + (int64_t)y12 * step, x11, x12, bgr);
+            hline(img + (int64_t)y21 * step, x21, x22, bgr);
+            hline(img + (int64_t)y22 * step, x21, x22, bgr);
+        } else if (x11 < W && x12 >= 0 && y21 < H && y22 >= 0) {
+            if (x11 < 0) x11 = 0;
+            if (x12 > W - 1) x12 = W - 1;
+            if ((unsigned)y11 < (unsigned)H) hline(img + (int64_t)y11 * step, x11, x12, bgr);
+            if ((unsigned)y12 < (unsigned)H) hline(img + (int64_t)y12 * step, x11, x12, bgr);
+            if (x21 < W && x22 >= 0) {
+                if (x21 < 0) x21 = 0;
+                if (x22 > W - 1) x22 = W - 1;
+                if ((unsigned)y21 < (unsigned)H) hline(img + (int64_t)y21 * step, x21, x22, bgr);
+                if ((unsigned)y22 < (unsigned)H) hline(img + (int64_t)y22 * step, x21, x22, bgr);
+            }
+        }
+        dy++;
+        err += plus;
+        plus += 2;
+        mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
+/* Per-row half-widths of the union footprint of the algorithm above, hw[0..radius];
+ * row offsets +-k get half-width hw[k]; returns radius+1.  Used by tests to derive
+ * the table the HIP overlay kernel takes as data. */
+int oracle_circle_halfwidths(int radius, int *hw)
+{
+    for (int k = 0; k <= radius; k++) hw[k] = -1;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        if (dx > hw[dy]) hw[dy] = dx;
+        if (dy > hw[dx]) hw[dx] = dy;
+        dy++; err += plus; plus += 2;
+        int mask = (err <= 0) - 1;
+        err -= minus & mask; dx += mask; minus -= mask & 2;
+    }
+    return radius + 1;
+}
+
+/*
+ * Render one frame: for every camera copy src[c] into the mosaic cell
+ * (tools.py:22-25: row = c/3, col = c%3 for the fixed 6-camera order) and then
+ * draw the visible points in index order (reproject.py:246-257).
+ * vu: C x N x 2 doubles (v,u), vis: C x N, colour_id: N (0 = lane grey, 1 = gold),
+ * palette_bgr: 2 x 3.  src: C x H x W x 3.  mosaic: (rows*H) x (cols*W) x 3.
+ */
+void oracle_render_frame(const uint8_t *src, uint8_t *mosaic, int C, int H, int W,
+                         int cols, const double *vu, const uint8_t *vis,
+                         const uint8_t *colour_id, int64_t N, int radius,
+                         const uint8_t *palette_bgr)
+{
+    int64_t step = (int64_t)cols * W * 3;
+    for (int c = 0; c < C; c++) {
+        uint8_t *cell = mosaic + (int64_t)(c / cols) * H * step + (int64_t)(c % cols) * W * 3;
+        for (int y = 0; y < H; y++)
+            memcpy(cell + (int64_t)y * step, src + (((int64_t)c * H + y) * W) * 3, (size_t)W * 3);
+        for (int64_t i = 0; i < N; i++) {
+            if (!vis[(int64_t)c * N + i]) continue;
+            int32_t vi = (int32_t)vu[((int64_t)c * N + i) * 2];      /* astype(np.int32): truncation */
+            int32_t ui = (int32_t)vu[((int64_t)c * N + i) * 2 + 1];
+            const uint8_t *p = palette_bgr + 3 * colour_id[i];
+            oracle_circle_fill(cell, H, W, step, ui, vi, radius, p[0], p[1], p[2]);
+        }
+    }
+}

@@ -1,0 +1,423 @@
+"""oracle/cama_oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+numpy/scipy restatement ("port") of the reference's CPU path for the CAMA
+reprojection hot path, written as plain functions.  It keeps the reference's
+loop structure (per frame -> per camera -> per instance numpy calls -> per point
+circle call) because that structure IS the CPU baseline bench.py times
+(`cpu_baseline.kind == "port"`).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; cama_amd/ never does.
+
+Pinned against tests/golden/*.npz, which were produced by importing the real
+reference in the build container (tests/golden/gen_golden.py).
+PARITY UNPINNED beyond the OpenCV boundary: the filled-circle footprint
+(oracle_circle_fill in cama_oracle.c), cv2.remap and cv2.imread have no golden
+vectors because OpenCV is installed on neither box.
+
+Each function cites the reference lines it follows (paths under /root/reference).
+"""
+import ctypes
+import json
+import os
+from os.path import join
+
+import numpy as np
+from scipy.spatial.transform import Rotation, Slerp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+GREY_RGB = (211, 211, 211)      # cama/reproject.py:14  "lane_marking"
+GOLD_RGB = (255, 215, 0)        # cama/reproject.py:16  "Crosswalk_Line" (used for every other class, :251-252)
+CROP_BOX = (-50.0, 50.0, -100.0, 100.0, -200.0, 200.0)   # cama/reproject.py:28-34
+STEP = 0.1                      # cama/reproject.py:23
+MAP_EXTENT = 600.0              # cama/reproject.py:26-27
+MOSAIC_ORDER = ["camera_front_left", "camera_front", "camera_front_right",
+                "camera_rear_left", "camera_rear", "camera_rear_right"]   # cama/tools.py:23-24
+
+
+def lib():
+    """ctypes handle of oracle/_build/liboracle.so (make -C oracle)."""
+    global _LIB
+    if _LIB is None:
+        path = join(_HERE, "_build", "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = ctypes.CDLL(path)
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        L.oracle_frame_project.argtypes = [vp, i32, i64, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+        L.oracle_frame_project.restype = None
+        L.oracle_transform.argtypes = [vp, i64, vp, vp]
+        L.oracle_transform.restype = None
+        L.oracle_circle_fill.argtypes = [vp, i32, i32, i64, i32, i32, i32, i32, i32, i32]
+        L.oracle_circle_fill.restype = None
+        L.oracle_circle_halfwidths.argtypes = [i32, vp]
+        L.oracle_circle_halfwidths.restype = i32
+        L.oracle_render_frame.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, i32, vp]
+        L.oracle_render_frame.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+# --------------------------------------------------------------------------- static map
+def densify(line_points):
+    """cama/reproject.py:51-63 == :81-93.  line_points: (k,2) float32, k >= 2."""
+    out = []
+    seg_len = np.linalg.norm(line_points[1:] - line_points[:-1], axis=-1)
+    for s in range(len(seg_len)):
+        a = line_points[s]
+        b = line_points[s + 1]
+        num = int(seg_len[s] / STEP)
+        if num == 0:
+            continue
+        for j in range(num):
+            out.append(a + (b - a) / num * j)
+    return np.array(out)
+
+
+def pixel_to_world_xy(pixel_xy):
+    """cama/reproject.py:36-40 (note the axis swap; centre is (0,0))."""
+    w = np.zeros_like(pixel_xy)
+    w[:, 0] = pixel_xy[:, 1] * STEP - MAP_EXTENT / 2 + 0
+    w[:, 1] = pixel_xy[:, 0] * STEP - MAP_EXTENT / 2 + 0
+    return w
+
+
+def static_map_cama(bev_height, labels):
+    """cama/reproject.py:72-106."""
+    result = []
+    for label in labels:
+        pts = label["data"]
+        if len(pts) <= 1:
+            continue
+        dense = densify(np.array(pts).astype(np.float32))
+        pix = dense.round().astype(np.uint16)
+        pix = pix[:, ::-1]
+        pix = pix.clip(0, bev_height.shape[0] - 1)
+        h = bev_height[pix[:, 0], pix[:, 1]]
+        xy = pixel_to_world_xy(dense)
+        xyz = np.concatenate((xy, h[:, None]), axis=-1).reshape(-1, 3)
+        result.append({"class": label["attrs"]["type"], "points": xyz})
+    return result
+
+
+def static_map_nuscenes(labels):
+    """cama/reproject.py:42-70."""
+    result = []
+    for label in labels:
+        pts = label["data"]
+        if len(pts) <= 1:
+            continue
+        dense = densify(np.array(pts).astype(np.float32))
+        h = np.zeros_like(dense[:, 0])
+        xyz = np.concatenate((dense, h[:, None]), axis=-1).reshape(-1, 3)
+        result.append({"class": label["attrs"]["type"], "points": xyz})
+    return result
+
+
+# --------------------------------------------------------------------------- pose track
+def inv_rigid(T):
+    """cama/pose_transformer.py:8-21."""
+    Rt = T[:3, :3].T
+    out = np.eye(4)
+    out[:3, :3] = Rt
+    out[:3, 3] = -Rt @ T[:3, 3]
+    return out
+
+
+def tum_to_poses(tum):
+    """cama/pose_transformer.py:429-438: rows t x y z qx qy qz qw -> (stamps (P,1), list of 4x4)."""
+    assert tum.shape[1] == 8
+    P = tum.shape[0]
+    M = np.zeros((P, 4, 4))
+    M[:, 3, 3] = 1
+    M[:, :3, :3] = Rotation.from_quat(tum[:, 4:8]).as_matrix()
+    M[:, :3, 3] = tum[:, 1:4]
+    return tum[:, 0:1], list(M)
+
+
+def right_compose(poses, ext):
+    """cama/pose_transformer.py:520-537."""
+    return [T @ ext for T in poses]
+
+
+def normalize_to_center(poses):
+    """cama/pose_transformer.py:324-336."""
+    ref_inv = inv_rigid(poses[len(poses) // 2])
+    return [ref_inv @ T for T in poses]
+
+
+def slerp_transform(left, right, ratio):
+    """cama/pose_transformer.py:24-44."""
+    assert 0 <= ratio <= 1
+    keys = Rotation.from_matrix(np.concatenate([left[np.newaxis, :3, :3], right[np.newaxis, :3, :3]], axis=0))
+    rot = Slerp([0, 1], keys)(ratio).as_matrix()
+    out = left * (1 - ratio) + right * ratio
+    out[:3, :3] = rot
+    return out
+
+
+def seek_pose(stamps, poses, query, max_diff, interpolate):
+    """cama/pose_transformer.py:589-652.  stamps: (P,1).  Raises RuntimeError like the reference."""
+    assert isinstance(query, float) and isinstance(max_diff, float)
+    if len(poses) == 0:
+        raise RuntimeError("No poses found, pleas load poses first")
+    if stamps.shape[0] == 0:
+        raise RuntimeError("No timestamps found, pleas load timestamps first")
+    assert np.all(stamps[1:, 0] >= stamps[:-1, 0]), "timestamps must be sorted"
+    hit = np.where(np.isclose(stamps[:, 0], query, rtol=1e-20, atol=1e-9))[0]
+    if hit.size > 0:
+        return poses[hit[0]]
+    right = np.searchsorted(stamps[:, 0], query, side="left")
+    left = right - 1
+    if interpolate:
+        if right >= stamps.shape[0]:
+            raise RuntimeError("query_time is out of range.")
+        if right == 0 and -1e-9 < (query - stamps[0]) < 0:
+            right, left = 1, 0
+        elif query - stamps[0] < -1e-9:
+            raise RuntimeError("query_time is out of range.")
+        gap = stamps[right] - stamps[left]
+        if gap > max_diff:
+            raise RuntimeError(f"time_diff = {gap} is greater than t_max_diff {max_diff}")
+        ratio = (query - stamps[left]) / gap
+        return slerp_transform(poses[left], poses[right], ratio)
+    dl = query - stamps[left] if left >= 0 else float("inf")
+    dr = stamps[right] - query if right < stamps.shape[0] else float("inf")
+    d = min(dl, dr)[0]
+    if d > max_diff:
+        raise RuntimeError(f"time_diff = {d} is greater than t_max_diff {max_diff}")
+    return poses[left if dl < dr else right]
+
+
+# --------------------------------------------------------------------------- clip reader subset
+def read_attribute(clip_path):
+    """cama/dataset_reader.py:29-37."""
+    p = join(clip_path, "attribute.json")
+    if not os.path.exists(p):
+        raise FileNotFoundError("can not find {}".format(p))
+    with open(p, "r") as f:
+        return json.load(f)
+
+
+def sensor_seconds(attribute, sensor, sync=True):
+    """cama/dataset_reader.py:39-43."""
+    ts = np.asarray(attribute["sync" if sync else "unsync"][sensor]).astype(np.double)
+    ts /= 1000.0
+    return ts.tolist()
+
+
+def _direct_extrinsic(cal, a, b):
+    """cama/dataset_reader.py:150-168."""
+    if a == b:
+        return np.eye(4, dtype=np.float32)
+    if f"{a}_2_{b}" in cal:
+        return np.asarray(cal[f"{a}_2_{b}"])
+    if f"{b}_2_{a}" in cal:
+        return inv_rigid(np.asarray(cal[f"{b}_2_{a}"]))
+    return None
+
+
+def extrinsic(attribute, a, b):
+    """cama/dataset_reader.py:170-248 (direct, inverse, else BFS shortest path over the calibration graph)."""
+    cal = attribute["calibration"]
+    T = _direct_extrinsic(cal, a, b)
+    if T is not None:
+        return T
+    graph = {}
+    for key in cal:
+        if "_2_" in key:
+            s, d = key.split("_2_")
+            graph.setdefault(s, []).append(d)
+            graph.setdefault(d, []).append(s)
+    seen, queue, path = [], [[a]], None
+    while queue and path is None:
+        cur = queue.pop(0)
+        node = cur[-1]
+        if node in seen:
+            continue
+        for nb in graph.get(node, []):
+            nxt = cur + [nb]
+            queue.append(nxt)
+            if nb == b:
+                path = nxt
+                break
+        seen.append(node)
+    if path is None:
+        print("extrinsic path not found!")
+        return None
+    T = np.eye(4, dtype=np.float32)
+    for i in range(len(path) - 1):
+        T = _direct_extrinsic(cal, path[i], path[i + 1]) @ T
+    return T
+
+
+def camera_model(attribute, name, output_size=(540, 960)):
+    """cama/reproject.py:164-182: chassis->camera, K scaled to the output size."""
+    intr = attribute["calibration"][name]
+    K0 = np.asarray(intr.get("K"))
+    W0, H0 = intr.get("image_width"), intr.get("image_height")
+    H, W = output_size
+    K = K0.copy()
+    K[0, :] = K[0, :] * W / W0
+    K[1, :] = K[1, :] * H / H0
+    return {"name": name, "chassis2camera": extrinsic(attribute, "chassis", name),
+            "K": K, "K_origin": K0, "W": W, "H": H, "W0": W0, "H0": H0,
+            "d_origin": np.asarray(intr.get("d"))}
+
+
+# --------------------------------------------------------------------------- per-frame geometry
+def transform_instances(instances, T):
+    """cama/reproject.py:108-116."""
+    out = []
+    for ins in instances:
+        p = ins["points"]
+        p = np.concatenate((p, np.ones((p.shape[0], 1))), axis=-1)
+        p = (T @ p.T).T
+        out.append({"class": ins["class"], "points": p[:, :3]})
+    return out
+
+
+def crop_instances(instances, box=CROP_BOX):
+    """cama/reproject.py:118-131."""
+    out = []
+    for ins in instances:
+        p = ins["points"]
+        m = (p[:, 0] >= box[0]) & (p[:, 0] <= box[1]) & (p[:, 1] >= box[2]) & (p[:, 1] <= box[3]) & \
+            (p[:, 2] >= box[4]) & (p[:, 2] <= box[5])
+        p = p[m]
+        if p.shape[0] > 0:
+            out.append({"class": ins["class"], "points": p})
+    return out
+
+
+def project_instances(instances, K, W, H):
+    """cama/reproject.py:187-205."""
+    out = []
+    for ins in instances:
+        p = (K @ ins["points"].T).T
+        front = p[:, 2] > 0
+        p = p[:, :] / p[:, 2:]
+        m = (p[:, 2] > 0) & (p[:, 0] >= 0) & (p[:, 0] < W) & (p[:, 1] >= 0) & (p[:, 1] < H)
+        m = m & front
+        p = p[m]
+        if p.shape[0] > 0:
+            out.append({"class": ins["class"], "points": p[:, :2][:, ::-1]})
+    return out
+
+
+def pose_track(clip_path, attribute, configs, dataset):
+    """cama/dataset.py:60-76."""
+    if dataset == "cama":
+        main = configs["camera_main"]
+        tum = np.loadtxt(join(clip_path, "odometry", f"{configs['pose_prefix']}_{main}.txt"))
+        stamps, poses = tum_to_poses(tum)
+        return stamps, right_compose(poses, extrinsic(attribute, "chassis", main))
+    tum = np.loadtxt(join(clip_path, "odometry", "wigo_offset_clip.txt"))
+    stamps, poses = tum_to_poses(tum)
+    return stamps, normalize_to_center(poses)
+
+
+def frame_world2chassis(stamps, poses, t):
+    """cama/dataset.py:91-99: fp64 seek -> float32 -> float32 general inverse.  May raise RuntimeError."""
+    c2w = seek_pose(stamps, poses, t, 0.5, True).astype(np.float32)
+    return np.linalg.inv(c2w)
+
+
+def iter_frames(clip_path, attribute, configs, static_map, dataset):
+    """cama/dataset.py:78-106: yields (image_idx, world2chassis, cropped chassis-frame instances)."""
+    stamps, poses = pose_track(clip_path, attribute, configs, dataset)
+    secs = sensor_seconds(attribute, configs["camera_main"], sync=True)
+    for idx in range(1, len(secs)):
+        try:
+            w2c = frame_world2chassis(stamps, poses, secs[idx])
+        except RuntimeError:
+            continue
+        yield idx, w2c, crop_instances(transform_instances(static_map, w2c))
+
+
+def project_all(cropped, cams):
+    """cama/dataset.py:108-117."""
+    return {c["name"]: project_instances(transform_instances(cropped, c["chassis2camera"]), c["K"], c["W"], c["H"])
+            for c in cams}
+
+
+# --------------------------------------------------------------------------- raster
+def colour_bgr(class_name):
+    """cama/reproject.py:250-254: everything but lane_marking is drawn in Crosswalk_Line gold; RGB -> BGR."""
+    rgb = GREY_RGB if class_name == "lane_marking" else GOLD_RGB
+    return tuple(int(v) for v in rgb[::-1])
+
+
+def render_instances(image, maps_2d, radius=2):
+    """cama/reproject.py:246-257 with cv2.circle replaced by the C restatement; per-point Python loop kept."""
+    L = lib()
+    H, W = image.shape[:2]
+    assert image.dtype == np.uint8 and image.flags.c_contiguous
+    base = image.ctypes.data
+    step = image.strides[0]
+    for ins in maps_2d:
+        pts = ins["points"].astype(np.int32)
+        b, g, r = colour_bgr(ins["class"])
+        for p in pts:
+            L.oracle_circle_fill(base, H, W, step, int(p[1]), int(p[0]), radius, b, g, r)
+    return image
+
+
+def mosaic(image_dict):
+    """cama/tools.py:22-25."""
+    top = np.concatenate([image_dict[n] for n in MOSAIC_ORDER[:3]], axis=1)
+    bottom = np.concatenate([image_dict[n] for n in MOSAIC_ORDER[3:]], axis=1)
+    return np.concatenate([top, bottom], axis=0)
+
+
+def circle_halfwidths(radius):
+    hw = np.zeros(radius + 1, np.int32)
+    lib().oracle_circle_halfwidths(radius, _ptr(hw))
+    return hw
+
+
+# --------------------------------------------------------------------------- flat (C) frame path
+def flatten_instances(instances):
+    """-> (xyz (N,3) contiguous, colour_id (N,) uint8, counts, classes)."""
+    classes = [ins["class"] for ins in instances]
+    counts = np.asarray([ins["points"].shape[0] for ins in instances], np.int64)
+    xyz = np.ascontiguousarray(np.concatenate([ins["points"] for ins in instances], axis=0)) if instances \
+        else np.zeros((0, 3), np.float32)
+    col = np.repeat(np.asarray([0 if c == "lane_marking" else 1 for c in classes], np.uint8), counts)
+    return xyz, col, counts, classes
+
+
+def frame_project_flat(xyz, w2c, cams, W, H, crop=CROP_BOX, want_chassis=False):
+    """FMA-chain C path over a flat point buffer: returns dict(vu (C,N,2), vis (C,N), crop_mask (N,), chassis)."""
+    L = lib()
+    N, C = xyz.shape[0], len(cams)
+    assert xyz.flags.c_contiguous and xyz.dtype in (np.float32, np.float64)
+    w2c64 = np.ascontiguousarray(w2c, dtype=np.float64)
+    c2cam = np.ascontiguousarray(np.stack([np.asarray(c["chassis2camera"], np.float64) for c in cams]))
+    K = np.ascontiguousarray(np.stack([np.asarray(c["K"], np.float64) for c in cams]))
+    cropa = np.asarray(crop, np.float64)
+    vu = np.full((C, N, 2), np.nan)
+    vis = np.zeros((C, N), np.uint8)
+    cmask = np.zeros(N, np.uint8)
+    chassis = np.zeros((N, 3)) if want_chassis else None
+    L.oracle_frame_project(_ptr(xyz), int(xyz.dtype == np.float64), N, _ptr(w2c64), _ptr(cropa),
+                           _ptr(c2cam), _ptr(K), C, W, H, _ptr(chassis), _ptr(cmask), _ptr(vu), _ptr(vis))
+    return {"vu": vu, "vis": vis, "crop_mask": cmask, "chassis": chassis}
+
+
+def frame_render_flat(src, vu, vis, colour_id, radius=2, cols=3):
+    """src (C,H,W,3) uint8 -> mosaic ((C/cols)*H, cols*W, 3) through the C renderer."""
+    L = lib()
+    C, H, W = src.shape[:3]
+    N = vis.shape[1]
+    rows = (C + cols - 1) // cols
+    out = np.zeros((rows * H, cols * W, 3), np.uint8)
+    pal = np.asarray([GREY_RGB[::-1], GOLD_RGB[::-1]], np.uint8)
+    L.oracle_render_frame(_ptr(np.ascontiguousarray(src)), _ptr(out), C, H, W, cols,
+                          _ptr(np.ascontiguousarray(vu)), _ptr(np.ascontiguousarray(vis)),
+                          _ptr(np.ascontiguousarray(colour_id)), N, radius, _ptr(pal))
+    return out
