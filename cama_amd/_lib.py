@@ -1,0 +1,70 @@
+"""ctypes binding of libcama_hip.so (include/cama_hip.h).
+
+The HIP library IS the product: there is no CPU fallback.  Importing this module
+never fails (so host-only code paths and the CPU test-suite can import the
+package), but the first call to `lib()` raises if the shared object is missing.
+"""
+import ctypes
+import os
+from os.path import dirname, join, abspath, exists
+
+_HERE = dirname(abspath(__file__))
+LIB_PATH = join(_HERE, "libcama_hip.so")
+ABI_VERSION = 1
+
+_vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/cama_hip.h one to one
+SIGNATURES = {
+    "cama_abi_version": (_i32, []),
+    "cama_last_error": (ctypes.c_char_p, []),
+    "cama_transform_points": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "cama_project_points": (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "cama_project_frames": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
+                                   _vp, _vp, _vp, _vp]),
+    "cama_render_scratch_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _i32]),
+    "cama_render_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
+                                  _vp, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "cama_stamp_scratch_bytes": (_sz, [_i32, _i32]),
+    "cama_stamp_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "cama_circle_halfwidths": (_i32, [_i32, _vp]),
+    "cama_overlay_band_rows": (_i32, [_i32]),
+}
+
+_lib = None
+
+
+class CamaHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not exists(LIB_PATH):
+            raise CamaHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  cama_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.cama_abi_version() != ABI_VERSION:
+            raise CamaHipError(f"ABI mismatch: library {L.cama_abi_version()} != binding {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise CamaHipError(f"libcama_hip error {rc}: {lib().cama_last_error().decode()}")
+
+
+def circle_halfwidths(radius):
+    import numpy as np
+    hw = np.zeros(radius + 1, np.int32)
+    n = lib().cama_circle_halfwidths(radius, hw.ctypes.data)
+    if n < 0:
+        check(n)
+    return hw

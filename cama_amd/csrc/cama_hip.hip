@@ -1,0 +1,758 @@
+// libcama_hip.so -- hand-written gfx950 (MI355X / CDNA4) kernels for the CAMA multi-camera
+// reprojection hot path, behind the C ABI declared in include/cama_hip.h.
+//
+// Path (reference, /root/reference): cama/dataset.py:78-126 (yield_frame -> project_all_camera ->
+// render_vectors), cama/reproject.py:108-131,187-205,246-257, cama/tools.py:22-25.
+//
+// Design (DESIGN.md has the full account):
+//   * The work is pointwise fp64 geometry + byte streaming: HBM-bound, no MFMA.
+//   * k_frames<MODE>: one thread per (frame, vertex).  The frame's world->chassis 3x4 and all
+//     cameras' chassis->camera 3x4 + K 3x3 are staged once per workgroup in LDS (<= 2.8 KB);
+//     the fp32 SoA vertex buffer is read once per frame for ALL cameras with fully coalesced
+//     dword loads; arithmetic is fp64 k-ordered FMA chains (bit-identical to the reference's
+//     numpy/OpenBLAS matmul), compiled with -ffp-contract=off so nothing else is fused.
+//     MODE_EMIT writes (v,u)+visibility; MODE_COUNT / MODE_FILL bin "stamps" (one per visible
+//     point per camera) by (frame, camera, row band) with wave-aggregated atomics.
+//   * k_overlay: one workgroup per (frame, camera, band of R full image rows).  The band is a
+//     single contiguous byte range of the source frame; it is read once with 16-byte loads and
+//     written once, already at its 2x3-mosaic address.  Bands that received stamps first resolve
+//     "last writer wins" deterministically: a per-pixel u32 owner table in LDS takes
+//     atomicMax(draw index) over the stamps' disc footprints, then the copy patches bytes whose
+//     pixel has an owner.  No pixel is read or written twice.
+//   * 64-wide wavefronts throughout (ballots are 64-bit, scans step to 32).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "cama_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(CAMA_EHIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int BLOCK = 256;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte chunk (global_load_dwordx4)
+constexpr int CAM_STRIDE = 21;  // 12 (3x4 of chassis->camera) + 9 (K)
+
+struct Crop { double v[6]; };
+struct Disc { int radius; int hw[CAMA_MAX_RADIUS + 1]; };
+struct Palette { uint32_t c[2]; };  // b | g<<8 | r<<16
+
+// ------------------------------------------------------------------------------------------
+// fp64 k-ordered FMA chains (see header: arithmetic contract)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void affine3x4(const double *M, double x, double y, double z,
+                                          double &ox, double &oy, double &oz)
+{
+    double a;
+    a = M[0] * x; a = __builtin_fma(M[1], y, a); a = __builtin_fma(M[2], z, a);  a = __builtin_fma(M[3], 1.0, a);  ox = a;
+    a = M[4] * x; a = __builtin_fma(M[5], y, a); a = __builtin_fma(M[6], z, a);  a = __builtin_fma(M[7], 1.0, a);  oy = a;
+    a = M[8] * x; a = __builtin_fma(M[9], y, a); a = __builtin_fma(M[10], z, a); a = __builtin_fma(M[11], 1.0, a); oz = a;
+}
+
+__device__ __forceinline__ void linear3x3(const double *K, double x, double y, double z,
+                                          double &o0, double &o1, double &o2)
+{
+    double a;
+    a = K[0] * x; a = __builtin_fma(K[1], y, a); a = __builtin_fma(K[2], z, a); o0 = a;
+    a = K[3] * x; a = __builtin_fma(K[4], y, a); a = __builtin_fma(K[5], z, a); o1 = a;
+    a = K[6] * x; a = __builtin_fma(K[7], y, a); a = __builtin_fma(K[8], z, a); o2 = a;
+}
+
+__device__ __forceinline__ bool in_crop(const Crop &c, double x, double y, double z)
+{
+    return (x >= c.v[0]) & (x <= c.v[1]) & (y >= c.v[2]) & (y <= c.v[3]) & (z >= c.v[4]) & (z <= c.v[5]);
+}
+
+// reproject.py:191-198.  h = K @ p_cam.  Visible iff h2 > 0 (mask_z), h2/h2 > 0 (false only for
+// h2 = +inf, where the quotient is nan) and 0 <= u < W, 0 <= v < H on the IEEE quotients.
+__device__ __forceinline__ bool pinhole(double h0, double h1, double h2, double Wd, double Hd,
+                                        double &u, double &v)
+{
+    u = h0 / h2;
+    v = h1 / h2;
+    return (h2 > 0.0) & (h2 < __builtin_huge_val()) & (u >= 0.0) & (u < Wd) & (v >= 0.0) & (v < Hd);
+}
+
+// stage [C] x (3x4 chassis->camera | 3x3 K) into LDS
+__device__ __forceinline__ void stage_cameras(double *s_cam, const double *c2cam, const double *K, int C)
+{
+    for (int t = threadIdx.x; t < C * CAM_STRIDE; t += BLOCK) {
+        int c = t / CAM_STRIDE, k = t - c * CAM_STRIDE;
+        s_cam[t] = (k < 12) ? c2cam[c * 16 + k] : K[c * 9 + (k - 12)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// API kernels (materialise coordinates)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_transform_points(const T *__restrict__ xyz, int64_t N,
+                                                            const double *__restrict__ Tm, Crop crop,
+                                                            int has_crop, double *__restrict__ out,
+                                                            uint8_t *__restrict__ mask)
+{
+    __shared__ double s_m[12];
+    const int f = blockIdx.y;
+    if (threadIdx.x < 12) s_m[threadIdx.x] = Tm[(size_t)f * 16 + threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const double x = (double)xyz[3 * i], y = (double)xyz[3 * i + 1], z = (double)xyz[3 * i + 2];
+    double ox, oy, oz;
+    affine3x4(s_m, x, y, z, ox, oy, oz);
+    if (out) {
+        double *o = out + ((size_t)f * N + i) * 3;
+        o[0] = ox; o[1] = oy; o[2] = oz;
+    }
+    if (mask) mask[(size_t)f * N + i] = has_crop ? (uint8_t)in_crop(crop, ox, oy, oz) : (uint8_t)1;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_project_points(const double *__restrict__ pts, int64_t n,
+                                                          const double *__restrict__ c2cam,
+                                                          const double *__restrict__ K, int C, int W, int H,
+                                                          double *__restrict__ vu, uint8_t *__restrict__ vis)
+{
+    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+    stage_cameras(s_cam, c2cam, K, C);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    const double Wd = (double)W, Hd = (double)H;
+    for (int c = 0; c < C; ++c) {
+        const double *m = s_cam + c * CAM_STRIDE;
+        double px, py, pz, h0, h1, h2, u, v;
+        affine3x4(m, x, y, z, px, py, pz);
+        linear3x3(m + 12, px, py, pz, h0, h1, h2);
+        const bool ok = pinhole(h0, h1, h2, Wd, Hd, u, v);
+        reinterpret_cast<double2 *>(vu)[(size_t)c * n + i] = make_double2(v, u);
+        vis[(size_t)c * n + i] = (uint8_t)ok;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused per-frame kernel
+// ------------------------------------------------------------------------------------------
+enum { MODE_EMIT = 0, MODE_COUNT = 1, MODE_FILL = 2 };
+
+struct FrameArgs {
+    const void *x, *y, *z;  // [N] each, float or double (template parameter T)
+    const uint8_t *colour;
+    int64_t N;
+    const double *w2c, *c2cam, *K;
+    int C, W, H;
+    Crop crop;
+    // MODE_EMIT
+    double *vu;
+    uint8_t *vis, *crop_mask;
+    // MODE_COUNT / MODE_FILL
+    int band_shift, NB, radius;
+    uint32_t *counts, *cursor;
+    const uint32_t *bin_off, *fc_base;
+    uint2 *stamps;
+};
+
+// Wave-aggregated atomicAdd keyed by bin: lanes of a wave that target the same counter issue one
+// atomic.  Vertices are stored polyline-major, so a wave usually hits 1-3 distinct bins.
+// Returns old value + rank within the group (the slot) for participating lanes.
+__device__ __forceinline__ uint32_t wave_bin_add(uint32_t *counters, uint32_t bin, bool active)
+{
+    const unsigned lane = __lane_id();
+    uint32_t slot = 0;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lbin = __shfl(bin, leader, 64);
+        const unsigned long long same = __ballot(active && bin == lbin) & todo;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&counters[lbin], (uint32_t)__popcll(same));
+        base = __shfl(base, leader, 64);
+        if ((same >> lane) & 1ull) slot = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
+
+template <int MODE, typename T>
+__global__ __launch_bounds__(BLOCK) void k_frames(FrameArgs a)
+{
+    __shared__ double s_w2c[12];
+    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+    const int f = blockIdx.y;
+    if (threadIdx.x < 12) s_w2c[threadIdx.x] = a.w2c[(size_t)f * 16 + threadIdx.x];
+    stage_cameras(s_cam, a.c2cam, a.K, a.C);
+    __syncthreads();
+
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = i < a.N;
+    double cx = 0, cy = 0, cz = 0;
+    bool in = false;
+    uint32_t key = 0;
+    if (valid) {
+        const double x = (double)static_cast<const T *>(a.x)[i], y = (double)static_cast<const T *>(a.y)[i],
+                     z = (double)static_cast<const T *>(a.z)[i];
+        affine3x4(s_w2c, x, y, z, cx, cy, cz);
+        in = in_crop(a.crop, cx, cy, cz);
+        if (MODE != MODE_EMIT) key = ((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1);
+        if (MODE == MODE_EMIT && a.crop_mask) a.crop_mask[(size_t)f * a.N + i] = (uint8_t)in;
+    }
+    // whole wave outside the crop box (the common case on large maps): nothing more to do
+    if (MODE != MODE_EMIT && !__any(in)) return;
+
+    const double Wd = (double)a.W, Hd = (double)a.H;
+    for (int c = 0; c < a.C; ++c) {
+        const double *m = s_cam + c * CAM_STRIDE;
+        bool ok = false;
+        double u = 0, v = 0;
+        if (in) {
+            double px, py, pz, h0, h1, h2;
+            affine3x4(m, cx, cy, cz, px, py, pz);
+            linear3x3(m + 12, px, py, pz, h0, h1, h2);
+            ok = pinhole(h0, h1, h2, Wd, Hd, u, v);
+        }
+        const size_t fc = (size_t)f * a.C + c;
+        if (MODE == MODE_EMIT) {
+            if (valid) {
+                if (in) reinterpret_cast<double2 *>(a.vu)[fc * a.N + i] = make_double2(v, u);
+                a.vis[fc * a.N + i] = (uint8_t)ok;
+            }
+        } else {
+            // reproject.py:249: astype(np.int32) truncation (values are >= 0 here)
+            const int ui = ok ? (int)u : 0, vi = ok ? (int)v : 0;
+            const int b0 = max(vi - a.radius, 0) >> a.band_shift;
+            const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;
+            const int nb = ok ? (b1 - b0 + 1) : 0;
+            int most = nb;
+            for (int d = 32; d; d >>= 1) most = max(most, __shfl_xor(most, d, 64));
+            for (int k = 0; k < most; ++k) {
+                const bool act = k < nb;
+                const uint32_t bin = (uint32_t)(fc * a.NB) + (uint32_t)(b0 + k);
+                if (MODE == MODE_COUNT) {
+                    wave_bin_add(a.counts, bin, act);
+                } else {
+                    const uint32_t slot = wave_bin_add(a.cursor, bin, act);
+                    if (act) {
+                        const size_t at = (size_t)a.fc_base[fc] + a.bin_off[bin] + slot;
+                        a.stamps[at] = make_uint2((uint32_t)ui | ((uint32_t)vi << 16), key);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// exclusive scan of each (frame,camera)'s band counters; one wave per (frame,camera)
+__global__ __launch_bounds__(64) void k_scan_bands(const uint32_t *__restrict__ counts,
+                                                   uint32_t *__restrict__ bin_off,
+                                                   uint32_t *__restrict__ fc_total, int NB)
+{
+    const int fc = blockIdx.x, lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (int base = 0; base < NB; base += 64) {
+        const int b = base + lane;
+        const uint32_t v = b < NB ? counts[(size_t)fc * NB + b] : 0u;
+        uint32_t s = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(s, d, 64);
+            if (lane >= d) s += t;
+        }
+        if (b < NB) bin_off[(size_t)fc * NB + b] = carry + s - v;
+        carry += __shfl(s, 63, 64);
+    }
+    if (lane == 0) fc_total[fc] = carry;
+}
+
+// exclusive scan over the (frame,camera) totals; a single wave
+__global__ __launch_bounds__(64) void k_scan_totals(const uint32_t *__restrict__ fc_total,
+                                                    uint32_t *__restrict__ fc_base, int n)
+{
+    const int lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        const uint32_t v = j < n ? fc_total[j] : 0u;
+        uint32_t s = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(s, d, 64);
+            if (lane >= d) s += t;
+        }
+        if (j < n) fc_base[j] = carry + s - v;
+        carry += __shfl(s, 63, 64);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// overlay: band copy + deterministic stamp resolution
+// ------------------------------------------------------------------------------------------
+struct OverlayArgs {
+    const uint8_t *src;
+    uint8_t *mosaic;
+    int C, H, W, cols, R, NB;
+    uint32_t cpr, cpr_magic;          // 16-byte chunks per row, ceil(2^32 / cpr)
+    size_t mosaic_row_bytes, mosaic_frame_bytes;
+    const uint32_t *counts, *bin_off, *fc_base;
+    const uint2 *stamps;
+    Disc disc;
+    Palette pal;
+};
+
+__device__ __forceinline__ void rasterise_stamps(uint32_t *s_owner, const uint2 *st, uint32_t n,
+                                                 int y0, int nrows, int W, const Disc &disc)
+{
+    for (uint32_t s = threadIdx.x; s < n; s += BLOCK) {
+        const uint2 r = st[s];
+        const int u = (int)(r.x & 0xffffu), v = (int)(r.x >> 16);
+        const uint32_t val = r.y + 1u;  // 0 = no owner
+        const int ylo = max(v - disc.radius, y0), yhi = min(v + disc.radius, y0 + nrows - 1);
+        for (int y = ylo; y <= yhi; ++y) {
+            const int hw = disc.hw[abs(y - v)];
+            if (hw < 0) continue;
+            const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
+            uint32_t *row = s_owner + (y - y0) * W;
+            for (int x = xlo; x <= xhi; ++x) atomicMax(&row[x], val);
+        }
+    }
+}
+
+// Patch the 16 bytes of chunk `col` of one row with the colours of the owned pixels it overlaps.
+// A chunk starts at byte 16*col = 3*p0 + ph and overlaps exactly pixels p0..p0+5.
+__device__ __forceinline__ void patch_chunk(u32x4 &d, const uint32_t *orow, uint32_t col, const Palette &pal)
+{
+    const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
+    uint32_t o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = orow[p0 + k];
+    if ((o[0] | o[1] | o[2] | o[3] | o[4] | o[5]) == 0u) return;
+    uint32_t c[6], m[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        m[k] = o[k] ? 0x00ffffffu : 0u;
+        c[k] = o[k] ? pal.c[(o[k] - 1u) & 1u] : 0u;
+    }
+    // 18-byte little-endian streams (pixel k at bytes 3k..3k+2) as 5 dwords
+    const uint32_t V0 = c[0] | (c[1] << 24), V1 = (c[1] >> 8) | (c[2] << 16), V2 = (c[2] >> 16) | (c[3] << 8),
+                   V3 = c[4] | (c[5] << 24), V4 = c[5] >> 8;
+    const uint32_t M0 = m[0] | (m[1] << 24), M1 = (m[1] >> 8) | (m[2] << 16), M2 = (m[2] >> 16) | (m[3] << 8),
+                   M3 = m[4] | (m[5] << 24), M4 = m[5] >> 8;
+    // chunk byte j is stream byte j + ph: funnel-shift right by ph bytes
+    const uint32_t v0 = __builtin_amdgcn_alignbyte(V1, V0, ph), v1 = __builtin_amdgcn_alignbyte(V2, V1, ph),
+                   v2 = __builtin_amdgcn_alignbyte(V3, V2, ph), v3 = __builtin_amdgcn_alignbyte(V4, V3, ph);
+    const uint32_t m0 = __builtin_amdgcn_alignbyte(M1, M0, ph), m1 = __builtin_amdgcn_alignbyte(M2, M1, ph),
+                   m2 = __builtin_amdgcn_alignbyte(M3, M2, ph), m3 = __builtin_amdgcn_alignbyte(M4, M3, ph);
+    d.x = (d.x & ~m0) | (v0 & m0);
+    d.y = (d.y & ~m1) | (v1 & m1);
+    d.z = (d.z & ~m2) | (v2 & m2);
+    d.w = (d.w & ~m3) | (v3 & m3);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_overlay(OverlayArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x W, used only by stamped bands
+    const uint32_t bin = blockIdx.x;
+    const uint32_t fc = bin / (uint32_t)a.NB, b = bin - fc * (uint32_t)a.NB;
+    const uint32_t f = fc / (uint32_t)a.C, c = fc - f * (uint32_t)a.C;
+    const int y0 = (int)b * a.R;
+    const int nrows = min(a.R, a.H - y0);
+    const int W = a.W;
+    const uint32_t n = a.counts[bin];
+
+    if (n) {
+        uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
+        const int n4 = (nrows * W + 3) >> 2;
+        for (int j = threadIdx.x; j < n4; j += BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        rasterise_stamps(s_owner, a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]), n, y0, nrows, W, a.disc);
+        __syncthreads();
+    }
+
+    const uint8_t *sband = a.src + ((size_t)fc * a.H + y0) * (size_t)W * 3;
+    uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
+                     ((size_t)(c / (uint32_t)a.cols) * a.H + y0) * a.mosaic_row_bytes +
+                     (size_t)(c % (uint32_t)a.cols) * W * 3;
+
+    if (VEC) {
+        // the band is one contiguous byte range in src: chunk j of the band is src16[j]
+        constexpr int U = 5;
+        const u32x4 *s16 = reinterpret_cast<const u32x4 *>(sband);
+        const uint32_t nchunks = (uint32_t)nrows * a.cpr;
+        for (uint32_t base = threadIdx.x; base < nchunks; base += BLOCK * U) {
+            u32x4 v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t idx = base + j * BLOCK;
+                if (idx < nchunks) v[j] = __builtin_nontemporal_load(s16 + idx);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t idx = base + j * BLOCK;
+                if (idx < nchunks) {
+                    const uint32_t row = __umulhi(idx, a.cpr_magic);
+                    const uint32_t col = idx - row * a.cpr;
+                    if (n) patch_chunk(v[j], s_owner + row * W, col, a.pal);
+                    u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
+                    __builtin_nontemporal_store(v[j], drow + col);
+                }
+            }
+        }
+    } else {
+        // generic width / alignment: one pixel per thread-iteration
+        const int npix = nrows * W;
+        for (int p = threadIdx.x; p < npix; p += BLOCK) {
+            const int row = p / W, x = p - row * W;
+            const uint8_t *s = sband + (size_t)p * 3;
+            uint8_t b0 = s[0], b1 = s[1], b2 = s[2];
+            if (n) {
+                const uint32_t o = s_owner[p];
+                if (o) {
+                    const uint32_t col = a.pal.c[(o - 1u) & 1u];
+                    b0 = (uint8_t)col; b1 = (uint8_t)(col >> 8); b2 = (uint8_t)(col >> 16);
+                }
+            }
+            uint8_t *d = dcell + (size_t)row * a.mosaic_row_bytes + (size_t)x * 3;
+            d[0] = b0; d[1] = b1; d[2] = b2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic single-image stamping (CameraManager.render_maps on caller-supplied points)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_stamp_global(const double *__restrict__ vu,
+                                                        const uint8_t *__restrict__ colour, int64_t n,
+                                                        uint32_t *__restrict__ owner, int H, int W, Disc disc)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    // reproject.py:249 astype(np.int32); cv2.circle clips to the image itself
+    const int v = (int)vu[2 * i], u = (int)vu[2 * i + 1];
+    const uint32_t val = ((((uint32_t)i) << 1) | (uint32_t)(colour[i] & 1)) + 1u;
+    for (int dy = -disc.radius; dy <= disc.radius; ++dy) {
+        const int y = v + dy;
+        if (y < 0 || y >= H) continue;
+        const int hw = disc.hw[abs(dy)];
+        if (hw < 0) continue;
+        const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
+        for (int x = xlo; x <= xhi; ++x) atomicMax(&owner[(size_t)y * W + x], val);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_apply_owner(const uint32_t *__restrict__ owner,
+                                                       uint8_t *__restrict__ image, int64_t npix, Palette pal)
+{
+    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= npix) return;
+    const uint32_t o = owner[p];
+    if (!o) return;
+    const uint32_t col = pal.c[(o - 1u) & 1u];
+    image[3 * p] = (uint8_t)col;
+    image[3 * p + 1] = (uint8_t)(col >> 8);
+    image[3 * p + 2] = (uint8_t)(col >> 16);
+}
+
+// ------------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------------
+int make_disc(int radius, const int32_t *hw, Disc &d)
+{
+    if (radius < 0 || radius > CAMA_MAX_RADIUS || !hw) return -1;
+    d.radius = radius;
+    for (int k = 0; k <= CAMA_MAX_RADIUS; ++k) d.hw[k] = (k <= radius) ? hw[k] : -1;
+    return 0;
+}
+
+Palette make_palette(const uint8_t *bgr)
+{
+    Palette p;
+    for (int k = 0; k < 2; ++k)
+        p.c[k] = (uint32_t)bgr[3 * k] | ((uint32_t)bgr[3 * k + 1] << 8) | ((uint32_t)bgr[3 * k + 2] << 16);
+    return p;
+}
+
+int band_rows_for(int W)
+{
+    const char *env = getenv("CAMA_BAND_ROWS");
+    if (env) {
+        int r = atoi(env);
+        if (r == 4 || r == 8 || r == 16 || r == 32) return r;
+    }
+    // owner table R*W*4 bytes in LDS; keep it near 52 KB so 3 workgroups share a CU's 160 KB
+    if (W <= 832) return 16;
+    if (W <= 1664) return 8;
+    return 4;
+}
+
+int log2i(int v)
+{
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct ScratchLayout {
+    size_t counts, cursor, bin_off, fc_total, fc_base, stamps, total;
+    uint64_t capacity;
+    int R, NB, bands_per_stamp;
+};
+
+int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLayout &L)
+{
+    L.R = band_rows_for(W);
+    L.NB = (H + L.R - 1) / L.R;
+    L.bands_per_stamp = (2 * radius) / L.R + 2;
+    const size_t nbins = (size_t)F * C * L.NB, nfc = (size_t)F * C;
+    L.capacity = (uint64_t)F * C * (uint64_t)N * L.bands_per_stamp;
+    size_t off = 0;
+    L.counts = off;   off = align_up(off + nbins * 4, 256);
+    L.cursor = off;   off = align_up(off + nbins * 4, 256);
+    L.bin_off = off;  off = align_up(off + nbins * 4, 256);
+    L.fc_total = off; off = align_up(off + nfc * 4, 256);
+    L.fc_base = off;  off = align_up(off + nfc * 4, 256);
+    L.stamps = off;   off = align_up(off + (size_t)L.capacity * 8, 256);
+    L.total = off;
+    return 0;
+}
+
+int check_common(int64_t N, int F, int C, int W, int H)
+{
+    if (N < 0 || N >= (1ll << 30)) return fail(CAMA_EINVAL, "N=%lld out of range [0, 2^30)", (long long)N);
+    if (F < 0 || F > 65535) return fail(CAMA_EINVAL, "F=%d out of range [0, 65535]", F);
+    if (C < 1 || C > CAMA_MAX_CAMERAS) return fail(CAMA_EINVAL, "C=%d out of range [1, %d]", C, CAMA_MAX_CAMERAS);
+    if (W < 1 || H < 1 || W > 65535 || H > 65535) return fail(CAMA_EINVAL, "W x H = %d x %d out of range", W, H);
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int cama_abi_version(void) { return CAMA_ABI_VERSION; }
+const char *cama_last_error(void) { return g_err; }
+
+int cama_circle_halfwidths(int32_t radius, int32_t *hw)
+{
+    if (radius < 0 || radius > CAMA_MAX_RADIUS || !hw) return fail(CAMA_EINVAL, "radius %d out of range", radius);
+    // OpenCV imgproc drawing.cpp Circle(), fill branch: union of the horizontal spans it draws per row
+    for (int k = 0; k <= radius; ++k) hw[k] = -1;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        if (dx > hw[dy]) hw[dy] = dx;
+        if (dy > hw[dx]) hw[dx] = dy;
+        ++dy;
+        err += plus;
+        plus += 2;
+        const int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+    return radius + 1;
+}
+
+int cama_overlay_band_rows(int32_t W) { return band_rows_for(W); }
+
+int cama_transform_points(const void *xyz, int32_t xyz_is_f64, int64_t N, const double *T, int32_t F,
+                          const double *crop, double *out_xyz, uint8_t *crop_mask, void *stream)
+{
+    if (int rc = check_common(N, F, 1, 1, 1)) return rc;
+    if (!xyz && N) return fail(CAMA_EINVAL, "xyz is NULL");
+    if (!T && F) return fail(CAMA_EINVAL, "T is NULL");
+    if (N == 0 || F == 0) return CAMA_OK;
+    Crop c{};
+    if (crop) memcpy(c.v, crop, sizeof(c.v));
+    dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK), (unsigned)F);
+    hipStream_t s = (hipStream_t)stream;
+    if (xyz_is_f64)
+        hipLaunchKernelGGL(k_transform_points<double>, grid, dim3(BLOCK), 0, s, (const double *)xyz, N, T, c,
+                           crop ? 1 : 0, out_xyz, crop_mask);
+    else
+        hipLaunchKernelGGL(k_transform_points<float>, grid, dim3(BLOCK), 0, s, (const float *)xyz, N, T, c,
+                           crop ? 1 : 0, out_xyz, crop_mask);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
+int cama_project_points(const double *chassis_xyz, int64_t n, const double *c2cam, const double *K, int32_t C,
+                        int32_t W, int32_t H, double *vu, uint8_t *vis, void *stream)
+{
+    if (int rc = check_common(n, 1, C, W, H)) return rc;
+    if (n == 0) return CAMA_OK;
+    if (!chassis_xyz || !c2cam || !K || !vu || !vis) return fail(CAMA_EINVAL, "NULL pointer argument");
+    hipLaunchKernelGGL(k_project_points, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, chassis_xyz, n, c2cam, K, C, W, H, vu, vis);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
+int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, int64_t N, const double *w2c,
+                        int32_t F,
+                        const double *c2cam, const double *K, int32_t C, const double *crop, int32_t W, int32_t H,
+                        double *vu, uint8_t *vis, uint8_t *crop_mask, void *stream)
+{
+    if (int rc = check_common(N, F, C, W, H)) return rc;
+    if (N == 0 || F == 0) return CAMA_OK;
+    if (!x || !y || !z || !w2c || !c2cam || !K || !crop || !vu || !vis)
+        return fail(CAMA_EINVAL, "NULL pointer argument");
+    FrameArgs a{};
+    a.x = x; a.y = y; a.z = z; a.N = N;
+    a.w2c = w2c; a.c2cam = c2cam; a.K = K; a.C = C; a.W = W; a.H = H;
+    memcpy(a.crop.v, crop, sizeof(a.crop.v));
+    a.vu = vu; a.vis = vis; a.crop_mask = crop_mask;
+    const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK), (unsigned)F);
+    if (xyz_is_f64)
+        hipLaunchKernelGGL((k_frames<MODE_EMIT, double>), grid, dim3(BLOCK), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((k_frames<MODE_EMIT, float>), grid, dim3(BLOCK), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
+size_t cama_render_scratch_bytes(int64_t N, int32_t F, int32_t C, int32_t H, int32_t W, int32_t radius)
+{
+    if (N < 0 || F < 0 || C < 1 || H < 1 || W < 1 || radius < 0) return 0;
+    ScratchLayout L;
+    layout_scratch(N, F, C, H, W, radius, L);
+    return L.total;
+}
+
+int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
+                       int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                       const double *crop, int32_t W, int32_t H, const uint8_t *src, uint8_t *mosaic, int32_t cols,
+                       int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
+                       size_t scratch_bytes, void *stream)
+{
+    if (int rc = check_common(N, F, C, W, H)) return rc;
+    if (F == 0) return CAMA_OK;
+    if (cols < 1) return fail(CAMA_EINVAL, "cols=%d", cols);
+    if (!w2c || !c2cam || !K || !crop || !src || !mosaic || !palette_bgr || !scratch)
+        return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (N && (!x || !y || !z || !colour_id)) return fail(CAMA_EINVAL, "NULL vertex buffer");
+    Disc disc;
+    if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
+    ScratchLayout L;
+    layout_scratch(N, F, C, H, W, radius, L);
+    if (scratch_bytes < L.total)
+        return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", scratch_bytes, L.total);
+    if (L.capacity >= (1ull << 32))
+        return fail(CAMA_EINVAL, "F*C*N*%d = %llu stamps exceed 32-bit offsets: render fewer frames per call",
+                    L.bands_per_stamp, (unsigned long long)L.capacity);
+    if ((size_t)F * C * L.NB >= (1ull << 31)) return fail(CAMA_EINVAL, "too many bands");
+    const size_t lds = align_up((size_t)L.R * W * 4, 16);
+    if (lds > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the LDS owner table", W);
+
+    hipStream_t s = (hipStream_t)stream;
+    char *base = (char *)scratch;
+    uint32_t *counts = (uint32_t *)(base + L.counts), *cursor = (uint32_t *)(base + L.cursor);
+    uint32_t *bin_off = (uint32_t *)(base + L.bin_off), *fc_total = (uint32_t *)(base + L.fc_total);
+    uint32_t *fc_base = (uint32_t *)(base + L.fc_base);
+    uint2 *stamps = (uint2 *)(base + L.stamps);
+    const int nfc = F * C;
+
+    // counts and cursor are adjacent: one memset
+    HIP_TRY(hipMemsetAsync(counts, 0, L.bin_off - L.counts, s));
+
+    FrameArgs a{};
+    a.x = x; a.y = y; a.z = z; a.colour = colour_id; a.N = N;
+    a.w2c = w2c; a.c2cam = c2cam; a.K = K; a.C = C; a.W = W; a.H = H;
+    memcpy(a.crop.v, crop, sizeof(a.crop.v));
+    a.band_shift = log2i(L.R); a.NB = L.NB; a.radius = radius;
+    a.counts = counts; a.cursor = cursor; a.bin_off = bin_off; a.fc_base = fc_base; a.stamps = stamps;
+    const dim3 fgrid((unsigned)((N + BLOCK - 1) / BLOCK), (unsigned)F);
+    if (N) {
+        if (xyz_is_f64)
+            hipLaunchKernelGGL((k_frames<MODE_COUNT, double>), fgrid, dim3(BLOCK), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_frames<MODE_COUNT, float>), fgrid, dim3(BLOCK), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_scan_bands, dim3(nfc), dim3(64), 0, s, counts, bin_off, fc_total, L.NB);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(64), 0, s, fc_total, fc_base, nfc);
+    HIP_TRY(hipGetLastError());
+    if (N) {
+        if (xyz_is_f64)
+            hipLaunchKernelGGL((k_frames<MODE_FILL, double>), fgrid, dim3(BLOCK), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_frames<MODE_FILL, float>), fgrid, dim3(BLOCK), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
+
+    OverlayArgs o{};
+    o.src = src; o.mosaic = mosaic; o.C = C; o.H = H; o.W = W; o.cols = cols; o.R = L.R; o.NB = L.NB;
+    const int rows = (C + cols - 1) / cols;
+    o.mosaic_row_bytes = (size_t)cols * W * 3;
+    o.mosaic_frame_bytes = (size_t)rows * H * o.mosaic_row_bytes;
+    o.counts = counts; o.bin_off = bin_off; o.fc_base = fc_base; o.stamps = stamps;
+    o.disc = disc; o.pal = make_palette(palette_bgr);
+    const bool vec = (W % 16 == 0) && (((uintptr_t)src | (uintptr_t)mosaic) % 16 == 0);
+    if (vec) {
+        o.cpr = (uint32_t)(W * 3 / 16);
+        o.cpr_magic = (uint32_t)(((1ull << 32) + o.cpr - 1) / o.cpr);
+    }
+    const unsigned nblocks = (unsigned)((size_t)nfc * L.NB);
+    if (lds > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (vec)
+        hipLaunchKernelGGL(k_overlay<true>, dim3(nblocks), dim3(BLOCK), lds, s, o);
+    else
+        hipLaunchKernelGGL(k_overlay<false>, dim3(nblocks), dim3(BLOCK), lds, s, o);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
+size_t cama_stamp_scratch_bytes(int32_t H, int32_t W)
+{
+    if (H < 1 || W < 1) return 0;
+    return align_up((size_t)H * W * 4, 256);
+}
+
+int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n, uint8_t *image, int32_t H, int32_t W,
+                      int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
+                      size_t scratch_bytes, void *stream)
+{
+    if (int rc = check_common(n, 1, 1, W, H)) return rc;
+    if (n == 0) return CAMA_OK;
+    if (!vu || !colour_id || !image || !palette_bgr || !scratch) return fail(CAMA_EINVAL, "NULL pointer argument");
+    Disc disc;
+    if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
+    const size_t need = cama_stamp_scratch_bytes(H, W);
+    if (scratch_bytes < need) return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", scratch_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)H * W * 4, s));
+    hipLaunchKernelGGL(k_stamp_global, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, vu, colour_id,
+                       n, (uint32_t *)scratch, H, W, disc);
+    HIP_TRY(hipGetLastError());
+    const int64_t npix = (int64_t)H * W;
+    hipLaunchKernelGGL(k_apply_owner, dim3((unsigned)((npix + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                       (const uint32_t *)scratch, image, npix, make_palette(palette_bgr));
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
+}  // extern "C"

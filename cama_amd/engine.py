@@ -1,0 +1,206 @@
+"""Device-side engine: owns the HBM-resident buffers of one clip and drives libcama_hip.so.
+
+PyTorch is used for device memory, streams and (in bench.py) torch.distributed only; every
+computation below is a call through the C ABI (include/cama_hip.h).  There is no CPU fallback:
+constructing an Engine without a GPU or without the built library raises.
+
+Reference semantics implemented by the kernels: cama/dataset.py:99-117, cama/reproject.py:108-131,
+187-205,246-257, cama/tools.py:22-25 (paths under /root/reference).
+"""
+import numpy as np
+
+from . import _lib
+
+CROP_BOX = (-50.0, 50.0, -100.0, 100.0, -200.0, 200.0)        # cama/reproject.py:28-34
+PALETTE_BGR = ((211, 211, 211), (0, 215, 255))                # grey lane_marking, gold everything else
+RADIUS = 2                                                    # cama/reproject.py:256
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class CameraRig:
+    """Per-clip calibration on the device: [C,16] chassis->camera and [C,9] K (scaled to W x H)."""
+
+    def __init__(self, names, chassis2camera, K, W, H, device):
+        torch = _torch()
+        self.names = list(names)
+        self.C = len(self.names)
+        self.W, self.H = int(W), int(H)
+        c2c = np.ascontiguousarray(np.stack([np.asarray(m, np.float64).reshape(4, 4) for m in chassis2camera]))
+        Ks = np.ascontiguousarray(np.stack([np.asarray(k, np.float64).reshape(3, 3) for k in K]))
+        self.c2cam_host, self.K_host = c2c, Ks
+        self.c2cam = torch.from_numpy(c2c.reshape(self.C, 16)).to(device)
+        self.K = torch.from_numpy(Ks.reshape(self.C, 9)).to(device)
+
+
+class DeviceMap:
+    """Static vertex buffer of one dataset pass: SoA x,y,z (float32 or float64) + colour id (uint8)."""
+
+    def __init__(self, xyz, colour_id, device):
+        torch = _torch()
+        xyz = np.asarray(xyz)
+        if xyz.dtype not in (np.float32, np.float64):
+            xyz = xyz.astype(np.float64)
+        assert xyz.ndim == 2 and xyz.shape[1] == 3
+        self.N = int(xyz.shape[0])
+        self.is_f64 = int(xyz.dtype == np.float64)
+        soa = np.ascontiguousarray(xyz.T)                       # [3,N]
+        self.soa = torch.from_numpy(soa).to(device)
+        self.colour = torch.from_numpy(np.ascontiguousarray(colour_id, dtype=np.uint8)).to(device)
+        assert self.colour.numel() == self.N
+
+    def ptrs(self):
+        es = self.soa.element_size()
+        base = self.soa.data_ptr()
+        return base, base + self.N * es, base + 2 * self.N * es
+
+
+class Engine:
+    def __init__(self, device="cuda:0", crop=CROP_BOX, radius=RADIUS, palette_bgr=PALETTE_BGR):
+        torch = _torch()
+        self.lib = _lib.lib()                                   # raises if the .so is missing
+        if not torch.cuda.is_available():
+            raise _lib.CamaHipError("cama_amd.Engine needs a GPU (torch.cuda.is_available() is False); "
+                                    "there is no CPU fallback")
+        self.device = torch.device(device)
+        self.crop = np.asarray(crop, np.float64)
+        self.radius = int(radius)
+        self.halfwidth = _lib.circle_halfwidths(self.radius)
+        self.palette = np.ascontiguousarray(np.asarray(palette_bgr, np.uint8).reshape(2, 3))
+        self._scratch = None
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return _torch().cuda.current_stream(self.device).cuda_stream
+
+    def _scratch_buf(self, nbytes):
+        torch = _torch()
+        if self._scratch is None or self._scratch.numel() < nbytes:
+            self._scratch = None
+            self._scratch = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._scratch
+
+    def _mats(self, mats):
+        """(F,4,4) array-like (float32 or float64, host) -> device [F,16] float64 (exact promotion)."""
+        torch = _torch()
+        if isinstance(mats, torch.Tensor):
+            m = mats.to(device=self.device, dtype=torch.float64).reshape(-1, 16).contiguous()
+            return m
+        m = np.ascontiguousarray(np.asarray(mats, dtype=np.float64).reshape(-1, 16))
+        return torch.from_numpy(m).to(self.device, non_blocking=True)
+
+    def upload_map(self, xyz, colour_id):
+        return DeviceMap(xyz, colour_id, self.device)
+
+    def make_rig(self, names, chassis2camera, K, W, H):
+        return CameraRig(names, chassis2camera, K, W, H, self.device)
+
+    # ------------------------------------------------------------------ API-mode kernels
+    def transform_points(self, xyz, mats, crop=None):
+        """(N,3) points x F matrices -> (out [F,N,3] float64, mask [F,N] uint8) device tensors."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            if isinstance(xyz, torch.Tensor):
+                p = xyz.to(self.device).contiguous()
+                is64 = int(p.dtype == torch.float64)
+                assert p.dtype in (torch.float32, torch.float64)
+            else:
+                a = np.asarray(xyz)
+                if a.dtype not in (np.float32, np.float64):
+                    a = a.astype(np.float64)
+                is64 = int(a.dtype == np.float64)
+                p = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            N = p.shape[0]
+            T = self._mats(mats)
+            F = T.shape[0]
+            out = torch.empty((F, N, 3), dtype=torch.float64, device=self.device)
+            mask = torch.empty((F, N), dtype=torch.uint8, device=self.device)
+            cropa = None if crop is None else np.ascontiguousarray(np.asarray(crop, np.float64))
+            _lib.check(self.lib.cama_transform_points(
+                p.data_ptr(), is64, N, T.data_ptr(), F, None if cropa is None else cropa.ctypes.data,
+                out.data_ptr(), mask.data_ptr(), self._stream()))
+            return out, mask
+
+    def project_points(self, rig, chassis_xyz):
+        """(n,3) float64 chassis-frame points -> (vu [C,n,2] float64, vis [C,n] uint8)."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            if isinstance(chassis_xyz, torch.Tensor):
+                p = chassis_xyz.to(device=self.device, dtype=torch.float64).contiguous()
+            else:
+                p = torch.from_numpy(np.ascontiguousarray(np.asarray(chassis_xyz, np.float64))).to(self.device)
+            n = p.shape[0]
+            vu = torch.empty((rig.C, n, 2), dtype=torch.float64, device=self.device)
+            vis = torch.empty((rig.C, n), dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.cama_project_points(p.data_ptr(), n, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
+                                                    rig.W, rig.H, vu.data_ptr(), vis.data_ptr(), self._stream()))
+            return vu, vis
+
+    def project_frames(self, dmap, rig, w2c):
+        """Fused chain, coordinates materialised: (vu [F,C,N,2], vis [F,C,N], crop_mask [F,N])."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            T = self._mats(w2c)
+            F = T.shape[0]
+            vu = torch.full((F, rig.C, dmap.N, 2), float("nan"), dtype=torch.float64, device=self.device)
+            vis = torch.empty((F, rig.C, dmap.N), dtype=torch.uint8, device=self.device)
+            cm = torch.empty((F, dmap.N), dtype=torch.uint8, device=self.device)
+            x, y, z = dmap.ptrs()
+            _lib.check(self.lib.cama_project_frames(
+                x, y, z, dmap.is_f64, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
+                self.crop.ctypes.data, rig.W, rig.H, vu.data_ptr(), vis.data_ptr(), cm.data_ptr(), self._stream()))
+            return vu, vis, cm
+
+    # ------------------------------------------------------------------ fused render
+    def mosaic_shape(self, rig, F, cols=3):
+        rows = (rig.C + cols - 1) // cols
+        return (F, rows * rig.H, cols * rig.W, 3)
+
+    def render_frames(self, dmap, rig, w2c, src, out=None, cols=3):
+        """src [F,C,H,W,3] uint8 device tensor -> mosaic [F, rows*H, cols*W, 3] uint8 device tensor."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            T = w2c if (isinstance(w2c, torch.Tensor) and w2c.dtype == torch.float64 and w2c.is_cuda
+                        and w2c.dim() == 2) else self._mats(w2c)
+            F = T.shape[0]
+            assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
+            assert tuple(src.shape) == (F, rig.C, rig.H, rig.W, 3), (tuple(src.shape), (F, rig.C, rig.H, rig.W, 3))
+            shape = self.mosaic_shape(rig, F, cols)
+            if out is None:
+                out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+            assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.uint8
+            need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
+            scratch = self._scratch_buf(need)
+            x, y, z = dmap.ptrs()
+            _lib.check(self.lib.cama_render_frames(
+                x, y, z, dmap.is_f64, dmap.colour.data_ptr(), dmap.N, T.data_ptr(), F,
+                rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C, self.crop.ctypes.data, rig.W, rig.H,
+                src.data_ptr(), out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
+                self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), self._stream()))
+            return out
+
+    def max_frames_per_call(self, dmap, rig, budget_bytes=4 << 30):
+        """Largest F whose worst-case stamp scratch fits `budget_bytes` (and 32-bit stamp offsets)."""
+        per = max(1, self.lib.cama_render_scratch_bytes(dmap.N, 1, rig.C, rig.H, rig.W, self.radius))
+        f_budget = max(1, int(budget_bytes // per))
+        f_off = max(1, int(((1 << 32) - 1) // max(1, rig.C * max(1, dmap.N) * 2)))
+        return min(f_budget, f_off, 65535)
+
+    def stamp_points(self, image, vu, colour_id):
+        """In-place render_maps on one device image [H,W,3]: points (n,2) (v,u) float64 in draw order."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            assert image.is_cuda and image.dtype == torch.uint8 and image.is_contiguous() and image.shape[2] == 3
+            H, W = int(image.shape[0]), int(image.shape[1])
+            p = torch.from_numpy(np.ascontiguousarray(np.asarray(vu, np.float64).reshape(-1, 2))).to(self.device)
+            col = torch.from_numpy(np.ascontiguousarray(np.asarray(colour_id, np.uint8))).to(self.device)
+            n = p.shape[0]
+            need = self.lib.cama_stamp_scratch_bytes(H, W)
+            scratch = self._scratch_buf(need)
+            _lib.check(self.lib.cama_stamp_points(p.data_ptr(), col.data_ptr(), n, image.data_ptr(), H, W,
+                                                  self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data,
+                                                  scratch.data_ptr(), scratch.numel(), self._stream()))
+            return image

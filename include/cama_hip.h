@@ -1,0 +1,145 @@
+/*
+ * cama_hip.h -- C ABI of libcama_hip.so: the MI355X (gfx950) implementation of the
+ * CAMA multi-camera reprojection hot path.
+ *
+ * The reference (manymuch/CAMA) is pure Python and has no FFI of its own; the
+ * drop-in boundary a user sees is the Python class surface main.py calls
+ * (cama/dataset.py:11 ClipManager, cama/reproject.py:20,163 MapManager /
+ * CameraManager, cama/tools.py:12 VideoGenerator).  This header is the native
+ * boundary UNDER that surface: each entry point names the reference lines whose
+ * third-party native call sites (numpy/BLAS matmul, boolean gathers, cv2.circle,
+ * np.concatenate) it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless the parameter
+ *     is documented "host"; the library never allocates, frees or synchronises.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is
+ *     enqueued asynchronously on it.
+ *   - return 0 on success; <0 on error: CAMA_EINVAL (bad argument, nothing was
+ *     enqueued), CAMA_EHIP (a HIP call failed).  cama_last_error() returns a
+ *     thread-local message for the most recent failure on the calling thread.
+ *   - no global state: calls on distinct streams / buffers are thread-safe.
+ *   - matrices are row-major doubles.  world->chassis matrices are the float32
+ *     np.linalg.inv result (cama/dataset.py:99) promoted to double on the host
+ *     (exact), so one matrix type crosses the boundary.
+ *   - arithmetic contract: float64, k-ordered FMA chains
+ *     acc = m0*x; acc = fma(m1,y,acc); acc = fma(m2,z,acc); [acc = fma(m3,1,acc)]
+ *     -- bit-identical to numpy/OpenBLAS float64 matmul on blocks of >= 2 points
+ *     (what the reference executes); IEEE float64 division; comparisons and the
+ *     int32 truncation exactly as the reference orders them.
+ */
+#ifndef CAMA_HIP_H
+#define CAMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAMA_ABI_VERSION 1
+#define CAMA_OK      0
+#define CAMA_EINVAL (-1)
+#define CAMA_EHIP   (-2)
+#define CAMA_MAX_CAMERAS 16
+#define CAMA_MAX_RADIUS  15
+
+int cama_abi_version(void);
+const char *cama_last_error(void);
+
+/*
+ * Homogeneous transform + optional inclusive crop test, F matrices over one point set.
+ * Replaces MapManager.transform_3d_instance_maps (cama/reproject.py:108-116) and the mask of
+ * MapManager.crop_3d_instance_maps (cama/reproject.py:118-131) as called from
+ * ClipManager.yield_frame (cama/dataset.py:99-105).
+ *   xyz        [N,3] AoS, float32 (xyz_is_f64 == 0) or float64
+ *   T          [F,16]
+ *   crop       host pointer to {xmin,xmax,ymin,ymax,zmin,zmax} or NULL (no test)
+ *   out_xyz    [F,N,3] float64 (may be NULL when only the mask is wanted)
+ *   crop_mask  [F,N] uint8 1 = inside (may be NULL)
+ */
+int cama_transform_points(const void *xyz, int32_t xyz_is_f64, int64_t N,
+                          const double *T, int32_t F, const double *crop,
+                          double *out_xyz, uint8_t *crop_mask, void *stream);
+
+/*
+ * Per-camera chassis->camera transform, intrinsics, z>0, divide, in-image mask.
+ * Replaces ClipManager.project_all_camera (cama/dataset.py:108-117) =
+ * transform_3d_instance_maps (cama/reproject.py:108-116) + CameraManager.project_to_image
+ * (cama/reproject.py:187-205) for a flat point list (compaction stays with the caller).
+ *   chassis_xyz [n,3] float64      c2cam [C,16]     K [C,9] (already scaled to W x H)
+ *   vu          [C,n,2] float64, (v,u) order, written for every point (inf/nan where z <= 0)
+ *   vis         [C,n] uint8
+ */
+int cama_project_points(const double *chassis_xyz, int64_t n,
+                        const double *c2cam, const double *K, int32_t C,
+                        int32_t W, int32_t H, double *vu, uint8_t *vis, void *stream);
+
+/*
+ * Fused chain for F frames over the static map (structure-of-arrays float32 vertex buffer):
+ * world->chassis, crop, then per camera chassis->camera, K, cull.  "Test/API mode" of the
+ * fused kernel: materialises coordinates.  Same reference lines as the two calls above.
+ *   x,y,z   [N] each, float32 (xyz_is_f64 == 0; the reference's dtype for a float32 BEV raster,
+ *           cama/reproject.py:79,103) or float64        w2c [F,16]
+ *   vu      [F,C,N,2] float64 (v,u); written where the point passed the crop
+ *   vis     [F,C,N] uint8; always written
+ *   crop_mask [F,N] uint8 or NULL
+ */
+int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, int64_t N,
+                        const double *w2c, int32_t F,
+                        const double *c2cam, const double *K, int32_t C,
+                        const double *crop /* host, 6 */, int32_t W, int32_t H,
+                        double *vu, uint8_t *vis, uint8_t *crop_mask, void *stream);
+
+/*
+ * Fused render of F frames: the whole per-frame hot path
+ *   yield_frame body (cama/dataset.py:99-105) -> project_all_camera (:108-117) ->
+ *   render_maps (cama/reproject.py:246-257: int32 truncation, colour by class, filled circle
+ *   per point, sequential = last writer wins) -> concate_image (cama/tools.py:22-25).
+ * No coordinates are materialised.  Stamps are binned by (frame, camera, row band), each band
+ * is resolved deterministically (per-pixel max draw index) and written once into the mosaic.
+ *   x,y,z      [N] float32/float64 (xyz_is_f64)   colour_id [N] uint8: palette index (0 lane grey, 1 gold)
+ *   w2c        [F,16]             c2cam [C,16]   K [C,9]   crop host[6]
+ *   src        [F,C,H,W,3] uint8 BGR frames (already at output size)
+ *   mosaic     [F, rows*H, cols*W, 3] uint8, rows = ceil(C/cols); camera c goes to cell
+ *              (c / cols, c % cols) -- tools.py:23-24 for C = 6, cols = 3 with camera_list order
+ *   radius     circle radius (reference: 2); halfwidth host[radius+1]: half-width of the filled
+ *              footprint on rows +-k (OpenCV midpoint circle; data, so a real-cv2 fixture can
+ *              correct it) -- see cama_circle_halfwidths()
+ *   palette_bgr host[2*3]
+ *   scratch    device scratch of at least cama_render_scratch_bytes(...) bytes
+ */
+size_t cama_render_scratch_bytes(int64_t N, int32_t F, int32_t C, int32_t H, int32_t W, int32_t radius);
+int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64,
+                       const uint8_t *colour_id, int64_t N,
+                       const double *w2c, int32_t F,
+                       const double *c2cam, const double *K, int32_t C,
+                       const double *crop, int32_t W, int32_t H,
+                       const uint8_t *src, uint8_t *mosaic, int32_t cols,
+                       int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                       void *scratch, size_t scratch_bytes, void *stream);
+
+/*
+ * Stamp-only overlay for caller-supplied 2D points (the generic CameraManager.render_maps,
+ * cama/reproject.py:246-257, for one image): points are (v,u) float64 in draw order.
+ *   vu [n,2] float64, colour_id [n] uint8, image [H,W,3] uint8 updated in place.
+ *   scratch: at least cama_stamp_scratch_bytes(H, W) bytes.
+ */
+size_t cama_stamp_scratch_bytes(int32_t H, int32_t W);
+int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n,
+                      uint8_t *image, int32_t H, int32_t W,
+                      int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                      void *scratch, size_t scratch_bytes, void *stream);
+
+/* Host helper: half-widths of OpenCV's filled midpoint circle, hw[0..radius]; returns radius+1 or <0. */
+int cama_circle_halfwidths(int32_t radius, int32_t *hw /* host */);
+
+/* Timing probe used by bench.py: enqueue-side band height used by the overlay kernel (rows per band). */
+int cama_overlay_band_rows(int32_t W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAMA_HIP_H */
