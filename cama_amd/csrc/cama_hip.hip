@@ -171,29 +171,9 @@ struct FrameArgs {
     uint2 *stamps;
 };
 
-// Wave-aggregated atomicAdd keyed by bin: lanes of a wave that target the same counter issue one
-// atomic.  Vertices are stored polyline-major, so a wave usually hits 1-3 distinct bins.
-// Returns old value + rank within the group (the slot) for participating lanes.
-__device__ __forceinline__ uint32_t wave_bin_add(uint32_t *counters, uint32_t bin, bool active)
-{
-    const unsigned lane = __lane_id();
-    uint32_t slot = 0;
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t lbin = __shfl(bin, leader, 64);
-        const unsigned long long same = __ballot(active && bin == lbin) & todo;
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&counters[lbin], (uint32_t)__popcll(same));
-        base = __shfl(base, leader, 64);
-        if ((same >> lane) & 1ull) slot = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    return slot;
-}
-
-template <int MODE, typename T>
-__global__ __launch_bounds__(BLOCK) void k_frames(FrameArgs a)
+// Emit mode: materialise (v,u) + visibility for every (frame, camera, vertex).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_frames_emit(FrameArgs a)
 {
     __shared__ double s_w2c[12];
     __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
@@ -201,61 +181,118 @@ __global__ __launch_bounds__(BLOCK) void k_frames(FrameArgs a)
     if (threadIdx.x < 12) s_w2c[threadIdx.x] = a.w2c[(size_t)f * 16 + threadIdx.x];
     stage_cameras(s_cam, a.c2cam, a.K, a.C);
     __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    const double x = (double)static_cast<const T *>(a.x)[i], y = (double)static_cast<const T *>(a.y)[i],
+                 z = (double)static_cast<const T *>(a.z)[i];
+    double cx, cy, cz;
+    affine3x4(s_w2c, x, y, z, cx, cy, cz);
+    const bool in = in_crop(a.crop, cx, cy, cz);
+    if (a.crop_mask) a.crop_mask[(size_t)f * a.N + i] = (uint8_t)in;
+    const double Wd = (double)a.W, Hd = (double)a.H;
+    for (int c = 0; c < a.C; ++c) {
+        const size_t at = ((size_t)f * a.C + c) * a.N + i;
+        bool ok = false;
+        if (in) {
+            const double *m = s_cam + c * CAM_STRIDE;
+            double px, py, pz, h0, h1, h2, u, v;
+            affine3x4(m, cx, cy, cz, px, py, pz);
+            linear3x3(m + 12, px, py, pz, h0, h1, h2);
+            ok = pinhole(h0, h1, h2, Wd, Hd, u, v);
+            reinterpret_cast<double2 *>(a.vu)[at] = make_double2(v, u);
+        }
+        a.vis[at] = (uint8_t)ok;
+    }
+}
+
+// Bin mode.  Every visible (vertex, camera) pair is a "stamp" {u:16, v:16, key = draw index << 1 | colour}
+// that must reach the 1-2 row bands its disc touches.  Two passes (count -> scan -> fill) with identical
+// arithmetic.  All per-stamp atomics are LDS atomics on a per-workgroup histogram of this frame's
+// C x NB bins (ds_add_rtn gives the rank inside the workgroup); global memory sees one independent
+// atomic per non-empty bin per workgroup, so nothing serialises on HBM/L2 latency.
+constexpr int CAM_GROUP = 8;  // cameras ranked per pass through the workgroup protocol (register-resident entries)
+
+template <int MODE, typename T>
+__global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [C*NB] counts, then (fill) [C*NB] bases
+    __shared__ double s_w2c[12];
+    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+    const int f = blockIdx.y;
+    const int nloc = a.C * a.NB;
+    uint32_t *s_cnt = s_hist, *s_base = s_hist + nloc;
+    if (threadIdx.x < 12) s_w2c[threadIdx.x] = a.w2c[(size_t)f * 16 + threadIdx.x];
+    stage_cameras(s_cam, a.c2cam, a.K, a.C);
+    for (int t = threadIdx.x; t < nloc; t += BLOCK) s_cnt[t] = 0u;
+    __syncthreads();
 
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool valid = i < a.N;
     double cx = 0, cy = 0, cz = 0;
     bool in = false;
     uint32_t key = 0;
-    if (valid) {
+    if (i < a.N) {
         const double x = (double)static_cast<const T *>(a.x)[i], y = (double)static_cast<const T *>(a.y)[i],
                      z = (double)static_cast<const T *>(a.z)[i];
         affine3x4(s_w2c, x, y, z, cx, cy, cz);
         in = in_crop(a.crop, cx, cy, cz);
-        if (MODE != MODE_EMIT) key = ((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1);
-        if (MODE == MODE_EMIT && a.crop_mask) a.crop_mask[(size_t)f * a.N + i] = (uint8_t)in;
+        key = ((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1);
     }
-    // whole wave outside the crop box (the common case on large maps): nothing more to do
-    if (MODE != MODE_EMIT && !__any(in)) return;
+    // whole workgroup outside the crop box (the common case on site-sized maps): done
+    if (!__syncthreads_or((int)in)) return;
 
     const double Wd = (double)a.W, Hd = (double)a.H;
-    for (int c = 0; c < a.C; ++c) {
-        const double *m = s_cam + c * CAM_STRIDE;
-        bool ok = false;
-        double u = 0, v = 0;
-        if (in) {
-            double px, py, pz, h0, h1, h2;
-            affine3x4(m, cx, cy, cz, px, py, pz);
-            linear3x3(m + 12, px, py, pz, h0, h1, h2);
-            ok = pinhole(h0, h1, h2, Wd, Hd, u, v);
-        }
-        const size_t fc = (size_t)f * a.C + c;
-        if (MODE == MODE_EMIT) {
-            if (valid) {
-                if (in) reinterpret_cast<double2 *>(a.vu)[fc * a.N + i] = make_double2(v, u);
-                a.vis[fc * a.N + i] = (uint8_t)ok;
-            }
-        } else {
-            // reproject.py:249: astype(np.int32) truncation (values are >= 0 here)
-            const int ui = ok ? (int)u : 0, vi = ok ? (int)v : 0;
-            const int b0 = max(vi - a.radius, 0) >> a.band_shift;
-            const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;
-            const int nb = ok ? (b1 - b0 + 1) : 0;
-            int most = nb;
-            for (int d = 32; d; d >>= 1) most = max(most, __shfl_xor(most, d, 64));
-            for (int k = 0; k < most; ++k) {
-                const bool act = k < nb;
-                const uint32_t bin = (uint32_t)(fc * a.NB) + (uint32_t)(b0 + k);
-                if (MODE == MODE_COUNT) {
-                    wave_bin_add(a.counts, bin, act);
-                } else {
-                    const uint32_t slot = wave_bin_add(a.cursor, bin, act);
-                    if (act) {
-                        const size_t at = (size_t)a.fc_base[fc] + a.bin_off[bin] + slot;
-                        a.stamps[at] = make_uint2((uint32_t)ui | ((uint32_t)vi << 16), key);
+    const size_t gbin0 = (size_t)f * nloc;
+    for (int c0 = 0; c0 < a.C; c0 += CAM_GROUP) {
+        uint32_t e_uv[CAM_GROUP], e_slot[2 * CAM_GROUP];
+#pragma unroll
+        for (int j = 0; j < CAM_GROUP; ++j) {
+            const int c = c0 + j;
+            e_slot[2 * j] = e_slot[2 * j + 1] = 0xffffffffu;
+            e_uv[j] = 0;
+            if (c < a.C && in) {
+                const double *m = s_cam + c * CAM_STRIDE;
+                double px, py, pz, h0, h1, h2, u, v;
+                affine3x4(m, cx, cy, cz, px, py, pz);
+                linear3x3(m + 12, px, py, pz, h0, h1, h2);
+                if (pinhole(h0, h1, h2, Wd, Hd, u, v)) {
+                    // reproject.py:249: astype(np.int32) truncation (values are >= 0 here)
+                    const int ui = (int)u, vi = (int)v;
+                    const int b0 = max(vi - a.radius, 0) >> a.band_shift;
+                    const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;   // b1 <= b0 + 1 (host checks 2r <= R)
+                    const uint32_t l0 = (uint32_t)(c * a.NB + b0);
+                    if (MODE == MODE_COUNT) {
+                        atomicAdd(&s_cnt[l0], 1u);
+                        if (b1 != b0) atomicAdd(&s_cnt[l0 + 1], 1u);
+                    } else {
+                        e_uv[j] = (uint32_t)ui | ((uint32_t)vi << 16);
+                        e_slot[2 * j] = (l0 << 8) | atomicAdd(&s_cnt[l0], 1u);
+                        if (b1 != b0) e_slot[2 * j + 1] = ((l0 + 1) << 8) | atomicAdd(&s_cnt[l0 + 1], 1u);
                     }
                 }
             }
+        }
+        if (MODE == MODE_FILL) {
+            __syncthreads();
+            const int cend = min(c0 + CAM_GROUP, a.C);
+            for (int t = c0 * a.NB + threadIdx.x; t < cend * a.NB; t += BLOCK) {
+                const uint32_t n = s_cnt[t];
+                uint32_t base = 0;
+                if (n) base = atomicAdd(&a.cursor[gbin0 + t], n) + a.bin_off[gbin0 + t] + a.fc_base[f * a.C + t / a.NB];
+                s_base[t] = base;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2 * CAM_GROUP; ++j) {
+                if (e_slot[j] != 0xffffffffu)
+                    a.stamps[(size_t)s_base[e_slot[j] >> 8] + (e_slot[j] & 0xffu)] = make_uint2(e_uv[j >> 1], key);
+            }
+        }
+    }
+    if (MODE == MODE_COUNT) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < nloc; t += BLOCK) {
+            const uint32_t n = s_cnt[t];
+            if (n) atomicAdd(&a.counts[gbin0 + t], n);
         }
     }
 }
@@ -520,7 +557,7 @@ int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLay
 {
     L.R = band_rows_for(W);
     L.NB = (H + L.R - 1) / L.R;
-    L.bands_per_stamp = (2 * radius) / L.R + 2;
+    L.bands_per_stamp = radius > 0 ? 2 : 1;  // 2r+1 rows touch <= 2 bands when 2r <= R (checked by the caller)
     const size_t nbins = (size_t)F * C * L.NB, nfc = (size_t)F * C;
     L.capacity = (uint64_t)F * C * (uint64_t)N * L.bands_per_stamp;
     size_t off = 0;
@@ -624,9 +661,9 @@ int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz
     a.vu = vu; a.vis = vis; a.crop_mask = crop_mask;
     const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK), (unsigned)F);
     if (xyz_is_f64)
-        hipLaunchKernelGGL((k_frames<MODE_EMIT, double>), grid, dim3(BLOCK), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_frames_emit<double>, grid, dim3(BLOCK), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((k_frames<MODE_EMIT, float>), grid, dim3(BLOCK), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_frames_emit<float>, grid, dim3(BLOCK), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CAMA_OK;
 }
@@ -661,6 +698,10 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
         return fail(CAMA_EINVAL, "F*C*N*%d = %llu stamps exceed 32-bit offsets: render fewer frames per call",
                     L.bands_per_stamp, (unsigned long long)L.capacity);
     if ((size_t)F * C * L.NB >= (1ull << 31)) return fail(CAMA_EINVAL, "too many bands");
+    if (2 * radius > L.R)
+        return fail(CAMA_EINVAL, "radius %d too large for the fused path (needs 2r <= band rows = %d)", radius, L.R);
+    if ((size_t)C * L.NB * 8 > 64 * 1024)
+        return fail(CAMA_EINVAL, "C*bands = %d*%d exceeds the per-workgroup LDS histogram", C, L.NB);
     const size_t lds = align_up((size_t)L.R * W * 4, 16);
     if (lds > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the LDS owner table", W);
 
@@ -682,11 +723,12 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
     a.band_shift = log2i(L.R); a.NB = L.NB; a.radius = radius;
     a.counts = counts; a.cursor = cursor; a.bin_off = bin_off; a.fc_base = fc_base; a.stamps = stamps;
     const dim3 fgrid((unsigned)((N + BLOCK - 1) / BLOCK), (unsigned)F);
+    const size_t hist_lds = align_up((size_t)C * L.NB * 4, 16);
     if (N) {
         if (xyz_is_f64)
-            hipLaunchKernelGGL((k_frames<MODE_COUNT, double>), fgrid, dim3(BLOCK), 0, s, a);
+            hipLaunchKernelGGL((k_frames_bin<MODE_COUNT, double>), fgrid, dim3(BLOCK), hist_lds, s, a);
         else
-            hipLaunchKernelGGL((k_frames<MODE_COUNT, float>), fgrid, dim3(BLOCK), 0, s, a);
+            hipLaunchKernelGGL((k_frames_bin<MODE_COUNT, float>), fgrid, dim3(BLOCK), hist_lds, s, a);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_scan_bands, dim3(nfc), dim3(64), 0, s, counts, bin_off, fc_total, L.NB);
@@ -695,9 +737,9 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
     HIP_TRY(hipGetLastError());
     if (N) {
         if (xyz_is_f64)
-            hipLaunchKernelGGL((k_frames<MODE_FILL, double>), fgrid, dim3(BLOCK), 0, s, a);
+            hipLaunchKernelGGL((k_frames_bin<MODE_FILL, double>), fgrid, dim3(BLOCK), 2 * hist_lds, s, a);
         else
-            hipLaunchKernelGGL((k_frames<MODE_FILL, float>), fgrid, dim3(BLOCK), 0, s, a);
+            hipLaunchKernelGGL((k_frames_bin<MODE_FILL, float>), fgrid, dim3(BLOCK), 2 * hist_lds, s, a);
         HIP_TRY(hipGetLastError());
     }
 
