@@ -1,0 +1,5 @@
+"""Drop-in module name of the reference (cama/reproject.py): re-exports the MI355X implementation."""
+from cama_amd.reproject import *  # noqa: F401,F403
+from cama_amd import reproject as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

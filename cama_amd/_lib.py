@@ -19,6 +19,7 @@ SIGNATURES = {
     "cama_abi_version": (_i32, []),
     "cama_last_error": (ctypes.c_char_p, []),
     "cama_transform_points": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "cama_crop_points": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "cama_project_points": (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "cama_project_frames": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
                                    _vp, _vp, _vp, _vp]),

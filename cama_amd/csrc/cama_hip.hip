@@ -126,6 +126,13 @@ __global__ __launch_bounds__(BLOCK) void k_transform_points(const T *__restrict_
     if (mask) mask[(size_t)f * N + i] = has_crop ? (uint8_t)in_crop(crop, ox, oy, oz) : (uint8_t)1;
 }
 
+__global__ __launch_bounds__(BLOCK) void k_crop_points(const double *__restrict__ pts, int64_t n, Crop crop,
+                                                       uint8_t *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) mask[i] = (uint8_t)in_crop(crop, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_project_points(const double *__restrict__ pts, int64_t n,
                                                           const double *__restrict__ c2cam,
                                                           const double *__restrict__ K, int C, int W, int H,
@@ -629,6 +636,19 @@ int cama_transform_points(const void *xyz, int32_t xyz_is_f64, int64_t N, const 
     else
         hipLaunchKernelGGL(k_transform_points<float>, grid, dim3(BLOCK), 0, s, (const float *)xyz, N, T, c,
                            crop ? 1 : 0, out_xyz, crop_mask);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
+int cama_crop_points(const double *xyz, int64_t n, const double *crop, uint8_t *mask, void *stream)
+{
+    if (int rc = check_common(n, 1, 1, 1, 1)) return rc;
+    if (n == 0) return CAMA_OK;
+    if (!xyz || !crop || !mask) return fail(CAMA_EINVAL, "NULL pointer argument");
+    Crop c;
+    memcpy(c.v, crop, sizeof(c.v));
+    hipLaunchKernelGGL(k_crop_points, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       xyz, n, c, mask);
     HIP_TRY(hipGetLastError());
     return CAMA_OK;
 }

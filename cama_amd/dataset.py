@@ -1,0 +1,321 @@
+"""ClipManager with the reference's surface (cama/dataset.py), running the per-frame work on MI355X.
+
+main.py's loop is unchanged:
+
+    cm = ClipManager(configs["cama_configs"], clip_path)
+    for image_idx, instance_map in cm.yield_frame(dataset="cama"):
+        maps_2d_dict = cm.project_all_camera(instance_map)
+        image_dict = cm.render_vectors(maps_2d_dict, image_idx)
+        image = vg.concate_image(image_dict)
+
+but the three objects that flow through it are lazy handles (FrameMaps -> ProjectedMaps -> RenderedFrame):
+as long as the caller only passes them along, nothing is materialised on the host and each frame is one
+fused device pass (cama_render_frames).  Indexing / iterating a handle materialises exactly what the
+reference would have returned (list of {"class","points"} dicts, float64, same order, empty instances
+dropped), computed by the same kernels in their coordinate-emitting mode.  Plain lists / dicts of numpy
+arrays are accepted too and take the generic upload -> kernel -> download path.
+
+Extensions beyond the reference surface (used by bench.py and by batch pipelines):
+    frame_poses(dataset)            all frames' world->chassis float32 matrices in one vectorised pass
+    render_clip(dataset, ...)       whole-clip fused render, F frames per launch, output stays in HBM
+    set_frame_source(source)        where camera frames come from (disk by default, HBM tensors for bench)
+Reference lines: cama/dataset.py:11-126.
+"""
+from collections.abc import Mapping, Sequence
+from os.path import exists, join
+
+import numpy as np
+
+from . import runtime
+from .dataset_reader import DatasetReader
+from .pose_transformer import PoseTransformer
+from .reproject import CameraManager, MapManager, colour_id_of, flatten_instances, split_instances
+from .tools import load_json
+
+try:                                    # progress bar exactly like the reference when tqdm is there
+    from tqdm import tqdm as _tqdm
+except ImportError:                     # pragma: no cover
+    def _tqdm(it, **_):
+        return it
+
+
+class _StaticMap:
+    """One dataset pass' static instances + their flat device copy (uploaded on first GPU use)."""
+
+    def __init__(self, instances):
+        self.instances = instances
+        self.xyz, self.counts, self.classes = flatten_instances(instances)
+        if self.xyz.dtype not in (np.float32, np.float64):
+            self.xyz = self.xyz.astype(np.float64)
+        self.colour = np.repeat(np.asarray([colour_id_of(c) for c in self.classes], np.uint8), self.counts)
+        self._dmap = None
+
+    def device(self):
+        if self._dmap is None:
+            self._dmap = runtime.engine().upload_map(self.xyz, self.colour)
+        return self._dmap
+
+
+class FrameMaps(Sequence):
+    """What yield_frame yields as `instance_map`: the clip's instances in the chassis frame of one image,
+    cropped (cama/dataset.py:99-106).  Lazy; behaves as the reference's list of dicts when touched."""
+
+    def __init__(self, owner, dataset, image_idx, world2chassis):
+        self.owner, self.dataset, self.image_idx = owner, dataset, image_idx
+        self.world2chassis = world2chassis          # (4,4) float32, the np.linalg.inv result
+        self._items = None
+
+    def _materialise(self):
+        if self._items is None:
+            sm = self.owner._static(self.dataset)
+            eng = runtime.engine()
+            if sm.xyz.shape[0] == 0:
+                self._items = []
+            else:
+                out, mask = eng.transform_points(sm.xyz, self.world2chassis[None], crop=self.owner.mm.crop_box())
+                self._items = split_instances(out[0].cpu().numpy(), sm.counts, sm.classes,
+                                              mask[0].cpu().numpy().astype(bool))
+        return self._items
+
+    def __len__(self):
+        return len(self._materialise())
+
+    def __getitem__(self, k):
+        return self._materialise()[k]
+
+
+class ProjectedMaps(Mapping):
+    """What project_all_camera returns for a FrameMaps: camera name -> list of {"class","points": (m,2) (v,u)}
+    (cama/dataset.py:108-117).  Lazy."""
+
+    def __init__(self, frame):
+        self.frame = frame
+        self._items = None
+
+    def _materialise(self):
+        if self._items is None:
+            fr = self.frame
+            owner = fr.owner
+            sm = owner._static(fr.dataset)
+            names = [cm.camera_name for cm in owner.cm_list]
+            if sm.xyz.shape[0] == 0:
+                self._items = {n: [] for n in names}
+            else:
+                eng = runtime.engine()
+                vu, vis, _ = eng.project_frames(sm.device(), owner._rig(), fr.world2chassis[None],
+                                                crop=owner.mm.crop_box())
+                vu, vis = vu[0].cpu().numpy(), vis[0].cpu().numpy().astype(bool)
+                self._items = {n: split_instances(vu[c], sm.counts, sm.classes, vis[c]) for c, n in enumerate(names)}
+        return self._items
+
+    def __getitem__(self, name):
+        return self._materialise()[name]
+
+    def __iter__(self):
+        return iter([cm.camera_name for cm in self.frame.owner.cm_list])
+
+    def __len__(self):
+        return len(self.frame.owner.cm_list)
+
+
+class RenderedFrame(Mapping):
+    """What render_vectors returns on the fused path: camera name -> (H,W,3) uint8 BGR ndarray
+    (cama/dataset.py:119-126), backed by the mosaic the overlay kernel wrote in HBM."""
+
+    def __init__(self, names, mosaic_dev, H, W, cols=3):
+        self.names, self.mosaic_device, self.H, self.W, self.cols = list(names), mosaic_dev, H, W, cols
+        self._host = None
+
+    def _mosaic_host(self):
+        if self._host is None:
+            self._host = self.mosaic_device.cpu().numpy()
+        return self._host
+
+    def mosaic(self, order=None):
+        """The 2x3 mosaic as ndarray if the camera order matches the kernel's cell layout, else None."""
+        if order is not None and list(order) != self.names:
+            return None
+        return self._mosaic_host()
+
+    def __getitem__(self, name):
+        c = self.names.index(name)
+        r, q = divmod(c, self.cols)
+        return self._mosaic_host()[r * self.H:(r + 1) * self.H, q * self.W:(q + 1) * self.W]
+
+    def __iter__(self):
+        return iter(self.names)
+
+    def __len__(self):
+        return len(self.names)
+
+
+class ClipManager:
+    def __init__(self, configs, clip_path=None, output_size=None):
+        self.configs = configs
+        self.mm = MapManager()
+        self.instance_maps = dict()
+        self.output_size = tuple(output_size) if output_size is not None else \
+            tuple(configs.get("output_size", (540, 960)))
+        self._static_cache = {}
+        self._rig_cache = None
+        self._frame_source = None
+        if clip_path is not None:
+            self.clip_path = clip_path
+            self.cm_list = self.prepare_camera_manager(clip_path)
+            cama_instance = self.load_clip_cama(clip_path)
+            if cama_instance is not None:
+                self.instance_maps["cama"] = cama_instance
+            nuscenes_instance = self.load_clip_nuscenes(clip_path)
+            if nuscenes_instance is not None:
+                self.instance_maps["nuscenes"] = nuscenes_instance
+
+    # ------------------------------------------------------------------ per-clip setup (host)
+    def load_clip_cama(self, clip_path):
+        label_json = join(clip_path, self.configs["result_dir"], self.configs["cama_map_file"])
+        if not exists(label_json):
+            return None
+        bev_height = np.load(join(clip_path, self.configs["result_dir"], self.configs["height_mlp"]))
+        return self.mm.calculate_3d_instance_maps(bev_height, load_json(label_json))
+
+    def load_clip_nuscenes(self, clip_path):
+        label_json = join(clip_path, self.configs["result_dir"], self.configs["nuscenes_map_file"])
+        if not exists(label_json):
+            return None
+        return self.mm.load_3d_instance_maps(load_json(label_json))
+
+    def prepare_camera_manager(self, clip_path):
+        return [CameraManager(clip_path, name, output_size=self.output_size) for name in self.configs["camera_list"]]
+
+    def get_pt_cama(self, dr):
+        """camera_main -> world track from the label zip, right-multiplied by chassis -> camera_main:
+        chassis -> world (cama/dataset.py:60-69)."""
+        main = self.configs["camera_main"]
+        pt = PoseTransformer()
+        pt.loadarray(dr.get_odometry(f"{self.configs['pose_prefix']}_{main}.txt"))
+        pt.right_rotate(dr.get_extrinsic("chassis", main))
+        return pt
+
+    def get_pt_nuscenes(self, dr):
+        """chassis -> (offset) world track re-expressed in its middle pose (cama/dataset.py:71-76)."""
+        pt = PoseTransformer()
+        pt.loadarray(dr.get_odometry("wigo_offset_clip.txt"))
+        pt.normalize2center()
+        return pt
+
+    # ------------------------------------------------------------------ device-side state
+    def _static(self, dataset):
+        ins = self.instance_maps[dataset]
+        sm = self._static_cache.get(dataset)
+        if sm is None or sm.instances is not ins:
+            sm = _StaticMap(ins)
+            self._static_cache[dataset] = sm
+        return sm
+
+    def _rig(self):
+        if self._rig_cache is None:
+            cms = self.cm_list
+            self._rig_cache = runtime.engine().make_rig(
+                [c.camera_name for c in cms], [c.get_chassis2camera() for c in cms], [c.K for c in cms],
+                cms[0].width, cms[0].height)
+        return self._rig_cache
+
+    def set_frame_source(self, source):
+        self._frame_source = source
+
+    def frame_source(self):
+        if self._frame_source is None:
+            from .frames import ClipFrameSource
+            self._frame_source = ClipFrameSource(self.cm_list, runtime.engine().device)
+        return self._frame_source
+
+    # ------------------------------------------------------------------ poses
+    def frame_poses(self, dataset):
+        """(image indices (F,), world->chassis (F,4,4) float32) for every renderable frame of the clip.
+
+        Same arithmetic as the per-frame body of yield_frame (cama/dataset.py:87-99) -- interpolated float64
+        chassis->world, cast to float32, float32 general inverse -- done for all frames at once.  Frames whose
+        pose lookup would raise RuntimeError are left out, as the reference skips them.  Index 0 is never
+        rendered (dataset.py:88 starts at 1)."""
+        dr = DatasetReader(self.clip_path)
+        if dataset == "nuscenes":
+            pt = self.get_pt_nuscenes(dr)
+        elif dataset == "cama":
+            pt = self.get_pt_cama(dr)
+        else:
+            raise UnboundLocalError(f"unknown dataset {dataset!r}")   # the reference fails on `pt` here
+        secs = dr.get_sensor_timestamp(self.configs["camera_main"], sync=True)
+        if len(secs) <= 1:
+            return np.zeros(0, np.int64), np.zeros((0, 4, 4), np.float32)
+        ok, c2w = pt.seek_many(secs[1:], 0.5, interpolate=True)
+        idx = np.flatnonzero(ok) + 1
+        c2w32 = c2w[ok].astype(np.float32)
+        w2c = np.linalg.inv(c2w32) if len(idx) else np.zeros((0, 4, 4), np.float32)
+        return idx, w2c
+
+    # ------------------------------------------------------------------ the reference's per-frame API
+    def yield_frame(self, dataset):
+        idx, w2c = self.frame_poses(dataset)
+        lookup = {int(i): k for k, i in enumerate(idx)}
+        n_stamps = len(DatasetReader(self.clip_path).get_sensor_timestamp(self.configs["camera_main"], sync=True))
+        for image_idx in _tqdm(range(1, n_stamps)):
+            k = lookup.get(image_idx)
+            if k is None:
+                continue            # pose lookup failed: frame skipped (cama/dataset.py:93-96)
+            yield (image_idx, FrameMaps(self, dataset, image_idx, w2c[k]))
+
+    def project_all_camera(self, maps_3d):
+        if isinstance(maps_3d, FrameMaps) and maps_3d.owner is self and maps_3d._items is None:
+            return ProjectedMaps(maps_3d)
+        # generic path: caller-supplied chassis-frame instances
+        pts, counts, classes = flatten_instances(list(maps_3d))
+        names = [cm.camera_name for cm in self.cm_list]
+        if pts.shape[0] == 0:
+            return {n: [] for n in names}
+        vu, vis = runtime.engine().project_points(self._rig(), pts)
+        vu, vis = vu.cpu().numpy(), vis.cpu().numpy().astype(bool)
+        return {n: split_instances(vu[c], counts, classes, vis[c]) for c, n in enumerate(names)}
+
+    def render_vectors(self, maps_2d_dict, image_idx):
+        if isinstance(maps_2d_dict, ProjectedMaps) and maps_2d_dict.frame.owner is self \
+                and maps_2d_dict._items is None and maps_2d_dict.frame.image_idx == image_idx:
+            fr = maps_2d_dict.frame
+            eng = runtime.engine()
+            rig = self._rig()
+            src = self.frame_source().batch([image_idx])
+            mosaic = eng.render_frames(self._static(fr.dataset).device(), rig, fr.world2chassis[None], src,
+                                       crop=self.mm.crop_box())
+            return RenderedFrame(rig.names, mosaic[0], rig.H, rig.W)
+        # generic path: caller-supplied 2D instances, one image at a time like the reference
+        out = {}
+        for cm in self.cm_list:
+            image = cm.read_resized_image_by_index(image_idx)
+            out[cm.camera_name] = cm.render_maps(image, maps_2d_dict[cm.camera_name])
+        return out
+
+    # ------------------------------------------------------------------ whole-clip fused path
+    def render_clip(self, dataset, out=None, frames_per_launch=None, poses=None):
+        """Render every frame of `dataset` in launches of up to `frames_per_launch` frames.
+
+        Returns (image indices (F,), mosaic device tensor [F, 2H, 3W, 3] uint8).  Nothing is copied to the host.
+        `poses` = a previous frame_poses() result to reuse."""
+        import torch
+        eng = runtime.engine()
+        rig = self._rig()
+        dmap = self._static(dataset).device()
+        idx, w2c = poses if poses is not None else self.frame_poses(dataset)
+        F = len(idx)
+        shape = eng.mosaic_shape(rig, F)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.uint8, device=eng.device)
+        assert tuple(out.shape) == shape
+        if F == 0:
+            return idx, out
+        step = frames_per_launch or eng.max_frames_per_call(dmap, rig)
+        T = eng._mats(w2c)
+        crop = self.mm.crop_box()
+        src_all = self.frame_source()
+        for lo in range(0, F, step):
+            hi = min(F, lo + step)
+            src = src_all.batch([int(i) for i in idx[lo:hi]])
+            eng.render_frames(dmap, rig, T[lo:hi], src, out=out[lo:hi], crop=crop)
+        return idx, out

@@ -124,6 +124,17 @@ class Engine:
                 out.data_ptr(), mask.data_ptr(), self._stream()))
             return out, mask
 
+    def crop_points(self, xyz, crop):
+        """(n,3) float64 points -> mask [n] uint8 (inclusive box test on the device)."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            p = torch.from_numpy(np.ascontiguousarray(np.asarray(xyz, np.float64))).to(self.device)
+            mask = torch.empty((p.shape[0],), dtype=torch.uint8, device=self.device)
+            cropa = np.ascontiguousarray(np.asarray(crop, np.float64))
+            _lib.check(self.lib.cama_crop_points(p.data_ptr(), p.shape[0], cropa.ctypes.data, mask.data_ptr(),
+                                                 self._stream()))
+            return mask
+
     def project_points(self, rig, chassis_xyz):
         """(n,3) float64 chassis-frame points -> (vu [C,n,2] float64, vis [C,n] uint8)."""
         torch = _torch()
@@ -139,9 +150,13 @@ class Engine:
                                                     rig.W, rig.H, vu.data_ptr(), vis.data_ptr(), self._stream()))
             return vu, vis
 
-    def project_frames(self, dmap, rig, w2c):
+    def _crop(self, crop):
+        return self.crop if crop is None else np.ascontiguousarray(np.asarray(crop, np.float64))
+
+    def project_frames(self, dmap, rig, w2c, crop=None):
         """Fused chain, coordinates materialised: (vu [F,C,N,2], vis [F,C,N], crop_mask [F,N])."""
         torch = _torch()
+        cropa = self._crop(crop)
         with torch.cuda.device(self.device):
             T = self._mats(w2c)
             F = T.shape[0]
@@ -151,7 +166,7 @@ class Engine:
             x, y, z = dmap.ptrs()
             _lib.check(self.lib.cama_project_frames(
                 x, y, z, dmap.is_f64, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
-                self.crop.ctypes.data, rig.W, rig.H, vu.data_ptr(), vis.data_ptr(), cm.data_ptr(), self._stream()))
+                cropa.ctypes.data, rig.W, rig.H, vu.data_ptr(), vis.data_ptr(), cm.data_ptr(), self._stream()))
             return vu, vis, cm
 
     # ------------------------------------------------------------------ fused render
@@ -159,9 +174,10 @@ class Engine:
         rows = (rig.C + cols - 1) // cols
         return (F, rows * rig.H, cols * rig.W, 3)
 
-    def render_frames(self, dmap, rig, w2c, src, out=None, cols=3):
+    def render_frames(self, dmap, rig, w2c, src, out=None, cols=3, crop=None):
         """src [F,C,H,W,3] uint8 device tensor -> mosaic [F, rows*H, cols*W, 3] uint8 device tensor."""
         torch = _torch()
+        cropa = self._crop(crop)
         with torch.cuda.device(self.device):
             T = w2c if (isinstance(w2c, torch.Tensor) and w2c.dtype == torch.float64 and w2c.is_cuda
                         and w2c.dim() == 2) else self._mats(w2c)
@@ -177,7 +193,7 @@ class Engine:
             x, y, z = dmap.ptrs()
             _lib.check(self.lib.cama_render_frames(
                 x, y, z, dmap.is_f64, dmap.colour.data_ptr(), dmap.N, T.data_ptr(), F,
-                rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C, self.crop.ctypes.data, rig.W, rig.H,
+                rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H,
                 src.data_ptr(), out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
                 self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), self._stream()))
             return out

@@ -100,7 +100,7 @@ def make_clip(clip_path, n_frames=5, seed=0, n_lines=6, verts_per_line=5,
               line_len_m=2.0, raster_size=400, image_mode="none",
               image_size=(900, 1600), pose_offset_s=0.25, pose_dt_s=0.5,
               with_cama=True, with_nuscenes=True, nus_line_len_m=None,
-              world_anchor=(-290.0, -280.0), extra_labels=True, d_nonzero=False):
+              world_anchor=(-290.0, -280.0), extra_labels=True, d_nonzero=False, origin_size=(900, 1600)):
     """Write one synthetic clip; returns a dict describing it.
 
     n_frames counts *sync timestamps* (the demo renders indices 1..n_frames-1,
@@ -145,10 +145,13 @@ def make_clip(clip_path, n_frames=5, seed=0, n_lines=6, verts_per_line=5,
         d = [0.0] * 8
         if d_nonzero:
             d = [-0.05, 0.01, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+        if tuple(origin_size) != (900, 1600):       # small native resolution for cheap tests
+            K[0] *= origin_size[1] / 1600.0
+            K[1] *= origin_size[0] / 900.0
         calibration[name] = {
             "center_u": K[0, 2], "center_v": K[1, 2], "distort": d,
             "focal_u": K[0, 0], "focal_v": K[1, 1], "fov": 70.0,
-            "image_height": 900, "image_width": 1600, "K": K.tolist(), "d": d,
+            "image_height": int(origin_size[0]), "image_width": int(origin_size[1]), "K": K.tolist(), "d": d,
         }
     attribute = {
         "start_time": frame_ms[0], "end_time": frame_ms[-1], "status": "synthetic",

@@ -65,6 +65,13 @@ int cama_transform_points(const void *xyz, int32_t xyz_is_f64, int64_t N,
                           double *out_xyz, uint8_t *crop_mask, void *stream);
 
 /*
+ * Inclusive axis-aligned box test on already-transformed points: the mask of
+ * MapManager.crop_3d_instance_maps (cama/reproject.py:118-131) for a flat point list.
+ *   xyz [n,3] float64, crop host[6] {xmin,xmax,ymin,ymax,zmin,zmax}, mask [n] uint8
+ */
+int cama_crop_points(const double *xyz, int64_t n, const double *crop, uint8_t *mask, void *stream);
+
+/*
  * Per-camera chassis->camera transform, intrinsics, z>0, divide, in-image mask.
  * Replaces ClipManager.project_all_camera (cama/dataset.py:108-117) =
  * transform_3d_instance_maps (cama/reproject.py:108-116) + CameraManager.project_to_image
