@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- 6-camera reprojection frames/sec on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): one synthetic scene per GPU -- 6 pinhole cameras,
+40 rendered frames at 1600x900, ~1e4 densified map vertices (CAMA-style labels: BEV pixels + height raster),
+pose rows offset from the frame stamps so every frame interpolates.  Camera frames (uint8 BGR) are resident in
+HBM before the timed region; the mosaic output stays in HBM.
+
+One STEP = one pass of the hot path over the scene:
+    ClipManager.render_clip("cama")  =  frame poses for all 40 frames (host: vectorised seek+slerp, float32
+    cast, float32 inverse) -> cama_render_frames (count -> scan -> fill -> overlay, one launch each for all frames).
+value = frames rendered by all ranks / max-over-ranks wall time of the K steps (barrier + synchronize on both sides).
+Scenes are independent, so N GPUs render N scenes (weak scaling, no data-path collective); the only collective is
+one all_gather of a 5-double metric record over RCCL.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel = k_overlay, HBM-bound.  achieved = algorithmic bytes per launch
+                (13*N + 36*W*H per frame, SURVEY.md 8d, x frames per launch) / its mean duration measured live
+                with hipEvents on the launch stream (cama_profile_*).  peak 8000 GB/s.
+  cpu_baseline  oracle/cama_oracle.py (numpy port of the reference, per-point circle calls into C) timed on this
+                box's host cores for a bounded number of passes over the same scene; rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=40, help="rendered frames per scene")
+    ap.add_argument("--verts", type=int, default=10000, help="approximate densified vertex count")
+    ap.add_argument("--height", type=int, default=900)
+    ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    return ap.parse_args()
+
+
+def build_scene(args, rank, device):
+    import torch
+    from cama_amd.dataset import ClipManager
+    from cama_amd.frames import DeviceFrameSource
+    from cama_amd.synth import DEFAULT_CAMA_CONFIGS, make_clip
+    H, W = args.height, args.width
+    tmp = tempfile.mkdtemp(prefix=f"cama_bench_r{rank}_")
+    clip = os.path.join(tmp, "clip")
+    n_lines = max(2, round(args.verts / 500))
+    # CAMA labels are densified at 0.1 BEV px = 1 cm: a 5 m polyline of 11 vertices gives ~500 points
+    make_clip(clip, n_frames=args.frames + 1, seed=rank, n_lines=n_lines, verts_per_line=11, line_len_m=5.0,
+              raster_size=3000, origin_size=(900, 1600), with_nuscenes=False, extra_labels=False)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W)), clip)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(rank)
+    frames = torch.randint(0, 256, (args.frames + 1, 6, H, W, 3), dtype=torch.uint8, device=device, generator=gen)
+    cm.set_frame_source(DeviceFrameSource(frames))
+    return cm, frames, clip
+
+
+def cpu_baseline(cm, frames, clip, args, budget_s):
+    """Reference-structured CPU path (oracle, numpy + per-point C circle) on the same scene; bounded."""
+    from oracle import cama_oracle as O
+    from cama_amd.synth import CAMERA_NAMES
+    H, W = args.height, args.width
+    att = O.read_attribute(clip)
+    cams = [O.camera_model(att, n, output_size=(H, W)) for n in CAMERA_NAMES]
+    labels = json.load(open(os.path.join(clip, "maps", "map_labels.json")))
+    bev = np.load(os.path.join(clip, "maps", "vision_road_mlp_ft.npy"))
+    static = O.static_map_cama(bev, labels)                     # per-clip setup, not timed (GPU side: ClipManager())
+    host_frames = frames.cpu().numpy()
+    stamps, poses = O.pose_track(clip, att, cm.configs, "cama")
+    secs = O.sensor_seconds(att, cm.configs["camera_main"], sync=True)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for idx in range(1, len(secs)):
+            w2c = O.frame_world2chassis(stamps, poses, secs[idx])
+            cropped = O.crop_instances(O.transform_instances(static, w2c))
+            maps_2d = O.project_all(cropped, cams)
+            imgs = {}
+            for c, cam in enumerate(cams):
+                img = host_frames[idx, c].copy()                # stands in for imread+remap (frames are pre-decoded)
+                imgs[cam["name"]] = O.render_instances(img, maps_2d[cam["name"]])
+            O.mosaic(imgs)
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{done} frames of the same scene ({W}x{H}, 6 cams) in {dt:.1f} s; oracle/cama_oracle.py "
+                      f"single thread; host has {os.cpu_count()} cores; frames pre-decoded in RAM (no JPEG/remap)"}
+
+
+def pmc_traffic(config_key):
+    """HBM bytes per overlay launch from a committed rocprofv3 --pmc run (profiles/pmc_traffic.json), else None."""
+    p = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(p))
+        return rec["bytes_per_launch"] if rec.get("config") == config_key else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    os.environ.setdefault("CAMA_DEVICE", f"cuda:{local}")
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from cama_amd import _lib, runtime
+    cm, frames, clip = build_scene(args, rank, device)
+    eng = runtime.engine()
+    rig = cm._rig()
+    N = cm._static("cama").device().N
+    idx, _ = cm.frame_poses("cama")
+    F = len(idx)
+    assert F == args.frames, (F, args.frames)
+    out = torch.empty(eng.mosaic_shape(rig, F), dtype=torch.uint8, device=device)
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        cm.render_clip("cama", out=out)
+    sync_all()
+    L = _lib.lib()
+    L.cama_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cm.render_clip("cama", out=out)
+    sync_all()
+    dt = time.perf_counter() - t0
+    import ctypes
+    ov_ms, ov_n = ctypes.c_double(0.0), ctypes.c_int32(0)
+    L.cama_profile_collect(ctypes.byref(ov_ms), ctypes.byref(ov_n))
+    L.cama_profile_enable(0)
+
+    rec = torch.tensor([float(F * args.steps), dt, ov_ms.value, float(ov_n.value), float(N)], dtype=torch.float64,
+                       device=device)
+    if world > 1:
+        allrec = torch.empty((world, rec.numel()), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allrec, rec)               # the one collective: metric reduction over RCCL/xGMI
+    else:
+        allrec = rec[None]
+    allrec = allrec.cpu().numpy()
+
+    if rank == 0:
+        H, W = args.height, args.width
+        total_frames = float(allrec[:, 0].sum())
+        wall = float(allrec[:, 1].max())
+        fps = total_frames / wall
+        bytes_per_frame = 13 * N + 36 * W * H
+        launches = max(1.0, float(allrec[0, 3]))
+        ov_avg_ms = float(allrec[0, 2]) / launches
+        frames_per_launch = F * args.steps / launches
+        achieved = bytes_per_frame * frames_per_launch / (ov_avg_ms * 1e-3) / 1e9 if ov_avg_ms > 0 else 0.0
+        cfg_key = f"N={N},F={F},{W}x{H}"
+        line = {
+            "metric": "6-cam frames/sec (1600x900, ~10k map verts)" if (W, H) == (1600, 900)
+                      else f"6-cam frames/sec ({W}x{H})",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: one scene per GPU, 6 cams x %d frames, %d densified verts, "
+                                   "%dx%d, frames resident in HBM" % (F, N, W, H),
+                       "frames_per_step": F, "verts": N, "width": W, "height": H,
+                       "sharding": "one scene per rank, no data-path collective"},
+            "hbm_GBps_whole_step": bytes_per_frame * fps / world / 1e9,
+            "hbm_frac_whole_step": bytes_per_frame * fps / world / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_overlay", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(cfg_key),
+                         "avg_launch_ms": ov_avg_ms, "launches": int(launches),
+                         "bytes_per_launch": bytes_per_frame * frames_per_launch},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(cm, frames, clip, args, args.cpu_seconds)
+            line["speedup_vs_cpu_baseline"] = fps / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

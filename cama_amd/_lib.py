@@ -30,6 +30,8 @@ SIGNATURES = {
     "cama_stamp_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_circle_halfwidths": (_i32, [_i32, _vp]),
     "cama_overlay_band_rows": (_i32, [_i32]),
+    "cama_profile_enable": (_i32, [_i32]),
+    "cama_profile_collect": (_i32, [_vp, _vp]),
 }
 
 _lib = None
@@ -46,6 +48,9 @@ def lib():
             raise CamaHipError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  cama_amd has no CPU fallback.")
+        # torch ships its own libamdhip64.so.7; load it first so this library binds to the SAME HIP runtime
+        # (two runtimes in one process do not share devices, streams or allocations)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

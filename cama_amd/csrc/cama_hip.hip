@@ -26,6 +26,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "cama_hip.h"
 
@@ -47,6 +49,26 @@ int fail(int code, const char *fmt, ...)
         hipError_t e_ = (expr);                                                            \
         if (e_ != hipSuccess) return fail(CAMA_EHIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// Opt-in timing of the dominant kernel (k_overlay) with HIP events recorded on the launch stream.
+struct ProfileState {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // recorded, not yet collected
+    std::vector<hipEvent_t> pool;
+};
+thread_local ProfileState g_prof;
+
+hipEvent_t prof_event()
+{
+    hipEvent_t e = nullptr;
+    if (!g_prof.pool.empty()) {
+        e = g_prof.pool.back();
+        g_prof.pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+    }
+    return e;
+}
 
 constexpr int BLOCK = 256;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte chunk (global_load_dwordx4)
@@ -619,6 +641,31 @@ int cama_circle_halfwidths(int32_t radius, int32_t *hw)
 
 int cama_overlay_band_rows(int32_t W) { return band_rows_for(W); }
 
+int cama_profile_enable(int32_t on)
+{
+    g_prof.on = on != 0;
+    return CAMA_OK;
+}
+
+int cama_profile_collect(double *total_ms, int32_t *launches)
+{
+    double sum = 0.0;
+    int n = 0;
+    for (auto &pr : g_prof.pending) {
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        sum += ms;
+        ++n;
+        g_prof.pool.push_back(pr.first);
+        g_prof.pool.push_back(pr.second);
+    }
+    g_prof.pending.clear();
+    if (total_ms) *total_ms = sum;
+    if (launches) *launches = n;
+    return CAMA_OK;
+}
+
 int cama_transform_points(const void *xyz, int32_t xyz_is_f64, int64_t N, const double *T, int32_t F,
                           const double *crop, double *out_xyz, uint8_t *crop_mask, void *stream)
 {
@@ -780,11 +827,21 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_prof.on) {
+        ev0 = prof_event();
+        ev1 = prof_event();
+        if (ev0 && ev1) HIP_TRY(hipEventRecord(ev0, s));
+    }
     if (vec)
         hipLaunchKernelGGL(k_overlay<true>, dim3(nblocks), dim3(BLOCK), lds, s, o);
     else
         hipLaunchKernelGGL(k_overlay<false>, dim3(nblocks), dim3(BLOCK), lds, s, o);
     HIP_TRY(hipGetLastError());
+    if (ev0 && ev1) {
+        HIP_TRY(hipEventRecord(ev1, s));
+        g_prof.pending.emplace_back(ev0, ev1);
+    }
     return CAMA_OK;
 }
 

@@ -157,6 +157,7 @@ class ClipManager:
         self.output_size = tuple(output_size) if output_size is not None else \
             tuple(configs.get("output_size", (540, 960)))
         self._static_cache = {}
+        self._track_cache = {}
         self._rig_cache = None
         self._frame_source = None
         if clip_path is not None:
@@ -229,6 +230,22 @@ class ClipManager:
         return self._frame_source
 
     # ------------------------------------------------------------------ poses
+    def _track(self, dataset):
+        """(PoseTransformer, frame seconds) of one dataset pass; parsed from the clip files once and kept, like the
+        static maps (the reference re-reads them on every yield_frame call, cama/dataset.py:80-87)."""
+        hit = self._track_cache.get(dataset)
+        if hit is None:
+            dr = DatasetReader(self.clip_path)
+            if dataset == "nuscenes":
+                pt = self.get_pt_nuscenes(dr)
+            elif dataset == "cama":
+                pt = self.get_pt_cama(dr)
+            else:
+                raise UnboundLocalError(f"unknown dataset {dataset!r}")   # the reference fails on `pt` here
+            hit = (pt, dr.get_sensor_timestamp(self.configs["camera_main"], sync=True))
+            self._track_cache[dataset] = hit
+        return hit
+
     def frame_poses(self, dataset):
         """(image indices (F,), world->chassis (F,4,4) float32) for every renderable frame of the clip.
 
@@ -236,14 +253,7 @@ class ClipManager:
         chassis->world, cast to float32, float32 general inverse -- done for all frames at once.  Frames whose
         pose lookup would raise RuntimeError are left out, as the reference skips them.  Index 0 is never
         rendered (dataset.py:88 starts at 1)."""
-        dr = DatasetReader(self.clip_path)
-        if dataset == "nuscenes":
-            pt = self.get_pt_nuscenes(dr)
-        elif dataset == "cama":
-            pt = self.get_pt_cama(dr)
-        else:
-            raise UnboundLocalError(f"unknown dataset {dataset!r}")   # the reference fails on `pt` here
-        secs = dr.get_sensor_timestamp(self.configs["camera_main"], sync=True)
+        pt, secs = self._track(dataset)
         if len(secs) <= 1:
             return np.zeros(0, np.int64), np.zeros((0, 4, 4), np.float32)
         ok, c2w = pt.seek_many(secs[1:], 0.5, interpolate=True)
@@ -256,7 +266,7 @@ class ClipManager:
     def yield_frame(self, dataset):
         idx, w2c = self.frame_poses(dataset)
         lookup = {int(i): k for k, i in enumerate(idx)}
-        n_stamps = len(DatasetReader(self.clip_path).get_sensor_timestamp(self.configs["camera_main"], sync=True))
+        n_stamps = len(self._track(dataset)[1])
         for image_idx in _tqdm(range(1, n_stamps)):
             k = lookup.get(image_idx)
             if k is None:

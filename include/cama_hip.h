@@ -143,8 +143,17 @@ int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n,
 /* Host helper: half-widths of OpenCV's filled midpoint circle, hw[0..radius]; returns radius+1 or <0. */
 int cama_circle_halfwidths(int32_t radius, int32_t *hw /* host */);
 
-/* Timing probe used by bench.py: enqueue-side band height used by the overlay kernel (rows per band). */
+/* Rows per band the overlay kernel uses for images of width W (its LDS owner table is rows*W*4 bytes). */
 int cama_overlay_band_rows(int32_t W);
+
+/*
+ * Live timing of the dominant kernel (the overlay) for roofline reporting.  While enabled on the calling
+ * thread, every cama_render_frames call records a hipEvent pair around its overlay launch, on the stream
+ * the kernel is launched on.  cama_profile_collect waits for the recorded events (host-blocking), returns
+ * the summed elapsed milliseconds and the number of launches since the last collect, and recycles the events.
+ */
+int cama_profile_enable(int32_t on);
+int cama_profile_collect(double *total_ms /* host */, int32_t *launches /* host */);
 
 #ifdef __cplusplus
 }
