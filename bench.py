@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--verts", type=int, default=10000, help="approximate densified vertex count")
     ap.add_argument("--height", type=int, default=900)
     ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="single stream: binning and overlay of consecutive steps do not overlap")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     return ap.parse_args()
 
@@ -149,14 +151,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    pipelined = not args.no_pipeline
     for _ in range(args.warmup):
-        cm.render_clip("cama", out=out)
+        cm.render_clip("cama", out=out, pipelined=pipelined)
+    eng.join()
     sync_all()
     L = _lib.lib()
     L.cama_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        cm.render_clip("cama", out=out)
+        cm.render_clip("cama", out=out, pipelined=pipelined)
+    eng.join()
     sync_all()
     dt = time.perf_counter() - t0
     import ctypes
@@ -193,7 +198,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: one scene per GPU, 6 cams x %d frames, %d densified verts, "
                                    "%dx%d, frames resident in HBM" % (F, N, W, H),
                        "frames_per_step": F, "verts": N, "width": W, "height": H,
-                       "sharding": "one scene per rank, no data-path collective"},
+                       "sharding": "one scene per rank, no data-path collective",
+                       "streams": "2 (binning of step k+1 overlaps overlay of step k)" if pipelined else "1"},
             "hbm_GBps_whole_step": bytes_per_frame * fps / world / 1e9,
             "hbm_frac_whole_step": bytes_per_frame * fps / world / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "k_overlay", "achieved": achieved, "peak": HBM_PEAK_GBS,

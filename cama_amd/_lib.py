@@ -9,7 +9,7 @@ import os
 from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
-LIB_PATH = join(_HERE, "libcama_hip.so")
+LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
 ABI_VERSION = 1
 
 _vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
@@ -26,6 +26,9 @@ SIGNATURES = {
     "cama_render_scratch_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _i32]),
     "cama_render_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
                                   _vp, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "cama_bin_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32,
+                               _vp, _sz, _vp]),
+    "cama_overlay_frames": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_stamp_scratch_bytes": (_sz, [_i32, _i32]),
     "cama_stamp_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_circle_halfwidths": (_i32, [_i32, _vp]),

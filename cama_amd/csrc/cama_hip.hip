@@ -72,6 +72,16 @@ hipEvent_t prof_event()
 
 constexpr int BLOCK = 256;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte chunk (global_load_dwordx4)
+#ifndef OVERLAY_UNROLL
+#define OVERLAY_UNROLL 5          // 16-byte chunks in flight per thread in the overlay copy loop
+#endif
+#ifdef OVERLAY_PLAIN_MEM
+#define OVERLAY_LOAD(p) (*(p))
+#define OVERLAY_STORE(v, p) (*(p) = (v))
+#else                             // streaming data, never re-read: non-temporal hint
+#define OVERLAY_LOAD(p) __builtin_nontemporal_load(p)
+#define OVERLAY_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
 constexpr int CAM_STRIDE = 21;  // 12 (3x4 of chassis->camera) + 9 (K)
 
 struct Crop { double v[6]; };
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(BLOCK) void k_overlay(OverlayArgs a)
 
     if (VEC) {
         // the band is one contiguous byte range in src: chunk j of the band is src16[j]
-        constexpr int U = 5;
+        constexpr int U = OVERLAY_UNROLL;
         const u32x4 *s16 = reinterpret_cast<const u32x4 *>(sband);
         const uint32_t nchunks = (uint32_t)nrows * a.cpr;
         for (uint32_t base = threadIdx.x; base < nchunks; base += BLOCK * U) {
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void k_overlay(OverlayArgs a)
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 const uint32_t idx = base + j * BLOCK;
-                if (idx < nchunks) v[j] = __builtin_nontemporal_load(s16 + idx);
+                if (idx < nchunks) v[j] = OVERLAY_LOAD(s16 + idx);
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) {
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(BLOCK) void k_overlay(OverlayArgs a)
                     const uint32_t col = idx - row * a.cpr;
                     if (n) patch_chunk(v[j], s_owner + row * W, col, a.pal);
                     u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
-                    __builtin_nontemporal_store(v[j], drow + col);
+                    OVERLAY_STORE(v[j], drow + col);
                 }
             }
         }
@@ -743,24 +753,15 @@ size_t cama_render_scratch_bytes(int64_t N, int32_t F, int32_t C, int32_t H, int
     return L.total;
 }
 
-int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
-                       int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
-                       const double *crop, int32_t W, int32_t H, const uint8_t *src, uint8_t *mosaic, int32_t cols,
-                       int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
-                       size_t scratch_bytes, void *stream)
+// validation shared by the bin / overlay halves of the fused render
+static int check_render(int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, int32_t radius, const void *scratch,
+                        size_t scratch_bytes, ScratchLayout &L)
 {
     if (int rc = check_common(N, F, C, W, H)) return rc;
-    if (F == 0) return CAMA_OK;
-    if (cols < 1) return fail(CAMA_EINVAL, "cols=%d", cols);
-    if (!w2c || !c2cam || !K || !crop || !src || !mosaic || !palette_bgr || !scratch)
-        return fail(CAMA_EINVAL, "NULL pointer argument");
-    if (N && (!x || !y || !z || !colour_id)) return fail(CAMA_EINVAL, "NULL vertex buffer");
-    Disc disc;
-    if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
-    ScratchLayout L;
+    if (radius < 0 || radius > CAMA_MAX_RADIUS) return fail(CAMA_EINVAL, "radius %d out of range", radius);
+    if (!scratch) return fail(CAMA_EINVAL, "scratch is NULL");
     layout_scratch(N, F, C, H, W, radius, L);
-    if (scratch_bytes < L.total)
-        return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", scratch_bytes, L.total);
+    if (scratch_bytes < L.total) return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", scratch_bytes, L.total);
     if (L.capacity >= (1ull << 32))
         return fail(CAMA_EINVAL, "F*C*N*%d = %llu stamps exceed 32-bit offsets: render fewer frames per call",
                     L.bands_per_stamp, (unsigned long long)L.capacity);
@@ -769,15 +770,26 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
         return fail(CAMA_EINVAL, "radius %d too large for the fused path (needs 2r <= band rows = %d)", radius, L.R);
     if ((size_t)C * L.NB * 8 > 64 * 1024)
         return fail(CAMA_EINVAL, "C*bands = %d*%d exceeds the per-workgroup LDS histogram", C, L.NB);
-    const size_t lds = align_up((size_t)L.R * W * 4, 16);
-    if (lds > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the LDS owner table", W);
+    if (align_up((size_t)L.R * W * 4, 16) > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the LDS owner table", W);
+    return CAMA_OK;
+}
+
+int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
+                    int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                    const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch, size_t scratch_bytes,
+                    void *stream)
+{
+    ScratchLayout L;
+    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+    if (F == 0) return CAMA_OK;
+    if (!w2c || !c2cam || !K || !crop) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (N && (!x || !y || !z || !colour_id)) return fail(CAMA_EINVAL, "NULL vertex buffer");
 
     hipStream_t s = (hipStream_t)stream;
     char *base = (char *)scratch;
     uint32_t *counts = (uint32_t *)(base + L.counts), *cursor = (uint32_t *)(base + L.cursor);
     uint32_t *bin_off = (uint32_t *)(base + L.bin_off), *fc_total = (uint32_t *)(base + L.fc_total);
     uint32_t *fc_base = (uint32_t *)(base + L.fc_base);
-    uint2 *stamps = (uint2 *)(base + L.stamps);
     const int nfc = F * C;
 
     // counts and cursor are adjacent: one memset
@@ -788,7 +800,8 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
     a.w2c = w2c; a.c2cam = c2cam; a.K = K; a.C = C; a.W = W; a.H = H;
     memcpy(a.crop.v, crop, sizeof(a.crop.v));
     a.band_shift = log2i(L.R); a.NB = L.NB; a.radius = radius;
-    a.counts = counts; a.cursor = cursor; a.bin_off = bin_off; a.fc_base = fc_base; a.stamps = stamps;
+    a.counts = counts; a.cursor = cursor; a.bin_off = bin_off; a.fc_base = fc_base;
+    a.stamps = (uint2 *)(base + L.stamps);
     const dim3 fgrid((unsigned)((N + BLOCK - 1) / BLOCK), (unsigned)F);
     const size_t hist_lds = align_up((size_t)C * L.NB * 4, 16);
     if (N) {
@@ -809,13 +822,32 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
             hipLaunchKernelGGL((k_frames_bin<MODE_FILL, float>), fgrid, dim3(BLOCK), 2 * hist_lds, s, a);
         HIP_TRY(hipGetLastError());
     }
+    return CAMA_OK;
+}
+
+int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                        int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                        const void *scratch, size_t scratch_bytes, void *stream)
+{
+    ScratchLayout L;
+    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+    if (F == 0) return CAMA_OK;
+    if (cols < 1) return fail(CAMA_EINVAL, "cols=%d", cols);
+    if (!src || !mosaic || !palette_bgr) return fail(CAMA_EINVAL, "NULL pointer argument");
+    Disc disc;
+    if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
+    const size_t lds = align_up((size_t)L.R * W * 4, 16);
+    hipStream_t s = (hipStream_t)stream;
+    const char *base = (const char *)scratch;
+    const int nfc = F * C;
 
     OverlayArgs o{};
     o.src = src; o.mosaic = mosaic; o.C = C; o.H = H; o.W = W; o.cols = cols; o.R = L.R; o.NB = L.NB;
     const int rows = (C + cols - 1) / cols;
     o.mosaic_row_bytes = (size_t)cols * W * 3;
     o.mosaic_frame_bytes = (size_t)rows * H * o.mosaic_row_bytes;
-    o.counts = counts; o.bin_off = bin_off; o.fc_base = fc_base; o.stamps = stamps;
+    o.counts = (const uint32_t *)(base + L.counts); o.bin_off = (const uint32_t *)(base + L.bin_off);
+    o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)(base + L.stamps);
     o.disc = disc; o.pal = make_palette(palette_bgr);
     const bool vec = (W % 16 == 0) && (((uintptr_t)src | (uintptr_t)mosaic) % 16 == 0);
     if (vec) {
@@ -843,6 +875,22 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
         g_prof.pending.emplace_back(ev0, ev1);
     }
     return CAMA_OK;
+}
+
+int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
+                       int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                       const double *crop, int32_t W, int32_t H, const uint8_t *src, uint8_t *mosaic, int32_t cols,
+                       int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
+                       size_t scratch_bytes, void *stream)
+{
+    // validate the overlay half first so that nothing is enqueued when it would be rejected
+    if (F > 0 && (!src || !mosaic || !palette_bgr || !halfwidth || cols < 1))
+        return check_common(N, F, C, W, H) ? CAMA_EINVAL : fail(CAMA_EINVAL, "NULL pointer argument");
+    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, N, w2c, F, c2cam, K, C, crop, W, H, radius, scratch,
+                                 scratch_bytes, stream))
+        return rc;
+    return cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch, scratch_bytes,
+                               stream);
 }
 
 size_t cama_stamp_scratch_bytes(int32_t H, int32_t W)

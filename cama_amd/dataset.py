@@ -303,11 +303,13 @@ class ClipManager:
         return out
 
     # ------------------------------------------------------------------ whole-clip fused path
-    def render_clip(self, dataset, out=None, frames_per_launch=None, poses=None):
+    def render_clip(self, dataset, out=None, frames_per_launch=None, poses=None, pipelined=False):
         """Render every frame of `dataset` in launches of up to `frames_per_launch` frames.
 
         Returns (image indices (F,), mosaic device tensor [F, 2H, 3W, 3] uint8).  Nothing is copied to the host.
-        `poses` = a previous frame_poses() result to reuse."""
+        `poses` = a previous frame_poses() result to reuse.  pipelined=True issues the binning and overlay halves on
+        two side streams (Engine.render_frames_pipelined) so consecutive launches / clips overlap; the caller must
+        then call runtime.engine().join() before consuming `out` on the current stream."""
         import torch
         eng = runtime.engine()
         rig = self._rig()
@@ -327,5 +329,8 @@ class ClipManager:
         for lo in range(0, F, step):
             hi = min(F, lo + step)
             src = src_all.batch([int(i) for i in idx[lo:hi]])
-            eng.render_frames(dmap, rig, T[lo:hi], src, out=out[lo:hi], crop=crop)
+            if pipelined:
+                eng.render_frames_pipelined(dmap, rig, T[lo:hi], src, out[lo:hi], crop=crop)
+            else:
+                eng.render_frames(dmap, rig, T[lo:hi], src, out=out[lo:hi], crop=crop)
         return idx, out

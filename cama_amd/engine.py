@@ -71,6 +71,7 @@ class Engine:
         self.halfwidth = _lib.circle_halfwidths(self.radius)
         self.palette = np.ascontiguousarray(np.asarray(palette_bgr, np.uint8).reshape(2, 3))
         self._scratch = None
+        self._pipe = None
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -197,6 +198,64 @@ class Engine:
                 src.data_ptr(), out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
                 self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), self._stream()))
             return out
+
+    # ------------------------------------------------------------------ pipelined render (two streams)
+    def _pipeline(self):
+        torch = _torch()
+        if self._pipe is None:
+            self._pipe = {"bin": torch.cuda.Stream(self.device), "ov": torch.cuda.Stream(self.device),
+                          "slots": [{"buf": None, "free": None} for _ in range(2)], "turn": 0, "last": None}
+        return self._pipe
+
+    def render_frames_pipelined(self, dmap, rig, w2c, src, out, cols=3, crop=None):
+        """Like render_frames, but the binning half runs on a side stream and the overlay half on another, with
+        double-buffered scratch: call k+1's binning overlaps call k's overlay (HBM-bound) instead of queueing
+        behind it.  `src` / `w2c` must be complete on the CURRENT stream at call time; `out` is complete only
+        after join() (which makes the current stream wait for every overlay issued so far)."""
+        torch = _torch()
+        cropa = self._crop(crop)
+        P = self._pipeline()
+        with torch.cuda.device(self.device):
+            T = w2c if (isinstance(w2c, torch.Tensor) and w2c.dtype == torch.float64 and w2c.is_cuda
+                        and w2c.dim() == 2) else self._mats(w2c)
+            F = T.shape[0]
+            assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
+            assert tuple(src.shape) == (F, rig.C, rig.H, rig.W, 3)
+            assert tuple(out.shape) == self.mosaic_shape(rig, F, cols) and out.is_contiguous()
+            need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
+            slot = P["slots"][P["turn"]]
+            P["turn"] ^= 1
+            s_bin, s_ov = P["bin"], P["ov"]
+            ready = torch.cuda.current_stream(self.device).record_event()
+            s_bin.wait_event(ready)
+            if slot["free"] is not None:
+                s_bin.wait_event(slot["free"])            # the overlay that last read this scratch slot is done
+            if slot["buf"] is None or slot["buf"].numel() < need:
+                with torch.cuda.stream(s_bin):
+                    slot["buf"] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            buf = slot["buf"]
+            x, y, z = dmap.ptrs()
+            _lib.check(self.lib.cama_bin_frames(
+                x, y, z, dmap.is_f64, dmap.colour.data_ptr(), dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
+                rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, self.radius, buf.data_ptr(), buf.numel(),
+                s_bin.cuda_stream))
+            binned = s_bin.record_event()
+            s_ov.wait_event(binned)
+            _lib.check(self.lib.cama_overlay_frames(
+                src.data_ptr(), out.data_ptr(), dmap.N, F, rig.C, rig.H, rig.W, cols, self.radius,
+                self.halfwidth.ctypes.data, self.palette.ctypes.data, buf.data_ptr(), buf.numel(), s_ov.cuda_stream))
+            slot["free"] = s_ov.record_event()
+            P["last"] = slot["free"]
+            # keep the tensors the side streams read alive until they are done
+            T.record_stream(s_bin)
+            src.record_stream(s_ov)
+            out.record_stream(s_ov)
+            return out
+
+    def join(self):
+        """Make the current stream wait for all pipelined overlays issued so far."""
+        if self._pipe is not None and self._pipe["last"] is not None:
+            _torch().cuda.current_stream(self.device).wait_event(self._pipe["last"])
 
     def max_frames_per_call(self, dmap, rig, budget_bytes=4 << 30):
         """Largest F whose worst-case stamp scratch fits `budget_bytes` (and 32-bit stamp offsets)."""

@@ -129,6 +129,24 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
                        void *scratch, size_t scratch_bytes, void *stream);
 
 /*
+ * The two halves of cama_render_frames, for callers that pipeline scenes: the binning half (count -> scan ->
+ * fill; touches only the vertex buffer, matrices and scratch) of scene k+1 can run on one stream while the
+ * overlay half (reads src + scratch, writes mosaic) of scene k streams on another, each scene with its own
+ * scratch.  cama_render_frames == cama_bin_frames followed by cama_overlay_frames on one stream.  The caller
+ * orders the overlay after its own binning (stream order or an event).  Arguments as above.
+ */
+int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64,
+                    const uint8_t *colour_id, int64_t N,
+                    const double *w2c, int32_t F,
+                    const double *c2cam, const double *K, int32_t C,
+                    const double *crop, int32_t W, int32_t H, int32_t radius,
+                    void *scratch, size_t scratch_bytes, void *stream);
+int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t F, int32_t C,
+                        int32_t H, int32_t W, int32_t cols,
+                        int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                        const void *scratch, size_t scratch_bytes, void *stream);
+
+/*
  * Stamp-only overlay for caller-supplied 2D points (the generic CameraManager.render_maps,
  * cama/reproject.py:246-257, for one image): points are (v,u) float64 in draw order.
  *   vu [n,2] float64, colour_id [n] uint8, image [H,W,3] uint8 updated in place.

@@ -100,6 +100,15 @@ def test_render_clip_batched_equals_per_frame_and_device_source(tmp_path):
     idx2, mosaic2 = cm.render_clip("cama", frames_per_launch=2)
     assert idx.tolist() == idx2.tolist() == [1, 2, 3, 4, 5, 6]
     assert torch.equal(mosaic, mosaic2)
+    # two-stream pipelined issue (several launches in flight, scratch double-buffered) gives the same bytes
+    from cama_amd import runtime
+    outs = [torch.zeros_like(mosaic) for _ in range(4)]
+    for o in outs:
+        cm.render_clip("cama", out=o, frames_per_launch=2, pipelined=True)
+    runtime.engine().join()
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, mosaic)
     per_frame = []
     for image_idx, instance_map in cm.yield_frame("cama"):
         per_frame.append(cm.render_vectors(cm.project_all_camera(instance_map), image_idx).mosaic())
