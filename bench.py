@@ -15,7 +15,7 @@ One STEP = one pass of the hot path over the scene:
     cast, float32 inverse) -> cama_render_frames (count -> scan -> fill -> overlay, one launch each for all frames).
 value = frames rendered by all ranks / max-over-ranks wall time of the K steps (barrier + synchronize on both sides).
 Scenes are independent, so N GPUs render N scenes (weak scaling, no data-path collective); the only collective is
-one all_gather of a 5-double metric record over RCCL.
+one all_gather of an 8-double metric record (frames, seconds, overlay time, bytes, overlay checksum) over RCCL.
 
 Extra objects in the JSON line:
   roofline      dominant kernel = k_overlay, HBM-bound.  achieved = algorithmic bytes per launch
@@ -43,8 +43,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=40, help="rendered frames per scene")
     ap.add_argument("--verts", type=int, default=10000, help="approximate densified vertex count")
     ap.add_argument("--height", type=int, default=900)
@@ -169,20 +169,17 @@ def main():
     L.cama_profile_collect(ctypes.byref(ov_ms), ctypes.byref(ov_n))
     L.cama_profile_enable(0)
 
-    rec = torch.tensor([float(F * args.steps), dt, ov_ms.value, float(ov_n.value), float(N)], dtype=torch.float64,
-                       device=device)
-    if world > 1:
-        allrec = torch.empty((world, rec.numel()), dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(allrec, rec)               # the one collective: metric reduction over RCCL/xGMI
-    else:
-        allrec = rec[None]
-    allrec = allrec.cpu().numpy()
+    from cama_amd import shard
+    H, W = args.height, args.width
+    h_lo, h_hi = shard.overlay_hash(out)                        # checksum of this rank's final mosaics (untimed)
+    rec = [float(F * args.steps), dt, ov_ms.value, float(ov_n.value), float(N),
+           float(args.steps) * shard.scene_cost(F, N, W, H), float(h_lo % 2 ** 52), float(h_hi % 2 ** 52)]
+    allrec = shard.gather_records(rec, device=device)           # the one collective: metric all_gather over RCCL/xGMI
+    agg = shard.reduce_metrics(allrec)
 
     if rank == 0:
-        H, W = args.height, args.width
-        total_frames = float(allrec[:, 0].sum())
-        wall = float(allrec[:, 1].max())
-        fps = total_frames / wall
+        wall = agg["seconds"]
+        fps = agg["frames_per_s"]
         bytes_per_frame = 13 * N + 36 * W * H
         launches = max(1.0, float(allrec[0, 3]))
         ov_avg_ms = float(allrec[0, 2]) / launches
@@ -200,6 +197,7 @@ def main():
                        "frames_per_step": F, "verts": N, "width": W, "height": H,
                        "sharding": "one scene per rank, no data-path collective",
                        "streams": "2 (binning of step k+1 overlaps overlay of step k)" if pipelined else "1"},
+            "overlay_hash_per_rank": agg["hash"],
             "hbm_GBps_whole_step": bytes_per_frame * fps / world / 1e9,
             "hbm_frac_whole_step": bytes_per_frame * fps / world / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "k_overlay", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -546,6 +546,35 @@ __global__ __launch_bounds__(BLOCK) void k_apply_owner(const uint32_t *__restric
 }
 
 // ------------------------------------------------------------------------------------------
+// frame resample: cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) over float32 maps (reproject.py:238-239)
+// OpenCV's 8-bit remap quantises coordinates to 1/32 px (INTER_BITS = 5) and blends with 15-bit fixed-point
+// weights; for bilinear the weights (32-a)(32-b)*32 ... are exact integers summing to 1 << 15.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_resample(const uint8_t *__restrict__ src, int64_t src_stride,
+                                                    uint8_t *__restrict__ dst, int64_t dst_stride, int H0, int W0,
+                                                    int H, int W, const float *__restrict__ mapx,
+                                                    const float *__restrict__ mapy)
+{
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= H * W) return;
+    const uint8_t *s = src + (size_t)blockIdx.y * src_stride;
+    uint8_t *d = dst + (size_t)blockIdx.y * dst_stride + (size_t)p * 3;
+    const int sx = __float2int_rn(mapx[p] * 32.0f), sy = __float2int_rn(mapy[p] * 32.0f);   // cvRound: half to even
+    const int x0 = sx >> 5, y0 = sy >> 5, a = sx & 31, b = sy & 31;
+    const int w00 = (32 - a) * (32 - b) * 32, w01 = a * (32 - b) * 32, w10 = (32 - a) * b * 32, w11 = a * b * 32;
+    const bool xin0 = (unsigned)x0 < (unsigned)W0, xin1 = (unsigned)(x0 + 1) < (unsigned)W0;
+    const bool yin0 = (unsigned)y0 < (unsigned)H0, yin1 = (unsigned)(y0 + 1) < (unsigned)H0;
+    const uint8_t *r0 = s + ((size_t)y0 * W0 + x0) * 3, *r1 = r0 + (size_t)W0 * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const int p00 = (xin0 & yin0) ? r0[ch] : 0, p01 = (xin1 & yin0) ? r0[3 + ch] : 0;
+        const int p10 = (xin0 & yin1) ? r1[ch] : 0, p11 = (xin1 & yin1) ? r1[3 + ch] : 0;
+        const int v = (w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11 + (1 << 14)) >> 15;
+        d[ch] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------------
 int make_disc(int radius, const int32_t *hw, Disc &d)
@@ -891,6 +920,21 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
         return rc;
     return cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch, scratch_bytes,
                                stream);
+}
+
+int cama_resample_frames(const uint8_t *src, int64_t src_stride_bytes, uint8_t *dst, int64_t dst_stride_bytes,
+                         int32_t n, int32_t H0, int32_t W0, int32_t H, int32_t W, const float *mapx,
+                         const float *mapy, void *stream)
+{
+    if (n < 0 || n > 65535) return fail(CAMA_EINVAL, "n=%d out of range [0, 65535]", n);
+    if (H0 < 1 || W0 < 1 || H < 1 || W < 1 || (int64_t)H * W > (1ll << 30))
+        return fail(CAMA_EINVAL, "bad image sizes %dx%d -> %dx%d", W0, H0, W, H);
+    if (n == 0) return CAMA_OK;
+    if (!src || !dst || !mapx || !mapy) return fail(CAMA_EINVAL, "NULL pointer argument");
+    hipLaunchKernelGGL(k_resample, dim3((unsigned)(((int64_t)H * W + BLOCK - 1) / BLOCK), (unsigned)n), dim3(BLOCK), 0,
+                       (hipStream_t)stream, src, src_stride_bytes, dst, dst_stride_bytes, H0, W0, H, W, mapx, mapy);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
 }
 
 size_t cama_stamp_scratch_bytes(int32_t H, int32_t W)

@@ -199,6 +199,31 @@ class Engine:
                 self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), self._stream()))
             return out
 
+    # ------------------------------------------------------------------ frame resample (undistort + resize)
+    def resample(self, cm, src, out=None):
+        """src [n,H0,W0,3] (or [H0,W0,3]) uint8 device frames of CameraManager `cm` -> [n,H,W,3] at its output size.
+        `out` may be a strided view whose frames are each contiguous (e.g. mosaic-source[:, c])."""
+        torch = _torch()
+        from .frames import camera_maps
+        with torch.cuda.device(self.device):
+            single = src.dim() == 3
+            s = src[None] if single else src
+            assert s.is_cuda and s.dtype == torch.uint8 and s.is_contiguous() and s.shape[3] == 3
+            n, H0, W0 = int(s.shape[0]), int(s.shape[1]), int(s.shape[2])
+            H, W = int(cm.height), int(cm.width)
+            dev_maps = getattr(cm, "_resample_maps_dev", None)
+            if dev_maps is None or dev_maps[0].device != self.device:
+                mx, my = camera_maps(cm)
+                dev_maps = (torch.from_numpy(mx).to(self.device), torch.from_numpy(my).to(self.device))
+                cm._resample_maps_dev = dev_maps
+            if out is None:
+                out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=self.device)
+            assert tuple(out.shape) == (n, H, W, 3) and out.dtype == torch.uint8 and out[0].is_contiguous()
+            stride = out.stride(0) if n > 1 else H * W * 3
+            _lib.check(self.lib.cama_resample_frames(s.data_ptr(), H0 * W0 * 3, out.data_ptr(), stride, n, H0, W0, H, W,
+                                                     dev_maps[0].data_ptr(), dev_maps[1].data_ptr(), self._stream()))
+            return out[0] if single else out
+
     # ------------------------------------------------------------------ pipelined render (two streams)
     def _pipeline(self):
         torch = _torch()

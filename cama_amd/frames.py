@@ -34,6 +34,44 @@ def read_bgr(path):
         return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
+def undistort_rectify_map(K_origin, dist, K_new, W, H):
+    """float32 (mapx, mapy), each (H,W): source pixel of every destination pixel -- what
+    cv2.initUndistortRectifyMap(K_origin, dist, None, K_new, (W,H), CV_32FC1) computes (reproject.py:238), in
+    float64 then cast: normalise with K_new^-1, apply the rational + tangential + thin-prism distortion model,
+    project with K_origin.  For zero distortion and K_new = diag(sx, sy, 1) K_origin this is src = dst / scale."""
+    K0 = np.asarray(K_origin, np.float64)
+    ir = np.linalg.inv(np.asarray(K_new, np.float64))
+    k = np.zeros(14)
+    d = np.asarray(dist, np.float64).reshape(-1)
+    k[:min(14, d.size)] = d[:14]
+    k1, k2, p1, p2, k3, k4, k5, k6, s1, s2, s3, s4 = k[:12]
+    j = np.arange(W, dtype=np.float64)[None, :]
+    i = np.arange(H, dtype=np.float64)[:, None]
+    xw = j * ir[0, 0] + i * ir[0, 1] + ir[0, 2]
+    yw = j * ir[1, 0] + i * ir[1, 1] + ir[1, 2]
+    w = j * ir[2, 0] + i * ir[2, 1] + ir[2, 2]
+    x, y = xw / w, yw / w
+    x2, y2 = x * x, y * y
+    r2 = x2 + y2
+    xy2 = 2 * x * y
+    kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2)
+    xd = x * kr + p1 * xy2 + p2 * (r2 + 2 * x2) + s1 * r2 + s2 * r2 * r2
+    yd = y * kr + p1 * (r2 + 2 * y2) + p2 * xy2 + s3 * r2 + s4 * r2 * r2
+    u = K0[0, 0] * xd + K0[0, 1] * yd + K0[0, 2]
+    v = K0[1, 1] * yd + K0[1, 2]
+    return np.ascontiguousarray(u.astype(np.float32)), np.ascontiguousarray(v.astype(np.float32))
+
+
+def camera_maps(cm):
+    """(mapx, mapy) of a CameraManager, built once and cached on it."""
+    maps = getattr(cm, "_resample_maps", None)
+    if maps is None:
+        d = cm.d_origin if cm.d == [] else cm.d
+        maps = undistort_rectify_map(cm.K_origin, [] if d is None else d, cm.K, cm.width, cm.height)
+        cm._resample_maps = maps
+    return maps
+
+
 def resample_host_image(cm, image):
     """Undistort + resize one host image to the CameraManager's output size on the device."""
     import torch
@@ -67,11 +105,17 @@ class ClipFrameSource:
 
     def batch(self, image_indices):
         import torch
+        from . import runtime
         c0 = self.cm_list[0]
-        out = torch.empty((len(image_indices), len(self.cm_list), c0.height, c0.width, 3), dtype=torch.uint8,
-                          device=self.device)
-        for k, idx in enumerate(image_indices):
-            for c, cm in enumerate(self.cm_list):
-                img = cm.read_resized_image_by_index(idx)
-                out[k, c].copy_(torch.from_numpy(np.ascontiguousarray(img)))
+        F, C = len(image_indices), len(self.cm_list)
+        out = torch.empty((F, C, c0.height, c0.width, 3), dtype=torch.uint8, device=self.device)
+        eng = runtime.engine()
+        for c, cm in enumerate(self.cm_list):
+            raw = [read_bgr(cm.get_image_path(idx, True)) for idx in image_indices]
+            if not cm.needs_resample():
+                for k, img in enumerate(raw):
+                    out[k, c].copy_(torch.from_numpy(np.ascontiguousarray(img)))
+            else:       # upload the raw frames of this camera, resample them on the device straight into `out`
+                stack = torch.from_numpy(np.ascontiguousarray(np.stack(raw))).to(self.device)
+                eng.resample(cm, stack, out=out[:, c])
         return out

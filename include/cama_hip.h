@@ -158,6 +158,19 @@ int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n,
                       int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
                       void *scratch, size_t scratch_bytes, void *stream);
 
+/*
+ * Undistort + resize resample of n frames of ONE camera through precomputed float32 maps: the
+ * cv2.remap(image, mapx, mapy, INTER_LINEAR) of CameraManager.resize_image (cama/reproject.py:232-240); the
+ * maps are what cv2.initUndistortRectifyMap(K_origin, d, None, K, (W,H), CV_32FC1) returns, built once per
+ * camera on the host (the reference rebuilds them per frame).  OpenCV semantics restated: coordinates rounded
+ * to 1/32 px, 15-bit fixed-point bilinear weights, BORDER_CONSTANT 0.  PARITY UNPINNED (no OpenCV on either box).
+ *   src  frame i at src + i*src_stride_bytes, [H0,W0,3] uint8     dst frame i at dst + i*dst_stride_bytes, [H,W,3]
+ *   mapx, mapy [H,W] float32 source coordinates of each destination pixel
+ */
+int cama_resample_frames(const uint8_t *src, int64_t src_stride_bytes, uint8_t *dst, int64_t dst_stride_bytes,
+                         int32_t n, int32_t H0, int32_t W0, int32_t H, int32_t W,
+                         const float *mapx, const float *mapy, void *stream);
+
 /* Host helper: half-widths of OpenCV's filled midpoint circle, hw[0..radius]; returns radius+1 or <0. */
 int cama_circle_halfwidths(int32_t radius, int32_t *hw /* host */);
 

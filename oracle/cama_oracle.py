@@ -380,6 +380,56 @@ def circle_halfwidths(radius):
     return hw
 
 
+# --------------------------------------------------------------------------- frame resample (OpenCV restated)
+def undistort_map(K_origin, dist, K_new, W, H):
+    """cv2.initUndistortRectifyMap(K_origin, dist, None, K_new, (W,H), CV_32FC1) as called at
+    cama/reproject.py:238, restated from OpenCV's documented model (calib3d/imgproc undistort): per destination
+    pixel normalise with inv(K_new), distort (k1,k2,p1,p2,k3,k4,k5,k6[,s1..s4]), project with K_origin; float64
+    arithmetic, float32 result.  PARITY UNPINNED (OpenCV absent).  Scalar loops on purpose (independent of the
+    product's vectorised builder)."""
+    K0 = np.asarray(K_origin, np.float64)
+    ir = np.linalg.inv(np.asarray(K_new, np.float64))
+    k = np.zeros(14)
+    d = np.asarray(dist, np.float64).reshape(-1)
+    k[:d.size] = d
+    mapx = np.zeros((H, W), np.float32)
+    mapy = np.zeros((H, W), np.float32)
+    for i in range(H):
+        for j in range(W):
+            w = j * ir[2, 0] + i * ir[2, 1] + ir[2, 2]
+            x = (j * ir[0, 0] + i * ir[0, 1] + ir[0, 2]) / w
+            y = (j * ir[1, 0] + i * ir[1, 1] + ir[1, 2]) / w
+            x2, y2 = x * x, y * y
+            r2 = x2 + y2
+            kr = (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2) / (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2)
+            xd = x * kr + k[2] * 2 * x * y + k[3] * (r2 + 2 * x2) + k[8] * r2 + k[9] * r2 * r2
+            yd = y * kr + k[2] * (r2 + 2 * y2) + k[3] * 2 * x * y + k[10] * r2 + k[11] * r2 * r2
+            mapx[i, j] = K0[0, 0] * xd + K0[0, 1] * yd + K0[0, 2]
+            mapy[i, j] = K0[1, 1] * yd + K0[1, 2]
+    return mapx, mapy
+
+
+def remap_bilinear(image, mapx, mapy):
+    """cv2.remap(image, mapx, mapy, INTER_LINEAR) for 8-bit images (cama/reproject.py:239), restated from OpenCV's
+    fixed-point path: coordinates cvRound(map * 32) (INTER_BITS = 5), tap (x >> 5, y >> 5), weights
+    (32-a)(32-b)*32 etc. out of 1 << 15 (INTER_REMAP_COEF_BITS = 15), rounding + (1 << 14) >> 15,
+    BORDER_CONSTANT 0.  PARITY UNPINNED (OpenCV absent)."""
+    H0, W0 = image.shape[:2]
+    sx = np.rint(mapx.astype(np.float32) * np.float32(32)).astype(np.int64)
+    sy = np.rint(mapy.astype(np.float32) * np.float32(32)).astype(np.int64)
+    x0, y0, a, b = sx >> 5, sy >> 5, sx & 31, sy & 31
+    img = image.astype(np.int64)
+
+    def tap(y, x):
+        ok = (x >= 0) & (x < W0) & (y >= 0) & (y < H0)
+        v = img[np.clip(y, 0, H0 - 1), np.clip(x, 0, W0 - 1)]
+        return v * ok[..., None]
+    w00, w01, w10, w11 = (32 - a) * (32 - b) * 32, a * (32 - b) * 32, (32 - a) * b * 32, a * b * 32
+    acc = (w00[..., None] * tap(y0, x0) + w01[..., None] * tap(y0, x0 + 1) +
+           w10[..., None] * tap(y0 + 1, x0) + w11[..., None] * tap(y0 + 1, x0 + 1) + (1 << 14)) >> 15
+    return np.clip(acc, 0, 255).astype(np.uint8)
+
+
 # --------------------------------------------------------------------------- flat (C) frame path
 def flatten_instances(instances):
     """-> (xyz (N,3) contiguous, colour_id (N,) uint8, counts, classes)."""

@@ -137,3 +137,41 @@ def test_crop_dict_override_is_honoured(tmp_path):
         full = golden_instances(g, f"nuscenes_f{image_idx}_crop")
         assert len(pts) < sum(p.shape[0] for _, p in full)
         break
+
+
+def test_default_output_size_flow_with_jpeg_frames(tmp_path):
+    """The reference's default CameraManager output (540,960) from 900x1600 JPEGs: decode (Pillow) -> device
+    resample -> fused overlay, vs the oracle's restated remap + circle on the same decoded frames."""
+    from cama.dataset import ClipManager
+    from cama.tools import VideoGenerator
+    from cama_amd.frames import read_bgr
+    from cama_amd.synth import make_clip
+    clip = str(tmp_path / "clip")
+    make_clip(clip, n_frames=2, seed=6, n_lines=6, verts_per_line=5, line_len_m=3.0, raster_size=400,
+              image_mode="jpg", image_size=(900, 1600), with_nuscenes=False)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)                  # default output_size (540, 960)
+    assert (cm.cm_list[0].height, cm.cm_list[0].width) == (540, 960)
+    att = O.read_attribute(clip)
+    cams = [O.camera_model(att, n) for n in CAMERA_NAMES]
+    vg = object.__new__(VideoGenerator)
+    (image_idx, instance_map), = list(cm.yield_frame("cama"))
+    image = vg.concate_image(cm.render_vectors(cm.project_all_camera(instance_map), image_idx))
+    assert image.shape == (1080, 2880, 3)
+    want = {i: m2 for i, _, _, m2 in _oracle_frames(clip, cm.configs, "cama", cm.instance_maps["cama"], cams)}
+    imgs = {}
+    for c in cams:
+        raw = read_bgr(f"{clip}/{c['name']}/{att['sync'][c['name']][image_idx]}.jpg")
+        assert raw.shape == (900, 1600, 3)
+        # separable zero-distortion map: build one row / one column with the oracle and broadcast
+        mx, _ = O.undistort_map(c["K_origin"], c["d_origin"], c["K"], 960, 1)
+        _, my = O.undistort_map(c["K_origin"], c["d_origin"], c["K"], 1, 540)
+        small = O.remap_bilinear(raw, np.broadcast_to(mx, (540, 960)), np.broadcast_to(my, (540, 960)))
+        imgs[c["name"]] = O.render_instances(small, want[image_idx][c["name"]])
+    assert np.array_equal(image, O.mosaic(imgs))
+    # the per-camera host API gives the same resized frame
+    cam0 = cm.cm_list[1]
+    assert np.array_equal(cam0.read_resized_image_by_index(image_idx),
+                          O.remap_bilinear(read_bgr(cam0.get_image_path(image_idx, True)),
+                                           *[np.broadcast_to(m, (540, 960)) for m in
+                                             (O.undistort_map(cam0.K_origin, cam0.d_origin, cam0.K, 960, 1)[0],
+                                              O.undistort_map(cam0.K_origin, cam0.d_origin, cam0.K, 1, 540)[1])]))

@@ -204,3 +204,37 @@ def test_bad_arguments_fail_loudly(engine):
     assert L.cama_render_frames(None, None, None, 0, None, 0, None, 1, None, None, 99, None, 10, 10, None, None, 3, 2,
                                 None, None, None, 0, None) == -1
     assert b"C=99" in L.cama_last_error()
+
+
+def test_resample_matches_restated_opencv_remap(engine):
+    """Undistort+resize kernel vs the oracle's restatement of cv2.initUndistortRectifyMap + cv2.remap."""
+    import torch
+    from cama_amd import frames as FR
+    rng = np.random.default_rng(12)
+    H0, W0, H, W = 45, 80, 27, 48          # same 0.6 scale as 900x1600 -> 540x960
+    K0 = np.array([[63.3, 0.0, 40.8], [0.0, 63.3, 24.6], [0.0, 0.0, 1.0]])
+    Kn = K0.copy()
+    Kn[0] *= W / W0
+    Kn[1] *= H / H0
+    img = rng.integers(0, 256, (3, H0, W0, 3), dtype=np.uint8)
+    for dist in ([0.0] * 8, [-0.21, 0.07, 0.001, -0.002, 0.01, 0.0, 0.0, 0.0]):
+        mx, my = O.undistort_map(K0, dist, Kn, W, H)
+        pmx, pmy = FR.undistort_rectify_map(K0, dist, Kn, W, H)
+        assert np.array_equal(mx, pmx) and np.array_equal(my, pmy)      # product map builder == oracle's scalar loops
+        if not any(dist):
+            jj, ii = np.meshgrid(np.arange(W), np.arange(H))
+            assert np.allclose(mx, jj / 0.6, atol=1e-4) and np.allclose(my, ii / 0.6, atol=1e-4)   # src = dst / scale
+
+        class _CM:          # the few attributes Engine.resample reads
+            height, width, K_origin, K, d, d_origin = H, W, K0, Kn, [], np.asarray(dist)
+        got = engine.resample(_CM(), torch.from_numpy(img).cuda()).cpu().numpy()
+        for k in range(3):
+            assert np.array_equal(got[k], O.remap_bilinear(img[k], mx, my))
+    # out-of-range taps read the constant border 0
+    mx2, my2 = mx - 30.0, my + 10.0
+
+    class _CM2:
+        height, width, K_origin, K, d, d_origin = H, W, K0, Kn, [], np.zeros(8)
+        _resample_maps = (np.ascontiguousarray(mx2), np.ascontiguousarray(my2))
+    got = engine.resample(_CM2(), torch.from_numpy(img[0]).cuda()).cpu().numpy()
+    assert np.array_equal(got, O.remap_bilinear(img[0], mx2, my2)) and (got == 0).any()
