@@ -288,14 +288,24 @@ __global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
             const int c = c0 + j;
             e_slot[2 * j] = e_slot[2 * j + 1] = 0xffffffffu;
             e_uv[j] = 0;
-            if (c < a.C && in) {
-                const double *m = s_cam + c * CAM_STRIDE;
-                double px, py, pz, h0, h1, h2, u, v;
-                affine3x4(m, cx, cy, cz, px, py, pz);
-                linear3x3(m + 12, px, py, pz, h0, h1, h2);
-                if (pinhole(h0, h1, h2, Wd, Hd, u, v)) {
+            // wave-uniform guard: the shuffle below must be executed by every lane
+            if (c < a.C) {
+                uint32_t uv = 0xffffffffu;      // packed truncated pixel, or "not visible"
+                if (in) {
+                    const double *m = s_cam + c * CAM_STRIDE;
+                    double px, py, pz, h0, h1, h2, u, v;
+                    affine3x4(m, cx, cy, cz, px, py, pz);
+                    linear3x3(m + 12, px, py, pz, h0, h1, h2);
                     // reproject.py:249: astype(np.int32) truncation (values are >= 0 here)
-                    const int ui = (int)u, vi = (int)v;
+                    if (pinhole(h0, h1, h2, Wd, Hd, u, v)) uv = (uint32_t)(int)u | ((uint32_t)(int)v << 16);
+                }
+                // A disc is invisible if a LATER point stamps the very same pixel (same footprint, higher draw
+                // index).  The next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most
+                // far-range stamps collapse here, exactly, before they cost atomics, HBM or LDS conflicts.
+                const uint32_t uv_next = __shfl_down(uv, 1, 64);
+                const bool keep = (uv != 0xffffffffu) && ((__lane_id() == 63u) || (uv_next != uv));
+                if (keep) {
+                    const int vi = (int)(uv >> 16);
                     const int b0 = max(vi - a.radius, 0) >> a.band_shift;
                     const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;   // b1 <= b0 + 1 (host checks 2r <= R)
                     const uint32_t l0 = (uint32_t)(c * a.NB + b0);
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
                         atomicAdd(&s_cnt[l0], 1u);
                         if (b1 != b0) atomicAdd(&s_cnt[l0 + 1], 1u);
                     } else {
-                        e_uv[j] = (uint32_t)ui | ((uint32_t)vi << 16);
+                        e_uv[j] = uv;
                         e_slot[2 * j] = (l0 << 8) | atomicAdd(&s_cnt[l0], 1u);
                         if (b1 != b0) e_slot[2 * j + 1] = ((l0 + 1) << 8) | atomicAdd(&s_cnt[l0 + 1], 1u);
                     }

@@ -238,3 +238,27 @@ def test_resample_matches_restated_opencv_remap(engine):
         _resample_maps = (np.ascontiguousarray(mx2), np.ascontiguousarray(my2))
     got = engine.resample(_CM2(), torch.from_numpy(img[0]).cuda()).cpu().numpy()
     assert np.array_equal(got, O.remap_bilinear(img[0], mx2, my2)) and (got == 0).any()
+
+
+def test_dense_polyline_duplicate_pixels(engine):
+    """1 mm-spaced points far from the camera: long runs of consecutive vertices truncate to the same pixel and
+    alternate colours; dropping all but the last of each run (done in the binning kernel) must not change a byte."""
+    import torch
+    W, H, N = 320, 180, 30000
+    t = np.linspace(0.0, 1.0, N)
+    xyz = np.stack([20.0 + 25.0 * t, -3.0 + 6.0 * t + 0.2 * np.sin(40 * t), 0.02 * np.cos(9 * t)], -1).astype(np.float32)
+    col = ((np.arange(N) // 3) % 2).astype(np.uint8)
+    _, _, cams, _ = _random_scene(5, 10, 1, W, H)
+    w2c = np.stack([np.eye(4, dtype=np.float32), np.linalg.inv(np.array(
+        [[1, 0, 0, 2.0], [0, 1, 0, 0.5], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32))])
+    rig = _rig(engine, cams)
+    dmap = engine.upload_map(xyz, col)
+    src = np.random.default_rng(4).integers(0, 256, (2, 6, H, W, 3), dtype=np.uint8)
+    out = engine.render_frames(dmap, rig, w2c, torch.from_numpy(src).cuda()).cpu().numpy()
+    for f in range(2):
+        flat = O.frame_project_flat(xyz, w2c[f], cams, W, H)
+        vis = flat["vis"][1].astype(bool)                      # front camera
+        px = flat["vu"][1][vis].astype(np.int32)
+        runs = (np.diff(px, axis=0) == 0).all(axis=1).sum()
+        assert vis.sum() > 5000 and runs > vis.sum() // 2       # the case really has long duplicate runs
+        assert np.array_equal(out[f], O.frame_render_flat(src[f], flat["vu"], flat["vis"], col))
