@@ -454,9 +454,26 @@ template <bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_overlay(OverlayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x W, used only by stamped bands
+#ifdef OVERLAY_ORDER_FCB
     const uint32_t bin = blockIdx.x;
     const uint32_t fc = bin / (uint32_t)a.NB, b = bin - fc * (uint32_t)a.NB;
     const uint32_t f = fc / (uint32_t)a.C, c = fc - f * (uint32_t)a.C;
+#else
+    // Workgroup order (frame, mosaic row of cameras, band, camera column): the `cols` cameras that share a mosaic
+    // row-band are adjacent in launch order, so R full mosaic rows (R * cols*W*3 contiguous bytes) are written
+    // close together in time instead of one third at a time.
+    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
+    const uint32_t camrows = (C + cols - 1) / cols;
+    uint32_t t = blockIdx.x;
+    const uint32_t cc = t % cols; t /= cols;
+    const uint32_t b = t % NB;    t /= NB;
+    const uint32_t cr = t % camrows;
+    const uint32_t f = t / camrows;
+    const uint32_t c = cr * cols + cc;
+    if (c >= C) return;                                  // ragged last camera row
+    const uint32_t fc = f * C + c;
+    const uint32_t bin = fc * NB + b;
+#endif
     const int y0 = (int)b * a.R;
     const int nrows = min(a.R, a.H - y0);
     const int W = a.W;
@@ -893,7 +910,11 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
         o.cpr = (uint32_t)(W * 3 / 16);
         o.cpr_magic = (uint32_t)(((1ull << 32) + o.cpr - 1) / o.cpr);
     }
+#ifdef OVERLAY_ORDER_FCB
     const unsigned nblocks = (unsigned)((size_t)nfc * L.NB);
+#else
+    const unsigned nblocks = (unsigned)((size_t)F * rows * cols * L.NB);   // (frame, camera row, band, camera column)
+#endif
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
