@@ -72,6 +72,9 @@ hipEvent_t prof_event()
 
 constexpr int BLOCK = 256;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte chunk (global_load_dwordx4)
+#ifndef OVERLAY_BLOCK
+#define OVERLAY_BLOCK 256         // threads per overlay workgroup (one workgroup per band)
+#endif
 #ifndef OVERLAY_UNROLL
 #define OVERLAY_UNROLL 5          // 16-byte chunks in flight per thread in the overlay copy loop
 #endif
@@ -122,6 +125,37 @@ __device__ __forceinline__ bool pinhole(double h0, double h1, double h2, double 
     u = h0 / h2;
     v = h1 / h2;
     return (h2 > 0.0) & (h2 < __builtin_huge_val()) & (u >= 0.0) & (u < Wd) & (v >= 0.0) & (v < Hd);
+}
+
+// Bin-mode projection of one chassis-frame point into camera `m` (= 3x4 | 3x3): returns true and the packed
+// truncated pixel iff the reference's mask (reproject.py:192-198) is true.  Same FMA chains as pinhole(); the two
+// early-outs only skip work whose result is provably "not visible":
+//  (a) K's third row is (0,0,k) for every pinhole K; then h2 = fma(k, pz, +-0) = k*pz, so the sign test can run on
+//      the third affine row alone (5 fp64 ops instead of ~50 for the half-space behind the camera);
+//  (b) h0 < -h2 or h0 > (W+1)*h2 (same for h1/H) puts the IEEE quotient below 0 / at or above W even after
+//      rounding (one pixel of margin >> 1 ulp), so the two divisions (~28 fp64 ops) are skipped.
+__device__ __forceinline__ bool visible_pixel(const double *m, double cx, double cy, double cz, double Wd, double Hd,
+                                              uint32_t &uv)
+{
+    const double *K = m + 12;
+    double a;
+    a = m[8] * cx; a = __builtin_fma(m[9], cy, a); a = __builtin_fma(m[10], cz, a); a = __builtin_fma(m[11], 1.0, a);
+    const double pz = a;
+    const bool pinhole_row = (K[6] == 0.0) & (K[7] == 0.0);
+    if (pinhole_row && !(K[8] * pz > 0.0)) return false;
+    a = m[0] * cx; a = __builtin_fma(m[1], cy, a); a = __builtin_fma(m[2], cz, a); a = __builtin_fma(m[3], 1.0, a);
+    const double px = a;
+    a = m[4] * cx; a = __builtin_fma(m[5], cy, a); a = __builtin_fma(m[6], cz, a); a = __builtin_fma(m[7], 1.0, a);
+    const double py = a;
+    double h0, h1, h2;
+    linear3x3(K, px, py, pz, h0, h1, h2);
+    if (!(h2 > 0.0)) return false;
+    if ((h0 < -h2) | (h0 > (Wd + 1.0) * h2) | (h1 < -h2) | (h1 > (Hd + 1.0) * h2)) return false;
+    double u, v;
+    if (!pinhole(h0, h1, h2, Wd, Hd, u, v)) return false;
+    // reproject.py:249: astype(np.int32) truncation (values are >= 0 here)
+    uv = (uint32_t)(int)u | ((uint32_t)(int)v << 16);
+    return true;
 }
 
 // stage [C] x (3x4 chassis->camera | 3x3 K) into LDS
@@ -292,12 +326,8 @@ __global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
             if (c < a.C) {
                 uint32_t uv = 0xffffffffu;      // packed truncated pixel, or "not visible"
                 if (in) {
-                    const double *m = s_cam + c * CAM_STRIDE;
-                    double px, py, pz, h0, h1, h2, u, v;
-                    affine3x4(m, cx, cy, cz, px, py, pz);
-                    linear3x3(m + 12, px, py, pz, h0, h1, h2);
-                    // reproject.py:249: astype(np.int32) truncation (values are >= 0 here)
-                    if (pinhole(h0, h1, h2, Wd, Hd, u, v)) uv = (uint32_t)(int)u | ((uint32_t)(int)v << 16);
+                    uint32_t packed;
+                    if (visible_pixel(s_cam + c * CAM_STRIDE, cx, cy, cz, Wd, Hd, packed)) uv = packed;
                 }
                 // A disc is invisible if a LATER point stamps the very same pixel (same footprint, higher draw
                 // index).  The next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most
@@ -404,7 +434,7 @@ struct OverlayArgs {
 __device__ __forceinline__ void rasterise_stamps(uint32_t *s_owner, const uint2 *st, uint32_t n,
                                                  int y0, int nrows, int W, const Disc &disc)
 {
-    for (uint32_t s = threadIdx.x; s < n; s += BLOCK) {
+    for (uint32_t s = threadIdx.x; s < n; s += OVERLAY_BLOCK) {
         const uint2 r = st[s];
         const int u = (int)(r.x & 0xffffu), v = (int)(r.x >> 16);
         const uint32_t val = r.y + 1u;  // 0 = no owner
@@ -451,7 +481,7 @@ __device__ __forceinline__ void patch_chunk(u32x4 &d, const uint32_t *orow, uint
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(BLOCK) void k_overlay(OverlayArgs a)
+__global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x W, used only by stamped bands
 #ifdef OVERLAY_ORDER_FCB
@@ -482,7 +512,7 @@ __global__ __launch_bounds__(BLOCK) void k_overlay(OverlayArgs a)
     if (n) {
         uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
         const int n4 = (nrows * W + 3) >> 2;
-        for (int j = threadIdx.x; j < n4; j += BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
+        for (int j = threadIdx.x; j < n4; j += OVERLAY_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
         __syncthreads();
         rasterise_stamps(s_owner, a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]), n, y0, nrows, W, a.disc);
         __syncthreads();
@@ -498,16 +528,16 @@ __global__ __launch_bounds__(BLOCK) void k_overlay(OverlayArgs a)
         constexpr int U = OVERLAY_UNROLL;
         const u32x4 *s16 = reinterpret_cast<const u32x4 *>(sband);
         const uint32_t nchunks = (uint32_t)nrows * a.cpr;
-        for (uint32_t base = threadIdx.x; base < nchunks; base += BLOCK * U) {
+        for (uint32_t base = threadIdx.x; base < nchunks; base += OVERLAY_BLOCK * U) {
             u32x4 v[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                const uint32_t idx = base + j * BLOCK;
+                const uint32_t idx = base + j * OVERLAY_BLOCK;
                 if (idx < nchunks) v[j] = OVERLAY_LOAD(s16 + idx);
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                const uint32_t idx = base + j * BLOCK;
+                const uint32_t idx = base + j * OVERLAY_BLOCK;
                 if (idx < nchunks) {
                     const uint32_t row = __umulhi(idx, a.cpr_magic);
                     const uint32_t col = idx - row * a.cpr;
@@ -520,7 +550,7 @@ __global__ __launch_bounds__(BLOCK) void k_overlay(OverlayArgs a)
     } else {
         // generic width / alignment: one pixel per thread-iteration
         const int npix = nrows * W;
-        for (int p = threadIdx.x; p < npix; p += BLOCK) {
+        for (int p = threadIdx.x; p < npix; p += OVERLAY_BLOCK) {
             const int row = p / W, x = p - row * W;
             const uint8_t *s = sband + (size_t)p * 3;
             uint8_t b0 = s[0], b1 = s[1], b2 = s[2];
@@ -627,10 +657,12 @@ int band_rows_for(int W)
         int r = atoi(env);
         if (r == 4 || r == 8 || r == 16 || r == 32) return r;
     }
-    // owner table R*W*4 bytes in LDS; keep it near 52 KB so 3 workgroups share a CU's 160 KB
-    if (W <= 832) return 16;
-    if (W <= 1664) return 8;
-    return 4;
+    // Measured on MI355X (profiles/): ~20 KB of image per workgroup streams best (more, smaller
+    // workgroups balance stamped bands and keep the LDS owner table R*W*4 <= 26 KB -> 6 workgroups per CU).
+    // R must stay >= 2*radius so a disc touches at most two bands.
+    if (W >= 1200) return 4;
+    if (W >= 600) return 8;
+    return 16;
 }
 
 int log2i(int v)
@@ -926,9 +958,9 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
         if (ev0 && ev1) HIP_TRY(hipEventRecord(ev0, s));
     }
     if (vec)
-        hipLaunchKernelGGL(k_overlay<true>, dim3(nblocks), dim3(BLOCK), lds, s, o);
+        hipLaunchKernelGGL(k_overlay<true>, dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
     else
-        hipLaunchKernelGGL(k_overlay<false>, dim3(nblocks), dim3(BLOCK), lds, s, o);
+        hipLaunchKernelGGL(k_overlay<false>, dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) {
         HIP_TRY(hipEventRecord(ev1, s));

@@ -262,3 +262,32 @@ def test_dense_polyline_duplicate_pixels(engine):
         runs = (np.diff(px, axis=0) == 0).all(axis=1).sum()
         assert vis.sum() > 5000 and runs > vis.sum() // 2       # the case really has long duplicate runs
         assert np.array_equal(out[f], O.frame_render_flat(src[f], flat["vu"], flat["vis"], col))
+
+
+def test_early_outs_do_not_change_visibility_on_knife_edges(engine):
+    """Points placed exactly on / within an ulp of the image borders and of the z = 0 plane of the front camera:
+    the bin kernel's depth and frustum early-outs must agree with the full chain (oracle) bit for bit."""
+    import torch
+    W, H = 160, 96
+    _, _, cams, _ = _random_scene(5, 10, 1, W, H)
+    cam = cams[1]
+    Kinv = np.linalg.inv(cam["K"])
+    c2cam_inv = np.linalg.inv(cam["chassis2camera"])
+    pts = []
+    for u in (0.0, np.nextafter(0.0, -1), 1e-300, -1e-300, W, np.nextafter(float(W), 0), W - 1e-9, W + 0.5, -0.5, W / 2):
+        for v in (0.0, np.nextafter(0.0, -1), H, np.nextafter(float(H), 0), H + 0.5, -0.5, H / 2):
+            for depth in (1e-6, 0.5, 7.0, 300.0, -1e-6, 0.0, -3.0):
+                pc = Kinv @ np.array([u * depth, v * depth, depth])
+                pts.append((c2cam_inv @ np.r_[pc, 1.0])[:3])
+    xyz = np.asarray(pts, np.float64)
+    col = (np.arange(len(xyz)) % 2).astype(np.uint8)
+    w2c = np.eye(4, dtype=np.float32)[None]
+    crop = [-1e9, 1e9, -1e9, 1e9, -1e9, 1e9]
+    rig = _rig(engine, cams)
+    dmap = engine.upload_map(xyz, col)
+    src = np.random.default_rng(4).integers(0, 256, (1, 6, H, W, 3), dtype=np.uint8)
+    out = engine.render_frames(dmap, rig, w2c, torch.from_numpy(src).cuda(), crop=crop).cpu().numpy()
+    flat = O.frame_project_flat(xyz, w2c[0], cams, W, H, crop=crop)
+    vu, vis, _ = (t.cpu().numpy() for t in engine.project_frames(dmap, rig, w2c, crop=crop))
+    assert np.array_equal(vis[0], flat["vis"]) and 50 < flat["vis"][1].sum() < len(xyz)
+    assert np.array_equal(out[0], O.frame_render_flat(src[0], flat["vu"], flat["vis"], col))

@@ -1,0 +1,101 @@
+// Micro-benchmark (not part of the product): what does a plain linear HBM->HBM copy reach on this chip with the
+// same 16-byte non-temporal accesses the overlay kernel uses?  hipcc --offload-arch=gfx950 -O3 copy_ceiling.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_copy(const u32x4* __restrict__ s, u32x4* __restrict__ d, size_t n)
+{
+    size_t base = (size_t)blockIdx.x * 256 * U + threadIdx.x;
+    u32x4 v[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) { size_t i = base + (size_t)j * 256; if (i < n) v[j] = NT ? __builtin_nontemporal_load(s + i) : s[i]; }
+#pragma unroll
+    for (int j = 0; j < U; ++j) { size_t i = base + (size_t)j * 256; if (i < n) { if (NT) __builtin_nontemporal_store(v[j], d + i); else d[i] = v[j]; } }
+}
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_copy_persist(const u32x4* __restrict__ s, u32x4* __restrict__ d, size_t n)
+{
+    for (size_t base = (size_t)blockIdx.x * 256 * U + threadIdx.x; base < n; base += (size_t)gridDim.x * 256 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) { size_t i = base + (size_t)j * 256; if (i < n) v[j] = NT ? __builtin_nontemporal_load(s + i) : s[i]; }
+#pragma unroll
+        for (int j = 0; j < U; ++j) { size_t i = base + (size_t)j * 256; if (i < n) { if (NT) __builtin_nontemporal_store(v[j], d + i); else d[i] = v[j]; } }
+    }
+}
+// one workgroup per image row, one 16-byte chunk per thread, destination in 2x3 mosaic layout
+template <int LDS_BYTES>
+__global__ __launch_bounds__(320) void k_copy_mosaic_rows(const u32x4* __restrict__ s, u32x4* __restrict__ d, int C, int H, int cpr)
+{
+    __shared__ unsigned pad[LDS_BYTES / 4 + 1];
+    if (LDS_BYTES > 4 && threadIdx.x == 1023) pad[threadIdx.x] = 1;    // keep the allocation
+    const unsigned row = blockIdx.x;                  // (f*C + c)*H + y
+    const unsigned fc = row / H, y = row - fc * H;
+    const unsigned f = fc / C, c = fc - f * C;
+    const unsigned col = threadIdx.x;
+    if (col >= (unsigned)cpr) return;
+    u32x4 v = __builtin_nontemporal_load(s + (size_t)row * cpr + col);
+    const size_t drow = ((size_t)f * 2 * H + (size_t)(c / 3) * H + y) * 3 * cpr + (size_t)(c % 3) * cpr;
+    __builtin_nontemporal_store(v, d + drow + col);
+}
+// band workgroups (R rows, 256 threads, U chunks in flight) with mosaic destination, no stamp logic
+template <int U, int LDS_BYTES>
+__global__ __launch_bounds__(256) void k_copy_mosaic_bands(const u32x4* __restrict__ s, u32x4* __restrict__ d, int C, int H, int cpr, int R, int NB)
+{
+    __shared__ unsigned pad[LDS_BYTES / 4 + 1];
+    if (LDS_BYTES > 4 && threadIdx.x == 1023) pad[threadIdx.x] = 1;
+    const unsigned bin = blockIdx.x;
+    const unsigned fc = bin / NB, b = bin - fc * NB;
+    const unsigned f = fc / C, c = fc - f * C;
+    const int y0 = b * R, nrows = min(R, H - y0);
+    const unsigned nchunks = nrows * cpr;
+    const u32x4* sb = s + ((size_t)fc * H + y0) * cpr;
+    u32x4* db = d + ((size_t)f * 2 * H + (size_t)(c / 3) * H + y0) * 3 * cpr + (size_t)(c % 3) * cpr;
+    for (unsigned base = threadIdx.x; base < nchunks; base += 256 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) { unsigned i = base + j * 256; if (i < nchunks) v[j] = __builtin_nontemporal_load(sb + i); }
+#pragma unroll
+        for (int j = 0; j < U; ++j) { unsigned i = base + j * 256; if (i < nchunks) { unsigned r = i / cpr, col = i - r * cpr; __builtin_nontemporal_store(v[j], db + (size_t)r * 3 * cpr + col); } }
+    }
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+template <typename F> void timeit(const char* name, size_t bytes, F launch)
+{
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch();
+    CK(hipEventRecord(a));
+    for (int i = 0; i < 20; ++i) launch();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
+    printf("%-34s %8.3f ms  %7.1f GB/s (read+write)\n", name, ms, 2.0 * bytes / ms / 1e6);
+}
+int main()
+{
+    size_t bytes = (size_t)40 * 6 * 900 * 1600 * 3;   // one step's source frames (dst mosaic has the same size)
+    size_t n = bytes / 16;
+    u32x4 *s, *d; CK(hipMalloc(&s, bytes)); CK(hipMalloc(&d, bytes));
+    CK(hipMemset(s, 1, bytes)); CK(hipMemset(d, 2, bytes));
+    timeit("oneshot U=1 nt", bytes, [&] { hipLaunchKernelGGL((k_copy<1, true>), dim3((n + 255) / 256), dim3(256), 0, 0, s, d, n); });
+    timeit("oneshot U=4 nt", bytes, [&] { hipLaunchKernelGGL((k_copy<4, true>), dim3((n + 1023) / 1024), dim3(256), 0, 0, s, d, n); });
+    timeit("oneshot U=8 nt", bytes, [&] { hipLaunchKernelGGL((k_copy<8, true>), dim3((n + 2047) / 2048), dim3(256), 0, 0, s, d, n); });
+    timeit("oneshot U=4 plain", bytes, [&] { hipLaunchKernelGGL((k_copy<4, false>), dim3((n + 1023) / 1024), dim3(256), 0, 0, s, d, n); });
+    timeit("persistent 2048wg U=4 nt", bytes, [&] { hipLaunchKernelGGL((k_copy_persist<4, true>), dim3(2048), dim3(256), 0, 0, s, d, n); });
+    timeit("persistent 1024wg U=8 nt", bytes, [&] { hipLaunchKernelGGL((k_copy_persist<8, true>), dim3(1024), dim3(256), 0, 0, s, d, n); });
+    timeit("persistent 4096wg U=2 nt", bytes, [&] { hipLaunchKernelGGL((k_copy_persist<2, true>), dim3(4096), dim3(256), 0, 0, s, d, n); });
+    {
+        int C = 6, H = 900, cpr = 300, F = 40;
+        timeit("mosaic rows (1 chunk/thread)", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_rows<4>), dim3(F * C * H), dim3(320), 0, 0, s, d, C, H, cpr); });
+        timeit("mosaic rows + 25KB LDS/WG", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_rows<25600>), dim3(F * C * H), dim3(320), 0, 0, s, d, C, H, cpr); });
+        timeit("mosaic bands R=8 U=5 no LDS", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands<5, 4>), dim3(F * C * 113), dim3(256), 0, 0, s, d, C, H, cpr, 8, 113); });
+        timeit("mosaic bands R=8 U=5 51KB LDS", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands<5, 51200>), dim3(F * C * 113), dim3(256), 0, 0, s, d, C, H, cpr, 8, 113); });
+        timeit("mosaic bands R=4 U=5 no LDS", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands<5, 4>), dim3(F * C * 225), dim3(256), 0, 0, s, d, C, H, cpr, 4, 225); });
+        timeit("mosaic bands R=4 U=5 25KB LDS", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands<5, 25600>), dim3(F * C * 225), dim3(256), 0, 0, s, d, C, H, cpr, 4, 225); });
+        timeit("mosaic bands R=2 U=3 no LDS", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands<3, 4>), dim3(F * C * 450), dim3(256), 0, 0, s, d, C, H, cpr, 2, 450); });
+        timeit("mosaic bands R=1 U=2 no LDS", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands<2, 4>), dim3(F * C * 900), dim3(256), 0, 0, s, d, C, H, cpr, 1, 900); });
+    }
+    timeit("hipMemcpyDtoD", bytes, [&] { CK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, 0)); });
+    return 0;
+}
