@@ -388,37 +388,82 @@ class PoseTransformer:
             raise RuntimeError(f"time_diff = {d} is greater than t_max_diff {t_max_diff}")
         return self.absolute_transform[lo if d_lo < d_hi else hi]
 
+    def _interp_tables(self):
+        """Per-track tables for seek_many, rebuilt only when the pose list or stamps object changes:
+        sorted stamps, the (P,4,4) stack, and for every interval i the scipy left rotation R_i and
+        log(R_i^-1 R_{i+1}) -- exactly what a two-key Slerp builds per query, computed once per interval."""
+        key = (id(self.absolute_transform), len(self.absolute_transform), id(self.timestamps))
+        hit = getattr(self, "_tables", None)
+        if hit is None or hit[0] != key or hit[1] is not self.absolute_transform:
+            self._check_ready()
+            s = np.ascontiguousarray(self.timestamps[:, 0], dtype=np.float64)
+            stack = _as_stack(self.absolute_transform)
+            if stack.shape[0] >= 2:
+                rl = Rotation.from_matrix(stack[:-1, :3, :3])
+                rr = Rotation.from_matrix(stack[1:, :3, :3])
+                rotvec = (rl.inv() * rr).as_rotvec()
+            else:
+                rl, rotvec = None, np.zeros((0, 3))
+            key = (id(self.absolute_transform), len(self.absolute_transform), id(self.timestamps))
+            hit = (key, self.absolute_transform, s, stack, rl, rotvec)
+            self._tables = hit
+        return hit[2:]
+
     def seek_many(self, query_times, t_max_diff, interpolate=True):
         """Vectorised seek_by_timestamp(interpolate=True) over Q queries.
 
         Returns (ok (Q,) bool, poses (Q,4,4) float64): ok[q] is False exactly where the scalar call would
-        raise RuntimeError; poses[q] is bit-identical to the scalar result where ok[q].
+        raise RuntimeError; poses[q] is bit-identical to the scalar result where ok[q] (scipy's Rotation
+        arithmetic is element-wise, and the per-interval tables hold the same values a per-query Slerp builds).
         """
         if not interpolate:
             raise NotImplementedError("seek_many implements the interpolating lookup only")
-        self._check_ready()
+        if self._have_nothing():
+            raise RuntimeError("No poses found, pleas load poses first")
+        s, stack, rl, rotvec = self._interp_tables()
         q = np.asarray(query_times, np.float64).reshape(-1)
-        s = self.timestamps[:, 0].astype(np.float64)
         P = s.shape[0]
-        stack = _as_stack(self.absolute_transform)
         out = np.zeros((q.shape[0], 4, 4))
         ok = np.zeros(q.shape[0], bool)
-        close = np.isclose(s[None, :], q[:, None], rtol=1e-20, atol=_EXACT_ATOL)
-        exact = close.any(axis=1)
-        out[exact] = stack[close.argmax(axis=1)[exact]]
-        ok[exact] = True
+        hi = np.searchsorted(s, q, side="left")
+        # exact stamp (|dt| <= 1e-9, pose_transformer.py:623): only the neighbours of the insertion point can match,
+        # and the FIRST matching row wins like np.where(...)[0][0]
+        lo_n = np.clip(hi - 1, 0, P - 1)
+        hi_n = np.clip(hi, 0, P - 1)
+        tol = _EXACT_ATOL + 1e-20 * np.abs(q)
+        m_lo = np.abs(s[lo_n] - q) <= tol
+        m_hi = np.abs(s[hi_n] - q) <= tol
+        exact = m_lo | m_hi
+        if exact.any():
+            pick = np.where(m_lo, lo_n, hi_n)
+            # duplicate stamps: walk back to the first row within tolerance
+            e = np.flatnonzero(exact)
+            first = pick[e]
+            while True:
+                prev = np.clip(first - 1, 0, P - 1)
+                step = (first > 0) & (np.abs(s[prev] - q[e]) <= tol[e])
+                if not step.any():
+                    break
+                first = np.where(step, prev, first)
+            out[e] = stack[first]
+            ok[e] = True
         rest = np.flatnonzero(~exact)
         if rest.size:
-            qr = q[rest]
-            hi = np.searchsorted(s, qr, side="left")
-            valid = (hi < P) & (hi > 0)        # hi == 0 with |dt| <= 1e-9 is an exact hit, handled above
-            hi_c = np.clip(hi, 1, P - 1)
+            qr, hr = q[rest], hi[rest]
+            valid = (hr < P) & (hr > 0)        # hi == 0 with |dt| <= 1e-9 is an exact hit, handled above
+            hi_c = np.clip(hr, 1, max(P - 1, 1))
             lo_c = hi_c - 1
-            gap = s[hi_c] - s[lo_c]
-            valid &= ~(gap > t_max_diff)
-            sel = np.flatnonzero(valid)
-            if sel.size:
-                ratio = (qr[sel] - s[lo_c[sel]]) / gap[sel]
-                out[rest[sel]] = slerp_transform_batch(stack[lo_c[sel]], stack[hi_c[sel]], ratio)
-                ok[rest[sel]] = True
+            if P >= 2:
+                gap = s[hi_c] - s[lo_c]
+                valid &= ~(gap > t_max_diff)
+                sel = np.flatnonzero(valid)
+                if sel.size:
+                    li, hi_i = lo_c[sel], hi_c[sel]
+                    ratio = (qr[sel] - s[li]) / gap[sel]
+                    rot = (rl[li] * Rotation.from_rotvec(rotvec[li] * ratio[:, None])).as_matrix()
+                    r = ratio[:, None, None]
+                    T = stack[li] * (1 - r) + stack[hi_i] * r
+                    T[:, :3, :3] = rot
+                    out[rest[sel]] = T
+                    ok[rest[sel]] = True
         return ok, out
