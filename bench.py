@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--verts", type=int, default=10000, help="approximate densified vertex count")
     ap.add_argument("--height", type=int, default=900)
     ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--map", choices=["lanes", "random"], default="lanes",
+                    help="lanes: CAMA-style densified polylines along the drive (configs[1..3]); random: --verts "
+                         "uniformly random map vertices over the 600 m map in random order (configs[4] stress)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single stream: binning and overlay of consecutive steps do not overlap")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
@@ -63,11 +66,20 @@ def build_scene(args, rank, device):
     H, W = args.height, args.width
     tmp = tempfile.mkdtemp(prefix=f"cama_bench_r{rank}_")
     clip = os.path.join(tmp, "clip")
-    n_lines = max(2, round(args.verts / 500))
+    n_lines = max(2, round(args.verts / 500)) if args.map == "lanes" else 4
     # CAMA labels are densified at 0.1 BEV px = 1 cm: a 5 m polyline of 11 vertices gives ~500 points
     make_clip(clip, n_frames=args.frames + 1, seed=rank, n_lines=n_lines, verts_per_line=11, line_len_m=5.0,
               raster_size=3000, origin_size=(900, 1600), with_nuscenes=False, extra_labels=False)
     cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W)), clip)
+    if args.map == "random":
+        # stress map: uniformly random vertices, no spatial coherence between consecutive draw indices.
+        # instance_maps is the reference's public per-clip dict (cama/dataset.py:13-24): replace the static map.
+        rng = np.random.default_rng(1000 + rank)
+        pts = np.stack([rng.uniform(-300, 300, args.verts), rng.uniform(-300, 300, args.verts),
+                        rng.normal(0, 0.05, args.verts)], axis=-1).astype(np.float32)
+        half = args.verts // 2
+        cm.instance_maps["cama"] = [{"class": "lane_marking", "points": pts[:half]},
+                                    {"class": "Road_teeth", "points": pts[half:]}]
     gen = torch.Generator(device=device)
     gen.manual_seed(rank)
     frames = torch.randint(0, 256, (args.frames + 1, 6, H, W, 3), dtype=torch.uint8, device=device, generator=gen)
@@ -194,7 +206,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: one scene per GPU, 6 cams x %d frames, %d densified verts, "
                                    "%dx%d, frames resident in HBM" % (F, N, W, H),
-                       "frames_per_step": F, "verts": N, "width": W, "height": H,
+                       "frames_per_step": F, "verts": N, "width": W, "height": H, "map": args.map,
                        "sharding": "one scene per rank, no data-path collective",
                        "streams": "2 (binning of step k+1 overlaps overlay of step k)" if pipelined else "1"},
             "overlay_hash_per_rank": agg["hash"],

@@ -24,9 +24,9 @@ SIGNATURES = {
     "cama_project_frames": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
                                    _vp, _vp, _vp, _vp]),
     "cama_render_scratch_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _i32]),
-    "cama_render_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
+    "cama_render_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
                                   _vp, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
-    "cama_bin_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32,
+    "cama_bin_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32,
                                _vp, _sz, _vp]),
     "cama_overlay_frames": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_resample_frames": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),

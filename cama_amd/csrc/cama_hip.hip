@@ -230,6 +230,7 @@ enum { MODE_EMIT = 0, MODE_COUNT = 1, MODE_FILL = 2 };
 struct FrameArgs {
     const void *x, *y, *z;  // [N] each, float or double (template parameter T)
     const uint8_t *colour;
+    const uint32_t *key;    // optional [N]: draw index << 1 | colour (maps stored in a different order than drawn)
     int64_t N;
     const double *w2c, *c2cam, *K;
     int C, W, H;
@@ -308,7 +309,9 @@ __global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
                      z = (double)static_cast<const T *>(a.z)[i];
         affine3x4(s_w2c, x, y, z, cx, cy, cz);
         in = in_crop(a.crop, cx, cy, cz);
-        key = ((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1);
+        // draw index << 1 | colour.  Spatially re-ordered maps carry it per vertex (a.key), otherwise it is the
+        // storage index itself
+        key = a.key ? a.key[i] : (((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1));
     }
     // whole workgroup outside the crop box (the common case on site-sized maps): done
     if (!__syncthreads_or((int)in)) return;
@@ -329,11 +332,13 @@ __global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
                     uint32_t packed;
                     if (visible_pixel(s_cam + c * CAM_STRIDE, cx, cy, cz, Wd, Hd, packed)) uv = packed;
                 }
-                // A disc is invisible if a LATER point stamps the very same pixel (same footprint, higher draw
-                // index).  The next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most
+                // A disc is invisible if a LATER point (higher draw index) stamps the very same pixel (same
+                // footprint).  The next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most
                 // far-range stamps collapse here, exactly, before they cost atomics, HBM or LDS conflicts.
                 const uint32_t uv_next = __shfl_down(uv, 1, 64);
-                const bool keep = (uv != 0xffffffffu) && ((__lane_id() == 63u) || (uv_next != uv));
+                const uint32_t key_next = __shfl_down(key, 1, 64);
+                const bool covered = (__lane_id() != 63u) && (uv_next == uv) && (key_next > key);
+                const bool keep = (uv != 0xffffffffu) && !covered;
                 if (keep) {
                     const int vi = (int)(uv >> 16);
                     const int b0 = max(vi - a.radius, 0) >> a.band_shift;
@@ -863,7 +868,7 @@ static int check_render(int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, i
 }
 
 int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
-                    int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                    const uint32_t *draw_key, int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
                     const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch, size_t scratch_bytes,
                     void *stream)
 {
@@ -871,7 +876,7 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
     if (F == 0) return CAMA_OK;
     if (!w2c || !c2cam || !K || !crop) return fail(CAMA_EINVAL, "NULL pointer argument");
-    if (N && (!x || !y || !z || !colour_id)) return fail(CAMA_EINVAL, "NULL vertex buffer");
+    if (N && (!x || !y || !z || (!colour_id && !draw_key))) return fail(CAMA_EINVAL, "NULL vertex buffer");
 
     hipStream_t s = (hipStream_t)stream;
     char *base = (char *)scratch;
@@ -884,7 +889,7 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     HIP_TRY(hipMemsetAsync(counts, 0, L.bin_off - L.counts, s));
 
     FrameArgs a{};
-    a.x = x; a.y = y; a.z = z; a.colour = colour_id; a.N = N;
+    a.x = x; a.y = y; a.z = z; a.colour = colour_id; a.key = draw_key; a.N = N;
     a.w2c = w2c; a.c2cam = c2cam; a.K = K; a.C = C; a.W = W; a.H = H;
     memcpy(a.crop.v, crop, sizeof(a.crop.v));
     a.band_shift = log2i(L.R); a.NB = L.NB; a.radius = radius;
@@ -970,7 +975,7 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
 }
 
 int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
-                       int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                       const uint32_t *draw_key, int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
                        const double *crop, int32_t W, int32_t H, const uint8_t *src, uint8_t *mosaic, int32_t cols,
                        int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
                        size_t scratch_bytes, void *stream)
@@ -978,7 +983,7 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
     // validate the overlay half first so that nothing is enqueued when it would be rejected
     if (F > 0 && (!src || !mosaic || !palette_bgr || !halfwidth || cols < 1))
         return check_common(N, F, C, W, H) ? CAMA_EINVAL : fail(CAMA_EINVAL, "NULL pointer argument");
-    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, N, w2c, F, c2cam, K, C, crop, W, H, radius, scratch,
+    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, N, w2c, F, c2cam, K, C, crop, W, H, radius, scratch,
                                  scratch_bytes, stream))
         return rc;
     return cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch, scratch_bytes,

@@ -36,10 +36,39 @@ class CameraRig:
         self.K = torch.from_numpy(Ks.reshape(self.C, 9)).to(device)
 
 
-class DeviceMap:
-    """Static vertex buffer of one dataset pass: SoA x,y,z (float32 or float64) + colour id (uint8)."""
+def morton_order(xyz):
+    """Permutation that sorts points along a 2-D Morton (Z-order) curve over their x/y bounding box."""
+    xy = np.asarray(xyz[:, :2], np.float64)
+    lo = xy.min(axis=0)
+    span = np.maximum(xy.max(axis=0) - lo, 1e-9)
+    q = np.minimum(((xy - lo) / span * 65535.0).astype(np.uint64), np.uint64(65535))
 
-    def __init__(self, xyz, colour_id, device):
+    def spread(v):                                  # 16 bits -> every other bit of 32
+        v = (v | (v << np.uint64(8))) & np.uint64(0x00FF00FF)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x0F0F0F0F)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x33333333)
+        v = (v | (v << np.uint64(1))) & np.uint64(0x55555555)
+        return v
+    return np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)), kind="stable")
+
+
+def lacks_spatial_order(xyz, threshold_m=2.0):
+    """True when consecutive vertices are typically metres apart (polyline maps are centimetres apart)."""
+    if xyz.shape[0] < 4096:
+        return False
+    step = np.abs(np.diff(np.asarray(xyz[:, :2], np.float64), axis=0)).max(axis=1)
+    return float(np.median(step)) > threshold_m
+
+
+class DeviceMap:
+    """Static vertex buffer of one dataset pass: SoA x,y,z (float32 or float64) + colour id (uint8).
+
+    Draw order = storage order (instance-major, point-minor), which is what the reference draws in.  Maps whose
+    storage order has no spatial coherence (consecutive vertices metres apart) additionally get a Morton-sorted
+    copy for the fused render: whole workgroups then fall inside / outside the crop box and hit few stamp bins,
+    and the original index travels as the stamp key so "last writer wins" is unchanged."""
+
+    def __init__(self, xyz, colour_id, device, spatial_sort="auto"):
         torch = _torch()
         xyz = np.asarray(xyz)
         if xyz.dtype not in (np.float32, np.float64):
@@ -47,15 +76,29 @@ class DeviceMap:
         assert xyz.ndim == 2 and xyz.shape[1] == 3
         self.N = int(xyz.shape[0])
         self.is_f64 = int(xyz.dtype == np.float64)
-        soa = np.ascontiguousarray(xyz.T)                       # [3,N]
-        self.soa = torch.from_numpy(soa).to(device)
-        self.colour = torch.from_numpy(np.ascontiguousarray(colour_id, dtype=np.uint8)).to(device)
-        assert self.colour.numel() == self.N
+        colour_id = np.ascontiguousarray(colour_id, dtype=np.uint8)
+        assert colour_id.shape[0] == self.N
+        self.soa = torch.from_numpy(np.ascontiguousarray(xyz.T)).to(device)          # [3,N]
+        self.colour = torch.from_numpy(colour_id).to(device)
+        self.sorted_soa = self.sorted_key = None
+        if spatial_sort is True or (spatial_sort == "auto" and lacks_spatial_order(xyz)):
+            order = morton_order(xyz)
+            key = ((order.astype(np.uint32) << np.uint32(1)) | (colour_id[order] & 1).astype(np.uint32))
+            self.sorted_soa = torch.from_numpy(np.ascontiguousarray(xyz[order].T)).to(device)
+            self.sorted_key = torch.from_numpy(np.ascontiguousarray(key)).to(device)
 
     def ptrs(self):
         es = self.soa.element_size()
         base = self.soa.data_ptr()
         return base, base + self.N * es, base + 2 * self.N * es
+
+    def render_ptrs(self):
+        """(x, y, z, colour, key) device pointers for the fused render: the sorted copy when there is one."""
+        if self.sorted_soa is None:
+            return self.ptrs() + (self.colour.data_ptr(), None)
+        es = self.sorted_soa.element_size()
+        base = self.sorted_soa.data_ptr()
+        return base, base + self.N * es, base + 2 * self.N * es, self.colour.data_ptr(), self.sorted_key.data_ptr()
 
 
 class Engine:
@@ -93,8 +136,8 @@ class Engine:
         m = np.ascontiguousarray(np.asarray(mats, dtype=np.float64).reshape(-1, 16))
         return torch.from_numpy(m).to(self.device, non_blocking=True)
 
-    def upload_map(self, xyz, colour_id):
-        return DeviceMap(xyz, colour_id, self.device)
+    def upload_map(self, xyz, colour_id, spatial_sort="auto"):
+        return DeviceMap(xyz, colour_id, self.device, spatial_sort=spatial_sort)
 
     def make_rig(self, names, chassis2camera, K, W, H):
         return CameraRig(names, chassis2camera, K, W, H, self.device)
@@ -191,9 +234,9 @@ class Engine:
             assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.uint8
             need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
             scratch = self._scratch_buf(need)
-            x, y, z = dmap.ptrs()
+            x, y, z, col, key = dmap.render_ptrs()
             _lib.check(self.lib.cama_render_frames(
-                x, y, z, dmap.is_f64, dmap.colour.data_ptr(), dmap.N, T.data_ptr(), F,
+                x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F,
                 rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H,
                 src.data_ptr(), out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
                 self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), self._stream()))
@@ -259,9 +302,9 @@ class Engine:
                 with torch.cuda.stream(s_bin):
                     slot["buf"] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
             buf = slot["buf"]
-            x, y, z = dmap.ptrs()
+            x, y, z, col, key = dmap.render_ptrs()
             _lib.check(self.lib.cama_bin_frames(
-                x, y, z, dmap.is_f64, dmap.colour.data_ptr(), dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
+                x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
                 rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, self.radius, buf.data_ptr(), buf.numel(),
                 s_bin.cuda_stream))
             binned = s_bin.record_event()

@@ -108,6 +108,9 @@ int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz
  * No coordinates are materialised.  Stamps are binned by (frame, camera, row band), each band
  * is resolved deterministically (per-pixel max draw index) and written once into the mosaic.
  *   x,y,z      [N] float32/float64 (xyz_is_f64)   colour_id [N] uint8: palette index (0 lane grey, 1 gold)
+ *   draw_key   NULL, or [N] uint32 = (draw index << 1) | colour for vertex buffers stored in another order than
+ *              they are drawn (e.g. spatially sorted): "last writer wins" follows the draw index, not storage
+ *              order; colour_id is ignored when draw_key is given
  *   w2c        [F,16]             c2cam [C,16]   K [C,9]   crop host[6]
  *   src        [F,C,H,W,3] uint8 BGR frames (already at output size)
  *   mosaic     [F, rows*H, cols*W, 3] uint8, rows = ceil(C/cols); camera c goes to cell
@@ -120,7 +123,7 @@ int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz
  */
 size_t cama_render_scratch_bytes(int64_t N, int32_t F, int32_t C, int32_t H, int32_t W, int32_t radius);
 int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                       const uint8_t *colour_id, int64_t N,
+                       const uint8_t *colour_id, const uint32_t *draw_key, int64_t N,
                        const double *w2c, int32_t F,
                        const double *c2cam, const double *K, int32_t C,
                        const double *crop, int32_t W, int32_t H,
@@ -136,7 +139,7 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
  * orders the overlay after its own binning (stream order or an event).  Arguments as above.
  */
 int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                    const uint8_t *colour_id, int64_t N,
+                    const uint8_t *colour_id, const uint32_t *draw_key, int64_t N,
                     const double *w2c, int32_t F,
                     const double *c2cam, const double *K, int32_t C,
                     const double *crop, int32_t W, int32_t H, int32_t radius,

@@ -201,7 +201,7 @@ def test_bad_arguments_fail_loudly(engine):
     L = _lib.lib()
     assert L.cama_project_points(None, 10, None, None, 6, 10, 10, None, None, None) == -1
     assert b"NULL" in L.cama_last_error()
-    assert L.cama_render_frames(None, None, None, 0, None, 0, None, 1, None, None, 99, None, 10, 10, None, None, 3, 2,
+    assert L.cama_render_frames(None, None, None, 0, None, None, 0, None, 1, None, None, 99, None, 10, 10, None, None, 3, 2,
                                 None, None, None, 0, None) == -1
     assert b"C=99" in L.cama_last_error()
 
@@ -291,3 +291,36 @@ def test_early_outs_do_not_change_visibility_on_knife_edges(engine):
     vu, vis, _ = (t.cpu().numpy() for t in engine.project_frames(dmap, rig, w2c, crop=crop))
     assert np.array_equal(vis[0], flat["vis"]) and 50 < flat["vis"][1].sum() < len(xyz)
     assert np.array_equal(out[0], O.frame_render_flat(src[0], flat["vu"], flat["vis"], col))
+
+
+def test_spatially_sorted_map_renders_identically(engine):
+    """An unordered (random) vertex buffer is rendered from a Morton-sorted copy keyed by the original draw index:
+    bytes must equal the oracle drawing in the ORIGINAL order, with heavy two-colour overlap."""
+    import torch
+    from cama_amd.engine import lacks_spatial_order, morton_order
+    W, H, N = 320, 180, 20000
+    rng = np.random.default_rng(17)
+    xyz = np.stack([rng.uniform(-60, 60, N), rng.uniform(-110, 110, N), rng.normal(0, 0.2, N)], -1).astype(np.float32)
+    xyz[:3000, :2] = rng.normal([12.0, 0.0], 0.4, (3000, 2))          # a dense clump straight ahead: many overlaps
+    xyz[:3000] = xyz[rng.permutation(3000)]
+    col = (rng.random(N) < 0.5).astype(np.uint8)
+    assert lacks_spatial_order(xyz)
+    order = morton_order(xyz)
+    assert sorted(order.tolist()) == list(range(N))
+    _, _, cams, w2c = _random_scene(5, 10, 2, W, H)
+    rig = _rig(engine, cams)
+    src = rng.integers(0, 256, (2, 6, H, W, 3), dtype=np.uint8)
+    auto = engine.upload_map(xyz, col)
+    plain = engine.upload_map(xyz, col, spatial_sort=False)
+    assert auto.sorted_key is not None and plain.sorted_key is None
+    a = engine.render_frames(auto, rig, w2c, torch.from_numpy(src).cuda()).cpu().numpy()
+    b = engine.render_frames(plain, rig, w2c, torch.from_numpy(src).cuda()).cpu().numpy()
+    assert np.array_equal(a, b)
+    for f in range(2):
+        flat = O.frame_project_flat(xyz, w2c[f], cams, W, H)
+        assert flat["vis"].sum() > 3000
+        assert np.array_equal(a[f], O.frame_render_flat(src[f], flat["vu"], flat["vis"], col))
+    # API mode is unaffected by the sorted copy (original order)
+    vu, vis, _ = (t.cpu().numpy() for t in engine.project_frames(auto, rig, w2c))
+    flat = O.frame_project_flat(xyz, w2c[0], cams, W, H)
+    assert np.array_equal(vis[0], flat["vis"])
