@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import argparse, torch
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 import bench
-ap = argparse.Namespace(frames=40, verts=int(os.environ.get("N", 10000)), height=int(os.environ.get("H", 900)), width=int(os.environ.get("W", 1600)))
+ap = argparse.Namespace(frames=40, verts=int(os.environ.get("N", 10000)), height=int(os.environ.get("H", 900)), width=int(os.environ.get("W", 1600)), map="lanes")
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
 cm, frames, clip = bench.build_scene(ap, 0, dev)
 from cama_amd import runtime
