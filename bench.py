@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--map", choices=["lanes", "random"], default="lanes",
                     help="lanes: CAMA-style densified polylines along the drive (configs[1..3]); random: --verts "
                          "uniformly random map vertices over the 600 m map in random order (configs[4] stress)")
+    ap.add_argument("--raw-frames", action="store_true",
+                    help="frames resident at sensor size 1600x900 and resampled (undistort+resize) to --height x "
+                         "--width on the device inside every step: the reference's default 540x960 pipeline")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single stream: binning and overlay of consecutive steps do not overlap")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
@@ -82,8 +85,14 @@ def build_scene(args, rank, device):
                                     {"class": "Road_teeth", "points": pts[half:]}]
     gen = torch.Generator(device=device)
     gen.manual_seed(rank)
-    frames = torch.randint(0, 256, (args.frames + 1, 6, H, W, 3), dtype=torch.uint8, device=device, generator=gen)
-    cm.set_frame_source(DeviceFrameSource(frames))
+    if getattr(args, "raw_frames", False):
+        from cama_amd.frames import RawDeviceFrameSource
+        frames = torch.randint(0, 256, (args.frames + 1, 6, 900, 1600, 3), dtype=torch.uint8, device=device,
+                               generator=gen)
+        cm.set_frame_source(RawDeviceFrameSource(frames, cm.cm_list))
+    else:
+        frames = torch.randint(0, 256, (args.frames + 1, 6, H, W, 3), dtype=torch.uint8, device=device, generator=gen)
+        cm.set_frame_source(DeviceFrameSource(frames))
     return cm, frames, clip
 
 
@@ -163,7 +172,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    pipelined = not args.no_pipeline
+    pipelined = not args.no_pipeline and not args.raw_frames
     for _ in range(args.warmup):
         cm.render_clip("cama", out=out, pipelined=pipelined)
     eng.join()
@@ -217,7 +226,9 @@ def main():
                          "avg_launch_ms": ov_avg_ms, "launches": int(launches),
                          "bytes_per_launch": bytes_per_frame * frames_per_launch},
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if args.raw_frames:
+            line["config"]["workload"] += "; raw 1600x900 frames resampled on device each step"
+        if world == 1 and args.cpu_seconds > 0 and not args.raw_frames:
             line["cpu_baseline"] = cpu_baseline(cm, frames, clip, args, args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = fps / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)

@@ -29,7 +29,7 @@ SIGNATURES = {
     "cama_bin_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32,
                                _vp, _sz, _vp]),
     "cama_overlay_frames": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
-    "cama_resample_frames": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "cama_resample_frames": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "cama_stamp_scratch_bytes": (_sz, [_i32, _i32]),
     "cama_stamp_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_circle_halfwidths": (_i32, [_i32, _vp]),

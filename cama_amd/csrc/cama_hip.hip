@@ -612,28 +612,116 @@ __global__ __launch_bounds__(BLOCK) void k_apply_owner(const uint32_t *__restric
 // OpenCV's 8-bit remap quantises coordinates to 1/32 px (INTER_BITS = 5) and blends with 15-bit fixed-point
 // weights; for bilinear the weights (32-a)(32-b)*32 ... are exact integers summing to 1 << 15.
 // ------------------------------------------------------------------------------------------
+struct Tap6 { uint32_t lo; uint32_t hi; };   // 6 useful bytes: pixel x0 (b,g,r) then pixel x0+1 (b,g,r)
+
+// two horizontally adjacent BGR pixels starting at byte address p (any alignment), as one 8-byte load when that
+// stays inside the buffer, else byte-wise
+__device__ __forceinline__ Tap6 load_tap(const uint8_t *p, bool wide_ok)
+{
+    Tap6 t;
+    if (wide_ok) {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        t.lo = *reinterpret_cast<const u32u *>(p);
+        t.hi = *reinterpret_cast<const u32u *>(p + 4);
+    } else {
+        t.lo = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        t.hi = (uint32_t)p[4] | ((uint32_t)p[5] << 8);
+    }
+    return t;
+}
+
+// One destination pixel of cv2.remap's 8-bit INTER_LINEAR path: returns b | g<<8 | r<<16.
+// OpenCV: v = (w00 p00 + w01 p01 + w10 p10 + w11 p11 + 2^14) >> 15 with w00 = (32-a)(32-b)*32 etc.  That sum is
+// exactly 32*S with  t_r = (32-a) p_r0 + a p_r1 (per source row r),  S = (32-b) t_0 + b t_1,  so v = (S + 512) >> 10.
+// The horizontal step is a byte dot product: the six tap bytes [b0 g0 r0 b1 | g1 r1] against weights placed on the
+// matching byte lanes (v_dot4_u32_u8), no unpacking.  Taps in the constant border contribute 0 = weight 0.
+__device__ __forceinline__ uint32_t remap_pixel(const uint8_t *__restrict__ s, size_t frame_bytes, int H0, int W0,
+                                                float mx, float my)
+{
+    const int sx = __float2int_rn(mx * 32.0f), sy = __float2int_rn(my * 32.0f);   // cvRound: half to even
+    const int x0 = sx >> 5, y0 = sy >> 5;
+    const bool xin0 = (unsigned)x0 < (unsigned)W0, xin1 = (unsigned)(x0 + 1) < (unsigned)W0;
+    const bool yin0 = (unsigned)y0 < (unsigned)H0, yin1 = (unsigned)(y0 + 1) < (unsigned)H0;
+    if (!((xin0 | xin1) & (yin0 | yin1))) return 0u;                    // all four taps in the constant border
+    const uint32_t a = (uint32_t)(sx & 31), b = (uint32_t)(sy & 31);
+    uint32_t wl = xin0 ? 32u - a : 0u, wr = xin1 ? a : 0u;              // left / right tap weights
+    const uint32_t wt = yin0 ? 32u - b : 0u, wb = yin1 ? b : 0u;        // top / bottom row weights
+    // clamp the addresses into the frame (masked taps have weight 0, whatever bytes are read)
+    const int xc = min(max(x0, 0), W0 - 1), y0c = min(max(y0, 0), H0 - 1), y1c = min(max(y0 + 1, 0), H0 - 1);
+    const size_t o0 = ((size_t)y0c * W0 + xc) * 3, o1 = ((size_t)y1c * W0 + xc) * 3;
+    const Tap6 t0 = load_tap(s + o0, o0 + 8 <= frame_bytes), t1 = load_tap(s + o1, o1 + 8 <= frame_bytes);
+    if (x0 < 0) { wl = wr; wr = 0u; }     // x0 == -1: the in-range (right) tap is the FIRST pixel that was loaded
+    // weights on byte lanes: lo = [b0 g0 r0 b1], hi = [g1 r1 . .]
+    const uint32_t wB = wl | (wr << 24), wGl = wl << 8, wGh = wr, wRl = wl << 16, wRh = wr << 8;
+    const uint32_t tB0 = __builtin_amdgcn_udot4(t0.lo, wB, 0u, false);
+    const uint32_t tG0 = __builtin_amdgcn_udot4(t0.hi, wGh, __builtin_amdgcn_udot4(t0.lo, wGl, 0u, false), false);
+    const uint32_t tR0 = __builtin_amdgcn_udot4(t0.hi, wRh, __builtin_amdgcn_udot4(t0.lo, wRl, 0u, false), false);
+    const uint32_t tB1 = __builtin_amdgcn_udot4(t1.lo, wB, 0u, false);
+    const uint32_t tG1 = __builtin_amdgcn_udot4(t1.hi, wGh, __builtin_amdgcn_udot4(t1.lo, wGl, 0u, false), false);
+    const uint32_t tR1 = __builtin_amdgcn_udot4(t1.hi, wRh, __builtin_amdgcn_udot4(t1.lo, wRl, 0u, false), false);
+    const uint32_t vB = (wt * tB0 + wb * tB1 + 512u) >> 10;             // <= 255 by construction
+    const uint32_t vG = (wt * tG0 + wb * tG1 + 512u) >> 10;
+    const uint32_t vR = (wt * tR0 + wb * tR1 + 512u) >> 10;
+    return vB | (vG << 8) | (vR << 16);
+}
+
+// map addressing: value for destination (y, x) is map[y * row_stride + x * col_stride]; full 2-D maps use (W, 1),
+// separable ones (zero distortion: mapx = f(x), mapy = g(y)) use (0, 1) and (1, 0) on W- and H-long vectors
+struct MapStride { int xr, xc, yr, yc; uint32_t w_magic; };
+
 __global__ __launch_bounds__(BLOCK) void k_resample(const uint8_t *__restrict__ src, int64_t src_stride,
                                                     uint8_t *__restrict__ dst, int64_t dst_stride, int H0, int W0,
                                                     int H, int W, const float *__restrict__ mapx,
-                                                    const float *__restrict__ mapy)
+                                                    const float *__restrict__ mapy, MapStride ms)
 {
     const int p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= H * W) return;
     const uint8_t *s = src + (size_t)blockIdx.y * src_stride;
     uint8_t *d = dst + (size_t)blockIdx.y * dst_stride + (size_t)p * 3;
-    const int sx = __float2int_rn(mapx[p] * 32.0f), sy = __float2int_rn(mapy[p] * 32.0f);   // cvRound: half to even
-    const int x0 = sx >> 5, y0 = sy >> 5, a = sx & 31, b = sy & 31;
-    const int w00 = (32 - a) * (32 - b) * 32, w01 = a * (32 - b) * 32, w10 = (32 - a) * b * 32, w11 = a * b * 32;
-    const bool xin0 = (unsigned)x0 < (unsigned)W0, xin1 = (unsigned)(x0 + 1) < (unsigned)W0;
-    const bool yin0 = (unsigned)y0 < (unsigned)H0, yin1 = (unsigned)(y0 + 1) < (unsigned)H0;
-    const uint8_t *r0 = s + ((size_t)y0 * W0 + x0) * 3, *r1 = r0 + (size_t)W0 * 3;
+    const int y = (int)__umulhi((uint32_t)p, ms.w_magic), x = p - y * W;
+    const uint32_t c = remap_pixel(s, (size_t)H0 * W0 * 3, H0, W0, mapx[y * ms.xr + x * ms.xc],
+                                   mapy[y * ms.yr + x * ms.yc]);
+    d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
+}
+
+// W % 16 == 0: thread <-> destination pixel for the gathers (adjacent lanes read adjacent source pixels, the map
+// loads are coalesced), PPT pixels per thread strided by the workgroup size so the dependent load chains
+// (map -> taps) of several pixels overlap; then the workgroup's bytes are transposed through LDS into aligned
+// 16-byte stores.  (One thread per 16 CONSECUTIVE pixels was tried: lanes 80 source bytes apart lose all
+// coalescing -- 4.7x slower; one pixel per thread is latency-bound at 8 workgroups/CU.)
+#ifndef RESAMPLE_PPT_N
+#define RESAMPLE_PPT_N 4
+#endif
+constexpr int RESAMPLE_PPT = RESAMPLE_PPT_N;
+
+__global__ __launch_bounds__(BLOCK) void k_resample16(const uint8_t *__restrict__ src, int64_t src_stride,
+                                                      uint8_t *__restrict__ dst, int64_t dst_stride, int H0, int W0,
+                                                      int H, int W, const float *__restrict__ mapx,
+                                                      const float *__restrict__ mapy, MapStride ms)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[BLOCK * RESAMPLE_PPT * 3];
+    const int npix = H * W;
+    const int first = blockIdx.x * (BLOCK * RESAMPLE_PPT);
+    const uint8_t *s = src + (size_t)blockIdx.y * src_stride;
+    float mx[RESAMPLE_PPT], my[RESAMPLE_PPT];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const int p00 = (xin0 & yin0) ? r0[ch] : 0, p01 = (xin1 & yin0) ? r0[3 + ch] : 0;
-        const int p10 = (xin0 & yin1) ? r1[ch] : 0, p11 = (xin1 & yin1) ? r1[3 + ch] : 0;
-        const int v = (w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11 + (1 << 14)) >> 15;
-        d[ch] = (uint8_t)min(max(v, 0), 255);
+    for (int j = 0; j < RESAMPLE_PPT; ++j) {
+        const int p = min(first + j * BLOCK + (int)threadIdx.x, npix - 1);
+        const int y = (int)__umulhi((uint32_t)p, ms.w_magic), x = p - y * W;
+        mx[j] = mapx[y * ms.xr + x * ms.xc];
+        my[j] = mapy[y * ms.yr + x * ms.yc];
     }
+#pragma unroll
+    for (int j = 0; j < RESAMPLE_PPT; ++j) {
+        const uint32_t c = remap_pixel(s, (size_t)H0 * W0 * 3, H0, W0, mx[j], my[j]);
+        uint8_t *o = s_out + 3 * (j * BLOCK + (int)threadIdx.x);
+        o[0] = (uint8_t)c; o[1] = (uint8_t)(c >> 8); o[2] = (uint8_t)(c >> 16);
+    }
+    __syncthreads();
+    // npix is a multiple of 16, so the tail workgroup ends on a chunk boundary
+    const int valid_chunks = (min(BLOCK * RESAMPLE_PPT, npix - first) * 3) >> 4;
+    u32x4 *d = reinterpret_cast<u32x4 *>(dst + (size_t)blockIdx.y * dst_stride + (size_t)first * 3);
+    for (int k = threadIdx.x; k < valid_chunks; k += BLOCK) d[k] = reinterpret_cast<const u32x4 *>(s_out)[k];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -992,15 +1080,26 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
 
 int cama_resample_frames(const uint8_t *src, int64_t src_stride_bytes, uint8_t *dst, int64_t dst_stride_bytes,
                          int32_t n, int32_t H0, int32_t W0, int32_t H, int32_t W, const float *mapx,
-                         const float *mapy, void *stream)
+                         const float *mapy, int32_t separable, void *stream)
 {
     if (n < 0 || n > 65535) return fail(CAMA_EINVAL, "n=%d out of range [0, 65535]", n);
-    if (H0 < 1 || W0 < 1 || H < 1 || W < 1 || (int64_t)H * W > (1ll << 30))
+    if (H0 < 1 || W0 < 1 || H < 1 || W < 1 || W > 65535 || (int64_t)H * W * (int64_t)W >= (1ll << 32))
         return fail(CAMA_EINVAL, "bad image sizes %dx%d -> %dx%d", W0, H0, W, H);
     if (n == 0) return CAMA_OK;
     if (!src || !dst || !mapx || !mapy) return fail(CAMA_EINVAL, "NULL pointer argument");
-    hipLaunchKernelGGL(k_resample, dim3((unsigned)(((int64_t)H * W + BLOCK - 1) / BLOCK), (unsigned)n), dim3(BLOCK), 0,
-                       (hipStream_t)stream, src, src_stride_bytes, dst, dst_stride_bytes, H0, W0, H, W, mapx, mapy);
+    MapStride ms;
+    ms.xr = separable ? 0 : W; ms.xc = 1; ms.yr = separable ? 1 : W; ms.yc = separable ? 0 : 1;
+    ms.w_magic = (uint32_t)(((1ull << 32) + (uint32_t)W - 1) / (uint32_t)W);     // exact for p*W < 2^32 (checked above)
+    const bool vec = (W % 16 == 0) && ((uintptr_t)dst % 16 == 0) && (dst_stride_bytes % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_resample16,
+                           dim3((unsigned)(((int64_t)H * W + BLOCK * RESAMPLE_PPT - 1) / (BLOCK * RESAMPLE_PPT)), (unsigned)n),
+                           dim3(BLOCK), 0, (hipStream_t)stream, src, src_stride_bytes, dst, dst_stride_bytes, H0, W0, H,
+                           W, mapx, mapy, ms);
+    else
+        hipLaunchKernelGGL(k_resample, dim3((unsigned)(((int64_t)H * W + BLOCK - 1) / BLOCK), (unsigned)n), dim3(BLOCK),
+                           0, (hipStream_t)stream, src, src_stride_bytes, dst, dst_stride_bytes, H0, W0, H, W, mapx, mapy,
+                           ms);
     HIP_TRY(hipGetLastError());
     return CAMA_OK;
 }

@@ -251,20 +251,26 @@ class Engine:
         with torch.cuda.device(self.device):
             single = src.dim() == 3
             s = src[None] if single else src
-            assert s.is_cuda and s.dtype == torch.uint8 and s.is_contiguous() and s.shape[3] == 3
+            assert s.is_cuda and s.dtype == torch.uint8 and s[0].is_contiguous() and s.shape[3] == 3
             n, H0, W0 = int(s.shape[0]), int(s.shape[1]), int(s.shape[2])
+            src_stride = s.stride(0) if n > 1 else H0 * W0 * 3
             H, W = int(cm.height), int(cm.width)
             dev_maps = getattr(cm, "_resample_maps_dev", None)
             if dev_maps is None or dev_maps[0].device != self.device:
                 mx, my = camera_maps(cm)
-                dev_maps = (torch.from_numpy(mx).to(self.device), torch.from_numpy(my).to(self.device))
+                # zero distortion gives separable maps: ship a W-vector and an H-vector instead of two H x W planes
+                sep = bool((mx == mx[0:1, :]).all() and (my == my[:, 0:1]).all())
+                if sep:
+                    mx, my = np.ascontiguousarray(mx[0, :]), np.ascontiguousarray(my[:, 0])
+                dev_maps = (torch.from_numpy(mx).to(self.device), torch.from_numpy(my).to(self.device), int(sep))
                 cm._resample_maps_dev = dev_maps
             if out is None:
                 out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=self.device)
             assert tuple(out.shape) == (n, H, W, 3) and out.dtype == torch.uint8 and out[0].is_contiguous()
             stride = out.stride(0) if n > 1 else H * W * 3
-            _lib.check(self.lib.cama_resample_frames(s.data_ptr(), H0 * W0 * 3, out.data_ptr(), stride, n, H0, W0, H, W,
-                                                     dev_maps[0].data_ptr(), dev_maps[1].data_ptr(), self._stream()))
+            _lib.check(self.lib.cama_resample_frames(s.data_ptr(), src_stride, out.data_ptr(), stride, n, H0, W0, H, W,
+                                                     dev_maps[0].data_ptr(), dev_maps[1].data_ptr(), dev_maps[2],
+                                                     self._stream()))
             return out[0] if single else out
 
     # ------------------------------------------------------------------ pipelined render (two streams)

@@ -119,3 +119,27 @@ class ClipFrameSource:
                 stack = torch.from_numpy(np.ascontiguousarray(np.stack(raw))).to(self.device)
                 eng.resample(cm, stack, out=out[:, c])
         return out
+
+
+class RawDeviceFrameSource:
+    """Raw (sensor-size) frames resident in HBM [F_total, C, H0, W0, 3]; every batch is undistort+resized on the
+    device to the CameraManagers' output size (the reference does this per image on the host,
+    cama/reproject.py:228-244)."""
+
+    def __init__(self, raw, cm_list):
+        self.raw, self.cm_list = raw, cm_list
+        self._buf = None
+
+    def batch(self, image_indices):
+        import torch
+        from . import runtime
+        eng = runtime.engine()
+        idx = list(image_indices)
+        assert idx == list(range(idx[0], idx[0] + len(idx))), "contiguous frame ranges only"
+        c0 = self.cm_list[0]
+        shape = (len(idx), len(self.cm_list), c0.height, c0.width, 3)
+        if self._buf is None or tuple(self._buf.shape) != shape:
+            self._buf = torch.empty(shape, dtype=torch.uint8, device=self.raw.device)
+        for c, cm in enumerate(self.cm_list):
+            eng.resample(cm, self.raw[idx[0]:idx[0] + len(idx), c], out=self._buf[:, c])
+        return self._buf

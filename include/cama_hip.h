@@ -168,11 +168,12 @@ int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n,
  * camera on the host (the reference rebuilds them per frame).  OpenCV semantics restated: coordinates rounded
  * to 1/32 px, 15-bit fixed-point bilinear weights, BORDER_CONSTANT 0.  PARITY UNPINNED (no OpenCV on either box).
  *   src  frame i at src + i*src_stride_bytes, [H0,W0,3] uint8     dst frame i at dst + i*dst_stride_bytes, [H,W,3]
- *   mapx, mapy [H,W] float32 source coordinates of each destination pixel
+ *   mapx, mapy [H,W] float32 source coordinates of each destination pixel (separable == 0), or, for separable maps
+ *              (zero distortion: mapx depends on the column only, mapy on the row only), mapx [W] and mapy [H]
  */
 int cama_resample_frames(const uint8_t *src, int64_t src_stride_bytes, uint8_t *dst, int64_t dst_stride_bytes,
                          int32_t n, int32_t H0, int32_t W0, int32_t H, int32_t W,
-                         const float *mapx, const float *mapy, void *stream);
+                         const float *mapx, const float *mapy, int32_t separable, void *stream);
 
 /* Host helper: half-widths of OpenCV's filled midpoint circle, hw[0..radius]; returns radius+1 or <0. */
 int cama_circle_halfwidths(int32_t radius, int32_t *hw /* host */);
