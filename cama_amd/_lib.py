@@ -12,7 +12,7 @@ _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
 ABI_VERSION = 1
 
-_vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+_vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
 # name -> (restype, argtypes); mirrors include/cama_hip.h one to one
 SIGNATURES = {
@@ -29,6 +29,8 @@ SIGNATURES = {
     "cama_bin_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32,
                                _vp, _sz, _vp]),
     "cama_overlay_frames": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "cama_build_static_map": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32, _i32, _i32,
+                                     _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "cama_resample_frames": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "cama_stamp_scratch_bytes": (_sz, [_i32, _i32]),
     "cama_stamp_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),

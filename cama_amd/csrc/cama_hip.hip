@@ -725,6 +725,65 @@ __global__ __launch_bounds__(BLOCK) void k_resample16(const uint8_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// static-map build (per clip): densify labels, lift with the BEV height raster, pixel -> world
+// reproject.py:42-106.  One thread per OUTPUT point; float32 arithmetic in the reference's operation order
+// (compiled -ffp-contract=off; HIP's float division is correctly rounded), so the buffer is bit-identical to the
+// host build.  Writes the SoA vertex buffer + colour ids the fused render consumes: the map never visits the host.
+// ------------------------------------------------------------------------------------------
+struct MapBuildArgs {
+    const float *verts;        // [V,2] label vertices (float32, as np.array(data).astype(np.float32))
+    const int32_t *seg_v0;     // [S] first vertex of each non-empty segment (its end is v0 + 1)
+    const int32_t *seg_num;    // [S] points emitted by the segment = int(|seg| / solution) > 0
+    const int64_t *seg_off;    // [S+1] exclusive scan of seg_num
+    const uint8_t *seg_colour; // [S]
+    int32_t S;
+    int64_t N;
+    int32_t lift;              // 1: CAMA labels (BEV pixels + raster), 0: nuScenes labels (metres, z = 0)
+    const void *raster;        // [rows, cols] float32 / float64
+    int32_t rows, cols;
+    float solution, half_w, half_h, cx, cy;
+    void *x, *y, *z;           // [N] each, float32 or float64 (TZ)
+    uint8_t *colour;           // [N]
+};
+
+template <typename TZ>
+__global__ __launch_bounds__(BLOCK) void k_build_map(MapBuildArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    // segment that owns output point i: last s with seg_off[s] <= i
+    int lo = 0, hi = a.S - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.seg_off[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const int s = lo;
+    const float j = (float)(i - a.seg_off[s]);
+    const float num = (float)a.seg_num[s];
+    const float2 p0 = reinterpret_cast<const float2 *>(a.verts)[a.seg_v0[s]];
+    const float2 p1 = reinterpret_cast<const float2 *>(a.verts)[a.seg_v0[s] + 1];
+    // start + (end - start) / num * j      (reproject.py:62 / :92)
+    const float px = p0.x + ((p1.x - p0.x) / num) * j;
+    const float py = p0.y + ((p1.y - p0.y) / num) * j;
+    TZ ox, oy, oz;
+    if (a.lift) {
+        // round().astype(np.uint16)[:, ::-1].clip(0, rows-1): half-to-even, C cast through int32 (wraps), (row, col)
+        const int row = min(max((int)(uint16_t)(int32_t)rintf(py), 0), a.rows - 1);
+        const int col = min(max((int)(uint16_t)(int32_t)rintf(px), 0), a.rows - 1);
+        oz = static_cast<const TZ *>(a.raster)[(size_t)row * a.cols + col];
+        // world x from pixel y and vice versa (reproject.py:38-39), float32
+        ox = (TZ)(((py * a.solution) - a.half_w) + a.cx);
+        oy = (TZ)(((px * a.solution) - a.half_h) + a.cy);
+    } else {
+        ox = (TZ)px; oy = (TZ)py; oz = (TZ)0;
+    }
+    static_cast<TZ *>(a.x)[i] = ox;
+    static_cast<TZ *>(a.y)[i] = oy;
+    static_cast<TZ *>(a.z)[i] = oz;
+    a.colour[i] = a.seg_colour[s];
+}
+
+// ------------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------------
 int make_disc(int radius, const int32_t *hw, Disc &d)
@@ -1100,6 +1159,30 @@ int cama_resample_frames(const uint8_t *src, int64_t src_stride_bytes, uint8_t *
         hipLaunchKernelGGL(k_resample, dim3((unsigned)(((int64_t)H * W + BLOCK - 1) / BLOCK), (unsigned)n), dim3(BLOCK),
                            0, (hipStream_t)stream, src, src_stride_bytes, dst, dst_stride_bytes, H0, W0, H, W, mapx, mapy,
                            ms);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
+int cama_build_static_map(const float *verts, const int32_t *seg_v0, const int32_t *seg_num, const int64_t *seg_off,
+                          const uint8_t *seg_colour, int32_t S, int64_t N, int32_t lift, const void *raster,
+                          int32_t raster_is_f64, int32_t rows, int32_t cols, float solution, float half_w, float half_h,
+                          float cx, float cy, void *x, void *y, void *z, uint8_t *colour, void *stream)
+{
+    if (S < 0 || N < 0 || N >= (1ll << 30)) return fail(CAMA_EINVAL, "S=%d N=%lld out of range", S, (long long)N);
+    if (N == 0) return CAMA_OK;
+    if (S == 0 || !verts || !seg_v0 || !seg_num || !seg_off || !seg_colour || !x || !y || !z || !colour)
+        return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (lift && (!raster || rows < 1 || cols < 1)) return fail(CAMA_EINVAL, "lift needs a height raster");
+    MapBuildArgs a{};
+    a.verts = verts; a.seg_v0 = seg_v0; a.seg_num = seg_num; a.seg_off = seg_off; a.seg_colour = seg_colour;
+    a.S = S; a.N = N; a.lift = lift; a.raster = raster; a.rows = rows; a.cols = cols;
+    a.solution = solution; a.half_w = half_w; a.half_h = half_h; a.cx = cx; a.cy = cy;
+    a.x = x; a.y = y; a.z = z; a.colour = colour;
+    const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK));
+    if (lift && raster_is_f64)
+        hipLaunchKernelGGL(k_build_map<double>, grid, dim3(BLOCK), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(k_build_map<float>, grid, dim3(BLOCK), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CAMA_OK;
 }

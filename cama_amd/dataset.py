@@ -44,16 +44,53 @@ class _StaticMap:
 
     def __init__(self, instances):
         self.instances = instances
-        self.xyz, self.counts, self.classes = flatten_instances(instances)
-        if self.xyz.dtype not in (np.float32, np.float64):
-            self.xyz = self.xyz.astype(np.float64)
-        self.colour = np.repeat(np.asarray([colour_id_of(c) for c in self.classes], np.uint8), self.counts)
         self._dmap = None
+        self._xyz = None
+        if isinstance(instances, StaticInstances):            # built on the device: no host copy unless asked for
+            self._dmap = instances.dmap
+            self.counts, self.classes = instances.counts, instances.classes
+        else:
+            self._xyz, self.counts, self.classes = flatten_instances(instances)
+            if self._xyz.dtype not in (np.float32, np.float64):
+                self._xyz = self._xyz.astype(np.float64)
+            self.colour = np.repeat(np.asarray([colour_id_of(c) for c in self.classes], np.uint8), self.counts)
+
+    @property
+    def xyz(self):
+        if self._xyz is None:
+            self._xyz, _, _ = flatten_instances(self.instances._materialise())
+        return self._xyz
+
+    @property
+    def n_points(self):
+        return int(self.counts.sum())
 
     def device(self):
         if self._dmap is None:
-            self._dmap = runtime.engine().upload_map(self.xyz, self.colour)
+            self._dmap = runtime.engine().upload_map(self._xyz, self.colour)
         return self._dmap
+
+
+class StaticInstances(Sequence):
+    """A dataset pass' static map built ON THE DEVICE (configs["device_map_build"]): behaves as the reference's
+    list of {"class","points"} dicts (cama/dataset.py:13-24) when touched -- the points are downloaded once --
+    while the fused render uses the device buffer directly."""
+
+    def __init__(self, dmap, counts, classes):
+        self.dmap, self.counts, self.classes = dmap, np.asarray(counts, np.int64), list(classes)
+        self._items = None
+
+    def _materialise(self):
+        if self._items is None:
+            xyz = np.ascontiguousarray(self.dmap.soa.cpu().numpy().T)
+            self._items = split_instances(xyz, self.counts, self.classes)
+        return self._items
+
+    def __len__(self):
+        return len(self.classes)
+
+    def __getitem__(self, k):
+        return self._materialise()[k]
 
 
 class FrameMaps(Sequence):
@@ -69,7 +106,7 @@ class FrameMaps(Sequence):
         if self._items is None:
             sm = self.owner._static(self.dataset)
             eng = runtime.engine()
-            if sm.xyz.shape[0] == 0:
+            if sm.n_points == 0:
                 self._items = []
             else:
                 out, mask = eng.transform_points(sm.xyz, self.world2chassis[None], crop=self.owner.mm.crop_box())
@@ -98,7 +135,7 @@ class ProjectedMaps(Mapping):
             owner = fr.owner
             sm = owner._static(fr.dataset)
             names = [cm.camera_name for cm in owner.cm_list]
-            if sm.xyz.shape[0] == 0:
+            if sm.n_points == 0:
                 self._items = {n: [] for n in names}
             else:
                 eng = runtime.engine()
@@ -176,13 +213,28 @@ class ClipManager:
         if not exists(label_json):
             return None
         bev_height = np.load(join(clip_path, self.configs["result_dir"], self.configs["height_mlp"]))
-        return self.mm.calculate_3d_instance_maps(bev_height, load_json(label_json))
+        labels = load_json(label_json)
+        if self.configs.get("device_map_build", False):
+            return self._build_on_device(labels, bev_height)
+        return self.mm.calculate_3d_instance_maps(bev_height, labels)
 
     def load_clip_nuscenes(self, clip_path):
         label_json = join(clip_path, self.configs["result_dir"], self.configs["nuscenes_map_file"])
         if not exists(label_json):
             return None
-        return self.mm.load_3d_instance_maps(load_json(label_json))
+        labels = load_json(label_json)
+        if self.configs.get("device_map_build", False):
+            return self._build_on_device(labels, None)
+        return self.mm.load_3d_instance_maps(labels)
+
+    def _build_on_device(self, labels, bev_height):
+        """Static map straight into HBM (cama_build_static_map); bit-identical to MapManager's host build."""
+        mm = self.mm
+        table = mm.segment_table(labels)
+        dmap = runtime.engine().build_static_map(table, lift=bev_height is not None, bev_height=bev_height,
+                                                 solution=mm.solution, map_width=mm.map_width, map_height=mm.map_height,
+                                                 center_x=mm.center_x, center_y=mm.center_y)
+        return StaticInstances(dmap, table["counts"], table["classes"])
 
     def prepare_camera_manager(self, clip_path):
         return [CameraManager(clip_path, name, output_size=self.output_size) for name in self.configs["camera_list"]]

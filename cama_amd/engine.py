@@ -136,6 +136,46 @@ class Engine:
         m = np.ascontiguousarray(np.asarray(mats, dtype=np.float64).reshape(-1, 16))
         return torch.from_numpy(m).to(self.device, non_blocking=True)
 
+    def build_static_map(self, table, lift, bev_height=None, solution=0.1, map_width=600, map_height=600,
+                         center_x=0, center_y=0):
+        """Device static-map build (cama_build_static_map) from MapManager.segment_table(): returns a DeviceMap whose
+        vertex buffer was produced on the GPU (bit-identical to the host build); nothing is copied back."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            N = int(table["seg_off"][-1])
+            S = int(table["seg_num"].shape[0])
+            is64 = bool(lift and bev_height is not None and bev_height.dtype == np.float64)
+            dt = torch.float64 if is64 else torch.float32
+            soa = torch.empty((3, N), dtype=dt, device=self.device)
+            colour = torch.empty((N,), dtype=torch.uint8, device=self.device)
+            dmap = DeviceMap.__new__(DeviceMap)
+            dmap.N, dmap.is_f64, dmap.soa, dmap.colour = N, int(is64), soa, colour
+            dmap.sorted_soa = dmap.sorted_key = None
+            if N == 0:
+                return dmap
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            verts, v0, num, off, col = (up(table[k]) for k in ("verts", "seg_v0", "seg_num", "seg_off", "seg_colour"))
+            raster = None
+            rows = cols = 0
+            if lift:
+                bev = np.asarray(bev_height)
+                if bev.dtype not in (np.float32, np.float64):
+                    bev = bev.astype(np.float64)
+                    is64 = True
+                assert bev.ndim == 2
+                rows, cols = int(bev.shape[0]), int(bev.shape[1])
+                raster = up(bev)
+            es = soa.element_size()
+            base = soa.data_ptr()
+            f32 = lambda v: float(np.float32(v))
+            _lib.check(self.lib.cama_build_static_map(
+                verts.data_ptr(), v0.data_ptr(), num.data_ptr(), off.data_ptr(), col.data_ptr(), S, N, int(bool(lift)),
+                None if raster is None else raster.data_ptr(), int(is64), rows, cols,
+                f32(solution), f32(map_width / 2), f32(map_height / 2), f32(center_x), f32(center_y),
+                base, base + N * es, base + 2 * N * es, colour.data_ptr(), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()      # the uploads above go out of scope here
+            return dmap
+
     def upload_map(self, xyz, colour_id, spatial_sort="auto"):
         return DeviceMap(xyz, colour_id, self.device, spatial_sort=spatial_sort)
 

@@ -97,6 +97,41 @@ class MapManager(BaseManager):
         step = delta[seg] / num[seg].astype(np.float32)[:, None]
         return line_points[:-1][seg] + step * j[:, None]
 
+    def segment_table(self, maps_2d):
+        """Host half of the device static-map build: the O(#label vertices) part of reproject.py:44-63 / :74-93.
+        Returns dict(verts (V,2) f32, seg_v0, seg_num (S,) i32, seg_off (S+1,) i64, seg_colour (S,) u8,
+        counts (I,) i64 points per kept label, classes [I]).  Same float32 operations as _densify; a label whose
+        segments all round to zero points raises IndexError like the reference."""
+        verts, seg_v0, seg_num, seg_colour, counts, classes = [], [], [], [], [], []
+        v_base = 0
+        for label in maps_2d:
+            pts = label["data"]
+            if len(pts) <= 1:
+                continue
+            line = np.array(pts).astype(np.float32)
+            delta = line[1:] - line[:-1]
+            num = (np.linalg.norm(delta, axis=-1) / self.solution).astype(np.int64)
+            total = int(num.sum())
+            if total == 0:
+                raise IndexError("too many indices for array: label densifies to zero points")
+            keep = np.flatnonzero(num > 0)
+            verts.append(line)
+            seg_v0.append(v_base + keep)
+            seg_num.append(num[keep])
+            seg_colour.append(np.full(keep.shape[0], colour_id_of(label["attrs"]["type"]), np.uint8))
+            counts.append(total)
+            classes.append(label["attrs"]["type"])
+            v_base += line.shape[0]
+        if not counts:
+            return {"verts": np.zeros((0, 2), np.float32), "seg_v0": np.zeros(0, np.int32),
+                    "seg_num": np.zeros(0, np.int32), "seg_off": np.zeros(1, np.int64),
+                    "seg_colour": np.zeros(0, np.uint8), "counts": np.zeros(0, np.int64), "classes": []}
+        num_all = np.concatenate(seg_num)
+        return {"verts": np.ascontiguousarray(np.concatenate(verts)),
+                "seg_v0": np.concatenate(seg_v0).astype(np.int32), "seg_num": num_all.astype(np.int32),
+                "seg_off": np.concatenate([[0], np.cumsum(num_all)]).astype(np.int64),
+                "seg_colour": np.concatenate(seg_colour), "counts": np.asarray(counts, np.int64), "classes": classes}
+
     def load_3d_instance_maps(self, maps_2d):
         """nuScenes labels (metres, z = 0): reproject.py:42-70."""
         instances = []

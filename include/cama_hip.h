@@ -162,6 +162,23 @@ int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n,
                       void *scratch, size_t scratch_bytes, void *stream);
 
 /*
+ * Per-clip static-map build on the device: MapManager.calculate_3d_instance_maps (cama/reproject.py:72-106, lift = 1)
+ * and MapManager.load_3d_instance_maps (cama/reproject.py:42-70, lift = 0) for all labels at once, one thread per
+ * densified point, float32 arithmetic in the reference's operation order (bit-identical, pinned by tests/golden).
+ * The host supplies the segment table (which needs only the O(#label vertices) segment lengths):
+ *   verts [V,2] float32; seg_v0/seg_num [S] for the segments with num = int(|seg| / solution) > 0;
+ *   seg_off [S+1] exclusive scan of seg_num (seg_off[S] = N); seg_colour [S] palette index of the label's class
+ *   raster [rows, cols] float32 (raster_is_f64 == 0) or float64: output is float64 exactly when the raster is
+ *   solution / half_w / half_h / cx / cy: MapManager.solution, map_width/2, map_height/2, center_x, center_y as float32
+ *   x, y, z [N] output vertex buffer (SoA), colour [N] uint8
+ */
+int cama_build_static_map(const float *verts, const int32_t *seg_v0, const int32_t *seg_num, const int64_t *seg_off,
+                          const uint8_t *seg_colour, int32_t S, int64_t N, int32_t lift,
+                          const void *raster, int32_t raster_is_f64, int32_t rows, int32_t cols,
+                          float solution, float half_w, float half_h, float cx, float cy,
+                          void *x, void *y, void *z, uint8_t *colour, void *stream);
+
+/*
  * Undistort + resize resample of n frames of ONE camera through precomputed float32 maps: the
  * cv2.remap(image, mapx, mapy, INTER_LINEAR) of CameraManager.resize_image (cama/reproject.py:232-240); the
  * maps are what cv2.initUndistortRectifyMap(K_origin, d, None, K, (W,H), CV_32FC1) returns, built once per

@@ -175,3 +175,48 @@ def test_default_output_size_flow_with_jpeg_frames(tmp_path):
                                            *[np.broadcast_to(m, (540, 960)) for m in
                                              (O.undistort_map(cam0.K_origin, cam0.d_origin, cam0.K, 960, 1)[0],
                                               O.undistort_map(cam0.K_origin, cam0.d_origin, cam0.K, 1, 540)[1])]))
+
+
+@pytest.mark.parametrize("tag", ["a", "d_nusonly"])
+def test_device_static_map_build_is_bit_identical(tag, tmp_path):
+    """configs["device_map_build"]: densify + height gather + pixel->world on the GPU == the reference's static map."""
+    from cama_amd.dataset import ClipManager, StaticInstances
+    g = load_golden(tag)
+    clip = rebuild_clip(g, tmp_path)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, device_map_build=True), clip)
+    host = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)
+    for ds in cm.instance_maps:
+        ins = cm.instance_maps[ds]
+        assert isinstance(ins, StaticInstances) and ins._items is None
+        # fused path straight from the device-built buffer (no host copy yet)
+        for (i, fm), (j, hm) in zip(cm.yield_frame(ds), host.yield_frame(ds)):
+            assert i == j
+            a, b = cm.project_all_camera(fm), host.project_all_camera(hm)
+            for name in CAMERA_NAMES:
+                assert_instances_equal(a[name], golden_instances(g, f"{ds}_f{i}_{name}_vu"))
+                assert_instances_equal(b[name], golden_instances(g, f"{ds}_f{i}_{name}_vu"))
+        # ... and the public list, when touched, is the reference's static map, bit for bit
+        assert_instances_equal(list(ins), golden_instances(g, f"{ds}_static"))
+        assert all(p["points"].dtype == np.float32 for p in ins)
+
+
+def test_device_static_map_float64_raster_and_edge_pixels(tmp_path):
+    import json
+    from cama_amd import runtime
+    from cama_amd.reproject import MapManager
+    rng = np.random.default_rng(2)
+    mm = MapManager()
+    bev = rng.normal(0, 0.1, (50, 50))                        # float64 raster -> float64 points
+    labels = [{"attrs": {"type": "lane_marking"}, "data": [[-3.2, 5.0], [4.0, 9.0], [4.02, 9.01], [60.0, 70.0]]},
+              {"attrs": {"type": "Road_teeth"}, "data": [[48.4, 0.5], [49.5, 2.5], [51.5, 48.5]]},
+              {"attrs": {"type": "x"}, "data": [[1, 1]]}]
+    want = mm.calculate_3d_instance_maps(bev, labels)
+    table = mm.segment_table(labels)
+    dmap = runtime.engine().build_static_map(table, lift=True, bev_height=bev)
+    assert dmap.is_f64 == 1 and dmap.N == sum(w["points"].shape[0] for w in want)
+    got = dmap.soa.cpu().numpy().T
+    assert np.array_equal(got, np.concatenate([w["points"] for w in want]))
+    want32 = mm.calculate_3d_instance_maps(bev.astype(np.float32), labels)
+    d32 = runtime.engine().build_static_map(table, lift=True, bev_height=bev.astype(np.float32))
+    assert np.array_equal(d32.soa.cpu().numpy().T, np.concatenate([w["points"] for w in want32]))
+    assert d32.colour.cpu().numpy().tolist() == [0] * want[0]["points"].shape[0] + [1] * want[1]["points"].shape[0]
