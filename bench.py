@@ -149,11 +149,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    device = torch.device(f"cuda:{local}")
+    # CAMA_BENCH_SHARE_GPU=1 + CAMA_BENCH_BACKEND=gloo: debugging aid to run the N>1 code path on a 1-GPU box
+    share = os.environ.get("CAMA_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("CAMA_BENCH_BACKEND", "nccl")
+    device = torch.device(f"cuda:{local % torch.cuda.device_count() if share else local}")
     torch.cuda.set_device(device)
-    os.environ.setdefault("CAMA_DEVICE", f"cuda:{local}")
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+    os.environ["CAMA_DEVICE"] = str(device)
+    use_dist = world > 1 or os.environ.get("CAMA_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: 1-rank RCCL group (debug)
+    if use_dist:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from cama_amd import _lib, runtime
@@ -168,7 +175,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -195,7 +202,8 @@ def main():
     h_lo, h_hi = shard.overlay_hash(out)                        # checksum of this rank's final mosaics (untimed)
     rec = [float(F * args.steps), dt, ov_ms.value, float(ov_n.value), float(N),
            float(args.steps) * shard.scene_cost(F, N, W, H), float(h_lo % 2 ** 52), float(h_hi % 2 ** 52)]
-    allrec = shard.gather_records(rec, device=device)           # the one collective: metric all_gather over RCCL/xGMI
+    # the one collective: metric all_gather over RCCL/xGMI
+    allrec = shard.gather_records(rec, device=device if backend == "nccl" else None)
     agg = shard.reduce_metrics(allrec)
 
     if rank == 0:
@@ -232,7 +240,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cm, frames, clip, args, args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = fps / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

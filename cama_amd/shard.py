@@ -61,7 +61,7 @@ def gather_records(record, device=None):
     import torch
     import torch.distributed as dist
     rec = torch.as_tensor(record, dtype=torch.float64, device=device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return rec[None].cpu().numpy()
     world = dist.get_world_size()
     out = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)    # flat: accepted by nccl and gloo
