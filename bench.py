@@ -20,7 +20,8 @@ one all_gather of an 8-double metric record (frames, seconds, overlay time, byte
 Extra objects in the JSON line:
   roofline      dominant kernel = k_overlay, HBM-bound.  achieved = algorithmic bytes per launch
                 (13*N + 36*W*H per frame, SURVEY.md 8d, x frames per launch) / its mean duration measured live
-                with hipEvents on the launch stream (cama_profile_*).  peak 8000 GB/s.
+                with hipEvents on the launch stream (cama_profile_*; every 8th launch is timed, a timed event pair
+                is two extra barrier packets).  peak 8000 GB/s.
   cpu_baseline  oracle/cama_oracle.py (numpy port of the reference, per-point circle calls into C) timed on this
                 box's host cores for a bounded number of passes over the same scene; rank 0, N=1 only.
 """
@@ -185,9 +186,13 @@ def main():
     eng.join()
     sync_all()
     L = _lib.lib()
-    L.cama_profile_enable(1)
+    # live hipEvent timing of the overlay kernel: sampled (every `prof_every`-th step) because a timed event pair is
+    # two extra barrier packets on the launch stream
+    prof_every = int(os.environ.get("CAMA_BENCH_PROFILE_EVERY", "8"))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if prof_every > 0:
+            L.cama_profile_enable(1 if k % prof_every == 0 else 0)
         cm.render_clip("cama", out=out, pipelined=pipelined)
     eng.join()
     sync_all()
