@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--raw-frames", action="store_true",
                     help="frames resident at sensor size 1600x900 and resampled (undistort+resize) to --height x "
                          "--width on the device inside every step: the reference's default 540x960 pipeline")
+    ap.add_argument("--unfused-resample", action="store_true",
+                    help="with --raw-frames: separate resample kernel + overlay instead of the fused raw-frame overlay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single stream: binning and overlay of consecutive steps do not overlap")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
@@ -90,7 +92,7 @@ def build_scene(args, rank, device):
         from cama_amd.frames import RawDeviceFrameSource
         frames = torch.randint(0, 256, (args.frames + 1, 6, 900, 1600, 3), dtype=torch.uint8, device=device,
                                generator=gen)
-        cm.set_frame_source(RawDeviceFrameSource(frames, cm.cm_list))
+        cm.set_frame_source(RawDeviceFrameSource(frames, cm.cm_list, fused=not getattr(args, "unfused_resample", False)))
     else:
         frames = torch.randint(0, 256, (args.frames + 1, 6, H, W, 3), dtype=torch.uint8, device=device, generator=gen)
         cm.set_frame_source(DeviceFrameSource(frames))

@@ -422,6 +422,71 @@ __global__ __launch_bounds__(64) void k_scan_totals(const uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) building blocks (reproject.py:238-239), shared by the stand-alone
+// resample kernel and by the overlay that reads raw sensor frames
+// ------------------------------------------------------------------------------------------
+struct Tap6 { uint32_t lo; uint32_t hi; };   // 6 useful bytes: pixel x0 (b,g,r) then pixel x0+1 (b,g,r)
+
+// two horizontally adjacent BGR pixels starting at byte offset `o` of a frame of `frame_bytes` bytes (any alignment),
+// always as two dword loads and without branches: a tap that would run past the end of the frame is read from
+// `frame_bytes - 8` and funnel-shifted into place (only the last two pixels of a frame ever need it)
+__device__ __forceinline__ Tap6 load_tap(const uint8_t *frame, size_t o, size_t frame_bytes)
+{
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    const size_t last = frame_bytes - 8;
+    const size_t at = o < last ? o : last;
+    const uint32_t sh = (uint32_t)(o - at) * 8u;                      // 0, or 8..40 bits at the very end
+    const uint64_t w = (uint64_t)*reinterpret_cast<const u32u *>(frame + at) |
+                       ((uint64_t)*reinterpret_cast<const u32u *>(frame + at + 4) << 32);
+    const uint64_t v = w >> sh;
+    Tap6 t;
+    t.lo = (uint32_t)v;
+    t.hi = (uint32_t)(v >> 32);
+    return t;
+}
+
+// One destination pixel of cv2.remap's 8-bit INTER_LINEAR path: returns b | g<<8 | r<<16.
+// OpenCV: v = (w00 p00 + w01 p01 + w10 p10 + w11 p11 + 2^14) >> 15 with w00 = (32-a)(32-b)*32 etc.  That sum is
+// exactly 32*S with  t_r = (32-a) p_r0 + a p_r1 (per source row r),  S = (32-b) t_0 + b t_1,  so v = (S + 512) >> 10.
+// The horizontal step is a byte dot product: the six tap bytes [b0 g0 r0 b1 | g1 r1] against weights placed on the
+// matching byte lanes (v_dot4_u32_u8), no unpacking.  Taps in the constant border contribute 0 = weight 0.
+__device__ __forceinline__ uint32_t remap_pixel(const uint8_t *__restrict__ s, size_t frame_bytes, int H0, int W0,
+                                                float mx, float my)
+{
+    const int sx = __float2int_rn(mx * 32.0f), sy = __float2int_rn(my * 32.0f);   // cvRound: half to even
+    const int x0 = sx >> 5, y0 = sy >> 5;
+    const bool xin0 = (unsigned)x0 < (unsigned)W0, xin1 = (unsigned)(x0 + 1) < (unsigned)W0;
+    const bool yin0 = (unsigned)y0 < (unsigned)H0, yin1 = (unsigned)(y0 + 1) < (unsigned)H0;
+    // (all four taps in the constant border: every weight below is 0 and the result is 0 -- no branch needed)
+    const uint32_t a = (uint32_t)(sx & 31), b = (uint32_t)(sy & 31);
+    uint32_t wl = xin0 ? 32u - a : 0u, wr = xin1 ? a : 0u;              // left / right tap weights
+    const uint32_t wt = yin0 ? 32u - b : 0u, wb = yin1 ? b : 0u;        // top / bottom row weights
+    // clamp the addresses into the frame (masked taps have weight 0, whatever bytes are read)
+    const int xc = min(max(x0, 0), W0 - 1), y0c = min(max(y0, 0), H0 - 1), y1c = min(max(y0 + 1, 0), H0 - 1);
+    const size_t o0 = ((size_t)y0c * W0 + xc) * 3, o1 = ((size_t)y1c * W0 + xc) * 3;
+    const Tap6 t0 = load_tap(s, o0, frame_bytes), t1 = load_tap(s, o1, frame_bytes);
+    const bool left_border = x0 < 0;      // x0 == -1: the in-range (right) tap is the FIRST pixel that was loaded
+    wl = left_border ? wr : wl;
+    wr = left_border ? 0u : wr;
+    // weights on byte lanes: lo = [b0 g0 r0 b1], hi = [g1 r1 . .]
+    const uint32_t wB = wl | (wr << 24), wGl = wl << 8, wGh = wr, wRl = wl << 16, wRh = wr << 8;
+    const uint32_t tB0 = __builtin_amdgcn_udot4(t0.lo, wB, 0u, false);
+    const uint32_t tG0 = __builtin_amdgcn_udot4(t0.hi, wGh, __builtin_amdgcn_udot4(t0.lo, wGl, 0u, false), false);
+    const uint32_t tR0 = __builtin_amdgcn_udot4(t0.hi, wRh, __builtin_amdgcn_udot4(t0.lo, wRl, 0u, false), false);
+    const uint32_t tB1 = __builtin_amdgcn_udot4(t1.lo, wB, 0u, false);
+    const uint32_t tG1 = __builtin_amdgcn_udot4(t1.hi, wGh, __builtin_amdgcn_udot4(t1.lo, wGl, 0u, false), false);
+    const uint32_t tR1 = __builtin_amdgcn_udot4(t1.hi, wRh, __builtin_amdgcn_udot4(t1.lo, wRl, 0u, false), false);
+    const uint32_t vB = (wt * tB0 + wb * tB1 + 512u) >> 10;             // <= 255 by construction
+    const uint32_t vG = (wt * tG0 + wb * tG1 + 512u) >> 10;
+    const uint32_t vR = (wt * tR0 + wb * tR1 + 512u) >> 10;
+    return vB | (vG << 8) | (vR << 16);
+}
+
+// map addressing: value for destination (y, x) is map[y * row_stride + x * col_stride]; full 2-D maps use (W, 1),
+// separable ones (zero distortion: mapx = f(x), mapy = g(y)) use (0, 1) and (1, 0) on W- and H-long vectors
+struct MapStride { int xr, xc, yr, yc; uint32_t w_magic; };
+
+// ------------------------------------------------------------------------------------------
 // overlay: band copy + deterministic stamp resolution
 // ------------------------------------------------------------------------------------------
 struct OverlayArgs {
@@ -434,6 +499,11 @@ struct OverlayArgs {
     const uint2 *stamps;
     Disc disc;
     Palette pal;
+    // RESAMPLE variant: src holds RAW frames [F,C,H0,W0,3]; each mosaic pixel is remapped from them on the fly
+    int H0, W0;
+    const float *mapx, *mapy;            // per camera: mapx + c * mapx_cam, mapy + c * mapy_cam
+    int64_t mapx_cam, mapy_cam;
+    MapStride ms;
 };
 
 __device__ __forceinline__ void rasterise_stamps(uint32_t *s_owner, const uint2 *st, uint32_t n,
@@ -485,7 +555,20 @@ __device__ __forceinline__ void patch_chunk(u32x4 &d, const uint32_t *orow, uint
     d.w = (d.w & ~m3) | (v3 & m3);
 }
 
-template <bool VEC>
+// 6 packed pixels (b | g<<8 | r<<16) that a 16-byte chunk starting `ph` bytes into the first one overlaps -> the chunk
+__device__ __forceinline__ u32x4 chunk_from_pixels(const uint32_t *c, uint32_t ph)
+{
+    const uint32_t V0 = c[0] | (c[1] << 24), V1 = (c[1] >> 8) | (c[2] << 16), V2 = (c[2] >> 16) | (c[3] << 8),
+                   V3 = c[4] | (c[5] << 24), V4 = c[5] >> 8;
+    u32x4 v;
+    v.x = __builtin_amdgcn_alignbyte(V1, V0, ph);
+    v.y = __builtin_amdgcn_alignbyte(V2, V1, ph);
+    v.z = __builtin_amdgcn_alignbyte(V3, V2, ph);
+    v.w = __builtin_amdgcn_alignbyte(V4, V3, ph);
+    return v;
+}
+
+template <bool VEC, bool RESAMPLE>
 __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x W, used only by stamped bands
@@ -523,10 +606,42 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
         __syncthreads();
     }
 
-    const uint8_t *sband = a.src + ((size_t)fc * a.H + y0) * (size_t)W * 3;
+    const uint8_t *sband = a.src + ((size_t)fc * a.H + y0) * (size_t)W * 3;      // (unused by RESAMPLE)
     uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
                      ((size_t)(c / (uint32_t)a.cols) * a.H + y0) * a.mosaic_row_bytes +
                      (size_t)(c % (uint32_t)a.cols) * W * 3;
+
+    if (RESAMPLE) {
+        // The source is the raw sensor frame of (f, c): every destination pixel is the fixed-point bilinear blend of
+        // its 2x2 source taps (cv2.remap semantics), computed here instead of being read from a pre-resized frame.
+        // A 16-byte chunk overlaps 6 destination pixels; adjacent lanes own adjacent chunks, so their taps are
+        // adjacent in the raw frame.  Raw bytes are read once from HBM (re-reads hit L1/L2), resized frames never
+        // exist in memory.
+        const size_t raw_frame = (size_t)a.H0 * a.W0 * 3;
+        const uint8_t *raw = a.src + (size_t)fc * raw_frame;
+        const float *mxc = a.mapx + (size_t)c * a.mapx_cam, *myc = a.mapy + (size_t)c * a.mapy_cam;
+        const uint32_t nchunks = (uint32_t)nrows * a.cpr;
+        for (uint32_t idx = threadIdx.x; idx < nchunks; idx += OVERLAY_BLOCK) {
+            const uint32_t row = __umulhi(idx, a.cpr_magic), col = idx - row * a.cpr;
+            const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
+            const int y = y0 + (int)row;
+            float mx[6], my[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int x = (int)p0 + k;
+                mx[k] = mxc[y * a.ms.xr + x * a.ms.xc];
+                my[k] = myc[y * a.ms.yr + x * a.ms.yc];
+            }
+            uint32_t px[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) px[k] = remap_pixel(raw, raw_frame, a.H0, a.W0, mx[k], my[k]);
+            u32x4 v = chunk_from_pixels(px, ph);
+            if (n) patch_chunk(v, s_owner + row * W, col, a.pal);
+            u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
+            OVERLAY_STORE(v, drow + col);
+        }
+        return;
+    }
 
     if (VEC) {
         // the band is one contiguous byte range in src: chunk j of the band is src16[j]
@@ -612,63 +727,6 @@ __global__ __launch_bounds__(BLOCK) void k_apply_owner(const uint32_t *__restric
 // OpenCV's 8-bit remap quantises coordinates to 1/32 px (INTER_BITS = 5) and blends with 15-bit fixed-point
 // weights; for bilinear the weights (32-a)(32-b)*32 ... are exact integers summing to 1 << 15.
 // ------------------------------------------------------------------------------------------
-struct Tap6 { uint32_t lo; uint32_t hi; };   // 6 useful bytes: pixel x0 (b,g,r) then pixel x0+1 (b,g,r)
-
-// two horizontally adjacent BGR pixels starting at byte address p (any alignment), as one 8-byte load when that
-// stays inside the buffer, else byte-wise
-__device__ __forceinline__ Tap6 load_tap(const uint8_t *p, bool wide_ok)
-{
-    Tap6 t;
-    if (wide_ok) {
-        typedef uint32_t __attribute__((aligned(1))) u32u;
-        t.lo = *reinterpret_cast<const u32u *>(p);
-        t.hi = *reinterpret_cast<const u32u *>(p + 4);
-    } else {
-        t.lo = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-        t.hi = (uint32_t)p[4] | ((uint32_t)p[5] << 8);
-    }
-    return t;
-}
-
-// One destination pixel of cv2.remap's 8-bit INTER_LINEAR path: returns b | g<<8 | r<<16.
-// OpenCV: v = (w00 p00 + w01 p01 + w10 p10 + w11 p11 + 2^14) >> 15 with w00 = (32-a)(32-b)*32 etc.  That sum is
-// exactly 32*S with  t_r = (32-a) p_r0 + a p_r1 (per source row r),  S = (32-b) t_0 + b t_1,  so v = (S + 512) >> 10.
-// The horizontal step is a byte dot product: the six tap bytes [b0 g0 r0 b1 | g1 r1] against weights placed on the
-// matching byte lanes (v_dot4_u32_u8), no unpacking.  Taps in the constant border contribute 0 = weight 0.
-__device__ __forceinline__ uint32_t remap_pixel(const uint8_t *__restrict__ s, size_t frame_bytes, int H0, int W0,
-                                                float mx, float my)
-{
-    const int sx = __float2int_rn(mx * 32.0f), sy = __float2int_rn(my * 32.0f);   // cvRound: half to even
-    const int x0 = sx >> 5, y0 = sy >> 5;
-    const bool xin0 = (unsigned)x0 < (unsigned)W0, xin1 = (unsigned)(x0 + 1) < (unsigned)W0;
-    const bool yin0 = (unsigned)y0 < (unsigned)H0, yin1 = (unsigned)(y0 + 1) < (unsigned)H0;
-    if (!((xin0 | xin1) & (yin0 | yin1))) return 0u;                    // all four taps in the constant border
-    const uint32_t a = (uint32_t)(sx & 31), b = (uint32_t)(sy & 31);
-    uint32_t wl = xin0 ? 32u - a : 0u, wr = xin1 ? a : 0u;              // left / right tap weights
-    const uint32_t wt = yin0 ? 32u - b : 0u, wb = yin1 ? b : 0u;        // top / bottom row weights
-    // clamp the addresses into the frame (masked taps have weight 0, whatever bytes are read)
-    const int xc = min(max(x0, 0), W0 - 1), y0c = min(max(y0, 0), H0 - 1), y1c = min(max(y0 + 1, 0), H0 - 1);
-    const size_t o0 = ((size_t)y0c * W0 + xc) * 3, o1 = ((size_t)y1c * W0 + xc) * 3;
-    const Tap6 t0 = load_tap(s + o0, o0 + 8 <= frame_bytes), t1 = load_tap(s + o1, o1 + 8 <= frame_bytes);
-    if (x0 < 0) { wl = wr; wr = 0u; }     // x0 == -1: the in-range (right) tap is the FIRST pixel that was loaded
-    // weights on byte lanes: lo = [b0 g0 r0 b1], hi = [g1 r1 . .]
-    const uint32_t wB = wl | (wr << 24), wGl = wl << 8, wGh = wr, wRl = wl << 16, wRh = wr << 8;
-    const uint32_t tB0 = __builtin_amdgcn_udot4(t0.lo, wB, 0u, false);
-    const uint32_t tG0 = __builtin_amdgcn_udot4(t0.hi, wGh, __builtin_amdgcn_udot4(t0.lo, wGl, 0u, false), false);
-    const uint32_t tR0 = __builtin_amdgcn_udot4(t0.hi, wRh, __builtin_amdgcn_udot4(t0.lo, wRl, 0u, false), false);
-    const uint32_t tB1 = __builtin_amdgcn_udot4(t1.lo, wB, 0u, false);
-    const uint32_t tG1 = __builtin_amdgcn_udot4(t1.hi, wGh, __builtin_amdgcn_udot4(t1.lo, wGl, 0u, false), false);
-    const uint32_t tR1 = __builtin_amdgcn_udot4(t1.hi, wRh, __builtin_amdgcn_udot4(t1.lo, wRl, 0u, false), false);
-    const uint32_t vB = (wt * tB0 + wb * tB1 + 512u) >> 10;             // <= 255 by construction
-    const uint32_t vG = (wt * tG0 + wb * tG1 + 512u) >> 10;
-    const uint32_t vR = (wt * tR0 + wb * tR1 + 512u) >> 10;
-    return vB | (vG << 8) | (vR << 16);
-}
-
-// map addressing: value for destination (y, x) is map[y * row_stride + x * col_stride]; full 2-D maps use (W, 1),
-// separable ones (zero distortion: mapx = f(x), mapy = g(y)) use (0, 1) and (1, 0) on W- and H-long vectors
-struct MapStride { int xr, xc, yr, yc; uint32_t w_magic; };
-
 __global__ __launch_bounds__(BLOCK) void k_resample(const uint8_t *__restrict__ src, int64_t src_stride,
                                                     uint8_t *__restrict__ dst, int64_t dst_stride, int H0, int W0,
                                                     int H, int W, const float *__restrict__ mapx,
@@ -1065,9 +1123,11 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     return CAMA_OK;
 }
 
-int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
-                        int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
-                        const void *scratch, size_t scratch_bytes, void *stream)
+struct RawSource { int H0, W0; const float *mapx, *mapy; int separable; };
+
+static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosaic, int64_t N, int32_t F, int32_t C,
+                        int32_t H, int32_t W, int32_t cols, int32_t radius, const int32_t *halfwidth,
+                        const uint8_t *palette_bgr, const void *scratch, size_t scratch_bytes, void *stream)
 {
     ScratchLayout L;
     if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
@@ -1089,10 +1149,20 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
     o.counts = (const uint32_t *)(base + L.counts); o.bin_off = (const uint32_t *)(base + L.bin_off);
     o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)(base + L.stamps);
     o.disc = disc; o.pal = make_palette(palette_bgr);
-    const bool vec = (W % 16 == 0) && (((uintptr_t)src | (uintptr_t)mosaic) % 16 == 0);
+    const bool vec = (W % 16 == 0) && ((((raw ? 0 : (uintptr_t)src)) | (uintptr_t)mosaic) % 16 == 0);
     if (vec) {
         o.cpr = (uint32_t)(W * 3 / 16);
         o.cpr_magic = (uint32_t)(((1ull << 32) + o.cpr - 1) / o.cpr);
+    }
+    if (raw) {
+        if (!vec) return fail(CAMA_EINVAL, "the raw-frame overlay needs W %% 16 == 0 and a 16-byte aligned mosaic");
+        if (raw->H0 < 1 || raw->W0 < 1 || (int64_t)raw->H0 * raw->W0 * 3 < 8 || !raw->mapx || !raw->mapy)
+            return fail(CAMA_EINVAL, "bad raw-frame source");
+        o.H0 = raw->H0; o.W0 = raw->W0; o.mapx = raw->mapx; o.mapy = raw->mapy;
+        o.mapx_cam = raw->separable ? W : (int64_t)H * W;
+        o.mapy_cam = raw->separable ? H : (int64_t)H * W;
+        o.ms.xr = raw->separable ? 0 : W; o.ms.xc = 1; o.ms.yr = raw->separable ? 1 : W; o.ms.yc = raw->separable ? 0 : 1;
+        o.ms.w_magic = 0;
     }
 #ifdef OVERLAY_ORDER_FCB
     const unsigned nblocks = (unsigned)((size_t)nfc * L.NB);
@@ -1100,8 +1170,9 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
     const unsigned nblocks = (unsigned)((size_t)F * rows * cols * L.NB);   // (frame, camera row, band, camera column)
 #endif
     if (lds > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_prof.on) {
@@ -1109,16 +1180,36 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
         ev1 = prof_event();
         if (ev0 && ev1) HIP_TRY(hipEventRecord(ev0, s));
     }
-    if (vec)
-        hipLaunchKernelGGL(k_overlay<true>, dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+    if (raw)
+        hipLaunchKernelGGL((k_overlay<true, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+    else if (vec)
+        hipLaunchKernelGGL((k_overlay<true, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
     else
-        hipLaunchKernelGGL(k_overlay<false>, dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+        hipLaunchKernelGGL((k_overlay<false, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) {
         HIP_TRY(hipEventRecord(ev1, s));
         g_prof.pending.emplace_back(ev0, ev1);
     }
     return CAMA_OK;
+}
+
+int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                        int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                        const void *scratch, size_t scratch_bytes, void *stream)
+{
+    return overlay_impl(src, nullptr, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
+                        scratch_bytes, stream);
+}
+
+int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const float *mapx, const float *mapy,
+                            int32_t separable, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                            int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                            const void *scratch, size_t scratch_bytes, void *stream)
+{
+    const RawSource rs{H0, W0, mapx, mapy, separable};
+    return overlay_impl(raw, &rs, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch, scratch_bytes,
+                        stream);
 }
 
 int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
@@ -1144,6 +1235,7 @@ int cama_resample_frames(const uint8_t *src, int64_t src_stride_bytes, uint8_t *
     if (n < 0 || n > 65535) return fail(CAMA_EINVAL, "n=%d out of range [0, 65535]", n);
     if (H0 < 1 || W0 < 1 || H < 1 || W < 1 || W > 65535 || (int64_t)H * W * (int64_t)W >= (1ll << 32))
         return fail(CAMA_EINVAL, "bad image sizes %dx%d -> %dx%d", W0, H0, W, H);
+    if ((int64_t)H0 * W0 * 3 < 8) return fail(CAMA_EINVAL, "source frame smaller than one 8-byte tap");
     if (n == 0) return CAMA_OK;
     if (!src || !dst || !mapx || !mapy) return fail(CAMA_EINVAL, "NULL pointer argument");
     MapStride ms;

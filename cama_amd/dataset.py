@@ -378,8 +378,13 @@ class ClipManager:
         T = eng._mats(w2c)
         crop = self.mm.crop_box()
         src_all = self.frame_source()
+        fused_raw = getattr(src_all, "fused", False) and hasattr(src_all, "raw_batch")
         for lo in range(0, F, step):
             hi = min(F, lo + step)
+            if fused_raw:      # raw sensor frames: undistort + resize inside the overlay kernel
+                eng.render_frames_raw(dmap, rig, T[lo:hi], src_all.raw_batch([int(i) for i in idx[lo:hi]]),
+                                      self.cm_list, out=out[lo:hi], crop=crop)
+                continue
             src = src_all.batch([int(i) for i in idx[lo:hi]])
             if pipelined:
                 eng.render_frames_pipelined(dmap, rig, T[lo:hi], src, out[lo:hi], crop=crop)

@@ -313,6 +313,57 @@ class Engine:
                                                      self._stream()))
             return out[0] if single else out
 
+    # ------------------------------------------------------------------ fused render from RAW sensor frames
+    def rig_maps(self, cm_list):
+        """Per-camera undistort/resize maps of a rig, concatenated on the device: (mapx, mapy, separable)."""
+        torch = _torch()
+        from .frames import camera_maps
+        key = tuple(id(cm) for cm in cm_list)
+        hit = getattr(self, "_rig_maps", None)
+        if hit is None or hit[0] != key:
+            maps = [camera_maps(cm) for cm in cm_list]
+            sep = all(bool((mx == mx[0:1, :]).all() and (my == my[:, 0:1]).all()) for mx, my in maps)
+            if sep:
+                mx = np.stack([m[0][0, :] for m in maps])
+                my = np.stack([m[1][:, 0] for m in maps])
+            else:
+                mx = np.stack([m[0].reshape(-1) for m in maps])
+                my = np.stack([m[1].reshape(-1) for m in maps])
+            hit = (key, torch.from_numpy(np.ascontiguousarray(mx)).to(self.device),
+                   torch.from_numpy(np.ascontiguousarray(my)).to(self.device), int(sep))
+            self._rig_maps = hit
+        return hit[1:]
+
+    def render_frames_raw(self, dmap, rig, w2c, raw, cm_list, out=None, cols=3, crop=None):
+        """Like render_frames, but `raw` [F,C,H0,W0,3] holds RAW sensor frames: undistort + resize to the rig's
+        output size happens inside the overlay kernel's source read (cama_overlay_frames_raw)."""
+        torch = _torch()
+        cropa = self._crop(crop)
+        with torch.cuda.device(self.device):
+            T = w2c if (isinstance(w2c, torch.Tensor) and w2c.dtype == torch.float64 and w2c.is_cuda
+                        and w2c.dim() == 2) else self._mats(w2c)
+            F = T.shape[0]
+            assert raw.is_cuda and raw.dtype == torch.uint8 and raw.is_contiguous() and raw.dim() == 5
+            assert raw.shape[0] == F and raw.shape[1] == rig.C and raw.shape[4] == 3
+            H0, W0 = int(raw.shape[2]), int(raw.shape[3])
+            shape = self.mosaic_shape(rig, F, cols)
+            if out is None:
+                out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+            assert tuple(out.shape) == shape and out.is_contiguous()
+            mapx, mapy, sep = self.rig_maps(cm_list)
+            need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
+            scratch = self._scratch_buf(need)
+            x, y, z, col, key = dmap.render_ptrs()
+            st = self._stream()
+            _lib.check(self.lib.cama_bin_frames(
+                x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
+                cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(), st))
+            _lib.check(self.lib.cama_overlay_frames_raw(
+                raw.data_ptr(), H0, W0, mapx.data_ptr(), mapy.data_ptr(), sep, out.data_ptr(), dmap.N, F, rig.C,
+                rig.H, rig.W, cols, self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data,
+                scratch.data_ptr(), scratch.numel(), st))
+            return out
+
     # ------------------------------------------------------------------ pipelined render (two streams)
     def _pipeline(self):
         torch = _torch()

@@ -126,9 +126,15 @@ class RawDeviceFrameSource:
     device to the CameraManagers' output size (the reference does this per image on the host,
     cama/reproject.py:228-244)."""
 
-    def __init__(self, raw, cm_list):
+    def __init__(self, raw, cm_list, fused=True):
         self.raw, self.cm_list = raw, cm_list
+        self.fused = fused          # True: ClipManager.render_clip hands the raw frames to the fused overlay kernel
         self._buf = None
+
+    def raw_batch(self, image_indices):
+        idx = list(image_indices)
+        assert idx == list(range(idx[0], idx[0] + len(idx))), "contiguous frame ranges only"
+        return self.raw[idx[0]:idx[0] + len(idx)]
 
     def batch(self, image_indices):
         import torch

@@ -150,6 +150,21 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
                         const void *scratch, size_t scratch_bytes, void *stream);
 
 /*
+ * Overlay half that reads RAW sensor frames: undistort + resize (the cv2.initUndistortRectifyMap + cv2.remap of
+ * CameraManager.resize_image, cama/reproject.py:232-240) is fused into the overlay's source read, so the
+ * reference-default pipeline 1600x900 JPEG frame -> 960x540 overlay -> 2880x1080 mosaic is one pass: every raw byte
+ * is read once, every mosaic byte written once, no resized frame exists in memory.  Same semantics as
+ * cama_resample_frames followed by cama_overlay_frames (tests/test_gpu_dropin.py checks byte equality).
+ *   raw   [F,C,H0,W0,3] uint8      mapx, mapy: per camera c at mapx + c*(separable ? W : H*W), mapy + c*(separable ?
+ *   H : H*W); separable as in cama_resample_frames.  Needs W % 16 == 0.  Other arguments as cama_overlay_frames.
+ */
+int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const float *mapx, const float *mapy,
+                            int32_t separable, uint8_t *mosaic, int64_t N, int32_t F, int32_t C,
+                            int32_t H, int32_t W, int32_t cols,
+                            int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                            const void *scratch, size_t scratch_bytes, void *stream);
+
+/*
  * Stamp-only overlay for caller-supplied 2D points (the generic CameraManager.render_maps,
  * cama/reproject.py:246-257, for one image): points are (v,u) float64 in draw order.
  *   vu [n,2] float64, colour_id [n] uint8, image [H,W,3] uint8 updated in place.

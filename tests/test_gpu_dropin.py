@@ -220,3 +220,39 @@ def test_device_static_map_float64_raster_and_edge_pixels(tmp_path):
     d32 = runtime.engine().build_static_map(table, lift=True, bev_height=bev.astype(np.float32))
     assert np.array_equal(d32.soa.cpu().numpy().T, np.concatenate([w["points"] for w in want32]))
     assert d32.colour.cpu().numpy().tolist() == [0] * want[0]["points"].shape[0] + [1] * want[1]["points"].shape[0]
+
+
+def test_fused_raw_frame_overlay_equals_resample_then_overlay(tmp_path):
+    """cama_overlay_frames_raw (undistort+resize fused into the overlay's source read) == cama_resample_frames followed
+    by the plain overlay, byte for byte; with and without lens distortion (separable / full 2-D maps)."""
+    import torch
+    from cama_amd.dataset import ClipManager
+    from cama_amd.frames import RawDeviceFrameSource
+    from cama_amd.synth import make_clip
+    for k, dist in enumerate((False, True)):
+        clip = str(tmp_path / f"clip{k}")
+        make_clip(clip, n_frames=4, seed=20 + k, n_lines=10, verts_per_line=5, line_len_m=3.0, raster_size=400,
+                  origin_size=(90, 160), with_nuscenes=False, d_nonzero=dist)
+        H, W = 54, 96                                                   # 0.6 scale like 900x1600 -> 540x960
+        outs = []
+        raw = torch.randint(0, 256, (4, 6, 90, 160, 3), dtype=torch.uint8, device="cuda")
+        for fused in (True, False):
+            cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W)), clip)
+            assert cm.cm_list[0].needs_resample()
+            cm.set_frame_source(RawDeviceFrameSource(raw, cm.cm_list, fused=fused))
+            idx, mosaic = cm.render_clip("cama")
+            torch.cuda.synchronize()
+            outs.append(mosaic.clone())
+        assert idx.tolist() == [1, 2, 3] and tuple(outs[0].shape) == (3, 2 * H, 3 * W, 3)
+        assert torch.equal(outs[0], outs[1])
+        # against the oracle's restated remap + circle
+        att = O.read_attribute(clip)
+        cams = [O.camera_model(att, n, output_size=(H, W)) for n in CAMERA_NAMES]
+        xyz, col, _, _ = O.flatten_instances(cm.instance_maps["cama"])
+        _, w2c = cm.frame_poses("cama")
+        rawh = raw.cpu().numpy()
+        small = np.stack([O.remap_bilinear(rawh[2, c], *O.undistort_map(cam["K_origin"], cam["d_origin"], cam["K"], W, H))
+                          for c, cam in enumerate(cams)])
+        flat = O.frame_project_flat(xyz, w2c[1], cams, W, H)
+        assert flat["vis"].sum() > 100
+        assert np.array_equal(outs[0][1].cpu().numpy(), O.frame_render_flat(small, flat["vu"], flat["vis"], col))
