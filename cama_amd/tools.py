@@ -1,17 +1,23 @@
 """VideoGenerator / load_json with the reference's surface (cama/tools.py).
 
 concate_image is the 2x3 mosaic the demo feeds to the encoder.  When render_vectors produced the frame on the
-device, the mosaic already exists (the overlay kernel writes straight into mosaic addresses), so
-concate_image only downloads it; for plain dicts of arrays it concatenates like the reference.
-The ffmpeg pipe itself is outside the hot path; it is created lazily so that importing this module (and
-building mosaics) works where ffmpeg-python is not installed.
+device, the mosaic already exists (the overlay kernel writes straight into mosaic addresses), so concate_image
+only downloads it; for plain dicts of arrays it concatenates like the reference.
+
+The encoder is outside the hot path.  The reference drives it through ffmpeg-python
+(tools.py:13-20); here the same stream -- raw bgr24 frames on stdin -> libx264, yuv420p, 10 fps, overwrite,
+quiet -- is a plain subprocess of the `ffmpeg` binary, started lazily so that importing this module and building
+mosaics works on machines without ffmpeg.  `self.writer` keeps the `.stdin` / `.wait()` interface callers use.
 """
 import json
+import shutil
+import subprocess
 
 import numpy as np
 
 MOSAIC_ORDER = ("camera_front_left", "camera_front", "camera_front_right",
                 "camera_rear_left", "camera_rear", "camera_rear_right")   # tools.py:23-24
+VIDEO_FPS = 10                                                            # tools.py:17
 
 
 def load_json(filename):
@@ -19,26 +25,30 @@ def load_json(filename):
         return json.load(f)
 
 
+def _encoder_command(path, width, height, fps=VIDEO_FPS):
+    return ["ffmpeg", "-loglevel", "quiet", "-y",
+            "-f", "rawvideo", "-pix_fmt", "bgr24", "-s", f"{width}x{height}", "-i", "pipe:",
+            "-pix_fmt", "yuv420p", "-vcodec", "libx264", "-r", str(fps), path]
+
+
 class VideoGenerator:
     def __init__(self, output_video_path, output_shape=(2880, 1080)):
-        import ffmpeg   # ffmpeg-python, as in the reference (tools.py:13-20)
-        self.writer = (
-            ffmpeg
-            .input('pipe:', format='rawvideo', pix_fmt='bgr24', s=f'{output_shape[0]}x{output_shape[1]}')
-            .output(output_video_path, pix_fmt='yuv420p', vcodec='libx264', r=10, loglevel='quiet')
-            .overwrite_output()
-            .run_async(pipe_stdin=True)
-        )
+        self.output_video_path = output_video_path
+        self.output_shape = tuple(output_shape)         # (width, height) of the mosaic
+        if shutil.which("ffmpeg") is None:
+            raise FileNotFoundError("the `ffmpeg` binary is needed to encode the reprojection video")
+        self.writer = subprocess.Popen(_encoder_command(output_video_path, *self.output_shape),
+                                       stdin=subprocess.PIPE)
 
     def concate_image(self, image_dict):
+        """camera name -> (H,W,3) images => (2H,3W,3): front_left | front | front_right over the three rear cameras."""
         mosaic = getattr(image_dict, "mosaic", None)
         if callable(mosaic):
-            got = mosaic(MOSAIC_ORDER)
-            if got is not None:
-                return got
-        top = np.concatenate([image_dict[n] for n in MOSAIC_ORDER[:3]], axis=1)
-        bottom = np.concatenate([image_dict[n] for n in MOSAIC_ORDER[3:]], axis=1)
-        return np.concatenate([top, bottom], axis=0)
+            ready = mosaic(MOSAIC_ORDER)               # already assembled in HBM by the overlay kernel
+            if ready is not None:
+                return ready
+        rows = [np.concatenate([image_dict[name] for name in MOSAIC_ORDER[r:r + 3]], axis=1) for r in (0, 3)]
+        return np.concatenate(rows, axis=0)
 
     def add_frame(self, image):
         self.writer.stdin.write(image.astype(np.uint8).tobytes())
@@ -46,8 +56,12 @@ class VideoGenerator:
     def add_frame_from_dict(self, image_dict):
         self.add_frame(self.concate_image(image_dict))
 
-    def __del__(self):
+    def close(self):
         writer = getattr(self, "writer", None)
         if writer is not None:
+            self.writer = None
             writer.stdin.close()
             writer.wait()
+
+    def __del__(self):
+        self.close()
