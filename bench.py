@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--verts", type=int, default=10000, help="approximate densified vertex count")
     ap.add_argument("--height", type=int, default=900)
     ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--scenes", type=int, default=0,
+                    help="total number of distinct scenes, sharded over the ranks (default: one per rank). "
+                         "73 = BASELINE configs[2], the v1.0-test sweep; every step renders all scenes of the rank")
     ap.add_argument("--map", choices=["lanes", "random"], default="lanes",
                     help="lanes: CAMA-style densified polylines along the drive (configs[1..3]); random: --verts "
                          "uniformly random map vertices over the 600 m map in random order (configs[4] stress)")
@@ -64,8 +67,9 @@ def parse_args():
     return ap.parse_args()
 
 
-def build_scene(args, rank, device):
+def build_scene(args, seed, device):
     import torch
+    rank = seed
     from cama_amd.dataset import ClipManager
     from cama_amd.frames import DeviceFrameSource
     from cama_amd.synth import DEFAULT_CAMA_CONFIGS, make_clip
@@ -166,15 +170,22 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from cama_amd import _lib, runtime
-    cm, frames, clip = build_scene(args, rank, device)
+    from cama_amd import _lib, runtime, shard
+    n_scenes = args.scenes if args.scenes > 0 else world
+    cost = shard.scene_cost(args.frames, args.verts, args.width, args.height)
+    mine = shard.assign_scenes([cost] * n_scenes, world)[rank]           # scene ids of this rank (seed = scene id)
+    scenes = [build_scene(args, sid, device) for sid in mine]
+    cm, frames, clip = scenes[0] if scenes else (None, None, None)
     eng = runtime.engine()
-    rig = cm._rig()
-    N = cm._static("cama").device().N
-    idx, _ = cm.frame_poses("cama")
-    F = len(idx)
-    assert F == args.frames, (F, args.frames)
-    out = torch.empty(eng.mosaic_shape(rig, F), dtype=torch.uint8, device=device)
+    F = args.frames
+    N = 0
+    out = None
+    for scm, _, _ in scenes:
+        idx, _ = scm.frame_poses("cama")
+        assert len(idx) == args.frames, (len(idx), args.frames)
+        N = max(N, scm._static("cama").device().N)
+    if scenes:
+        out = torch.empty(eng.mosaic_shape(cm._rig(), F), dtype=torch.uint8, device=device)   # shared by the scenes
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -183,8 +194,12 @@ def main():
             torch.cuda.synchronize(device)
 
     pipelined = not args.no_pipeline and not args.raw_frames
+    def step():
+        for scm, _, _ in scenes:
+            scm.render_clip("cama", out=out, pipelined=pipelined)
+
     for _ in range(args.warmup):
-        cm.render_clip("cama", out=out, pipelined=pipelined)
+        step()
     eng.join()
     sync_all()
     L = _lib.lib()
@@ -195,7 +210,7 @@ def main():
     for k in range(args.steps):
         if prof_every > 0:
             L.cama_profile_enable(1 if k % prof_every == 0 else 0)
-        cm.render_clip("cama", out=out, pipelined=pipelined)
+        step()
     eng.join()
     sync_all()
     dt = time.perf_counter() - t0
@@ -204,11 +219,10 @@ def main():
     L.cama_profile_collect(ctypes.byref(ov_ms), ctypes.byref(ov_n))
     L.cama_profile_enable(0)
 
-    from cama_amd import shard
     H, W = args.height, args.width
-    h_lo, h_hi = shard.overlay_hash(out)                        # checksum of this rank's final mosaics (untimed)
-    rec = [float(F * args.steps), dt, ov_ms.value, float(ov_n.value), float(N),
-           float(args.steps) * shard.scene_cost(F, N, W, H), float(h_lo % 2 ** 52), float(h_hi % 2 ** 52)]
+    h_lo, h_hi = shard.overlay_hash(out) if out is not None else (0, 0)   # checksum of the last mosaics (untimed)
+    rec = [float(F * args.steps * len(scenes)), dt, ov_ms.value, float(ov_n.value), float(N),
+           float(args.steps) * len(scenes) * shard.scene_cost(F, N, W, H), float(h_lo % 2 ** 52), float(h_hi % 2 ** 52)]
     # the one collective: metric all_gather over RCCL/xGMI
     allrec = shard.gather_records(rec, device=device if backend == "nccl" else None)
     agg = shard.reduce_metrics(allrec)
@@ -219,7 +233,8 @@ def main():
         bytes_per_frame = 13 * N + 36 * W * H
         launches = max(1.0, float(allrec[0, 3]))
         ov_avg_ms = float(allrec[0, 2]) / launches
-        frames_per_launch = F * args.steps / launches
+        per_call = min(F, eng.max_frames_per_call(cm._static("cama").device(), cm._rig()))
+        frames_per_launch = F / float(-(-F // per_call))         # render_clip splits big clips into several launches
         achieved = bytes_per_frame * frames_per_launch / (ov_avg_ms * 1e-3) / 1e9 if ov_avg_ms > 0 else 0.0
         cfg_key = f"N={N},F={F},{W}x{H}"
         line = {
@@ -228,14 +243,16 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: one scene per GPU, 6 cams x %d frames, %d densified verts, "
-                                   "%dx%d, frames resident in HBM" % (F, N, W, H),
+            "config": {"workload": "BASELINE configs[%d]: %d scene(s) over %d GPU(s), 6 cams x %d frames, %d densified "
+                                   "verts, %dx%d, frames resident in HBM" % (2 if n_scenes > world else 1, n_scenes, world,
+                                                                           F, N, W, H),
+                       "scenes": n_scenes,
                        "frames_per_step": F, "verts": N, "width": W, "height": H, "map": args.map,
                        "sharding": "one scene per rank, no data-path collective",
                        "streams": "2 (binning of step k+1 overlaps overlay of step k)" if pipelined else "1"},
             "overlay_hash_per_rank": agg["hash"],
-            "hbm_GBps_whole_step": bytes_per_frame * fps / world / 1e9,
-            "hbm_frac_whole_step": bytes_per_frame * fps / world / 1e9 / HBM_PEAK_GBS,
+            "hbm_GBps_whole_step": bytes_per_frame * (float(allrec[0, 0]) / float(allrec[0, 1])) / 1e9,   # rank 0's GPU
+            "hbm_frac_whole_step": bytes_per_frame * (float(allrec[0, 0]) / float(allrec[0, 1])) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "k_overlay", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(cfg_key),
                          "avg_launch_ms": ov_avg_ms, "launches": int(launches),
