@@ -445,6 +445,25 @@ __device__ __forceinline__ Tap6 load_tap(const uint8_t *frame, size_t o, size_t 
     return t;
 }
 
+// Horizontal byte dot products + vertical blend of one pixel's 2x2 taps (see remap_pixel): t0 / t1 = six bytes
+// [b0 g0 r0 b1 | g1 r1] of the top / bottom source row, wl/wr and wt/wb = tap weights out of 32 (0 when masked).
+__device__ __forceinline__ uint32_t blend_taps(const Tap6 &t0, const Tap6 &t1, uint32_t wl, uint32_t wr, uint32_t wt,
+                                               uint32_t wb)
+{
+    // weights on byte lanes: lo = [b0 g0 r0 b1], hi = [g1 r1 . .]
+    const uint32_t wB = wl | (wr << 24), wGl = wl << 8, wGh = wr, wRl = wl << 16, wRh = wr << 8;
+    const uint32_t tB0 = __builtin_amdgcn_udot4(t0.lo, wB, 0u, false);
+    const uint32_t tG0 = __builtin_amdgcn_udot4(t0.hi, wGh, __builtin_amdgcn_udot4(t0.lo, wGl, 0u, false), false);
+    const uint32_t tR0 = __builtin_amdgcn_udot4(t0.hi, wRh, __builtin_amdgcn_udot4(t0.lo, wRl, 0u, false), false);
+    const uint32_t tB1 = __builtin_amdgcn_udot4(t1.lo, wB, 0u, false);
+    const uint32_t tG1 = __builtin_amdgcn_udot4(t1.hi, wGh, __builtin_amdgcn_udot4(t1.lo, wGl, 0u, false), false);
+    const uint32_t tR1 = __builtin_amdgcn_udot4(t1.hi, wRh, __builtin_amdgcn_udot4(t1.lo, wRl, 0u, false), false);
+    const uint32_t vB = (wt * tB0 + wb * tB1 + 512u) >> 10;             // <= 255 by construction
+    const uint32_t vG = (wt * tG0 + wb * tG1 + 512u) >> 10;
+    const uint32_t vR = (wt * tR0 + wb * tR1 + 512u) >> 10;
+    return vB | (vG << 8) | (vR << 16);
+}
+
 // One destination pixel of cv2.remap's 8-bit INTER_LINEAR path: returns b | g<<8 | r<<16.
 // OpenCV: v = (w00 p00 + w01 p01 + w10 p10 + w11 p11 + 2^14) >> 15 with w00 = (32-a)(32-b)*32 etc.  That sum is
 // exactly 32*S with  t_r = (32-a) p_r0 + a p_r1 (per source row r),  S = (32-b) t_0 + b t_1,  so v = (S + 512) >> 10.
@@ -468,19 +487,43 @@ __device__ __forceinline__ uint32_t remap_pixel(const uint8_t *__restrict__ s, s
     const bool left_border = x0 < 0;      // x0 == -1: the in-range (right) tap is the FIRST pixel that was loaded
     wl = left_border ? wr : wl;
     wr = left_border ? 0u : wr;
-    // weights on byte lanes: lo = [b0 g0 r0 b1], hi = [g1 r1 . .]
-    const uint32_t wB = wl | (wr << 24), wGl = wl << 8, wGh = wr, wRl = wl << 16, wRh = wr << 8;
-    const uint32_t tB0 = __builtin_amdgcn_udot4(t0.lo, wB, 0u, false);
-    const uint32_t tG0 = __builtin_amdgcn_udot4(t0.hi, wGh, __builtin_amdgcn_udot4(t0.lo, wGl, 0u, false), false);
-    const uint32_t tR0 = __builtin_amdgcn_udot4(t0.hi, wRh, __builtin_amdgcn_udot4(t0.lo, wRl, 0u, false), false);
-    const uint32_t tB1 = __builtin_amdgcn_udot4(t1.lo, wB, 0u, false);
-    const uint32_t tG1 = __builtin_amdgcn_udot4(t1.hi, wGh, __builtin_amdgcn_udot4(t1.lo, wGl, 0u, false), false);
-    const uint32_t tR1 = __builtin_amdgcn_udot4(t1.hi, wRh, __builtin_amdgcn_udot4(t1.lo, wRl, 0u, false), false);
-    const uint32_t vB = (wt * tB0 + wb * tB1 + 512u) >> 10;             // <= 255 by construction
-    const uint32_t vG = (wt * tG0 + wb * tG1 + 512u) >> 10;
-    const uint32_t vR = (wt * tR0 + wb * tR1 + 512u) >> 10;
-    return vB | (vG << 8) | (vR << 16);
+    return blend_taps(t0, t1, wl, wr, wt, wb);
 }
+
+// Horizontal part of the remap of one destination COLUMN, packed: bits 0-15 source byte offset of the left tap
+// (clamped into the row), 16-21 left weight, 22-27 right weight (out of 32; 0 for taps in the constant border; for
+// x0 == -1 the in-range tap is the first loaded pixel, so the weights are swapped).  Depends only on mapx[x].
+__device__ __forceinline__ uint32_t pack_column(float mx, int W0)
+{
+    const int sx = __float2int_rn(mx * 32.0f);                          // cvRound: half to even
+    const int x0 = sx >> 5;
+    const uint32_t a = (uint32_t)(sx & 31);
+    const bool xin0 = (unsigned)x0 < (unsigned)W0, xin1 = (unsigned)(x0 + 1) < (unsigned)W0;
+    uint32_t wl = xin0 ? 32u - a : 0u, wr = xin1 ? a : 0u;
+    const bool left_border = x0 < 0;
+    wl = left_border ? wr : wl;
+    wr = left_border ? 0u : wr;
+    const uint32_t off = (uint32_t)min(max(x0, 0), W0 - 1) * 3u;
+    return off | (wl << 16) | (wr << 22);
+}
+
+// one destination pixel from source rows staged in LDS: row0 / row1 = the two staged rows (clamped into the staged
+// range; wt / wb are 0 when the row is outside the frame), col = pack_column() of the destination column.
+// 6 tap bytes per row at an arbitrary byte offset = three ALIGNED dword reads + funnel shifts (misaligned DS reads are
+// split by the hardware and were 3-4x slower); rows start 16-byte aligned and the buffer is padded.
+__device__ __forceinline__ uint32_t remap_pixel_lds(const uint8_t *row0, const uint8_t *row1, uint32_t col, uint32_t wt,
+                                                    uint32_t wb)
+{
+    const uint32_t off = col & 0xffffu, sh = off & 3u, wl = (col >> 16) & 63u, wr = col >> 22;
+    const uint32_t *q0 = reinterpret_cast<const uint32_t *>(row0 + (off & ~3u));
+    const uint32_t *q1 = reinterpret_cast<const uint32_t *>(row1 + (off & ~3u));
+    const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2], b0 = q1[0], b1 = q1[1], b2 = q1[2];
+    Tap6 t0, t1;
+    t0.lo = __builtin_amdgcn_alignbyte(a1, a0, sh); t0.hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
+    t1.lo = __builtin_amdgcn_alignbyte(b1, b0, sh); t1.hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
+    return blend_taps(t0, t1, wl, wr, wt, wb);
+}
+
 
 // map addressing: value for destination (y, x) is map[y * row_stride + x * col_stride]; full 2-D maps use (W, 1),
 // separable ones (zero distortion: mapx = f(x), mapy = g(y)) use (0, 1) and (1, 0) on W- and H-long vectors
@@ -506,10 +549,11 @@ struct OverlayArgs {
     MapStride ms;
 };
 
+template <int THREADS = OVERLAY_BLOCK>
 __device__ __forceinline__ void rasterise_stamps(uint32_t *s_owner, const uint2 *st, uint32_t n,
                                                  int y0, int nrows, int W, const Disc &disc)
 {
-    for (uint32_t s = threadIdx.x; s < n; s += OVERLAY_BLOCK) {
+    for (uint32_t s = threadIdx.x; s < n; s += THREADS) {
         const uint2 r = st[s];
         const int u = (int)(r.x & 0xffffu), v = (int)(r.x >> 16);
         const uint32_t val = r.y + 1u;  // 0 = no owner
@@ -685,6 +729,83 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
             d[0] = b0; d[1] = b1; d[2] = b2;
         }
     }
+}
+
+// Raw-frame overlay, LDS-staged (separable maps = zero lens distortion, the nuScenes / CAMA calibration):
+// the source rows a band of R destination rows needs (host-precomputed [first, count] per camera and band) are
+// streamed into LDS once with 16-byte loads -- the only global reads of image data -- and every bilinear tap is an
+// LDS read.  The gather variant (k_overlay<true,true>) spends ~40 VMEM instructions per 16 output bytes; this one
+// spends one per 16 INPUT bytes.  LDS: owner table R*W*4 + staged rows + the camera's mapx vector.
+#ifndef RAWLDS_BLOCK
+#define RAWLDS_BLOCK 512            // LDS allows 2 workgroups per CU: 512 threads each = 16 waves to hide LDS taps
+#endif
+__global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, const int2 *__restrict__ band_rows,
+                                                                  int max_src_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
+    const uint32_t camrows = (C + cols - 1) / cols;
+    uint32_t t = blockIdx.x;
+    const uint32_t cc = t % cols; t /= cols;
+    const uint32_t b = t % NB;    t /= NB;
+    const uint32_t cr = t % camrows;
+    const uint32_t f = t / camrows;
+    const uint32_t c = cr * cols + cc;
+    if (c >= C) return;
+    const uint32_t fc = f * C + c;
+    const uint32_t bin = fc * NB + b;
+    const int y0 = (int)b * a.R;
+    const int nrows = min(a.R, a.H - y0);
+    const int W = a.W, W0 = a.W0;
+    const uint32_t n = a.counts[bin];
+    const size_t row_bytes = (size_t)W0 * 3;
+
+    uint32_t *s_owner = s_dyn;                                               // [R*W]
+    uint32_t *s_col = s_dyn + (((size_t)a.R * W + 3) & ~(size_t)3);         // [W] pack_column() of every column
+    uint8_t *s_src = static_cast<uint8_t *>(__builtin_assume_aligned(        // 16-byte aligned
+        reinterpret_cast<uint8_t *>(s_col + ((W + 3) & ~3)), 16));           // [max_src_rows * row_bytes + 16]
+
+    // stage: source rows of this band (contiguous in the raw frame) + the camera's column map
+    const int2 br = band_rows[c * NB + b];
+    const uint32_t nchunk_src = (uint32_t)((size_t)br.y * row_bytes >> 4);
+    const u32x4 *g = reinterpret_cast<const u32x4 *>(a.src + (size_t)fc * a.H0 * row_bytes + (size_t)br.x * row_bytes);
+    for (uint32_t i = threadIdx.x; i < nchunk_src; i += RAWLDS_BLOCK)
+        reinterpret_cast<u32x4 *>(s_src)[i] = OVERLAY_LOAD(g + i);
+    const float *mxc = a.mapx + (size_t)c * a.mapx_cam, *myc = a.mapy + (size_t)c * a.mapy_cam;
+    for (int x = threadIdx.x; x < W; x += RAWLDS_BLOCK) s_col[x] = pack_column(mxc[x], W0);
+    if (n) {
+        uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
+        const int n4 = (nrows * W + 3) >> 2;
+        for (int j = threadIdx.x; j < n4; j += RAWLDS_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        rasterise_stamps<RAWLDS_BLOCK>(s_owner, a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]), n, y0, nrows, W, a.disc);
+    }
+    __syncthreads();
+
+    uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
+                     ((size_t)(c / cols) * a.H + y0) * a.mosaic_row_bytes + (size_t)(c % cols) * W * 3;
+    const uint32_t nchunks = (uint32_t)nrows * a.cpr;
+    const int ylast = br.x + br.y - 1;
+    for (uint32_t idx = threadIdx.x; idx < nchunks; idx += RAWLDS_BLOCK) {
+        const uint32_t row = __umulhi(idx, a.cpr_magic), col = idx - row * a.cpr;
+        const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
+        // vertical part of the remap: once per chunk (all six pixels share the destination row)
+        const int sy = __float2int_rn(myc[y0 + (int)row] * 32.0f);
+        const int yy0 = sy >> 5;
+        const uint32_t bw = (uint32_t)(sy & 31);
+        const uint32_t wt = ((unsigned)yy0 < (unsigned)a.H0) ? 32u - bw : 0u;
+        const uint32_t wb = ((unsigned)(yy0 + 1) < (unsigned)a.H0) ? bw : 0u;
+        const uint8_t *row0 = s_src + (size_t)(min(max(yy0, br.x), ylast) - br.x) * row_bytes;
+        const uint8_t *row1 = s_src + (size_t)(min(max(yy0 + 1, br.x), ylast) - br.x) * row_bytes;
+        uint32_t px[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) px[k] = remap_pixel_lds(row0, row1, s_col[p0 + k], wt, wb);
+        u32x4 v = chunk_from_pixels(px, ph);
+        if (n) patch_chunk(v, s_owner + row * W, col, a.pal);
+        u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
+        OVERLAY_STORE(v, drow + col);
+    }
+    (void)max_src_rows;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -870,8 +991,8 @@ int band_rows_for(int W)
     // Measured on MI355X (profiles/): ~20 KB of image per workgroup streams best (more, smaller
     // workgroups balance stamped bands and keep the LDS owner table R*W*4 <= 26 KB -> 6 workgroups per CU).
     // R must stay >= 2*radius so a disc touches at most two bands.
-    if (W >= 1200) return 4;
-    if (W >= 600) return 8;
+    if (W >= 600) return 4;
+    if (W >= 300) return 8;
     return 16;
 }
 
@@ -1123,7 +1244,7 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     return CAMA_OK;
 }
 
-struct RawSource { int H0, W0; const float *mapx, *mapy; int separable; };
+struct RawSource { int H0, W0; const float *mapx, *mapy; int separable; const int32_t *band_rows; int max_src_rows; };
 
 static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosaic, int64_t N, int32_t F, int32_t C,
                         int32_t H, int32_t W, int32_t cols, int32_t radius, const int32_t *halfwidth,
@@ -1180,7 +1301,23 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
         ev1 = prof_event();
         if (ev0 && ev1) HIP_TRY(hipEventRecord(ev0, s));
     }
-    if (raw)
+    // LDS-staged raw variant when the maps are separable, the host supplied the per-band source rows, rows are
+    // 16-byte multiples and the staging buffer fits; else the gather variant
+    size_t lds_raw = 0;
+    bool raw_lds = false;
+    if (raw && raw->separable && raw->band_rows && raw->max_src_rows > 0 && ((size_t)raw->W0 * 3) % 16 == 0 &&
+        ((uintptr_t)src % 16 == 0)) {
+        lds_raw = (((size_t)L.R * W + 3) & ~(size_t)3) * 4 + (((size_t)W + 3) & ~(size_t)3) * 4 +
+                  (size_t)raw->max_src_rows * raw->W0 * 3 + 16;
+        raw_lds = lds_raw <= 160 * 1024;
+    }
+    if (raw_lds) {
+        if (lds_raw > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_rawlds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_raw));
+        hipLaunchKernelGGL(k_overlay_rawlds, dim3(nblocks), dim3(RAWLDS_BLOCK), lds_raw, s, o,
+                           reinterpret_cast<const int2 *>(raw->band_rows), raw->max_src_rows);
+    } else if (raw)
         hipLaunchKernelGGL((k_overlay<true, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
     else if (vec)
         hipLaunchKernelGGL((k_overlay<true, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
@@ -1203,11 +1340,12 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
 }
 
 int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const float *mapx, const float *mapy,
-                            int32_t separable, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
-                            int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
-                            const void *scratch, size_t scratch_bytes, void *stream)
+                            int32_t separable, const int32_t *band_src_rows, int32_t max_src_rows, uint8_t *mosaic,
+                            int64_t N, int32_t F, int32_t C, int32_t H, int32_t W, int32_t cols, int32_t radius,
+                            const int32_t *halfwidth, const uint8_t *palette_bgr, const void *scratch,
+                            size_t scratch_bytes, void *stream)
 {
-    const RawSource rs{H0, W0, mapx, mapy, separable};
+    const RawSource rs{H0, W0, mapx, mapy, separable, band_src_rows, max_src_rows};
     return overlay_impl(raw, &rs, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch, scratch_bytes,
                         stream);
 }

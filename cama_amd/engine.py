@@ -329,8 +329,24 @@ class Engine:
             else:
                 mx = np.stack([m[0].reshape(-1) for m in maps])
                 my = np.stack([m[1].reshape(-1) for m in maps])
+            band_rows, max_rows = None, 0
+            if sep:
+                # source rows every band of R destination rows touches (same rounding as the kernel: 1/32 px)
+                H, H0 = int(cm_list[0].height), int(cm_list[0].height_origin)
+                R = self.lib.cama_overlay_band_rows(int(cm_list[0].width))
+                NB = (H + R - 1) // R
+                yy0 = np.rint(my.astype(np.float32) * np.float32(32)).astype(np.int64) >> 5      # [C,H]
+                if (np.diff(yy0, axis=1) >= 0).all():
+                    rows = np.zeros((len(cm_list), NB, 2), np.int32)
+                    for b in range(NB):
+                        lo = np.clip(yy0[:, b * R], 0, H0 - 1)
+                        hi = np.clip(yy0[:, min(H, b * R + R) - 1] + 1, 0, H0 - 1)
+                        rows[:, b, 0] = lo
+                        rows[:, b, 1] = hi - lo + 1
+                    band_rows = torch.from_numpy(rows).to(self.device)
+                    max_rows = int(rows[:, :, 1].max())
             hit = (key, torch.from_numpy(np.ascontiguousarray(mx)).to(self.device),
-                   torch.from_numpy(np.ascontiguousarray(my)).to(self.device), int(sep))
+                   torch.from_numpy(np.ascontiguousarray(my)).to(self.device), int(sep), band_rows, max_rows)
             self._rig_maps = hit
         return hit[1:]
 
@@ -350,7 +366,7 @@ class Engine:
             if out is None:
                 out = torch.empty(shape, dtype=torch.uint8, device=self.device)
             assert tuple(out.shape) == shape and out.is_contiguous()
-            mapx, mapy, sep = self.rig_maps(cm_list)
+            mapx, mapy, sep, band_rows, max_rows = self.rig_maps(cm_list)
             need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
             scratch = self._scratch_buf(need)
             x, y, z, col, key = dmap.render_ptrs()
@@ -359,7 +375,8 @@ class Engine:
                 x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
                 cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(), st))
             _lib.check(self.lib.cama_overlay_frames_raw(
-                raw.data_ptr(), H0, W0, mapx.data_ptr(), mapy.data_ptr(), sep, out.data_ptr(), dmap.N, F, rig.C,
+                raw.data_ptr(), H0, W0, mapx.data_ptr(), mapy.data_ptr(), sep,
+                None if band_rows is None else band_rows.data_ptr(), max_rows, out.data_ptr(), dmap.N, F, rig.C,
                 rig.H, rig.W, cols, self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data,
                 scratch.data_ptr(), scratch.numel(), st))
             return out
