@@ -739,8 +739,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 #ifndef RAWLDS_BLOCK
 #define RAWLDS_BLOCK 512            // LDS allows 2 workgroups per CU: 512 threads each = 16 waves to hide LDS taps
 #endif
-__global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, const int2 *__restrict__ band_rows,
-                                                                  int max_src_rows)
+__global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, const int2 *__restrict__ band_rows)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
@@ -805,7 +804,6 @@ __global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, 
         u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
         OVERLAY_STORE(v, drow + col);
     }
-    (void)max_src_rows;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1260,7 +1258,9 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     const size_t lds = align_up((size_t)L.R * W * 4, 16);
     hipStream_t s = (hipStream_t)stream;
     const char *base = (const char *)scratch;
+#ifdef OVERLAY_ORDER_FCB
     const int nfc = F * C;
+#endif
 
     OverlayArgs o{};
     o.src = src; o.mosaic = mosaic; o.C = C; o.H = H; o.W = W; o.cols = cols; o.R = L.R; o.NB = L.NB;
@@ -1316,7 +1316,7 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
             HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_rawlds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_raw));
         hipLaunchKernelGGL(k_overlay_rawlds, dim3(nblocks), dim3(RAWLDS_BLOCK), lds_raw, s, o,
-                           reinterpret_cast<const int2 *>(raw->band_rows), raw->max_src_rows);
+                           reinterpret_cast<const int2 *>(raw->band_rows));
     } else if (raw)
         hipLaunchKernelGGL((k_overlay<true, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
     else if (vec)

@@ -324,3 +324,37 @@ def test_spatially_sorted_map_renders_identically(engine):
     vu, vis, _ = (t.cpu().numpy() for t in engine.project_frames(auto, rig, w2c))
     flat = O.frame_project_flat(xyz, w2c[0], cams, W, H)
     assert np.array_equal(vis[0], flat["vis"])
+
+
+@pytest.mark.parametrize("C", [1, 4, 9])
+def test_other_camera_counts(engine, C):
+    """Rigs that are not 2x3: one camera, a ragged last mosaic row (4 = 3 + 1), and more cameras than the bin
+    kernel ranks per round (9 > 8)."""
+    import torch
+    from cama_amd.synth import camera_to_chassis, K_NUSCENES_LIKE
+    W, H, N, F = 160, 96, 6000, 2
+    rng = np.random.default_rng(40 + C)
+    xyz, col, _, w2c = _random_scene(50 + C, N, F, W, H)
+    cams = []
+    for k in range(C):
+        T = np.linalg.inv(camera_to_chassis(360.0 * k / C + 7.0) @ _small_rot(rng))
+        K = np.array(K_NUSCENES_LIKE)
+        K[0] *= W / 1600.0
+        K[1] *= H / 900.0
+        cams.append({"name": f"cam{k}", "chassis2camera": T, "K": K, "W": W, "H": H})
+    rig = _rig(engine, cams)
+    dmap = engine.upload_map(xyz, col, spatial_sort=False)
+    src = rng.integers(0, 256, (F, C, H, W, 3), dtype=np.uint8)
+    out = engine.render_frames(dmap, rig, w2c, torch.from_numpy(src).cuda()).cpu().numpy()
+    rows = (C + 2) // 3
+    assert out.shape == (F, rows * H, 3 * W, 3)
+    drawn = 0
+    for f in range(F):
+        flat = O.frame_project_flat(xyz, w2c[f], cams, W, H)
+        want = O.frame_render_flat(src[f], flat["vu"], flat["vis"], col)
+        # cells of a ragged last row that hold no camera are never written by the kernel: compare camera cells only
+        for c in range(C):
+            r, q = divmod(c, 3)
+            assert np.array_equal(out[f, r * H:(r + 1) * H, q * W:(q + 1) * W], want[r * H:(r + 1) * H, q * W:(q + 1) * W])
+        drawn += int(flat["vis"].sum())
+    assert drawn > 500
