@@ -116,12 +116,14 @@ def cpu_baseline(cm, frames, clip, args, budget_s):
     host_frames = frames.cpu().numpy()
     stamps, poses = O.pose_track(clip, att, cm.configs, "cama")
     secs = O.sensor_seconds(att, cm.configs["camera_main"], sync=True)
-    done, t0 = 0, time.perf_counter()
+    done, t0, t_geom = 0, time.perf_counter(), 0.0
     while True:
         for idx in range(1, len(secs)):
+            g0 = time.perf_counter()
             w2c = O.frame_world2chassis(stamps, poses, secs[idx])
             cropped = O.crop_instances(O.transform_instances(static, w2c))
             maps_2d = O.project_all(cropped, cams)
+            t_geom += time.perf_counter() - g0
             imgs = {}
             for c, cam in enumerate(cams):
                 img = host_frames[idx, c].copy()                # stands in for imread+remap (frames are pre-decoded)
@@ -135,7 +137,9 @@ def cpu_baseline(cm, frames, clip, args, budget_s):
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{done} frames of the same scene ({W}x{H}, 6 cams) in {dt:.1f} s; oracle/cama_oracle.py "
-                      f"single thread; host has {os.cpu_count()} cores; frames pre-decoded in RAM (no JPEG/remap)"}
+                      f"single thread; host has {os.cpu_count()} cores; frames pre-decoded in RAM (no JPEG/remap); "
+                      f"numpy geometry stages alone (pose+transform+crop+project): {done / t_geom:.0f} frames/s",
+            "geometry_only_fps": done / t_geom}
 
 
 def pmc_traffic(config_key):
