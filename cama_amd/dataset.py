@@ -343,9 +343,15 @@ class ClipManager:
             fr = maps_2d_dict.frame
             eng = runtime.engine()
             rig = self._rig()
-            src = self.frame_source().batch([image_idx])
-            mosaic = eng.render_frames(self._static(fr.dataset).device(), rig, fr.world2chassis[None], src,
-                                       crop=self.mm.crop_box())
+            source = self.frame_source()
+            dmap = self._static(fr.dataset).device()
+            if getattr(source, "fused", False) and hasattr(source, "raw_batch"):
+                # raw sensor frames: undistort + resize happens inside the overlay kernel
+                mosaic = eng.render_frames_raw(dmap, rig, fr.world2chassis[None], source.raw_batch([image_idx]),
+                                               self.cm_list, crop=self.mm.crop_box())
+            else:
+                mosaic = eng.render_frames(dmap, rig, fr.world2chassis[None], source.batch([image_idx]),
+                                           crop=self.mm.crop_box())
             return RenderedFrame(rig.names, mosaic[0], rig.H, rig.W)
         # generic path: caller-supplied 2D instances, one image at a time like the reference
         out = {}

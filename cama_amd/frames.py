@@ -97,29 +97,69 @@ class DeviceFrameSource:
 
 
 class ClipFrameSource:
-    """Decode + (if needed) resample + upload the demo's per-camera frame files."""
+    """Decode + upload the demo's per-camera frame files (<clip>/<camera>/<timestamp>.jpg|.npy).
 
-    def __init__(self, cm_list, device):
+    Decode is the real bottleneck of the demo once the reprojection runs on the GPU (examples/demo_synthetic.py:
+    ~12 ms per 1600x900 JPEG on one host core, 96 % of a frame).  libjpeg releases the GIL, so the cameras of a frame
+    are decoded by a thread pool, and the next frame's files are prefetched while the current frame is consumed.
+    Raw frames go to the device as they are; undistort + resize happens inside the overlay kernel
+    (cama_overlay_frames_raw) when the output size differs from the sensor size."""
+
+    def __init__(self, cm_list, device, workers=None, prefetch=3):
         self.cm_list = cm_list
         self.device = device
+        self.fused = any(cm.needs_resample() for cm in cm_list)     # hand RAW frames to the fused overlay
+        self._pool = None
+        self._workers = workers or min(24, (os.cpu_count() or 4))
+        self._prefetch = prefetch
+        self._pending = {}                                            # image index -> list of futures
+
+    def _executor(self):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self._workers, thread_name_prefix="cama-decode")
+        return self._pool
+
+    def _submit(self, idx):
+        if idx not in self._pending:
+            ex = self._executor()
+            self._pending[idx] = [ex.submit(read_bgr, cm.get_image_path(idx, True)) for cm in self.cm_list]
+        return self._pending[idx]
+
+    def _n_frames(self):
+        return len(self.cm_list[0].dr.attribute["sync"][self.cm_list[0].camera_name])
+
+    def _decoded(self, image_indices):
+        """host uint8 array [F,C,H0,W0,3] of the requested frames (decoded in parallel, next frame prefetched)."""
+        idx = [int(i) for i in image_indices]
+        for i in idx:
+            self._submit(i)
+        for ahead in range(1, int(self._prefetch) + 1):              # keep the decode workers busy
+            if idx and idx[-1] + ahead < self._n_frames():
+                self._submit(idx[-1] + ahead)
+        frames = [np.stack([fut.result() for fut in self._pending.pop(i)]) for i in idx]
+        for stale in [k for k in self._pending if k < idx[0]]:       # never consumed (skipped frames)
+            for fut in self._pending.pop(stale):
+                fut.cancel()
+        return np.stack(frames)
+
+    def raw_batch(self, image_indices):
+        import torch
+        return torch.from_numpy(self._decoded(image_indices)).to(self.device)
 
     def batch(self, image_indices):
         import torch
+        raw = self.raw_batch(image_indices)
+        if not self.fused:
+            return raw
         from . import runtime
-        c0 = self.cm_list[0]
-        F, C = len(image_indices), len(self.cm_list)
-        out = torch.empty((F, C, c0.height, c0.width, 3), dtype=torch.uint8, device=self.device)
         eng = runtime.engine()
+        c0 = self.cm_list[0]
+        out = torch.empty((raw.shape[0], len(self.cm_list), c0.height, c0.width, 3), dtype=torch.uint8,
+                          device=self.device)
         for c, cm in enumerate(self.cm_list):
-            raw = [read_bgr(cm.get_image_path(idx, True)) for idx in image_indices]
-            if not cm.needs_resample():
-                for k, img in enumerate(raw):
-                    out[k, c].copy_(torch.from_numpy(np.ascontiguousarray(img)))
-            else:       # upload the raw frames of this camera, resample them on the device straight into `out`
-                stack = torch.from_numpy(np.ascontiguousarray(np.stack(raw))).to(self.device)
-                eng.resample(cm, stack, out=out[:, c])
+            eng.resample(cm, raw[:, c], out=out[:, c])
         return out
-
 
 class RawDeviceFrameSource:
     """Raw (sensor-size) frames resident in HBM [F_total, C, H0, W0, 3]; every batch is undistort+resized on the
