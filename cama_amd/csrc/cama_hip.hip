@@ -458,9 +458,10 @@ __device__ __forceinline__ uint32_t blend_taps(const Tap6 &t0, const Tap6 &t1, u
     const uint32_t tB1 = __builtin_amdgcn_udot4(t1.lo, wB, 0u, false);
     const uint32_t tG1 = __builtin_amdgcn_udot4(t1.hi, wGh, __builtin_amdgcn_udot4(t1.lo, wGl, 0u, false), false);
     const uint32_t tR1 = __builtin_amdgcn_udot4(t1.hi, wRh, __builtin_amdgcn_udot4(t1.lo, wRl, 0u, false), false);
-    const uint32_t vB = (wt * tB0 + wb * tB1 + 512u) >> 10;             // <= 255 by construction
-    const uint32_t vG = (wt * tG0 + wb * tG1 + 512u) >> 10;
-    const uint32_t vR = (wt * tR0 + wb * tR1 + 512u) >> 10;
+    // weights <= 32 and t <= 32*255: 24-bit multiply-adds (v_mad_u32_u24, full rate; v_mul_lo_u32 is quarter rate)
+    const uint32_t vB = (__umul24(wt, tB0) + __umul24(wb, tB1) + 512u) >> 10;   // <= 255 by construction
+    const uint32_t vG = (__umul24(wt, tG0) + __umul24(wb, tG1) + 512u) >> 10;
+    const uint32_t vR = (__umul24(wt, tR0) + __umul24(wb, tR1) + 512u) >> 10;
     return vB | (vG << 8) | (vR << 16);
 }
 
@@ -737,14 +738,23 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 // LDS read.  The gather variant (k_overlay<true,true>) spends ~40 VMEM instructions per 16 output bytes; this one
 // spends one per 16 INPUT bytes.  LDS: owner table R*W*4 + staged rows + the camera's mapx vector.
 #ifndef RAWLDS_BLOCK
-#define RAWLDS_BLOCK 512            // LDS allows 2 workgroups per CU: 512 threads each = 16 waves to hide LDS taps
+#define RAWLDS_BLOCK 256
 #endif
-__global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, const int2 *__restrict__ band_rows)
+// Raw-frame overlay, LDS-staged (separable maps = zero lens distortion, the nuScenes / CAMA calibration).
+// One workgroup per (frame, camera, band of R destination rows, column tile of Wt destination columns): the source
+// rows x source byte range that tile needs (host-precomputed per camera/band and per camera/tile) are streamed into
+// LDS once with 16-byte loads -- the only global reads of image data -- and every bilinear tap is an aligned LDS dword
+// read.  The gather variant (k_overlay<true,true>) spends ~40 VMEM instructions per 16 output bytes; this one spends
+// one per 16 INPUT bytes.  Column tiles keep a workgroup's LDS near 20 KB (7 workgroups per CU) instead of 62 KB.
+// LDS: owner table R*Wt*4 | per-column packed taps Wt*4 | staged source rows.
+__global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, const int2 *__restrict__ band_rows,
+                                                                 const int2 *__restrict__ tile_bytes, int TX, int Wt)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
     const uint32_t camrows = (C + cols - 1) / cols;
     uint32_t t = blockIdx.x;
+    const uint32_t tx = t % (uint32_t)TX; t /= (uint32_t)TX;
     const uint32_t cc = t % cols; t /= cols;
     const uint32_t b = t % NB;    t /= NB;
     const uint32_t cr = t % camrows;
@@ -755,38 +765,60 @@ __global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, 
     const uint32_t bin = fc * NB + b;
     const int y0 = (int)b * a.R;
     const int nrows = min(a.R, a.H - y0);
-    const int W = a.W, W0 = a.W0;
+    const int W0 = a.W0, x_first = (int)tx * Wt;
     const uint32_t n = a.counts[bin];
     const size_t row_bytes = (size_t)W0 * 3;
 
-    uint32_t *s_owner = s_dyn;                                               // [R*W]
-    uint32_t *s_col = s_dyn + (((size_t)a.R * W + 3) & ~(size_t)3);         // [W] pack_column() of every column
-    uint8_t *s_src = static_cast<uint8_t *>(__builtin_assume_aligned(        // 16-byte aligned
-        reinterpret_cast<uint8_t *>(s_col + ((W + 3) & ~3)), 16));           // [max_src_rows * row_bytes + 16]
+    const int2 br = band_rows[c * NB + b];          // first source row, number of source rows
+    const int2 tb = tile_bytes[c * TX + tx];        // first source byte within a row (16-aligned), bytes (x16)
+    const uint32_t stride = (uint32_t)tb.y;         // LDS row stride
 
-    // stage: source rows of this band (contiguous in the raw frame) + the camera's column map
-    const int2 br = band_rows[c * NB + b];
-    const uint32_t nchunk_src = (uint32_t)((size_t)br.y * row_bytes >> 4);
-    const u32x4 *g = reinterpret_cast<const u32x4 *>(a.src + (size_t)fc * a.H0 * row_bytes + (size_t)br.x * row_bytes);
-    for (uint32_t i = threadIdx.x; i < nchunk_src; i += RAWLDS_BLOCK)
-        reinterpret_cast<u32x4 *>(s_src)[i] = OVERLAY_LOAD(g + i);
+    uint32_t *s_owner = s_dyn;                                               // [R*Wt]
+    uint32_t *s_col = s_dyn + (((size_t)a.R * Wt + 3) & ~(size_t)3);        // [Wt] pack_column(), offsets tile-relative
+    uint8_t *s_src = static_cast<uint8_t *>(__builtin_assume_aligned(        // [rows * stride + 16]
+        reinterpret_cast<uint8_t *>(s_col + ((Wt + 3) & ~3)), 16));
+
+    // stage the tile's source bytes row by row + this tile's column taps
+    const uint8_t *g0 = a.src + (size_t)fc * a.H0 * row_bytes + (size_t)br.x * row_bytes + (size_t)tb.x;
+    const uint32_t cpr_src = stride >> 4, nchunk_src = (uint32_t)br.y * cpr_src;
+    for (uint32_t i = threadIdx.x; i < nchunk_src; i += RAWLDS_BLOCK) {
+        const uint32_t r = i / cpr_src, j = i - r * cpr_src;
+        reinterpret_cast<u32x4 *>(s_src + (size_t)r * stride)[j] =
+            OVERLAY_LOAD(reinterpret_cast<const u32x4 *>(g0 + (size_t)r * row_bytes) + j);
+    }
     const float *mxc = a.mapx + (size_t)c * a.mapx_cam, *myc = a.mapy + (size_t)c * a.mapy_cam;
-    for (int x = threadIdx.x; x < W; x += RAWLDS_BLOCK) s_col[x] = pack_column(mxc[x], W0);
+    for (int x = threadIdx.x; x < Wt; x += RAWLDS_BLOCK) s_col[x] = pack_column(mxc[x_first + x], W0) - (uint32_t)tb.x;
     if (n) {
         uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
-        const int n4 = (nrows * W + 3) >> 2;
+        const int n4 = (nrows * Wt + 3) >> 2;
         for (int j = threadIdx.x; j < n4; j += RAWLDS_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
         __syncthreads();
-        rasterise_stamps<RAWLDS_BLOCK>(s_owner, a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]), n, y0, nrows, W, a.disc);
+        // the band's stamps, clipped to this tile's columns
+        const uint2 *st = a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]);
+        for (uint32_t s = threadIdx.x; s < n; s += RAWLDS_BLOCK) {
+            const uint2 rec = st[s];
+            const int u = (int)(rec.x & 0xffffu), v = (int)(rec.x >> 16);
+            const uint32_t val = rec.y + 1u;
+            const int ylo = max(v - a.disc.radius, y0), yhi = min(v + a.disc.radius, y0 + nrows - 1);
+            for (int y = ylo; y <= yhi; ++y) {
+                const int hw = a.disc.hw[abs(y - v)];
+                if (hw < 0) continue;
+                const int xlo = max(max(u - hw, 0), x_first), xhi = min(min(u + hw, a.W - 1), x_first + Wt - 1);
+                uint32_t *orow = s_owner + (y - y0) * Wt - x_first;
+                for (int x = xlo; x <= xhi; ++x) atomicMax(&orow[x], val);
+            }
+        }
     }
     __syncthreads();
 
     uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
-                     ((size_t)(c / cols) * a.H + y0) * a.mosaic_row_bytes + (size_t)(c % cols) * W * 3;
-    const uint32_t nchunks = (uint32_t)nrows * a.cpr;
+                     ((size_t)(c / cols) * a.H + y0) * a.mosaic_row_bytes + (size_t)(c % cols) * a.W * 3 +
+                     (size_t)x_first * 3;
+    const uint32_t cpr_t = (uint32_t)(Wt * 3) >> 4;             // 16-byte chunks per tile row
+    const uint32_t nchunks = (uint32_t)nrows * cpr_t;
     const int ylast = br.x + br.y - 1;
     for (uint32_t idx = threadIdx.x; idx < nchunks; idx += RAWLDS_BLOCK) {
-        const uint32_t row = __umulhi(idx, a.cpr_magic), col = idx - row * a.cpr;
+        const uint32_t row = idx / cpr_t, col = idx - row * cpr_t;
         const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
         // vertical part of the remap: once per chunk (all six pixels share the destination row)
         const int sy = __float2int_rn(myc[y0 + (int)row] * 32.0f);
@@ -794,13 +826,13 @@ __global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, 
         const uint32_t bw = (uint32_t)(sy & 31);
         const uint32_t wt = ((unsigned)yy0 < (unsigned)a.H0) ? 32u - bw : 0u;
         const uint32_t wb = ((unsigned)(yy0 + 1) < (unsigned)a.H0) ? bw : 0u;
-        const uint8_t *row0 = s_src + (size_t)(min(max(yy0, br.x), ylast) - br.x) * row_bytes;
-        const uint8_t *row1 = s_src + (size_t)(min(max(yy0 + 1, br.x), ylast) - br.x) * row_bytes;
+        const uint8_t *row0 = s_src + __umul24((uint32_t)(min(max(yy0, br.x), ylast) - br.x), stride);
+        const uint8_t *row1 = s_src + __umul24((uint32_t)(min(max(yy0 + 1, br.x), ylast) - br.x), stride);
         uint32_t px[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) px[k] = remap_pixel_lds(row0, row1, s_col[p0 + k], wt, wb);
         u32x4 v = chunk_from_pixels(px, ph);
-        if (n) patch_chunk(v, s_owner + row * W, col, a.pal);
+        if (n) patch_chunk(v, s_owner + row * Wt, col, a.pal);
         u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
         OVERLAY_STORE(v, drow + col);
     }
@@ -1242,7 +1274,15 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     return CAMA_OK;
 }
 
-struct RawSource { int H0, W0; const float *mapx, *mapy; int separable; const int32_t *band_rows; int max_src_rows; };
+struct RawSource {
+    int H0, W0;
+    const float *mapx, *mapy;
+    int separable;
+    const int32_t *band_rows;   // [C,NB,2] or NULL
+    int max_src_rows;
+    const int32_t *tile_bytes;  // [C,TX,2] or NULL
+    int tiles_x, max_tile_bytes;
+};
 
 static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosaic, int64_t N, int32_t F, int32_t C,
                         int32_t H, int32_t W, int32_t cols, int32_t radius, const int32_t *halfwidth,
@@ -1305,18 +1345,22 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     // 16-byte multiples and the staging buffer fits; else the gather variant
     size_t lds_raw = 0;
     bool raw_lds = false;
-    if (raw && raw->separable && raw->band_rows && raw->max_src_rows > 0 && ((size_t)raw->W0 * 3) % 16 == 0 &&
-        ((uintptr_t)src % 16 == 0)) {
-        lds_raw = (((size_t)L.R * W + 3) & ~(size_t)3) * 4 + (((size_t)W + 3) & ~(size_t)3) * 4 +
-                  (size_t)raw->max_src_rows * raw->W0 * 3 + 16;
+    int Wt = 0;
+    if (raw && raw->separable && raw->band_rows && raw->tile_bytes && raw->max_src_rows > 0 && raw->tiles_x >= 1 &&
+        W % raw->tiles_x == 0 && (W / raw->tiles_x) % 16 == 0 && raw->max_tile_bytes % 16 == 0 &&
+        ((size_t)raw->W0 * 3) % 16 == 0 && ((uintptr_t)src % 16 == 0)) {
+        Wt = W / raw->tiles_x;
+        lds_raw = (((size_t)L.R * Wt + 3) & ~(size_t)3) * 4 + (((size_t)Wt + 3) & ~(size_t)3) * 4 +
+                  (size_t)raw->max_src_rows * raw->max_tile_bytes + 16;
         raw_lds = lds_raw <= 160 * 1024;
     }
     if (raw_lds) {
         if (lds_raw > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_rawlds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_raw));
-        hipLaunchKernelGGL(k_overlay_rawlds, dim3(nblocks), dim3(RAWLDS_BLOCK), lds_raw, s, o,
-                           reinterpret_cast<const int2 *>(raw->band_rows));
+        hipLaunchKernelGGL(k_overlay_rawlds, dim3(nblocks * (unsigned)raw->tiles_x), dim3(RAWLDS_BLOCK), lds_raw, s, o,
+                           reinterpret_cast<const int2 *>(raw->band_rows),
+                           reinterpret_cast<const int2 *>(raw->tile_bytes), raw->tiles_x, Wt);
     } else if (raw)
         hipLaunchKernelGGL((k_overlay<true, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
     else if (vec)
@@ -1340,12 +1384,13 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
 }
 
 int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const float *mapx, const float *mapy,
-                            int32_t separable, const int32_t *band_src_rows, int32_t max_src_rows, uint8_t *mosaic,
+                            int32_t separable, const int32_t *band_src_rows, int32_t max_src_rows,
+                            const int32_t *tile_src_bytes, int32_t tiles_x, int32_t max_tile_bytes, uint8_t *mosaic,
                             int64_t N, int32_t F, int32_t C, int32_t H, int32_t W, int32_t cols, int32_t radius,
                             const int32_t *halfwidth, const uint8_t *palette_bgr, const void *scratch,
                             size_t scratch_bytes, void *stream)
 {
-    const RawSource rs{H0, W0, mapx, mapy, separable, band_src_rows, max_src_rows};
+    const RawSource rs{H0, W0, mapx, mapy, separable, band_src_rows, max_src_rows, tile_src_bytes, tiles_x, max_tile_bytes};
     return overlay_impl(raw, &rs, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch, scratch_bytes,
                         stream);
 }

@@ -329,7 +329,7 @@ class Engine:
             else:
                 mx = np.stack([m[0].reshape(-1) for m in maps])
                 my = np.stack([m[1].reshape(-1) for m in maps])
-            band_rows, max_rows = None, 0
+            band_rows, max_rows, tiles, tiles_x, max_tile = None, 0, None, 0, 0
             if sep:
                 # source rows every band of R destination rows touches (same rounding as the kernel: 1/32 px)
                 H, H0 = int(cm_list[0].height), int(cm_list[0].height_origin)
@@ -345,8 +345,26 @@ class Engine:
                         rows[:, b, 1] = hi - lo + 1
                     band_rows = torch.from_numpy(rows).to(self.device)
                     max_rows = int(rows[:, :, 1].max())
+                    # column tiles of ~256-384 destination pixels (a multiple of 16): source byte range of each
+                    Wd, W0 = int(cm_list[0].width), int(cm_list[0].width_origin)
+                    tiles_x = max([t for t in range(1, Wd // 16 + 1)
+                                   if Wd % t == 0 and (Wd // t) % 16 == 0 and Wd // t >= 256] or [1])
+                    Wt = Wd // tiles_x
+                    x0 = np.clip(np.rint(mx.astype(np.float32) * np.float32(32)).astype(np.int64) >> 5, 0, W0 - 1)  # [C,W]
+                    tb = np.zeros((len(cm_list), tiles_x, 2), np.int32)
+                    for t in range(tiles_x):
+                        off = x0[:, t * Wt:(t + 1) * Wt] * 3
+                        start = (off.min(axis=1) // 16) * 16
+                        end = np.minimum(((off.max(axis=1) // 4) * 4 + 12 + 15) // 16 * 16, W0 * 3)
+                        tb[:, t, 0] = start
+                        tb[:, t, 1] = end - start
+                    max_tile = int(tb[:, :, 1].max())
+                    tb[:, :, 1] = max_tile                      # one LDS row stride for every tile (clamped below)
+                    tb[:, :, 0] = np.minimum(tb[:, :, 0], W0 * 3 - max_tile)
+                    tiles = torch.from_numpy(tb).to(self.device)
             hit = (key, torch.from_numpy(np.ascontiguousarray(mx)).to(self.device),
-                   torch.from_numpy(np.ascontiguousarray(my)).to(self.device), int(sep), band_rows, max_rows)
+                   torch.from_numpy(np.ascontiguousarray(my)).to(self.device), int(sep), band_rows, max_rows,
+                   tiles, tiles_x, max_tile)
             self._rig_maps = hit
         return hit[1:]
 
@@ -366,7 +384,7 @@ class Engine:
             if out is None:
                 out = torch.empty(shape, dtype=torch.uint8, device=self.device)
             assert tuple(out.shape) == shape and out.is_contiguous()
-            mapx, mapy, sep, band_rows, max_rows = self.rig_maps(cm_list)
+            mapx, mapy, sep, band_rows, max_rows, tiles, tiles_x, max_tile = self.rig_maps(cm_list)
             need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
             scratch = self._scratch_buf(need)
             x, y, z, col, key = dmap.render_ptrs()
@@ -376,7 +394,8 @@ class Engine:
                 cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(), st))
             _lib.check(self.lib.cama_overlay_frames_raw(
                 raw.data_ptr(), H0, W0, mapx.data_ptr(), mapy.data_ptr(), sep,
-                None if band_rows is None else band_rows.data_ptr(), max_rows, out.data_ptr(), dmap.N, F, rig.C,
+                None if band_rows is None else band_rows.data_ptr(), max_rows,
+                None if tiles is None else tiles.data_ptr(), tiles_x, max_tile, out.data_ptr(), dmap.N, F, rig.C,
                 rig.H, rig.W, cols, self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data,
                 scratch.data_ptr(), scratch.numel(), st))
             return out

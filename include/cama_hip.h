@@ -159,11 +159,16 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
  *   H : H*W); separable as in cama_resample_frames.  Needs W % 16 == 0.  Other arguments as cama_overlay_frames.
  *   band_src_rows  NULL, or (separable maps only) device [C, NB, 2] int32 {first source row, number of source rows}
  *              that band b = rows [b*R, b*R+R) of camera c reads, R = cama_overlay_band_rows(W), NB = ceil(H/R),
- *              with max_src_rows their maximum: enables the LDS-staged variant (source rows streamed into LDS once
- *              with 16-byte loads, all taps from LDS) when W0*3 % 16 == 0 and the rows fit the 160 KB LDS
+ *              with max_src_rows their maximum, and
+ *   tile_src_bytes device [C, tiles_x, 2] int32 {first source byte within a row (16-aligned), byte count (x16)} that
+ *              column tile t = destination columns [t*W/tiles_x, (t+1)*W/tiles_x) of camera c reads (W/tiles_x a
+ *              multiple of 16), max_tile_bytes their maximum byte count: together they enable the LDS-staged variant
+ *              (each tile's source bytes streamed into LDS once with 16-byte loads, all taps from LDS) when
+ *              W0*3 % 16 == 0 and a tile fits the 160 KB LDS; otherwise the gather variant runs
  */
 int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const float *mapx, const float *mapy,
                             int32_t separable, const int32_t *band_src_rows, int32_t max_src_rows,
+                            const int32_t *tile_src_bytes, int32_t tiles_x, int32_t max_tile_bytes,
                             uint8_t *mosaic, int64_t N, int32_t F, int32_t C,
                             int32_t H, int32_t W, int32_t cols,
                             int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
