@@ -1251,7 +1251,12 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     a.band_shift = log2i(L.R); a.NB = L.NB; a.radius = radius;
     a.counts = counts; a.cursor = cursor; a.bin_off = bin_off; a.fc_base = fc_base;
     a.stamps = (uint2 *)(base + L.stamps);
-    const dim3 fgrid((unsigned)((N + BLOCK - 1) / BLOCK), (unsigned)F);
+    // XCD-aware mapping: workgroup (x, y) has linear id x + y * gridDim.x and runs on XCD id % 8.  With gridDim.x a
+    // multiple of 8, vertex chunk x is processed on the SAME XCD for every frame y, so on big maps each XCD's 4 MB L2
+    // keeps its 1/8 of the vertex buffer across all frames instead of re-fetching it per frame (padding workgroups
+    // exit at once: no vertex, no survivor).
+    const unsigned vblocks = (unsigned)((N + BLOCK - 1) / BLOCK);
+    const dim3 fgrid(getenv("CAMA_NO_XCD_PAD") ? vblocks : ((vblocks + 7u) & ~7u), (unsigned)F);
     const size_t hist_lds = align_up((size_t)C * L.NB * 4, 16);
     if (N) {
         if (xyz_is_f64)
