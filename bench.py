@@ -248,8 +248,8 @@ def main():
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %d scene(s) over %d GPU(s), 6 cams x %d frames, %d densified "
-                                   "verts, %dx%d, frames resident in HBM" % (2 if n_scenes > world else 1, n_scenes, world,
-                                                                           F, N, W, H),
+                                   "verts, %dx%d, frames resident in HBM" % (4 if args.map == "random" else 2 if n_scenes > world else 1,
+                                                                           n_scenes, world, F, N, W, H),
                        "scenes": n_scenes,
                        "frames_per_step": F, "verts": N, "width": W, "height": H, "map": args.map,
                        "sharding": "one scene per rank, no data-path collective",
