@@ -434,6 +434,7 @@ class Engine:
             if slot["buf"] is None or slot["buf"].numel() < need:
                 with torch.cuda.stream(s_bin):
                     slot["buf"] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+                slot["buf"].record_stream(s_ov)      # also read by the overlay stream: keep the allocator informed
             buf = slot["buf"]
             x, y, z, col, key = dmap.render_ptrs()
             _lib.check(self.lib.cama_bin_frames(
