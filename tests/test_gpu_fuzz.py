@@ -1,0 +1,90 @@
+"""Randomised differential test: fused render (C ABI) vs the C oracle over random rigs / sizes / radii / maps.
+CAMA_FUZZ_ITERS overrides the number of cases (default 40)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cama_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng):
+    from scipy.spatial.transform import Rotation
+    W = int(rng.choice([16, 48, 64, 100, 160, 272, 333, 640]))
+    H = int(rng.integers(9, 150))
+    C = int(rng.integers(1, 10))
+    F = int(rng.integers(1, 4))
+    N = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, 3000, 5000, 20000]))
+    radius = int(rng.choice([0, 1, 2, 2, 2, 3]))
+    f64 = bool(rng.random() < 0.3)
+    kind = rng.choice(["cloud", "line", "clump"])
+    if kind == "cloud":
+        xyz = rng.uniform([-40, -60, -1], [40, 60, 1], (N, 3))
+    elif kind == "line":
+        t = np.linspace(0, 1, N)[:, None]
+        xyz = np.array([2.0, -3.0, 0.0]) + t * np.array([45.0, 7.0, 0.2]) + rng.normal(0, 0.01, (N, 3))
+    else:
+        xyz = rng.normal([8.0, 0.0, 1.4], [0.3, 0.3, 0.2], (N, 3))
+    xyz = xyz.astype(np.float64 if f64 else np.float32)
+    col = (rng.random(N) < 0.5).astype(np.uint8)
+    cams = []
+    for k in range(C):
+        T = np.eye(4)
+        yaw = rng.normal(0, 0.15) if k == 0 else rng.uniform(-np.pi, np.pi)      # camera 0 looks down +x, at the map
+        T[:3, :3] = Rotation.from_euler("zyx", [yaw, rng.normal(0, 0.05), rng.normal(0, 0.05)]).as_matrix() @ \
+            np.array([[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]]).T
+        T[:3, 3] = rng.normal(0, 1.0, 3) + (np.array([0.0, 0.0, 1.5]) if k == 0 else 0.0)
+        K = np.array([[rng.uniform(0.4, 1.2) * W, 0.0, W / 2 + rng.normal(0, 3)],
+                      [0.0, rng.uniform(0.4, 1.2) * W, H / 2 + rng.normal(0, 3)], [0.0, 0.0, 1.0]])
+        r = rng.random()
+        if r < 0.2:
+            K[0, 1] = rng.normal(0, 2.0)                      # skew
+        elif r < 0.3:
+            K[2, 0], K[2, 1] = rng.normal(0, 1e-3, 2)          # projective last row: the general (non-pinhole) path
+        elif r < 0.35:
+            K[2, 2] = -1.0                                     # flipped depth sign
+        cams.append({"name": f"c{k}", "chassis2camera": np.linalg.inv(T), "K": K, "W": W, "H": H})
+    w2c = []
+    for f in range(F):
+        M = np.eye(4)
+        M[:3, :3] = Rotation.from_euler("z", rng.uniform(-0.2, 0.2)).as_matrix()
+        M[:3, 3] = rng.normal(0, 1.0, 3)
+        w2c.append(np.linalg.inv(M.astype(np.float32)))
+    crop = [-50, 50, -100, 100, -200, 200] if rng.random() < 0.6 else \
+        sorted(rng.uniform(-30, 30, 2).tolist()) + sorted(rng.uniform(-30, 30, 2).tolist()) + [-5.0, 5.0]
+    return dict(W=W, H=H, C=C, F=F, N=N, radius=radius, xyz=xyz, col=col, cams=cams, w2c=np.stack(w2c), crop=crop,
+                sort=bool(rng.random() < 0.3), kind=str(kind))
+
+
+def test_fuzz_against_oracle():
+    import torch
+    from cama_amd.engine import Engine
+    iters = int(os.environ.get("CAMA_FUZZ_ITERS", "40"))
+    rng = np.random.default_rng(int(os.environ.get("CAMA_FUZZ_SEED", "2024")))
+    engines = {}
+    for it in range(iters):
+        c = _case(rng)
+        e = engines.setdefault(c["radius"], Engine("cuda:0", radius=c["radius"]))
+        rig = e.make_rig([k["name"] for k in c["cams"]], [k["chassis2camera"] for k in c["cams"]],
+                         [k["K"] for k in c["cams"]], c["W"], c["H"])
+        dmap = e.upload_map(c["xyz"], c["col"], spatial_sort=True if c["sort"] else False)
+        src = rng.integers(0, 256, (c["F"], c["C"], c["H"], c["W"], 3), dtype=np.uint8)
+        band = e.lib.cama_overlay_band_rows(c["W"])
+        if 2 * c["radius"] > band:
+            continue
+        out = e.render_frames(dmap, rig, c["w2c"], torch.from_numpy(src).cuda(), crop=c["crop"]).cpu().numpy()
+        vu, vis, _ = (t.cpu().numpy() for t in e.project_frames(dmap, rig, c["w2c"], crop=c["crop"]))
+        tag = {k: c[k] for k in ("W", "H", "C", "F", "N", "radius", "sort", "kind")}
+        for f in range(c["F"]):
+            flat = O.frame_project_flat(np.ascontiguousarray(c["xyz"]), c["w2c"][f], c["cams"], c["W"], c["H"], crop=c["crop"])
+            assert np.array_equal(vis[f], flat["vis"]), (it, tag)
+            m = flat["vis"].astype(bool)
+            assert np.array_equal(vu[f][m], flat["vu"][m]), (it, tag)
+            want = O.frame_render_flat(src[f], flat["vu"], flat["vis"], c["col"], radius=c["radius"])
+            for cam in range(c["C"]):
+                r, q = divmod(cam, 3)
+                a = out[f, r * c["H"]:(r + 1) * c["H"], q * c["W"]:(q + 1) * c["W"]]
+                b = want[r * c["H"]:(r + 1) * c["H"], q * c["W"]:(q + 1) * c["W"]]
+                assert np.array_equal(a, b), (it, tag, cam, int((a != b).any(axis=-1).sum()))
