@@ -6,6 +6,8 @@ from os.path import abspath, dirname, exists, getmtime, join
 _HERE = dirname(abspath(__file__))
 REPO = dirname(_HERE)
 SOURCES = [join(_HERE, "csrc", "cama_hip.hip")]
+DEVICE_HEADERS = [join(_HERE, "csrc", n) for n in ("project_kernels.hpp", "remap_device.hpp", "overlay_kernels.hpp",
+                                                    "resample_kernels.hpp", "map_kernels.hpp")]
 HEADER = join(REPO, "include", "cama_hip.h")
 OUT = join(_HERE, "libcama_hip.so")
 # -ffp-contract=off: the fp64 FMA chains are written explicitly; nothing else may be fused
@@ -14,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 
 
 def build(force=False, verbose=False):
-    newest = max(getmtime(p) for p in SOURCES + [HEADER])
+    newest = max(getmtime(p) for p in SOURCES + DEVICE_HEADERS + [HEADER])
     if not force and exists(OUT) and getmtime(OUT) >= newest:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -91,907 +91,11 @@ struct Crop { double v[6]; };
 struct Disc { int radius; int hw[CAMA_MAX_RADIUS + 1]; };
 struct Palette { uint32_t c[2]; };  // b | g<<8 | r<<16
 
-// ------------------------------------------------------------------------------------------
-// fp64 k-ordered FMA chains (see header: arithmetic contract)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void affine3x4(const double *M, double x, double y, double z,
-                                          double &ox, double &oy, double &oz)
-{
-    double a;
-    a = M[0] * x; a = __builtin_fma(M[1], y, a); a = __builtin_fma(M[2], z, a);  a = __builtin_fma(M[3], 1.0, a);  ox = a;
-    a = M[4] * x; a = __builtin_fma(M[5], y, a); a = __builtin_fma(M[6], z, a);  a = __builtin_fma(M[7], 1.0, a);  oy = a;
-    a = M[8] * x; a = __builtin_fma(M[9], y, a); a = __builtin_fma(M[10], z, a); a = __builtin_fma(M[11], 1.0, a); oz = a;
-}
-
-__device__ __forceinline__ void linear3x3(const double *K, double x, double y, double z,
-                                          double &o0, double &o1, double &o2)
-{
-    double a;
-    a = K[0] * x; a = __builtin_fma(K[1], y, a); a = __builtin_fma(K[2], z, a); o0 = a;
-    a = K[3] * x; a = __builtin_fma(K[4], y, a); a = __builtin_fma(K[5], z, a); o1 = a;
-    a = K[6] * x; a = __builtin_fma(K[7], y, a); a = __builtin_fma(K[8], z, a); o2 = a;
-}
-
-__device__ __forceinline__ bool in_crop(const Crop &c, double x, double y, double z)
-{
-    return (x >= c.v[0]) & (x <= c.v[1]) & (y >= c.v[2]) & (y <= c.v[3]) & (z >= c.v[4]) & (z <= c.v[5]);
-}
-
-// reproject.py:191-198.  h = K @ p_cam.  Visible iff h2 > 0 (mask_z), h2/h2 > 0 (false only for
-// h2 = +inf, where the quotient is nan) and 0 <= u < W, 0 <= v < H on the IEEE quotients.
-__device__ __forceinline__ bool pinhole(double h0, double h1, double h2, double Wd, double Hd,
-                                        double &u, double &v)
-{
-    u = h0 / h2;
-    v = h1 / h2;
-    return (h2 > 0.0) & (h2 < __builtin_huge_val()) & (u >= 0.0) & (u < Wd) & (v >= 0.0) & (v < Hd);
-}
-
-// Bin-mode projection of one chassis-frame point into camera `m` (= 3x4 | 3x3): returns true and the packed
-// truncated pixel iff the reference's mask (reproject.py:192-198) is true.  Same FMA chains as pinhole(); the two
-// early-outs only skip work whose result is provably "not visible":
-//  (a) K's third row is (0,0,k) for every pinhole K; then h2 = fma(k, pz, +-0) = k*pz, so the sign test can run on
-//      the third affine row alone (5 fp64 ops instead of ~50 for the half-space behind the camera);
-//  (b) h0 < -h2 or h0 > (W+1)*h2 (same for h1/H) puts the IEEE quotient below 0 / at or above W even after
-//      rounding (one pixel of margin >> 1 ulp), so the two divisions (~28 fp64 ops) are skipped.
-__device__ __forceinline__ bool visible_pixel(const double *m, double cx, double cy, double cz, double Wd, double Hd,
-                                              uint32_t &uv)
-{
-    const double *K = m + 12;
-    double a;
-    a = m[8] * cx; a = __builtin_fma(m[9], cy, a); a = __builtin_fma(m[10], cz, a); a = __builtin_fma(m[11], 1.0, a);
-    const double pz = a;
-    const bool pinhole_row = (K[6] == 0.0) & (K[7] == 0.0);
-    if (pinhole_row && !(K[8] * pz > 0.0)) return false;
-    a = m[0] * cx; a = __builtin_fma(m[1], cy, a); a = __builtin_fma(m[2], cz, a); a = __builtin_fma(m[3], 1.0, a);
-    const double px = a;
-    a = m[4] * cx; a = __builtin_fma(m[5], cy, a); a = __builtin_fma(m[6], cz, a); a = __builtin_fma(m[7], 1.0, a);
-    const double py = a;
-    double h0, h1, h2;
-    linear3x3(K, px, py, pz, h0, h1, h2);
-    if (!(h2 > 0.0)) return false;
-    if ((h0 < -h2) | (h0 > (Wd + 1.0) * h2) | (h1 < -h2) | (h1 > (Hd + 1.0) * h2)) return false;
-    double u, v;
-    if (!pinhole(h0, h1, h2, Wd, Hd, u, v)) return false;
-    // reproject.py:249: astype(np.int32) truncation (values are >= 0 here)
-    uv = (uint32_t)(int)u | ((uint32_t)(int)v << 16);
-    return true;
-}
-
-// stage [C] x (3x4 chassis->camera | 3x3 K) into LDS
-__device__ __forceinline__ void stage_cameras(double *s_cam, const double *c2cam, const double *K, int C)
-{
-    for (int t = threadIdx.x; t < C * CAM_STRIDE; t += BLOCK) {
-        int c = t / CAM_STRIDE, k = t - c * CAM_STRIDE;
-        s_cam[t] = (k < 12) ? c2cam[c * 16 + k] : K[c * 9 + (k - 12)];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// API kernels (materialise coordinates)
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_transform_points(const T *__restrict__ xyz, int64_t N,
-                                                            const double *__restrict__ Tm, Crop crop,
-                                                            int has_crop, double *__restrict__ out,
-                                                            uint8_t *__restrict__ mask)
-{
-    __shared__ double s_m[12];
-    const int f = blockIdx.y;
-    if (threadIdx.x < 12) s_m[threadIdx.x] = Tm[(size_t)f * 16 + threadIdx.x];
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= N) return;
-    const double x = (double)xyz[3 * i], y = (double)xyz[3 * i + 1], z = (double)xyz[3 * i + 2];
-    double ox, oy, oz;
-    affine3x4(s_m, x, y, z, ox, oy, oz);
-    if (out) {
-        double *o = out + ((size_t)f * N + i) * 3;
-        o[0] = ox; o[1] = oy; o[2] = oz;
-    }
-    if (mask) mask[(size_t)f * N + i] = has_crop ? (uint8_t)in_crop(crop, ox, oy, oz) : (uint8_t)1;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_crop_points(const double *__restrict__ pts, int64_t n, Crop crop,
-                                                       uint8_t *__restrict__ mask)
-{
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) mask[i] = (uint8_t)in_crop(crop, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_project_points(const double *__restrict__ pts, int64_t n,
-                                                          const double *__restrict__ c2cam,
-                                                          const double *__restrict__ K, int C, int W, int H,
-                                                          double *__restrict__ vu, uint8_t *__restrict__ vis)
-{
-    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
-    stage_cameras(s_cam, c2cam, K, C);
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-    const double Wd = (double)W, Hd = (double)H;
-    for (int c = 0; c < C; ++c) {
-        const double *m = s_cam + c * CAM_STRIDE;
-        double px, py, pz, h0, h1, h2, u, v;
-        affine3x4(m, x, y, z, px, py, pz);
-        linear3x3(m + 12, px, py, pz, h0, h1, h2);
-        const bool ok = pinhole(h0, h1, h2, Wd, Hd, u, v);
-        reinterpret_cast<double2 *>(vu)[(size_t)c * n + i] = make_double2(v, u);
-        vis[(size_t)c * n + i] = (uint8_t)ok;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// fused per-frame kernel
-// ------------------------------------------------------------------------------------------
-enum { MODE_EMIT = 0, MODE_COUNT = 1, MODE_FILL = 2 };
-
-struct FrameArgs {
-    const void *x, *y, *z;  // [N] each, float or double (template parameter T)
-    const uint8_t *colour;
-    const uint32_t *key;    // optional [N]: draw index << 1 | colour (maps stored in a different order than drawn)
-    int64_t N;
-    const double *w2c, *c2cam, *K;
-    int C, W, H;
-    Crop crop;
-    // MODE_EMIT
-    double *vu;
-    uint8_t *vis, *crop_mask;
-    // MODE_COUNT / MODE_FILL
-    int band_shift, NB, radius;
-    uint32_t *counts, *cursor;
-    const uint32_t *bin_off, *fc_base;
-    uint2 *stamps;
-};
-
-// Emit mode: materialise (v,u) + visibility for every (frame, camera, vertex).
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_frames_emit(FrameArgs a)
-{
-    __shared__ double s_w2c[12];
-    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
-    const int f = blockIdx.y;
-    if (threadIdx.x < 12) s_w2c[threadIdx.x] = a.w2c[(size_t)f * 16 + threadIdx.x];
-    stage_cameras(s_cam, a.c2cam, a.K, a.C);
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.N) return;
-    const double x = (double)static_cast<const T *>(a.x)[i], y = (double)static_cast<const T *>(a.y)[i],
-                 z = (double)static_cast<const T *>(a.z)[i];
-    double cx, cy, cz;
-    affine3x4(s_w2c, x, y, z, cx, cy, cz);
-    const bool in = in_crop(a.crop, cx, cy, cz);
-    if (a.crop_mask) a.crop_mask[(size_t)f * a.N + i] = (uint8_t)in;
-    const double Wd = (double)a.W, Hd = (double)a.H;
-    for (int c = 0; c < a.C; ++c) {
-        const size_t at = ((size_t)f * a.C + c) * a.N + i;
-        bool ok = false;
-        if (in) {
-            const double *m = s_cam + c * CAM_STRIDE;
-            double px, py, pz, h0, h1, h2, u, v;
-            affine3x4(m, cx, cy, cz, px, py, pz);
-            linear3x3(m + 12, px, py, pz, h0, h1, h2);
-            ok = pinhole(h0, h1, h2, Wd, Hd, u, v);
-            reinterpret_cast<double2 *>(a.vu)[at] = make_double2(v, u);
-        }
-        a.vis[at] = (uint8_t)ok;
-    }
-}
-
-// Bin mode.  Every visible (vertex, camera) pair is a "stamp" {u:16, v:16, key = draw index << 1 | colour}
-// that must reach the 1-2 row bands its disc touches.  Two passes (count -> scan -> fill) with identical
-// arithmetic.  All per-stamp atomics are LDS atomics on a per-workgroup histogram of this frame's
-// C x NB bins (ds_add_rtn gives the rank inside the workgroup); global memory sees one independent
-// atomic per non-empty bin per workgroup, so nothing serialises on HBM/L2 latency.
-constexpr int CAM_GROUP = 8;  // cameras ranked per pass through the workgroup protocol (register-resident entries)
-
-template <int MODE, typename T>
-__global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [C*NB] counts, then (fill) [C*NB] bases
-    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
-    const int f = blockIdx.y;
-    const int nloc = a.C * a.NB;
-    uint32_t *s_cnt = s_hist, *s_base = s_hist + nloc;
-
-    // world->chassis + crop FIRST, with the frame's matrix read through wave-uniform (scalar) loads: on site-sized
-    // maps ~95 % of the workgroups end here and never pay for staging the cameras or clearing the histogram
-    const double *w2c = a.w2c + (size_t)f * 16;
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    double cx = 0, cy = 0, cz = 0;
-    bool in = false;
-    uint32_t key = 0;
-    if (i < a.N) {
-        const double x = (double)static_cast<const T *>(a.x)[i], y = (double)static_cast<const T *>(a.y)[i],
-                     z = (double)static_cast<const T *>(a.z)[i];
-        affine3x4(w2c, x, y, z, cx, cy, cz);
-        in = in_crop(a.crop, cx, cy, cz);
-        // draw index << 1 | colour.  Spatially re-ordered maps carry it per vertex (a.key), otherwise it is the
-        // storage index itself
-        key = a.key ? a.key[i] : (((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1));
-    }
-    // whole workgroup outside the crop box (the common case on site-sized maps): done
-    if (!__syncthreads_or((int)in)) return;
-    stage_cameras(s_cam, a.c2cam, a.K, a.C);
-    for (int t = threadIdx.x; t < nloc; t += BLOCK) s_cnt[t] = 0u;
-    __syncthreads();
-
-    const double Wd = (double)a.W, Hd = (double)a.H;
-    const size_t gbin0 = (size_t)f * nloc;
-    for (int c0 = 0; c0 < a.C; c0 += CAM_GROUP) {
-        uint32_t e_uv[CAM_GROUP], e_slot[2 * CAM_GROUP];
-#pragma unroll
-        for (int j = 0; j < CAM_GROUP; ++j) {
-            const int c = c0 + j;
-            e_slot[2 * j] = e_slot[2 * j + 1] = 0xffffffffu;
-            e_uv[j] = 0;
-            // wave-uniform guard: the shuffle below must be executed by every lane
-            if (c < a.C) {
-                uint32_t uv = 0xffffffffu;      // packed truncated pixel, or "not visible"
-                if (in) {
-                    uint32_t packed;
-                    if (visible_pixel(s_cam + c * CAM_STRIDE, cx, cy, cz, Wd, Hd, packed)) uv = packed;
-                }
-                // A disc is invisible if a LATER point (higher draw index) stamps the very same pixel (same
-                // footprint).  The next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most
-                // far-range stamps collapse here, exactly, before they cost atomics, HBM or LDS conflicts.
-                const uint32_t uv_next = __shfl_down(uv, 1, 64);
-                const uint32_t key_next = __shfl_down(key, 1, 64);
-                const bool covered = (__lane_id() != 63u) && (uv_next == uv) && (key_next > key);
-                const bool keep = (uv != 0xffffffffu) && !covered;
-                if (keep) {
-                    const int vi = (int)(uv >> 16);
-                    const int b0 = max(vi - a.radius, 0) >> a.band_shift;
-                    const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;   // b1 <= b0 + 1 (host checks 2r <= R)
-                    const uint32_t l0 = (uint32_t)(c * a.NB + b0);
-                    if (MODE == MODE_COUNT) {
-                        atomicAdd(&s_cnt[l0], 1u);
-                        if (b1 != b0) atomicAdd(&s_cnt[l0 + 1], 1u);
-                    } else {
-                        e_uv[j] = uv;
-                        e_slot[2 * j] = (l0 << 8) | atomicAdd(&s_cnt[l0], 1u);
-                        if (b1 != b0) e_slot[2 * j + 1] = ((l0 + 1) << 8) | atomicAdd(&s_cnt[l0 + 1], 1u);
-                    }
-                }
-            }
-        }
-        if (MODE == MODE_FILL) {
-            __syncthreads();
-            const int cend = min(c0 + CAM_GROUP, a.C);
-            for (int t = c0 * a.NB + threadIdx.x; t < cend * a.NB; t += BLOCK) {
-                const uint32_t n = s_cnt[t];
-                uint32_t base = 0;
-                if (n) base = atomicAdd(&a.cursor[gbin0 + t], n) + a.bin_off[gbin0 + t] + a.fc_base[f * a.C + t / a.NB];
-                s_base[t] = base;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 2 * CAM_GROUP; ++j) {
-                if (e_slot[j] != 0xffffffffu)
-                    a.stamps[(size_t)s_base[e_slot[j] >> 8] + (e_slot[j] & 0xffu)] = make_uint2(e_uv[j >> 1], key);
-            }
-        }
-    }
-    if (MODE == MODE_COUNT) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < nloc; t += BLOCK) {
-            const uint32_t n = s_cnt[t];
-            if (n) atomicAdd(&a.counts[gbin0 + t], n);
-        }
-    }
-}
-
-// exclusive scan of each (frame,camera)'s band counters; one wave per (frame,camera)
-__global__ __launch_bounds__(64) void k_scan_bands(const uint32_t *__restrict__ counts,
-                                                   uint32_t *__restrict__ bin_off,
-                                                   uint32_t *__restrict__ fc_total, int NB)
-{
-    const int fc = blockIdx.x, lane = threadIdx.x;
-    uint32_t carry = 0;
-    for (int base = 0; base < NB; base += 64) {
-        const int b = base + lane;
-        const uint32_t v = b < NB ? counts[(size_t)fc * NB + b] : 0u;
-        uint32_t s = v;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(s, d, 64);
-            if (lane >= d) s += t;
-        }
-        if (b < NB) bin_off[(size_t)fc * NB + b] = carry + s - v;
-        carry += __shfl(s, 63, 64);
-    }
-    if (lane == 0) fc_total[fc] = carry;
-}
-
-// exclusive scan over the (frame,camera) totals; a single wave
-__global__ __launch_bounds__(64) void k_scan_totals(const uint32_t *__restrict__ fc_total,
-                                                    uint32_t *__restrict__ fc_base, int n)
-{
-    const int lane = threadIdx.x;
-    uint32_t carry = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int j = base + lane;
-        const uint32_t v = j < n ? fc_total[j] : 0u;
-        uint32_t s = v;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(s, d, 64);
-            if (lane >= d) s += t;
-        }
-        if (j < n) fc_base[j] = carry + s - v;
-        carry += __shfl(s, 63, 64);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) building blocks (reproject.py:238-239), shared by the stand-alone
-// resample kernel and by the overlay that reads raw sensor frames
-// ------------------------------------------------------------------------------------------
-struct Tap6 { uint32_t lo; uint32_t hi; };   // 6 useful bytes: pixel x0 (b,g,r) then pixel x0+1 (b,g,r)
-
-// two horizontally adjacent BGR pixels starting at byte offset `o` of a frame of `frame_bytes` bytes (any alignment),
-// always as two dword loads and without branches: a tap that would run past the end of the frame is read from
-// `frame_bytes - 8` and funnel-shifted into place (only the last two pixels of a frame ever need it)
-__device__ __forceinline__ Tap6 load_tap(const uint8_t *frame, size_t o, size_t frame_bytes)
-{
-    typedef uint32_t __attribute__((aligned(1))) u32u;
-    const size_t last = frame_bytes - 8;
-    const size_t at = o < last ? o : last;
-    const uint32_t sh = (uint32_t)(o - at) * 8u;                      // 0, or 8..40 bits at the very end
-    const uint64_t w = (uint64_t)*reinterpret_cast<const u32u *>(frame + at) |
-                       ((uint64_t)*reinterpret_cast<const u32u *>(frame + at + 4) << 32);
-    const uint64_t v = w >> sh;
-    Tap6 t;
-    t.lo = (uint32_t)v;
-    t.hi = (uint32_t)(v >> 32);
-    return t;
-}
-
-// Horizontal byte dot products + vertical blend of one pixel's 2x2 taps (see remap_pixel): t0 / t1 = six bytes
-// [b0 g0 r0 b1 | g1 r1] of the top / bottom source row, wl/wr and wt/wb = tap weights out of 32 (0 when masked).
-__device__ __forceinline__ uint32_t blend_taps(const Tap6 &t0, const Tap6 &t1, uint32_t wl, uint32_t wr, uint32_t wt,
-                                               uint32_t wb)
-{
-    // weights on byte lanes: lo = [b0 g0 r0 b1], hi = [g1 r1 . .]
-    const uint32_t wB = wl | (wr << 24), wGl = wl << 8, wGh = wr, wRl = wl << 16, wRh = wr << 8;
-    const uint32_t tB0 = __builtin_amdgcn_udot4(t0.lo, wB, 0u, false);
-    const uint32_t tG0 = __builtin_amdgcn_udot4(t0.hi, wGh, __builtin_amdgcn_udot4(t0.lo, wGl, 0u, false), false);
-    const uint32_t tR0 = __builtin_amdgcn_udot4(t0.hi, wRh, __builtin_amdgcn_udot4(t0.lo, wRl, 0u, false), false);
-    const uint32_t tB1 = __builtin_amdgcn_udot4(t1.lo, wB, 0u, false);
-    const uint32_t tG1 = __builtin_amdgcn_udot4(t1.hi, wGh, __builtin_amdgcn_udot4(t1.lo, wGl, 0u, false), false);
-    const uint32_t tR1 = __builtin_amdgcn_udot4(t1.hi, wRh, __builtin_amdgcn_udot4(t1.lo, wRl, 0u, false), false);
-    // weights <= 32 and t <= 32*255: 24-bit multiply-adds (v_mad_u32_u24, full rate; v_mul_lo_u32 is quarter rate)
-    const uint32_t vB = (__umul24(wt, tB0) + __umul24(wb, tB1) + 512u) >> 10;   // <= 255 by construction
-    const uint32_t vG = (__umul24(wt, tG0) + __umul24(wb, tG1) + 512u) >> 10;
-    const uint32_t vR = (__umul24(wt, tR0) + __umul24(wb, tR1) + 512u) >> 10;
-    return vB | (vG << 8) | (vR << 16);
-}
-
-// One destination pixel of cv2.remap's 8-bit INTER_LINEAR path: returns b | g<<8 | r<<16.
-// OpenCV: v = (w00 p00 + w01 p01 + w10 p10 + w11 p11 + 2^14) >> 15 with w00 = (32-a)(32-b)*32 etc.  That sum is
-// exactly 32*S with  t_r = (32-a) p_r0 + a p_r1 (per source row r),  S = (32-b) t_0 + b t_1,  so v = (S + 512) >> 10.
-// The horizontal step is a byte dot product: the six tap bytes [b0 g0 r0 b1 | g1 r1] against weights placed on the
-// matching byte lanes (v_dot4_u32_u8), no unpacking.  Taps in the constant border contribute 0 = weight 0.
-__device__ __forceinline__ uint32_t remap_pixel(const uint8_t *__restrict__ s, size_t frame_bytes, int H0, int W0,
-                                                float mx, float my)
-{
-    const int sx = __float2int_rn(mx * 32.0f), sy = __float2int_rn(my * 32.0f);   // cvRound: half to even
-    const int x0 = sx >> 5, y0 = sy >> 5;
-    const bool xin0 = (unsigned)x0 < (unsigned)W0, xin1 = (unsigned)(x0 + 1) < (unsigned)W0;
-    const bool yin0 = (unsigned)y0 < (unsigned)H0, yin1 = (unsigned)(y0 + 1) < (unsigned)H0;
-    // (all four taps in the constant border: every weight below is 0 and the result is 0 -- no branch needed)
-    const uint32_t a = (uint32_t)(sx & 31), b = (uint32_t)(sy & 31);
-    uint32_t wl = xin0 ? 32u - a : 0u, wr = xin1 ? a : 0u;              // left / right tap weights
-    const uint32_t wt = yin0 ? 32u - b : 0u, wb = yin1 ? b : 0u;        // top / bottom row weights
-    // clamp the addresses into the frame (masked taps have weight 0, whatever bytes are read)
-    const int xc = min(max(x0, 0), W0 - 1), y0c = min(max(y0, 0), H0 - 1), y1c = min(max(y0 + 1, 0), H0 - 1);
-    const size_t o0 = ((size_t)y0c * W0 + xc) * 3, o1 = ((size_t)y1c * W0 + xc) * 3;
-    const Tap6 t0 = load_tap(s, o0, frame_bytes), t1 = load_tap(s, o1, frame_bytes);
-    const bool left_border = x0 < 0;      // x0 == -1: the in-range (right) tap is the FIRST pixel that was loaded
-    wl = left_border ? wr : wl;
-    wr = left_border ? 0u : wr;
-    return blend_taps(t0, t1, wl, wr, wt, wb);
-}
-
-// Horizontal part of the remap of one destination COLUMN, packed: bits 0-15 source byte offset of the left tap
-// (clamped into the row), 16-21 left weight, 22-27 right weight (out of 32; 0 for taps in the constant border; for
-// x0 == -1 the in-range tap is the first loaded pixel, so the weights are swapped).  Depends only on mapx[x].
-__device__ __forceinline__ uint32_t pack_column(float mx, int W0)
-{
-    const int sx = __float2int_rn(mx * 32.0f);                          // cvRound: half to even
-    const int x0 = sx >> 5;
-    const uint32_t a = (uint32_t)(sx & 31);
-    const bool xin0 = (unsigned)x0 < (unsigned)W0, xin1 = (unsigned)(x0 + 1) < (unsigned)W0;
-    uint32_t wl = xin0 ? 32u - a : 0u, wr = xin1 ? a : 0u;
-    const bool left_border = x0 < 0;
-    wl = left_border ? wr : wl;
-    wr = left_border ? 0u : wr;
-    const uint32_t off = (uint32_t)min(max(x0, 0), W0 - 1) * 3u;
-    return off | (wl << 16) | (wr << 22);
-}
-
-// one destination pixel from source rows staged in LDS: row0 / row1 = the two staged rows (clamped into the staged
-// range; wt / wb are 0 when the row is outside the frame), col = pack_column() of the destination column.
-// 6 tap bytes per row at an arbitrary byte offset = three ALIGNED dword reads + funnel shifts (misaligned DS reads are
-// split by the hardware and were 3-4x slower); rows start 16-byte aligned and the buffer is padded.
-__device__ __forceinline__ uint32_t remap_pixel_lds(const uint8_t *row0, const uint8_t *row1, uint32_t col, uint32_t wt,
-                                                    uint32_t wb)
-{
-    const uint32_t off = col & 0xffffu, sh = off & 3u, wl = (col >> 16) & 63u, wr = col >> 22;
-    const uint32_t *q0 = reinterpret_cast<const uint32_t *>(row0 + (off & ~3u));
-    const uint32_t *q1 = reinterpret_cast<const uint32_t *>(row1 + (off & ~3u));
-    const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2], b0 = q1[0], b1 = q1[1], b2 = q1[2];
-    Tap6 t0, t1;
-    t0.lo = __builtin_amdgcn_alignbyte(a1, a0, sh); t0.hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
-    t1.lo = __builtin_amdgcn_alignbyte(b1, b0, sh); t1.hi = __builtin_amdgcn_alignbyte(b2, b1, sh);
-    return blend_taps(t0, t1, wl, wr, wt, wb);
-}
-
-
-// map addressing: value for destination (y, x) is map[y * row_stride + x * col_stride]; full 2-D maps use (W, 1),
-// separable ones (zero distortion: mapx = f(x), mapy = g(y)) use (0, 1) and (1, 0) on W- and H-long vectors
-struct MapStride { int xr, xc, yr, yc; uint32_t w_magic; };
-
-// ------------------------------------------------------------------------------------------
-// overlay: band copy + deterministic stamp resolution
-// ------------------------------------------------------------------------------------------
-struct OverlayArgs {
-    const uint8_t *src;
-    uint8_t *mosaic;
-    int C, H, W, cols, R, NB;
-    uint32_t cpr, cpr_magic;          // 16-byte chunks per row, ceil(2^32 / cpr)
-    size_t mosaic_row_bytes, mosaic_frame_bytes;
-    const uint32_t *counts, *bin_off, *fc_base;
-    const uint2 *stamps;
-    Disc disc;
-    Palette pal;
-    // RESAMPLE variant: src holds RAW frames [F,C,H0,W0,3]; each mosaic pixel is remapped from them on the fly
-    int H0, W0;
-    const float *mapx, *mapy;            // per camera: mapx + c * mapx_cam, mapy + c * mapy_cam
-    int64_t mapx_cam, mapy_cam;
-    MapStride ms;
-};
-
-template <int THREADS = OVERLAY_BLOCK>
-__device__ __forceinline__ void rasterise_stamps(uint32_t *s_owner, const uint2 *st, uint32_t n,
-                                                 int y0, int nrows, int W, const Disc &disc)
-{
-    for (uint32_t s = threadIdx.x; s < n; s += THREADS) {
-        const uint2 r = st[s];
-        const int u = (int)(r.x & 0xffffu), v = (int)(r.x >> 16);
-        const uint32_t val = r.y + 1u;  // 0 = no owner
-        const int ylo = max(v - disc.radius, y0), yhi = min(v + disc.radius, y0 + nrows - 1);
-        for (int y = ylo; y <= yhi; ++y) {
-            const int hw = disc.hw[abs(y - v)];
-            if (hw < 0) continue;
-            const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
-            uint32_t *row = s_owner + (y - y0) * W;
-            for (int x = xlo; x <= xhi; ++x) atomicMax(&row[x], val);
-        }
-    }
-}
-
-// Patch the 16 bytes of chunk `col` of one row with the colours of the owned pixels it overlaps.
-// A chunk starts at byte 16*col = 3*p0 + ph and overlaps exactly pixels p0..p0+5.
-__device__ __forceinline__ void patch_chunk(u32x4 &d, const uint32_t *orow, uint32_t col, const Palette &pal)
-{
-    const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
-    uint32_t o[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] = orow[p0 + k];
-    if ((o[0] | o[1] | o[2] | o[3] | o[4] | o[5]) == 0u) return;
-    uint32_t c[6], m[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        m[k] = o[k] ? 0x00ffffffu : 0u;
-        c[k] = o[k] ? pal.c[(o[k] - 1u) & 1u] : 0u;
-    }
-    // 18-byte little-endian streams (pixel k at bytes 3k..3k+2) as 5 dwords
-    const uint32_t V0 = c[0] | (c[1] << 24), V1 = (c[1] >> 8) | (c[2] << 16), V2 = (c[2] >> 16) | (c[3] << 8),
-                   V3 = c[4] | (c[5] << 24), V4 = c[5] >> 8;
-    const uint32_t M0 = m[0] | (m[1] << 24), M1 = (m[1] >> 8) | (m[2] << 16), M2 = (m[2] >> 16) | (m[3] << 8),
-                   M3 = m[4] | (m[5] << 24), M4 = m[5] >> 8;
-    // chunk byte j is stream byte j + ph: funnel-shift right by ph bytes
-    const uint32_t v0 = __builtin_amdgcn_alignbyte(V1, V0, ph), v1 = __builtin_amdgcn_alignbyte(V2, V1, ph),
-                   v2 = __builtin_amdgcn_alignbyte(V3, V2, ph), v3 = __builtin_amdgcn_alignbyte(V4, V3, ph);
-    const uint32_t m0 = __builtin_amdgcn_alignbyte(M1, M0, ph), m1 = __builtin_amdgcn_alignbyte(M2, M1, ph),
-                   m2 = __builtin_amdgcn_alignbyte(M3, M2, ph), m3 = __builtin_amdgcn_alignbyte(M4, M3, ph);
-    d.x = (d.x & ~m0) | (v0 & m0);
-    d.y = (d.y & ~m1) | (v1 & m1);
-    d.z = (d.z & ~m2) | (v2 & m2);
-    d.w = (d.w & ~m3) | (v3 & m3);
-}
-
-// 6 packed pixels (b | g<<8 | r<<16) that a 16-byte chunk starting `ph` bytes into the first one overlaps -> the chunk
-__device__ __forceinline__ u32x4 chunk_from_pixels(const uint32_t *c, uint32_t ph)
-{
-    const uint32_t V0 = c[0] | (c[1] << 24), V1 = (c[1] >> 8) | (c[2] << 16), V2 = (c[2] >> 16) | (c[3] << 8),
-                   V3 = c[4] | (c[5] << 24), V4 = c[5] >> 8;
-    u32x4 v;
-    v.x = __builtin_amdgcn_alignbyte(V1, V0, ph);
-    v.y = __builtin_amdgcn_alignbyte(V2, V1, ph);
-    v.z = __builtin_amdgcn_alignbyte(V3, V2, ph);
-    v.w = __builtin_amdgcn_alignbyte(V4, V3, ph);
-    return v;
-}
-
-template <bool VEC, bool RESAMPLE>
-__global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x W, used only by stamped bands
-#ifdef OVERLAY_ORDER_FCB
-    const uint32_t bin = blockIdx.x;
-    const uint32_t fc = bin / (uint32_t)a.NB, b = bin - fc * (uint32_t)a.NB;
-    const uint32_t f = fc / (uint32_t)a.C, c = fc - f * (uint32_t)a.C;
-#else
-    // Workgroup order (frame, mosaic row of cameras, band, camera column): the `cols` cameras that share a mosaic
-    // row-band are adjacent in launch order, so R full mosaic rows (R * cols*W*3 contiguous bytes) are written
-    // close together in time instead of one third at a time.
-    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
-    const uint32_t camrows = (C + cols - 1) / cols;
-    uint32_t t = blockIdx.x;
-    const uint32_t cc = t % cols; t /= cols;
-    const uint32_t b = t % NB;    t /= NB;
-    const uint32_t cr = t % camrows;
-    const uint32_t f = t / camrows;
-    const uint32_t c = cr * cols + cc;
-    if (c >= C) return;                                  // ragged last camera row
-    const uint32_t fc = f * C + c;
-    const uint32_t bin = fc * NB + b;
-#endif
-    const int y0 = (int)b * a.R;
-    const int nrows = min(a.R, a.H - y0);
-    const int W = a.W;
-    const uint32_t n = a.counts[bin];
-
-    if (n) {
-        uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
-        const int n4 = (nrows * W + 3) >> 2;
-        for (int j = threadIdx.x; j < n4; j += OVERLAY_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
-        rasterise_stamps(s_owner, a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]), n, y0, nrows, W, a.disc);
-        __syncthreads();
-    }
-
-    const uint8_t *sband = a.src + ((size_t)fc * a.H + y0) * (size_t)W * 3;      // (unused by RESAMPLE)
-    uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
-                     ((size_t)(c / (uint32_t)a.cols) * a.H + y0) * a.mosaic_row_bytes +
-                     (size_t)(c % (uint32_t)a.cols) * W * 3;
-
-    if (RESAMPLE) {
-        // The source is the raw sensor frame of (f, c): every destination pixel is the fixed-point bilinear blend of
-        // its 2x2 source taps (cv2.remap semantics), computed here instead of being read from a pre-resized frame.
-        // A 16-byte chunk overlaps 6 destination pixels; adjacent lanes own adjacent chunks, so their taps are
-        // adjacent in the raw frame.  Raw bytes are read once from HBM (re-reads hit L1/L2), resized frames never
-        // exist in memory.
-        const size_t raw_frame = (size_t)a.H0 * a.W0 * 3;
-        const uint8_t *raw = a.src + (size_t)fc * raw_frame;
-        const float *mxc = a.mapx + (size_t)c * a.mapx_cam, *myc = a.mapy + (size_t)c * a.mapy_cam;
-        const uint32_t nchunks = (uint32_t)nrows * a.cpr;
-        for (uint32_t idx = threadIdx.x; idx < nchunks; idx += OVERLAY_BLOCK) {
-            const uint32_t row = __umulhi(idx, a.cpr_magic), col = idx - row * a.cpr;
-            const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
-            const int y = y0 + (int)row;
-            float mx[6], my[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int x = (int)p0 + k;
-                mx[k] = mxc[y * a.ms.xr + x * a.ms.xc];
-                my[k] = myc[y * a.ms.yr + x * a.ms.yc];
-            }
-            uint32_t px[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) px[k] = remap_pixel(raw, raw_frame, a.H0, a.W0, mx[k], my[k]);
-            u32x4 v = chunk_from_pixels(px, ph);
-            if (n) patch_chunk(v, s_owner + row * W, col, a.pal);
-            u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
-            OVERLAY_STORE(v, drow + col);
-        }
-        return;
-    }
-
-    if (VEC) {
-        // the band is one contiguous byte range in src: chunk j of the band is src16[j]
-        constexpr int U = OVERLAY_UNROLL;
-        const u32x4 *s16 = reinterpret_cast<const u32x4 *>(sband);
-        const uint32_t nchunks = (uint32_t)nrows * a.cpr;
-        for (uint32_t base = threadIdx.x; base < nchunks; base += OVERLAY_BLOCK * U) {
-            u32x4 v[U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const uint32_t idx = base + j * OVERLAY_BLOCK;
-                if (idx < nchunks) v[j] = OVERLAY_LOAD(s16 + idx);
-            }
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const uint32_t idx = base + j * OVERLAY_BLOCK;
-                if (idx < nchunks) {
-                    const uint32_t row = __umulhi(idx, a.cpr_magic);
-                    const uint32_t col = idx - row * a.cpr;
-                    if (n) patch_chunk(v[j], s_owner + row * W, col, a.pal);
-                    u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
-                    OVERLAY_STORE(v[j], drow + col);
-                }
-            }
-        }
-    } else {
-        // generic width / alignment: one pixel per thread-iteration
-        const int npix = nrows * W;
-        for (int p = threadIdx.x; p < npix; p += OVERLAY_BLOCK) {
-            const int row = p / W, x = p - row * W;
-            const uint8_t *s = sband + (size_t)p * 3;
-            uint8_t b0 = s[0], b1 = s[1], b2 = s[2];
-            if (n) {
-                const uint32_t o = s_owner[p];
-                if (o) {
-                    const uint32_t col = a.pal.c[(o - 1u) & 1u];
-                    b0 = (uint8_t)col; b1 = (uint8_t)(col >> 8); b2 = (uint8_t)(col >> 16);
-                }
-            }
-            uint8_t *d = dcell + (size_t)row * a.mosaic_row_bytes + (size_t)x * 3;
-            d[0] = b0; d[1] = b1; d[2] = b2;
-        }
-    }
-}
-
-// Raw-frame overlay, LDS-staged (separable maps = zero lens distortion, the nuScenes / CAMA calibration):
-// the source rows a band of R destination rows needs (host-precomputed [first, count] per camera and band) are
-// streamed into LDS once with 16-byte loads -- the only global reads of image data -- and every bilinear tap is an
-// LDS read.  The gather variant (k_overlay<true,true>) spends ~40 VMEM instructions per 16 output bytes; this one
-// spends one per 16 INPUT bytes.  LDS: owner table R*W*4 + staged rows + the camera's mapx vector.
-#ifndef RAWLDS_BLOCK
-#define RAWLDS_BLOCK 256
-#endif
-// Raw-frame overlay, LDS-staged (separable maps = zero lens distortion, the nuScenes / CAMA calibration).
-// One workgroup per (frame, camera, band of R destination rows, column tile of Wt destination columns): the source
-// rows x source byte range that tile needs (host-precomputed per camera/band and per camera/tile) are streamed into
-// LDS once with 16-byte loads -- the only global reads of image data -- and every bilinear tap is an aligned LDS dword
-// read.  The gather variant (k_overlay<true,true>) spends ~40 VMEM instructions per 16 output bytes; this one spends
-// one per 16 INPUT bytes.  Column tiles keep a workgroup's LDS near 20 KB (7 workgroups per CU) instead of 62 KB.
-// LDS: owner table R*Wt*4 | per-column packed taps Wt*4 | staged source rows.
-__global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, const int2 *__restrict__ band_rows,
-                                                                 const int2 *__restrict__ tile_bytes, int TX, int Wt)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
-    const uint32_t camrows = (C + cols - 1) / cols;
-    uint32_t t = blockIdx.x;
-    const uint32_t tx = t % (uint32_t)TX; t /= (uint32_t)TX;
-    const uint32_t cc = t % cols; t /= cols;
-    const uint32_t b = t % NB;    t /= NB;
-    const uint32_t cr = t % camrows;
-    const uint32_t f = t / camrows;
-    const uint32_t c = cr * cols + cc;
-    if (c >= C) return;
-    const uint32_t fc = f * C + c;
-    const uint32_t bin = fc * NB + b;
-    const int y0 = (int)b * a.R;
-    const int nrows = min(a.R, a.H - y0);
-    const int W0 = a.W0, x_first = (int)tx * Wt;
-    const uint32_t n = a.counts[bin];
-    const size_t row_bytes = (size_t)W0 * 3;
-
-    const int2 br = band_rows[c * NB + b];          // first source row, number of source rows
-    const int2 tb = tile_bytes[c * TX + tx];        // first source byte within a row (16-aligned), bytes (x16)
-    const uint32_t stride = (uint32_t)tb.y;         // LDS row stride
-
-    uint32_t *s_owner = s_dyn;                                               // [R*Wt]
-    uint32_t *s_col = s_dyn + (((size_t)a.R * Wt + 3) & ~(size_t)3);        // [Wt] pack_column(), offsets tile-relative
-    uint8_t *s_src = static_cast<uint8_t *>(__builtin_assume_aligned(        // [rows * stride + 16]
-        reinterpret_cast<uint8_t *>(s_col + ((Wt + 3) & ~3)), 16));
-
-    // stage the tile's source bytes row by row + this tile's column taps
-    const uint8_t *g0 = a.src + (size_t)fc * a.H0 * row_bytes + (size_t)br.x * row_bytes + (size_t)tb.x;
-    const uint32_t cpr_src = stride >> 4, nchunk_src = (uint32_t)br.y * cpr_src;
-    for (uint32_t i = threadIdx.x; i < nchunk_src; i += RAWLDS_BLOCK) {
-        const uint32_t r = i / cpr_src, j = i - r * cpr_src;
-        reinterpret_cast<u32x4 *>(s_src + (size_t)r * stride)[j] =
-            OVERLAY_LOAD(reinterpret_cast<const u32x4 *>(g0 + (size_t)r * row_bytes) + j);
-    }
-    const float *mxc = a.mapx + (size_t)c * a.mapx_cam, *myc = a.mapy + (size_t)c * a.mapy_cam;
-    for (int x = threadIdx.x; x < Wt; x += RAWLDS_BLOCK) s_col[x] = pack_column(mxc[x_first + x], W0) - (uint32_t)tb.x;
-    if (n) {
-        uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
-        const int n4 = (nrows * Wt + 3) >> 2;
-        for (int j = threadIdx.x; j < n4; j += RAWLDS_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
-        // the band's stamps, clipped to this tile's columns
-        const uint2 *st = a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]);
-        for (uint32_t s = threadIdx.x; s < n; s += RAWLDS_BLOCK) {
-            const uint2 rec = st[s];
-            const int u = (int)(rec.x & 0xffffu), v = (int)(rec.x >> 16);
-            const uint32_t val = rec.y + 1u;
-            const int ylo = max(v - a.disc.radius, y0), yhi = min(v + a.disc.radius, y0 + nrows - 1);
-            for (int y = ylo; y <= yhi; ++y) {
-                const int hw = a.disc.hw[abs(y - v)];
-                if (hw < 0) continue;
-                const int xlo = max(max(u - hw, 0), x_first), xhi = min(min(u + hw, a.W - 1), x_first + Wt - 1);
-                uint32_t *orow = s_owner + (y - y0) * Wt - x_first;
-                for (int x = xlo; x <= xhi; ++x) atomicMax(&orow[x], val);
-            }
-        }
-    }
-    __syncthreads();
-
-    uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
-                     ((size_t)(c / cols) * a.H + y0) * a.mosaic_row_bytes + (size_t)(c % cols) * a.W * 3 +
-                     (size_t)x_first * 3;
-    const uint32_t cpr_t = (uint32_t)(Wt * 3) >> 4;             // 16-byte chunks per tile row
-    const uint32_t nchunks = (uint32_t)nrows * cpr_t;
-    const int ylast = br.x + br.y - 1;
-    for (uint32_t idx = threadIdx.x; idx < nchunks; idx += RAWLDS_BLOCK) {
-        const uint32_t row = idx / cpr_t, col = idx - row * cpr_t;
-        const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
-        // vertical part of the remap: once per chunk (all six pixels share the destination row)
-        const int sy = __float2int_rn(myc[y0 + (int)row] * 32.0f);
-        const int yy0 = sy >> 5;
-        const uint32_t bw = (uint32_t)(sy & 31);
-        const uint32_t wt = ((unsigned)yy0 < (unsigned)a.H0) ? 32u - bw : 0u;
-        const uint32_t wb = ((unsigned)(yy0 + 1) < (unsigned)a.H0) ? bw : 0u;
-        const uint8_t *row0 = s_src + __umul24((uint32_t)(min(max(yy0, br.x), ylast) - br.x), stride);
-        const uint8_t *row1 = s_src + __umul24((uint32_t)(min(max(yy0 + 1, br.x), ylast) - br.x), stride);
-        uint32_t px[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) px[k] = remap_pixel_lds(row0, row1, s_col[p0 + k], wt, wb);
-        u32x4 v = chunk_from_pixels(px, ph);
-        if (n) patch_chunk(v, s_owner + row * Wt, col, a.pal);
-        u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
-        OVERLAY_STORE(v, drow + col);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// generic single-image stamping (CameraManager.render_maps on caller-supplied points)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_stamp_global(const double *__restrict__ vu,
-                                                        const uint8_t *__restrict__ colour, int64_t n,
-                                                        uint32_t *__restrict__ owner, int H, int W, Disc disc)
-{
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    // reproject.py:249 astype(np.int32); cv2.circle clips to the image itself
-    const int v = (int)vu[2 * i], u = (int)vu[2 * i + 1];
-    const uint32_t val = ((((uint32_t)i) << 1) | (uint32_t)(colour[i] & 1)) + 1u;
-    for (int dy = -disc.radius; dy <= disc.radius; ++dy) {
-        const int y = v + dy;
-        if (y < 0 || y >= H) continue;
-        const int hw = disc.hw[abs(dy)];
-        if (hw < 0) continue;
-        const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
-        for (int x = xlo; x <= xhi; ++x) atomicMax(&owner[(size_t)y * W + x], val);
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_apply_owner(const uint32_t *__restrict__ owner,
-                                                       uint8_t *__restrict__ image, int64_t npix, Palette pal)
-{
-    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= npix) return;
-    const uint32_t o = owner[p];
-    if (!o) return;
-    const uint32_t col = pal.c[(o - 1u) & 1u];
-    image[3 * p] = (uint8_t)col;
-    image[3 * p + 1] = (uint8_t)(col >> 8);
-    image[3 * p + 2] = (uint8_t)(col >> 16);
-}
-
-// ------------------------------------------------------------------------------------------
-// frame resample: cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) over float32 maps (reproject.py:238-239)
-// OpenCV's 8-bit remap quantises coordinates to 1/32 px (INTER_BITS = 5) and blends with 15-bit fixed-point
-// weights; for bilinear the weights (32-a)(32-b)*32 ... are exact integers summing to 1 << 15.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_resample(const uint8_t *__restrict__ src, int64_t src_stride,
-                                                    uint8_t *__restrict__ dst, int64_t dst_stride, int H0, int W0,
-                                                    int H, int W, const float *__restrict__ mapx,
-                                                    const float *__restrict__ mapy, MapStride ms)
-{
-    const int p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= H * W) return;
-    const uint8_t *s = src + (size_t)blockIdx.y * src_stride;
-    uint8_t *d = dst + (size_t)blockIdx.y * dst_stride + (size_t)p * 3;
-    const int y = (int)__umulhi((uint32_t)p, ms.w_magic), x = p - y * W;
-    const uint32_t c = remap_pixel(s, (size_t)H0 * W0 * 3, H0, W0, mapx[y * ms.xr + x * ms.xc],
-                                   mapy[y * ms.yr + x * ms.yc]);
-    d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
-}
-
-// W % 16 == 0: thread <-> destination pixel for the gathers (adjacent lanes read adjacent source pixels, the map
-// loads are coalesced), PPT pixels per thread strided by the workgroup size so the dependent load chains
-// (map -> taps) of several pixels overlap; then the workgroup's bytes are transposed through LDS into aligned
-// 16-byte stores.  (One thread per 16 CONSECUTIVE pixels was tried: lanes 80 source bytes apart lose all
-// coalescing -- 4.7x slower; one pixel per thread is latency-bound at 8 workgroups/CU.)
-#ifndef RESAMPLE_PPT_N
-#define RESAMPLE_PPT_N 4
-#endif
-constexpr int RESAMPLE_PPT = RESAMPLE_PPT_N;
-
-__global__ __launch_bounds__(BLOCK) void k_resample16(const uint8_t *__restrict__ src, int64_t src_stride,
-                                                      uint8_t *__restrict__ dst, int64_t dst_stride, int H0, int W0,
-                                                      int H, int W, const float *__restrict__ mapx,
-                                                      const float *__restrict__ mapy, MapStride ms)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[BLOCK * RESAMPLE_PPT * 3];
-    const int npix = H * W;
-    const int first = blockIdx.x * (BLOCK * RESAMPLE_PPT);
-    const uint8_t *s = src + (size_t)blockIdx.y * src_stride;
-    float mx[RESAMPLE_PPT], my[RESAMPLE_PPT];
-#pragma unroll
-    for (int j = 0; j < RESAMPLE_PPT; ++j) {
-        const int p = min(first + j * BLOCK + (int)threadIdx.x, npix - 1);
-        const int y = (int)__umulhi((uint32_t)p, ms.w_magic), x = p - y * W;
-        mx[j] = mapx[y * ms.xr + x * ms.xc];
-        my[j] = mapy[y * ms.yr + x * ms.yc];
-    }
-#pragma unroll
-    for (int j = 0; j < RESAMPLE_PPT; ++j) {
-        const uint32_t c = remap_pixel(s, (size_t)H0 * W0 * 3, H0, W0, mx[j], my[j]);
-        uint8_t *o = s_out + 3 * (j * BLOCK + (int)threadIdx.x);
-        o[0] = (uint8_t)c; o[1] = (uint8_t)(c >> 8); o[2] = (uint8_t)(c >> 16);
-    }
-    __syncthreads();
-    // npix is a multiple of 16, so the tail workgroup ends on a chunk boundary
-    const int valid_chunks = (min(BLOCK * RESAMPLE_PPT, npix - first) * 3) >> 4;
-    u32x4 *d = reinterpret_cast<u32x4 *>(dst + (size_t)blockIdx.y * dst_stride + (size_t)first * 3);
-    for (int k = threadIdx.x; k < valid_chunks; k += BLOCK) d[k] = reinterpret_cast<const u32x4 *>(s_out)[k];
-}
-
-// ------------------------------------------------------------------------------------------
-// static-map build (per clip): densify labels, lift with the BEV height raster, pixel -> world
-// reproject.py:42-106.  One thread per OUTPUT point; float32 arithmetic in the reference's operation order
-// (compiled -ffp-contract=off; HIP's float division is correctly rounded), so the buffer is bit-identical to the
-// host build.  Writes the SoA vertex buffer + colour ids the fused render consumes: the map never visits the host.
-// ------------------------------------------------------------------------------------------
-struct MapBuildArgs {
-    const float *verts;        // [V,2] label vertices (float32, as np.array(data).astype(np.float32))
-    const int32_t *seg_v0;     // [S] first vertex of each non-empty segment (its end is v0 + 1)
-    const int32_t *seg_num;    // [S] points emitted by the segment = int(|seg| / solution) > 0
-    const int64_t *seg_off;    // [S+1] exclusive scan of seg_num
-    const uint8_t *seg_colour; // [S]
-    int32_t S;
-    int64_t N;
-    int32_t lift;              // 1: CAMA labels (BEV pixels + raster), 0: nuScenes labels (metres, z = 0)
-    const void *raster;        // [rows, cols] float32 / float64
-    int32_t rows, cols;
-    float solution, half_w, half_h, cx, cy;
-    void *x, *y, *z;           // [N] each, float32 or float64 (TZ)
-    uint8_t *colour;           // [N]
-};
-
-template <typename TZ>
-__global__ __launch_bounds__(BLOCK) void k_build_map(MapBuildArgs a)
-{
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.N) return;
-    // segment that owns output point i: last s with seg_off[s] <= i
-    int lo = 0, hi = a.S - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (a.seg_off[mid] <= i) lo = mid; else hi = mid - 1;
-    }
-    const int s = lo;
-    const float j = (float)(i - a.seg_off[s]);
-    const float num = (float)a.seg_num[s];
-    const float2 p0 = reinterpret_cast<const float2 *>(a.verts)[a.seg_v0[s]];
-    const float2 p1 = reinterpret_cast<const float2 *>(a.verts)[a.seg_v0[s] + 1];
-    // start + (end - start) / num * j      (reproject.py:62 / :92)
-    const float px = p0.x + ((p1.x - p0.x) / num) * j;
-    const float py = p0.y + ((p1.y - p0.y) / num) * j;
-    TZ ox, oy, oz;
-    if (a.lift) {
-        // round().astype(np.uint16)[:, ::-1].clip(0, rows-1): half-to-even, C cast through int32 (wraps), (row, col)
-        const int row = min(max((int)(uint16_t)(int32_t)rintf(py), 0), a.rows - 1);
-        const int col = min(max((int)(uint16_t)(int32_t)rintf(px), 0), a.rows - 1);
-        oz = static_cast<const TZ *>(a.raster)[(size_t)row * a.cols + col];
-        // world x from pixel y and vice versa (reproject.py:38-39), float32
-        ox = (TZ)(((py * a.solution) - a.half_w) + a.cx);
-        oy = (TZ)(((px * a.solution) - a.half_h) + a.cy);
-    } else {
-        ox = (TZ)px; oy = (TZ)py; oz = (TZ)0;
-    }
-    static_cast<TZ *>(a.x)[i] = ox;
-    static_cast<TZ *>(a.y)[i] = oy;
-    static_cast<TZ *>(a.z)[i] = oz;
-    a.colour[i] = a.seg_colour[s];
-}
+#include "project_kernels.hpp"
+#include "remap_device.hpp"
+#include "overlay_kernels.hpp"
+#include "resample_kernels.hpp"
+#include "map_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host helpers

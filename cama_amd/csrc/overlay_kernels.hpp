@@ -1,0 +1,347 @@
+// overlay_kernels.hpp -- part of libcama_hip.so (included by cama_hip.hip inside its anonymous namespace).
+// Overlay kernels: band copy + deterministic stamp resolution (plain, raw-frame gather, raw-frame LDS-staged)
+// and the generic single-image stamping.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// overlay: band copy + deterministic stamp resolution
+// ------------------------------------------------------------------------------------------
+struct OverlayArgs {
+    const uint8_t *src;
+    uint8_t *mosaic;
+    int C, H, W, cols, R, NB;
+    uint32_t cpr, cpr_magic;          // 16-byte chunks per row, ceil(2^32 / cpr)
+    size_t mosaic_row_bytes, mosaic_frame_bytes;
+    const uint32_t *counts, *bin_off, *fc_base;
+    const uint2 *stamps;
+    Disc disc;
+    Palette pal;
+    // RESAMPLE variant: src holds RAW frames [F,C,H0,W0,3]; each mosaic pixel is remapped from them on the fly
+    int H0, W0;
+    const float *mapx, *mapy;            // per camera: mapx + c * mapx_cam, mapy + c * mapy_cam
+    int64_t mapx_cam, mapy_cam;
+    MapStride ms;
+};
+
+template <int THREADS = OVERLAY_BLOCK>
+__device__ __forceinline__ void rasterise_stamps(uint32_t *s_owner, const uint2 *st, uint32_t n,
+                                                 int y0, int nrows, int W, const Disc &disc)
+{
+    for (uint32_t s = threadIdx.x; s < n; s += THREADS) {
+        const uint2 r = st[s];
+        const int u = (int)(r.x & 0xffffu), v = (int)(r.x >> 16);
+        const uint32_t val = r.y + 1u;  // 0 = no owner
+        const int ylo = max(v - disc.radius, y0), yhi = min(v + disc.radius, y0 + nrows - 1);
+        for (int y = ylo; y <= yhi; ++y) {
+            const int hw = disc.hw[abs(y - v)];
+            if (hw < 0) continue;
+            const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
+            uint32_t *row = s_owner + (y - y0) * W;
+            for (int x = xlo; x <= xhi; ++x) atomicMax(&row[x], val);
+        }
+    }
+}
+
+// Patch the 16 bytes of chunk `col` of one row with the colours of the owned pixels it overlaps.
+// A chunk starts at byte 16*col = 3*p0 + ph and overlaps exactly pixels p0..p0+5.
+__device__ __forceinline__ void patch_chunk(u32x4 &d, const uint32_t *orow, uint32_t col, const Palette &pal)
+{
+    const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
+    uint32_t o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = orow[p0 + k];
+    if ((o[0] | o[1] | o[2] | o[3] | o[4] | o[5]) == 0u) return;
+    uint32_t c[6], m[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        m[k] = o[k] ? 0x00ffffffu : 0u;
+        c[k] = o[k] ? pal.c[(o[k] - 1u) & 1u] : 0u;
+    }
+    // 18-byte little-endian streams (pixel k at bytes 3k..3k+2) as 5 dwords
+    const uint32_t V0 = c[0] | (c[1] << 24), V1 = (c[1] >> 8) | (c[2] << 16), V2 = (c[2] >> 16) | (c[3] << 8),
+                   V3 = c[4] | (c[5] << 24), V4 = c[5] >> 8;
+    const uint32_t M0 = m[0] | (m[1] << 24), M1 = (m[1] >> 8) | (m[2] << 16), M2 = (m[2] >> 16) | (m[3] << 8),
+                   M3 = m[4] | (m[5] << 24), M4 = m[5] >> 8;
+    // chunk byte j is stream byte j + ph: funnel-shift right by ph bytes
+    const uint32_t v0 = __builtin_amdgcn_alignbyte(V1, V0, ph), v1 = __builtin_amdgcn_alignbyte(V2, V1, ph),
+                   v2 = __builtin_amdgcn_alignbyte(V3, V2, ph), v3 = __builtin_amdgcn_alignbyte(V4, V3, ph);
+    const uint32_t m0 = __builtin_amdgcn_alignbyte(M1, M0, ph), m1 = __builtin_amdgcn_alignbyte(M2, M1, ph),
+                   m2 = __builtin_amdgcn_alignbyte(M3, M2, ph), m3 = __builtin_amdgcn_alignbyte(M4, M3, ph);
+    d.x = (d.x & ~m0) | (v0 & m0);
+    d.y = (d.y & ~m1) | (v1 & m1);
+    d.z = (d.z & ~m2) | (v2 & m2);
+    d.w = (d.w & ~m3) | (v3 & m3);
+}
+
+// 6 packed pixels (b | g<<8 | r<<16) that a 16-byte chunk starting `ph` bytes into the first one overlaps -> the chunk
+__device__ __forceinline__ u32x4 chunk_from_pixels(const uint32_t *c, uint32_t ph)
+{
+    const uint32_t V0 = c[0] | (c[1] << 24), V1 = (c[1] >> 8) | (c[2] << 16), V2 = (c[2] >> 16) | (c[3] << 8),
+                   V3 = c[4] | (c[5] << 24), V4 = c[5] >> 8;
+    u32x4 v;
+    v.x = __builtin_amdgcn_alignbyte(V1, V0, ph);
+    v.y = __builtin_amdgcn_alignbyte(V2, V1, ph);
+    v.z = __builtin_amdgcn_alignbyte(V3, V2, ph);
+    v.w = __builtin_amdgcn_alignbyte(V4, V3, ph);
+    return v;
+}
+
+template <bool VEC, bool RESAMPLE>
+__global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x W, used only by stamped bands
+#ifdef OVERLAY_ORDER_FCB
+    const uint32_t bin = blockIdx.x;
+    const uint32_t fc = bin / (uint32_t)a.NB, b = bin - fc * (uint32_t)a.NB;
+    const uint32_t f = fc / (uint32_t)a.C, c = fc - f * (uint32_t)a.C;
+#else
+    // Workgroup order (frame, mosaic row of cameras, band, camera column): the `cols` cameras that share a mosaic
+    // row-band are adjacent in launch order, so R full mosaic rows (R * cols*W*3 contiguous bytes) are written
+    // close together in time instead of one third at a time.
+    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
+    const uint32_t camrows = (C + cols - 1) / cols;
+    uint32_t t = blockIdx.x;
+    const uint32_t cc = t % cols; t /= cols;
+    const uint32_t b = t % NB;    t /= NB;
+    const uint32_t cr = t % camrows;
+    const uint32_t f = t / camrows;
+    const uint32_t c = cr * cols + cc;
+    if (c >= C) return;                                  // ragged last camera row
+    const uint32_t fc = f * C + c;
+    const uint32_t bin = fc * NB + b;
+#endif
+    const int y0 = (int)b * a.R;
+    const int nrows = min(a.R, a.H - y0);
+    const int W = a.W;
+    const uint32_t n = a.counts[bin];
+
+    if (n) {
+        uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
+        const int n4 = (nrows * W + 3) >> 2;
+        for (int j = threadIdx.x; j < n4; j += OVERLAY_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        rasterise_stamps(s_owner, a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]), n, y0, nrows, W, a.disc);
+        __syncthreads();
+    }
+
+    const uint8_t *sband = a.src + ((size_t)fc * a.H + y0) * (size_t)W * 3;      // (unused by RESAMPLE)
+    uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
+                     ((size_t)(c / (uint32_t)a.cols) * a.H + y0) * a.mosaic_row_bytes +
+                     (size_t)(c % (uint32_t)a.cols) * W * 3;
+
+    if (RESAMPLE) {
+        // The source is the raw sensor frame of (f, c): every destination pixel is the fixed-point bilinear blend of
+        // its 2x2 source taps (cv2.remap semantics), computed here instead of being read from a pre-resized frame.
+        // A 16-byte chunk overlaps 6 destination pixels; adjacent lanes own adjacent chunks, so their taps are
+        // adjacent in the raw frame.  Raw bytes are read once from HBM (re-reads hit L1/L2), resized frames never
+        // exist in memory.
+        const size_t raw_frame = (size_t)a.H0 * a.W0 * 3;
+        const uint8_t *raw = a.src + (size_t)fc * raw_frame;
+        const float *mxc = a.mapx + (size_t)c * a.mapx_cam, *myc = a.mapy + (size_t)c * a.mapy_cam;
+        const uint32_t nchunks = (uint32_t)nrows * a.cpr;
+        for (uint32_t idx = threadIdx.x; idx < nchunks; idx += OVERLAY_BLOCK) {
+            const uint32_t row = __umulhi(idx, a.cpr_magic), col = idx - row * a.cpr;
+            const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
+            const int y = y0 + (int)row;
+            float mx[6], my[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int x = (int)p0 + k;
+                mx[k] = mxc[y * a.ms.xr + x * a.ms.xc];
+                my[k] = myc[y * a.ms.yr + x * a.ms.yc];
+            }
+            uint32_t px[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) px[k] = remap_pixel(raw, raw_frame, a.H0, a.W0, mx[k], my[k]);
+            u32x4 v = chunk_from_pixels(px, ph);
+            if (n) patch_chunk(v, s_owner + row * W, col, a.pal);
+            u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
+            OVERLAY_STORE(v, drow + col);
+        }
+        return;
+    }
+
+    if (VEC) {
+        // the band is one contiguous byte range in src: chunk j of the band is src16[j]
+        constexpr int U = OVERLAY_UNROLL;
+        const u32x4 *s16 = reinterpret_cast<const u32x4 *>(sband);
+        const uint32_t nchunks = (uint32_t)nrows * a.cpr;
+        for (uint32_t base = threadIdx.x; base < nchunks; base += OVERLAY_BLOCK * U) {
+            u32x4 v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t idx = base + j * OVERLAY_BLOCK;
+                if (idx < nchunks) v[j] = OVERLAY_LOAD(s16 + idx);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t idx = base + j * OVERLAY_BLOCK;
+                if (idx < nchunks) {
+                    const uint32_t row = __umulhi(idx, a.cpr_magic);
+                    const uint32_t col = idx - row * a.cpr;
+                    if (n) patch_chunk(v[j], s_owner + row * W, col, a.pal);
+                    u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
+                    OVERLAY_STORE(v[j], drow + col);
+                }
+            }
+        }
+    } else {
+        // generic width / alignment: one pixel per thread-iteration
+        const int npix = nrows * W;
+        for (int p = threadIdx.x; p < npix; p += OVERLAY_BLOCK) {
+            const int row = p / W, x = p - row * W;
+            const uint8_t *s = sband + (size_t)p * 3;
+            uint8_t b0 = s[0], b1 = s[1], b2 = s[2];
+            if (n) {
+                const uint32_t o = s_owner[p];
+                if (o) {
+                    const uint32_t col = a.pal.c[(o - 1u) & 1u];
+                    b0 = (uint8_t)col; b1 = (uint8_t)(col >> 8); b2 = (uint8_t)(col >> 16);
+                }
+            }
+            uint8_t *d = dcell + (size_t)row * a.mosaic_row_bytes + (size_t)x * 3;
+            d[0] = b0; d[1] = b1; d[2] = b2;
+        }
+    }
+}
+
+// Raw-frame overlay, LDS-staged (separable maps = zero lens distortion, the nuScenes / CAMA calibration):
+// the source rows a band of R destination rows needs (host-precomputed [first, count] per camera and band) are
+// streamed into LDS once with 16-byte loads -- the only global reads of image data -- and every bilinear tap is an
+// LDS read.  The gather variant (k_overlay<true,true>) spends ~40 VMEM instructions per 16 output bytes; this one
+// spends one per 16 INPUT bytes.  LDS: owner table R*W*4 + staged rows + the camera's mapx vector.
+#ifndef RAWLDS_BLOCK
+#define RAWLDS_BLOCK 256
+#endif
+// Raw-frame overlay, LDS-staged (separable maps = zero lens distortion, the nuScenes / CAMA calibration).
+// One workgroup per (frame, camera, band of R destination rows, column tile of Wt destination columns): the source
+// rows x source byte range that tile needs (host-precomputed per camera/band and per camera/tile) are streamed into
+// LDS once with 16-byte loads -- the only global reads of image data -- and every bilinear tap is an aligned LDS dword
+// read.  The gather variant (k_overlay<true,true>) spends ~40 VMEM instructions per 16 output bytes; this one spends
+// one per 16 INPUT bytes.  Column tiles keep a workgroup's LDS near 20 KB (7 workgroups per CU) instead of 62 KB.
+// LDS: owner table R*Wt*4 | per-column packed taps Wt*4 | staged source rows.
+__global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, const int2 *__restrict__ band_rows,
+                                                                 const int2 *__restrict__ tile_bytes, int TX, int Wt)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
+    const uint32_t camrows = (C + cols - 1) / cols;
+    uint32_t t = blockIdx.x;
+    const uint32_t tx = t % (uint32_t)TX; t /= (uint32_t)TX;
+    const uint32_t cc = t % cols; t /= cols;
+    const uint32_t b = t % NB;    t /= NB;
+    const uint32_t cr = t % camrows;
+    const uint32_t f = t / camrows;
+    const uint32_t c = cr * cols + cc;
+    if (c >= C) return;
+    const uint32_t fc = f * C + c;
+    const uint32_t bin = fc * NB + b;
+    const int y0 = (int)b * a.R;
+    const int nrows = min(a.R, a.H - y0);
+    const int W0 = a.W0, x_first = (int)tx * Wt;
+    const uint32_t n = a.counts[bin];
+    const size_t row_bytes = (size_t)W0 * 3;
+
+    const int2 br = band_rows[c * NB + b];          // first source row, number of source rows
+    const int2 tb = tile_bytes[c * TX + tx];        // first source byte within a row (16-aligned), bytes (x16)
+    const uint32_t stride = (uint32_t)tb.y;         // LDS row stride
+
+    uint32_t *s_owner = s_dyn;                                               // [R*Wt]
+    uint32_t *s_col = s_dyn + (((size_t)a.R * Wt + 3) & ~(size_t)3);        // [Wt] pack_column(), offsets tile-relative
+    uint8_t *s_src = static_cast<uint8_t *>(__builtin_assume_aligned(        // [rows * stride + 16]
+        reinterpret_cast<uint8_t *>(s_col + ((Wt + 3) & ~3)), 16));
+
+    // stage the tile's source bytes row by row + this tile's column taps
+    const uint8_t *g0 = a.src + (size_t)fc * a.H0 * row_bytes + (size_t)br.x * row_bytes + (size_t)tb.x;
+    const uint32_t cpr_src = stride >> 4, nchunk_src = (uint32_t)br.y * cpr_src;
+    for (uint32_t i = threadIdx.x; i < nchunk_src; i += RAWLDS_BLOCK) {
+        const uint32_t r = i / cpr_src, j = i - r * cpr_src;
+        reinterpret_cast<u32x4 *>(s_src + (size_t)r * stride)[j] =
+            OVERLAY_LOAD(reinterpret_cast<const u32x4 *>(g0 + (size_t)r * row_bytes) + j);
+    }
+    const float *mxc = a.mapx + (size_t)c * a.mapx_cam, *myc = a.mapy + (size_t)c * a.mapy_cam;
+    for (int x = threadIdx.x; x < Wt; x += RAWLDS_BLOCK) s_col[x] = pack_column(mxc[x_first + x], W0) - (uint32_t)tb.x;
+    if (n) {
+        uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
+        const int n4 = (nrows * Wt + 3) >> 2;
+        for (int j = threadIdx.x; j < n4; j += RAWLDS_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        // the band's stamps, clipped to this tile's columns
+        const uint2 *st = a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]);
+        for (uint32_t s = threadIdx.x; s < n; s += RAWLDS_BLOCK) {
+            const uint2 rec = st[s];
+            const int u = (int)(rec.x & 0xffffu), v = (int)(rec.x >> 16);
+            const uint32_t val = rec.y + 1u;
+            const int ylo = max(v - a.disc.radius, y0), yhi = min(v + a.disc.radius, y0 + nrows - 1);
+            for (int y = ylo; y <= yhi; ++y) {
+                const int hw = a.disc.hw[abs(y - v)];
+                if (hw < 0) continue;
+                const int xlo = max(max(u - hw, 0), x_first), xhi = min(min(u + hw, a.W - 1), x_first + Wt - 1);
+                uint32_t *orow = s_owner + (y - y0) * Wt - x_first;
+                for (int x = xlo; x <= xhi; ++x) atomicMax(&orow[x], val);
+            }
+        }
+    }
+    __syncthreads();
+
+    uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
+                     ((size_t)(c / cols) * a.H + y0) * a.mosaic_row_bytes + (size_t)(c % cols) * a.W * 3 +
+                     (size_t)x_first * 3;
+    const uint32_t cpr_t = (uint32_t)(Wt * 3) >> 4;             // 16-byte chunks per tile row
+    const uint32_t nchunks = (uint32_t)nrows * cpr_t;
+    const int ylast = br.x + br.y - 1;
+    for (uint32_t idx = threadIdx.x; idx < nchunks; idx += RAWLDS_BLOCK) {
+        const uint32_t row = idx / cpr_t, col = idx - row * cpr_t;
+        const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
+        // vertical part of the remap: once per chunk (all six pixels share the destination row)
+        const int sy = __float2int_rn(myc[y0 + (int)row] * 32.0f);
+        const int yy0 = sy >> 5;
+        const uint32_t bw = (uint32_t)(sy & 31);
+        const uint32_t wt = ((unsigned)yy0 < (unsigned)a.H0) ? 32u - bw : 0u;
+        const uint32_t wb = ((unsigned)(yy0 + 1) < (unsigned)a.H0) ? bw : 0u;
+        const uint8_t *row0 = s_src + __umul24((uint32_t)(min(max(yy0, br.x), ylast) - br.x), stride);
+        const uint8_t *row1 = s_src + __umul24((uint32_t)(min(max(yy0 + 1, br.x), ylast) - br.x), stride);
+        uint32_t px[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) px[k] = remap_pixel_lds(row0, row1, s_col[p0 + k], wt, wb);
+        u32x4 v = chunk_from_pixels(px, ph);
+        if (n) patch_chunk(v, s_owner + row * Wt, col, a.pal);
+        u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
+        OVERLAY_STORE(v, drow + col);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic single-image stamping (CameraManager.render_maps on caller-supplied points)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_stamp_global(const double *__restrict__ vu,
+                                                        const uint8_t *__restrict__ colour, int64_t n,
+                                                        uint32_t *__restrict__ owner, int H, int W, Disc disc)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    // reproject.py:249 astype(np.int32); cv2.circle clips to the image itself
+    const int v = (int)vu[2 * i], u = (int)vu[2 * i + 1];
+    const uint32_t val = ((((uint32_t)i) << 1) | (uint32_t)(colour[i] & 1)) + 1u;
+    for (int dy = -disc.radius; dy <= disc.radius; ++dy) {
+        const int y = v + dy;
+        if (y < 0 || y >= H) continue;
+        const int hw = disc.hw[abs(dy)];
+        if (hw < 0) continue;
+        const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
+        for (int x = xlo; x <= xhi; ++x) atomicMax(&owner[(size_t)y * W + x], val);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_apply_owner(const uint32_t *__restrict__ owner,
+                                                       uint8_t *__restrict__ image, int64_t npix, Palette pal)
+{
+    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= npix) return;
+    const uint32_t o = owner[p];
+    if (!o) return;
+    const uint32_t col = pal.c[(o - 1u) & 1u];
+    image[3 * p] = (uint8_t)col;
+    image[3 * p + 1] = (uint8_t)(col >> 8);
+    image[3 * p + 2] = (uint8_t)(col >> 16);
+}

@@ -1,0 +1,335 @@
+// project_kernels.hpp -- part of libcama_hip.so (included by cama_hip.hip inside its anonymous namespace).
+// Projection kernels: fp64 FMA chains, API-mode kernels (transform / crop / project), the fused per-frame
+// kernels (coordinate-emitting mode and the count/fill stamp binning) and the bin scans.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// fp64 k-ordered FMA chains (see header: arithmetic contract)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void affine3x4(const double *M, double x, double y, double z,
+                                          double &ox, double &oy, double &oz)
+{
+    double a;
+    a = M[0] * x; a = __builtin_fma(M[1], y, a); a = __builtin_fma(M[2], z, a);  a = __builtin_fma(M[3], 1.0, a);  ox = a;
+    a = M[4] * x; a = __builtin_fma(M[5], y, a); a = __builtin_fma(M[6], z, a);  a = __builtin_fma(M[7], 1.0, a);  oy = a;
+    a = M[8] * x; a = __builtin_fma(M[9], y, a); a = __builtin_fma(M[10], z, a); a = __builtin_fma(M[11], 1.0, a); oz = a;
+}
+
+__device__ __forceinline__ void linear3x3(const double *K, double x, double y, double z,
+                                          double &o0, double &o1, double &o2)
+{
+    double a;
+    a = K[0] * x; a = __builtin_fma(K[1], y, a); a = __builtin_fma(K[2], z, a); o0 = a;
+    a = K[3] * x; a = __builtin_fma(K[4], y, a); a = __builtin_fma(K[5], z, a); o1 = a;
+    a = K[6] * x; a = __builtin_fma(K[7], y, a); a = __builtin_fma(K[8], z, a); o2 = a;
+}
+
+__device__ __forceinline__ bool in_crop(const Crop &c, double x, double y, double z)
+{
+    return (x >= c.v[0]) & (x <= c.v[1]) & (y >= c.v[2]) & (y <= c.v[3]) & (z >= c.v[4]) & (z <= c.v[5]);
+}
+
+// reproject.py:191-198.  h = K @ p_cam.  Visible iff h2 > 0 (mask_z), h2/h2 > 0 (false only for
+// h2 = +inf, where the quotient is nan) and 0 <= u < W, 0 <= v < H on the IEEE quotients.
+__device__ __forceinline__ bool pinhole(double h0, double h1, double h2, double Wd, double Hd,
+                                        double &u, double &v)
+{
+    u = h0 / h2;
+    v = h1 / h2;
+    return (h2 > 0.0) & (h2 < __builtin_huge_val()) & (u >= 0.0) & (u < Wd) & (v >= 0.0) & (v < Hd);
+}
+
+// Bin-mode projection of one chassis-frame point into camera `m` (= 3x4 | 3x3): returns true and the packed
+// truncated pixel iff the reference's mask (reproject.py:192-198) is true.  Same FMA chains as pinhole(); the two
+// early-outs only skip work whose result is provably "not visible":
+//  (a) K's third row is (0,0,k) for every pinhole K; then h2 = fma(k, pz, +-0) = k*pz, so the sign test can run on
+//      the third affine row alone (5 fp64 ops instead of ~50 for the half-space behind the camera);
+//  (b) h0 < -h2 or h0 > (W+1)*h2 (same for h1/H) puts the IEEE quotient below 0 / at or above W even after
+//      rounding (one pixel of margin >> 1 ulp), so the two divisions (~28 fp64 ops) are skipped.
+__device__ __forceinline__ bool visible_pixel(const double *m, double cx, double cy, double cz, double Wd, double Hd,
+                                              uint32_t &uv)
+{
+    const double *K = m + 12;
+    double a;
+    a = m[8] * cx; a = __builtin_fma(m[9], cy, a); a = __builtin_fma(m[10], cz, a); a = __builtin_fma(m[11], 1.0, a);
+    const double pz = a;
+    const bool pinhole_row = (K[6] == 0.0) & (K[7] == 0.0);
+    if (pinhole_row && !(K[8] * pz > 0.0)) return false;
+    a = m[0] * cx; a = __builtin_fma(m[1], cy, a); a = __builtin_fma(m[2], cz, a); a = __builtin_fma(m[3], 1.0, a);
+    const double px = a;
+    a = m[4] * cx; a = __builtin_fma(m[5], cy, a); a = __builtin_fma(m[6], cz, a); a = __builtin_fma(m[7], 1.0, a);
+    const double py = a;
+    double h0, h1, h2;
+    linear3x3(K, px, py, pz, h0, h1, h2);
+    if (!(h2 > 0.0)) return false;
+    if ((h0 < -h2) | (h0 > (Wd + 1.0) * h2) | (h1 < -h2) | (h1 > (Hd + 1.0) * h2)) return false;
+    double u, v;
+    if (!pinhole(h0, h1, h2, Wd, Hd, u, v)) return false;
+    // reproject.py:249: astype(np.int32) truncation (values are >= 0 here)
+    uv = (uint32_t)(int)u | ((uint32_t)(int)v << 16);
+    return true;
+}
+
+// stage [C] x (3x4 chassis->camera | 3x3 K) into LDS
+__device__ __forceinline__ void stage_cameras(double *s_cam, const double *c2cam, const double *K, int C)
+{
+    for (int t = threadIdx.x; t < C * CAM_STRIDE; t += BLOCK) {
+        int c = t / CAM_STRIDE, k = t - c * CAM_STRIDE;
+        s_cam[t] = (k < 12) ? c2cam[c * 16 + k] : K[c * 9 + (k - 12)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// API kernels (materialise coordinates)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_transform_points(const T *__restrict__ xyz, int64_t N,
+                                                            const double *__restrict__ Tm, Crop crop,
+                                                            int has_crop, double *__restrict__ out,
+                                                            uint8_t *__restrict__ mask)
+{
+    __shared__ double s_m[12];
+    const int f = blockIdx.y;
+    if (threadIdx.x < 12) s_m[threadIdx.x] = Tm[(size_t)f * 16 + threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const double x = (double)xyz[3 * i], y = (double)xyz[3 * i + 1], z = (double)xyz[3 * i + 2];
+    double ox, oy, oz;
+    affine3x4(s_m, x, y, z, ox, oy, oz);
+    if (out) {
+        double *o = out + ((size_t)f * N + i) * 3;
+        o[0] = ox; o[1] = oy; o[2] = oz;
+    }
+    if (mask) mask[(size_t)f * N + i] = has_crop ? (uint8_t)in_crop(crop, ox, oy, oz) : (uint8_t)1;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_crop_points(const double *__restrict__ pts, int64_t n, Crop crop,
+                                                       uint8_t *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) mask[i] = (uint8_t)in_crop(crop, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_project_points(const double *__restrict__ pts, int64_t n,
+                                                          const double *__restrict__ c2cam,
+                                                          const double *__restrict__ K, int C, int W, int H,
+                                                          double *__restrict__ vu, uint8_t *__restrict__ vis)
+{
+    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+    stage_cameras(s_cam, c2cam, K, C);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    const double Wd = (double)W, Hd = (double)H;
+    for (int c = 0; c < C; ++c) {
+        const double *m = s_cam + c * CAM_STRIDE;
+        double px, py, pz, h0, h1, h2, u, v;
+        affine3x4(m, x, y, z, px, py, pz);
+        linear3x3(m + 12, px, py, pz, h0, h1, h2);
+        const bool ok = pinhole(h0, h1, h2, Wd, Hd, u, v);
+        reinterpret_cast<double2 *>(vu)[(size_t)c * n + i] = make_double2(v, u);
+        vis[(size_t)c * n + i] = (uint8_t)ok;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused per-frame kernel
+// ------------------------------------------------------------------------------------------
+enum { MODE_EMIT = 0, MODE_COUNT = 1, MODE_FILL = 2 };
+
+struct FrameArgs {
+    const void *x, *y, *z;  // [N] each, float or double (template parameter T)
+    const uint8_t *colour;
+    const uint32_t *key;    // optional [N]: draw index << 1 | colour (maps stored in a different order than drawn)
+    int64_t N;
+    const double *w2c, *c2cam, *K;
+    int C, W, H;
+    Crop crop;
+    // MODE_EMIT
+    double *vu;
+    uint8_t *vis, *crop_mask;
+    // MODE_COUNT / MODE_FILL
+    int band_shift, NB, radius;
+    uint32_t *counts, *cursor;
+    const uint32_t *bin_off, *fc_base;
+    uint2 *stamps;
+};
+
+// Emit mode: materialise (v,u) + visibility for every (frame, camera, vertex).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_frames_emit(FrameArgs a)
+{
+    __shared__ double s_w2c[12];
+    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+    const int f = blockIdx.y;
+    if (threadIdx.x < 12) s_w2c[threadIdx.x] = a.w2c[(size_t)f * 16 + threadIdx.x];
+    stage_cameras(s_cam, a.c2cam, a.K, a.C);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    const double x = (double)static_cast<const T *>(a.x)[i], y = (double)static_cast<const T *>(a.y)[i],
+                 z = (double)static_cast<const T *>(a.z)[i];
+    double cx, cy, cz;
+    affine3x4(s_w2c, x, y, z, cx, cy, cz);
+    const bool in = in_crop(a.crop, cx, cy, cz);
+    if (a.crop_mask) a.crop_mask[(size_t)f * a.N + i] = (uint8_t)in;
+    const double Wd = (double)a.W, Hd = (double)a.H;
+    for (int c = 0; c < a.C; ++c) {
+        const size_t at = ((size_t)f * a.C + c) * a.N + i;
+        bool ok = false;
+        if (in) {
+            const double *m = s_cam + c * CAM_STRIDE;
+            double px, py, pz, h0, h1, h2, u, v;
+            affine3x4(m, cx, cy, cz, px, py, pz);
+            linear3x3(m + 12, px, py, pz, h0, h1, h2);
+            ok = pinhole(h0, h1, h2, Wd, Hd, u, v);
+            reinterpret_cast<double2 *>(a.vu)[at] = make_double2(v, u);
+        }
+        a.vis[at] = (uint8_t)ok;
+    }
+}
+
+// Bin mode.  Every visible (vertex, camera) pair is a "stamp" {u:16, v:16, key = draw index << 1 | colour}
+// that must reach the 1-2 row bands its disc touches.  Two passes (count -> scan -> fill) with identical
+// arithmetic.  All per-stamp atomics are LDS atomics on a per-workgroup histogram of this frame's
+// C x NB bins (ds_add_rtn gives the rank inside the workgroup); global memory sees one independent
+// atomic per non-empty bin per workgroup, so nothing serialises on HBM/L2 latency.
+constexpr int CAM_GROUP = 8;  // cameras ranked per pass through the workgroup protocol (register-resident entries)
+
+template <int MODE, typename T>
+__global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [C*NB] counts, then (fill) [C*NB] bases
+    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+    const int f = blockIdx.y;
+    const int nloc = a.C * a.NB;
+    uint32_t *s_cnt = s_hist, *s_base = s_hist + nloc;
+
+    // world->chassis + crop FIRST, with the frame's matrix read through wave-uniform (scalar) loads: on site-sized
+    // maps ~95 % of the workgroups end here and never pay for staging the cameras or clearing the histogram
+    const double *w2c = a.w2c + (size_t)f * 16;
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    double cx = 0, cy = 0, cz = 0;
+    bool in = false;
+    uint32_t key = 0;
+    if (i < a.N) {
+        const double x = (double)static_cast<const T *>(a.x)[i], y = (double)static_cast<const T *>(a.y)[i],
+                     z = (double)static_cast<const T *>(a.z)[i];
+        affine3x4(w2c, x, y, z, cx, cy, cz);
+        in = in_crop(a.crop, cx, cy, cz);
+        // draw index << 1 | colour.  Spatially re-ordered maps carry it per vertex (a.key), otherwise it is the
+        // storage index itself
+        key = a.key ? a.key[i] : (((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1));
+    }
+    // whole workgroup outside the crop box (the common case on site-sized maps): done
+    if (!__syncthreads_or((int)in)) return;
+    stage_cameras(s_cam, a.c2cam, a.K, a.C);
+    for (int t = threadIdx.x; t < nloc; t += BLOCK) s_cnt[t] = 0u;
+    __syncthreads();
+
+    const double Wd = (double)a.W, Hd = (double)a.H;
+    const size_t gbin0 = (size_t)f * nloc;
+    for (int c0 = 0; c0 < a.C; c0 += CAM_GROUP) {
+        uint32_t e_uv[CAM_GROUP], e_slot[2 * CAM_GROUP];
+#pragma unroll
+        for (int j = 0; j < CAM_GROUP; ++j) {
+            const int c = c0 + j;
+            e_slot[2 * j] = e_slot[2 * j + 1] = 0xffffffffu;
+            e_uv[j] = 0;
+            // wave-uniform guard: the shuffle below must be executed by every lane
+            if (c < a.C) {
+                uint32_t uv = 0xffffffffu;      // packed truncated pixel, or "not visible"
+                if (in) {
+                    uint32_t packed;
+                    if (visible_pixel(s_cam + c * CAM_STRIDE, cx, cy, cz, Wd, Hd, packed)) uv = packed;
+                }
+                // A disc is invisible if a LATER point (higher draw index) stamps the very same pixel (same
+                // footprint).  The next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most
+                // far-range stamps collapse here, exactly, before they cost atomics, HBM or LDS conflicts.
+                const uint32_t uv_next = __shfl_down(uv, 1, 64);
+                const uint32_t key_next = __shfl_down(key, 1, 64);
+                const bool covered = (__lane_id() != 63u) && (uv_next == uv) && (key_next > key);
+                const bool keep = (uv != 0xffffffffu) && !covered;
+                if (keep) {
+                    const int vi = (int)(uv >> 16);
+                    const int b0 = max(vi - a.radius, 0) >> a.band_shift;
+                    const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;   // b1 <= b0 + 1 (host checks 2r <= R)
+                    const uint32_t l0 = (uint32_t)(c * a.NB + b0);
+                    if (MODE == MODE_COUNT) {
+                        atomicAdd(&s_cnt[l0], 1u);
+                        if (b1 != b0) atomicAdd(&s_cnt[l0 + 1], 1u);
+                    } else {
+                        e_uv[j] = uv;
+                        e_slot[2 * j] = (l0 << 8) | atomicAdd(&s_cnt[l0], 1u);
+                        if (b1 != b0) e_slot[2 * j + 1] = ((l0 + 1) << 8) | atomicAdd(&s_cnt[l0 + 1], 1u);
+                    }
+                }
+            }
+        }
+        if (MODE == MODE_FILL) {
+            __syncthreads();
+            const int cend = min(c0 + CAM_GROUP, a.C);
+            for (int t = c0 * a.NB + threadIdx.x; t < cend * a.NB; t += BLOCK) {
+                const uint32_t n = s_cnt[t];
+                uint32_t base = 0;
+                if (n) base = atomicAdd(&a.cursor[gbin0 + t], n) + a.bin_off[gbin0 + t] + a.fc_base[f * a.C + t / a.NB];
+                s_base[t] = base;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2 * CAM_GROUP; ++j) {
+                if (e_slot[j] != 0xffffffffu)
+                    a.stamps[(size_t)s_base[e_slot[j] >> 8] + (e_slot[j] & 0xffu)] = make_uint2(e_uv[j >> 1], key);
+            }
+        }
+    }
+    if (MODE == MODE_COUNT) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < nloc; t += BLOCK) {
+            const uint32_t n = s_cnt[t];
+            if (n) atomicAdd(&a.counts[gbin0 + t], n);
+        }
+    }
+}
+
+// exclusive scan of each (frame,camera)'s band counters; one wave per (frame,camera)
+__global__ __launch_bounds__(64) void k_scan_bands(const uint32_t *__restrict__ counts,
+                                                   uint32_t *__restrict__ bin_off,
+                                                   uint32_t *__restrict__ fc_total, int NB)
+{
+    const int fc = blockIdx.x, lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (int base = 0; base < NB; base += 64) {
+        const int b = base + lane;
+        const uint32_t v = b < NB ? counts[(size_t)fc * NB + b] : 0u;
+        uint32_t s = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(s, d, 64);
+            if (lane >= d) s += t;
+        }
+        if (b < NB) bin_off[(size_t)fc * NB + b] = carry + s - v;
+        carry += __shfl(s, 63, 64);
+    }
+    if (lane == 0) fc_total[fc] = carry;
+}
+
+// exclusive scan over the (frame,camera) totals; a single wave
+__global__ __launch_bounds__(64) void k_scan_totals(const uint32_t *__restrict__ fc_total,
+                                                    uint32_t *__restrict__ fc_base, int n)
+{
+    const int lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        const uint32_t v = j < n ? fc_total[j] : 0u;
+        uint32_t s = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(s, d, 64);
+            if (lane >= d) s += t;
+        }
+        if (j < n) fc_base[j] = carry + s - v;
+        carry += __shfl(s, 63, 64);
+    }
+}
