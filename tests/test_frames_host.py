@@ -1,0 +1,54 @@
+"""Host-side frame ingest (cama_amd/frames.py): decode, .npy twins, thread-pool prefetch; and the undistort map builder.
+CPU only."""
+import numpy as np
+
+from cama_amd import frames as FR
+from cama_amd.dataset import ClipManager
+from cama_amd.synth import DEFAULT_CAMA_CONFIGS, make_clip
+
+
+def test_clip_frame_source_decodes_in_order_with_prefetch(tmp_path):
+    clip = str(tmp_path / "clip")
+    make_clip(clip, n_frames=6, seed=3, n_lines=2, verts_per_line=3, line_len_m=1.0, raster_size=300,
+              image_mode="jpg", image_size=(36, 64), origin_size=(36, 64), with_nuscenes=False)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(36, 64)), clip)
+    src = FR.ClipFrameSource(cm.cm_list, device=None, workers=4, prefetch=2)
+    assert src.fused is False                                   # output size == sensor size, no distortion
+    got = src._decoded([1, 2])
+    assert got.shape == (2, 6, 36, 64, 3) and got.dtype == np.uint8
+    for k, idx in enumerate((1, 2)):
+        for c, cam in enumerate(cm.cm_list):
+            assert np.array_equal(got[k, c], FR.read_bgr(cam.get_image_path(idx, True)))
+    assert sorted(src._pending) == [3, 4]                       # two frames ahead are already being decoded
+    got5 = src._decoded([5])                                    # jump: stale prefetches are dropped, no leak
+    assert got5.shape[0] == 1 and all(k >= 5 for k in src._pending)
+    assert np.array_equal(got5[0, 2], FR.read_bgr(cm.cm_list[2].get_image_path(5, True)))
+
+
+def test_read_bgr_npy_twin_and_channel_order(tmp_path):
+    from PIL import Image
+    img = np.zeros((8, 12, 3), np.uint8)
+    img[..., 0], img[..., 1], img[..., 2] = 10, 120, 250        # B, G, R
+    np.save(tmp_path / "a.npy", img)
+    assert np.array_equal(FR.read_bgr(str(tmp_path / "a.jpg")), img)          # .jpg missing -> .npy twin
+    assert np.array_equal(FR.read_bgr(str(tmp_path / "a.npy")), img)
+    Image.fromarray(img[:, :, ::-1]).save(tmp_path / "b.png")                 # lossless, RGB on disk
+    assert np.array_equal(FR.read_bgr(str(tmp_path / "b.png")), img)          # comes back as BGR like cv2.imread
+
+
+def test_undistort_map_identity_scale_and_monotonic():
+    K0 = np.array([[1266.4, 0.0, 816.3], [0.0, 1266.4, 491.5], [0.0, 0.0, 1.0]])
+    Kn = K0.copy()
+    Kn[0] *= 960 / 1600
+    Kn[1] *= 540 / 900
+    mx, my = FR.undistort_rectify_map(K0, [0.0] * 8, Kn, 960, 540)
+    assert mx.dtype == np.float32 and mx.shape == (540, 960)
+    jj, ii = np.meshgrid(np.arange(960), np.arange(540))
+    assert np.allclose(mx, jj / 0.6, atol=2e-4) and np.allclose(my, ii / 0.6, atol=2e-4)     # src = dst / scale
+    assert (mx == mx[0:1]).all() and (my == my[:, 0:1]).all()                                # separable
+    mxi, myi = FR.undistort_rectify_map(K0, [], K0, 1600, 900)
+    # identity calibration: the float64 round trip through K^-1 and K leaves ~1e-13 px, far below the 1/32 px grid
+    assert np.allclose(mxi[0], np.arange(1600), atol=1e-4) and np.allclose(myi[:, 0], np.arange(900), atol=1e-4)
+    assert np.array_equal(np.rint(mxi[0] * 32), np.arange(1600) * 32.0)
+    mxd, _ = FR.undistort_rectify_map(K0, [-0.2, 0.05, 0, 0, 0, 0, 0, 0], Kn, 960, 540)
+    assert not (mxd == mxd[0:1]).all()                                                       # distortion breaks separability
