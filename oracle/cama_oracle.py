@@ -413,7 +413,13 @@ def remap_bilinear(image, mapx, mapy):
     """cv2.remap(image, mapx, mapy, INTER_LINEAR) for 8-bit images (cama/reproject.py:239), restated from OpenCV's
     fixed-point path: coordinates cvRound(map * 32) (INTER_BITS = 5), tap (x >> 5, y >> 5), weights
     (32-a)(32-b)*32 etc. out of 1 << 15 (INTER_REMAP_COEF_BITS = 15), rounding + (1 << 14) >> 15,
-    BORDER_CONSTANT 0.  PARITY UNPINNED (OpenCV absent)."""
+    BORDER_CONSTANT 0.  PARITY UNPINNED (OpenCV absent).
+
+    Why exact integers are the right restatement: OpenCV's weight table (initInterTab2D, fixpt) is
+    saturate_cast<short>(w * 32768) of float products of multiples of 1/32 -- exact -- and sums to 32768 for every
+    fraction except (0,0), where the single weight 1.0 saturates to 32767 and the table's sum fix-up gives the missing
+    1 to another tap; (32767*p00 + p11 + 16384) >> 15 still equals p00 for 8-bit pixels, the same value as the exact
+    weights produce."""
     H0, W0 = image.shape[:2]
     sx = np.rint(mapx.astype(np.float32) * np.float32(32)).astype(np.int64)
     sy = np.rint(mapy.astype(np.float32) * np.float32(32)).astype(np.int64)
