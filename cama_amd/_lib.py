@@ -32,6 +32,7 @@ SIGNATURES = {
     "cama_build_static_map": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32, _i32, _i32,
                                      _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "cama_resample_frames": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "cama_overlay_frames_alpha": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
     "cama_overlay_frames_raw": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
                                        _vp, _vp, _vp, _sz, _vp]),
     "cama_stamp_scratch_bytes": (_sz, [_i32, _i32]),

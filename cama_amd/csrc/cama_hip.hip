@@ -89,7 +89,7 @@ constexpr int CAM_STRIDE = 21;  // 12 (3x4 of chassis->camera) + 9 (K)
 
 struct Crop { double v[6]; };
 struct Disc { int radius; int hw[CAMA_MAX_RADIUS + 1]; };
-struct Palette { uint32_t c[2]; };  // b | g<<8 | r<<16
+struct Palette { uint32_t c[2]; uint32_t alpha256; };  // colours b | g<<8 | r<<16; alpha in 1/256 (256 = opaque)
 
 #include "project_kernels.hpp"
 #include "remap_device.hpp"
@@ -108,9 +108,10 @@ int make_disc(int radius, const int32_t *hw, Disc &d)
     return 0;
 }
 
-Palette make_palette(const uint8_t *bgr)
+Palette make_palette(const uint8_t *bgr, uint32_t alpha256 = 256u)
 {
     Palette p;
+    p.alpha256 = alpha256;
     for (int k = 0; k < 2; ++k)
         p.c[k] = (uint32_t)bgr[3 * k] | ((uint32_t)bgr[3 * k + 1] << 8) | ((uint32_t)bgr[3 * k + 2] << 16);
     return p;
@@ -384,6 +385,8 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     return CAMA_OK;
 }
 
+thread_local uint32_t g_next_alpha256 = 256u;   // consumed by the next overlay launch (cama_overlay_frames_alpha)
+
 struct RawSource {
     int H0, W0;
     const float *mapx, *mapy;
@@ -419,7 +422,8 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     o.mosaic_frame_bytes = (size_t)rows * H * o.mosaic_row_bytes;
     o.counts = (const uint32_t *)(base + L.counts); o.bin_off = (const uint32_t *)(base + L.bin_off);
     o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)(base + L.stamps);
-    o.disc = disc; o.pal = make_palette(palette_bgr);
+    o.disc = disc; o.pal = make_palette(palette_bgr, g_next_alpha256);
+    g_next_alpha256 = 256u;
     const bool vec = (W % 16 == 0) && ((((raw ? 0 : (uintptr_t)src)) | (uintptr_t)mosaic) % 16 == 0);
     if (vec) {
         o.cpr = (uint32_t)(W * 3 / 16);
@@ -473,7 +477,12 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
                            reinterpret_cast<const int2 *>(raw->tile_bytes), raw->tiles_x, Wt);
     } else if (raw)
         hipLaunchKernelGGL((k_overlay<true, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
-    else if (vec)
+    else if (o.pal.alpha256 != 256u) {      // translucent extension: its own instantiations, the exact kernels stay lean
+        if (vec)
+            hipLaunchKernelGGL((k_overlay<true, false, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+        else
+            hipLaunchKernelGGL((k_overlay<false, false, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+    } else if (vec)
         hipLaunchKernelGGL((k_overlay<true, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
     else
         hipLaunchKernelGGL((k_overlay<false, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
@@ -491,6 +500,18 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
 {
     return overlay_impl(src, nullptr, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
                         scratch_bytes, stream);
+}
+
+int cama_overlay_frames_alpha(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                              int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                              int32_t alpha256, const void *scratch, size_t scratch_bytes, void *stream)
+{
+    if (alpha256 < 0 || alpha256 > 256) return fail(CAMA_EINVAL, "alpha256=%d out of range [0, 256]", alpha256);
+    g_next_alpha256 = (uint32_t)alpha256;
+    const int rc = overlay_impl(src, nullptr, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
+                                scratch_bytes, stream);
+    g_next_alpha256 = 256u;
+    return rc;
 }
 
 int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const float *mapx, const float *mapy,

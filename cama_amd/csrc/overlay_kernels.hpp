@@ -44,6 +44,16 @@ __device__ __forceinline__ void rasterise_stamps(uint32_t *s_owner, const uint2 
 
 // Patch the 16 bytes of chunk `col` of one row with the colours of the owned pixels it overlaps.
 // A chunk starts at byte 16*col = 3*p0 + ph and overlaps exactly pixels p0..p0+5.
+// per-byte (colour*a + source*(256-a) + 128) >> 8 on four packed bytes: even and odd bytes as two 16-bit lanes each
+__device__ __forceinline__ uint32_t blend_bytes(uint32_t src, uint32_t col, uint32_t a)
+{
+    const uint32_t na = 256u - a;
+    const uint32_t e = ((col & 0x00ff00ffu) * a + (src & 0x00ff00ffu) * na + 0x00800080u) >> 8;
+    const uint32_t o = (((col >> 8) & 0x00ff00ffu) * a + ((src >> 8) & 0x00ff00ffu) * na + 0x00800080u) >> 8;
+    return (e & 0x00ff00ffu) | ((o & 0x00ff00ffu) << 8);
+}
+
+template <bool ALPHA = false>
 __device__ __forceinline__ void patch_chunk(u32x4 &d, const uint32_t *orow, uint32_t col, const Palette &pal)
 {
     const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
@@ -67,10 +77,17 @@ __device__ __forceinline__ void patch_chunk(u32x4 &d, const uint32_t *orow, uint
                    v2 = __builtin_amdgcn_alignbyte(V3, V2, ph), v3 = __builtin_amdgcn_alignbyte(V4, V3, ph);
     const uint32_t m0 = __builtin_amdgcn_alignbyte(M1, M0, ph), m1 = __builtin_amdgcn_alignbyte(M2, M1, ph),
                    m2 = __builtin_amdgcn_alignbyte(M3, M2, ph), m3 = __builtin_amdgcn_alignbyte(M4, M3, ph);
-    d.x = (d.x & ~m0) | (v0 & m0);
-    d.y = (d.y & ~m1) | (v1 & m1);
-    d.z = (d.z & ~m2) | (v2 & m2);
-    d.w = (d.w & ~m3) | (v3 & m3);
+    if (!ALPHA) {                         // reference semantics: opaque overwrite (cv2.circle with a solid colour)
+        d.x = (d.x & ~m0) | (v0 & m0);
+        d.y = (d.y & ~m1) | (v1 & m1);
+        d.z = (d.z & ~m2) | (v2 & m2);
+        d.w = (d.w & ~m3) | (v3 & m3);
+    } else {                              // extension: owned pixels = round(alpha*colour + (1-alpha)*source), once
+        d.x = (d.x & ~m0) | (blend_bytes(d.x, v0, pal.alpha256) & m0);
+        d.y = (d.y & ~m1) | (blend_bytes(d.y, v1, pal.alpha256) & m1);
+        d.z = (d.z & ~m2) | (blend_bytes(d.z, v2, pal.alpha256) & m2);
+        d.w = (d.w & ~m3) | (blend_bytes(d.w, v3, pal.alpha256) & m3);
+    }
 }
 
 // 6 packed pixels (b | g<<8 | r<<16) that a 16-byte chunk starting `ph` bytes into the first one overlaps -> the chunk
@@ -86,7 +103,7 @@ __device__ __forceinline__ u32x4 chunk_from_pixels(const uint32_t *c, uint32_t p
     return v;
 }
 
-template <bool VEC, bool RESAMPLE>
+template <bool VEC, bool RESAMPLE, bool ALPHA = false>
 __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x W, used only by stamped bands
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
                 if (idx < nchunks) {
                     const uint32_t row = __umulhi(idx, a.cpr_magic);
                     const uint32_t col = idx - row * a.cpr;
-                    if (n) patch_chunk(v[j], s_owner + row * W, col, a.pal);
+                    if (n) patch_chunk<ALPHA>(v[j], s_owner + row * W, col, a.pal);
                     u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
                     OVERLAY_STORE(v[j], drow + col);
                 }
@@ -196,7 +213,9 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
                 const uint32_t o = s_owner[p];
                 if (o) {
                     const uint32_t col = a.pal.c[(o - 1u) & 1u];
-                    b0 = (uint8_t)col; b1 = (uint8_t)(col >> 8); b2 = (uint8_t)(col >> 16);
+                    const uint32_t srcw = (uint32_t)b0 | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16);
+                    const uint32_t w = ALPHA ? blend_bytes(srcw, col, a.pal.alpha256) : col;
+                    b0 = (uint8_t)w; b1 = (uint8_t)(w >> 8); b2 = (uint8_t)(w >> 16);
                 }
             }
             uint8_t *d = dcell + (size_t)row * a.mosaic_row_bytes + (size_t)x * 3;

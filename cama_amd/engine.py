@@ -102,7 +102,7 @@ class DeviceMap:
 
 
 class Engine:
-    def __init__(self, device="cuda:0", crop=CROP_BOX, radius=RADIUS, palette_bgr=PALETTE_BGR):
+    def __init__(self, device="cuda:0", crop=CROP_BOX, radius=RADIUS, palette_bgr=PALETTE_BGR, alpha=1.0):
         torch = _torch()
         self.lib = _lib.lib()                                   # raises if the .so is missing
         if not torch.cuda.is_available():
@@ -111,6 +111,9 @@ class Engine:
         self.device = torch.device(device)
         self.crop = np.asarray(crop, np.float64)
         self.radius = int(radius)
+        # extension: translucent stamps (the reference is opaque = 1.0); applied by render_frames only
+        self.alpha256 = int(round(float(alpha) * 256))
+        assert 0 <= self.alpha256 <= 256
         self.halfwidth = _lib.circle_halfwidths(self.radius)
         self.palette = np.ascontiguousarray(np.asarray(palette_bgr, np.uint8).reshape(2, 3))
         self._scratch = None
@@ -275,6 +278,16 @@ class Engine:
             need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
             scratch = self._scratch_buf(need)
             x, y, z, col, key = dmap.render_ptrs()
+            if self.alpha256 != 256:        # extension path: binning + translucent overlay
+                _lib.check(self.lib.cama_bin_frames(
+                    x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(),
+                    rig.C, cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(),
+                    self._stream()))
+                _lib.check(self.lib.cama_overlay_frames_alpha(
+                    src.data_ptr(), out.data_ptr(), dmap.N, F, rig.C, rig.H, rig.W, cols, self.radius,
+                    self.halfwidth.ctypes.data, self.palette.ctypes.data, self.alpha256, scratch.data_ptr(),
+                    scratch.numel(), self._stream()))
+                return out
             _lib.check(self.lib.cama_render_frames(
                 x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F,
                 rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H,

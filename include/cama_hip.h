@@ -150,6 +150,16 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
                         const void *scratch, size_t scratch_bytes, void *stream);
 
 /*
+ * EXTENSION (no reference semantics; the reference draws opaque discs, cama/reproject.py:253-256): overlay half with
+ * translucent stamps.  A pixel covered by stamps becomes round(alpha*colour + (1-alpha)*source) ONCE, colour = the last
+ * writer's; alpha256 = alpha in 1/256, 256 == cama_overlay_frames.  Checked against the oracle's own restatement.
+ */
+int cama_overlay_frames_alpha(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t F, int32_t C,
+                              int32_t H, int32_t W, int32_t cols,
+                              int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                              int32_t alpha256, const void *scratch, size_t scratch_bytes, void *stream);
+
+/*
  * Overlay half that reads RAW sensor frames: undistort + resize (the cv2.initUndistortRectifyMap + cv2.remap of
  * CameraManager.resize_image, cama/reproject.py:232-240) is fused into the overlay's source read, so the
  * reference-default pipeline 1600x900 JPEG frame -> 960x540 overlay -> 2880x1080 mosaic is one pass: every raw byte

@@ -196,3 +196,34 @@ void oracle_render_frame(const uint8_t *src, uint8_t *mosaic, int C, int H, int 
         }
     }
 }
+
+/*
+ * EXTENSION checker (no reference semantics: the reference is opaque): translucent stamps.  A pixel covered by at
+ * least one disc becomes (colour*alpha256 + source*(256-alpha256) + 128) >> 8 per byte, colour = the last writer's.
+ * Implemented as: draw the discs into a colour layer pre-filled with a sentinel, then composite once.
+ */
+void oracle_render_frame_alpha(const uint8_t *src, uint8_t *mosaic, int C, int H, int W, int cols, const double *vu,
+                               const uint8_t *vis, const uint8_t *colour_id, int64_t N, int radius,
+                               const uint8_t *palette_bgr, int alpha256, uint8_t *layer /* H*W*3 scratch */)
+{
+    int64_t step = (int64_t)cols * W * 3;
+    const uint8_t sentinel[3] = {1, 2, 3};
+    for (int c = 0; c < C; c++) {
+        uint8_t *cell = mosaic + (int64_t)(c / cols) * H * step + (int64_t)(c % cols) * W * 3;
+        for (int64_t p = 0; p < (int64_t)H * W; p++) memcpy(layer + 3 * p, sentinel, 3);
+        for (int64_t i = 0; i < N; i++) {
+            if (!vis[(int64_t)c * N + i]) continue;
+            int32_t vi = (int32_t)vu[((int64_t)c * N + i) * 2], ui = (int32_t)vu[((int64_t)c * N + i) * 2 + 1];
+            const uint8_t *q = palette_bgr + 3 * colour_id[i];
+            oracle_circle_fill(layer, H, W, (int64_t)W * 3, ui, vi, radius, q[0], q[1], q[2]);
+        }
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const uint8_t *s3 = src + (((int64_t)c * H + y) * W + x) * 3, *l3 = layer + ((int64_t)y * W + x) * 3;
+                uint8_t *d3 = cell + (int64_t)y * step + (int64_t)x * 3;
+                int owned = memcmp(l3, sentinel, 3) != 0;
+                for (int k = 0; k < 3; k++)
+                    d3[k] = owned ? (uint8_t)((l3[k] * alpha256 + s3[k] * (256 - alpha256) + 128) >> 8) : s3[k];
+            }
+    }
+}

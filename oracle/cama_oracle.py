@@ -54,6 +54,8 @@ def lib():
         L.oracle_circle_halfwidths.restype = i32
         L.oracle_render_frame.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, i32, vp]
         L.oracle_render_frame.restype = None
+        L.oracle_render_frame_alpha.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, i32, vp, i32, vp]
+        L.oracle_render_frame_alpha.restype = None
         _LIB = L
     return _LIB
 
@@ -465,14 +467,21 @@ def frame_project_flat(xyz, w2c, cams, W, H, crop=CROP_BOX, want_chassis=False):
     return {"vu": vu, "vis": vis, "crop_mask": cmask, "chassis": chassis}
 
 
-def frame_render_flat(src, vu, vis, colour_id, radius=2, cols=3):
-    """src (C,H,W,3) uint8 -> mosaic ((C/cols)*H, cols*W, 3) through the C renderer."""
+def frame_render_flat(src, vu, vis, colour_id, radius=2, cols=3, alpha256=256):
+    """src (C,H,W,3) uint8 -> mosaic ((C/cols)*H, cols*W, 3) through the C renderer.  alpha256 < 256 selects the
+    translucent EXTENSION (own restatement, no reference semantics)."""
     L = lib()
     C, H, W = src.shape[:3]
     N = vis.shape[1]
     rows = (C + cols - 1) // cols
     out = np.zeros((rows * H, cols * W, 3), np.uint8)
     pal = np.asarray([GREY_RGB[::-1], GOLD_RGB[::-1]], np.uint8)
+    if alpha256 != 256:
+        layer = np.zeros((H, W, 3), np.uint8)
+        L.oracle_render_frame_alpha(_ptr(np.ascontiguousarray(src)), _ptr(out), C, H, W, cols,
+                                    _ptr(np.ascontiguousarray(vu)), _ptr(np.ascontiguousarray(vis)),
+                                    _ptr(np.ascontiguousarray(colour_id)), N, radius, _ptr(pal), int(alpha256), _ptr(layer))
+        return out
     L.oracle_render_frame(_ptr(np.ascontiguousarray(src)), _ptr(out), C, H, W, cols,
                           _ptr(np.ascontiguousarray(vu)), _ptr(np.ascontiguousarray(vis)),
                           _ptr(np.ascontiguousarray(colour_id)), N, radius, _ptr(pal))

@@ -358,3 +358,23 @@ def test_other_camera_counts(engine, C):
             assert np.array_equal(out[f, r * H:(r + 1) * H, q * W:(q + 1) * W], want[r * H:(r + 1) * H, q * W:(q + 1) * W])
         drawn += int(flat["vis"].sum())
     assert drawn > 500
+
+
+def test_alpha_extension_matches_own_restatement():
+    """EXTENSION (the reference is opaque): translucent stamps, checked against the oracle's restatement; alpha = 1
+    stays byte-identical to the opaque path."""
+    import torch
+    from cama_amd.engine import Engine
+    for W, H in ((160, 96), (100, 37)):                        # vector path and generic-width path
+        xyz, col, cams, w2c = _random_scene(70 + W, 4000, 2, W, H)
+        src = np.random.default_rng(W).integers(0, 256, (2, 6, H, W, 3), dtype=np.uint8)
+        for alpha256 in (256, 128, 77, 0):
+            e = Engine("cuda:0", alpha=alpha256 / 256.0)
+            rig = _rig(e, cams)
+            out = e.render_frames(e.upload_map(xyz, col), rig, w2c, torch.from_numpy(src).cuda()).cpu().numpy()
+            for f in range(2):
+                flat = O.frame_project_flat(xyz, w2c[f], cams, W, H)
+                want = O.frame_render_flat(src[f], flat["vu"], flat["vis"], col, alpha256=alpha256)
+                assert np.array_equal(out[f], want), (W, alpha256, f)
+                if alpha256 == 0:
+                    assert np.array_equal(out[f], O.mosaic({c["name"]: src[f, k] for k, c in enumerate(cams)}))
