@@ -256,3 +256,30 @@ def test_fused_raw_frame_overlay_equals_resample_then_overlay(tmp_path):
         flat = O.frame_project_flat(xyz, w2c[1], cams, W, H)
         assert flat["vis"].sum() > 100
         assert np.array_equal(outs[0][1].cpu().numpy(), O.frame_render_flat(small, flat["vu"], flat["vis"], col))
+
+
+def test_integration_md_binding_example_runs(repo_root):
+    """The ctypes stub shown in INTEGRATION.md (what a maintainer of the reference would add) is real code: extract
+    it, point it at the built library, render with it and compare with the engine."""
+    import re
+    import torch
+    from cama_amd import _lib
+    from cama_amd.engine import Engine
+    from tests.test_gpu_kernels import _random_scene, _rig
+    text = open(f"{repo_root}/INTEGRATION.md").read()
+    code = re.search(r"```python\n(# cama/_hip\.py.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libcama_hip.so")', f'ctypes.CDLL("{_lib.LIB_PATH}")')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    W, H, N, F = 160, 96, 3000, 2
+    xyz, col, cams, w2c = _random_scene(91, N, F, W, H)
+    e = Engine("cuda:0")
+    rig = _rig(e, cams)
+    src = torch.randint(0, 256, (F, 6, H, W, 3), dtype=torch.uint8, device="cuda")
+    want = e.render_frames(e.upload_map(xyz, col, spatial_sort=False), rig, w2c, src)
+    out = torch.empty_like(want)
+    ns["render_frames"](torch.from_numpy(np.ascontiguousarray(xyz.T)).cuda(), torch.from_numpy(col).cuda(),
+                        torch.from_numpy(np.asarray(w2c, np.float64).reshape(F, 16)).cuda(), rig.c2cam, rig.K,
+                        [-50, 50, -100, 100, -200, 200], src, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
