@@ -35,6 +35,11 @@ SIGNATURES = {
     "cama_overlay_frames_alpha": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
     "cama_overlay_frames_raw": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
                                        _vp, _vp, _vp, _sz, _vp]),
+    "cama_pipeline_create": (_i32, [_vp]),
+    "cama_pipeline_destroy": (_i32, [_vp]),
+    "cama_pipeline_render": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
+                                    _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cama_pipeline_join": (_i32, [_vp, _vp]),
     "cama_stamp_scratch_bytes": (_sz, [_i32, _i32]),
     "cama_stamp_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_circle_halfwidths": (_i32, [_i32, _vp]),

@@ -593,6 +593,97 @@ int cama_build_static_map(const float *verts, const int32_t *seg_v0, const int32
     return CAMA_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// two-stream pipeline context: binning of batch k+1 overlaps the overlay of batch k
+// ------------------------------------------------------------------------------------------
+struct cama_pipeline {
+    hipStream_t s_bin = nullptr, s_ov = nullptr;
+    hipEvent_t ready = nullptr, binned[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
+    bool freed_valid[2] = {false, false};
+    int turn = 0;
+    bool any = false;
+    int last = 0;
+};
+
+int cama_pipeline_create(cama_pipeline **out)
+{
+    if (!out) return fail(CAMA_EINVAL, "out is NULL");
+    cama_pipeline *p = new cama_pipeline();
+    // device-scope release, no timing: a default event makes the recording stream do a system-scope release after
+    // an overlay that wrote ~1 GB, which showed up as ~20 us between consecutive overlays
+    const unsigned flags = hipEventDisableTiming | hipEventReleaseToDevice;
+    hipError_t e = hipStreamCreateWithFlags(&p->s_bin, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_ov, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready, flags);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipEventCreateWithFlags(&p->binned[k], flags);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->freed[k], flags);
+    }
+    if (e != hipSuccess) {
+        delete p;
+        return fail(CAMA_EHIP, "cama_pipeline_create -> %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return CAMA_OK;
+}
+
+int cama_pipeline_destroy(cama_pipeline *p)
+{
+    if (!p) return CAMA_OK;
+    if (p->s_bin) { (void)hipStreamSynchronize(p->s_bin); (void)hipStreamDestroy(p->s_bin); }
+    if (p->s_ov) { (void)hipStreamSynchronize(p->s_ov); (void)hipStreamDestroy(p->s_ov); }
+    if (p->ready) (void)hipEventDestroy(p->ready);
+    for (int k = 0; k < 2; ++k) {
+        if (p->binned[k]) (void)hipEventDestroy(p->binned[k]);
+        if (p->freed[k]) (void)hipEventDestroy(p->freed[k]);
+    }
+    delete p;
+    return CAMA_OK;
+}
+
+int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
+                         const uint8_t *colour_id, const uint32_t *draw_key, int64_t N, const double *w2c, int32_t F,
+                         const double *c2cam, const double *K, int32_t C, const double *crop, int32_t W, int32_t H,
+                         const uint8_t *src, uint8_t *mosaic, int32_t cols, int32_t radius, const int32_t *halfwidth,
+                         const uint8_t *palette_bgr, void *scratch0, void *scratch1, size_t scratch_bytes,
+                         void *input_stream)
+{
+    if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
+    if (!scratch0 || !scratch1) return fail(CAMA_EINVAL, "two scratch buffers are needed");
+    const int slot = p->turn;
+    void *scratch = slot ? scratch1 : scratch0;
+    // inputs (w2c upload, frames) are complete on the caller's stream at this point
+    HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
+    HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
+    if (p->freed_valid[slot]) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->freed[slot], 0));   // overlay that read this slot
+    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, N, w2c, F, c2cam, K, C, crop, W, H, radius,
+                                 scratch, scratch_bytes, p->s_bin))
+        return rc;
+    HIP_TRY(hipEventRecord(p->binned[slot], p->s_bin));
+    // (overlays stay on ONE stream: two overlays in flight at once interleave their streams in DRAM -- measured
+    // 106.8 k vs 109.9 k frames/s)
+    hipStream_t so = p->s_ov;
+    HIP_TRY(hipStreamWaitEvent(so, p->binned[slot], 0));
+    HIP_TRY(hipStreamWaitEvent(so, p->ready, 0));
+    if (int rc = cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
+                                     scratch_bytes, so))
+        return rc;
+    HIP_TRY(hipEventRecord(p->freed[slot], so));
+    p->freed_valid[slot] = true;
+    p->last = slot;
+    p->any = true;
+    p->turn ^= 1;
+    return CAMA_OK;
+}
+
+int cama_pipeline_join(cama_pipeline *p, void *stream)
+{
+    if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
+    for (int k = 0; k < 2; ++k)
+        if (p->freed_valid[k]) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->freed[k], 0));
+    return CAMA_OK;
+}
+
 size_t cama_stamp_scratch_bytes(int32_t H, int32_t W)
 {
     if (H < 1 || W < 1) return 0;

@@ -415,17 +415,19 @@ class Engine:
 
     # ------------------------------------------------------------------ pipelined render (two streams)
     def _pipeline(self):
-        torch = _torch()
+        import ctypes
         if self._pipe is None:
-            self._pipe = {"bin": torch.cuda.Stream(self.device), "ov": torch.cuda.Stream(self.device),
-                          "slots": [{"buf": None, "free": None} for _ in range(2)], "turn": 0, "last": None}
+            handle = ctypes.c_void_p()
+            _lib.check(self.lib.cama_pipeline_create(ctypes.byref(handle)))
+            self._pipe = {"handle": handle, "scratch": [None, None], "keep": []}
         return self._pipe
 
     def render_frames_pipelined(self, dmap, rig, w2c, src, out, cols=3, crop=None):
-        """Like render_frames, but the binning half runs on a side stream and the overlay half on another, with
-        double-buffered scratch: call k+1's binning overlaps call k's overlay (HBM-bound) instead of queueing
-        behind it.  `src` / `w2c` must be complete on the CURRENT stream at call time; `out` is complete only
-        after join() (which makes the current stream wait for every overlay issued so far)."""
+        """Like render_frames, but through the library's two-stream pipeline (cama_pipeline_render): the binning half
+        runs on one internal stream and the overlay half on another with double-buffered scratch, so call k+1's
+        binning overlaps call k's overlay (HBM-bound) instead of queueing behind it.  `src` / `w2c` must be complete
+        on the CURRENT stream at call time; `out` is complete only after join() (which makes the current stream wait
+        for every overlay issued so far)."""
         torch = _torch()
         cropa = self._crop(crop)
         P = self._pipeline()
@@ -436,41 +438,39 @@ class Engine:
             assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
             assert tuple(src.shape) == (F, rig.C, rig.H, rig.W, 3)
             assert tuple(out.shape) == self.mosaic_shape(rig, F, cols) and out.is_contiguous()
-            need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
-            slot = P["slots"][P["turn"]]
-            P["turn"] ^= 1
-            s_bin, s_ov = P["bin"], P["ov"]
-            ready = torch.cuda.current_stream(self.device).record_event()
-            s_bin.wait_event(ready)
-            if slot["free"] is not None:
-                s_bin.wait_event(slot["free"])            # the overlay that last read this scratch slot is done
-            if slot["buf"] is None or slot["buf"].numel() < need:
-                with torch.cuda.stream(s_bin):
-                    slot["buf"] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
-                slot["buf"].record_stream(s_ov)      # also read by the overlay stream: keep the allocator informed
-            buf = slot["buf"]
+            need = int(self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius))
+            for k in range(2):
+                if P["scratch"][k] is None or P["scratch"][k].numel() < need:
+                    if P["scratch"][k] is not None:
+                        self.join()
+                        torch.cuda.current_stream(self.device).synchronize()     # old buffer may still be in use
+                    P["scratch"][k] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            s0, s1 = P["scratch"]
             x, y, z, col, key = dmap.render_ptrs()
-            _lib.check(self.lib.cama_bin_frames(
-                x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
-                rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, self.radius, buf.data_ptr(), buf.numel(),
-                s_bin.cuda_stream))
-            binned = s_bin.record_event()
-            s_ov.wait_event(binned)
-            _lib.check(self.lib.cama_overlay_frames(
-                src.data_ptr(), out.data_ptr(), dmap.N, F, rig.C, rig.H, rig.W, cols, self.radius,
-                self.halfwidth.ctypes.data, self.palette.ctypes.data, buf.data_ptr(), buf.numel(), s_ov.cuda_stream))
-            slot["free"] = s_ov.record_event()
-            P["last"] = slot["free"]
-            # keep the tensors the side streams read alive until they are done
-            T.record_stream(s_bin)
-            src.record_stream(s_ov)
-            out.record_stream(s_ov)
+            _lib.check(self.lib.cama_pipeline_render(
+                P["handle"], x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
+                rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, src.data_ptr(), out.data_ptr(), cols,
+                self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(),
+                min(s0.numel(), s1.numel()), self._stream()))
+            # the internal streams are invisible to torch's allocator: keep what they read alive until join()
+            P["keep"].append((T, src, out))
+            if len(P["keep"]) > 8:
+                del P["keep"][:-8]
             return out
 
     def join(self):
         """Make the current stream wait for all pipelined overlays issued so far."""
-        if self._pipe is not None and self._pipe["last"] is not None:
-            _torch().cuda.current_stream(self.device).wait_event(self._pipe["last"])
+        if self._pipe is not None:
+            _lib.check(self.lib.cama_pipeline_join(self._pipe["handle"], self._stream()))
+
+    def __del__(self):
+        pipe = getattr(self, "_pipe", None)
+        if pipe is not None:
+            try:
+                self.lib.cama_pipeline_destroy(pipe["handle"])
+            except Exception:
+                pass
+            self._pipe = None
 
     def max_frames_per_call(self, dmap, rig, budget_bytes=4 << 30):
         """Largest F whose worst-case stamp scratch fits `budget_bytes` (and 32-bit stamp offsets)."""

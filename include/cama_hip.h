@@ -150,6 +150,27 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
                         const void *scratch, size_t scratch_bytes, void *stream);
 
 /*
+ * Two-stream pipeline context for callers that render many batches (scenes, or frame ranges of a long scene) back to
+ * back: cama_pipeline_render enqueues cama_bin_frames on an internal stream and cama_overlay_frames on another, so the
+ * binning of batch k+1 overlaps the HBM-bound overlay of batch k; scratch0 / scratch1 (each >=
+ * cama_render_scratch_bytes) are used alternately.  Inputs must be complete on `input_stream` when the call is made;
+ * outputs are complete after cama_pipeline_join(p, stream) in `stream`'s order.  The context owns two HIP streams and
+ * five events (device-scope release, no timing) and no device memory.  One context per thread.
+ */
+typedef struct cama_pipeline cama_pipeline;
+int cama_pipeline_create(cama_pipeline **out);
+int cama_pipeline_destroy(cama_pipeline *p);
+int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
+                         const uint8_t *colour_id, const uint32_t *draw_key, int64_t N,
+                         const double *w2c, int32_t F,
+                         const double *c2cam, const double *K, int32_t C,
+                         const double *crop, int32_t W, int32_t H,
+                         const uint8_t *src, uint8_t *mosaic, int32_t cols,
+                         int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                         void *scratch0, void *scratch1, size_t scratch_bytes, void *input_stream);
+int cama_pipeline_join(cama_pipeline *p, void *stream);
+
+/*
  * EXTENSION (no reference semantics; the reference draws opaque discs, cama/reproject.py:253-256): overlay half with
  * translucent stamps.  A pixel covered by stamps becomes round(alpha*colour + (1-alpha)*source) ONCE, colour = the last
  * writer's; alpha256 = alpha in 1/256, 256 == cama_overlay_frames.  Checked against the oracle's own restatement.
