@@ -23,27 +23,28 @@ struct OverlayArgs {
     MapStride ms;
 };
 
+// one stamp's disc -> atomicMax(draw key) over its footprint rows inside the band
+__device__ __forceinline__ void rasterise_one(uint32_t *s_owner, const uint2 r, int y0, int nrows, int W, const Disc &disc)
+{
+    const int u = (int)(r.x & 0xffffu), v = (int)(r.x >> 16);
+    const uint32_t val = r.y + 1u;  // 0 = no owner
+    const int ylo = max(v - disc.radius, y0), yhi = min(v + disc.radius, y0 + nrows - 1);
+    for (int y = ylo; y <= yhi; ++y) {
+        const int hw = disc.hw[abs(y - v)];
+        if (hw < 0) continue;
+        const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
+        uint32_t *row = s_owner + (y - y0) * W;
+        for (int x = xlo; x <= xhi; ++x) atomicMax(&row[x], val);
+    }
+}
+
 template <int THREADS = OVERLAY_BLOCK>
 __device__ __forceinline__ void rasterise_stamps(uint32_t *s_owner, const uint2 *st, uint32_t n,
                                                  int y0, int nrows, int W, const Disc &disc)
 {
-    for (uint32_t s = threadIdx.x; s < n; s += THREADS) {
-        const uint2 r = st[s];
-        const int u = (int)(r.x & 0xffffu), v = (int)(r.x >> 16);
-        const uint32_t val = r.y + 1u;  // 0 = no owner
-        const int ylo = max(v - disc.radius, y0), yhi = min(v + disc.radius, y0 + nrows - 1);
-        for (int y = ylo; y <= yhi; ++y) {
-            const int hw = disc.hw[abs(y - v)];
-            if (hw < 0) continue;
-            const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
-            uint32_t *row = s_owner + (y - y0) * W;
-            for (int x = xlo; x <= xhi; ++x) atomicMax(&row[x], val);
-        }
-    }
+    for (uint32_t s = threadIdx.x; s < n; s += THREADS) rasterise_one(s_owner, st[s], y0, nrows, W, disc);
 }
 
-// Patch the 16 bytes of chunk `col` of one row with the colours of the owned pixels it overlaps.
-// A chunk starts at byte 16*col = 3*p0 + ph and overlaps exactly pixels p0..p0+5.
 // per-byte (colour*a + source*(256-a) + 128) >> 8 on four packed bytes: even and odd bytes as two 16-bit lanes each
 __device__ __forceinline__ uint32_t blend_bytes(uint32_t src, uint32_t col, uint32_t a)
 {
@@ -133,11 +134,17 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
     const uint32_t n = a.counts[bin];
 
     if (n) {
+        // this thread's first stamp record is fetched BEFORE the table is cleared: its HBM/L2 latency overlaps the clear
+        const uint2 *st = a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]);
+        uint2 first = make_uint2(0u, 0u);
+        if (threadIdx.x < n) first = st[threadIdx.x];
         uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
         const int n4 = (nrows * W + 3) >> 2;
         for (int j = threadIdx.x; j < n4; j += OVERLAY_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
         __syncthreads();
-        rasterise_stamps(s_owner, a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]), n, y0, nrows, W, a.disc);
+        if (threadIdx.x < n) rasterise_one(s_owner, first, y0, nrows, W, a.disc);
+        for (uint32_t s = threadIdx.x + OVERLAY_BLOCK; s < n; s += OVERLAY_BLOCK)
+            rasterise_one(s_owner, st[s], y0, nrows, W, a.disc);
         __syncthreads();
     }
 
