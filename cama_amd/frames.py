@@ -14,6 +14,26 @@ import os
 import numpy as np
 
 
+def read_rgb_or_bgr(path):
+    """(array (H,W,3) uint8, is_rgb): decode without the host-side channel flip (Pillow decodes to RGB; the flip to the
+    reference's BGR order is then done on the device).  cv2 / .npy sources are BGR already."""
+    stem = os.path.splitext(path)[0]
+    if not os.path.exists(path) and os.path.exists(stem + ".npy"):
+        return np.load(stem + ".npy"), False
+    if path.endswith(".npy"):
+        return np.load(path), False
+    try:
+        import cv2
+        img = cv2.imread(path)
+        if img is None:
+            raise FileNotFoundError(path)
+        return img, False
+    except ImportError:
+        from PIL import Image
+        with Image.open(path) as im:
+            return np.array(im.convert("RGB")), True        # own, writable buffer (copied inside the worker thread)
+
+
 def read_bgr(path):
     """(H,W,3) uint8 BGR from a .jpg/.png path; falls back to the `.npy` twin of the same stem."""
     stem = os.path.splitext(path)[0]
@@ -110,7 +130,7 @@ class ClipFrameSource:
         self.device = device
         self.fused = any(cm.needs_resample() for cm in cm_list)     # hand RAW frames to the fused overlay
         self._pool = None
-        self._workers = workers or min(24, (os.cpu_count() or 4))
+        self._workers = workers or min(12, (os.cpu_count() or 4))    # measured: 12 threads peak (~500 images/s), GIL beyond
         self._prefetch = prefetch
         self._pending = {}                                            # image index -> list of futures
 
@@ -123,29 +143,58 @@ class ClipFrameSource:
     def _submit(self, idx):
         if idx not in self._pending:
             ex = self._executor()
-            self._pending[idx] = [ex.submit(read_bgr, cm.get_image_path(idx, True)) for cm in self.cm_list]
+            self._pending[idx] = [ex.submit(read_rgb_or_bgr, cm.get_image_path(idx, True)) for cm in self.cm_list]
         return self._pending[idx]
 
     def _n_frames(self):
         return len(self.cm_list[0].dr.attribute["sync"][self.cm_list[0].camera_name])
 
-    def _decoded(self, image_indices):
-        """host uint8 array [F,C,H0,W0,3] of the requested frames (decoded in parallel, next frame prefetched)."""
+    def _collect(self, image_indices):
+        """[(frame k, camera c, array, is_rgb)] of the requested frames (decoded in parallel, next frames prefetched)."""
         idx = [int(i) for i in image_indices]
         for i in idx:
             self._submit(i)
         for ahead in range(1, int(self._prefetch) + 1):              # keep the decode workers busy
             if idx and idx[-1] + ahead < self._n_frames():
                 self._submit(idx[-1] + ahead)
-        frames = [np.stack([fut.result() for fut in self._pending.pop(i)]) for i in idx]
+        out = []
+        for k, i in enumerate(idx):
+            for c, fut in enumerate(self._pending.pop(i)):
+                arr, is_rgb = fut.result()
+                out.append((k, c, arr, is_rgb))
         for stale in [k for k in self._pending if k < idx[0]]:       # never consumed (skipped frames)
             for fut in self._pending.pop(stale):
                 fut.cancel()
-        return np.stack(frames)
+        return out
+
+    def _decoded(self, image_indices):
+        """host uint8 BGR array [F,C,H0,W0,3] of the requested frames."""
+        items = self._collect(image_indices)
+        F = len(list(image_indices))
+        first = items[0][2]
+        host = np.empty((F, len(self.cm_list)) + first.shape, np.uint8)
+        for k, c, arr, is_rgb in items:
+            host[k, c] = arr[:, :, ::-1] if is_rgb else arr
+        return host
 
     def raw_batch(self, image_indices):
+        """device uint8 BGR tensor [F,C,H0,W0,3]: every image goes to its slot as decoded (no host-side stacking or
+        channel flip: both hold the GIL the decode threads need); RGB-decoded frames are flipped on the device."""
         import torch
-        return torch.from_numpy(self._decoded(image_indices)).to(self.device)
+        items = self._collect(image_indices)
+        F = len(list(image_indices))
+        shape = items[0][2].shape
+        dev = torch.empty((F, len(self.cm_list)) + tuple(shape), dtype=torch.uint8, device=self.device)
+        rgb = torch.zeros((F, len(self.cm_list)), dtype=torch.bool)
+        for k, c, arr, is_rgb in items:
+            dev[k, c].copy_(torch.from_numpy(arr), non_blocking=False)
+            rgb[k, c] = is_rgb
+        if bool(rgb.all()):
+            dev = dev.flip(-1).contiguous()
+        elif bool(rgb.any()):
+            m = rgb.to(self.device)
+            dev[m] = dev[m].flip(-1)
+        return dev
 
     def batch(self, image_indices):
         import torch
