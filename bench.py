@@ -56,9 +56,11 @@ def parse_args():
     ap.add_argument("--shard-frames", action="store_true",
                     help="strong scaling of ONE long scene: every rank renders a contiguous range of its --frames "
                          "(shard.frame_ranges) instead of a scene of its own")
-    ap.add_argument("--map", choices=["lanes", "random"], default="lanes",
+    ap.add_argument("--map", choices=["lanes", "random", "site"], default="lanes",
                     help="lanes: CAMA-style densified polylines along the drive (configs[1..3]); random: --verts "
-                         "uniformly random map vertices over the 600 m map in random order (configs[4] stress)")
+                         "uniformly random map vertices over the 600 m map in random order (configs[4] stress); "
+                         "site: --verts points on 50 m polylines (1 cm spacing) spread over the whole 600 m map "
+                         "(configs[3]: site-aggregated labels, ~5 %% inside the crop box at a time)")
     ap.add_argument("--raw-frames", action="store_true",
                     help="frames resident at sensor size 1600x900 and resampled (undistort+resize) to --height x "
                          "--width on the device inside every step: the reference's default 540x960 pipeline")
@@ -84,6 +86,20 @@ def build_scene(args, seed, device):
     make_clip(clip, n_frames=args.frames + 1, seed=rank, n_lines=n_lines, verts_per_line=11, line_len_m=5.0,
               raster_size=3000, origin_size=(900, 1600), with_nuscenes=False, extra_labels=False)
     cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W)), clip)
+    if args.map == "site":
+        # site-aggregated map: long polylines with random headings all over the 600 m extent, stored polyline-major
+        rng = np.random.default_rng(2000 + rank)
+        per_line = 5000                                            # 50 m at 1 cm
+        n_l = max(1, args.verts // per_line)
+        t = (np.arange(per_line) * 0.01)[None, :]
+        p0 = rng.uniform(-290, 240, (n_l, 2))
+        ang = rng.uniform(0, 2 * np.pi, n_l)
+        x = p0[:, 0:1] + t * np.cos(ang)[:, None]
+        y = p0[:, 1:2] + t * np.sin(ang)[:, None] + 0.3 * np.sin(t * 0.2)
+        z = rng.normal(0, 0.05, (n_l, per_line))
+        pts = np.stack([x, y, z], axis=-1).astype(np.float32)
+        cls = ["lane_marking", "Road_teeth", "Crosswalk_Line"]
+        cm.instance_maps["cama"] = [{"class": cls[i % 3], "points": pts[i]} for i in range(n_l)]
     if args.map == "random":
         # stress map: uniformly random vertices, no spatial coherence between consecutive draw indices.
         # instance_maps is the reference's public per-clip dict (cama/dataset.py:13-24): replace the static map.
@@ -260,7 +276,7 @@ def main():
             "scaling": "strong" if args.shard_frames else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %d scene(s) over %d GPU(s), 6 cams x %d frames, %d densified "
-                                   "verts, %dx%d, frames resident in HBM" % (4 if args.map == "random" else 2 if n_scenes > world else 1,
+                                   "verts, %dx%d, frames resident in HBM" % (4 if args.map == "random" else 3 if args.map == "site" else 2 if n_scenes > world else 1,
                                                                            n_scenes, world, F, N, W, H),
                        "scenes": n_scenes,
                        "frames_per_step": F, "verts": N, "width": W, "height": H, "map": args.map,

@@ -142,7 +142,7 @@ int log2i(int v)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct ScratchLayout {
-    size_t counts, cursor, bin_off, fc_total, fc_base, stamps, total;
+    size_t counts, cursor, work_count, bin_off, fc_total, fc_base, stamps, work, list_cap, total;
     uint64_t capacity;
     int R, NB, bands_per_stamp;
 };
@@ -157,12 +157,29 @@ int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLay
     size_t off = 0;
     L.counts = off;   off = align_up(off + nbins * 4, 256);
     L.cursor = off;   off = align_up(off + nbins * 4, 256);
+    L.work_count = off; off += 256;          // zeroed together with counts and cursor
     L.bin_off = off;  off = align_up(off + nbins * 4, 256);
     L.fc_total = off; off = align_up(off + nfc * 4, 256);
     L.fc_base = off;  off = align_up(off + nfc * 4, 256);
     L.stamps = off;   off = align_up(off + (size_t)L.capacity * 8, 256);
+    // work lists of the crop cull: 8 (one per XCD), each up to ceil(vblocks / 8) * F uint32 items
+    L.list_cap = (size_t)(((N + BLOCK - 1) / BLOCK + 7) / 8) * (size_t)F;
+    L.work = off;     off = align_up(off + 8 * L.list_cap * 4, 256);
     L.total = off;
     return 0;
+}
+
+// (block, frame) items from which the crop cull goes through a work list + persistent workgroups; and how many of those
+// workgroups (256 CUs x 8 resident).  Env overrides are for A/B measurements only.
+uint64_t cull_list_threshold()
+{
+    static const uint64_t v = getenv("CAMA_CULL_LIST_MIN") ? strtoull(getenv("CAMA_CULL_LIST_MIN"), nullptr, 10) : 16384ull;
+    return v;
+}
+unsigned persistent_workgroups()
+{
+    static const unsigned v = getenv("CAMA_PERSISTENT_WGS") ? (unsigned)atoi(getenv("CAMA_PERSISTENT_WGS")) : 2048u;
+    return v ? (v + 7u) & ~7u : 2048u;
 }
 
 int check_common(int64_t N, int F, int C, int W, int H)
@@ -329,8 +346,26 @@ static int check_render(int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, i
     return CAMA_OK;
 }
 
+int cama_map_bounds_block(void) { return BLOCK; }
+
+int cama_map_bounds(const void *x, const void *y, const void *z, int32_t xyz_is_f64, int64_t N, double *bounds,
+                    void *stream)
+{
+    if (N < 0) return fail(CAMA_EINVAL, "N=%lld", (long long)N);
+    if (N == 0) return CAMA_OK;
+    if (!x || !y || !z || !bounds) return fail(CAMA_EINVAL, "NULL pointer argument");
+    const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK));
+    if (xyz_is_f64)
+        hipLaunchKernelGGL(k_block_bounds<double>, grid, dim3(BLOCK), 0, (hipStream_t)stream, x, y, z, N, bounds);
+    else
+        hipLaunchKernelGGL(k_block_bounds<float>, grid, dim3(BLOCK), 0, (hipStream_t)stream, x, y, z, N, bounds);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
 int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
-                    const uint32_t *draw_key, int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                    const uint32_t *draw_key, const double *block_bounds, int64_t N, const double *w2c, int32_t F,
+                    const double *c2cam, const double *K, int32_t C,
                     const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch, size_t scratch_bytes,
                     void *stream)
 {
@@ -347,11 +382,11 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     uint32_t *fc_base = (uint32_t *)(base + L.fc_base);
     const int nfc = F * C;
 
-    // counts and cursor are adjacent: one memset
+    // counts, cursor and the work-list counter are adjacent: one memset
     HIP_TRY(hipMemsetAsync(counts, 0, L.bin_off - L.counts, s));
 
     FrameArgs a{};
-    a.x = x; a.y = y; a.z = z; a.colour = colour_id; a.key = draw_key; a.N = N;
+    a.x = x; a.y = y; a.z = z; a.colour = colour_id; a.key = draw_key; a.bounds = block_bounds; a.N = N;
     a.w2c = w2c; a.c2cam = c2cam; a.K = K; a.C = C; a.W = W; a.H = H;
     memcpy(a.crop.v, crop, sizeof(a.crop.v));
     a.band_shift = log2i(L.R); a.NB = L.NB; a.radius = radius;
@@ -364,7 +399,25 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     const unsigned vblocks = (unsigned)((N + BLOCK - 1) / BLOCK);
     const dim3 fgrid(getenv("CAMA_NO_XCD_PAD") ? vblocks : ((vblocks + 7u) & ~7u), (unsigned)F);
     const size_t hist_lds = align_up((size_t)C * L.NB * 4, 16);
-    if (N) {
+    // Many (block, frame) items and a spatial index: cull them one thread per item into a work list and let persistent
+    // workgroups walk the survivors (an empty workgroup still costs ~0.8 ns of dispatch; 1.25 M of them = 1 ms).
+    const bool use_list = block_bounds && (uint64_t)vblocks * (uint64_t)F >= cull_list_threshold();
+    uint32_t *work_count = (uint32_t *)(base + L.work_count), *work = (uint32_t *)(base + L.work);
+    const dim3 lgrid(persistent_workgroups());
+    if (N && use_list) {
+        Crop cr;
+        memcpy(cr.v, crop, sizeof(cr.v));
+        hipLaunchKernelGGL(k_cull_blocks, dim3((vblocks + BLOCK - 1) / BLOCK, (unsigned)F), dim3(BLOCK), 0, s, block_bounds,
+                           w2c, cr, vblocks, (uint32_t)L.list_cap, work_count, work);
+        HIP_TRY(hipGetLastError());
+        if (xyz_is_f64)
+            hipLaunchKernelGGL((k_frames_bin_list<MODE_COUNT, double>), lgrid, dim3(BLOCK), hist_lds, s, a, work_count, work,
+                               vblocks, (uint32_t)L.list_cap);
+        else
+            hipLaunchKernelGGL((k_frames_bin_list<MODE_COUNT, float>), lgrid, dim3(BLOCK), hist_lds, s, a, work_count, work,
+                               vblocks, (uint32_t)L.list_cap);
+        HIP_TRY(hipGetLastError());
+    } else if (N) {
         if (xyz_is_f64)
             hipLaunchKernelGGL((k_frames_bin<MODE_COUNT, double>), fgrid, dim3(BLOCK), hist_lds, s, a);
         else
@@ -375,7 +428,15 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(64), 0, s, fc_total, fc_base, nfc);
     HIP_TRY(hipGetLastError());
-    if (N) {
+    if (N && use_list) {
+        if (xyz_is_f64)
+            hipLaunchKernelGGL((k_frames_bin_list<MODE_FILL, double>), lgrid, dim3(BLOCK), 2 * hist_lds, s, a, work_count,
+                               work, vblocks, (uint32_t)L.list_cap);
+        else
+            hipLaunchKernelGGL((k_frames_bin_list<MODE_FILL, float>), lgrid, dim3(BLOCK), 2 * hist_lds, s, a, work_count,
+                               work, vblocks, (uint32_t)L.list_cap);
+        HIP_TRY(hipGetLastError());
+    } else if (N) {
         if (xyz_is_f64)
             hipLaunchKernelGGL((k_frames_bin<MODE_FILL, double>), fgrid, dim3(BLOCK), 2 * hist_lds, s, a);
         else
@@ -527,7 +588,8 @@ int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const fl
 }
 
 int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
-                       const uint32_t *draw_key, int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                       const uint32_t *draw_key, const double *block_bounds, int64_t N, const double *w2c, int32_t F,
+                       const double *c2cam, const double *K, int32_t C,
                        const double *crop, int32_t W, int32_t H, const uint8_t *src, uint8_t *mosaic, int32_t cols,
                        int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
                        size_t scratch_bytes, void *stream)
@@ -535,7 +597,7 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
     // validate the overlay half first so that nothing is enqueued when it would be rejected
     if (F > 0 && (!src || !mosaic || !palette_bgr || !halfwidth || cols < 1))
         return check_common(N, F, C, W, H) ? CAMA_EINVAL : fail(CAMA_EINVAL, "NULL pointer argument");
-    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, N, w2c, F, c2cam, K, C, crop, W, H, radius, scratch,
+    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, N, w2c, F, c2cam, K, C, crop, W, H, radius, scratch,
                                  scratch_bytes, stream))
         return rc;
     return cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch, scratch_bytes,
@@ -642,7 +704,8 @@ int cama_pipeline_destroy(cama_pipeline *p)
 }
 
 int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                         const uint8_t *colour_id, const uint32_t *draw_key, int64_t N, const double *w2c, int32_t F,
+                         const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int64_t N,
+                         const double *w2c, int32_t F,
                          const double *c2cam, const double *K, int32_t C, const double *crop, int32_t W, int32_t H,
                          const uint8_t *src, uint8_t *mosaic, int32_t cols, int32_t radius, const int32_t *halfwidth,
                          const uint8_t *palette_bgr, void *scratch0, void *scratch1, size_t scratch_bytes,
@@ -656,7 +719,7 @@ int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const v
     HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
     HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
     if (p->freed_valid[slot]) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->freed[slot], 0));   // overlay that read this slot
-    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, N, w2c, F, c2cam, K, C, crop, W, H, radius,
+    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, N, w2c, F, c2cam, K, C, crop, W, H, radius,
                                  scratch, scratch_bytes, p->s_bin))
         return rc;
     HIP_TRY(hipEventRecord(p->binned[slot], p->s_bin));

@@ -139,10 +139,72 @@ __global__ __launch_bounds__(BLOCK) void k_project_points(const double *__restri
 // ------------------------------------------------------------------------------------------
 enum { MODE_EMIT = 0, MODE_COUNT = 1, MODE_FILL = 2 };
 
+// Conservative "no vertex of this block can be inside the crop box" test on the block's world-space AABB
+// {xlo,xhi,ylo,yhi,zlo,zhi}: the chassis-frame extent of the box along each crop axis is centre +- sum|m_k|*half,
+// widened by a margin 7 orders above fp64 rounding, so a block is skipped only when in_crop() is false for every
+// vertex in it -- the result is bit-identical with and without the cull.  Every comparison is false on NaN/inf, i.e.
+// "not culled".
+__device__ __forceinline__ bool block_outside_crop(const double *m, const double *b, const Crop &crop)
+{
+    const double mx = 0.5 * (b[0] + b[1]), my = 0.5 * (b[2] + b[3]), mz = 0.5 * (b[4] + b[5]);
+    const double ex = 0.5 * (b[1] - b[0]), ey = 0.5 * (b[3] - b[2]), ez = 0.5 * (b[5] - b[4]);
+    bool out = false;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double c0 = m[4 * r], c1 = m[4 * r + 1], c2 = m[4 * r + 2], c3 = m[4 * r + 3];
+        const double mid = c0 * mx + c1 * my + c2 * mz + c3;
+        const double rad = fabs(c0) * ex + fabs(c1) * ey + fabs(c2) * ez;
+        const double mag = fabs(c0 * mx) + fabs(c1 * my) + fabs(c2 * mz) + fabs(c3) + rad;
+        const double margin = 1e-6 + 1e-9 * mag;
+        out |= (mid + rad + margin < crop.v[2 * r]) | (mid - rad - margin > crop.v[2 * r + 1]);
+    }
+    return out;
+}
+
+// Per-block AABB of the vertex buffer (block = the BLOCK vertices one k_frames_bin workgroup owns).  NaN coordinates
+// are ignored by fmin/fmax (such a vertex is never inside the crop box); an all-NaN block yields an empty box.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_block_bounds(const void *x, const void *y, const void *z, int64_t N,
+                                                        double *__restrict__ bounds)
+{
+    __shared__ double s_part[BLOCK / 64][6];
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const double inf = __builtin_huge_val();
+    double v[6] = {inf, -inf, inf, -inf, inf, -inf};
+    if (i < N) {
+        v[0] = v[1] = (double)static_cast<const T *>(x)[i];
+        v[2] = v[3] = (double)static_cast<const T *>(y)[i];
+        v[4] = v[5] = (double)static_cast<const T *>(z)[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (v[k] != v[k]) v[k] = (k & 1) ? -inf : inf;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 6; k += 2) {
+            v[k] = fmin(v[k], __shfl_xor(v[k], off, 64));
+            v[k + 1] = fmax(v[k + 1], __shfl_xor(v[k + 1], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_part[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double r = s_part[0][threadIdx.x];
+        for (int w = 1; w < BLOCK / 64; ++w)
+            r = (threadIdx.x & 1) ? fmax(r, s_part[w][threadIdx.x]) : fmin(r, s_part[w][threadIdx.x]);
+        bounds[(size_t)blockIdx.x * 6 + threadIdx.x] = r;
+    }
+}
+
 struct FrameArgs {
     const void *x, *y, *z;  // [N] each, float or double (template parameter T)
     const uint8_t *colour;
     const uint32_t *key;    // optional [N]: draw index << 1 | colour (maps stored in a different order than drawn)
+    const double *bounds;   // optional [ceil(N/BLOCK),6]: per-vertex-block AABB (k_block_bounds), for the crop cull
     int64_t N;
     const double *w2c, *c2cam, *K;
     int C, W, H;
@@ -198,19 +260,24 @@ __global__ __launch_bounds__(BLOCK) void k_frames_emit(FrameArgs a)
 // atomic per non-empty bin per workgroup, so nothing serialises on HBM/L2 latency.
 constexpr int CAM_GROUP = 8;  // cameras ranked per pass through the workgroup protocol (register-resident entries)
 
-template <int MODE, typename T>
-__global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
+// One (vertex block, frame) work item of the binning passes.  `cams_ready` (workgroup-uniform) lets a persistent
+// workgroup stage the cameras once for all its items.  CULL: test the block's AABB first (grid-per-item launch).
+template <int MODE, typename T, bool CULL>
+__device__ __forceinline__ void bin_block(const FrameArgs &a, const int64_t vblock, const int f, uint32_t *s_hist,
+                                          double *s_cam, bool &cams_ready)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [C*NB] counts, then (fill) [C*NB] bases
-    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
-    const int f = blockIdx.y;
     const int nloc = a.C * a.NB;
     uint32_t *s_cnt = s_hist, *s_base = s_hist + nloc;
 
     // world->chassis + crop FIRST, with the frame's matrix read through wave-uniform (scalar) loads: on site-sized
     // maps ~95 % of the workgroups end here and never pay for staging the cameras or clearing the histogram
     const double *w2c = a.w2c + (size_t)f * 16;
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t i = vblock * BLOCK + threadIdx.x;
+    // ... and with the map's block AABBs (cama_map_bounds) those workgroups do not even read their vertices
+    if (CULL && a.bounds) {
+        if (vblock * BLOCK >= a.N) return;
+        if (block_outside_crop(w2c, a.bounds + (size_t)vblock * 6, a.crop)) return;
+    }
     double cx = 0, cy = 0, cz = 0;
     bool in = false;
     uint32_t key = 0;
@@ -225,7 +292,10 @@ __global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
     }
     // whole workgroup outside the crop box (the common case on site-sized maps): done
     if (!__syncthreads_or((int)in)) return;
-    stage_cameras(s_cam, a.c2cam, a.K, a.C);
+    if (!cams_ready) {
+        stage_cameras(s_cam, a.c2cam, a.K, a.C);
+        cams_ready = true;
+    }
     for (int t = threadIdx.x; t < nloc; t += BLOCK) s_cnt[t] = 0u;
     __syncthreads();
 
@@ -291,6 +361,57 @@ __global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
             const uint32_t n = s_cnt[t];
             if (n) atomicAdd(&a.counts[gbin0 + t], n);
         }
+    }
+}
+
+template <int MODE, typename T>
+__global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [C*NB] counts, then (fill) [C*NB] bases
+    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+    bool cams_ready = false;
+    bin_block<MODE, T, true>(a, (int64_t)blockIdx.x, (int)blockIdx.y, s_hist, s_cam, cams_ready);
+}
+
+// Site-sized maps: F * ceil(N/BLOCK) work items, ~95 % of them outside the crop box.  Even an empty workgroup costs
+// ~0.8 ns of dispatch (measured: 1.25 M workgroups / ms), so the items are culled first, one THREAD per item, into
+// work lists (k_cull_blocks), and persistent workgroups walk the survivors.  There is one list per XCD: vertex block b
+// always goes to list b % 8 and list l is walked by the workgroups with blockIdx.x % 8 == l, i.e. (round-robin
+// dispatch) by XCD l, so every XCD's L2 keeps its eighth of the live vertex blocks across all frames.
+__global__ __launch_bounds__(BLOCK) void k_cull_blocks(const double *__restrict__ bounds, const double *__restrict__ w2c,
+                                                       Crop crop, uint32_t vblocks, uint32_t list_cap,
+                                                       uint32_t *__restrict__ work_count, uint32_t *__restrict__ work)
+{
+    const uint32_t b = blockIdx.x * BLOCK + threadIdx.x, f = blockIdx.y;   // b % 8 == lane % 8
+    bool keep = false;
+    if (b < vblocks) keep = !block_outside_crop(w2c + (size_t)f * 16, bounds + (size_t)b * 6, crop);
+    const uint64_t m = __ballot(keep);
+    if (!m) return;
+    // one atomic per (wave, list): lane l < 8 reserves for list l, whose members are the lanes = l (mod 8)
+    const uint32_t lane = __lane_id();
+    const uint64_t mine = m & (0x0101010101010101ull << (lane & 7u));
+    uint32_t base = 0;
+    if (lane < 8u && mine) base = atomicAdd(&work_count[lane], (uint32_t)__popcll(mine));
+    base = __shfl(base, (int)(lane & 7u), 64);
+    if (keep)
+        work[(size_t)(lane & 7u) * list_cap + base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = f * vblocks + b;
+}
+
+template <int MODE, typename T>
+__global__ __launch_bounds__(BLOCK) void k_frames_bin_list(FrameArgs a, const uint32_t *__restrict__ work_count,
+                                                           const uint32_t *__restrict__ work, uint32_t vblocks,
+                                                           uint32_t list_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
+    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+    bool cams_ready = false;
+    const uint32_t list = blockIdx.x & 7u;          // gridDim.x is a multiple of 8
+    const uint32_t n = work_count[list];
+    work += (size_t)list * list_cap;
+    for (uint32_t w = blockIdx.x >> 3; w < n; w += gridDim.x >> 3) {
+        const uint32_t item = work[w];
+        // the barrier at the top of bin_block (__syncthreads_or) also fences the previous item's LDS reads
+        bin_block<MODE, T, false>(a, (int64_t)(item % vblocks), (int)(item / vblocks), s_hist, s_cam, cams_ready);
     }
 }
 

@@ -8,6 +8,7 @@ Reference semantics implemented by the kernels: cama/dataset.py:99-117, cama/rep
 187-205,246-257, cama/tools.py:22-25 (paths under /root/reference).
 """
 import numpy as np
+import os
 
 from . import _lib
 
@@ -86,19 +87,52 @@ class DeviceMap:
             key = ((order.astype(np.uint32) << np.uint32(1)) | (colour_id[order] & 1).astype(np.uint32))
             self.sorted_soa = torch.from_numpy(np.ascontiguousarray(xyz[order].T)).to(device)
             self.sorted_key = torch.from_numpy(np.ascontiguousarray(key)).to(device)
+        self._index()
+
+    def _index(self):
+        """Spatial index for the fused render's crop step: per-block AABBs of the buffer it reads (cama_map_bounds,
+        include/cama_hip.h) + the map's overall XY extent (host), which decides whether the index is worth using."""
+        torch = _torch()
+        self.bounds, self.extent_xy = None, (0.0, 0.0)
+        if not self.N or os.environ.get("CAMA_NO_BOUNDS"):
+            return
+        L = _lib.lib()
+        blk = L.cama_map_bounds_block()
+        device = self.soa.device
+        with torch.cuda.device(device):
+            self.bounds = torch.empty(((self.N + blk - 1) // blk, 6), dtype=torch.float64, device=device)
+            x, y, z = self.render_ptrs()[:3]
+            _lib.check(L.cama_map_bounds(x, y, z, self.is_f64, self.N, self.bounds.data_ptr(),
+                                         torch.cuda.current_stream(device).cuda_stream))
+            lo = self.bounds[:, 0:4:2].min(dim=0).values
+            hi = self.bounds[:, 1:4:2].max(dim=0).values
+            ext = (hi - lo).cpu().numpy()
+        self.extent_xy = tuple(float(e) if np.isfinite(e) and e > 0 else 0.0 for e in ext)
+
+    def site_sized(self, crop):
+        """True when the map's XY footprint is well beyond the crop box (site-aggregated maps: most vertex blocks are
+        outside it on any frame) -- then the block cull pays; on clip-sized maps nearly every block survives and the
+        plain grid launch is faster (measured: 29.8k vs 25.5k frames/s on 10^6 in-crop points)."""
+        crop_area = float(crop[1] - crop[0]) * float(crop[3] - crop[2])
+        return self.extent_xy[0] * self.extent_xy[1] > 2.0 * crop_area
 
     def ptrs(self):
         es = self.soa.element_size()
         base = self.soa.data_ptr()
         return base, base + self.N * es, base + 2 * self.N * es
 
-    def render_ptrs(self):
-        """(x, y, z, colour, key) device pointers for the fused render: the sorted copy when there is one."""
+    def render_ptrs(self, crop=None):
+        """(x, y, z, colour, key, block bounds) device pointers for the fused render: the sorted copy when there is
+        one; the bounds only for maps that are site-sized against `crop`."""
+        bounds = None
+        if crop is not None and getattr(self, "bounds", None) is not None and self.site_sized(crop):
+            bounds = self.bounds.data_ptr()
         if self.sorted_soa is None:
-            return self.ptrs() + (self.colour.data_ptr(), None)
+            return self.ptrs() + (self.colour.data_ptr(), None, bounds)
         es = self.sorted_soa.element_size()
         base = self.sorted_soa.data_ptr()
-        return base, base + self.N * es, base + 2 * self.N * es, self.colour.data_ptr(), self.sorted_key.data_ptr()
+        return (base, base + self.N * es, base + 2 * self.N * es, self.colour.data_ptr(), self.sorted_key.data_ptr(),
+                bounds)
 
 
 class Engine:
@@ -154,6 +188,7 @@ class Engine:
             dmap = DeviceMap.__new__(DeviceMap)
             dmap.N, dmap.is_f64, dmap.soa, dmap.colour = N, int(is64), soa, colour
             dmap.sorted_soa = dmap.sorted_key = None
+            dmap.bounds, dmap.extent_xy = None, (0.0, 0.0)
             if N == 0:
                 return dmap
             up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
@@ -176,7 +211,8 @@ class Engine:
                 None if raster is None else raster.data_ptr(), int(is64), rows, cols,
                 f32(solution), f32(map_width / 2), f32(map_height / 2), f32(center_x), f32(center_y),
                 base, base + N * es, base + 2 * N * es, colour.data_ptr(), self._stream()))
-            torch.cuda.current_stream(self.device).synchronize()      # the uploads above go out of scope here
+            dmap._index()                                             # synchronises: the uploads above may go now
+            torch.cuda.current_stream(self.device).synchronize()
             return dmap
 
     def upload_map(self, xyz, colour_id, spatial_sort="auto"):
@@ -277,10 +313,10 @@ class Engine:
             assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.uint8
             need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
             scratch = self._scratch_buf(need)
-            x, y, z, col, key = dmap.render_ptrs()
+            x, y, z, col, key, bnd = dmap.render_ptrs(cropa)
             if self.alpha256 != 256:        # extension path: binning + translucent overlay
                 _lib.check(self.lib.cama_bin_frames(
-                    x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(),
+                    x, y, z, dmap.is_f64, col, key, bnd, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(),
                     rig.C, cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(),
                     self._stream()))
                 _lib.check(self.lib.cama_overlay_frames_alpha(
@@ -289,7 +325,7 @@ class Engine:
                     scratch.numel(), self._stream()))
                 return out
             _lib.check(self.lib.cama_render_frames(
-                x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F,
+                x, y, z, dmap.is_f64, col, key, bnd, dmap.N, T.data_ptr(), F,
                 rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H,
                 src.data_ptr(), out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
                 self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), self._stream()))
@@ -400,10 +436,10 @@ class Engine:
             mapx, mapy, sep, band_rows, max_rows, tiles, tiles_x, max_tile = self.rig_maps(cm_list)
             need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
             scratch = self._scratch_buf(need)
-            x, y, z, col, key = dmap.render_ptrs()
+            x, y, z, col, key, bnd = dmap.render_ptrs(cropa)
             st = self._stream()
             _lib.check(self.lib.cama_bin_frames(
-                x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
+                x, y, z, dmap.is_f64, col, key, bnd, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
                 cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(), st))
             _lib.check(self.lib.cama_overlay_frames_raw(
                 raw.data_ptr(), H0, W0, mapx.data_ptr(), mapy.data_ptr(), sep,
@@ -446,9 +482,9 @@ class Engine:
                         torch.cuda.current_stream(self.device).synchronize()     # old buffer may still be in use
                     P["scratch"][k] = torch.empty(need, dtype=torch.uint8, device=self.device)
             s0, s1 = P["scratch"]
-            x, y, z, col, key = dmap.render_ptrs()
+            x, y, z, col, key, bnd = dmap.render_ptrs(cropa)
             _lib.check(self.lib.cama_pipeline_render(
-                P["handle"], x, y, z, dmap.is_f64, col, key, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
+                P["handle"], x, y, z, dmap.is_f64, col, key, bnd, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
                 rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, src.data_ptr(), out.data_ptr(), cols,
                 self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(),
                 min(s0.numel(), s1.numel()), self._stream()))

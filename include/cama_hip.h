@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 1
+#define CAMA_ABI_VERSION 2
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -111,6 +111,9 @@ int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz
  *   draw_key   NULL, or [N] uint32 = (draw index << 1) | colour for vertex buffers stored in another order than
  *              they are drawn (e.g. spatially sorted): "last writer wins" follows the draw index, not storage
  *              order; colour_id is ignored when draw_key is given
+ *   block_bounds NULL, or the map's per-block AABBs from cama_map_bounds(): vertex blocks that cannot reach the crop
+ *              box are skipped without reading their vertices (site-sized maps: ~95 % of them).  Conservative, so
+ *              the output is bit-identical with and without it
  *   w2c        [F,16]             c2cam [C,16]   K [C,9]   crop host[6]
  *   src        [F,C,H,W,3] uint8 BGR frames (already at output size)
  *   mosaic     [F, rows*H, cols*W, 3] uint8, rows = ceil(C/cols); camera c goes to cell
@@ -122,8 +125,18 @@ int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz
  *   scratch    device scratch of at least cama_render_scratch_bytes(...) bytes
  */
 size_t cama_render_scratch_bytes(int64_t N, int32_t F, int32_t C, int32_t H, int32_t W, int32_t radius);
+
+/*
+ * Spatial index of a static map for the crop step (MapManager.crop_3d_instance_maps, cama/reproject.py:118-131, which
+ * the reference evaluates for every vertex of the site map on every frame): bounds[b] = {xlo,xhi,ylo,yhi,zlo,zhi} of
+ * vertices [b*B, (b+1)*B), B = cama_map_bounds_block(); bounds is device double[ceil(N/B)*6].  Computed once per
+ * map (or per spatially sorted copy), passed as `block_bounds` to the render entries.
+ */
+int cama_map_bounds_block(void);
+int cama_map_bounds(const void *x, const void *y, const void *z, int32_t xyz_is_f64, int64_t N, double *bounds,
+                    void *stream);
 int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                       const uint8_t *colour_id, const uint32_t *draw_key, int64_t N,
+                       const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int64_t N,
                        const double *w2c, int32_t F,
                        const double *c2cam, const double *K, int32_t C,
                        const double *crop, int32_t W, int32_t H,
@@ -139,7 +152,7 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
  * orders the overlay after its own binning (stream order or an event).  Arguments as above.
  */
 int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                    const uint8_t *colour_id, const uint32_t *draw_key, int64_t N,
+                    const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int64_t N,
                     const double *w2c, int32_t F,
                     const double *c2cam, const double *K, int32_t C,
                     const double *crop, int32_t W, int32_t H, int32_t radius,
@@ -161,7 +174,7 @@ typedef struct cama_pipeline cama_pipeline;
 int cama_pipeline_create(cama_pipeline **out);
 int cama_pipeline_destroy(cama_pipeline *p);
 int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                         const uint8_t *colour_id, const uint32_t *draw_key, int64_t N,
+                         const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int64_t N,
                          const double *w2c, int32_t F,
                          const double *c2cam, const double *K, int32_t C,
                          const double *crop, int32_t W, int32_t H,

@@ -201,7 +201,7 @@ def test_bad_arguments_fail_loudly(engine):
     L = _lib.lib()
     assert L.cama_project_points(None, 10, None, None, 6, 10, 10, None, None, None) == -1
     assert b"NULL" in L.cama_last_error()
-    assert L.cama_render_frames(None, None, None, 0, None, None, 0, None, 1, None, None, 99, None, 10, 10, None, None, 3, 2,
+    assert L.cama_render_frames(None, None, None, 0, None, None, None, 0, None, 1, None, None, 99, None, 10, 10, None, None, 3, 2,
                                 None, None, None, 0, None) == -1
     assert b"C=99" in L.cama_last_error()
 
@@ -324,6 +324,86 @@ def test_spatially_sorted_map_renders_identically(engine):
     vu, vis, _ = (t.cpu().numpy() for t in engine.project_frames(auto, rig, w2c))
     flat = O.frame_project_flat(xyz, w2c[0], cams, W, H)
     assert np.array_equal(vis[0], flat["vis"])
+
+
+def test_block_bounds_match_numpy(engine):
+    """cama_map_bounds: per-256-vertex AABBs, ragged tail, NaNs ignored, all-NaN block = empty box."""
+    import torch
+    from cama_amd import _lib
+    L = _lib.lib()
+    blk = L.cama_map_bounds_block()
+    rng = np.random.default_rng(3)
+    for dt in (np.float32, np.float64):
+        N = 5 * blk + 37
+        xyz = (rng.normal(0, 100, (N, 3))).astype(dt)
+        xyz[rng.integers(0, N, 50), rng.integers(0, 3, 50)] = np.nan
+        xyz[2 * blk:3 * blk] = np.nan
+        dm = engine.upload_map(xyz, np.zeros(N, np.uint8), spatial_sort=False)
+        got = dm.bounds.cpu().numpy()
+        assert got.shape == (6, 6)
+        for b in range(6):
+            chunk = xyz[b * blk:(b + 1) * blk].astype(np.float64)
+            for k in range(3):
+                col = chunk[:, k][~np.isnan(chunk[:, k])]
+                lo, hi = (col.min(), col.max()) if col.size else (np.inf, -np.inf)
+                assert got[b, 2 * k] == lo and got[b, 2 * k + 1] == hi
+
+
+@pytest.mark.parametrize("n_l,F", [(120, 5), (600, 15)])
+def test_crop_cull_by_block_bounds_is_invisible(engine, n_l, F):
+    """Site-sized map (polylines over +-300 m, ~5 % inside the crop box): rendering with the block-AABB cull, without
+    it, and the oracle (which crops every vertex, reproject.py:118-131) give the same bytes -- including vertices
+    exactly ON the crop faces, blocks straddling them, a frame far outside the map, and NaN vertices.  The second
+    size has >= 16384 (block, frame) items: the work-list + persistent-workgroup path (k_cull_blocks)."""
+    import torch
+    from cama_amd.engine import CROP_BOX
+    W, H = 320, 180
+    rng = np.random.default_rng(23)
+    per = 512
+    assert (n_l * per // 256) * F >= 16384 or n_l < 200
+    t = (np.arange(per) * 0.1)[None, :]
+    p0 = rng.uniform(-300, 250, (n_l, 2))
+    ang = rng.uniform(0, 2 * np.pi, n_l)
+    xyz = np.stack([p0[:, 0:1] + t * np.cos(ang)[:, None], p0[:, 1:2] + t * np.sin(ang)[:, None],
+                    rng.normal(0, 0.05, (n_l, per))], -1).reshape(-1, 3).astype(np.float32)
+    # frame 0 is the identity pose: put vertices exactly on each crop face (inclusive bounds) and one ulp outside
+    xmin, xmax, ymin, ymax, zmin, zmax = CROP_BOX
+    faces = np.array([[xmin, 0, 0], [xmax, 0, 0], [5, ymin, 0], [5, ymax, 0], [5, 1, zmin], [5, 1, zmax]], np.float32)
+    outside = faces.copy()
+    for k, (axis, sign) in enumerate([(0, -1), (0, 1), (1, -1), (1, 1), (2, -1), (2, 1)]):
+        outside[k, axis] = np.nextafter(faces[k, axis], np.float32(sign * np.inf), dtype=np.float32)
+    xyz[256 * 3:256 * 3 + 6] = faces
+    xyz[256 * 7:256 * 7 + 6] = outside
+    xyz[256 * 9 + 5] = np.nan
+    col = (rng.random(len(xyz)) < 0.5).astype(np.uint8)
+    _, _, cams, _ = _random_scene(5, 10, 1, W, H)
+    w2c = [np.eye(4)]
+    poses = [(100.0, -50.0, 0.7), (-200.0, 180.0, 2.9), (5000.0, 5000.0, 0.1), (-20.0, 10.0, -1.3)]
+    poses += [(rng.uniform(-280, 280), rng.uniform(-280, 280), rng.uniform(-3, 3)) for _ in range(F - 5)]
+    for (px, py, a) in poses:
+        T = np.eye(4)
+        T[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+        T[:3, 3] = [px, py, 0.01]
+        w2c.append(np.linalg.inv(T.astype(np.float32)))
+    w2c = np.stack(w2c).astype(np.float64)
+    rig = _rig(engine, cams)
+    src = rng.integers(0, 256, (F, 6, H, W, 3), dtype=np.uint8)
+    with_b = engine.upload_map(xyz, col, spatial_sort=False)
+    without = engine.upload_map(xyz, col, spatial_sort=False)
+    assert with_b.bounds is not None
+    without.bounds = None
+    a = engine.render_frames(with_b, rig, w2c, torch.from_numpy(src).cuda()).cpu().numpy()
+    b = engine.render_frames(without, rig, w2c, torch.from_numpy(src).cuda()).cpu().numpy()
+    assert np.array_equal(a, b)
+    n_in = []
+    for f in range(F):
+        flat = O.frame_project_flat(xyz, w2c[f], cams, W, H)
+        n_in.append(int(flat["crop_mask"].sum()))
+        assert np.array_equal(a[f], O.frame_render_flat(src[f], flat["vu"], flat["vis"], col))
+    assert n_in[3] == 0 and min(n_in[0], n_in[1], n_in[2], n_in[4]) > 50 and max(n_in) < 0.2 * len(xyz), n_in
+    # the on-face vertices are inside (inclusive), their one-ulp neighbours are not
+    flat0 = O.frame_project_flat(xyz, w2c[0], cams, W, H)
+    assert flat0["crop_mask"][256 * 3:256 * 3 + 6].all() and not flat0["crop_mask"][256 * 7:256 * 7 + 6].any()
 
 
 @pytest.mark.parametrize("C", [1, 4, 9])
