@@ -454,7 +454,8 @@ class Engine:
         import ctypes
         if self._pipe is None:
             handle = ctypes.c_void_p()
-            _lib.check(self.lib.cama_pipeline_create(ctypes.byref(handle)))
+            with _torch().cuda.device(self.device):          # its streams live on this engine's GPU
+                _lib.check(self.lib.cama_pipeline_create(ctypes.byref(handle)))
             self._pipe = {"handle": handle, "scratch": [None, None], "keep": []}
         return self._pipe
 
