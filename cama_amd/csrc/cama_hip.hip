@@ -726,8 +726,8 @@ int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const v
     // (overlays stay on ONE stream: two overlays in flight at once interleave their streams in DRAM -- measured
     // 106.8 k vs 109.9 k frames/s)
     hipStream_t so = p->s_ov;
+    // `binned` also carries `ready` (s_bin waited for it above): one barrier packet between overlays, not two
     HIP_TRY(hipStreamWaitEvent(so, p->binned[slot], 0));
-    HIP_TRY(hipStreamWaitEvent(so, p->ready, 0));
     if (int rc = cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
                                      scratch_bytes, so))
         return rc;

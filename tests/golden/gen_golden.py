@@ -33,6 +33,27 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 REFERENCE = "/root/reference"
 
 
+def _drop_cama_modules():
+    for m in [k for k in sys.modules if k == "cama" or k.startswith("cama.")]:
+        del sys.modules[m]
+
+
+def bind_reference_package():
+    """Make `import cama.<x>` resolve to /root/reference/cama.  The reference's `cama/` has no __init__.py (a
+    namespace package), so a regular package of the same name anywhere on sys.path -- this repo's drop-in `cama/`
+    shim -- would win no matter the path order; bind the name explicitly instead."""
+    _drop_cama_modules()
+    pkg = types.ModuleType("cama")
+    pkg.__path__ = [os.path.join(REFERENCE, "cama")]
+    sys.modules["cama"] = pkg
+
+
+def assert_from_reference(*modules):
+    for m in modules:
+        f = os.path.abspath(sys.modules[m.__module__].__file__ if not isinstance(m, types.ModuleType) else m.__file__)
+        assert f.startswith(os.path.abspath(REFERENCE) + os.sep), f
+
+
 class _Recorder:
     def __init__(self):
         self.calls = []
@@ -87,15 +108,13 @@ def run_clip(tag, clip_kwargs, mutate=None):
     from cama_amd.synth import make_clip, DEFAULT_CAMA_CONFIGS
     rec = _Recorder()
     install_stubs(rec)
-    for m in [k for k in sys.modules if k == "cama" or k.startswith("cama.")]:
-        del sys.modules[m]
+    bind_reference_package()
     sys.path.insert(0, REFERENCE)
     try:
         from cama.dataset import ClipManager
         from cama.dataset_reader import DatasetReader
         from cama.tools import VideoGenerator
-        import cama as _cama
-        assert _cama.__path__[0].startswith(REFERENCE), _cama.__path__
+        assert_from_reference(ClipManager, DatasetReader, VideoGenerator)
         tmp = tempfile.mkdtemp(prefix="golden_")
         clip = os.path.join(tmp, "clip")
         make_clip(clip, **clip_kwargs)
@@ -173,9 +192,11 @@ def mutate_pose_gaps(clip):
 def run_pose_seek():
     rec = _Recorder()
     install_stubs(rec)
+    bind_reference_package()
     sys.path.insert(0, REFERENCE)
     try:
         from cama.pose_transformer import PoseTransformer, SlerpTransform, invT
+        assert_from_reference(PoseTransformer, invT)
         from scipy.spatial.transform import Rotation
         rng = np.random.default_rng(7)
         P = 9
@@ -236,10 +257,12 @@ def run_pose_seek():
 def run_mosaic():
     rec = _Recorder()
     install_stubs(rec)
+    bind_reference_package()
     sys.path.insert(0, REFERENCE)
     try:
         from cama.tools import VideoGenerator
         from cama_amd.synth import CAMERA_NAMES
+        assert_from_reference(VideoGenerator)
         rng = np.random.default_rng(3)
         H, W = 6, 8
         imgs = {n: rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for n in CAMERA_NAMES}
@@ -256,11 +279,120 @@ def run_mosaic():
             del sys.modules[m]
 
 
+def make_eval_trajectories(seed=11, P=1300):
+    """Synthetic gt / pred TUM arrays for the PoseEvaluator fixtures (shared with tests: pure numpy + scipy)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    t = 50.0 + 0.1 * np.arange(P) + rng.uniform(-0.004, 0.004, P)
+    yaw = np.cumsum(rng.normal(0.0, 0.004, P)) + 0.3 * np.sin(np.arange(P) / 150.0)
+    speed = 9.0 + np.sin(np.arange(P) / 40.0)
+    xy = np.cumsum(np.stack([np.cos(yaw), np.sin(yaw)], 1) * (0.1 * speed)[:, None], axis=0)
+    z = 0.5 * np.sin(np.arange(P) / 90.0)
+    rot = Rotation.from_euler("zyx", np.stack([yaw, 0.02 * np.sin(np.arange(P) / 30.0), np.zeros(P)], 1))
+    gt = np.concatenate([t[:, None], xy, z[:, None], rot.as_quat()], axis=1)
+    # prediction: another sensor frame + scale drift + noise, stamps jittered, some frames missing
+    S = Rotation.from_rotvec([0.05, -0.1, 0.7])
+    keep = np.ones(P, bool)
+    keep[rng.choice(P, 60, replace=False)] = False
+    keep[:2] = True
+    pos = 0.83 * S.apply(gt[:, 1:4]) + np.array([3.0, -2.0, 0.7]) + np.cumsum(rng.normal(0, 0.004, (P, 3)), axis=0)
+    prot = S * rot * Rotation.from_rotvec(np.cumsum(rng.normal(0, 2e-4, (P, 3)), axis=0))
+    pred = np.concatenate([(t + rng.uniform(-0.012, 0.012, P))[:, None], pos, prot.as_quat()], axis=1)[keep]
+    return gt, pred
+
+
+def run_pose_eval():
+    rec = _Recorder()
+    install_stubs(rec)
+    sys.path.insert(0, REFERENCE)
+    try:
+        bind_reference_package()
+        from cama.pose_evaluator import PoseEvaluator
+        assert_from_reference(PoseEvaluator)
+        gt, pred = make_eval_trajectories()
+        out = {"gt": gt, "pred": pred}
+        cases = [("7dof", 1.0, 0), ("6dof", 1.0, 0), ("scale", 1.0, 0), ("scale_7dof", 1.0, 0), ("None", 1.0, 0),
+                 ("6dof", 1.2, 0), ("7dof", 1.0, 0.3)]
+        names = []
+        for k, (alignment, scale, offset) in enumerate(cases):
+            pe = PoseEvaluator(alignment=alignment, scale=scale, offset=offset)
+            p = pred.copy()
+            if offset:
+                p[:, 0] -= offset
+            res = pe.eval(gt.copy(), p)
+            tag = f"case{k}"
+            names.append(f"{alignment}|{scale}|{offset}")
+            out[tag + "_keys"] = np.array(list(res.keys()))
+            for key, val in res.items():
+                out[f"{tag}_{key}"] = np.asarray(val, dtype=np.float64)
+            if scale != 1.0:
+                out[tag + "_pred_after"] = p                 # load_poses scales x,y of the caller's array in place
+            out[tag + "_n_poses"] = np.int64(len(pe.poses_pred))
+            out[tag + "_pose_pred_last"] = pe.poses_pred[len(pe.poses_pred) - 1]
+            out[tag + "_pose_gt_last"] = pe.poses_gt[len(pe.poses_gt) - 1]
+            seq = pe.calc_sequence_errors(pe.poses_gt, pe.poses_pred)
+            out[tag + "_seq_err_rows"] = np.int64(len(seq))
+            if k in (0, 5):
+                out[tag + "_seq_err"] = np.asarray(seq, dtype=np.float64)
+            seg = pe.compute_segment_error(seq)
+            out[tag + "_seg_lengths"] = np.array([l for l in pe.lengths if len(seg[l])], dtype=np.int64)
+            out[tag + "_seg_err"] = np.asarray([seg[l] for l in pe.lengths if len(seg[l])], dtype=np.float64)
+        out["case_names"] = np.array(names)
+        # pieces
+        pe = PoseEvaluator(alignment="7dof")
+        m = pe.associate(pe.array2dict(gt), pe.array2dict(pred))
+        out["assoc_matches"] = np.asarray(m, dtype=np.float64)
+        pe_off = PoseEvaluator(alignment="7dof", max_t_diff=0.25, offset=0.07)
+        out["assoc_matches_wide"] = np.asarray(pe_off.associate(pe_off.array2dict(gt[:200]), pe_off.array2dict(pred[:150])),
+                                               dtype=np.float64)
+        rng = np.random.default_rng(5)
+        x = rng.normal(0, 10, (3, 57))
+        from scipy.spatial.transform import Rotation
+        y = 1.7 * Rotation.from_rotvec([0.3, 0.2, -0.9]).apply(x.T).T + np.array([[1.0], [2.0], [3.0]]) + rng.normal(0, 0.01, (3, 57))
+        for ws in (False, True):
+            r, t, c = pe.umeyama_alignment(x, y, ws)
+            out[f"umeyama_{int(ws)}_r"], out[f"umeyama_{int(ws)}_t"], out[f"umeyama_{int(ws)}_c"] = r, t, np.float64(c)
+        out["umeyama_x"], out["umeyama_y"] = x, y
+        # reflection branch (det < 0): mirrored target
+        ym = y.copy()
+        ym[2] *= -1
+        r, t, c = pe.umeyama_alignment(x, ym, True)
+        out["umeyama_mirror_r"], out["umeyama_mirror_t"], out["umeyama_mirror_c"] = r, t, np.float64(c)
+        poses = pe.quaternion2transform(gt[:40, 1:])
+        out["q2t"] = np.stack([poses[i] for i in range(40)])
+        out["traj_dist"] = np.asarray(pe.trajectory_distances(poses))
+        E = np.linalg.inv(poses[3]) @ poses[17]
+        out["err_terms"] = np.array([pe.rotation_error(E), pe.translation_error(E), *pe.rpy_error(E)])
+        out["last_frame"] = np.array([pe.last_frame_from_segment_length(list(out["traj_dist"]), f, L)
+                                      for f in (0, 5, 39) for L in (1.0, 10.0, 1000.0)], dtype=np.int64)
+        # too few matches
+        try:
+            PoseEvaluator(alignment="7dof").eval(gt[:8].copy(), pred[:8].copy())
+            out["few_matches_raises"] = np.int8(0)
+        except RuntimeError:
+            out["few_matches_raises"] = np.int8(1)
+        try:
+            PoseEvaluator(alignment="7dof", scale=1.1)
+            out["bad_scale_raises"] = np.int8(0)
+        except RuntimeError:
+            out["bad_scale_raises"] = np.int8(1)
+        np.savez_compressed(os.path.join(HERE, "pose_eval.npz"), **out)
+        print("pose_eval.npz:", names, "seq_err rows", [int(out[f"case{k}_seq_err_rows"]) for k in range(len(cases))],
+              "matches", len(m))
+    finally:
+        sys.path.remove(REFERENCE)
+        for m_ in [k for k in sys.modules if k == "cama" or k.startswith("cama.")]:
+            del sys.modules[m_]
+
+
 def main():
     if not os.path.isdir(REFERENCE):
         print("reference not present; golden vectors are committed, nothing to do")
         return 0
     sys.path.insert(0, REPO)
+    if len(sys.argv) > 1 and sys.argv[1] == "pose_eval":          # regenerate one fixture only
+        run_pose_eval()
+        return 0
     run_clip("a", dict(n_frames=5, seed=0, n_lines=6, verts_per_line=5, line_len_m=2.0, raster_size=400))
     run_clip("b_exact", dict(n_frames=4, seed=1, n_lines=4, verts_per_line=4, line_len_m=1.5,
                              raster_size=300, pose_offset_s=0.0))
@@ -272,6 +404,7 @@ def main():
                             raster_size=300, with_cama=False))
     run_pose_seek()
     run_mosaic()
+    run_pose_eval()
     return 0
 
 
