@@ -1,9 +1,8 @@
-"""Clip ("pack") reader: the subset of the reference's DatasetReader (cama/dataset_reader.py) that the
-reprojection path touches -- attribute.json, sensor timestamps, the calibration graph, intrinsics,
-odometry text files, sensor file paths.  Pure host-side file parsing, once per clip.
-
-Out of scope: the lidar / IMU / GNSS / wheel iterators and their TUM converters
-(dataset_reader.py:45-71,86-93,296-407); they raise NotImplementedError here.
+"""Clip ("pack") reader with the reference's DatasetReader surface (cama/dataset_reader.py): attribute.json, sensor
+timestamps, the calibration graph, intrinsics, odometry text files, sensor file paths -- what the reprojection path
+touches -- plus the per-sensor iterators (lidar / IMU / GNSS / wheel / camera / semantic) and the GNSS / wheel ->
+TUM converters.  Pure host-side file parsing, once per clip.  Images are decoded with Pillow (no OpenCV in this
+image) and returned in OpenCV's channel order (BGR / BGRA).
 """
 import json
 import os
@@ -144,10 +143,89 @@ class DatasetReader:
     def get_odometry(self, name_txt):
         return np.loadtxt(os.path.join(self.pack_path, "odometry", name_txt))
 
-    # ------------------------------------------------------------------ out of scope
-    def _out_of_scope(self, *a, **k):
-        raise NotImplementedError("sensor iterators other than camera paths are outside the reprojection path "
-                                  "(SURVEY.md section 8); use the reference's DatasetReader for them")
+    # ------------------------------------------------------------------ per-sensor iterators
+    @staticmethod
+    def _stamp_of(path):
+        """<dir>/<timestamp_ms>.<ext> -> seconds (dataset_reader.py:94-99)."""
+        return float(os.path.basename(path).split(".")[0]) / 1000.0
 
-    yield_lidar = yield_IMU = yield_GNSS = yield_wheel = yield_camera = yield_semantic = _out_of_scope
-    get_GNSS_tum = get_wheel_tum = _out_of_scope
+    def _yield_json_frames(self, sensor_dir, stamps_ms):
+        """(seconds, frame dict) for every stamp of a sensor logged into one <pack>/<sensor_dir>/data.json."""
+        with open(os.path.join(self.pack_path, sensor_dir, "data.json"), "r") as f:
+            frames = json.load(f)
+        for ts in stamps_ms:
+            yield float(ts) / 1000.0, frames[str(ts)]
+
+    def yield_lidar(self, start_idx=None, end_idx=None, deskewed=False):
+        """(seconds, (n,6) float64 [x y z intensity ring t]) per sweep (dataset_reader.py:45-51)."""
+        for path in self.yield_sensor_filepath("lidar_top", "bin", start_idx=start_idx, end_idx=end_idx):
+            if deskewed:
+                path = path.replace("lidar_top", "deskewed_lidar_top")
+            yield self._stamp_of(path), np.fromfile(path, dtype=np.double).reshape(-1, 6)
+
+    def yield_IMU(self, start_idx=None, end_idx=None, start_time=None, end_time=None):
+        """All unsynced IMU frames; the range arguments are accepted and ignored like the reference's (:53-61)."""
+        yield from self._yield_json_frames("IMU", self.attribute["unsync"]["IMU"])
+
+    def yield_GNSS(self, start_idx=None, end_idx=None):
+        yield from self._yield_json_frames("UB482", self.attribute["unsync"]["UB482"])       # :63-70
+
+    def yield_wheel(self, sync=True, start_idx=None, end_idx=None):
+        yield from self._yield_json_frames("wheel", self.attribute["sync" if sync else "unsync"]["wheel"])   # :85-92
+
+    def yield_camera(self, camera="camera_front", start_idx=None, end_idx=None):
+        """(seconds, (H,W,3) uint8 BGR) per frame (dataset_reader.py:72-76)."""
+        from .frames import read_bgr
+        for path in self.yield_sensor_filepath(camera, "jpg", start_idx=start_idx, end_idx=end_idx):
+            yield self._stamp_of(path), read_bgr(path)
+
+    def yield_semantic(self, camera="camera_front", start_idx=None, end_idx=None):
+        """(seconds, label image as stored: (H,W) or (H,W,3|4) in BGR(A) order) from <pack>/seg_<camera>/ (:78-83)."""
+        from PIL import Image
+        for path in self.yield_sensor_filepath(camera, "png", start_idx=start_idx, end_idx=end_idx):
+            path = path.replace(camera, "seg_" + camera)
+            with Image.open(path) as im:
+                arr = np.array(im.convert("RGB") if im.mode == "P" else im)
+            if arr.ndim == 3 and arr.shape[2] >= 3:
+                arr = np.ascontiguousarray(arr[..., [2, 1, 0] + list(range(3, arr.shape[2]))])
+            yield self._stamp_of(path), arr
+
+    # ------------------------------------------------------------------ GNSS / wheel odometry as TUM rows
+    def get_GNSS_tum(self):
+        """(n,8) [t x y z qx qy qz qw] from the GNSS log; "position" is a dict (x,y,z / x,y,z,w) in current logs and
+        a list in the deprecated packstreamer format, decided on the first frame (dataset_reader.py:296-348)."""
+        rows, keyed = [], None
+        for t, g in self.yield_GNSS():
+            if keyed is None:
+                keyed = "x" in g["position"]
+            if keyed:
+                p, q = g["position"], g["orientation"]
+                rows.append([t, p["x"], p["y"], p["z"], q["x"], q["y"], q["z"], q["w"]])
+            else:
+                _warn_packstreamer()
+                rows.append([t, *g["position"][:3], *g["orientation"][:4]])
+        return np.asarray(rows)
+
+    def get_wheel_tum(self, sync=False):
+        """(n,8) TUM rows from wheel odometry: full roll/pitch/yaw + z in the deprecated format, planar (yaw only,
+        z = 0) in the current one; quaternion from intrinsic XYZ euler angles (dataset_reader.py:350-407)."""
+        from scipy.spatial.transform import Rotation
+        frames = list(self.yield_wheel(sync=sync))
+        if not frames:
+            return np.asarray([])
+        full = "roll" in frames[0][1]
+        if full:
+            for _ in frames:
+                _warn_packstreamer()
+            rpy = np.array([[w["roll"], w["pitch"], w["yaw"]] for _, w in frames], dtype=np.float64)
+            z = [w["z"] for _, w in frames]
+        else:
+            rpy = np.array([[0, 0, w["yaw"]] for _, w in frames], dtype=np.float64)
+            z = [0] * len(frames)
+        quat = Rotation.from_euler("XYZ", rpy, degrees=False).as_quat()
+        return np.asarray([[t, w["x"], w["y"], z[i], *quat[i]] for i, (t, w) in enumerate(frames)])
+
+
+def _warn_packstreamer():
+    from warnings import warn
+    warn("Warning(Deprecation): clip/pack results extracted by packstreamer will not be supported in the future")

@@ -385,13 +385,87 @@ def run_pose_eval():
             del sys.modules[m_]
 
 
+def make_sensor_pack(root, legacy):
+    """Tiny synthetic pack with lidar sweeps and IMU / GNSS / wheel logs (current dict-style frames, or the
+    deprecated list-style ones when `legacy`), shared by the generator and the tests."""
+    rng = np.random.default_rng(21 + int(legacy))
+    os.makedirs(root, exist_ok=True)
+    lidar = [1700000000000 + 100 * i for i in range(4)]
+    fast = [1700000000000 + 33 * i for i in range(9)]
+    attr = {"sync": {"lidar_top": lidar, "wheel": lidar}, "unsync": {"IMU": fast, "UB482": fast[::2], "wheel": fast},
+            "calibration": {}}
+    json.dump(attr, open(os.path.join(root, "attribute.json"), "w"))
+    for d in ("lidar_top", "deskewed_lidar_top", "IMU", "UB482", "wheel"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    for k, ts in enumerate(lidar):
+        rng.normal(0, 20, (5 + k, 6)).tofile(os.path.join(root, "lidar_top", f"{ts}.bin"))
+        rng.normal(0, 20, (5 + k, 6)).tofile(os.path.join(root, "deskewed_lidar_top", f"{ts}.bin"))
+    imu = {str(ts): {"acc": rng.normal(0, 1, 3).tolist(), "gyro": rng.normal(0, 0.1, 3).tolist()} for ts in fast}
+    json.dump(imu, open(os.path.join(root, "IMU", "data.json"), "w"))
+    gnss, wheel = {}, {}
+    for ts in fast:
+        pos, quat = rng.normal(0, 100, 3).tolist(), rng.normal(0, 1, 4)
+        quat = (quat / np.linalg.norm(quat)).tolist()
+        if legacy:
+            gnss[str(ts)] = {"position": pos, "orientation": quat}
+            wheel[str(ts)] = {"x": rng.normal(), "y": rng.normal(), "z": rng.normal(), "roll": rng.normal(0, 0.05),
+                              "pitch": rng.normal(0, 0.05), "yaw": rng.normal(0, 1.5)}
+        else:
+            gnss[str(ts)] = {"position": dict(zip("xyz", pos)), "orientation": dict(zip("xyzw", quat))}
+            wheel[str(ts)] = {"x": rng.normal(), "y": rng.normal(), "yaw": rng.normal(0, 1.5)}
+    for ts in lidar:
+        wheel.setdefault(str(ts), dict(wheel[str(fast[0])]))
+    json.dump(gnss, open(os.path.join(root, "UB482", "data.json"), "w"))
+    json.dump(wheel, open(os.path.join(root, "wheel", "data.json"), "w"))
+    return root
+
+
+def run_dataset_reader():
+    import warnings
+    rec = _Recorder()
+    install_stubs(rec)
+    bind_reference_package()
+    sys.path.insert(0, REFERENCE)
+    tmp = tempfile.mkdtemp(prefix="golden_pack_")
+    try:
+        from cama.dataset_reader import DatasetReader
+        assert_from_reference(DatasetReader)
+        out = {}
+        for legacy in (0, 1):
+            dr = DatasetReader(make_sensor_pack(os.path.join(tmp, f"pack{legacy}"), bool(legacy)))
+            tag = f"p{legacy}_"
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                out[tag + "gnss_tum"] = dr.get_GNSS_tum()
+                out[tag + "wheel_tum_unsync"] = dr.get_wheel_tum()
+                out[tag + "wheel_tum_sync"] = dr.get_wheel_tum(sync=True)
+                out[tag + "n_warnings"] = np.int64(len(w))
+            for deskewed in (0, 1):
+                sweeps = list(dr.yield_lidar(start_idx=1, deskewed=bool(deskewed)))
+                out[f"{tag}lidar{deskewed}_t"] = np.array([t for t, _ in sweeps])
+                out[f"{tag}lidar{deskewed}_n"] = np.array([len(p) for _, p in sweeps])
+                out[f"{tag}lidar{deskewed}_sum"] = np.array([p.sum() for _, p in sweeps])
+            for name, it in (("imu", dr.yield_IMU()), ("gnss", dr.yield_GNSS()), ("wheel", dr.yield_wheel()),
+                             ("wheel_unsync", dr.yield_wheel(sync=False))):
+                frames = list(it)
+                out[f"{tag}{name}_t"] = np.array([t for t, _ in frames])
+                out[f"{tag}{name}_json"] = np.array(json.dumps([f for _, f in frames], sort_keys=True))
+        np.savez_compressed(os.path.join(HERE, "dataset_reader.npz"), **out)
+        print("dataset_reader.npz:", len(out), "arrays; warnings", int(out["p0_n_warnings"]), int(out["p1_n_warnings"]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        sys.path.remove(REFERENCE)
+        _drop_cama_modules()
+
+
 def main():
     if not os.path.isdir(REFERENCE):
         print("reference not present; golden vectors are committed, nothing to do")
         return 0
     sys.path.insert(0, REPO)
-    if len(sys.argv) > 1 and sys.argv[1] == "pose_eval":          # regenerate one fixture only
-        run_pose_eval()
+    only = {"pose_eval": run_pose_eval, "dataset_reader": run_dataset_reader}
+    if len(sys.argv) > 1 and sys.argv[1] in only:                 # regenerate one fixture only
+        only[sys.argv[1]]()
         return 0
     run_clip("a", dict(n_frames=5, seed=0, n_lines=6, verts_per_line=5, line_len_m=2.0, raster_size=400))
     run_clip("b_exact", dict(n_frames=4, seed=1, n_lines=4, verts_per_line=4, line_len_m=1.5,
@@ -405,6 +479,7 @@ def main():
     run_pose_seek()
     run_mosaic()
     run_pose_eval()
+    run_dataset_reader()
     return 0
 
 

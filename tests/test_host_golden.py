@@ -1,6 +1,7 @@
 """Product host logic (cama_amd: static-map build, calibration, pose track, frame poses) against the golden
 vectors captured from the reference.  CPU only: nothing here touches the GPU or the oracle."""
 import json
+import os
 from os.path import join
 
 import numpy as np
@@ -169,3 +170,61 @@ def test_engine_fails_loudly_without_gpu():
     from cama_amd.engine import Engine
     with pytest.raises(_lib.CamaHipError):
         Engine("cuda:0")
+
+
+def test_dataset_reader_sensor_iterators_match_reference(tmp_path):
+    """lidar / IMU / GNSS / wheel iterators and the GNSS / wheel -> TUM converters (dataset_reader.py:45-93,296-407)
+    on the synthetic packs of tests/golden/gen_golden.py (current and deprecated log formats), against the
+    reference's outputs captured in dataset_reader.npz; exact (same numpy / scipy element-wise arithmetic)."""
+    import importlib.util
+    import warnings
+    from cama_amd.dataset_reader import DatasetReader
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(os.path.dirname(__file__), "golden",
+                                                                             "gen_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "dataset_reader.npz"))
+    for legacy in (0, 1):
+        dr = DatasetReader(gen.make_sensor_pack(str(tmp_path / f"pack{legacy}"), bool(legacy)))
+        tag = f"p{legacy}_"
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert np.array_equal(dr.get_GNSS_tum(), G[tag + "gnss_tum"])
+            assert np.array_equal(dr.get_wheel_tum(), G[tag + "wheel_tum_unsync"])
+            assert np.array_equal(dr.get_wheel_tum(sync=True), G[tag + "wheel_tum_sync"])
+            assert len(w) == int(G[tag + "n_warnings"])              # deprecated formats warn once per frame
+        for deskewed in (0, 1):
+            sweeps = list(dr.yield_lidar(start_idx=1, deskewed=bool(deskewed)))
+            assert np.array_equal([t for t, _ in sweeps], G[f"{tag}lidar{deskewed}_t"])
+            assert [len(p) for _, p in sweeps] == G[f"{tag}lidar{deskewed}_n"].tolist()
+            assert np.array_equal([p.sum() for _, p in sweeps], G[f"{tag}lidar{deskewed}_sum"])
+            assert all(p.dtype == np.float64 and p.shape[1] == 6 for _, p in sweeps)
+        for name, it in (("imu", dr.yield_IMU()), ("gnss", dr.yield_GNSS()), ("wheel", dr.yield_wheel()),
+                         ("wheel_unsync", dr.yield_wheel(sync=False))):
+            frames = list(it)
+            assert np.array_equal([t for t, _ in frames], G[f"{tag}{name}_t"])
+            assert json.dumps([f for _, f in frames], sort_keys=True) == str(G[f"{tag}{name}_json"])
+
+
+def test_dataset_reader_image_iterators(tmp_path):
+    """yield_camera / yield_semantic: Pillow decode, OpenCV channel order (the reference uses cv2.imread, :72-83)."""
+    from PIL import Image
+    from cama_amd.dataset_reader import DatasetReader
+    stamps = [1700000000000, 1700000000100]
+    os.makedirs(tmp_path / "camera_front")
+    os.makedirs(tmp_path / "seg_camera_front")
+    json.dump({"sync": {"camera_front": stamps}, "unsync": {}, "calibration": {}}, open(tmp_path / "attribute.json", "w"))
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (12, 16, 3), dtype=np.uint8)
+    lab = rng.integers(0, 20, (12, 16), dtype=np.uint8)
+    for ts in stamps:
+        Image.fromarray(rgb).save(tmp_path / "camera_front" / f"{ts}.jpg", quality=100, subsampling=0)
+        Image.fromarray(lab).save(tmp_path / "seg_camera_front" / f"{ts}.png")
+    dr = DatasetReader(str(tmp_path))
+    cams = list(dr.yield_camera("camera_front"))
+    assert [t for t, _ in cams] == [s / 1000.0 for s in stamps]
+    assert cams[0][1].shape == (12, 16, 3) and np.abs(cams[0][1][..., ::-1].astype(int) - rgb).max() <= 12   # BGR, lossy
+    segs = list(dr.yield_semantic("camera_front", start_idx=1))
+    assert len(segs) == 1 and segs[0][0] == stamps[1] / 1000.0 and np.array_equal(segs[0][1], lab)
+    Image.fromarray(rgb).save(tmp_path / "seg_camera_front" / f"{stamps[0]}.png")
+    assert np.array_equal(next(dr.yield_semantic("camera_front"))[1], rgb[..., ::-1])
