@@ -19,8 +19,13 @@ def _case(rng):
     N = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, 3000, 5000, 20000]))
     radius = int(rng.choice([0, 1, 2, 2, 2, 3]))
     f64 = bool(rng.random() < 0.3)
-    kind = rng.choice(["cloud", "line", "clump"])
-    if kind == "cloud":
+    kind = rng.choice(["cloud", "line", "clump", "site"])
+    if kind == "site":                     # site-sized: most vertex blocks outside the crop box (block-AABB cull)
+        xyz = rng.uniform([-300, -300, -1], [300, 300, 1], (N, 3))
+        xyz[: N // 3] = rng.uniform([-30, -40, -1], [40, 40, 1], (N // 3, 3))
+        if rng.random() < 0.5:
+            xyz = xyz[np.argsort(np.floor(xyz[:, 0] / 20) * 1000 + np.floor(xyz[:, 1] / 20), kind="stable")]
+    elif kind == "cloud":
         xyz = rng.uniform([-40, -60, -1], [40, 60, 1], (N, 3))
     elif kind == "line":
         t = np.linspace(0, 1, N)[:, None]
@@ -56,6 +61,19 @@ def _case(rng):
         sorted(rng.uniform(-30, 30, 2).tolist()) + sorted(rng.uniform(-30, 30, 2).tolist()) + [-5.0, 5.0]
     return dict(W=W, H=H, C=C, F=F, N=N, radius=radius, xyz=xyz, col=col, cams=cams, w2c=np.stack(w2c), crop=crop,
                 sort=bool(rng.random() < 0.3), kind=str(kind))
+
+
+def test_fuzz_work_list_path():
+    """Same fuzz in a child process with CAMA_CULL_LIST_MIN=1: every render that carries block bounds goes through
+    k_cull_blocks + the persistent k_frames_bin_list instead of the grid launch."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CAMA_CULL_LIST_MIN="1", CAMA_FUZZ_ITERS=os.environ.get("CAMA_FUZZ_ITERS", "40"),
+               CAMA_FUZZ_SEED="77")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
+                        __file__ + "::test_fuzz_against_oracle"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_fuzz_against_oracle():
