@@ -88,7 +88,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte chun
 constexpr int CAM_STRIDE = 21;  // 12 (3x4 of chassis->camera) + 9 (K)
 
 struct Crop { double v[6]; };
-struct Disc { int radius; int hw[CAMA_MAX_RADIUS + 1]; };
+// Filled-circle footprint: row |dy| = k spans u +- hw(k).  Packed (4 bits per row + a row mask) so that the kernels
+// read it from SGPRs; as an int array in the kernel arguments every dynamically indexed hw[k] was a global load (+ a
+// full vmcnt drain) inside the rasterisation loop.
+struct Disc { int radius; uint32_t rows; uint64_t hw4; };
+__device__ __forceinline__ int disc_halfwidth(const Disc &d, int k)
+{
+    return ((d.rows >> k) & 1u) ? (int)((d.hw4 >> (4 * k)) & 15ull) : -1;
+}
 struct Palette { uint32_t c[2]; uint32_t alpha256; };  // colours b | g<<8 | r<<16; alpha in 1/256 (256 = opaque)
 
 #include "project_kernels.hpp"
@@ -104,7 +111,14 @@ int make_disc(int radius, const int32_t *hw, Disc &d)
 {
     if (radius < 0 || radius > CAMA_MAX_RADIUS || !hw) return -1;
     d.radius = radius;
-    for (int k = 0; k <= CAMA_MAX_RADIUS; ++k) d.hw[k] = (k <= radius) ? hw[k] : -1;
+    d.rows = 0;
+    d.hw4 = 0;
+    for (int k = 0; k <= radius; ++k) {
+        if (hw[k] > CAMA_MAX_RADIUS) return -1;
+        if (hw[k] < 0) continue;                 // row not drawn
+        d.rows |= 1u << k;
+        d.hw4 |= (uint64_t)hw[k] << (4 * k);
+    }
     return 0;
 }
 
@@ -161,7 +175,7 @@ int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLay
     L.bin_off = off;  off = align_up(off + nbins * 4, 256);
     L.fc_total = off; off = align_up(off + nfc * 4, 256);
     L.fc_base = off;  off = align_up(off + nfc * 4, 256);
-    L.stamps = off;   off = align_up(off + (size_t)L.capacity * 8, 256);
+    L.stamps = off;   off = align_up(off + (size_t)L.capacity * 8 + 8, 256);   // >= 1 record: empty bins read stamps[0]
     // work lists of the crop cull: 8 (one per XCD), each up to ceil(vblocks / 8) * F uint32 items
     L.list_cap = (size_t)(((N + BLOCK - 1) / BLOCK + 7) / 8) * (size_t)F;
     L.work = off;     off = align_up(off + 8 * L.list_cap * 4, 256);

@@ -30,7 +30,7 @@ __device__ __forceinline__ void rasterise_one(uint32_t *s_owner, const uint2 r, 
     const uint32_t val = r.y + 1u;  // 0 = no owner
     const int ylo = max(v - disc.radius, y0), yhi = min(v + disc.radius, y0 + nrows - 1);
     for (int y = ylo; y <= yhi; ++y) {
-        const int hw = disc.hw[abs(y - v)];
+        const int hw = disc_halfwidth(disc, abs(y - v));
         if (hw < 0) continue;
         const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
         uint32_t *row = s_owner + (y - y0) * W;
@@ -66,7 +66,7 @@ __device__ __forceinline__ void patch_chunk(u32x4 &d, const uint32_t *orow, uint
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         m[k] = o[k] ? 0x00ffffffu : 0u;
-        c[k] = o[k] ? pal.c[(o[k] - 1u) & 1u] : 0u;
+        c[k] = o[k] ? (((o[k] - 1u) & 1u) ? pal.c[1] : pal.c[0]) : 0u;     // select, not an indexed kernarg load
     }
     // 18-byte little-endian streams (pixel k at bytes 3k..3k+2) as 5 dwords
     const uint32_t V0 = c[0] | (c[1] << 24), V1 = (c[1] >> 8) | (c[2] << 16), V2 = (c[2] >> 16) | (c[3] << 8),
@@ -104,6 +104,15 @@ __device__ __forceinline__ u32x4 chunk_from_pixels(const uint32_t *c, uint32_t p
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the
+// band's source loads that are deliberately left in flight across the rasterisation.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <bool VEC, bool RESAMPLE, bool ALPHA = false>
 __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 {
@@ -133,22 +142,39 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
     const int W = a.W;
     const uint32_t n = a.counts[bin];
 
+    // A stamped band fetches this thread's first stamp record and THEN issues its (first, normally only) batch of
+    // 16-byte source loads, all before clearing / rasterising: the source chunks do not depend on the owner table, so
+    // their HBM latency runs under the LDS work, and the stamp record -- issued first, VMEM returns in order -- can
+    // be waited for without draining them.
+    // (the record load is unconditional -- lanes without a stamp re-read the bin's last one, empty bins read
+    // stamps[0] -- because a load inside a divergent branch is waited for right there)
+    const uint2 *st = a.stamps + (n ? (size_t)a.fc_base[fc] + a.bin_off[bin] : (size_t)0);
+    const uint2 first = st[n ? min(threadIdx.x, n - 1u) : 0u];
+    __builtin_amdgcn_sched_barrier(0);          // keep the record load ahead of the source loads (in-order vmcnt)
+
+    const uint8_t *sband = a.src + ((size_t)fc * a.H + y0) * (size_t)W * 3;      // (unused by RESAMPLE)
+    constexpr int U = OVERLAY_UNROLL;
+    const u32x4 *s16 = reinterpret_cast<const u32x4 *>(sband);
+    const uint32_t nchunks = (uint32_t)nrows * a.cpr;
+    u32x4 v[U];
+    if (VEC && !RESAMPLE) {
+        // unconditional (index clamped to the band's last chunk): loads under a divergent branch are waited for at
+        // the end of the branch, which would serialise them
+#pragma unroll
+        for (int j = 0; j < U; ++j) v[j] = OVERLAY_LOAD(s16 + min(threadIdx.x + j * OVERLAY_BLOCK, nchunks - 1u));
+    }
+
     if (n) {
-        // this thread's first stamp record is fetched BEFORE the table is cleared: its HBM/L2 latency overlaps the clear
-        const uint2 *st = a.stamps + ((size_t)a.fc_base[fc] + a.bin_off[bin]);
-        uint2 first = make_uint2(0u, 0u);
-        if (threadIdx.x < n) first = st[threadIdx.x];
         uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
         const int n4 = (nrows * W + 3) >> 2;
         for (int j = threadIdx.x; j < n4; j += OVERLAY_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
+        lds_barrier();
         if (threadIdx.x < n) rasterise_one(s_owner, first, y0, nrows, W, a.disc);
         for (uint32_t s = threadIdx.x + OVERLAY_BLOCK; s < n; s += OVERLAY_BLOCK)
             rasterise_one(s_owner, st[s], y0, nrows, W, a.disc);
-        __syncthreads();
+        lds_barrier();
     }
 
-    const uint8_t *sband = a.src + ((size_t)fc * a.H + y0) * (size_t)W * 3;      // (unused by RESAMPLE)
     uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
                      ((size_t)(c / (uint32_t)a.cols) * a.H + y0) * a.mosaic_row_bytes +
                      (size_t)(c % (uint32_t)a.cols) * W * 3;
@@ -187,15 +213,10 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 
     if (VEC) {
         // the band is one contiguous byte range in src: chunk j of the band is src16[j]
-        constexpr int U = OVERLAY_UNROLL;
-        const u32x4 *s16 = reinterpret_cast<const u32x4 *>(sband);
-        const uint32_t nchunks = (uint32_t)nrows * a.cpr;
         for (uint32_t base = threadIdx.x; base < nchunks; base += OVERLAY_BLOCK * U) {
-            u32x4 v[U];
+            if (base != threadIdx.x) {              // later batches (bands wider than OVERLAY_BLOCK * U chunks)
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const uint32_t idx = base + j * OVERLAY_BLOCK;
-                if (idx < nchunks) v[j] = OVERLAY_LOAD(s16 + idx);
+                for (int j = 0; j < U; ++j) v[j] = OVERLAY_LOAD(s16 + min(base + j * OVERLAY_BLOCK, nchunks - 1u));
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) {
@@ -219,7 +240,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
             if (n) {
                 const uint32_t o = s_owner[p];
                 if (o) {
-                    const uint32_t col = a.pal.c[(o - 1u) & 1u];
+                    const uint32_t col = ((o - 1u) & 1u) ? a.pal.c[1] : a.pal.c[0];
                     const uint32_t srcw = (uint32_t)b0 | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16);
                     const uint32_t w = ALPHA ? blend_bytes(srcw, col, a.pal.alpha256) : col;
                     b0 = (uint8_t)w; b1 = (uint8_t)(w >> 8); b2 = (uint8_t)(w >> 16);
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, 
             const uint32_t val = rec.y + 1u;
             const int ylo = max(v - a.disc.radius, y0), yhi = min(v + a.disc.radius, y0 + nrows - 1);
             for (int y = ylo; y <= yhi; ++y) {
-                const int hw = a.disc.hw[abs(y - v)];
+                const int hw = disc_halfwidth(a.disc, abs(y - v));
                 if (hw < 0) continue;
                 const int xlo = max(max(u - hw, 0), x_first), xhi = min(min(u + hw, a.W - 1), x_first + Wt - 1);
                 uint32_t *orow = s_owner + (y - y0) * Wt - x_first;
@@ -352,7 +373,7 @@ __global__ __launch_bounds__(BLOCK) void k_stamp_global(const double *__restrict
     for (int dy = -disc.radius; dy <= disc.radius; ++dy) {
         const int y = v + dy;
         if (y < 0 || y >= H) continue;
-        const int hw = disc.hw[abs(dy)];
+        const int hw = disc_halfwidth(disc, abs(dy));
         if (hw < 0) continue;
         const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
         for (int x = xlo; x <= xhi; ++x) atomicMax(&owner[(size_t)y * W + x], val);
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply_owner(const uint32_t *__restric
     if (p >= npix) return;
     const uint32_t o = owner[p];
     if (!o) return;
-    const uint32_t col = pal.c[(o - 1u) & 1u];
+    const uint32_t col = ((o - 1u) & 1u) ? pal.c[1] : pal.c[0];
     image[3 * p] = (uint8_t)col;
     image[3 * p + 1] = (uint8_t)(col >> 8);
     image[3 * p + 2] = (uint8_t)(col >> 16);
