@@ -103,6 +103,7 @@ struct Palette { uint32_t c[2]; uint32_t alpha256; };  // colours b | g<<8 | r<<
 #include "overlay_kernels.hpp"
 #include "resample_kernels.hpp"
 #include "map_kernels.hpp"
+#include "jpeg_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host helpers
@@ -791,3 +792,145 @@ int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n, uin
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------ device JPEG decode
+struct JpegLayout {
+    size_t clean, tile_count, tile_base, nbits, E, nb, wg_total, coef, planes, total;
+    size_t coef_elems, plane_bytes;
+    uint32_t total_wgs, total_tiles, max_blocks;
+};
+
+// derived descriptor fields + scratch layout; `write` = fill the [plan] fields (cama_jpeg_plan) or check them
+static int jpeg_layout(cama_jpeg_image *imgs, const cama_jpeg_image *cimgs, int32_t n, uint64_t stream_bytes, bool write,
+                       JpegLayout &L)
+{
+    if (n < 1 || n > 65535) return fail(CAMA_EINVAL, "n=%d images out of range [1, 65535]", n);
+    uint32_t wg = 0, tile = 0, max_blocks = 0;
+    size_t coef = 0, planes = 0;
+    uint64_t prev_end = 0;
+    for (int i = 0; i < n; ++i) {
+        const cama_jpeg_image &D = cimgs[i];
+        if (D.width < 1 || D.width > 65535 || D.height < 1 || D.height > 65535)
+            return fail(CAMA_EINVAL, "image %d: %ux%u out of range", i, D.width, D.height);
+        if (!(D.ncomp == 1 || D.ncomp == 3)) return fail(CAMA_EINVAL, "image %d: %u components", i, D.ncomp);
+        const bool samp_ok = (D.hs == 1 && D.vs == 1) || (D.ncomp == 3 && D.hs == 2 && (D.vs == 1 || D.vs == 2));
+        if (!samp_ok) return fail(CAMA_EINVAL, "image %d: sampling %ux%u not supported", i, D.hs, D.vs);
+        for (uint32_t c = 0; c < D.ncomp; ++c)
+            if (D.comp_dc[c] > 1 || D.comp_ac[c] > 1) return fail(CAMA_EINVAL, "image %d: Huffman selector > 1", i);
+        if (D.stream_off % 16 || D.stream_off < prev_end || D.stream_len < 1 || D.stream_len > (1u << 29) ||
+            D.stream_off + D.stream_len + 64 > stream_bytes)
+            return fail(CAMA_EINVAL, "image %d: segment [%llu, +%u) not 16-aligned / overlapping / without 64 spare bytes",
+                        i, (unsigned long long)D.stream_off, D.stream_len);
+        prev_end = D.stream_off + D.stream_len + 64;
+        cama_jpeg_image W = D;
+        W.mx = (D.width + 8 * D.hs - 1) / (8 * D.hs);
+        W.my = (D.height + 8 * D.vs - 1) / (8 * D.vs);
+        W.bpm = D.ncomp == 1 ? 1u : D.hs * D.vs + 2u;
+        const uint64_t blocks = (uint64_t)W.mx * W.my * W.bpm;
+        if (blocks > (1u << 28)) return fail(CAMA_EINVAL, "image %d: too many blocks", i);
+        W.total_blocks = (uint32_t)blocks;
+        const uint32_t nsub = (uint32_t)(((uint64_t)D.stream_len * 8 + JPEG_SUB_BITS - 1) / JPEG_SUB_BITS);
+        W.wg0 = wg;
+        W.nwg = (nsub + JPEG_WG - 1) / JPEG_WG;
+        W.tile0 = tile;
+        W.ntile = (D.stream_len + JPEG_TILE - 1) / JPEG_TILE;
+        W.coef_off = coef;
+        coef += (size_t)blocks * 64;
+        for (uint32_t c = 0; c < 3; ++c) {
+            W.plane_off[c] = 0; W.plane_w[c] = 0; W.plane_h[c] = 0;
+            if (c < D.ncomp) {
+                W.plane_w[c] = W.mx * (c == 0 ? D.hs : 1u) * 8u;
+                W.plane_h[c] = W.my * (c == 0 ? D.vs : 1u) * 8u;
+                W.plane_off[c] = planes;
+                planes += align_up((size_t)W.plane_w[c] * W.plane_h[c], 16);
+            }
+        }
+        W.reserved[0] = W.reserved[1] = 0;
+        wg += W.nwg;
+        tile += W.ntile;
+        max_blocks = std::max(max_blocks, W.total_blocks);
+        if (write) imgs[i] = W;
+        else if (memcmp(&W, &D, sizeof(W)) != 0)
+            return fail(CAMA_EINVAL, "image %d: descriptor was not produced by cama_jpeg_plan()", i);
+    }
+    L.total_wgs = wg; L.total_tiles = tile; L.max_blocks = max_blocks;
+    L.coef_elems = coef; L.plane_bytes = planes;
+    size_t off = 0;
+    L.clean = off;      off = align_up(off + (size_t)stream_bytes + 64, 256);
+    L.tile_count = off; off = align_up(off + (size_t)tile * 4, 256);
+    L.tile_base = off;  off = align_up(off + (size_t)tile * 4, 256);
+    L.nbits = off;      off = align_up(off + (size_t)n * 4, 256);
+    L.E = off;          off = align_up(off + (size_t)wg * JPEG_WG * 8, 256);
+    L.nb = off;         off = align_up(off + (size_t)wg * JPEG_WG * 4, 256);
+    L.wg_total = off;   off = align_up(off + (size_t)wg * 4, 256);
+    L.coef = off;       off = align_up(off + coef * 2, 256);
+    L.planes = off;     off = align_up(off + planes, 256);
+    L.total = off;
+    return CAMA_OK;
+}
+
+extern "C" size_t cama_jpeg_image_bytes(void) { return sizeof(cama_jpeg_image); }
+extern "C" size_t cama_jpeg_huff_set_bytes(void) { return sizeof(JpegHuffSet); }
+
+extern "C" int cama_jpeg_plan(cama_jpeg_image *imgs, int32_t n, uint64_t stream_bytes, cama_jpeg_plan_info *info)
+{
+    if (!imgs || !info) return fail(CAMA_EINVAL, "NULL pointer argument");
+    JpegLayout L;
+    if (int rc = jpeg_layout(imgs, imgs, n, stream_bytes, true, L)) return rc;
+    info->scratch_bytes = L.total;
+    info->total_wgs = L.total_wgs;
+    info->total_tiles = L.total_tiles;
+    info->max_blocks = L.max_blocks;
+    info->reserved = 0;
+    return CAMA_OK;
+}
+
+extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, const cama_jpeg_image *imgs,
+                                const cama_jpeg_image *imgs_dev, int32_t n, const void *huff_sets, int32_t n_huff_sets,
+                                const uint16_t *quant_sets, int32_t n_quant_sets, uint8_t *out, uint64_t out_stride,
+                                int32_t bgr, void *scratch, size_t scratch_bytes, int32_t *status, void *stream_handle)
+{
+    if (!stream || !imgs || !imgs_dev || !huff_sets || !quant_sets || !out || !scratch || !status)
+        return fail(CAMA_EINVAL, "NULL pointer argument");
+    JpegLayout L;
+    if (int rc = jpeg_layout(nullptr, imgs, n, stream_bytes, false, L)) return rc;
+    if (scratch_bytes < L.total) return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", scratch_bytes, L.total);
+    uint32_t maxw = 0, maxh = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((int32_t)imgs[i].huff_set >= n_huff_sets || (int32_t)imgs[i].quant_set >= n_quant_sets)
+            return fail(CAMA_EINVAL, "image %d: table set index out of range", i);
+        if ((uint64_t)imgs[i].width * imgs[i].height * 3 > out_stride)
+            return fail(CAMA_EINVAL, "image %d: %ux%ux3 bytes exceed out_stride %llu", i, imgs[i].width, imgs[i].height,
+                        (unsigned long long)out_stride);
+        maxw = std::max(maxw, imgs[i].width);
+        maxh = std::max(maxh, imgs[i].height);
+    }
+    if ((uintptr_t)stream % 16 || (uintptr_t)scratch % 256 || (uintptr_t)huff_sets % 16)
+        return fail(CAMA_EINVAL, "stream / huff_sets must be 16-byte and scratch 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream_handle;
+    char *base = (char *)scratch;
+    JpegArgs a{};
+    a.stream = stream; a.clean = (uint8_t *)(base + L.clean); a.imgs = imgs_dev; a.n = n;
+    a.huff = (const JpegHuffSet *)huff_sets; a.quant = quant_sets;
+    a.tile_count = (uint32_t *)(base + L.tile_count); a.tile_base = (uint32_t *)(base + L.tile_base);
+    a.nbits = (uint32_t *)(base + L.nbits); a.E = (uint64_t *)(base + L.E); a.nb = (uint32_t *)(base + L.nb);
+    a.wg_total = (uint32_t *)(base + L.wg_total); a.coef = (int16_t *)(base + L.coef);
+    a.planes = (uint8_t *)(base + L.planes); a.out = out; a.out_stride = (size_t)out_stride; a.bgr = bgr;
+    a.status = status;
+    HIP_TRY(hipMemsetAsync(a.clean, 0, (size_t)stream_bytes + 64, s));
+    HIP_TRY(hipMemsetAsync(a.coef, 0, L.coef_elems * 2, s));
+    HIP_TRY(hipMemsetAsync(status, 0, (size_t)n * 4, s));
+    hipLaunchKernelGGL(k_jpeg_count, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
+    hipLaunchKernelGGL(k_jpeg_tilescan, dim3((unsigned)n), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_jpeg_unstuff, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
+    hipLaunchKernelGGL(k_jpeg_sync<1>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a, 0u);
+    hipLaunchKernelGGL(k_jpeg_sync<2>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a, 0u);
+    hipLaunchKernelGGL(k_jpeg_write, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
+    hipLaunchKernelGGL(k_jpeg_dc, dim3((unsigned)n, 3), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_jpeg_idct, dim3((L.max_blocks + 31) / 32, (unsigned)n), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_jpeg_colour, dim3((maxw + 255) / 256, (maxh + JPEG_COLOUR_ROWS - 1) / JPEG_COLOUR_ROWS, (unsigned)n),
+                       dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+

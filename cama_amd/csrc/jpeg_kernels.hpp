@@ -1,0 +1,581 @@
+// Device baseline-JPEG decoder (frame ingest; the reference decodes every frame with cv2.imread =
+// libjpeg(-turbo) on one host core, cama/reproject.py:224,243).  Included by cama_hip.hip inside its anonymous namespace.
+//
+// Bit-exact restatement of libjpeg-turbo's default decode path (JDCT_ISLOW integer IDCT, "fancy" triangle chroma
+// upsampling, 16-bit fixed-point YCbCr->RGB), pinned by oracle/jpeg_oracle.py == Pillow's libjpeg-turbo.
+//
+// Stages, all images of a batch per launch:
+//   k_jpeg_count / k_jpeg_tilescan / k_jpeg_unstuff   remove 0xFF00 byte stuffing (count, per-image scan, compact)
+//   k_jpeg_sync<1>   Huffman decode of every 1024-bit subsequence from a SPECULATIVE start (its first bit, block 0,
+//                    DC expected), then a fixpoint inside each 256-subsequence workgroup: a subsequence is re-decoded
+//                    from its predecessor's end state until no end state changes.  Huffman streams self-synchronise,
+//                    so a wrong start usually reaches the right end state within one or two subsequences.
+//   k_jpeg_sync<2>   the same fixpoint seeded with the true entry state of each workgroup (= the previous
+//                    workgroup's last end state), which repairs the leading subsequences of every workgroup
+//   k_jpeg_write     final decode of every subsequence from its now exact start state; coefficients are written at
+//                    block index = exclusive scan of the per-subsequence completed-block counts; every end state is
+//                    re-checked, an inconsistency raises the image's status flag (the caller falls back to the host)
+//   k_jpeg_dc        per component prefix sum of the DC differences
+//   k_jpeg_idct      dequantise + islow IDCT, 8 lanes per block, column pass -> LDS -> row pass -> component planes
+//   k_jpeg_colour    fancy upsampling + colour conversion, one thread per output pixel, BGR or RGB
+
+constexpr int JPEG_SUB_WORDS = 32;                 // subsequence: 32 dwords = 1024 bits
+constexpr int JPEG_SUB_BITS = JPEG_SUB_WORDS * 32;
+constexpr int JPEG_WG = 256;                       // subsequences (threads) per workgroup
+constexpr int JPEG_TILE = 1024;                    // unstuff tile, bytes (4 per thread)
+constexpr int JPEG_LUT_BITS = 10;
+
+// Huffman table set as uploaded by the host (cama_amd/jpeg.py: build_huff_set) and copied verbatim to LDS.
+// Tables: 0 = DC0, 1 = AC0, 2 = DC1, 3 = AC1.
+struct JpegHuffSet {
+    uint16_t lut[4][1 << JPEG_LUT_BITS];   // (length << 8) | symbol for codes of <= 10 bits, 0 otherwise
+    int32_t maxcode[4][17];                // largest code of each length (length 11..16 used), -1 if none
+    int32_t valoff[4][17];                 // index of a length's first symbol minus its first code
+    uint8_t vals[4][256];
+    uint8_t pad[48];                       // sizeof == 9808, a multiple of 16
+};
+static_assert(sizeof(JpegHuffSet) == 9808, "JpegHuffSet layout");
+
+struct JpegArgs {
+    const uint8_t *stream;            // stuffed entropy segments
+    uint8_t *clean;                   // unstuffed copy (same offsets)
+    const cama_jpeg_image *imgs;      // device copy of the planned descriptors
+    int n;
+    const JpegHuffSet *huff;
+    const uint16_t *quant;            // [sets][3][64] natural order
+    uint32_t *tile_count, *tile_base; // per unstuff tile
+    uint32_t *nbits;                  // per image: bits in the unstuffed stream
+    uint64_t *E;                      // per subsequence: end state  pos << 16 | blk << 8 | k
+    uint32_t *nb;                     // per subsequence: blocks completed
+    uint32_t *wg_total;               // per decode workgroup: blocks completed
+    int16_t *coef;
+    uint8_t *planes;
+    uint8_t *out;                     // [n, height, width, 3]
+    size_t out_stride;                // bytes between images
+    int bgr;
+    int32_t *status;                  // per image, 0 = ok
+};
+
+__device__ __forceinline__ int jpeg_find_image(const cama_jpeg_image *imgs, int n, uint32_t id, bool by_tile)
+{
+    int lo = 0, hi = n - 1;           // last image whose first workgroup / tile is <= id
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const uint32_t first = by_tile ? imgs[mid].tile0 : imgs[mid].wg0;
+        if (first <= id) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------ byte unstuffing
+// byte i of an entropy segment is dropped iff it is the 0x00 that follows a 0xFF (T.81 B.1.1.5)
+__device__ __forceinline__ uint32_t jpeg_drop_mask(const uint8_t *seg, uint32_t len, uint32_t i0, uint32_t &bytes)
+{
+    // bytes i0..i0+3 (zero beyond len) and which of them are stuffed zeros
+    uint32_t m = 0;
+    bytes = 0;
+    uint32_t prev = i0 ? seg[i0 - 1] : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = i0 + k;
+        const uint32_t b = i < len ? seg[i] : 0u;
+        if (i < len && b == 0u && prev == 0xFFu) m |= 1u << k;
+        bytes |= b << (8 * k);
+        prev = b;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(JPEG_TILE / 4) void k_jpeg_count(JpegArgs a)
+{
+    const int img = jpeg_find_image(a.imgs, a.n, blockIdx.x, true);
+    const cama_jpeg_image &D = a.imgs[img];
+    const uint32_t i0 = (blockIdx.x - D.tile0) * JPEG_TILE + threadIdx.x * 4;
+    uint32_t bytes;
+    const uint32_t m = i0 < D.stream_len ? jpeg_drop_mask(a.stream + D.stream_off, D.stream_len, i0, bytes) : 0u;
+    uint32_t c = __popc(m);
+#pragma unroll
+    for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off, 64);
+    __shared__ uint32_t s_w[JPEG_TILE / 4 / 64];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < JPEG_TILE / 4 / 64; ++w) t += s_w[w];
+        a.tile_count[blockIdx.x] = t;
+    }
+}
+
+// one workgroup per image: exclusive scan of its tiles' drop counts, and the image's unstuffed bit count
+__global__ __launch_bounds__(256) void k_jpeg_tilescan(JpegArgs a)
+{
+    const cama_jpeg_image &D = a.imgs[blockIdx.x];
+    __shared__ uint32_t s_part[256];
+    const uint32_t per = (D.ntile + 255u) / 256u;
+    const uint32_t t0 = min(threadIdx.x * per, D.ntile), t1 = min(t0 + per, D.ntile);
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; ++t) sum += a.tile_count[D.tile0 + t];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < 256; ++k) {
+            const uint32_t v = s_part[k];
+            s_part[k] = run;
+            run += v;
+        }
+        a.nbits[blockIdx.x] = (D.stream_len - run) * 8u;
+    }
+    __syncthreads();
+    uint32_t run = s_part[threadIdx.x];
+    for (uint32_t t = t0; t < t1; ++t) {
+        a.tile_base[D.tile0 + t] = run;
+        run += a.tile_count[D.tile0 + t];
+    }
+}
+
+__global__ __launch_bounds__(JPEG_TILE / 4) void k_jpeg_unstuff(JpegArgs a)
+{
+    const int img = jpeg_find_image(a.imgs, a.n, blockIdx.x, true);
+    const cama_jpeg_image &D = a.imgs[img];
+    const uint32_t i0 = (blockIdx.x - D.tile0) * JPEG_TILE + threadIdx.x * 4;
+    uint32_t bytes = 0;
+    const uint32_t m = i0 < D.stream_len ? jpeg_drop_mask(a.stream + D.stream_off, D.stream_len, i0, bytes) : 0u;
+    // exclusive prefix of the drop counts inside the tile
+    const uint32_t c = __popc(m);
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += v;
+    }
+    __shared__ uint32_t s_w[JPEG_TILE / 4 / 64];
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = a.tile_base[blockIdx.x] + incl - c;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += s_w[w];
+    uint8_t *dst = a.clean + D.stream_off;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = i0 + k;
+        if (i < D.stream_len) {
+            if (m & (1u << k)) ++before;
+            else dst[i - before] = (uint8_t)(bytes >> (8 * k));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ Huffman decoding
+struct JpegState { uint32_t pos, blk, k; };
+__device__ __forceinline__ uint64_t jpeg_pack(const JpegState &s) { return ((uint64_t)s.pos << 16) | (s.blk << 8) | s.k; }
+__device__ __forceinline__ JpegState jpeg_unpack(uint64_t v)
+{
+    return JpegState{(uint32_t)(v >> 16), (uint32_t)(v >> 8) & 0xffu, (uint32_t)v & 0xffu};
+}
+
+struct JpegWgCtx {
+    const uint32_t *words;     // LDS: this workgroup's stream words, big-endian numeric, one pad word per 32
+    uint32_t word0;            // image-relative index of words[0]
+    const JpegHuffSet *H;      // LDS
+    uint32_t dc_mask, ac_mask; // bit b: Huffman table selector (0/1) of block b of the MCU
+    uint32_t bpm;
+};
+
+__device__ __forceinline__ uint32_t jpeg_window(const JpegWgCtx &c, uint32_t pos)
+{
+    const uint32_t w = (pos >> 5) - c.word0;
+    const uint32_t hi = c.words[w + (w >> 5)], lo = c.words[(w + 1) + ((w + 1) >> 5)];
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) << (pos & 31u) >> 32);
+}
+
+__device__ __forceinline__ uint32_t jpeg_symbol(const JpegHuffSet &H, uint32_t tab, uint32_t window)
+{
+    const uint32_t e = H.lut[tab][window >> (32 - JPEG_LUT_BITS)];
+    if (e) return e;
+    for (int l = JPEG_LUT_BITS + 1; l <= 16; ++l) {
+        const int32_t code = (int32_t)(window >> (32 - l));
+        if (code <= H.maxcode[tab][l]) return ((uint32_t)l << 8) | H.vals[tab][(code + H.valoff[tab][l]) & 255];
+    }
+    return 16u << 8;           // no such code (only on speculative paths): skip 16 bits, symbol 0
+}
+
+__constant__ uint8_t c_jpeg_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                                          12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                          35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                                          58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// Decode every symbol that STARTS in [s.pos, end): T.81 F.2.2 with the decoder state (block in MCU, zigzag index).
+// WRITE: store the coefficients of block `block` onwards (DC as the raw difference).
+template <bool WRITE>
+__device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegState &s, uint32_t end, int16_t *coef,
+                                                     uint32_t block, uint32_t total_blocks)
+{
+    uint32_t nb = 0;
+    while (s.pos < end) {
+        const uint32_t win = jpeg_window(c, s.pos);
+        uint32_t len, size, run = 0;
+        if (s.k == 0) {
+            const uint32_t e = jpeg_symbol(*c.H, ((c.dc_mask >> s.blk) & 1u) * 2u, win);
+            len = e >> 8;
+            size = e & 15u;
+        } else {
+            const uint32_t e = jpeg_symbol(*c.H, ((c.ac_mask >> s.blk) & 1u) * 2u + 1u, win);
+            len = e >> 8;
+            size = e & 15u;
+            run = (e >> 4) & 15u;
+            if (size == 0u) run = (run == 15u) ? 16u : 64u;       // ZRL: skip 16; EOB: to the end of the block
+        }
+        const uint32_t at = s.k + (s.k ? (size ? run : 0u) : 0u);
+        if (WRITE && size && at < 64u && block + nb < total_blocks) {
+            const uint32_t v = (win << len) >> (32u - size);
+            const int32_t val = (v < (1u << (size - 1u))) ? (int32_t)v - (int32_t)((1u << size) - 1u) : (int32_t)v;
+            coef[(size_t)(block + nb) * 64 + c_jpeg_zigzag[at]] = (int16_t)val;
+        }
+        s.pos += len + size;
+        s.k = s.k ? (size ? at + 1u : s.k + run) : 1u;
+        if (s.k >= 64u) {
+            s.k = 0;
+            s.blk = (s.blk + 1u == c.bpm) ? 0u : s.blk + 1u;
+            ++nb;
+        }
+    }
+    return nb;
+}
+
+// common prologue: stream words + tables to LDS
+struct JpegWgShared {
+    JpegHuffSet H;
+    uint32_t words[JPEG_WG * JPEG_SUB_WORDS + JPEG_WG + 40];
+    uint64_t E[JPEG_WG];
+    uint32_t nb[JPEG_WG];
+    uint8_t flag[2][JPEG_WG];
+};
+
+__device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg_image &D, uint32_t lw, JpegWgShared &S,
+                                              JpegWgCtx &c)
+{
+    // tables
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.huff + D.huff_set);
+    uint4 *dst = reinterpret_cast<uint4 *>(&S.H);
+    for (uint32_t i = threadIdx.x; i < sizeof(JpegHuffSet) / 16; i += JPEG_WG) dst[i] = src[i];
+    // stream: dwords [lw*256*32, +256*32 + 2) of the unstuffed segment (stream_off is 16-byte aligned; the region
+    // past the segment is zero: the clean buffer is cleared per batch)
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(a.clean + D.stream_off);
+    const uint32_t w0 = lw * JPEG_WG * JPEG_SUB_WORDS;
+    const uint32_t nwords_img = (D.stream_len + 3u) / 4u + 4u;          // slack words exist (plan pads every segment)
+    for (uint32_t i = threadIdx.x; i < JPEG_WG * JPEG_SUB_WORDS + 2; i += JPEG_WG) {
+        const uint32_t w = w0 + i;
+        S.words[i + (i >> 5)] = w < nwords_img ? __builtin_bswap32(g[w]) : 0u;
+    }
+    c.words = S.words;
+    c.word0 = w0;
+    c.H = &S.H;
+    c.bpm = D.bpm;
+    uint32_t b = 0;
+    c.dc_mask = c.ac_mask = 0;
+    const uint32_t luma_blocks = D.hs * D.vs;
+    for (uint32_t ci = 0; ci < D.ncomp; ++ci) {
+        const uint32_t nblk = ci == 0 ? luma_blocks : 1u;
+        for (uint32_t j = 0; j < nblk; ++j, ++b) {
+            c.dc_mask |= (D.comp_dc[ci] & 1u) << b;
+            c.ac_mask |= (D.comp_ac[ci] & 1u) << b;
+        }
+    }
+}
+
+// PHASE 1: speculative decode + fixpoint inside the workgroup.  PHASE 2: fixpoint seeded with the true entry state.
+template <int PHASE>
+__global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a, uint32_t sub_total0)
+{
+    (void)sub_total0;
+    __shared__ JpegWgShared S;
+    const int img = jpeg_find_image(a.imgs, a.n, blockIdx.x, false);
+    const cama_jpeg_image &D = a.imgs[img];
+    const uint32_t lw = blockIdx.x - D.wg0;
+    const uint32_t nbits = a.nbits[img];
+    const uint32_t sub0 = lw * JPEG_WG;                                  // image-relative first subsequence
+    if ((uint64_t)sub0 * JPEG_SUB_BITS >= nbits) {                      // workgroup beyond the unstuffed stream
+        if (threadIdx.x == 0) a.wg_total[blockIdx.x] = 0;
+        return;
+    }
+    if (PHASE == 2 && lw == 0) return;                                  // its entry state was exact in phase 1
+    JpegWgCtx c;
+    jpeg_wg_setup(a, D, lw, S, c);
+    const uint32_t nsub_img = (nbits + JPEG_SUB_BITS - 1) / JPEG_SUB_BITS;
+    const uint32_t last = min((uint32_t)JPEG_WG - 1u, nsub_img - 1u - sub0);   // last subsequence with bits
+    const uint32_t t = sub0 + threadIdx.x;
+    const bool active = threadIdx.x <= last;
+    const uint32_t lo = t * JPEG_SUB_BITS, hi = min(lo + JPEG_SUB_BITS, nbits);
+    const size_t gsub = (size_t)D.wg0 * JPEG_WG + (size_t)lw * JPEG_WG + threadIdx.x;   // global subsequence slot
+    int cur = 0;
+    __syncthreads();
+    if (PHASE == 1) {
+        JpegState s{lo, 0u, 0u};
+        uint32_t nb = 0;
+        if (active) nb = jpeg_decode_span<false>(c, s, hi, nullptr, 0, 0);
+        S.E[threadIdx.x] = jpeg_pack(s);
+        S.nb[threadIdx.x] = nb;
+        S.flag[0][threadIdx.x] = 1;
+    } else {
+        S.E[threadIdx.x] = a.E[gsub];
+        S.nb[threadIdx.x] = a.nb[gsub];
+        S.flag[0][threadIdx.x] = 0;
+        if (threadIdx.x == 0) {
+            // entry = end state of the previous workgroup's last subsequence
+            JpegState s = jpeg_unpack(a.E[gsub - 1]);
+            const uint32_t nb = jpeg_decode_span<false>(c, s, hi, nullptr, 0, 0);
+            const uint64_t e = jpeg_pack(s);
+            S.flag[0][0] = (e != S.E[0]) || (nb != S.nb[0]);
+            S.E[0] = e;
+            S.nb[0] = nb;
+        }
+    }
+    for (int round = 0; round < JPEG_WG; ++round) {
+        __syncthreads();
+        const bool redo = active && threadIdx.x > 0 && S.flag[cur][threadIdx.x - 1];
+        const uint64_t start = threadIdx.x > 0 ? S.E[threadIdx.x - 1] : 0ull;
+        __syncthreads();
+        int changed = 0;
+        if (redo) {
+            JpegState s = jpeg_unpack(start);
+            const uint32_t nb = jpeg_decode_span<false>(c, s, hi, nullptr, 0, 0);
+            const uint64_t e = jpeg_pack(s);
+            changed = (e != S.E[threadIdx.x]);
+            S.E[threadIdx.x] = e;
+            S.nb[threadIdx.x] = nb;          // the count depends on the start state even when the end state does not
+        }
+        S.flag[cur ^ 1][threadIdx.x] = (uint8_t)changed;
+        cur ^= 1;
+        if (!__syncthreads_or(changed)) break;
+    }
+    __syncthreads();
+    a.E[gsub] = S.E[min(threadIdx.x, last)];                              // slots past `last` mirror it (entry of the next wg)
+    a.nb[gsub] = active ? S.nb[threadIdx.x] : 0u;
+    // workgroup total
+    uint32_t v = active ? S.nb[threadIdx.x] : 0u;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off, 64);
+    __shared__ uint32_t s_tot[JPEG_WG / 64];
+    if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < JPEG_WG / 64; ++w) tot += s_tot[w];
+        a.wg_total[blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(JPEG_WG) void k_jpeg_write(JpegArgs a)
+{
+    __shared__ JpegWgShared S;
+    __shared__ uint32_t s_scan[JPEG_WG];
+    const int img = jpeg_find_image(a.imgs, a.n, blockIdx.x, false);
+    const cama_jpeg_image &D = a.imgs[img];
+    const uint32_t lw = blockIdx.x - D.wg0;
+    const uint32_t nbits = a.nbits[img];
+    const uint32_t sub0 = lw * JPEG_WG;
+    if ((uint64_t)sub0 * JPEG_SUB_BITS >= nbits) return;
+    JpegWgCtx c;
+    jpeg_wg_setup(a, D, lw, S, c);
+    const uint32_t nsub_img = (nbits + JPEG_SUB_BITS - 1) / JPEG_SUB_BITS;
+    const uint32_t last = min((uint32_t)JPEG_WG - 1u, nsub_img - 1u - sub0);
+    const uint32_t t = sub0 + threadIdx.x;
+    const bool active = threadIdx.x <= last;
+    const uint32_t lo = t * JPEG_SUB_BITS, hi = min(lo + JPEG_SUB_BITS, nbits);
+    const size_t gsub = (size_t)D.wg0 * JPEG_WG + (size_t)lw * JPEG_WG + threadIdx.x;
+    // blocks completed before this workgroup, then before this subsequence
+    uint32_t before = 0;
+    for (uint32_t w = threadIdx.x; w < lw; w += JPEG_WG) before += a.wg_total[D.wg0 + w];
+    const uint32_t mine = active ? a.nb[gsub] : 0u;
+    s_scan[threadIdx.x] = before;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < JPEG_WG; ++k) tot += s_scan[k];
+        S.nb[0] = tot;                                   // reuse: base of the workgroup
+    }
+    __syncthreads();
+    const uint32_t base = S.nb[0];
+    __syncthreads();
+    s_scan[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = base;
+        for (int k = 0; k < JPEG_WG; ++k) {
+            const uint32_t v = s_scan[k];
+            s_scan[k] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    JpegState s = (t == 0) ? JpegState{0u, 0u, 0u} : jpeg_unpack(a.E[gsub - 1]);
+    const uint32_t nb = jpeg_decode_span<true>(c, s, hi, a.coef + D.coef_off, s_scan[threadIdx.x], D.total_blocks);
+    int bad = (jpeg_pack(s) != a.E[gsub]) || (nb != mine);
+    if (t == nsub_img - 1u && s_scan[threadIdx.x] + nb != D.total_blocks) bad |= 2;
+    if (bad) atomicOr(&a.status[img], bad);
+}
+
+// per (image, component): DC[i] = sum of the differences up to block i of that component (T.81 F.2.1.3.1)
+__global__ __launch_bounds__(256) void k_jpeg_dc(JpegArgs a)
+{
+    const cama_jpeg_image &D = a.imgs[blockIdx.x];
+    const uint32_t ci = blockIdx.y;
+    if (ci >= D.ncomp) return;
+    const uint32_t hv = ci == 0 ? D.hs * D.vs : 1u;
+    const uint32_t first = ci == 0 ? 0u : D.hs * D.vs + (ci - 1u);
+    const uint32_t n = D.mx * D.my * hv;
+    int16_t *coef = a.coef + D.coef_off;
+    const uint32_t per = (n + 255u) / 256u;
+    const uint32_t i0 = min(threadIdx.x * per, n), i1 = min(i0 + per, n);
+    int32_t sum = 0;
+    for (uint32_t i = i0; i < i1; ++i) sum += coef[(size_t)((i / hv) * D.bpm + first + i % hv) * 64];
+    __shared__ int32_t s_part[256];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t run = 0;
+        for (int k = 0; k < 256; ++k) {
+            const int32_t v = s_part[k];
+            s_part[k] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    int32_t run = s_part[threadIdx.x];
+    for (uint32_t i = i0; i < i1; ++i) {
+        int16_t *p = coef + (size_t)((i / hv) * D.bpm + first + i % hv) * 64;
+        run += *p;
+        *p = (int16_t)run;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ IDCT (IJG jidctint "islow")
+__device__ __forceinline__ void jpeg_idct8(const int32_t d[8], int32_t o[8], int shift)
+{
+    constexpr int32_t F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633,
+                      F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995,
+                      F_3_072 = 25172;
+    int32_t z1 = (d[2] + d[6]) * F_0_541;
+    const int32_t tmp2 = z1 + d[6] * (-F_1_847), tmp3 = z1 + d[2] * F_0_765;
+    const int32_t tmp0 = (int32_t)((uint32_t)(d[0] + d[4]) << 13), tmp1 = (int32_t)((uint32_t)(d[0] - d[4]) << 13);
+    const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    int32_t t0 = d[7], t1 = d[5], t2 = d[3], t3 = d[1];
+    z1 = t0 + t3;
+    int32_t z2 = t1 + t2, z3 = t0 + t2, z4 = t1 + t3;
+    const int32_t z5 = (z3 + z4) * F_1_175;
+    t0 *= F_0_298; t1 *= F_2_053; t2 *= F_3_072; t3 *= F_1_501;
+    z1 *= -F_0_899; z2 *= -F_2_562;
+    z3 = z3 * (-F_1_961) + z5;
+    z4 = z4 * (-F_0_390) + z5;
+    t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+    const int32_t r = 1 << (shift - 1);
+    o[0] = (tmp10 + t3 + r) >> shift; o[7] = (tmp10 - t3 + r) >> shift;
+    o[1] = (tmp11 + t2 + r) >> shift; o[6] = (tmp11 - t2 + r) >> shift;
+    o[2] = (tmp12 + t1 + r) >> shift; o[5] = (tmp12 - t1 + r) >> shift;
+    o[3] = (tmp13 + t0 + r) >> shift; o[4] = (tmp13 - t0 + r) >> shift;
+}
+
+__device__ __forceinline__ uint32_t jpeg_range_limit(int32_t v)       // IJG range_limit[v & RANGE_MASK], +128 level shift
+{
+    const uint32_t x = (uint32_t)v & 1023u;
+    return x < 128u ? x + 128u : (x < 512u ? 255u : (x < 896u ? 0u : x - 896u));
+}
+
+// grid (ceil(max_blocks / 32), n); 256 threads = 32 blocks x 8 lanes
+__global__ __launch_bounds__(256) void k_jpeg_idct(JpegArgs a)
+{
+    __shared__ int32_t s_ws[32][8][9];
+    const cama_jpeg_image &D = a.imgs[blockIdx.y];
+    const uint32_t lane = threadIdx.x & 7u, lb = threadIdx.x >> 3;
+    const uint32_t j = blockIdx.x * 32u + lb;                    // scan-order block
+    const bool live = j < D.total_blocks;
+    uint32_t ci = 0, bx = 0, by = 0;
+    if (live) {
+        const uint32_t mcu = j / D.bpm, within = j - mcu * D.bpm, luma = D.hs * D.vs;
+        const uint32_t mcx = mcu % D.mx, mcy = mcu / D.mx;
+        if (within < luma) {
+            bx = mcx * D.hs + within % D.hs;
+            by = mcy * D.vs + within / D.hs;
+        } else {
+            ci = within - luma + 1u;
+            bx = mcx;
+            by = mcy;
+        }
+        // pass 1: column `lane`
+        const int16_t *cf = a.coef + D.coef_off + (size_t)j * 64;
+        const uint16_t *q = a.quant + ((size_t)D.quant_set * 3 + ci) * 64;
+        int32_t d[8], o[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d[r] = (int32_t)cf[r * 8 + lane] * (int32_t)q[r * 8 + lane];
+        jpeg_idct8(d, o, 13 - 2);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s_ws[lb][r][lane] = o[r];
+    }
+    __syncthreads();
+    if (!live) return;
+    int32_t d[8], o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = s_ws[lb][lane][k];
+    jpeg_idct8(d, o, 13 + 2 + 3);
+    uint32_t p0 = 0, p1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p0 |= jpeg_range_limit(o[k]) << (8 * k);
+        p1 |= jpeg_range_limit(o[k + 4]) << (8 * k);
+    }
+    uint8_t *plane = a.planes + D.plane_off[ci];
+    *reinterpret_cast<uint2 *>(plane + (size_t)(by * 8u + lane) * D.plane_w[ci] + bx * 8u) = make_uint2(p0, p1);
+}
+
+// ------------------------------------------------------------------------------------------ upsampling + colour
+__device__ __forceinline__ int32_t jpeg_chroma(const uint8_t *p, uint32_t pw, uint32_t cw, uint32_t ch, uint32_t hs,
+                                               uint32_t vs, uint32_t x, uint32_t y)
+{
+    if (hs == 1u) return p[(size_t)y * pw + x];
+    const uint32_t cx = x >> 1;
+    if (vs == 1u) {                                              // h2v1_fancy_upsample
+        const uint8_t *row = p + (size_t)y * pw;
+        const int32_t v = row[cx];
+        if (x & 1u) return cx + 1u == cw ? v : (v * 3 + row[cx + 1] + 2) >> 2;
+        return cx == 0u ? v : (v * 3 + row[cx - 1] + 1) >> 2;
+    }
+    // h2v2_fancy_upsample: column sums of (3 * nearer row + further row), then the same 3:1 blend across columns
+    const uint32_t cy = y >> 1;
+    const uint32_t ny = (y & 1u) ? min(cy + 1u, ch - 1u) : (cy ? cy - 1u : 0u);
+    const uint8_t *r0 = p + (size_t)cy * pw, *r1 = p + (size_t)ny * pw;
+    const int32_t s = r0[cx] * 3 + r1[cx];
+    if (x & 1u) {
+        if (cx + 1u == cw) return (s * 4 + 7) >> 4;
+        return (s * 3 + (r0[cx + 1] * 3 + r1[cx + 1]) + 7) >> 4;
+    }
+    if (cx == 0u) return (s * 4 + 8) >> 4;
+    return (s * 3 + (r0[cx - 1] * 3 + r1[cx - 1]) + 8) >> 4;
+}
+
+// grid (ceil(W/256), ceil(H/4), n), 256 threads: one output column, 4 rows each
+constexpr int JPEG_COLOUR_ROWS = 4;
+__global__ __launch_bounds__(256) void k_jpeg_colour(JpegArgs a)
+{
+    const cama_jpeg_image &D = a.imgs[blockIdx.z];
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= D.width) return;
+    for (uint32_t y = blockIdx.y * JPEG_COLOUR_ROWS; y < min((blockIdx.y + 1u) * JPEG_COLOUR_ROWS, D.height); ++y) {
+    const int32_t Y = a.planes[D.plane_off[0] + (size_t)y * D.plane_w[0] + x];
+    int32_t r = Y, g = Y, b = Y;
+    if (D.ncomp == 3u) {
+        const uint32_t cw = (D.width + D.hs - 1u) / D.hs, ch = (D.height + D.vs - 1u) / D.vs;
+        const int32_t cb = jpeg_chroma(a.planes + D.plane_off[1], D.plane_w[1], cw, ch, D.hs, D.vs, x, y) - 128;
+        const int32_t cr = jpeg_chroma(a.planes + D.plane_off[2], D.plane_w[2], cw, ch, D.hs, D.vs, x, y) - 128;
+        // IJG jdcolor: 16-bit fixed point, arithmetic shifts
+        r = Y + ((91881 * cr + 32768) >> 16);
+        g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+        b = Y + ((116130 * cb + 32768) >> 16);
+        r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
+    }
+    uint8_t *o = a.out + (size_t)blockIdx.z * a.out_stride + ((size_t)y * D.width + x) * 3;
+    o[0] = (uint8_t)(a.bgr ? b : r);
+    o[1] = (uint8_t)g;
+    o[2] = (uint8_t)(a.bgr ? r : b);
+    }
+}

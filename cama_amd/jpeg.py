@@ -1,0 +1,293 @@
+"""Device JPEG decode for frame ingest: the host side of cama_jpeg_decode (include/cama_hip.h).
+
+The reference decodes every camera frame with cv2.imread on one host core (cama/reproject.py:224,243;
+cama/dataset_reader.py:72-76) -- ~10 ms per 1600x900 image, 96 % of a demo frame once the reprojection runs on the GPU.
+Here the host only walks the marker segments (a few dozen bytes of headers per file), packs the entropy-coded bytes of
+a whole batch into one upload and hands descriptors + tables to the device decoder, whose output is byte-identical to
+libjpeg-turbo's (tests/test_gpu_jpeg.py against Pillow and oracle/jpeg_oracle.py).
+
+Scope of the device path: baseline sequential (SOF0), 8 bit, grey or YCbCr with 4:4:4 / 4:2:2 / 4:2:0 sampling, one
+interleaved scan, no restart intervals.  Anything else -- and any stream the device flags as inconsistent -- is decoded
+by Pillow on the host and uploaded, so `decode()` always returns every image.
+"""
+import io
+
+import numpy as np
+
+from . import _lib
+
+IMAGE_DTYPE = np.dtype([
+    ("stream_off", "<u8"), ("coef_off", "<u8"), ("plane_off", "<u8", (3,)),
+    ("stream_len", "<u4"), ("width", "<u4"), ("height", "<u4"), ("ncomp", "<u4"), ("hs", "<u4"), ("vs", "<u4"),
+    ("huff_set", "<u4"), ("quant_set", "<u4"), ("comp_dc", "<u4", (3,)), ("comp_ac", "<u4", (3,)),
+    ("mx", "<u4"), ("my", "<u4"), ("bpm", "<u4"), ("total_blocks", "<u4"),
+    ("wg0", "<u4"), ("nwg", "<u4"), ("tile0", "<u4"), ("ntile", "<u4"),
+    ("plane_w", "<u4", (3,)), ("plane_h", "<u4", (3,)), ("reserved", "<u4", (2,))])          # == cama_jpeg_image
+
+LUT_BITS = 10
+HUFF_DTYPE = np.dtype([("lut", "<u2", (4, 1 << LUT_BITS)), ("maxcode", "<i4", (4, 17)), ("valoff", "<i4", (4, 17)),
+                       ("vals", "u1", (4, 256)), ("pad", "u1", (48,))])                       # == JpegHuffSet
+
+_ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20,
+                    13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52,
+                    45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
+
+
+class Unsupported(ValueError):
+    """The file is outside the device decoder's scope; use the host decoder."""
+
+
+class JpegHeader:
+    __slots__ = ("width", "height", "ncomp", "hs", "vs", "quant", "huff", "comp_dc", "comp_ac", "scan_start",
+                 "scan_end")
+
+
+def parse_header(data):
+    """Walk the marker segments up to SOS (T.81 B.2).  Returns a JpegHeader whose `quant` is (3,64) uint16 in natural
+    order, `huff` the raw DHT payloads {(class, id): bytes}, and [scan_start, scan_end) the entropy-coded bytes."""
+    if data[:2] != b"\xff\xd8":
+        raise Unsupported("not a JPEG")
+    n = len(data)
+    i = 2
+    qt, huff, frame, dri = {}, {}, None, 0
+    while i + 4 <= n:
+        if data[i] != 0xFF:
+            raise Unsupported("marker expected")
+        m = data[i + 1]
+        if m == 0xFF:
+            i += 1
+            continue
+        if m in (0xD8, 0x01) or 0xD0 <= m <= 0xD7:
+            i += 2
+            continue
+        L = (data[i + 2] << 8) | data[i + 3]
+        seg = data[i + 4:i + 2 + L]
+        if m == 0xDB:
+            j = 0
+            while j < len(seg):
+                if seg[j] >> 4:
+                    raise Unsupported("16-bit quantisation table")
+                qt[seg[j] & 15] = np.frombuffer(seg, np.uint8, 64, j + 1)
+                j += 65
+        elif m == 0xC4:
+            j = 0
+            while j < len(seg):
+                cnt = sum(seg[j + 1:j + 17])
+                huff[(seg[j] >> 4, seg[j] & 15)] = bytes(seg[j + 1:j + 17 + cnt])
+                j += 17 + cnt
+        elif m == 0xC0:
+            frame = seg
+        elif 0xC1 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
+            raise Unsupported("not baseline sequential DCT")
+        elif m == 0xDD:
+            dri = (seg[0] << 8) | seg[1]
+        elif m == 0xDA:
+            if frame is None:
+                raise Unsupported("SOS before SOF")
+            break
+        elif m == 0xD9:
+            raise Unsupported("no scan")
+        i += 2 + L
+    else:
+        raise Unsupported("truncated")
+    h = JpegHeader()
+    if frame[0] != 8:
+        raise Unsupported("sample precision")
+    h.height, h.width, h.ncomp = (frame[1] << 8) | frame[2], (frame[3] << 8) | frame[4], frame[5]
+    if h.ncomp not in (1, 3) or h.width == 0 or h.height == 0:
+        raise Unsupported("component count / size")
+    comps = [(frame[6 + 3 * k], frame[7 + 3 * k] >> 4, frame[7 + 3 * k] & 15, frame[8 + 3 * k]) for k in range(h.ncomp)]
+    if dri:
+        raise Unsupported("restart intervals")
+    if seg[0] != h.ncomp or tuple(seg[1 + 2 * h.ncomp:4 + 2 * h.ncomp]) != (0, 63, 0):
+        raise Unsupported("not one interleaved full-spectrum scan")
+    h.comp_dc, h.comp_ac = [0, 0, 0], [0, 0, 0]
+    for k in range(h.ncomp):
+        if seg[1 + 2 * k] != comps[k][0]:
+            raise Unsupported("scan component order")
+        h.comp_dc[k], h.comp_ac[k] = seg[2 + 2 * k] >> 4, seg[2 + 2 * k] & 15
+        if h.comp_dc[k] > 1 or h.comp_ac[k] > 1 or (0, h.comp_dc[k]) not in huff or (1, h.comp_ac[k]) not in huff:
+            raise Unsupported("Huffman table selector")
+    if h.ncomp == 1:
+        h.hs = h.vs = 1
+    else:
+        h.hs, h.vs = comps[0][1], comps[0][2]
+        if (h.hs, h.vs) not in ((1, 1), (2, 1), (2, 2)) or any(c[1:3] != (1, 1) for c in comps[1:]):
+            raise Unsupported("sampling factors")
+    h.quant = np.zeros((3, 64), np.uint16)
+    for k in range(h.ncomp):
+        if comps[k][3] not in qt:
+            raise Unsupported("missing quantisation table")
+        h.quant[k, _ZIGZAG] = qt[comps[k][3]]
+    h.huff = huff
+    h.scan_start = i + 2 + L
+    end = data.rfind(b"\xff\xd9")
+    if end < h.scan_start:
+        raise Unsupported("no EOI")
+    h.scan_end = end
+    return h
+
+
+def build_huff_set(huff):
+    """{(class, id): DHT payload (16 counts + symbols)} -> one HUFF_DTYPE record: tables DC0, AC0, DC1, AC1 with a
+    10-bit lookup (length << 8 | symbol) and the canonical maxcode / value-offset arrays for longer codes (T.81 C, F.2.2.3)."""
+    rec = np.zeros((), HUFF_DTYPE)
+    rec["maxcode"][...] = -1
+    for (cls, tid), payload in huff.items():
+        if tid > 1:
+            continue
+        t = tid * 2 + cls
+        bits = np.frombuffer(payload, np.uint8, 16)
+        vals = np.frombuffer(payload, np.uint8, offset=16)
+        rec["vals"][t, :len(vals)] = vals
+        code = k = 0
+        for l in range(1, 17):
+            cnt = int(bits[l - 1])
+            if cnt:
+                rec["valoff"][t, l] = k - code
+                rec["maxcode"][t, l] = code + cnt - 1
+                if l <= LUT_BITS:
+                    span = 1 << (LUT_BITS - l)
+                    entries = (np.uint16(l) << 8) | vals[k:k + cnt].astype(np.uint16)
+                    rec["lut"][t, code << (LUT_BITS - l):(code + cnt) << (LUT_BITS - l)] = np.repeat(entries, span)
+                code += cnt
+                k += cnt
+            code <<= 1
+    return rec
+
+
+def _host_decode(data, bgr):
+    from PIL import Image
+    with Image.open(io.BytesIO(data)) as im:
+        arr = np.array(im.convert("RGB"))
+    return arr[:, :, ::-1] if bgr else arr
+
+
+class DeviceJpegDecoder:
+    """Batch decoder bound to one GPU.  decode(list of JPEG byte strings) -> uint8 tensor [n, H, W, 3] on the device
+    (all images of a batch must share one size; BGR by default = cv2.imread's order)."""
+
+    def __init__(self, device):
+        import torch
+        self.lib = _lib.lib()
+        if not torch.cuda.is_available():
+            raise _lib.CamaHipError("DeviceJpegDecoder needs a GPU; there is no CPU fallback for the device path")
+        assert self.lib.cama_jpeg_image_bytes() == IMAGE_DTYPE.itemsize
+        assert self.lib.cama_jpeg_huff_set_bytes() == HUFF_DTYPE.itemsize
+        self.device = torch.device(device)
+        self._huff_index, self._huff_host, self._huff_dev = {}, [], None
+        self._quant_index, self._quant_host, self._quant_dev = {}, [], None
+        self._scratch = None
+        self._pinned = None
+        self.stats = {"device": 0, "host_unsupported": 0, "host_flagged": 0}
+
+    # ------------------------------------------------------------------ table caches (device copies grow on demand)
+    def _huff_id(self, huff):
+        key = tuple(sorted((k, v) for k, v in huff.items() if k[1] <= 1))
+        idx = self._huff_index.get(key)
+        if idx is None:
+            idx = self._huff_index[key] = len(self._huff_host)
+            self._huff_host.append(build_huff_set(huff))
+            self._huff_dev = None
+        return idx
+
+    def _quant_id(self, quant):
+        key = quant.tobytes()
+        idx = self._quant_index.get(key)
+        if idx is None:
+            idx = self._quant_index[key] = len(self._quant_host)
+            self._quant_host.append(quant.copy())
+            self._quant_dev = None
+        return idx
+
+    def _tables(self):
+        import torch
+        if self._huff_dev is None:
+            blob = np.stack(self._huff_host).view(np.uint8).reshape(len(self._huff_host), -1)
+            self._huff_dev = torch.from_numpy(blob.copy()).to(self.device)
+        if self._quant_dev is None:
+            self._quant_dev = torch.from_numpy(np.stack(self._quant_host).astype(np.uint16).view(np.int16)).to(self.device)
+        return self._huff_dev, self._quant_dev
+
+    # ------------------------------------------------------------------ decode
+    def decode(self, blobs, bgr=True, out=None):
+        import torch
+        n = len(blobs)
+        assert n >= 1
+        headers = []
+        for b in blobs:
+            try:
+                headers.append(parse_header(b))
+            except Unsupported:
+                headers.append(None)
+        ok = [i for i, h in enumerate(headers) if h is not None]
+        size = None
+        for h in headers:
+            if h is not None:
+                size = (h.height, h.width)
+                break
+        if size is None:                                             # nothing for the device: all on the host
+            first = _host_decode(blobs[0], bgr)
+            size = first.shape[:2]
+        H, W = size
+        ok = [i for i in ok if (headers[i].height, headers[i].width) == (H, W)]
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=self.device)
+            assert tuple(out.shape) == (n, H, W, 3) and out.is_contiguous() and out.dtype == torch.uint8
+            flagged = []
+            if ok:
+                flagged = self._decode_device([blobs[i] for i in ok], [headers[i] for i in ok], ok, out, bgr)
+            host = [i for i in range(n) if i not in set(ok)] + flagged
+            self.stats["device"] += len(ok) - len(flagged)
+            self.stats["host_unsupported"] += n - len(ok)
+            self.stats["host_flagged"] += len(flagged)
+            for i in host:
+                arr = _host_decode(blobs[i], bgr)
+                if arr.shape[:2] != (H, W):
+                    raise ValueError(f"image {i} is {arr.shape[1]}x{arr.shape[0]}, the batch is {W}x{H}")
+                out[i].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+        return out
+
+    def _decode_device(self, blobs, headers, slots, out, bgr):
+        """Decode the supported images into out[slots]; returns the slots the device flagged as inconsistent."""
+        import torch
+        n = len(blobs)
+        imgs = np.zeros(n, IMAGE_DTYPE)
+        off = 0
+        for i, (b, h) in enumerate(zip(blobs, headers)):
+            d = imgs[i]
+            d["stream_off"], d["stream_len"] = off, h.scan_end - h.scan_start
+            d["width"], d["height"], d["ncomp"], d["hs"], d["vs"] = h.width, h.height, h.ncomp, h.hs, h.vs
+            d["huff_set"], d["quant_set"] = self._huff_id(h.huff), self._quant_id(h.quant)
+            d["comp_dc"], d["comp_ac"] = h.comp_dc, h.comp_ac
+            off = (off + int(d["stream_len"]) + 64 + 15) & ~15
+        stream_bytes = off + 64
+        if self._pinned is None or self._pinned.numel() < stream_bytes:
+            self._pinned = torch.empty(max(stream_bytes, 1 << 20), dtype=torch.uint8).pin_memory()
+        host = self._pinned.numpy()
+        for i, (b, h) in enumerate(zip(blobs, headers)):
+            o = int(imgs[i]["stream_off"])
+            host[o:o + int(imgs[i]["stream_len"])] = np.frombuffer(b, np.uint8, int(imgs[i]["stream_len"]), h.scan_start)
+        info = np.zeros(3, np.uint64)                      # cama_jpeg_plan_info: u64 scratch_bytes + 4 x u32
+        _lib.check(self.lib.cama_jpeg_plan(imgs.ctypes.data, n, stream_bytes, info.ctypes.data))
+        scratch_bytes = int(info[0])
+        if self._scratch is None or self._scratch.numel() < scratch_bytes:
+            self._scratch = None
+            self._scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=self.device)
+        stream_dev = self._pinned[:stream_bytes].to(self.device, non_blocking=True)
+        imgs_dev = torch.from_numpy(imgs.view(np.uint8).reshape(n, -1)).to(self.device)
+        huff_dev, quant_dev = self._tables()
+        status = torch.empty(n, dtype=torch.int32, device=self.device)
+        contiguous = slots == list(range(slots[0], slots[0] + n))
+        target = out[slots[0]:slots[0] + n] if contiguous else torch.empty((n,) + tuple(out.shape[1:]), dtype=torch.uint8,
+                                                                            device=self.device)
+        _lib.check(self.lib.cama_jpeg_decode(
+            stream_dev.data_ptr(), stream_bytes, imgs.ctypes.data, imgs_dev.data_ptr(), n, huff_dev.data_ptr(),
+            huff_dev.shape[0], quant_dev.data_ptr(), quant_dev.shape[0], target.data_ptr(), target.stride(0), int(bool(bgr)),
+            self._scratch.data_ptr(), self._scratch.numel(), status.data_ptr(),
+            torch.cuda.current_stream(self.device).cuda_stream))
+        if not contiguous:
+            out[torch.as_tensor(slots, device=self.device)] = target
+        bad = status.cpu().numpy()                                   # one small readback per batch (also orders the pinned buffer's reuse)
+        return [slots[i] for i in np.flatnonzero(bad)]

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 2
+#define CAMA_ABI_VERSION 3
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -275,6 +275,54 @@ int cama_overlay_band_rows(int32_t W);
  */
 int cama_profile_enable(int32_t on);
 int cama_profile_collect(double *total_ms /* host */, int32_t *launches /* host */);
+
+/*
+ * Device baseline-JPEG decode of a batch of camera frames: what CameraManager.read_resized_image /
+ * read_image (cama/reproject.py:224,243: cv2.imread) and DatasetReader.yield_camera (cama/dataset_reader.py:72-76)
+ * do with libjpeg(-turbo) on one host core per image.  Output is byte-identical to libjpeg-turbo's default decode
+ * (islow IDCT, fancy upsampling; oracle/jpeg_oracle.py pins it to Pillow's bundled libjpeg-turbo).
+ *
+ * The host parses the markers (cama_amd/jpeg.py) and uploads: the concatenated entropy-coded segments (byte stuffing
+ * still in place; every segment starts on a 16-byte boundary and is followed by >= 64 spare bytes), one descriptor
+ * per image, the Huffman table sets (device layout: cama_jpeg_huff_set_bytes() each, built by the host from the DHT
+ * segments) and the quantisation tables ([set][component 0..2][64] uint16, natural order).
+ * Scope: SOF0, 8 bit, 1 or 3 components in one interleaved scan, luma sampling 1x1 / 2x1 / 2x2 with 1x1 chroma, no
+ * restart intervals.  Everything else is the caller's host fallback.
+ *   cama_jpeg_plan    fills the derived descriptor fields and reports grid sizes and scratch bytes (host only)
+ *   cama_jpeg_decode  imgs_dev = device copy of the PLANNED descriptors; out [n] images of height*width*3 bytes,
+ *                     out_stride bytes apart, BGR (bgr != 0: OpenCV order) or RGB; status [n] int32 on the device:
+ *                     0 ok, != 0 the stream did not decode consistently (corrupt or unsupported): use the host
+ *                     decoder for that image
+ */
+typedef struct cama_jpeg_image {
+    uint64_t stream_off;        /* byte offset of the entropy-coded segment in `stream`, multiple of 16 */
+    uint64_t coef_off;          /* [plan] int16 elements into the coefficient scratch */
+    uint64_t plane_off[3];      /* [plan] bytes into the plane scratch */
+    uint32_t stream_len;        /* bytes up to (not including) the marker that ends the scan */
+    uint32_t width, height;
+    uint32_t ncomp;             /* 1 or 3 */
+    uint32_t hs, vs;            /* luma sampling factors */
+    uint32_t huff_set, quant_set;
+    uint32_t comp_dc[3], comp_ac[3];   /* Huffman table selector (0/1) per component */
+    uint32_t mx, my, bpm, total_blocks;                 /* [plan] MCU grid, blocks per MCU, blocks in the scan */
+    uint32_t wg0, nwg, tile0, ntile;                    /* [plan] decode workgroups / unstuff tiles of this image */
+    uint32_t plane_w[3], plane_h[3];                    /* [plan] padded component planes */
+    uint32_t reserved[2];
+} cama_jpeg_image;
+
+typedef struct cama_jpeg_plan_info {
+    uint64_t scratch_bytes;
+    uint32_t total_wgs, total_tiles, max_blocks, reserved;
+} cama_jpeg_plan_info;
+
+size_t cama_jpeg_image_bytes(void);       /* sizeof(cama_jpeg_image), for bindings that mirror the struct */
+size_t cama_jpeg_huff_set_bytes(void);    /* bytes of one Huffman table set in device layout */
+int cama_jpeg_plan(cama_jpeg_image *imgs /* host, in/out */, int32_t n, uint64_t stream_bytes,
+                   cama_jpeg_plan_info *info /* host, out */);
+int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, const cama_jpeg_image *imgs /* host, planned */,
+                     const cama_jpeg_image *imgs_dev, int32_t n, const void *huff_sets, int32_t n_huff_sets,
+                     const uint16_t *quant_sets, int32_t n_quant_sets, uint8_t *out, uint64_t out_stride, int32_t bgr,
+                     void *scratch, size_t scratch_bytes, int32_t *status, void *stream_handle);
 
 #ifdef __cplusplus
 }

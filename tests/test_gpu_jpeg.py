@@ -1,0 +1,85 @@
+"""Device JPEG decoder (cama_jpeg_decode through cama_amd.jpeg.DeviceJpegDecoder) against the real decoder: Pillow's
+bundled libjpeg-turbo, byte for byte -- sizes off the MCU grid, all supported subsamplings, qualities, grey, optimised
+Huffman tables, mixed batches, host fallback for files outside the device scope, and a full-size 1600x900 rig."""
+import io
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from tests.test_oracle_jpeg import encode, pillow_rgb, synth_image
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dec():
+    import torch
+    assert torch.cuda.is_available()
+    from cama_amd.jpeg import DeviceJpegDecoder
+    return DeviceJpegDecoder("cuda:0")
+
+
+@pytest.mark.parametrize("size", [(16, 16), (8, 8), (17, 23), (48, 64), (90, 160), (1, 1), (15, 31), (203, 317)])
+@pytest.mark.parametrize("sub", [0, 1, 2])
+def test_device_decode_equals_libjpeg_turbo(dec, size, sub):
+    blobs = [encode(synth_image(size[0], size[1], kind, seed=q), quality=q, subsampling=sub)
+             for kind in ("smooth", "noise", "edges") for q in (50, 90, 100)]
+    before = dict(dec.stats)
+    got = dec.decode(blobs, bgr=False).cpu().numpy()
+    assert dec.stats["device"] - before["device"] == len(blobs), dec.stats        # none fell back to the host
+    for k, b in enumerate(blobs):
+        assert np.array_equal(got[k], pillow_rgb(b)), (size, sub, k)
+    bgr = dec.decode(blobs[:2]).cpu().numpy()
+    assert np.array_equal(bgr[0], pillow_rgb(blobs[0])[:, :, ::-1])
+
+
+def test_grey_optimised_tables_and_mixed_batch(dec):
+    img = synth_image(120, 200, "noise", seed=5)
+    img[:, :100] = synth_image(120, 100, "smooth")
+    blobs = [encode(img[..., 0], quality=85), encode(img, quality=80, subsampling=2, optimize=True),
+             encode(img, quality=95, subsampling=0), encode(img, quality=30, subsampling=1, optimize=True)]
+    got = dec.decode(blobs, bgr=False).cpu().numpy()
+    for k, b in enumerate(blobs):
+        assert np.array_equal(got[k], pillow_rgb(b)), k
+
+
+def test_files_outside_the_device_scope_fall_back_to_the_host(dec):
+    img = synth_image(64, 96, "smooth")
+    blobs = [encode(img, quality=90, progressive=True), encode(img, quality=90, restart_marker_blocks=2),
+             encode(img, quality=90)]
+    before = dict(dec.stats)
+    got = dec.decode(blobs, bgr=False).cpu().numpy()
+    assert dec.stats["host_unsupported"] - before["host_unsupported"] == 2
+    for k, b in enumerate(blobs):
+        assert np.array_equal(got[k], pillow_rgb(b)), k
+
+
+def test_corrupt_stream_is_flagged_and_redecoded_on_the_host(dec):
+    img = synth_image(96, 128, "noise", seed=9)
+    good = encode(img, quality=90)
+    from cama_amd.jpeg import parse_header
+    h = parse_header(good)
+    cut = bytearray(good)
+    del cut[h.scan_start + (h.scan_end - h.scan_start) // 2:h.scan_end - 8]       # drop the second half of the scan
+    before = dict(dec.stats)
+    try:
+        got = dec.decode([good, bytes(cut)], bgr=False).cpu().numpy()
+    except Exception:
+        got = None                                                                # Pillow may refuse the truncated file
+    assert dec.stats["host_flagged"] - before["host_flagged"] == 1
+    if got is not None:
+        assert np.array_equal(got[0], pillow_rgb(good))
+
+
+def test_full_size_rig(dec):
+    """Six 1600x900 frames (one per camera), noise (worst case: ~1.3 MB each) and photo-like content."""
+    rng = np.random.default_rng(0)
+    y, x = np.mgrid[0:900, 0:1600]
+    base = np.stack([(x * 0.16 + 20 * np.sin(y / 30)) % 256, (y * 0.28) % 256, ((x + y) * 0.1) % 256], -1)
+    imgs = [rng.integers(0, 256, (900, 1600, 3), dtype=np.uint8) for _ in range(2)] + \
+           [np.clip(base + rng.normal(0, s, base.shape), 0, 255).astype(np.uint8) for s in (0, 4, 8, 16)]
+    blobs = [encode(im, quality=90) for im in imgs]
+    got = dec.decode(blobs).cpu().numpy()
+    for k, b in enumerate(blobs):
+        assert np.array_equal(got[k][:, :, ::-1], pillow_rgb(b)), k
