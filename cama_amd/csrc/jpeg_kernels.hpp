@@ -29,12 +29,13 @@ constexpr int JPEG_LUT_BITS = 10;
 // Tables: 0 = DC0, 1 = AC0, 2 = DC1, 3 = AC1.
 struct JpegHuffSet {
     uint16_t lut[4][1 << JPEG_LUT_BITS];   // (length << 8) | symbol for codes of <= 10 bits, 0 otherwise
-    int32_t maxcode[4][17];                // largest code of each length (length 11..16 used), -1 if none
+    uint32_t lim[4][8];                    // [t][i], i = 0..5: 16-bit left-aligned exclusive upper limit of the codes
+                                           // of length <= 11+i; a longer code's length is 11 + #limits <= its prefix
     int32_t valoff[4][17];                 // index of a length's first symbol minus its first code
     uint8_t vals[4][256];
-    uint8_t pad[48];                       // sizeof == 9808, a multiple of 16
+    uint8_t pad[16];                       // sizeof == 9632, a multiple of 16
 };
-static_assert(sizeof(JpegHuffSet) == 9808, "JpegHuffSet layout");
+static_assert(sizeof(JpegHuffSet) == 9632, "JpegHuffSet layout");
 
 struct JpegArgs {
     const uint8_t *stream;            // stuffed entropy segments
@@ -181,22 +182,18 @@ struct JpegWgCtx {
     uint32_t bpm;
 };
 
-__device__ __forceinline__ uint32_t jpeg_window(const JpegWgCtx &c, uint32_t pos)
-{
-    const uint32_t w = (pos >> 5) - c.word0;
-    const uint32_t hi = c.words[w + (w >> 5)], lo = c.words[(w + 1) + ((w + 1) >> 5)];
-    return (uint32_t)(((((uint64_t)hi) << 32) | lo) << (pos & 31u) >> 32);
-}
-
 __device__ __forceinline__ uint32_t jpeg_symbol(const JpegHuffSet &H, uint32_t tab, uint32_t window)
 {
     const uint32_t e = H.lut[tab][window >> (32 - JPEG_LUT_BITS)];
     if (e) return e;
-    for (int l = JPEG_LUT_BITS + 1; l <= 16; ++l) {
-        const int32_t code = (int32_t)(window >> (32 - l));
-        if (code <= H.maxcode[tab][l]) return ((uint32_t)l << 8) | H.vals[tab][(code + H.valoff[tab][l]) & 255];
-    }
-    return 16u << 8;           // no such code (only on speculative paths): skip 16 bits, symbol 0
+    // longer than 10 bits: canonical codes grow with their length, so the length is 11 + the number of per-length
+    // limits (left-aligned to 16 bits, monotone) that the 16-bit prefix has reached -- no dependent loop
+    const uint32_t w16 = window >> 16;
+    const uint4 lim0 = *reinterpret_cast<const uint4 *>(&H.lim[tab][0]);
+    const uint2 lim1 = *reinterpret_cast<const uint2 *>(&H.lim[tab][4]);
+    const uint32_t l = 11u + (w16 >= lim0.x) + (w16 >= lim0.y) + (w16 >= lim0.z) + (w16 >= lim0.w) + (w16 >= lim1.x);
+    if (w16 >= lim1.y) return 16u << 8;        // no such code (only on speculative paths): skip 16 bits, symbol 0
+    return (l << 8) | H.vals[tab][((w16 >> (16u - l)) + (uint32_t)H.valoff[tab][l]) & 255u];
 }
 
 __constant__ uint8_t c_jpeg_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
@@ -205,33 +202,41 @@ __constant__ uint8_t c_jpeg_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24
                                           58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 // Decode every symbol that STARTS in [s.pos, end): T.81 F.2.2 with the decoder state (block in MCU, zigzag index).
-// WRITE: store the coefficients of block `block` onwards (DC as the raw difference).
+// The bit window lives in a 64-bit register (>= 32 valid bits at the top), refilled with one LDS read per 32 bits
+// consumed, so the dependent chain per symbol is one table lookup.  WRITE: store the coefficients of block `block`
+// onwards (DC as the raw difference).
 template <bool WRITE>
 __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegState &s, uint32_t end, int16_t *coef,
                                                      uint32_t block, uint32_t total_blocks)
 {
     uint32_t nb = 0;
+    if (s.pos >= end) return 0;
+    uint32_t w = (s.pos >> 5) - c.word0;
+    uint64_t buf = ((((uint64_t)c.words[w + (w >> 5)]) << 32) | c.words[(w + 1) + ((w + 1) >> 5)]) << (s.pos & 31u);
+    int cnt = 64 - (int)(s.pos & 31u);
+    w += 2;
     while (s.pos < end) {
-        const uint32_t win = jpeg_window(c, s.pos);
-        uint32_t len, size, run = 0;
-        if (s.k == 0) {
-            const uint32_t e = jpeg_symbol(*c.H, ((c.dc_mask >> s.blk) & 1u) * 2u, win);
-            len = e >> 8;
-            size = e & 15u;
-        } else {
-            const uint32_t e = jpeg_symbol(*c.H, ((c.ac_mask >> s.blk) & 1u) * 2u + 1u, win);
-            len = e >> 8;
-            size = e & 15u;
-            run = (e >> 4) & 15u;
-            if (size == 0u) run = (run == 15u) ? 16u : 64u;       // ZRL: skip 16; EOB: to the end of the block
-        }
-        const uint32_t at = s.k + (s.k ? (size ? run : 0u) : 0u);
+        const uint32_t win = (uint32_t)(buf >> 32);
+        const uint32_t tab = s.k ? ((c.ac_mask >> s.blk) & 1u) * 2u + 1u : ((c.dc_mask >> s.blk) & 1u) * 2u;
+        const uint32_t e = jpeg_symbol(*c.H, tab, win);
+        const uint32_t len = e >> 8, size = e & 15u;
+        uint32_t run = s.k ? (e >> 4) & 15u : 0u;
+        if (s.k && size == 0u) run = (run == 15u) ? 16u : 64u;          // ZRL: skip 16; EOB: to the end of the block
+        const uint32_t at = s.k + (size ? run : 0u);                      // zigzag index of a coded coefficient
         if (WRITE && size && at < 64u && block + nb < total_blocks) {
             const uint32_t v = (win << len) >> (32u - size);
             const int32_t val = (v < (1u << (size - 1u))) ? (int32_t)v - (int32_t)((1u << size) - 1u) : (int32_t)v;
             coef[(size_t)(block + nb) * 64 + c_jpeg_zigzag[at]] = (int16_t)val;
         }
-        s.pos += len + size;
+        const uint32_t used = len + size;
+        s.pos += used;
+        buf <<= used;
+        cnt -= (int)used;
+        if (cnt < 32) {
+            buf |= ((uint64_t)c.words[w + (w >> 5)]) << (32 - cnt);
+            cnt += 32;
+            ++w;
+        }
         s.k = s.k ? (size ? at + 1u : s.k + run) : 1u;
         if (s.k >= 64u) {
             s.k = 0;
@@ -262,8 +267,8 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
     // past the segment is zero: the clean buffer is cleared per batch)
     const uint32_t *g = reinterpret_cast<const uint32_t *>(a.clean + D.stream_off);
     const uint32_t w0 = lw * JPEG_WG * JPEG_SUB_WORDS;
-    const uint32_t nwords_img = (D.stream_len + 3u) / 4u + 4u;          // slack words exist (plan pads every segment)
-    for (uint32_t i = threadIdx.x; i < JPEG_WG * JPEG_SUB_WORDS + 2; i += JPEG_WG) {
+    const uint32_t nwords_img = (D.stream_len + 3u) / 4u + 8u;          // slack words exist (plan pads every segment)
+    for (uint32_t i = threadIdx.x; i < JPEG_WG * JPEG_SUB_WORDS + 4; i += JPEG_WG) {
         const uint32_t w = w0 + i;
         S.words[i + (i >> 5)] = w < nwords_img ? __builtin_bswap32(g[w]) : 0u;
     }
@@ -417,7 +422,8 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_write(JpegArgs a)
 }
 
 // per (image, component): DC[i] = sum of the differences up to block i of that component (T.81 F.2.1.3.1)
-__global__ __launch_bounds__(256) void k_jpeg_dc(JpegArgs a)
+constexpr int JPEG_DC_THREADS = 1024;
+__global__ __launch_bounds__(JPEG_DC_THREADS) void k_jpeg_dc(JpegArgs a)
 {
     const cama_jpeg_image &D = a.imgs[blockIdx.x];
     const uint32_t ci = blockIdx.y;
@@ -426,23 +432,22 @@ __global__ __launch_bounds__(256) void k_jpeg_dc(JpegArgs a)
     const uint32_t first = ci == 0 ? 0u : D.hs * D.vs + (ci - 1u);
     const uint32_t n = D.mx * D.my * hv;
     int16_t *coef = a.coef + D.coef_off;
-    const uint32_t per = (n + 255u) / 256u;
+    const uint32_t per = (n + JPEG_DC_THREADS - 1u) / JPEG_DC_THREADS;
     const uint32_t i0 = min(threadIdx.x * per, n), i1 = min(i0 + per, n);
     int32_t sum = 0;
     for (uint32_t i = i0; i < i1; ++i) sum += coef[(size_t)((i / hv) * D.bpm + first + i % hv) * 64];
-    __shared__ int32_t s_part[256];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int32_t run = 0;
-        for (int k = 0; k < 256; ++k) {
-            const int32_t v = s_part[k];
-            s_part[k] = run;
-            run += v;
-        }
+    // exclusive scan of the per-thread sums: inside each wave by shuffles, across the 16 waves through LDS
+    int32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t v = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += v;
     }
+    __shared__ int32_t s_wave[JPEG_DC_THREADS / 64];
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
     __syncthreads();
-    int32_t run = s_part[threadIdx.x];
+    int32_t run = incl - sum;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += s_wave[w];
     for (uint32_t i = i0; i < i1; ++i) {
         int16_t *p = coef + (size_t)((i / hv) * D.bpm + first + i % hv) * 64;
         run += *p;
@@ -529,53 +534,96 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(JpegArgs a)
 }
 
 // ------------------------------------------------------------------------------------------ upsampling + colour
-__device__ __forceinline__ int32_t jpeg_chroma(const uint8_t *p, uint32_t pw, uint32_t cw, uint32_t ch, uint32_t hs,
-                                               uint32_t vs, uint32_t x, uint32_t y)
+// 8 consecutive chroma-upsampled samples of one output row starting at x0 (multiple of 8), from dword loads:
+// the triangle filters need chroma columns x0/2-1 .. x0/2+4 of one (h2v1) or two (h2v2) rows.
+__device__ __forceinline__ void jpeg_chroma8(const uint8_t *p, uint32_t pw, uint32_t cw, uint32_t ch, uint32_t hs,
+                                             uint32_t vs, uint32_t x0, uint32_t y, int32_t out[8])
 {
-    if (hs == 1u) return p[(size_t)y * pw + x];
-    const uint32_t cx = x >> 1;
-    if (vs == 1u) {                                              // h2v1_fancy_upsample
-        const uint8_t *row = p + (size_t)y * pw;
-        const int32_t v = row[cx];
-        if (x & 1u) return cx + 1u == cw ? v : (v * 3 + row[cx + 1] + 2) >> 2;
-        return cx == 0u ? v : (v * 3 + row[cx - 1] + 1) >> 2;
+    if (hs == 1u) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p + (size_t)y * pw + x0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            out[k] = (int32_t)((v.x >> (8 * k)) & 255u);
+            out[k + 4] = (int32_t)((v.y >> (8 * k)) & 255u);
+        }
+        return;
     }
-    // h2v2_fancy_upsample: column sums of (3 * nearer row + further row), then the same 3:1 blend across columns
-    const uint32_t cy = y >> 1;
-    const uint32_t ny = (y & 1u) ? min(cy + 1u, ch - 1u) : (cy ? cy - 1u : 0u);
+    const uint32_t cx0 = x0 >> 1;                                   // multiple of 4
+    const uint32_t cy = vs == 2u ? y >> 1 : y;
+    const uint32_t ny = vs == 2u ? ((y & 1u) ? min(cy + 1u, ch - 1u) : (cy ? cy - 1u : 0u)) : cy;
     const uint8_t *r0 = p + (size_t)cy * pw, *r1 = p + (size_t)ny * pw;
-    const int32_t s = r0[cx] * 3 + r1[cx];
-    if (x & 1u) {
-        if (cx + 1u == cw) return (s * 4 + 7) >> 4;
-        return (s * 3 + (r0[cx + 1] * 3 + r1[cx + 1]) + 7) >> 4;
+    const uint32_t lo = cx0 ? cx0 - 4u : 0u, hi = cx0 + 4u < pw ? cx0 + 4u : cx0;
+    const uint32_t a0 = *reinterpret_cast<const uint32_t *>(r0 + lo), a1 = *reinterpret_cast<const uint32_t *>(r0 + cx0),
+                   a2 = *reinterpret_cast<const uint32_t *>(r0 + hi);
+    const uint32_t b0 = *reinterpret_cast<const uint32_t *>(r1 + lo), b1 = *reinterpret_cast<const uint32_t *>(r1 + cx0),
+                   b2 = *reinterpret_cast<const uint32_t *>(r1 + hi);
+    // column values s[-1..4]: h2v2 = 3 * nearer row + further row, h2v1 = the sample itself
+    int32_t s[6];
+    const int32_t wn = vs == 2u ? 3 : 1, wf = vs == 2u ? 1 : 0;
+    s[0] = wn * (int32_t)(a0 >> 24) + wf * (int32_t)(b0 >> 24);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k + 1] = wn * (int32_t)((a1 >> (8 * k)) & 255u) + wf * (int32_t)((b1 >> (8 * k)) & 255u);
+    s[5] = wn * (int32_t)(a2 & 255u) + wf * (int32_t)(b2 & 255u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t cx = cx0 + k;
+        const int32_t c = s[k + 1];
+        if (vs == 2u) {
+            out[2 * k] = cx == 0u ? (c * 4 + 8) >> 4 : (c * 3 + s[k] + 8) >> 4;
+            out[2 * k + 1] = cx + 1u >= cw ? (c * 4 + 7) >> 4 : (c * 3 + s[k + 2] + 7) >> 4;
+        } else {
+            out[2 * k] = cx == 0u ? c : (c * 3 + s[k] + 1) >> 2;
+            out[2 * k + 1] = cx + 1u >= cw ? c : (c * 3 + s[k + 2] + 2) >> 2;
+        }
     }
-    if (cx == 0u) return (s * 4 + 8) >> 4;
-    return (s * 3 + (r0[cx - 1] * 3 + r1[cx - 1]) + 8) >> 4;
 }
 
-// grid (ceil(W/256), ceil(H/4), n), 256 threads: one output column, 4 rows each
+// grid (ceil(W/2048), ceil(H/4), n), 256 threads: 8 consecutive pixels (24 bytes = three 8-byte stores when the row
+// pitch allows it) of 4 rows each; planes are read with dword / 8-byte loads
 constexpr int JPEG_COLOUR_ROWS = 4;
 __global__ __launch_bounds__(256) void k_jpeg_colour(JpegArgs a)
 {
     const cama_jpeg_image &D = a.imgs[blockIdx.z];
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
-    if (x >= D.width) return;
+    const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 8u;
+    if (x0 >= D.width) return;
+    const uint32_t cw = (D.width + D.hs - 1u) / D.hs, ch = (D.height + D.vs - 1u) / D.vs;
+    uint8_t *img = a.out + (size_t)blockIdx.z * a.out_stride;
+    const bool packed = (D.width & 7u) == 0u && ((uintptr_t)img & 7u) == 0u;
     for (uint32_t y = blockIdx.y * JPEG_COLOUR_ROWS; y < min((blockIdx.y + 1u) * JPEG_COLOUR_ROWS, D.height); ++y) {
-    const int32_t Y = a.planes[D.plane_off[0] + (size_t)y * D.plane_w[0] + x];
-    int32_t r = Y, g = Y, b = Y;
-    if (D.ncomp == 3u) {
-        const uint32_t cw = (D.width + D.hs - 1u) / D.hs, ch = (D.height + D.vs - 1u) / D.vs;
-        const int32_t cb = jpeg_chroma(a.planes + D.plane_off[1], D.plane_w[1], cw, ch, D.hs, D.vs, x, y) - 128;
-        const int32_t cr = jpeg_chroma(a.planes + D.plane_off[2], D.plane_w[2], cw, ch, D.hs, D.vs, x, y) - 128;
-        // IJG jdcolor: 16-bit fixed point, arithmetic shifts
-        r = Y + ((91881 * cr + 32768) >> 16);
-        g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
-        b = Y + ((116130 * cb + 32768) >> 16);
-        r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
-    }
-    uint8_t *o = a.out + (size_t)blockIdx.z * a.out_stride + ((size_t)y * D.width + x) * 3;
-    o[0] = (uint8_t)(a.bgr ? b : r);
-    o[1] = (uint8_t)g;
-    o[2] = (uint8_t)(a.bgr ? r : b);
+        const uint2 yv = *reinterpret_cast<const uint2 *>(a.planes + D.plane_off[0] + (size_t)y * D.plane_w[0] + x0);
+        int32_t cb[8], cr[8];
+        if (D.ncomp == 3u) {
+            jpeg_chroma8(a.planes + D.plane_off[1], D.plane_w[1], cw, ch, D.hs, D.vs, x0, y, cb);
+            jpeg_chroma8(a.planes + D.plane_off[2], D.plane_w[2], cw, ch, D.hs, D.vs, x0, y, cr);
+        }
+        uint32_t px[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int32_t Y = (int32_t)(((k < 4 ? yv.x : yv.y) >> (8 * (k & 3))) & 255u);
+            int32_t r = Y, g = Y, b = Y;
+            if (D.ncomp == 3u) {
+                const int32_t u = cb[k] - 128, v = cr[k] - 128;
+                // IJG jdcolor: 16-bit fixed point, arithmetic shifts
+                r = Y + ((91881 * v + 32768) >> 16);
+                g = Y + ((-22554 * u + 32768 - 46802 * v) >> 16);
+                b = Y + ((116130 * u + 32768) >> 16);
+                r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
+            }
+            px[k] = a.bgr ? ((uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16))
+                          : ((uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16));
+        }
+        uint8_t *o = img + ((size_t)y * D.width + x0) * 3;
+        if (packed) {
+            uint2 *o8 = reinterpret_cast<uint2 *>(o);
+            o8[0] = make_uint2(px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16));
+            o8[1] = make_uint2((px[2] >> 16) | (px[3] << 8), px[4] | (px[5] << 24));
+            o8[2] = make_uint2((px[5] >> 8) | (px[6] << 16), (px[6] >> 16) | (px[7] << 8));
+        } else {
+            for (uint32_t k = 0; k < 8u && x0 + k < D.width; ++k) {
+                o[3 * k] = (uint8_t)px[k];
+                o[3 * k + 1] = (uint8_t)(px[k] >> 8);
+                o[3 * k + 2] = (uint8_t)(px[k] >> 16);
+            }
+        }
     }
 }

@@ -34,6 +34,21 @@ def read_rgb_or_bgr(path):
             return np.array(im.convert("RGB")), True        # own, writable buffer (copied inside the worker thread)
 
 
+def _read_jpeg_bytes_or_array(path):
+    """(bytes, False) for an existing JPEG file (to be decoded on the device), else what read_rgb_or_bgr returns."""
+    if path.lower().endswith((".jpg", ".jpeg")) and os.path.exists(path):
+        with open(path, "rb") as f:
+            return f.read(), False
+    return read_rgb_or_bgr(path)
+
+
+def _decode_bytes(data):
+    import io
+    from PIL import Image
+    with Image.open(io.BytesIO(data)) as im:
+        return np.array(im.convert("RGB"))
+
+
 def read_bgr(path):
     """(H,W,3) uint8 BGR from a .jpg/.png path; falls back to the `.npy` twin of the same stem."""
     stem = os.path.splitext(path)[0]
@@ -125,10 +140,15 @@ class ClipFrameSource:
     Raw frames go to the device as they are; undistort + resize happens inside the overlay kernel
     (cama_overlay_frames_raw) when the output size differs from the sensor size."""
 
-    def __init__(self, cm_list, device, workers=None, prefetch=3):
+    def __init__(self, cm_list, device, workers=None, prefetch=3, decoder=None):
         self.cm_list = cm_list
         self.device = device
         self.fused = any(cm.needs_resample() for cm in cm_list)     # hand RAW frames to the fused overlay
+        # "device": JPEG files are read as bytes and decoded on the GPU (cama_amd.jpeg, byte-identical to libjpeg-turbo);
+        # "host": decoded by the worker threads.  CAMA_JPEG_DECODER overrides the default.
+        self.decoder = decoder or os.environ.get("CAMA_JPEG_DECODER", "device" if device is not None else "host")
+        assert self.decoder in ("device", "host")
+        self._jpeg = None
         self._pool = None
         self._workers = workers or min(12, (os.cpu_count() or 4))    # measured: 12 threads peak (~500 images/s), GIL beyond
         self._prefetch = prefetch
@@ -143,7 +163,8 @@ class ClipFrameSource:
     def _submit(self, idx):
         if idx not in self._pending:
             ex = self._executor()
-            self._pending[idx] = [ex.submit(read_rgb_or_bgr, cm.get_image_path(idx, True)) for cm in self.cm_list]
+            fetch = _read_jpeg_bytes_or_array if self.decoder == "device" else read_rgb_or_bgr
+            self._pending[idx] = [ex.submit(fetch, cm.get_image_path(idx, True)) for cm in self.cm_list]
         return self._pending[idx]
 
     def _n_frames(self):
@@ -171,6 +192,8 @@ class ClipFrameSource:
         """host uint8 BGR array [F,C,H0,W0,3] of the requested frames."""
         items = self._collect(image_indices)
         F = len(list(image_indices))
+        items = [(k, c, _decode_bytes(arr), True) if isinstance(arr, (bytes, bytearray)) else (k, c, arr, is_rgb)
+                 for k, c, arr, is_rgb in items]
         first = items[0][2]
         host = np.empty((F, len(self.cm_list)) + first.shape, np.uint8)
         for k, c, arr, is_rgb in items:
@@ -183,6 +206,15 @@ class ClipFrameSource:
         import torch
         items = self._collect(image_indices)
         F = len(list(image_indices))
+        if all(isinstance(arr, (bytes, bytearray)) for _, _, arr, _ in items):
+            # compressed bytes straight to the device decoder: one upload + one decode for the whole batch, BGR out
+            if self._jpeg is None:
+                from .jpeg import DeviceJpegDecoder
+                self._jpeg = DeviceJpegDecoder(self.device)
+            flat = self._jpeg.decode([arr for _, _, arr, _ in items], bgr=True)
+            return flat.view((F, len(self.cm_list)) + tuple(flat.shape[1:]))
+        items = [(k, c, _decode_bytes(arr) if isinstance(arr, (bytes, bytearray)) else arr,
+                  True if isinstance(arr, (bytes, bytearray)) else is_rgb) for k, c, arr, is_rgb in items]
         shape = items[0][2].shape
         dev = torch.empty((F, len(self.cm_list)) + tuple(shape), dtype=torch.uint8, device=self.device)
         rgb = torch.zeros((F, len(self.cm_list)), dtype=torch.bool)

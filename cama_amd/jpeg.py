@@ -25,8 +25,8 @@ IMAGE_DTYPE = np.dtype([
     ("plane_w", "<u4", (3,)), ("plane_h", "<u4", (3,)), ("reserved", "<u4", (2,))])          # == cama_jpeg_image
 
 LUT_BITS = 10
-HUFF_DTYPE = np.dtype([("lut", "<u2", (4, 1 << LUT_BITS)), ("maxcode", "<i4", (4, 17)), ("valoff", "<i4", (4, 17)),
-                       ("vals", "u1", (4, 256)), ("pad", "u1", (48,))])                       # == JpegHuffSet
+HUFF_DTYPE = np.dtype([("lut", "<u2", (4, 1 << LUT_BITS)), ("lim", "<u4", (4, 8)), ("valoff", "<i4", (4, 17)),
+                       ("vals", "u1", (4, 256)), ("pad", "u1", (16,))])                       # == JpegHuffSet
 
 _ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20,
                     13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52,
@@ -42,7 +42,32 @@ class JpegHeader:
                  "scan_end")
 
 
+_HEADER_CACHE = {}
+
+
 def parse_header(data):
+    """Header of a JPEG file; the frames of one camera share every byte up to the scan, so the parsed header is cached
+    on those bytes and only the scan's end is looked up per file."""
+    sos = data.find(b"\xff\xda")
+    if sos > 0 and sos + 4 <= len(data):
+        key = bytes(data[:sos + 2 + ((data[sos + 2] << 8) | data[sos + 3])])
+        hit = _HEADER_CACHE.get(key)
+        if hit is None:
+            hit = _parse_header(data)
+            if len(_HEADER_CACHE) < 256 and hit.scan_start == len(key):
+                _HEADER_CACHE[key] = hit
+            return hit
+        h = JpegHeader()
+        for name in JpegHeader.__slots__:
+            setattr(h, name, getattr(hit, name))
+        h.scan_end = data.rfind(b"\xff\xd9")
+        if h.scan_end < h.scan_start:
+            raise Unsupported("no EOI")
+        return h
+    return _parse_header(data)
+
+
+def _parse_header(data):
     """Walk the marker segments up to SOS (T.81 B.2).  Returns a JpegHeader whose `quant` is (3,64) uint16 in natural
     order, `huff` the raw DHT payloads {(class, id): bytes}, and [scan_start, scan_end) the entropy-coded bytes."""
     if data[:2] != b"\xff\xd8":
@@ -130,9 +155,9 @@ def parse_header(data):
 
 def build_huff_set(huff):
     """{(class, id): DHT payload (16 counts + symbols)} -> one HUFF_DTYPE record: tables DC0, AC0, DC1, AC1 with a
-    10-bit lookup (length << 8 | symbol) and the canonical maxcode / value-offset arrays for longer codes (T.81 C, F.2.2.3)."""
+    10-bit lookup (length << 8 | symbol) and, for longer codes, per-length 16-bit limits + value offsets (the canonical
+    code structure of T.81 C / F.2.2.3: a code's length is 11 + the number of limits its 16-bit prefix has reached)."""
     rec = np.zeros((), HUFF_DTYPE)
-    rec["maxcode"][...] = -1
     for (cls, tid), payload in huff.items():
         if tid > 1:
             continue
@@ -145,13 +170,15 @@ def build_huff_set(huff):
             cnt = int(bits[l - 1])
             if cnt:
                 rec["valoff"][t, l] = k - code
-                rec["maxcode"][t, l] = code + cnt - 1
                 if l <= LUT_BITS:
                     span = 1 << (LUT_BITS - l)
                     entries = (np.uint16(l) << 8) | vals[k:k + cnt].astype(np.uint16)
                     rec["lut"][t, code << (LUT_BITS - l):(code + cnt) << (LUT_BITS - l)] = np.repeat(entries, span)
                 code += cnt
                 k += cnt
+            if l > LUT_BITS:
+                # exclusive upper limit of all codes of length <= l, left-aligned to 16 bits (monotone in l)
+                rec["lim"][t, l - LUT_BITS - 1] = code << (16 - l)
             code <<= 1
     return rec
 

@@ -83,3 +83,22 @@ def test_full_size_rig(dec):
     got = dec.decode(blobs).cpu().numpy()
     for k, b in enumerate(blobs):
         assert np.array_equal(got[k][:, :, ::-1], pillow_rgb(b)), k
+
+
+def test_clip_frame_source_device_decode_equals_host_decode(tmp_path):
+    """ClipFrameSource (the demo's ingest): JPEG bytes -> device decoder gives the same BGR frames as the host
+    decoder threads, for a synthetic clip with 6 cameras."""
+    import torch
+    from cama_amd import frames as FR
+    from cama_amd.dataset import ClipManager
+    from cama_amd.synth import DEFAULT_CAMA_CONFIGS, make_clip
+    clip = str(tmp_path / "clip")
+    make_clip(clip, n_frames=4, seed=2, n_lines=4, verts_per_line=4, line_len_m=2.0, raster_size=300,
+              image_mode="jpg", image_size=(180, 320), with_nuscenes=False, extra_labels=False)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)
+    dev = FR.ClipFrameSource(cm.cm_list, torch.device("cuda:0"), decoder="device")
+    host = FR.ClipFrameSource(cm.cm_list, torch.device("cuda:0"), decoder="host")
+    a = dev.raw_batch([1, 2, 3]).cpu().numpy()
+    b = host.raw_batch([1, 2, 3]).cpu().numpy()
+    assert a.shape == b.shape == (3, 6, 180, 320, 3) and np.array_equal(a, b)
+    assert dev._jpeg.stats["device"] == 18 and dev._jpeg.stats["host_flagged"] == 0
