@@ -4,8 +4,9 @@ per-stage clock: where does a frame's time go once the reprojection hot path run
 
     python examples/demo_synthetic.py [--frames 8] [--keep DIR]
 
-Stages per frame: JPEG decode (Pillow / cv2 on the host), upload (PCIe), device work (undistort+resize, project,
-stamp, mosaic: one fused pass), download of the 2880x1080 mosaic.  The encoder (ffmpeg) is not run.
+The loop itself uses the device JPEG decoder (CAMA_JPEG_DECODER=host switches back to the host thread pool).
+Stage clock per frame: JPEG decode on the host (Pillow / cv2) vs on the device, upload (PCIe), device work
+(undistort+resize, project, stamp, mosaic: one fused pass), download of the 2880x1080 mosaic.  No encoder (ffmpeg).
 """
 import argparse
 import os
@@ -68,6 +69,20 @@ def main():
         e = time.perf_counter()
         t_dec += b - a; t_up += c_ - b; t_gpu += d - c_; t_down += e - d
     F = len(idx)
+    # the same six files through the device decoder (compressed bytes up, decode on the GPU)
+    from cama_amd.jpeg import DeviceJpegDecoder
+    dec = DeviceJpegDecoder(eng.device)
+    blobs = [open(c.get_image_path(int(idx[0]), True), "rb").read() for c in cm.cm_list]
+    dev2 = dec.decode(blobs)
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    for _ in range(10):
+        dec.decode(blobs, out=dev2)
+    torch.cuda.synchronize()
+    t_devdec = (time.perf_counter() - a) / 10
+    assert torch.equal(dev2, dev[0])                     # byte-identical to the host decoder
+    print(f"device JPEG decode: 6 frames ({sum(map(len, blobs)) / 6e3:.0f} KB each) in {t_devdec * 1e3:.2f} ms "
+          f"(host, one core: {t_dec / F * 1e3:.1f} ms)")
     print(f"per frame: decode 6 JPEGs {t_dec / F * 1e3:.1f} ms | upload 26 MB {t_up / F * 1e3:.2f} ms | "
           f"device (resample+project+stamp+mosaic, 1 frame/launch) {t_gpu / F * 1e3:.3f} ms | "
           f"download 9.3 MB {t_down / F * 1e3:.2f} ms")
