@@ -180,14 +180,13 @@ struct JpegWgCtx {
     const JpegHuffSet *H;      // LDS
     uint32_t dc_mask, ac_mask; // bit b: Huffman table selector (0/1) of block b of the MCU
     uint32_t bpm;
+    const uint8_t *zigzag;     // LDS copy of the zigzag -> natural order table
 };
 
-__device__ __forceinline__ uint32_t jpeg_symbol(const JpegHuffSet &H, uint32_t tab, uint32_t window)
+// codes longer than 10 bits: canonical codes grow with their length, so the length is 11 + the number of per-length
+// limits (left-aligned to 16 bits, monotone) that the 16-bit prefix has reached -- no dependent loop
+__device__ __forceinline__ uint32_t jpeg_symbol_long(const JpegHuffSet &H, uint32_t tab, uint32_t window)
 {
-    const uint32_t e = H.lut[tab][window >> (32 - JPEG_LUT_BITS)];
-    if (e) return e;
-    // longer than 10 bits: canonical codes grow with their length, so the length is 11 + the number of per-length
-    // limits (left-aligned to 16 bits, monotone) that the 16-bit prefix has reached -- no dependent loop
     const uint32_t w16 = window >> 16;
     const uint4 lim0 = *reinterpret_cast<const uint4 *>(&H.lim[tab][0]);
     const uint2 lim1 = *reinterpret_cast<const uint2 *>(&H.lim[tab][4]);
@@ -202,48 +201,66 @@ __constant__ uint8_t c_jpeg_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24
                                           58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 // Decode every symbol that STARTS in [s.pos, end): T.81 F.2.2 with the decoder state (block in MCU, zigzag index).
-// The bit window lives in a 64-bit register (>= 32 valid bits at the top), refilled with one LDS read per 32 bits
-// consumed, so the dependent chain per symbol is one table lookup.  WRITE: store the coefficients of block `block`
-// onwards (DC as the raw difference).
+// A lone wave issues one instruction every ~11 cycles here (measured), so the loop is written for instruction count:
+// the bit window is a 64-bit value in two 32-bit registers (hi always holds 32 valid bits; v_alignbit shifts, one
+// unconditional LDS read per symbol for the refill word), table choice and state update are selects, and the only
+// divergent branches are the >10-bit codes and the coefficient store.  WRITE: store the coefficients of block
+// `block` onwards (DC as the raw difference).
 template <bool WRITE>
 __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegState &s, uint32_t end, int16_t *coef,
                                                      uint32_t block, uint32_t total_blocks)
 {
-    uint32_t nb = 0;
     if (s.pos >= end) return 0;
-    uint32_t w = (s.pos >> 5) - c.word0;
-    uint64_t buf = ((((uint64_t)c.words[w + (w >> 5)]) << 32) | c.words[(w + 1) + ((w + 1) >> 5)]) << (s.pos & 31u);
-    int cnt = 64 - (int)(s.pos & 31u);
-    w += 2;
-    while (s.pos < end) {
-        const uint32_t win = (uint32_t)(buf >> 32);
-        const uint32_t tab = s.k ? ((c.ac_mask >> s.blk) & 1u) * 2u + 1u : ((c.dc_mask >> s.blk) & 1u) * 2u;
-        const uint32_t e = jpeg_symbol(*c.H, tab, win);
-        const uint32_t len = e >> 8, size = e & 15u;
-        uint32_t run = s.k ? (e >> 4) & 15u : 0u;
-        if (s.k && size == 0u) run = (run == 15u) ? 16u : 64u;          // ZRL: skip 16; EOB: to the end of the block
-        const uint32_t at = s.k + (size ? run : 0u);                      // zigzag index of a coded coefficient
-        if (WRITE && size && at < 64u && block + nb < total_blocks) {
-            const uint32_t v = (win << len) >> (32u - size);
-            const int32_t val = (v < (1u << (size - 1u))) ? (int32_t)v - (int32_t)((1u << size) - 1u) : (int32_t)v;
-            coef[(size_t)(block + nb) * 64 + c_jpeg_zigzag[at]] = (int16_t)val;
-        }
-        const uint32_t used = len + size;
-        s.pos += used;
-        buf <<= used;
-        cnt -= (int)used;
-        if (cnt < 32) {
-            buf |= ((uint64_t)c.words[w + (w >> 5)]) << (32 - cnt);
-            cnt += 32;
-            ++w;
-        }
-        s.k = s.k ? (size ? at + 1u : s.k + run) : 1u;
-        if (s.k >= 64u) {
-            s.k = 0;
-            s.blk = (s.blk + 1u == c.bpm) ? 0u : s.blk + 1u;
-            ++nb;
-        }
+    uint32_t nb = 0, pos = s.pos, blk = s.blk, k = s.k;
+    uint32_t w = (pos >> 5) - c.word0;
+    uint32_t hi, lo, cnt;                                           // cnt = valid bits in lo (all of hi is valid)
+    {
+        const uint32_t w0 = c.words[w + (w >> 5)], w1 = c.words[(w + 1) + ((w + 1) >> 5)], sh = pos & 31u;
+        hi = sh ? __builtin_amdgcn_alignbit(w0, w1, 32u - sh) : w0;
+        lo = sh ? w1 << sh : w1;
+        cnt = 32u - sh;
+        w += 2;
     }
+    const uint16_t *lut = &c.H->lut[0][0];
+    while (pos < end) {
+        const uint32_t isac = k ? 1u : 0u;
+        const uint32_t tab = (((isac ? c.ac_mask : c.dc_mask) >> blk) & 1u) * 2u + isac;
+        uint32_t e = lut[(tab << JPEG_LUT_BITS) + (hi >> (32 - JPEG_LUT_BITS))];
+        const uint32_t next = c.words[w + (w >> 5)];               // refill word (used when lo runs dry)
+        if (e == 0u) e = jpeg_symbol_long(*c.H, tab, hi);
+        const uint32_t len = e >> 8, size = e & 15u, run = (e >> 4) & 15u;
+        // zigzag index of the coded coefficient (DC: 0) and the index after this symbol
+        const uint32_t at = isac ? k + run : 0u;
+        const uint32_t knext = isac ? (size ? at + 1u : (run == 15u ? k + 16u : 64u)) : 1u;
+        if (WRITE && size && at < 64u && block + nb < total_blocks) {
+            const uint32_t v = (hi << len) >> (32u - size);
+            const int32_t val = (v < (1u << (size - 1u))) ? (int32_t)v - (int32_t)((1u << size) - 1u) : (int32_t)v;
+            coef[(size_t)(block + nb) * 64 + c.zigzag[at]] = (int16_t)val;
+        }
+        const uint32_t used = len + size;                            // 1..31
+        pos += used;
+        hi = __builtin_amdgcn_alignbit(hi, lo, 32u - used);
+        lo <<= used;
+        // lo holds cnt valid bits at its top; after consuming `used`: cnt - used (may go negative -> refill)
+        const int32_t left = (int32_t)cnt - (int32_t)used;
+        if (left < 0) {
+            // hi is short of -left bits at its bottom: they are the top bits of `next`
+            const uint32_t miss = (uint32_t)(-left);
+            hi |= next >> (32u - miss);
+            lo = next << miss;
+            cnt = 32u - miss;
+            ++w;
+        } else {
+            cnt = (uint32_t)left;
+        }
+        const bool done = knext >= 64u;
+        k = done ? 0u : knext;
+        blk = done ? (blk + 1u == c.bpm ? 0u : blk + 1u) : blk;
+        nb += done ? 1u : 0u;
+    }
+    s.pos = pos;
+    s.blk = blk;
+    s.k = k;
     return nb;
 }
 
@@ -254,6 +271,7 @@ struct JpegWgShared {
     uint64_t E[JPEG_WG];
     uint32_t nb[JPEG_WG];
     uint8_t flag[2][JPEG_WG];
+    uint8_t zigzag[64];
 };
 
 __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg_image &D, uint32_t lw, JpegWgShared &S,
@@ -272,6 +290,8 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
         const uint32_t w = w0 + i;
         S.words[i + (i >> 5)] = w < nwords_img ? __builtin_bswap32(g[w]) : 0u;
     }
+    if (threadIdx.x < 64) S.zigzag[threadIdx.x] = c_jpeg_zigzag[threadIdx.x];
+    c.zigzag = S.zigzag;
     c.words = S.words;
     c.word0 = w0;
     c.H = &S.H;
