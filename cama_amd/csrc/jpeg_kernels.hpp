@@ -570,6 +570,14 @@ __device__ __forceinline__ void jpeg_chroma8(const uint8_t *p, uint32_t pw, uint
     }
     const uint32_t cx0 = x0 >> 1;                                   // multiple of 4
     const uint32_t cy = vs == 2u ? y >> 1 : y;
+    if (cw <= 2u) {
+        // libjpeg-turbo uses the fancy routines only for downsampled widths > 2 (jdsample.c); narrower components
+        // are replicated
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(p + (size_t)cy * pw + cx0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[2 * k] = out[2 * k + 1] = (int32_t)((v >> (8 * k)) & 255u);
+        return;
+    }
     const uint32_t ny = vs == 2u ? ((y & 1u) ? min(cy + 1u, ch - 1u) : (cy ? cy - 1u : 0u)) : cy;
     const uint8_t *r0 = p + (size_t)cy * pw, *r1 = p + (size_t)ny * pw;
     const uint32_t lo = cx0 ? cx0 - 4u : 0u, hi = cx0 + 4u < pw ? cx0 + 4u : cx0;

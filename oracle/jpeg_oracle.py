@@ -285,7 +285,11 @@ def component_planes(hdr, coef):
 
 
 def upsample_h2v1(p, w_out):
-    """IJG h2v1_fancy_upsample on a plane cropped to its downsampled size."""
+    """IJG h2v1_fancy_upsample on a plane cropped to its downsampled size.  libjpeg-turbo selects the fancy routine
+    only for downsampled widths > 2 (jdsample.c: `do_fancy && compptr->downsampled_width > 2`); narrower components
+    are upsampled by plain replication."""
+    if p.shape[1] <= 2:
+        return np.repeat(p, 2, axis=1)[:, :w_out]
     a = p.astype(np.int32)
     left = np.concatenate([a[:, :1], a[:, :-1]], axis=1)
     right = np.concatenate([a[:, 1:], a[:, -1:]], axis=1)
@@ -298,7 +302,10 @@ def upsample_h2v1(p, w_out):
 
 
 def upsample_h2v2(p, w_out, h_out):
-    """IJG h2v2_fancy_upsample: 9/3/3/1 triangle filter, vertical neighbours replicated at the image edges."""
+    """IJG h2v2_fancy_upsample: 9/3/3/1 triangle filter, vertical neighbours replicated at the image edges; plain
+    replication for downsampled widths <= 2 (see upsample_h2v1)."""
+    if p.shape[1] <= 2:
+        return np.repeat(np.repeat(p, 2, axis=0), 2, axis=1)[:h_out, :w_out]
     a = p.astype(np.int32)
     up = np.concatenate([a[:1], a[:-1]], axis=0)
     dn = np.concatenate([a[1:], a[-1:]], axis=0)

@@ -33,7 +33,8 @@ def pillow_rgb(data):
     return np.array(Image.open(io.BytesIO(data)).convert("RGB"))
 
 
-@pytest.mark.parametrize("size", [(16, 16), (8, 8), (17, 23), (48, 64), (90, 160), (1, 1), (15, 31)])
+@pytest.mark.parametrize("size", [(16, 16), (8, 8), (17, 23), (48, 64), (90, 160), (1, 1), (15, 31), (21, 3), (5, 4),
+                                  (33, 2), (2, 5), (3, 6)])
 @pytest.mark.parametrize("sub", [0, 1, 2])
 def test_oracle_decodes_like_libjpeg_turbo(size, sub):
     for kind in ("smooth", "noise", "edges"):
