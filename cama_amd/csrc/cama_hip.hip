@@ -923,8 +923,8 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
     hipLaunchKernelGGL(k_jpeg_count, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
     hipLaunchKernelGGL(k_jpeg_tilescan, dim3((unsigned)n), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_jpeg_unstuff, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
-    hipLaunchKernelGGL(k_jpeg_sync<1>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a, 0u);
-    hipLaunchKernelGGL(k_jpeg_sync<2>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a, 0u);
+    hipLaunchKernelGGL(k_jpeg_sync<1>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
+    hipLaunchKernelGGL(k_jpeg_sync<2>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
     hipLaunchKernelGGL(k_jpeg_write, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
     hipLaunchKernelGGL(k_jpeg_dc, dim3((unsigned)n, 3), dim3(JPEG_DC_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((L.max_blocks + 31) / 32, (unsigned)n), dim3(256), 0, s, a);

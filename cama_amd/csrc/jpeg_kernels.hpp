@@ -310,9 +310,8 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
 
 // PHASE 1: speculative decode + fixpoint inside the workgroup.  PHASE 2: fixpoint seeded with the true entry state.
 template <int PHASE>
-__global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a, uint32_t sub_total0)
+__global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
 {
-    (void)sub_total0;
     __shared__ JpegWgShared S;
     const int img = jpeg_find_image(a.imgs, a.n, blockIdx.x, false);
     const cama_jpeg_image &D = a.imgs[img];
