@@ -150,7 +150,9 @@ class ClipFrameSource:
         assert self.decoder in ("device", "host")
         self._jpeg = None
         self._pool = None
-        self._workers = workers or min(12, (os.cpu_count() or 4))    # measured: 12 threads peak (~500 images/s), GIL beyond
+        # host decode: 12 threads peak (~500 images/s; the GIL beyond that).  Device decode: the workers only read
+        # files, a few are enough (more just burn the container's CPU quota)
+        self._workers = workers or (4 if self.decoder == "device" else min(12, (os.cpu_count() or 4)))
         self._prefetch = prefetch
         self._pending = {}                                            # image index -> list of futures
 
