@@ -264,6 +264,53 @@ __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegSta
     return nb;
 }
 
+// The same decode executed by a whole WAVE for ONE subsequence: lane i looks up, under all four tables, the symbol
+// that would start at bit pos + i; the wave then walks the actual symbol chain with scalar state and v_readlane
+// (no memory access per symbol).  A lone lane needs ~700 cycles per symbol (dependent LDS lookup + ~75 instructions
+// at one instruction per ~11 cycles); this needs one round of lookups per 64 bits plus ~20 scalar instructions per
+// symbol.  64x less throughput per wave, ~5x less latency: used where only a few subsequences are left to re-decode,
+// i.e. exactly the serial chains that set the kernel time.  State transitions are identical to jpeg_decode_span.
+__device__ __forceinline__ uint32_t jpeg_decode_span_wave(const JpegWgCtx &c, JpegState &s, uint32_t end)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t pos = s.pos, blk = s.blk, k = s.k, nb = 0;            // wave-uniform
+    const uint16_t *lut = &c.H->lut[0][0];
+    while (pos < end) {
+        const uint32_t bp = pos + lane;
+        const uint32_t w = (bp >> 5) - c.word0, sh = bp & 31u;
+        const uint32_t hi = c.words[w + (w >> 5)], lo = c.words[(w + 1) + ((w + 1) >> 5)];
+        const uint32_t win = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+        uint32_t e0 = lut[(0u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
+        uint32_t e1 = lut[(1u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
+        uint32_t e2 = lut[(2u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
+        uint32_t e3 = lut[(3u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
+        if (e0 == 0u) e0 = jpeg_symbol_long(*c.H, 0u, win);
+        if (e1 == 0u) e1 = jpeg_symbol_long(*c.H, 1u, win);
+        if (e2 == 0u) e2 = jpeg_symbol_long(*c.H, 2u, win);
+        if (e3 == 0u) e3 = jpeg_symbol_long(*c.H, 3u, win);
+        const uint32_t e01 = e0 | (e1 << 16), e23 = e2 | (e3 << 16);
+        uint32_t off = 0;
+        while (off < 64u && pos + off < end) {
+            const uint32_t isac = k ? 1u : 0u;
+            const uint32_t sel = ((isac ? c.ac_mask : c.dc_mask) >> blk) & 1u;       // table = sel * 2 + isac
+            const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)(sel ? e23 : e01), (int)off);
+            const uint32_t e = isac ? pair >> 16 : pair & 0xffffu;
+            const uint32_t len = e >> 8, size = e & 15u, run = (e >> 4) & 15u;
+            const uint32_t knext = isac ? (size ? k + run + 1u : (run == 15u ? k + 16u : 64u)) : 1u;
+            off += len + size;
+            const bool done = knext >= 64u;
+            k = done ? 0u : knext;
+            blk = done ? (blk + 1u == c.bpm ? 0u : blk + 1u) : blk;
+            nb += done ? 1u : 0u;
+        }
+        pos += off;
+    }
+    s.pos = pos;
+    s.blk = blk;
+    s.k = k;
+    return nb;
+}
+
 // common prologue: stream words + tables to LDS
 struct JpegWgShared {
     JpegHuffSet H;
@@ -286,7 +333,7 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
     const uint32_t *g = reinterpret_cast<const uint32_t *>(a.clean + D.stream_off);
     const uint32_t w0 = lw * JPEG_WG * JPEG_SUB_WORDS;
     const uint32_t nwords_img = (D.stream_len + 3u) / 4u + 8u;          // slack words exist (plan pads every segment)
-    for (uint32_t i = threadIdx.x; i < JPEG_WG * JPEG_SUB_WORDS + 4; i += JPEG_WG) {
+    for (uint32_t i = threadIdx.x; i < JPEG_WG * JPEG_SUB_WORDS + 8; i += JPEG_WG) {
         const uint32_t w = w0 + i;
         S.words[i + (i >> 5)] = w < nwords_img ? __builtin_bswap32(g[w]) : 0u;
     }
@@ -344,33 +391,71 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
         S.E[threadIdx.x] = a.E[gsub];
         S.nb[threadIdx.x] = a.nb[gsub];
         S.flag[0][threadIdx.x] = 0;
-        if (threadIdx.x == 0) {
-            // entry = end state of the previous workgroup's last subsequence
-            JpegState s = jpeg_unpack(a.E[gsub - 1]);
-            const uint32_t nb = jpeg_decode_span<false>(c, s, hi, nullptr, 0, 0);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            // entry = end state of the previous workgroup's last subsequence; decoded by wave 0 as a whole
+            JpegState s = jpeg_unpack(a.E[(size_t)blockIdx.x * JPEG_WG - 1]);
+            const uint32_t hi0 = min((sub0 + 1u) * JPEG_SUB_BITS, nbits);
+            const uint32_t nb = jpeg_decode_span_wave(c, s, hi0);
             const uint64_t e = jpeg_pack(s);
-            S.flag[0][0] = (e != S.E[0]) || (nb != S.nb[0]);
-            S.E[0] = e;
-            S.nb[0] = nb;
+            if (threadIdx.x == 0) {
+                S.flag[0][0] = (e != S.E[0]) || (nb != S.nb[0]);
+                S.E[0] = e;
+                S.nb[0] = nb;
+            }
         }
     }
+    // Fixpoint rounds.  While many subsequences changed, every thread re-decodes its own; once at most
+    // JPEG_WAVE_MAX are left (the serial chains), each is re-decoded by a whole wave (jpeg_decode_span_wave).
+    constexpr uint32_t JPEG_WAVE_MAX = 4;
+    __shared__ uint16_t s_list[JPEG_WG];
+    __shared__ uint64_t s_start[JPEG_WAVE_MAX];
+    __shared__ uint32_t s_wcount[JPEG_WG / 64];
     for (int round = 0; round < JPEG_WG; ++round) {
         __syncthreads();
         const bool redo = active && threadIdx.x > 0 && S.flag[cur][threadIdx.x - 1];
         const uint64_t start = threadIdx.x > 0 ? S.E[threadIdx.x - 1] : 0ull;
-        __syncthreads();
-        int changed = 0;
-        if (redo) {
-            JpegState s = jpeg_unpack(start);
-            const uint32_t nb = jpeg_decode_span<false>(c, s, hi, nullptr, 0, 0);
-            const uint64_t e = jpeg_pack(s);
-            changed = (e != S.E[threadIdx.x]);
-            S.E[threadIdx.x] = e;
-            S.nb[threadIdx.x] = nb;          // the count depends on the start state even when the end state does not
+        const uint64_t mask = __ballot(redo);
+        if ((threadIdx.x & 63) == 0) s_wcount[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+        S.flag[cur ^ 1][threadIdx.x] = 0;
+        __syncthreads();                                                 // every start is read before any end is written
+        uint32_t before = 0, m = 0;
+#pragma unroll
+        for (int wv = 0; wv < JPEG_WG / 64; ++wv) {
+            const uint32_t cnt = s_wcount[wv];
+            before += wv < (int)(threadIdx.x >> 6) ? cnt : 0u;
+            m += cnt;
         }
-        S.flag[cur ^ 1][threadIdx.x] = (uint8_t)changed;
+        if (m == 0u) break;                                              // uniform
+        if (m > JPEG_WAVE_MAX) {
+            if (redo) {
+                JpegState st = jpeg_unpack(start);
+                const uint32_t nb = jpeg_decode_span<false>(c, st, hi, nullptr, 0, 0);
+                const uint64_t e = jpeg_pack(st);
+                S.flag[cur ^ 1][threadIdx.x] = (uint8_t)(e != S.E[threadIdx.x]);
+                S.E[threadIdx.x] = e;
+                S.nb[threadIdx.x] = nb;  // the count depends on the start state even when the end state does not
+            }
+        } else {
+            if (redo) {
+                const uint32_t q = before + (uint32_t)__popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+                s_list[q] = (uint16_t)threadIdx.x;
+                s_start[q] = start;
+            }
+            __syncthreads();
+            for (uint32_t q = threadIdx.x >> 6; q < m; q += JPEG_WG / 64) {
+                const uint32_t j = s_list[q];
+                JpegState st = jpeg_unpack(s_start[q]);
+                const uint32_t nb = jpeg_decode_span_wave(c, st, min((sub0 + j + 1u) * JPEG_SUB_BITS, nbits));
+                const uint64_t e = jpeg_pack(st);
+                if ((threadIdx.x & 63) == 0) {
+                    S.flag[cur ^ 1][j] = (uint8_t)(e != S.E[j]);
+                    S.E[j] = e;
+                    S.nb[j] = nb;
+                }
+            }
+        }
         cur ^= 1;
-        if (!__syncthreads_or(changed)) break;
     }
     __syncthreads();
     a.E[gsub] = S.E[min(threadIdx.x, last)];                              // slots past `last` mirror it (entry of the next wg)
@@ -440,8 +525,11 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_write(JpegArgs a)
     if (bad) atomicOr(&a.status[img], bad);
 }
 
-// per (image, component): DC[i] = sum of the differences up to block i of that component (T.81 F.2.1.3.1)
+// per (image, component): DC[i] = sum of the differences up to block i of that component (T.81 F.2.1.3.1).
+// One workgroup per component; the DC terms sit 128 bytes apart (one per block), so each thread gathers its
+// consecutive blocks in batches of independent loads (one memory latency per batch, not per block).
 constexpr int JPEG_DC_THREADS = 1024;
+constexpr int JPEG_DC_BATCH = 8;
 __global__ __launch_bounds__(JPEG_DC_THREADS) void k_jpeg_dc(JpegArgs a)
 {
     const cama_jpeg_image &D = a.imgs[blockIdx.x];
@@ -453,8 +541,22 @@ __global__ __launch_bounds__(JPEG_DC_THREADS) void k_jpeg_dc(JpegArgs a)
     int16_t *coef = a.coef + D.coef_off;
     const uint32_t per = (n + JPEG_DC_THREADS - 1u) / JPEG_DC_THREADS;
     const uint32_t i0 = min(threadIdx.x * per, n), i1 = min(i0 + per, n);
+    // scan-order block of this component's i-th block: (i / hv) * bpm + first + i % hv, advanced incrementally
+    const uint32_t mcu0 = i0 / hv, sub0 = i0 - mcu0 * hv;
     int32_t sum = 0;
-    for (uint32_t i = i0; i < i1; ++i) sum += coef[(size_t)((i / hv) * D.bpm + first + i % hv) * 64];
+    {
+        uint32_t mcu = mcu0, sub = sub0;
+        for (uint32_t i = i0; i < i1; i += JPEG_DC_BATCH) {
+            int32_t v[JPEG_DC_BATCH];
+#pragma unroll
+            for (int q = 0; q < JPEG_DC_BATCH; ++q) {
+                v[q] = (i + q < i1) ? (int32_t)coef[(size_t)(mcu * D.bpm + first + sub) * 64] : 0;
+                if (++sub == hv) { sub = 0; ++mcu; }
+            }
+#pragma unroll
+            for (int q = 0; q < JPEG_DC_BATCH; ++q) sum += v[q];
+        }
+    }
     // exclusive scan of the per-thread sums: inside each wave by shuffles, across the 16 waves through LDS
     int32_t incl = sum;
 #pragma unroll
@@ -467,10 +569,21 @@ __global__ __launch_bounds__(JPEG_DC_THREADS) void k_jpeg_dc(JpegArgs a)
     __syncthreads();
     int32_t run = incl - sum;
     for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += s_wave[w];
-    for (uint32_t i = i0; i < i1; ++i) {
-        int16_t *p = coef + (size_t)((i / hv) * D.bpm + first + i % hv) * 64;
-        run += *p;
-        *p = (int16_t)run;
+    uint32_t mcu = mcu0, sub = sub0;
+    for (uint32_t i = i0; i < i1; i += JPEG_DC_BATCH) {
+        int32_t v[JPEG_DC_BATCH];
+        int16_t *ptr[JPEG_DC_BATCH];
+#pragma unroll
+        for (int q = 0; q < JPEG_DC_BATCH; ++q) {
+            ptr[q] = coef + (size_t)(mcu * D.bpm + first + sub) * 64;
+            v[q] = (i + q < i1) ? (int32_t)*ptr[q] : 0;
+            if (++sub == hv) { sub = 0; ++mcu; }
+        }
+#pragma unroll
+        for (int q = 0; q < JPEG_DC_BATCH; ++q) {
+            run += v[q];
+            if (i + q < i1) *ptr[q] = (int16_t)run;
+        }
     }
 }
 
