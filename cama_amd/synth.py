@@ -222,6 +222,18 @@ def make_clip(clip_path, n_frames=5, seed=0, n_lines=6, verts_per_line=5,
         for ci, name in enumerate(CAMERA_NAMES):
             os.makedirs(join(clip_path, name), exist_ok=True)
             for fi, ts in enumerate(frame_ms):
+                if image_mode == "jpg_photo":
+                    # photo-like content (smooth structure + sensor noise): ~300 KB per 1600x900 JPEG, where pure
+                    # noise ("jpg", the worst case for any JPEG decoder) gives ~1.3 MB.  Own generator: the draws of
+                    # the other modes (golden fixtures) are untouched.
+                    prng = np.random.default_rng([seed, ci, fi])
+                    yy, xx = np.mgrid[0:H, 0:W]
+                    base = np.stack([(xx * 0.16 + 20 * np.sin(yy / 30 + fi)) % 256, (yy * 0.28 + 7 * ci) % 256,
+                                     ((xx + yy) * 0.1 + 3 * fi) % 256], -1)
+                    img = np.clip(base + prng.normal(0, 6, base.shape), 0, 255).astype(np.uint8)
+                    from PIL import Image
+                    Image.fromarray(img[:, :, ::-1]).save(join(clip_path, name, f"{ts}.jpg"), quality=90)
+                    continue
                 img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
                 if image_mode == "npy":
                     np.save(join(clip_path, name, f"{ts}.npy"), img)

@@ -11,7 +11,7 @@ ap.add_argument("--frames", type=int, default=60)
 a = ap.parse_args()
 clip = os.path.join(tempfile.mkdtemp(prefix="cama_clip_"), "clip")
 make_clip(clip, n_frames=a.frames + 1, seed=0, n_lines=20, verts_per_line=11, line_len_m=5.0, raster_size=3000,
-          image_mode="jpg", image_size=(900, 1600), with_nuscenes=False, extra_labels=False)
+          image_mode=os.environ.get("CAMA_DEMO_IMAGES", "jpg_photo"), image_size=(900, 1600), with_nuscenes=False, extra_labels=False)
 cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)
 for step in (6, 20, 40):
     for _ in range(2):

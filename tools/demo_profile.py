@@ -7,7 +7,7 @@ from cama_amd.synth import DEFAULT_CAMA_CONFIGS, make_clip
 root = tempfile.mkdtemp(prefix="cama_demo_")
 clip = os.path.join(root, "clip")
 make_clip(clip, n_frames=61, seed=0, n_lines=20, verts_per_line=11, line_len_m=5.0, raster_size=3000,
-          image_mode="jpg", image_size=(900, 1600), with_nuscenes=False, extra_labels=False)
+          image_mode=os.environ.get("CAMA_DEMO_IMAGES", "jpg_photo"), image_size=(900, 1600), with_nuscenes=False, extra_labels=False)
 cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)
 vg = object.__new__(VideoGenerator)
 def loop():
