@@ -194,7 +194,7 @@ class DeviceJpegDecoder:
     """Batch decoder bound to one GPU.  decode(list of JPEG byte strings) -> uint8 tensor [n, H, W, 3] on the device
     (all images of a batch must share one size; BGR by default = cv2.imread's order)."""
 
-    def __init__(self, device):
+    def __init__(self, device, lanes=4, min_group=24):
         import torch
         self.lib = _lib.lib()
         if not torch.cuda.is_available():
@@ -204,8 +204,12 @@ class DeviceJpegDecoder:
         self.device = torch.device(device)
         self._huff_index, self._huff_host, self._huff_dev = {}, [], None
         self._quant_index, self._quant_host, self._quant_dev = {}, [], None
-        self._scratch = None
-        self._pinned = None
+        # The decode kernels last as long as their slowest workgroup (the longest re-synchronisation chain), not as
+        # long as their work: independent groups of images on separate streams overlap almost perfectly, so a batch
+        # is split over up to `lanes` streams, each with its own staging buffer and scratch.
+        self.lanes = int(lanes)
+        self.min_group = int(min_group)
+        self._lane = [None] * self.lanes
         self.stats = {"device": 0, "host_unsupported": 0, "host_flagged": 0}
 
     # ------------------------------------------------------------------ table caches (device copies grow on demand)
@@ -264,7 +268,14 @@ class DeviceJpegDecoder:
             assert tuple(out.shape) == (n, H, W, 3) and out.is_contiguous() and out.dtype == torch.uint8
             flagged = []
             if ok:
-                flagged = self._decode_device([blobs[i] for i in ok], [headers[i] for i in ok], ok, out, bgr)
+                groups = max(1, min(self.lanes, len(ok) // self.min_group))
+                bounds = [len(ok) * g // groups for g in range(groups + 1)]
+                cur = torch.cuda.current_stream(self.device)
+                tickets = [self._submit(g, [blobs[i] for i in ok[bounds[g]:bounds[g + 1]]],
+                                        [headers[i] for i in ok[bounds[g]:bounds[g + 1]]], ok[bounds[g]:bounds[g + 1]],
+                                        out, bgr, cur) for g in range(groups)]
+                for t in tickets:
+                    flagged += self._finish(t, out, cur)
             host = [i for i in range(n) if i not in set(ok)] + flagged
             self.stats["device"] += len(ok) - len(flagged)
             self.stats["host_unsupported"] += n - len(ok)
@@ -276,13 +287,16 @@ class DeviceJpegDecoder:
                 out[i].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
         return out
 
-    def _decode_device(self, blobs, headers, slots, out, bgr):
-        """Decode the supported images into out[slots]; returns the slots the device flagged as inconsistent."""
+    def _submit(self, g, blobs, headers, slots, out, bgr, cur):
+        """Pack, upload and launch the decode of one group on lane g's stream; returns a ticket for _finish."""
         import torch
+        L = self._lane[g]
+        if L is None:
+            L = self._lane[g] = {"stream": torch.cuda.Stream(device=self.device), "pinned": None, "scratch": None}
         n = len(blobs)
         imgs = np.zeros(n, IMAGE_DTYPE)
         off = 0
-        for i, (b, h) in enumerate(zip(blobs, headers)):
+        for i, h in enumerate(headers):
             d = imgs[i]
             d["stream_off"], d["stream_len"] = off, h.scan_end - h.scan_start
             d["width"], d["height"], d["ncomp"], d["hs"], d["vs"] = h.width, h.height, h.ncomp, h.hs, h.vs
@@ -290,31 +304,43 @@ class DeviceJpegDecoder:
             d["comp_dc"], d["comp_ac"] = h.comp_dc, h.comp_ac
             off = (off + int(d["stream_len"]) + 64 + 15) & ~15
         stream_bytes = off + 64
-        if self._pinned is None or self._pinned.numel() < stream_bytes:
-            self._pinned = torch.empty(max(stream_bytes, 1 << 20), dtype=torch.uint8).pin_memory()
-        host = self._pinned.numpy()
+        if L["pinned"] is None or L["pinned"].numel() < stream_bytes:
+            L["pinned"] = torch.empty(max(stream_bytes, 1 << 20), dtype=torch.uint8).pin_memory()
+        host = L["pinned"].numpy()
         for i, (b, h) in enumerate(zip(blobs, headers)):
             o = int(imgs[i]["stream_off"])
             host[o:o + int(imgs[i]["stream_len"])] = np.frombuffer(b, np.uint8, int(imgs[i]["stream_len"]), h.scan_start)
         info = np.zeros(3, np.uint64)                      # cama_jpeg_plan_info: u64 scratch_bytes + 4 x u32
         _lib.check(self.lib.cama_jpeg_plan(imgs.ctypes.data, n, stream_bytes, info.ctypes.data))
         scratch_bytes = int(info[0])
-        if self._scratch is None or self._scratch.numel() < scratch_bytes:
-            self._scratch = None
-            self._scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=self.device)
-        stream_dev = self._pinned[:stream_bytes].to(self.device, non_blocking=True)
-        imgs_dev = torch.from_numpy(imgs.view(np.uint8).reshape(n, -1)).to(self.device)
-        huff_dev, quant_dev = self._tables()
-        status = torch.empty(n, dtype=torch.int32, device=self.device)
+        huff_dev, quant_dev = self._tables()               # (on the caller's stream: the lane waits for it below)
         contiguous = slots == list(range(slots[0], slots[0] + n))
-        target = out[slots[0]:slots[0] + n] if contiguous else torch.empty((n,) + tuple(out.shape[1:]), dtype=torch.uint8,
-                                                                            device=self.device)
-        _lib.check(self.lib.cama_jpeg_decode(
-            stream_dev.data_ptr(), stream_bytes, imgs.ctypes.data, imgs_dev.data_ptr(), n, huff_dev.data_ptr(),
-            huff_dev.shape[0], quant_dev.data_ptr(), quant_dev.shape[0], target.data_ptr(), target.stride(0), int(bool(bgr)),
-            self._scratch.data_ptr(), self._scratch.numel(), status.data_ptr(),
-            torch.cuda.current_stream(self.device).cuda_stream))
-        if not contiguous:
-            out[torch.as_tensor(slots, device=self.device)] = target
-        bad = status.cpu().numpy()                                   # one small readback per batch (also orders the pinned buffer's reuse)
-        return [slots[i] for i in np.flatnonzero(bad)]
+        st = L["stream"]
+        st.wait_stream(cur)                                # `out`, the tables and earlier work of the caller
+        with torch.cuda.stream(st):
+            if L["scratch"] is None or L["scratch"].numel() < scratch_bytes:
+                L["scratch"] = None
+                L["scratch"] = torch.empty(scratch_bytes, dtype=torch.uint8, device=self.device)
+            stream_dev = L["pinned"][:stream_bytes].to(self.device, non_blocking=True)
+            imgs_dev = torch.from_numpy(imgs.view(np.uint8).reshape(n, -1)).to(self.device, non_blocking=True)
+            status = torch.empty(n, dtype=torch.int32, device=self.device)
+            target = out[slots[0]:slots[0] + n] if contiguous else \
+                torch.empty((n,) + tuple(out.shape[1:]), dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.cama_jpeg_decode(
+                stream_dev.data_ptr(), stream_bytes, imgs.ctypes.data, imgs_dev.data_ptr(), n, huff_dev.data_ptr(),
+                huff_dev.shape[0], quant_dev.data_ptr(), quant_dev.shape[0], target.data_ptr(), target.stride(0),
+                int(bool(bgr)), L["scratch"].data_ptr(), L["scratch"].numel(), status.data_ptr(), st.cuda_stream))
+            if not contiguous:
+                out[torch.as_tensor(slots, device=self.device)] = target
+            status_host = torch.empty(n, dtype=torch.int32).pin_memory()
+            status_host.copy_(status, non_blocking=True)
+        out.record_stream(st)
+        return {"lane": L, "slots": slots, "status": status_host, "keep": (stream_dev, imgs_dev, status, target, imgs)}
+
+    def _finish(self, ticket, out, cur):
+        """Wait for a group; returns the slots the device flagged as inconsistent (to be decoded on the host)."""
+        st = ticket["lane"]["stream"]
+        st.synchronize()                                   # one small readback per group (also frees the staging buffer)
+        cur.wait_stream(st)
+        bad = ticket["status"].numpy()
+        return [ticket["slots"][i] for i in np.flatnonzero(bad)]
