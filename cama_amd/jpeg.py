@@ -292,7 +292,8 @@ class DeviceJpegDecoder:
         import torch
         L = self._lane[g]
         if L is None:
-            L = self._lane[g] = {"stream": torch.cuda.Stream(device=self.device), "pinned": None, "scratch": None}
+            L = self._lane[g] = {"stream": torch.cuda.Stream(device=self.device), "pinned": None, "scratch": None,
+                                 "status": None}
         n = len(blobs)
         imgs = np.zeros(n, IMAGE_DTYPE)
         off = 0
@@ -332,15 +333,16 @@ class DeviceJpegDecoder:
                 int(bool(bgr)), L["scratch"].data_ptr(), L["scratch"].numel(), status.data_ptr(), st.cuda_stream))
             if not contiguous:
                 out[torch.as_tensor(slots, device=self.device)] = target
-            status_host = torch.empty(n, dtype=torch.int32).pin_memory()
-            status_host.copy_(status, non_blocking=True)
-        out.record_stream(st)
-        return {"lane": L, "slots": slots, "status": status_host, "keep": (stream_dev, imgs_dev, status, target, imgs)}
+            if L["status"] is None or L["status"].numel() < n:
+                L["status"] = torch.empty(max(n, 256), dtype=torch.int32).pin_memory()
+            L["status"][:n].copy_(status, non_blocking=True)
+        # (no record_stream on `out`: _finish synchronises every lane before decode() returns)
+        return {"lane": L, "slots": slots, "n": n, "keep": (stream_dev, imgs_dev, status, target, imgs)}
 
     def _finish(self, ticket, out, cur):
         """Wait for a group; returns the slots the device flagged as inconsistent (to be decoded on the host)."""
         st = ticket["lane"]["stream"]
         st.synchronize()                                   # one small readback per group (also frees the staging buffer)
         cur.wait_stream(st)
-        bad = ticket["status"].numpy()
+        bad = ticket["lane"]["status"][:ticket["n"]].numpy()
         return [ticket["slots"][i] for i in np.flatnonzero(bad)]
