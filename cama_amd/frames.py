@@ -149,6 +149,7 @@ class ClipFrameSource:
         self.decoder = decoder or os.environ.get("CAMA_JPEG_DECODER", "device" if device is not None else "host")
         assert self.decoder in ("device", "host")
         self._jpeg = None
+        self._ahead = {}                                              # tuple(image indices) -> PendingDecode
         self._pool = None
         # host decode: 12 threads peak (~500 images/s; the GIL beyond that).  Device decode: the workers only read
         # files, a few are enough (more just burn the container's CPU quota)
@@ -206,14 +207,17 @@ class ClipFrameSource:
         """device uint8 BGR tensor [F,C,H0,W0,3]: every image goes to its slot as decoded (no host-side stacking or
         channel flip: both hold the GIL the decode threads need); RGB-decoded frames are flipped on the device."""
         import torch
+        image_indices = [int(i) for i in image_indices]
+        F = len(image_indices)
+        ahead = self._ahead.pop(tuple(image_indices), None) if self._ahead else None
+        if ahead is not None:                                        # decoded while the previous batch was consumed
+            flat = ahead.result()
+            self._decode_ahead(image_indices)
+            return flat.view((F, len(self.cm_list)) + tuple(flat.shape[1:]))
         items = self._collect(image_indices)
-        F = len(list(image_indices))
         if all(isinstance(arr, (bytes, bytearray)) for _, _, arr, _ in items):
             # compressed bytes straight to the device decoder: one upload + one decode for the whole batch, BGR out
-            if self._jpeg is None:
-                from .jpeg import DeviceJpegDecoder
-                self._jpeg = DeviceJpegDecoder(self.device)
-            flat = self._jpeg.decode([arr for _, _, arr, _ in items], bgr=True)
+            flat = self._device_decode(image_indices, items)
             return flat.view((F, len(self.cm_list)) + tuple(flat.shape[1:]))
         items = [(k, c, _decode_bytes(arr) if isinstance(arr, (bytes, bytearray)) else arr,
                   True if isinstance(arr, (bytes, bytearray)) else is_rgb) for k, c, arr, is_rgb in items]
@@ -229,6 +233,41 @@ class ClipFrameSource:
             m = rgb.to(self.device)
             dev[m] = dev[m].flip(-1)
         return dev
+
+    def _device_decode(self, image_indices, items):
+        if self._jpeg is None:
+            from .jpeg import DeviceJpegDecoder
+            self._jpeg = DeviceJpegDecoder(self.device)
+        flat = self._jpeg.decode([arr for _, _, arr, _ in items], bgr=True)
+        self._decode_ahead(image_indices)
+        return flat
+
+    def _decode_ahead(self, image_indices):
+        """Start decoding the batch that follows `image_indices` (same length, consecutive frames) on the decoder's
+        side streams: the decode kernels are latency-bound and leave most of the GPU idle, so the next frame's decode
+        runs under the current frame's host work and overlay."""
+        step = len(image_indices)
+        nxt = [i + step for i in image_indices]
+        for stale in [k for k in self._ahead if k != tuple(nxt)]:
+            self._ahead.pop(stale).result()                              # release its lanes
+        if nxt[-1] >= self._n_frames() or tuple(nxt) in self._ahead or image_indices != list(range(image_indices[0], image_indices[0] + step)):
+            return
+        items = self._collect(nxt)
+        if all(isinstance(arr, (bytes, bytearray)) for _, _, arr, _ in items):
+            self._ahead[tuple(nxt)] = self._jpeg.decode_async([arr for _, _, arr, _ in items], bgr=True)
+        else:                                                            # mixed sources: leave them to the normal path
+            self._requeue(nxt, items)
+
+    def _requeue(self, idx, items):
+        from concurrent.futures import Future
+        for i in idx:
+            futs = []
+            for k, c, arr, is_rgb in items:
+                if idx[k] == i:
+                    f = Future()
+                    f.set_result((arr, is_rgb))
+                    futs.append(f)
+            self._pending[i] = futs
 
     def batch(self, image_indices):
         import torch

@@ -209,7 +209,7 @@ class DeviceJpegDecoder:
         # is split over up to `lanes` streams, each with its own staging buffer and scratch.
         self.lanes = int(lanes)
         self.min_group = int(min_group)
-        self._lane = [None] * self.lanes
+        self._lane = []
         self.stats = {"device": 0, "host_unsupported": 0, "host_flagged": 0}
 
     # ------------------------------------------------------------------ table caches (device copies grow on demand)
@@ -242,6 +242,12 @@ class DeviceJpegDecoder:
 
     # ------------------------------------------------------------------ decode
     def decode(self, blobs, bgr=True, out=None):
+        return self.decode_async(blobs, bgr=bgr, out=out).result()
+
+    def decode_async(self, blobs, bgr=True, out=None):
+        """Parse, upload and launch; returns a PendingDecode whose result() waits, re-decodes flagged / unsupported
+        images on the host and returns the [n, H, W, 3] tensor.  Several decodes may be in flight (each takes its
+        own lanes), e.g. the next frame's while the current one is consumed."""
         import torch
         n = len(blobs)
         assert n >= 1
@@ -251,49 +257,44 @@ class DeviceJpegDecoder:
                 headers.append(parse_header(b))
             except Unsupported:
                 headers.append(None)
-        ok = [i for i, h in enumerate(headers) if h is not None]
         size = None
         for h in headers:
             if h is not None:
                 size = (h.height, h.width)
                 break
         if size is None:                                             # nothing for the device: all on the host
-            first = _host_decode(blobs[0], bgr)
-            size = first.shape[:2]
+            size = _host_decode(blobs[0], bgr).shape[:2]
         H, W = size
-        ok = [i for i in ok if (headers[i].height, headers[i].width) == (H, W)]
+        ok = [i for i, h in enumerate(headers) if h is not None and (h.height, h.width) == (H, W)]
         with torch.cuda.device(self.device):
             if out is None:
                 out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=self.device)
             assert tuple(out.shape) == (n, H, W, 3) and out.is_contiguous() and out.dtype == torch.uint8
-            flagged = []
+            tickets = []
             if ok:
                 groups = max(1, min(self.lanes, len(ok) // self.min_group))
                 bounds = [len(ok) * g // groups for g in range(groups + 1)]
                 cur = torch.cuda.current_stream(self.device)
-                tickets = [self._submit(g, [blobs[i] for i in ok[bounds[g]:bounds[g + 1]]],
+                tickets = [self._submit([blobs[i] for i in ok[bounds[g]:bounds[g + 1]]],
                                         [headers[i] for i in ok[bounds[g]:bounds[g + 1]]], ok[bounds[g]:bounds[g + 1]],
                                         out, bgr, cur) for g in range(groups)]
-                for t in tickets:
-                    flagged += self._finish(t, out, cur)
-            host = [i for i in range(n) if i not in set(ok)] + flagged
-            self.stats["device"] += len(ok) - len(flagged)
-            self.stats["host_unsupported"] += n - len(ok)
-            self.stats["host_flagged"] += len(flagged)
-            for i in host:
-                arr = _host_decode(blobs[i], bgr)
-                if arr.shape[:2] != (H, W):
-                    raise ValueError(f"image {i} is {arr.shape[1]}x{arr.shape[0]}, the batch is {W}x{H}")
-                out[i].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
-        return out
+        return PendingDecode(self, blobs, ok, tickets, out, bgr)
 
-    def _submit(self, g, blobs, headers, slots, out, bgr, cur):
-        """Pack, upload and launch the decode of one group on lane g's stream; returns a ticket for _finish."""
+    def _lane_acquire(self):
         import torch
-        L = self._lane[g]
-        if L is None:
-            L = self._lane[g] = {"stream": torch.cuda.Stream(device=self.device), "pinned": None, "scratch": None,
-                                 "status": None}
+        for L in self._lane:
+            if L is not None and not L["busy"]:
+                L["busy"] = True
+                return L
+        L = {"stream": torch.cuda.Stream(device=self.device), "pinned": None, "scratch": None, "status": None,
+             "busy": True}
+        self._lane = [x for x in self._lane if x is not None] + [L]
+        return L
+
+    def _submit(self, blobs, headers, slots, out, bgr, cur):
+        """Pack, upload and launch the decode of one group on a free lane's stream; returns a ticket for _finish."""
+        import torch
+        L = self._lane_acquire()
         n = len(blobs)
         imgs = np.zeros(n, IMAGE_DTYPE)
         off = 0
@@ -344,5 +345,36 @@ class DeviceJpegDecoder:
         st = ticket["lane"]["stream"]
         st.synchronize()                                   # one small readback per group (also frees the staging buffer)
         cur.wait_stream(st)
-        bad = ticket["lane"]["status"][:ticket["n"]].numpy()
+        bad = ticket["lane"]["status"][:ticket["n"]].numpy().copy()
+        ticket["lane"]["busy"] = False
         return [ticket["slots"][i] for i in np.flatnonzero(bad)]
+
+
+class PendingDecode:
+    def __init__(self, dec, blobs, ok, tickets, out, bgr):
+        self.dec, self.blobs, self.ok, self.tickets, self.out, self.bgr = dec, blobs, ok, tickets, out, bgr
+        self._done = False
+
+    def result(self):
+        import torch
+        if self._done:
+            return self.out
+        dec, out, n = self.dec, self.out, len(self.blobs)
+        with torch.cuda.device(dec.device):
+            cur = torch.cuda.current_stream(dec.device)
+            flagged = []
+            for t in self.tickets:
+                flagged += dec._finish(t, out, cur)
+            on_device = set(self.ok)
+            host = [i for i in range(n) if i not in on_device] + flagged
+            dec.stats["device"] += len(self.ok) - len(flagged)
+            dec.stats["host_unsupported"] += n - len(self.ok)
+            dec.stats["host_flagged"] += len(flagged)
+            for i in host:
+                arr = _host_decode(self.blobs[i], self.bgr)
+                if tuple(arr.shape[:2]) != tuple(out.shape[1:3]):
+                    raise ValueError(f"image {i} is {arr.shape[1]}x{arr.shape[0]}, the batch is {out.shape[2]}x{out.shape[1]}")
+                out[i].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+        self._done = True
+        self.blobs = self.tickets = None
+        return out
