@@ -808,6 +808,7 @@ static int jpeg_layout(cama_jpeg_image *imgs, const cama_jpeg_image *cimgs, int3
     uint32_t wg = 0, tile = 0, max_blocks = 0;
     size_t coef = 0, planes = 0;
     uint64_t prev_end = 0;
+    std::vector<cama_jpeg_image> planned((size_t)n);
     for (int i = 0; i < n; ++i) {
         const cama_jpeg_image &D = cimgs[i];
         if (D.width < 1 || D.width > 65535 || D.height < 1 || D.height > 65535)
@@ -815,13 +816,19 @@ static int jpeg_layout(cama_jpeg_image *imgs, const cama_jpeg_image *cimgs, int3
         if (!(D.ncomp == 1 || D.ncomp == 3)) return fail(CAMA_EINVAL, "image %d: %u components", i, D.ncomp);
         const bool samp_ok = (D.hs == 1 && D.vs == 1) || (D.ncomp == 3 && D.hs == 2 && (D.vs == 1 || D.vs == 2));
         if (!samp_ok) return fail(CAMA_EINVAL, "image %d: sampling %ux%u not supported", i, D.hs, D.vs);
+        if (D.kind > CAMA_JPEG_PIXELS) return fail(CAMA_EINVAL, "image %d: kind %u", i, D.kind);
         for (uint32_t c = 0; c < D.ncomp; ++c)
             if (D.comp_dc[c] > 1 || D.comp_ac[c] > 1) return fail(CAMA_EINVAL, "image %d: Huffman selector > 1", i);
-        if (D.stream_off % 16 || D.stream_off < prev_end || D.stream_len < 1 || D.stream_len > (1u << 29) ||
-            D.stream_off + D.stream_len + 64 > stream_bytes)
-            return fail(CAMA_EINVAL, "image %d: segment [%llu, +%u) not 16-aligned / overlapping / without 64 spare bytes",
-                        i, (unsigned long long)D.stream_off, D.stream_len);
-        prev_end = D.stream_off + D.stream_len + 64;
+        const bool has_stream = D.kind != CAMA_JPEG_PIXELS, has_pixels = D.kind != CAMA_JPEG_SEGMENT;
+        if (has_stream) {
+            if (D.stream_off % 16 || D.stream_off < prev_end || D.stream_len < 1 || D.stream_len > (1u << 29) ||
+                D.stream_off + D.stream_len + 64 > stream_bytes)
+                return fail(CAMA_EINVAL, "image %d: segment [%llu, +%u) not 16-aligned / overlapping / without 64 spare bytes",
+                            i, (unsigned long long)D.stream_off, D.stream_len);
+            prev_end = D.stream_off + D.stream_len + 64;
+        } else if (D.stream_len != 0) {
+            return fail(CAMA_EINVAL, "image %d: a pixels-only descriptor carries no stream", i);
+        }
         cama_jpeg_image W = D;
         W.mx = (D.width + 8 * D.hs - 1) / (8 * D.hs);
         W.my = (D.height + 8 * D.vs - 1) / (8 * D.vs);
@@ -834,21 +841,33 @@ static int jpeg_layout(cama_jpeg_image *imgs, const cama_jpeg_image *cimgs, int3
         W.nwg = (nsub + JPEG_WG - 1) / JPEG_WG;
         W.tile0 = tile;
         W.ntile = (D.stream_len + JPEG_TILE - 1) / JPEG_TILE;
-        W.coef_off = coef;
-        coef += (size_t)blocks * 64;
+        if (D.kind == CAMA_JPEG_SEGMENT) {
+            if (D.parent >= (uint32_t)i) return fail(CAMA_EINVAL, "image %d: parent %u must come earlier", i, D.parent);
+            const cama_jpeg_image &P = planned[D.parent];
+            if (P.kind != CAMA_JPEG_PIXELS || P.ncomp != D.ncomp || P.hs != D.hs || P.vs != D.vs || W.my != 1 ||
+                (uint64_t)D.first_block + blocks > P.total_blocks || D.first_block % W.bpm)
+                return fail(CAMA_EINVAL, "image %d: restart segment does not fit its parent %u", i, D.parent);
+            W.coef_off = P.coef_off + (uint64_t)D.first_block * 64;
+            W.out_slot = 0;
+        } else {
+            W.coef_off = coef;
+            coef += (size_t)blocks * 64;
+            W.parent = 0; W.first_block = 0;
+            if (D.out_slot >= (uint32_t)n) return fail(CAMA_EINVAL, "image %d: out_slot %u out of range", i, D.out_slot);
+        }
         for (uint32_t c = 0; c < 3; ++c) {
             W.plane_off[c] = 0; W.plane_w[c] = 0; W.plane_h[c] = 0;
-            if (c < D.ncomp) {
+            if (c < D.ncomp && has_pixels) {
                 W.plane_w[c] = W.mx * (c == 0 ? D.hs : 1u) * 8u;
                 W.plane_h[c] = W.my * (c == 0 ? D.vs : 1u) * 8u;
                 W.plane_off[c] = planes;
                 planes += align_up((size_t)W.plane_w[c] * W.plane_h[c], 16);
             }
         }
-        W.reserved[0] = W.reserved[1] = 0;
         wg += W.nwg;
         tile += W.ntile;
-        max_blocks = std::max(max_blocks, W.total_blocks);
+        if (has_pixels) max_blocks = std::max(max_blocks, W.total_blocks);
+        planned[i] = W;
         if (write) imgs[i] = W;
         else if (memcmp(&W, &D, sizeof(W)) != 0)
             return fail(CAMA_EINVAL, "image %d: descriptor was not produced by cama_jpeg_plan()", i);
@@ -899,11 +918,13 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
     for (int i = 0; i < n; ++i) {
         if ((int32_t)imgs[i].huff_set >= n_huff_sets || (int32_t)imgs[i].quant_set >= n_quant_sets)
             return fail(CAMA_EINVAL, "image %d: table set index out of range", i);
-        if ((uint64_t)imgs[i].width * imgs[i].height * 3 > out_stride)
+        if (imgs[i].kind != CAMA_JPEG_SEGMENT && (uint64_t)imgs[i].width * imgs[i].height * 3 > out_stride)
             return fail(CAMA_EINVAL, "image %d: %ux%ux3 bytes exceed out_stride %llu", i, imgs[i].width, imgs[i].height,
                         (unsigned long long)out_stride);
-        maxw = std::max(maxw, imgs[i].width);
-        maxh = std::max(maxh, imgs[i].height);
+        if (imgs[i].kind != CAMA_JPEG_SEGMENT) {
+            maxw = std::max(maxw, imgs[i].width);
+            maxh = std::max(maxh, imgs[i].height);
+        }
     }
     if ((uintptr_t)stream % 16 || (uintptr_t)scratch % 256 || (uintptr_t)huff_sets % 16)
         return fail(CAMA_EINVAL, "stream / huff_sets must be 16-byte and scratch 256-byte aligned");
@@ -920,12 +941,14 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
     HIP_TRY(hipMemsetAsync(a.clean, 0, (size_t)stream_bytes + 64, s));
     HIP_TRY(hipMemsetAsync(a.coef, 0, L.coef_elems * 2, s));
     HIP_TRY(hipMemsetAsync(status, 0, (size_t)n * 4, s));
-    hipLaunchKernelGGL(k_jpeg_count, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
+    if (L.total_tiles) hipLaunchKernelGGL(k_jpeg_count, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
     hipLaunchKernelGGL(k_jpeg_tilescan, dim3((unsigned)n), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_jpeg_unstuff, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
-    hipLaunchKernelGGL(k_jpeg_sync<1>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
-    hipLaunchKernelGGL(k_jpeg_sync<2>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
-    hipLaunchKernelGGL(k_jpeg_write, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
+    if (L.total_tiles) hipLaunchKernelGGL(k_jpeg_unstuff, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
+    if (L.total_wgs) {
+        hipLaunchKernelGGL(k_jpeg_sync<1>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
+        hipLaunchKernelGGL(k_jpeg_sync<2>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
+        hipLaunchKernelGGL(k_jpeg_write, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
+    }
     hipLaunchKernelGGL(k_jpeg_dc, dim3((unsigned)n, 3), dim3(JPEG_DC_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((L.max_blocks + 31) / 32, (unsigned)n), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_jpeg_colour, dim3((maxw + 2047) / 2048, (maxh + JPEG_COLOUR_ROWS - 1) / JPEG_COLOUR_ROWS, (unsigned)n),

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(JPEG_DC_THREADS) void k_jpeg_dc(JpegArgs a)
 {
     const cama_jpeg_image &D = a.imgs[blockIdx.x];
     const uint32_t ci = blockIdx.y;
-    if (ci >= D.ncomp) return;
+    if (ci >= D.ncomp || D.kind == CAMA_JPEG_PIXELS) return;     // restart intervals: one scan per interval (DC resets)
     const uint32_t hv = ci == 0 ? D.hs * D.vs : 1u;
     const uint32_t first = ci == 0 ? 0u : D.hs * D.vs + (ci - 1u);
     const uint32_t n = D.mx * D.my * hv;
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(JpegArgs a)
     const cama_jpeg_image &D = a.imgs[blockIdx.y];
     const uint32_t lane = threadIdx.x & 7u, lb = threadIdx.x >> 3;
     const uint32_t j = blockIdx.x * 32u + lb;                    // scan-order block
-    const bool live = j < D.total_blocks;
+    const bool live = j < D.total_blocks && D.kind != CAMA_JPEG_SEGMENT;
     uint32_t ci = 0, bx = 0, by = 0;
     if (live) {
         const uint32_t mcu = j / D.bpm, within = j - mcu * D.bpm, luma = D.hs * D.vs;
@@ -725,9 +725,9 @@ __global__ __launch_bounds__(256) void k_jpeg_colour(JpegArgs a)
 {
     const cama_jpeg_image &D = a.imgs[blockIdx.z];
     const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 8u;
-    if (x0 >= D.width) return;
+    if (x0 >= D.width || D.kind == CAMA_JPEG_SEGMENT) return;
     const uint32_t cw = (D.width + D.hs - 1u) / D.hs, ch = (D.height + D.vs - 1u) / D.vs;
-    uint8_t *img = a.out + (size_t)blockIdx.z * a.out_stride;
+    uint8_t *img = a.out + (size_t)D.out_slot * a.out_stride;
     const bool packed = (D.width & 7u) == 0u && ((uintptr_t)img & 7u) == 0u;
     for (uint32_t y = blockIdx.y * JPEG_COLOUR_ROWS; y < min((blockIdx.y + 1u) * JPEG_COLOUR_ROWS, D.height); ++y) {
         const uint2 yv = *reinterpret_cast<const uint2 *>(a.planes + D.plane_off[0] + (size_t)y * D.plane_w[0] + x0);

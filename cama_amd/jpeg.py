@@ -7,7 +7,7 @@ a whole batch into one upload and hands descriptors + tables to the device decod
 libjpeg-turbo's (tests/test_gpu_jpeg.py against Pillow and oracle/jpeg_oracle.py).
 
 Scope of the device path: baseline sequential (SOF0), 8 bit, grey or YCbCr with 4:4:4 / 4:2:2 / 4:2:0 sampling, one
-interleaved scan, no restart intervals.  Anything else -- and any stream the device flags as inconsistent -- is decoded
+interleaved scan, with or without restart intervals (every interval becomes its own entropy segment).  Anything else -- and any stream the device flags as inconsistent -- is decoded
 by Pillow on the host and uploaded, so `decode()` always returns every image.
 """
 import io
@@ -22,7 +22,9 @@ IMAGE_DTYPE = np.dtype([
     ("huff_set", "<u4"), ("quant_set", "<u4"), ("comp_dc", "<u4", (3,)), ("comp_ac", "<u4", (3,)),
     ("mx", "<u4"), ("my", "<u4"), ("bpm", "<u4"), ("total_blocks", "<u4"),
     ("wg0", "<u4"), ("nwg", "<u4"), ("tile0", "<u4"), ("ntile", "<u4"),
-    ("plane_w", "<u4", (3,)), ("plane_h", "<u4", (3,)), ("reserved", "<u4", (2,))])          # == cama_jpeg_image
+    ("plane_w", "<u4", (3,)), ("plane_h", "<u4", (3,)),
+    ("kind", "<u4"), ("parent", "<u4"), ("first_block", "<u4"), ("out_slot", "<u4")])       # == cama_jpeg_image
+KIND_WHOLE, KIND_SEGMENT, KIND_PIXELS = 0, 1, 2
 
 LUT_BITS = 10
 HUFF_DTYPE = np.dtype([("lut", "<u2", (4, 1 << LUT_BITS)), ("lim", "<u4", (4, 8)), ("valoff", "<i4", (4, 17)),
@@ -39,7 +41,7 @@ class Unsupported(ValueError):
 
 class JpegHeader:
     __slots__ = ("width", "height", "ncomp", "hs", "vs", "quant", "huff", "comp_dc", "comp_ac", "scan_start",
-                 "scan_end")
+                 "scan_end", "restart_interval")
 
 
 _HEADER_CACHE = {}
@@ -122,8 +124,7 @@ def _parse_header(data):
     if h.ncomp not in (1, 3) or h.width == 0 or h.height == 0:
         raise Unsupported("component count / size")
     comps = [(frame[6 + 3 * k], frame[7 + 3 * k] >> 4, frame[7 + 3 * k] & 15, frame[8 + 3 * k]) for k in range(h.ncomp)]
-    if dri:
-        raise Unsupported("restart intervals")
+    h.restart_interval = dri
     if seg[0] != h.ncomp or tuple(seg[1 + 2 * h.ncomp:4 + 2 * h.ncomp]) != (0, 63, 0):
         raise Unsupported("not one interleaved full-spectrum scan")
     h.comp_dc, h.comp_ac = [0, 0, 0], [0, 0, 0]
@@ -181,6 +182,25 @@ def build_huff_set(huff):
                 rec["lim"][t, l - LUT_BITS - 1] = code << (16 - l)
             code <<= 1
     return rec
+
+
+def restart_segments(data, h):
+    """[(start, end, first_mcu, n_mcu)] byte ranges of the restart intervals of the scan (T.81 B.2.1: RSTm markers
+    between them), or None when their number does not match the frame (corrupt: leave it to the host decoder)."""
+    a = np.frombuffer(data, np.uint8, h.scan_end - h.scan_start, h.scan_start)
+    ff = np.flatnonzero(a[:-1] == 0xFF)
+    nxt = a[ff + 1]
+    rst = ff[(nxt >= 0xD0) & (nxt <= 0xD7)]
+    mcus = -(-h.width // (8 * h.hs)) * -(-h.height // (8 * h.vs))
+    ri = h.restart_interval
+    if len(rst) + 1 != -(-mcus // ri):
+        return None
+    starts = np.concatenate([[0], rst + 2])
+    ends = np.concatenate([rst, [len(a)]])
+    if np.any(ends <= starts):
+        return None
+    return [(h.scan_start + int(s0), h.scan_start + int(e0), k * ri, min(ri, mcus - k * ri))
+            for k, (s0, e0) in enumerate(zip(starts, ends))]
 
 
 def _host_decode(data, bgr):
@@ -296,24 +316,63 @@ class DeviceJpegDecoder:
         import torch
         L = self._lane_acquire()
         n = len(blobs)
-        imgs = np.zeros(n, IMAGE_DTYPE)
-        off = 0
-        for i, h in enumerate(headers):
-            d = imgs[i]
-            d["stream_off"], d["stream_len"] = off, h.scan_end - h.scan_start
-            d["width"], d["height"], d["ncomp"], d["hs"], d["vs"] = h.width, h.height, h.ncomp, h.hs, h.vs
-            d["huff_set"], d["quant_set"] = self._huff_id(h.huff), self._quant_id(h.quant)
-            d["comp_dc"], d["comp_ac"] = h.comp_dc, h.comp_ac
-            off = (off + int(d["stream_len"]) + 64 + 15) & ~15
+        # descriptors: one per image without restart intervals; with them, a pixels-only parent + one entropy segment
+        # per interval (include/cama_hip.h)
+        parts, pieces, owner, broken = [], [], [], []
+        off = nd = 0
+        for i, (b, h) in enumerate(zip(blobs, headers)):
+            rec = np.zeros(1, IMAGE_DTYPE)
+            rec["width"], rec["height"], rec["ncomp"], rec["hs"], rec["vs"] = h.width, h.height, h.ncomp, h.hs, h.vs
+            rec["huff_set"], rec["quant_set"] = self._huff_id(h.huff), self._quant_id(h.quant)
+            rec["comp_dc"], rec["comp_ac"], rec["out_slot"] = h.comp_dc, h.comp_ac, i
+            if not h.restart_interval:
+                ln = h.scan_end - h.scan_start
+                rec["kind"], rec["stream_off"], rec["stream_len"] = KIND_WHOLE, off, ln
+                parts.append(rec)
+                pieces.append((off, b, h.scan_start, h.scan_end))
+                owner.append(np.full(1, i))
+                off = (off + ln + 64 + 15) & ~15
+                nd += 1
+                continue
+            segs = restart_segments(b, h)
+            rec["kind"] = KIND_PIXELS
+            if segs is None:
+                broken.append(i)                                   # marker count does not match: host decoder
+                parts.append(rec)
+                owner.append(np.full(1, i))
+                nd += 1
+                continue
+            s0, e0, mcu0, nmcu = (np.array(col, dtype=np.int64) for col in zip(*segs))
+            ln = e0 - s0
+            padded = (ln + 64 + 15) & ~15
+            offs = off + np.concatenate([[0], np.cumsum(padded)[:-1]])
+            seg = np.repeat(rec, len(segs))
+            seg["kind"], seg["parent"], seg["out_slot"] = KIND_SEGMENT, nd, 0
+            seg["first_block"] = mcu0 * (1 if h.ncomp == 1 else h.hs * h.vs + 2)
+            seg["width"], seg["height"] = nmcu * 8 * h.hs, 8 * h.vs
+            seg["stream_off"], seg["stream_len"] = offs, ln
+            parts += [rec, seg]
+            pieces.append((int(offs[0]), b, h.scan_start, h.scan_end, s0, e0, offs))
+            owner.append(np.full(1 + len(segs), i))
+            off += int(padded.sum())
+            nd += 1 + len(segs)
         stream_bytes = off + 64
+        imgs = np.concatenate(parts)
+        owner = np.concatenate(owner)
         if L["pinned"] is None or L["pinned"].numel() < stream_bytes:
             L["pinned"] = torch.empty(max(stream_bytes, 1 << 20), dtype=torch.uint8).pin_memory()
         host = L["pinned"].numpy()
-        for i, (b, h) in enumerate(zip(blobs, headers)):
-            o = int(imgs[i]["stream_off"])
-            host[o:o + int(imgs[i]["stream_len"])] = np.frombuffer(b, np.uint8, int(imgs[i]["stream_len"]), h.scan_start)
+        for piece in pieces:
+            if len(piece) == 4:
+                o, b, s0, e0 = piece
+                host[o:o + (e0 - s0)] = np.frombuffer(b, np.uint8, e0 - s0, s0)
+            else:                                                   # restart intervals: one copy per segment
+                _, b, _, _, s0, e0, offs = piece
+                src = np.frombuffer(b, np.uint8)
+                for a0, a1, o in zip(s0.tolist(), e0.tolist(), offs.tolist()):
+                    host[o:o + (a1 - a0)] = src[a0:a1]
         info = np.zeros(3, np.uint64)                      # cama_jpeg_plan_info: u64 scratch_bytes + 4 x u32
-        _lib.check(self.lib.cama_jpeg_plan(imgs.ctypes.data, n, stream_bytes, info.ctypes.data))
+        _lib.check(self.lib.cama_jpeg_plan(imgs.ctypes.data, nd, stream_bytes, info.ctypes.data))
         scratch_bytes = int(info[0])
         huff_dev, quant_dev = self._tables()               # (on the caller's stream: the lane waits for it below)
         contiguous = slots == list(range(slots[0], slots[0] + n))
@@ -324,21 +383,22 @@ class DeviceJpegDecoder:
                 L["scratch"] = None
                 L["scratch"] = torch.empty(scratch_bytes, dtype=torch.uint8, device=self.device)
             stream_dev = L["pinned"][:stream_bytes].to(self.device, non_blocking=True)
-            imgs_dev = torch.from_numpy(imgs.view(np.uint8).reshape(n, -1)).to(self.device, non_blocking=True)
-            status = torch.empty(n, dtype=torch.int32, device=self.device)
+            imgs_dev = torch.from_numpy(imgs.view(np.uint8).reshape(nd, -1)).to(self.device, non_blocking=True)
+            status = torch.empty(nd, dtype=torch.int32, device=self.device)
             target = out[slots[0]:slots[0] + n] if contiguous else \
                 torch.empty((n,) + tuple(out.shape[1:]), dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.cama_jpeg_decode(
-                stream_dev.data_ptr(), stream_bytes, imgs.ctypes.data, imgs_dev.data_ptr(), n, huff_dev.data_ptr(),
+                stream_dev.data_ptr(), stream_bytes, imgs.ctypes.data, imgs_dev.data_ptr(), nd, huff_dev.data_ptr(),
                 huff_dev.shape[0], quant_dev.data_ptr(), quant_dev.shape[0], target.data_ptr(), target.stride(0),
                 int(bool(bgr)), L["scratch"].data_ptr(), L["scratch"].numel(), status.data_ptr(), st.cuda_stream))
             if not contiguous:
                 out[torch.as_tensor(slots, device=self.device)] = target
-            if L["status"] is None or L["status"].numel() < n:
-                L["status"] = torch.empty(max(n, 256), dtype=torch.int32).pin_memory()
-            L["status"][:n].copy_(status, non_blocking=True)
+            if L["status"] is None or L["status"].numel() < nd:
+                L["status"] = torch.empty(max(nd, 256), dtype=torch.int32).pin_memory()
+            L["status"][:nd].copy_(status, non_blocking=True)
         # (no record_stream on `out`: _finish synchronises every lane before decode() returns)
-        return {"lane": L, "slots": slots, "n": n, "keep": (stream_dev, imgs_dev, status, target, imgs)}
+        return {"lane": L, "slots": slots, "n": nd, "owner": owner, "broken": broken,
+                "keep": (stream_dev, imgs_dev, status, target, imgs)}
 
     def _finish(self, ticket, out, cur):
         """Wait for a group; returns the slots the device flagged as inconsistent (to be decoded on the host)."""
@@ -347,7 +407,8 @@ class DeviceJpegDecoder:
         cur.wait_stream(st)
         bad = ticket["lane"]["status"][:ticket["n"]].numpy().copy()
         ticket["lane"]["busy"] = False
-        return [ticket["slots"][i] for i in np.flatnonzero(bad)]
+        local = {int(ticket["owner"][r]) for r in np.flatnonzero(bad)} | set(ticket["broken"])   # descriptor -> image
+        return [ticket["slots"][i] for i in sorted(local)]
 
 
 class PendingDecode:

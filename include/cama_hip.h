@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 3
+#define CAMA_ABI_VERSION 4
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -286,10 +286,10 @@ int cama_profile_collect(double *total_ms /* host */, int32_t *launches /* host 
  * still in place; every segment starts on a 16-byte boundary and is followed by >= 64 spare bytes), one descriptor
  * per image, the Huffman table sets (device layout: cama_jpeg_huff_set_bytes() each, built by the host from the DHT
  * segments) and the quantisation tables ([set][component 0..2][64] uint16, natural order).
- * Scope: SOF0, 8 bit, 1 or 3 components in one interleaved scan, luma sampling 1x1 / 2x1 / 2x2 with 1x1 chroma, no
- * restart intervals.  Everything else is the caller's host fallback.
+ * Scope: SOF0, 8 bit, 1 or 3 components in one interleaved scan, luma sampling 1x1 / 2x1 / 2x2 with 1x1 chroma,
+ * restart intervals through per-interval descriptors.  Everything else is the caller's host fallback.
  *   cama_jpeg_plan    fills the derived descriptor fields and reports grid sizes and scratch bytes (host only)
- *   cama_jpeg_decode  imgs_dev = device copy of the PLANNED descriptors; out [n] images of height*width*3 bytes,
+ *   cama_jpeg_decode  imgs_dev = device copy of the PLANNED descriptors; out: image `out_slot` of height*width*3 bytes,
  *                     out_stride bytes apart, BGR (bgr != 0: OpenCV order) or RGB; status [n] int32 on the device:
  *                     0 ok, != 0 the stream did not decode consistently (corrupt or unsupported): use the host
  *                     decoder for that image
@@ -307,8 +307,18 @@ typedef struct cama_jpeg_image {
     uint32_t mx, my, bpm, total_blocks;                 /* [plan] MCU grid, blocks per MCU, blocks in the scan */
     uint32_t wg0, nwg, tile0, ntile;                    /* [plan] decode workgroups / unstuff tiles of this image */
     uint32_t plane_w[3], plane_h[3];                    /* [plan] padded component planes */
-    uint32_t reserved[2];
+    /* Restart intervals (DRI): the image becomes one CAMA_JPEG_PIXELS descriptor (geometry, tables, planes, output;
+     * stream_len = 0) followed by one CAMA_JPEG_SEGMENT descriptor per restart interval (its bytes between two RSTn
+     * markers; width = MCUs in the interval * 8 * hs, height = 8 * vs, so that mx = MCU count, my = 1), which only
+     * takes part in the entropy stages and writes into the parent's coefficients from block `first_block` on. */
+    uint32_t kind;              /* CAMA_JPEG_WHOLE / _SEGMENT / _PIXELS */
+    uint32_t parent;            /* _SEGMENT: index of its _PIXELS descriptor (earlier in the array) */
+    uint32_t first_block;       /* _SEGMENT: first scan-order block of the interval */
+    uint32_t out_slot;          /* _WHOLE / _PIXELS: image index in `out` */
 } cama_jpeg_image;
+#define CAMA_JPEG_WHOLE   0
+#define CAMA_JPEG_SEGMENT 1
+#define CAMA_JPEG_PIXELS  2
 
 typedef struct cama_jpeg_plan_info {
     uint64_t scratch_bytes;

@@ -45,10 +45,34 @@ def test_grey_optimised_tables_and_mixed_batch(dec):
         assert np.array_equal(got[k], pillow_rgb(b)), k
 
 
+def test_restart_intervals_decode_on_the_device(dec):
+    """DRI files: every restart interval is its own entropy segment (exact start state, DC predictors reset)."""
+    rng = np.random.default_rng(4)
+    blobs = []
+    for (h, w) in [(64, 96), (203, 317), (33, 47)]:
+        img = synth_image(h, w, "noise", seed=h)
+        img[:, :w // 2] = synth_image(h, w // 2, "smooth")
+        for sub in (0, 1, 2):
+            for kw in (dict(restart_marker_blocks=1), dict(restart_marker_blocks=5), dict(restart_marker_rows=1),
+                       dict(restart_marker_rows=2, optimize=True)):
+                blobs.append((h, w, encode(img, quality=int(rng.integers(30, 100)), subsampling=sub, **kw)))
+    before = dict(dec.stats)
+    for (h, w) in [(64, 96), (203, 317), (33, 47)]:
+        group = [b for (hh, ww, b) in blobs if (hh, ww) == (h, w)] + [encode(synth_image(h, w, "edges"), quality=80)]
+        got = dec.decode(group, bgr=False).cpu().numpy()
+        for k, b in enumerate(group):
+            assert np.array_equal(got[k], pillow_rgb(b)), (h, w, k)
+    assert dec.stats["device"] - before["device"] == len(blobs) + 3 and dec.stats["host_flagged"] == before["host_flagged"]
+    big = encode(synth_image(900, 1600, "noise", seed=1), quality=90, restart_marker_rows=1)
+    got = dec.decode([big], bgr=False).cpu().numpy()
+    assert np.array_equal(got[0], pillow_rgb(big)) and dec.stats["host_flagged"] == before["host_flagged"]
+
+
 def test_files_outside_the_device_scope_fall_back_to_the_host(dec):
     img = synth_image(64, 96, "smooth")
-    blobs = [encode(img, quality=90, progressive=True), encode(img, quality=90, restart_marker_blocks=2),
-             encode(img, quality=90)]
+    cmyk = io.BytesIO()
+    Image.fromarray(img).convert("CMYK").save(cmyk, format="JPEG")
+    blobs = [encode(img, quality=90, progressive=True), cmyk.getvalue(), encode(img, quality=90)]
     before = dict(dec.stats)
     got = dec.decode(blobs, bgr=False).cpu().numpy()
     assert dec.stats["host_unsupported"] - before["host_unsupported"] == 2
@@ -126,11 +150,17 @@ def test_fuzz_random_images_sizes_and_encoder_settings(dec):
             else:
                 img = synth_image(h, w, str(kind), seed=int(rng.integers(1 << 30)))
             kw = dict(quality=int(rng.integers(1, 101)), optimize=bool(rng.random() < 0.3))
+            r = rng.random()
+            if r < 0.15:
+                kw["restart_marker_blocks"] = int(rng.integers(1, 40))
+            elif r < 0.3:
+                kw["restart_marker_rows"] = int(rng.integers(1, 4))
             grey, sub = rng.random() < 0.15, int(rng.integers(0, 3))
             try:
                 blobs.append(encode(img[..., 0], **kw) if grey else encode(img, subsampling=sub, **kw))
             except OSError:                          # Pillow's ENCODER gives up on some optimize + size combinations
                 kw["optimize"] = False
+                kw.pop("restart_marker_blocks", None)
                 blobs.append(encode(img[..., 0], **kw) if grey else encode(img, subsampling=sub, **kw))
         got = dec.decode(blobs, bgr=False).cpu().numpy()
         total += len(blobs)

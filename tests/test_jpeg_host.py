@@ -53,20 +53,30 @@ def test_header_and_tables_agree_with_the_oracle(kw):
 
 def test_scope_checks():
     img = synth_image(32, 48, "smooth")
-    for bad in (encode(img, progressive=True), encode(img, restart_marker_blocks=1), b"not a jpeg"):
+    for bad in (encode(img, progressive=True), b"not a jpeg"):
         with pytest.raises(PJ.Unsupported):
             PJ.parse_header(bad)
+    # restart intervals: one entropy segment per interval, the markers themselves excluded
+    data = encode(img, restart_marker_blocks=2, subsampling=2)
+    h = PJ.parse_header(data)
+    segs = PJ.restart_segments(data, h)
+    assert h.restart_interval == 2 and len(segs) == 3 and [s[2:] for s in segs] == [(0, 2), (2, 2), (4, 2)]
+    ref_scan = J.parse(data)["scan"]
+    joined = b"".join(data[a:b] + (b"" if k == len(segs) - 1 else ref_scan[b - h.scan_start:b - h.scan_start + 2])
+                      for k, (a, b, _, _) in enumerate(segs))
+    assert joined == ref_scan and all(ref_scan[b - h.scan_start] == 0xFF for (_, b, _, _) in segs[:-1])
 
 
 def test_descriptor_layout_and_plan():
     L = _lib.lib()
-    assert PJ.IMAGE_DTYPE.itemsize == L.cama_jpeg_image_bytes() == 160
+    assert PJ.IMAGE_DTYPE.itemsize == L.cama_jpeg_image_bytes() == 168
     imgs = np.zeros(2, PJ.IMAGE_DTYPE)
     for i, (w, h, hs, vs, ln) in enumerate([(1600, 900, 2, 2, 300000), (33, 17, 2, 1, 700)]):
         d = imgs[i]
         d["stream_off"], d["stream_len"] = (0 if i == 0 else 300080), ln
         d["width"], d["height"], d["ncomp"], d["hs"], d["vs"] = w, h, 3, hs, vs
         d["comp_dc"], d["comp_ac"] = [0, 1, 1], [0, 1, 1]
+        d["out_slot"] = i
     info = np.zeros(3, np.uint64)
     assert L.cama_jpeg_plan(imgs.ctypes.data, 2, 300080 + 700 + 64, info.ctypes.data) == 0, L.cama_last_error()
     a, b = imgs[0], imgs[1]
@@ -81,3 +91,26 @@ def test_descriptor_layout_and_plan():
     imgs[1]["vs"] = 1
     imgs[1]["stream_off"] = 16
     assert L.cama_jpeg_plan(imgs.ctypes.data, 2, 400000, info.ctypes.data) == -1
+
+
+def test_plan_restart_interval_descriptors():
+    """A pixels-only parent + one entropy segment per restart interval: segments write into the parent's coefficient
+    block range and own no planes; the parent owns no workgroups."""
+    L = _lib.lib()
+    imgs = np.zeros(4, PJ.IMAGE_DTYPE)
+    common = dict(ncomp=3, hs=2, vs=2, comp_dc=[0, 1, 1], comp_ac=[0, 1, 1])
+    rows = [dict(common, kind=PJ.KIND_PIXELS, width=64, height=32, out_slot=0),
+            dict(common, kind=PJ.KIND_SEGMENT, parent=0, first_block=0, width=3 * 16, height=16, stream_off=0, stream_len=500),
+            dict(common, kind=PJ.KIND_SEGMENT, parent=0, first_block=18, width=3 * 16, height=16, stream_off=576, stream_len=300),
+            dict(common, kind=PJ.KIND_SEGMENT, parent=0, first_block=36, width=2 * 16, height=16, stream_off=960, stream_len=900)]
+    for r, row in enumerate(rows):
+        for k, v in row.items():
+            imgs[r][k] = v
+    info = np.zeros(3, np.uint64)
+    assert L.cama_jpeg_plan(imgs.ctypes.data, 4, 2048, info.ctypes.data) == 0, L.cama_last_error()
+    assert imgs[0]["total_blocks"] == 4 * 2 * 6 and imgs[0]["nwg"] == 0 and imgs[0]["plane_w"][0] == 64
+    assert [int(d["total_blocks"]) for d in imgs[1:]] == [18, 18, 12]
+    assert [int(d["coef_off"]) for d in imgs[1:]] == [int(imgs[0]["coef_off"]) + 64 * b for b in (0, 18, 36)]
+    assert all(d["plane_w"][0] == 0 for d in imgs[1:]) and [int(d["wg0"]) for d in imgs] == [0, 0, 1, 2]
+    imgs[3]["first_block"] = 40                               # would run past the parent's blocks
+    assert L.cama_jpeg_plan(imgs.ctypes.data, 4, 2048, info.ctypes.data) == -1 and b"parent" in L.cama_last_error()

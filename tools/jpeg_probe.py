@@ -9,6 +9,7 @@ from cama_amd.jpeg import DeviceJpegDecoder
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=6)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--restart-rows", type=int, default=0, help="encode with a restart interval of this many MCU rows")
 ap.add_argument("--lanes", type=int, default=4)
 ap.add_argument("--min-group", type=int, default=24)
 a = ap.parse_args()
@@ -18,7 +19,8 @@ base = np.stack([(x * 0.16 + 20 * np.sin(y / 30)) % 256, (y * 0.28) % 256, ((x +
 
 
 def enc(im, q=90):
-    b = io.BytesIO(); Image.fromarray(im).save(b, format="JPEG", quality=q); return b.getvalue()
+    kw = dict(restart_marker_rows=a.restart_rows) if a.restart_rows else {}
+    b = io.BytesIO(); Image.fromarray(im).save(b, format="JPEG", quality=q, **kw); return b.getvalue()
 
 
 sets = {"noise": [enc(rng.integers(0, 256, (900, 1600, 3), dtype=np.uint8)) for _ in range(a.batch)],
