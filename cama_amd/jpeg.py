@@ -230,6 +230,7 @@ class DeviceJpegDecoder:
         self.lanes = int(lanes)
         self.min_group = int(min_group)
         self._lane = []
+        self._templates = {}
         self.stats = {"device": 0, "host_unsupported": 0, "host_flagged": 0}
 
     # ------------------------------------------------------------------ table caches (device copies grow on demand)
@@ -250,6 +251,21 @@ class DeviceJpegDecoder:
             self._quant_host.append(quant.copy())
             self._quant_dev = None
         return idx
+
+    def _template(self, h):
+        """Descriptor with everything that comes from the header filled in; cached per parsed header (the frames of a
+        camera share one: parse_header hands out copies that reference the same table objects)."""
+        key = (id(h.huff), id(h.quant), h.width, h.height)
+        hit = self._templates.get(key)
+        if hit is None or hit[0] is not h.huff:
+            rec = np.zeros(1, IMAGE_DTYPE)
+            rec["width"], rec["height"], rec["ncomp"], rec["hs"], rec["vs"] = h.width, h.height, h.ncomp, h.hs, h.vs
+            rec["huff_set"], rec["quant_set"] = self._huff_id(h.huff), self._quant_id(h.quant)
+            rec["comp_dc"], rec["comp_ac"] = h.comp_dc, h.comp_ac
+            if len(self._templates) > 256:
+                self._templates.clear()
+            hit = self._templates[key] = (h.huff, rec)
+        return hit[1]
 
     def _tables(self):
         import torch
@@ -320,20 +336,30 @@ class DeviceJpegDecoder:
         # per interval (include/cama_hip.h)
         parts, pieces, owner, broken = [], [], [], []
         off = nd = 0
+        # images without restart intervals first, as one vectorised block of descriptors
+        whole = [i for i, h in enumerate(headers) if not h.restart_interval]
+        if whole:
+            lens = np.array([headers[i].scan_end - headers[i].scan_start for i in whole], dtype=np.int64)
+            padded = (lens + 64 + 15) & ~15
+            offs = np.concatenate([[0], np.cumsum(padded)[:-1]])
+            tmpl = [self._template(headers[i]) for i in whole]
+            if all(t is tmpl[0] for t in tmpl):                  # one camera model: the usual case
+                blk = np.repeat(tmpl[0], len(whole))
+            else:                                                # (np.concatenate on structured arrays is slow)
+                blk = np.empty(len(whole), IMAGE_DTYPE)
+                for k, t in enumerate(tmpl):
+                    blk[k] = t[0]
+            blk["kind"], blk["out_slot"], blk["stream_off"], blk["stream_len"] = KIND_WHOLE, whole, offs, lens
+            parts.append(blk)
+            owner.append(np.asarray(whole))
+            pieces += [(int(o), blobs[i], headers[i].scan_start, headers[i].scan_end) for o, i in zip(offs.tolist(), whole)]
+            off = int(padded.sum())
+            nd = len(whole)
         for i, (b, h) in enumerate(zip(blobs, headers)):
-            rec = np.zeros(1, IMAGE_DTYPE)
-            rec["width"], rec["height"], rec["ncomp"], rec["hs"], rec["vs"] = h.width, h.height, h.ncomp, h.hs, h.vs
-            rec["huff_set"], rec["quant_set"] = self._huff_id(h.huff), self._quant_id(h.quant)
-            rec["comp_dc"], rec["comp_ac"], rec["out_slot"] = h.comp_dc, h.comp_ac, i
             if not h.restart_interval:
-                ln = h.scan_end - h.scan_start
-                rec["kind"], rec["stream_off"], rec["stream_len"] = KIND_WHOLE, off, ln
-                parts.append(rec)
-                pieces.append((off, b, h.scan_start, h.scan_end))
-                owner.append(np.full(1, i))
-                off = (off + ln + 64 + 15) & ~15
-                nd += 1
                 continue
+            rec = self._template(h).copy()
+            rec["out_slot"] = i
             segs = restart_segments(b, h)
             rec["kind"] = KIND_PIXELS
             if segs is None:
@@ -357,7 +383,14 @@ class DeviceJpegDecoder:
             off += int(padded.sum())
             nd += 1 + len(segs)
         stream_bytes = off + 64
-        imgs = np.concatenate(parts)
+        if len(parts) == 1:
+            imgs = parts[0]
+        else:
+            imgs = np.empty(nd, IMAGE_DTYPE)
+            at = 0
+            for part in parts:
+                imgs[at:at + len(part)] = part
+                at += len(part)
         owner = np.concatenate(owner)
         if L["pinned"] is None or L["pinned"].numel() < stream_bytes:
             L["pinned"] = torch.empty(max(stream_bytes, 1 << 20), dtype=torch.uint8).pin_memory()
