@@ -51,7 +51,9 @@ class VideoGenerator:
         return np.concatenate(rows, axis=0)
 
     def add_frame(self, image):
-        self.writer.stdin.write(image.astype(np.uint8).tobytes())
+        """Raw BGR24 bytes of the mosaic into the encoder's pipe (tools.py:28-32 writes image.astype(uint8).tobytes():
+        the same bytes; a contiguous uint8 array goes out through the buffer protocol without the two 9 MB copies)."""
+        self.writer.stdin.write(memoryview(np.ascontiguousarray(image, dtype=np.uint8)).cast("B"))
 
     def add_frame_from_dict(self, image_dict):
         self.add_frame(self.concate_image(image_dict))

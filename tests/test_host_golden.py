@@ -228,3 +228,27 @@ def test_dataset_reader_image_iterators(tmp_path):
     assert len(segs) == 1 and segs[0][0] == stamps[1] / 1000.0 and np.array_equal(segs[0][1], lab)
     Image.fromarray(rgb).save(tmp_path / "seg_camera_front" / f"{stamps[0]}.png")
     assert np.array_equal(next(dr.yield_semantic("camera_front"))[1], rgb[..., ::-1])
+
+
+def test_add_frame_pipes_the_reference_bytes():
+    """VideoGenerator.add_frame writes exactly image.astype(uint8).tobytes() (tools.py:28-32), zero-copy when it can."""
+    class _Pipe:
+        def __init__(self):
+            self.data = b""
+
+        def write(self, b):
+            self.data += bytes(b)
+
+    class _Writer:
+        stdin = _Pipe()
+
+    vg = object.__new__(VideoGenerator)
+    vg.writer = _Writer()
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (6, 8, 3), dtype=np.uint8)
+    want = b""
+    for img in (a, a[:, ::2], a.astype(np.int64)):
+        vg.add_frame(img)
+        want += img.astype(np.uint8).tobytes()
+    assert _Writer.stdin.data == want
+    vg.writer = None

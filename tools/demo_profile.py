@@ -1,5 +1,6 @@
 import os, sys, time, tempfile, cProfile, pstats
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
 import torch
 from cama.dataset import ClipManager
 from cama.tools import VideoGenerator
@@ -16,7 +17,7 @@ def loop():
         maps_2d_dict = cm.project_all_camera(instance_map)
         image_dict = cm.render_vectors(maps_2d_dict, image_idx)
         image = vg.concate_image(image_dict)
-        image.astype("uint8").tobytes() if hasattr(image, "astype") else None
+        memoryview(np.ascontiguousarray(image, dtype=np.uint8)).cast("B")      # what VideoGenerator.add_frame pipes out
         n += 1
     return n
 loop()
