@@ -150,6 +150,7 @@ class ClipFrameSource:
         assert self.decoder in ("device", "host")
         self._jpeg = None
         self._ahead = {}                                              # tuple(image indices) -> PendingDecode
+        self._decode_depth = 2                                        # batches decoded ahead of the consumer
         self._pool = None
         # host decode: 12 threads peak (~500 images/s; the GIL beyond that).  Device decode: the workers only read
         # files, a few are enough (more just burn the container's CPU quota)
@@ -247,16 +248,25 @@ class ClipFrameSource:
         side streams: the decode kernels are latency-bound and leave most of the GPU idle, so the next frame's decode
         runs under the current frame's host work and overlay."""
         step = len(image_indices)
-        nxt = [i + step for i in image_indices]
-        for stale in [k for k in self._ahead if k != tuple(nxt)]:
-            self._ahead.pop(stale).result()                              # release its lanes
-        if nxt[-1] >= self._n_frames() or tuple(nxt) in self._ahead or image_indices != list(range(image_indices[0], image_indices[0] + step)):
+        if image_indices != list(range(image_indices[0], image_indices[0] + step)):
             return
-        items = self._collect(nxt)
-        if all(isinstance(arr, (bytes, bytearray)) for _, _, arr, _ in items):
-            self._ahead[tuple(nxt)] = self._jpeg.decode_async([arr for _, _, arr, _ in items], bgr=True)
-        else:                                                            # mixed sources: leave them to the normal path
-            self._requeue(nxt, items)
+        wanted = []
+        for d in range(1, self._decode_depth + 1):                       # the next `depth` batches
+            nxt = [i + d * step for i in image_indices]
+            if nxt[-1] >= self._n_frames():
+                break
+            wanted.append(tuple(nxt))
+        for stale in [k for k in self._ahead if k not in wanted]:
+            self._ahead.pop(stale).result()                              # release its lanes
+        for key in wanted:
+            if key in self._ahead:
+                continue
+            items = self._collect(list(key))
+            if all(isinstance(arr, (bytes, bytearray)) for _, _, arr, _ in items):
+                self._ahead[key] = self._jpeg.decode_async([arr for _, _, arr, _ in items], bgr=True)
+            else:                                                        # mixed sources: leave them to the normal path
+                self._requeue(list(key), items)
+                break
 
     def _requeue(self, idx, items):
         from concurrent.futures import Future
