@@ -10,7 +10,7 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _u64 = ctypes.c_uint64

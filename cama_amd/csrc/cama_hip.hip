@@ -796,7 +796,7 @@ int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n, uin
 // ------------------------------------------------------------------------------------------ device JPEG decode
 struct JpegLayout {
     size_t clean, tile_count, tile_base, nbits, E, nb, wg_total, coef, planes, total;
-    size_t coef_elems, plane_bytes;
+    size_t coef_elems, plane_bytes, clean_bytes;
     uint32_t total_wgs, total_tiles, max_blocks;
 };
 
@@ -806,8 +806,7 @@ static int jpeg_layout(cama_jpeg_image *imgs, const cama_jpeg_image *cimgs, int3
 {
     if (n < 1 || n > 65535) return fail(CAMA_EINVAL, "n=%d images out of range [1, 65535]", n);
     uint32_t wg = 0, tile = 0, max_blocks = 0;
-    size_t coef = 0, planes = 0;
-    uint64_t prev_end = 0;
+    size_t coef = 0, planes = 0, clean = 0;
     std::vector<cama_jpeg_image> planned((size_t)n);
     for (int i = 0; i < n; ++i) {
         const cama_jpeg_image &D = cimgs[i];
@@ -821,15 +820,15 @@ static int jpeg_layout(cama_jpeg_image *imgs, const cama_jpeg_image *cimgs, int3
             if (D.comp_dc[c] > 1 || D.comp_ac[c] > 1) return fail(CAMA_EINVAL, "image %d: Huffman selector > 1", i);
         const bool has_stream = D.kind != CAMA_JPEG_PIXELS, has_pixels = D.kind != CAMA_JPEG_SEGMENT;
         if (has_stream) {
-            if (D.stream_off % 16 || D.stream_off < prev_end || D.stream_len < 1 || D.stream_len > (1u << 29) ||
-                D.stream_off + D.stream_len + 64 > stream_bytes)
-                return fail(CAMA_EINVAL, "image %d: segment [%llu, +%u) not 16-aligned / overlapping / without 64 spare bytes",
-                            i, (unsigned long long)D.stream_off, D.stream_len);
-            prev_end = D.stream_off + D.stream_len + 64;
+            if (D.stream_len < 1 || D.stream_len > (1u << 29) || D.stream_off + D.stream_len > stream_bytes)
+                return fail(CAMA_EINVAL, "image %d: segment [%llu, +%u) outside the %llu stream bytes", i,
+                            (unsigned long long)D.stream_off, D.stream_len, (unsigned long long)stream_bytes);
         } else if (D.stream_len != 0) {
             return fail(CAMA_EINVAL, "image %d: a pixels-only descriptor carries no stream", i);
         }
         cama_jpeg_image W = D;
+        W.clean_off = has_stream ? clean : 0;
+        if (has_stream) clean += align_up((size_t)D.stream_len + 64, 16);   // zero slack after every unstuffed segment
         W.mx = (D.width + 8 * D.hs - 1) / (8 * D.hs);
         W.my = (D.height + 8 * D.vs - 1) / (8 * D.vs);
         W.bpm = D.ncomp == 1 ? 1u : D.hs * D.vs + 2u;
@@ -873,9 +872,9 @@ static int jpeg_layout(cama_jpeg_image *imgs, const cama_jpeg_image *cimgs, int3
             return fail(CAMA_EINVAL, "image %d: descriptor was not produced by cama_jpeg_plan()", i);
     }
     L.total_wgs = wg; L.total_tiles = tile; L.max_blocks = max_blocks;
-    L.coef_elems = coef; L.plane_bytes = planes;
+    L.coef_elems = coef; L.plane_bytes = planes; L.clean_bytes = clean + 64;
     size_t off = 0;
-    L.clean = off;      off = align_up(off + (size_t)stream_bytes + 64, 256);
+    L.clean = off;      off = align_up(off + clean + 64, 256);
     L.tile_count = off; off = align_up(off + (size_t)tile * 4, 256);
     L.tile_base = off;  off = align_up(off + (size_t)tile * 4, 256);
     L.nbits = off;      off = align_up(off + (size_t)n * 4, 256);
@@ -926,8 +925,8 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
             maxh = std::max(maxh, imgs[i].height);
         }
     }
-    if ((uintptr_t)stream % 16 || (uintptr_t)scratch % 256 || (uintptr_t)huff_sets % 16)
-        return fail(CAMA_EINVAL, "stream / huff_sets must be 16-byte and scratch 256-byte aligned");
+    if ((uintptr_t)scratch % 256 || (uintptr_t)huff_sets % 16)
+        return fail(CAMA_EINVAL, "huff_sets must be 16-byte and scratch 256-byte aligned");
     hipStream_t s = (hipStream_t)stream_handle;
     char *base = (char *)scratch;
     JpegArgs a{};
@@ -938,7 +937,7 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
     a.wg_total = (uint32_t *)(base + L.wg_total); a.coef = (int16_t *)(base + L.coef);
     a.planes = (uint8_t *)(base + L.planes); a.out = out; a.out_stride = (size_t)out_stride; a.bgr = bgr;
     a.status = status;
-    HIP_TRY(hipMemsetAsync(a.clean, 0, (size_t)stream_bytes + 64, s));
+    HIP_TRY(hipMemsetAsync(a.clean, 0, L.clean_bytes, s));
     HIP_TRY(hipMemsetAsync(a.coef, 0, L.coef_elems * 2, s));
     HIP_TRY(hipMemsetAsync(status, 0, (size_t)n * 4, s));
     if (L.total_tiles) hipLaunchKernelGGL(k_jpeg_count, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);

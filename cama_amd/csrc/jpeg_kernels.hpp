@@ -155,7 +155,7 @@ __global__ __launch_bounds__(JPEG_TILE / 4) void k_jpeg_unstuff(JpegArgs a)
     __syncthreads();
     uint32_t before = a.tile_base[blockIdx.x] + incl - c;
     for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += s_w[w];
-    uint8_t *dst = a.clean + D.stream_off;
+    uint8_t *dst = a.clean + D.clean_off;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t i = i0 + k;
@@ -328,9 +328,9 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
     const uint4 *src = reinterpret_cast<const uint4 *>(a.huff + D.huff_set);
     uint4 *dst = reinterpret_cast<uint4 *>(&S.H);
     for (uint32_t i = threadIdx.x; i < sizeof(JpegHuffSet) / 16; i += JPEG_WG) dst[i] = src[i];
-    // stream: dwords [lw*256*32, +256*32 + 2) of the unstuffed segment (stream_off is 16-byte aligned; the region
+    // stream: dwords [lw*256*32, +256*32 + 2) of the unstuffed segment (clean_off is 16-byte aligned; the region
     // past the segment is zero: the clean buffer is cleared per batch)
-    const uint32_t *g = reinterpret_cast<const uint32_t *>(a.clean + D.stream_off);
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(a.clean + D.clean_off);
     const uint32_t w0 = lw * JPEG_WG * JPEG_SUB_WORDS;
     const uint32_t nwords_img = (D.stream_len + 3u) / 4u + 8u;          // slack words exist (plan pads every segment)
     for (uint32_t i = threadIdx.x; i < JPEG_WG * JPEG_SUB_WORDS + 8; i += JPEG_WG) {

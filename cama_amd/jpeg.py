@@ -17,7 +17,7 @@ import numpy as np
 from . import _lib
 
 IMAGE_DTYPE = np.dtype([
-    ("stream_off", "<u8"), ("coef_off", "<u8"), ("plane_off", "<u8", (3,)),
+    ("stream_off", "<u8"), ("clean_off", "<u8"), ("coef_off", "<u8"), ("plane_off", "<u8", (3,)),
     ("stream_len", "<u4"), ("width", "<u4"), ("height", "<u4"), ("ncomp", "<u4"), ("hs", "<u4"), ("vs", "<u4"),
     ("huff_set", "<u4"), ("quant_set", "<u4"), ("comp_dc", "<u4", (3,)), ("comp_ac", "<u4", (3,)),
     ("mx", "<u4"), ("my", "<u4"), ("bpm", "<u4"), ("total_blocks", "<u4"),
@@ -184,23 +184,27 @@ def build_huff_set(huff):
     return rec
 
 
+_RST = [bytes((0xFF, 0xD0 + k)) for k in range(8)]
+
+
 def restart_segments(data, h):
-    """[(start, end, first_mcu, n_mcu)] byte ranges of the restart intervals of the scan (T.81 B.2.1: RSTm markers
-    between them), or None when their number does not match the frame (corrupt: leave it to the host decoder)."""
-    a = np.frombuffer(data, np.uint8, h.scan_end - h.scan_start, h.scan_start)
-    ff = np.flatnonzero(a[:-1] == 0xFF)
-    nxt = a[ff + 1]
-    rst = ff[(nxt >= 0xD0) & (nxt <= 0xD7)]
+    """[(start, end, first_mcu, n_mcu)] byte ranges of the restart intervals of the scan (T.81 B.2.1: the markers
+    RST0..RST7 cycle between them; 0xFF 0xDk cannot occur inside entropy-coded data), or None when their number does
+    not match the frame (corrupt: leave it to the host decoder)."""
     mcus = -(-h.width // (8 * h.hs)) * -(-h.height // (8 * h.vs))
     ri = h.restart_interval
-    if len(rst) + 1 != -(-mcus // ri):
+    nseg = -(-mcus // ri)
+    pos, segs = h.scan_start, []
+    for k in range(nseg - 1):
+        m = data.find(_RST[k & 7], pos, h.scan_end)
+        if m <= pos:
+            return None
+        segs.append((pos, m, k * ri, ri))
+        pos = m + 2
+    if pos >= h.scan_end or any(data.find(r, pos, h.scan_end) >= 0 for r in _RST):
         return None
-    starts = np.concatenate([[0], rst + 2])
-    ends = np.concatenate([rst, [len(a)]])
-    if np.any(ends <= starts):
-        return None
-    return [(h.scan_start + int(s0), h.scan_start + int(e0), k * ri, min(ri, mcus - k * ri))
-            for k, (s0, e0) in enumerate(zip(starts, ends))]
+    segs.append((pos, h.scan_end, (nseg - 1) * ri, mcus - (nseg - 1) * ri))
+    return segs
 
 
 def _host_decode(data, bgr):
@@ -334,14 +338,21 @@ class DeviceJpegDecoder:
         n = len(blobs)
         # descriptors: one per image without restart intervals; with them, a pixels-only parent + one entropy segment
         # per interval (include/cama_hip.h)
-        parts, pieces, owner, broken = [], [], [], []
-        off = nd = 0
-        # images without restart intervals first, as one vectorised block of descriptors
+        parts, owner, broken = [], [], []
+        nd = 0
+        # the scans go into the staging buffer back to back (no alignment needed: descriptors point into it, the
+        # library lays out its own aligned unstuffed copies)
+        lens = np.array([h.scan_end - h.scan_start for h in headers], dtype=np.int64)
+        base = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        stream_bytes = int(lens.sum())
+        if L["pinned"] is None or L["pinned"].numel() < stream_bytes:
+            L["pinned"] = torch.empty(max(stream_bytes, 1 << 20), dtype=torch.uint8).pin_memory()
+        host = L["pinned"].numpy()
+        for o, ln, b, h in zip(base.tolist(), lens.tolist(), blobs, headers):
+            host[o:o + ln] = np.frombuffer(b, np.uint8, ln, h.scan_start)
+        # descriptors: images without restart intervals first, as one vectorised block
         whole = [i for i, h in enumerate(headers) if not h.restart_interval]
         if whole:
-            lens = np.array([headers[i].scan_end - headers[i].scan_start for i in whole], dtype=np.int64)
-            padded = (lens + 64 + 15) & ~15
-            offs = np.concatenate([[0], np.cumsum(padded)[:-1]])
             tmpl = [self._template(headers[i]) for i in whole]
             if all(t is tmpl[0] for t in tmpl):                  # one camera model: the usual case
                 blk = np.repeat(tmpl[0], len(whole))
@@ -349,12 +360,11 @@ class DeviceJpegDecoder:
                 blk = np.empty(len(whole), IMAGE_DTYPE)
                 for k, t in enumerate(tmpl):
                     blk[k] = t[0]
-            blk["kind"], blk["out_slot"], blk["stream_off"], blk["stream_len"] = KIND_WHOLE, whole, offs, lens
+            blk["kind"], blk["out_slot"], blk["stream_off"], blk["stream_len"] = KIND_WHOLE, whole, base[whole], lens[whole]
             parts.append(blk)
             owner.append(np.asarray(whole))
-            pieces += [(int(o), blobs[i], headers[i].scan_start, headers[i].scan_end) for o, i in zip(offs.tolist(), whole)]
-            off = int(padded.sum())
             nd = len(whole)
+        # restart intervals: a pixels-only parent + one entropy segment per interval, all pointing into the one scan copy
         for i, (b, h) in enumerate(zip(blobs, headers)):
             if not h.restart_interval:
                 continue
@@ -369,20 +379,14 @@ class DeviceJpegDecoder:
                 nd += 1
                 continue
             s0, e0, mcu0, nmcu = (np.array(col, dtype=np.int64) for col in zip(*segs))
-            ln = e0 - s0
-            padded = (ln + 64 + 15) & ~15
-            offs = off + np.concatenate([[0], np.cumsum(padded)[:-1]])
             seg = np.repeat(rec, len(segs))
             seg["kind"], seg["parent"], seg["out_slot"] = KIND_SEGMENT, nd, 0
             seg["first_block"] = mcu0 * (1 if h.ncomp == 1 else h.hs * h.vs + 2)
             seg["width"], seg["height"] = nmcu * 8 * h.hs, 8 * h.vs
-            seg["stream_off"], seg["stream_len"] = offs, ln
+            seg["stream_off"], seg["stream_len"] = int(base[i]) + (s0 - h.scan_start), e0 - s0
             parts += [rec, seg]
-            pieces.append((int(offs[0]), b, h.scan_start, h.scan_end, s0, e0, offs))
             owner.append(np.full(1 + len(segs), i))
-            off += int(padded.sum())
             nd += 1 + len(segs)
-        stream_bytes = off + 64
         if len(parts) == 1:
             imgs = parts[0]
         else:
@@ -392,18 +396,6 @@ class DeviceJpegDecoder:
                 imgs[at:at + len(part)] = part
                 at += len(part)
         owner = np.concatenate(owner)
-        if L["pinned"] is None or L["pinned"].numel() < stream_bytes:
-            L["pinned"] = torch.empty(max(stream_bytes, 1 << 20), dtype=torch.uint8).pin_memory()
-        host = L["pinned"].numpy()
-        for piece in pieces:
-            if len(piece) == 4:
-                o, b, s0, e0 = piece
-                host[o:o + (e0 - s0)] = np.frombuffer(b, np.uint8, e0 - s0, s0)
-            else:                                                   # restart intervals: one copy per segment
-                _, b, _, _, s0, e0, offs = piece
-                src = np.frombuffer(b, np.uint8)
-                for a0, a1, o in zip(s0.tolist(), e0.tolist(), offs.tolist()):
-                    host[o:o + (a1 - a0)] = src[a0:a1]
         info = np.zeros(3, np.uint64)                      # cama_jpeg_plan_info: u64 scratch_bytes + 4 x u32
         _lib.check(self.lib.cama_jpeg_plan(imgs.ctypes.data, nd, stream_bytes, info.ctypes.data))
         scratch_bytes = int(info[0])

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 4
+#define CAMA_ABI_VERSION 5
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -282,8 +282,8 @@ int cama_profile_collect(double *total_ms /* host */, int32_t *launches /* host 
  * do with libjpeg(-turbo) on one host core per image.  Output is byte-identical to libjpeg-turbo's default decode
  * (islow IDCT, fancy upsampling; oracle/jpeg_oracle.py pins it to Pillow's bundled libjpeg-turbo).
  *
- * The host parses the markers (cama_amd/jpeg.py) and uploads: the concatenated entropy-coded segments (byte stuffing
- * still in place; every segment starts on a 16-byte boundary and is followed by >= 64 spare bytes), one descriptor
+ * The host parses the markers (cama_amd/jpeg.py) and uploads: the bytes that hold the entropy-coded segments (whole
+ * files are fine: a descriptor points at its segment, byte stuffing still in place, any alignment), one descriptor
  * per image, the Huffman table sets (device layout: cama_jpeg_huff_set_bytes() each, built by the host from the DHT
  * segments) and the quantisation tables ([set][component 0..2][64] uint16, natural order).
  * Scope: SOF0, 8 bit, 1 or 3 components in one interleaved scan, luma sampling 1x1 / 2x1 / 2x2 with 1x1 chroma,
@@ -295,7 +295,8 @@ int cama_profile_collect(double *total_ms /* host */, int32_t *launches /* host 
  *                     decoder for that image
  */
 typedef struct cama_jpeg_image {
-    uint64_t stream_off;        /* byte offset of the entropy-coded segment in `stream`, multiple of 16 */
+    uint64_t stream_off;        /* byte offset of the entropy-coded segment in `stream` (any alignment) */
+    uint64_t clean_off;         /* [plan] byte offset of its unstuffed copy in the scratch, 16-byte aligned */
     uint64_t coef_off;          /* [plan] int16 elements into the coefficient scratch */
     uint64_t plane_off[3];      /* [plan] bytes into the plane scratch */
     uint32_t stream_len;        /* bytes up to (not including) the marker that ends the scan */

@@ -69,7 +69,7 @@ def test_scope_checks():
 
 def test_descriptor_layout_and_plan():
     L = _lib.lib()
-    assert PJ.IMAGE_DTYPE.itemsize == L.cama_jpeg_image_bytes() == 168
+    assert PJ.IMAGE_DTYPE.itemsize == L.cama_jpeg_image_bytes() == 176
     imgs = np.zeros(2, PJ.IMAGE_DTYPE)
     for i, (w, h, hs, vs, ln) in enumerate([(1600, 900, 2, 2, 300000), (33, 17, 2, 1, 700)]):
         d = imgs[i]
@@ -89,7 +89,7 @@ def test_descriptor_layout_and_plan():
     imgs[1]["vs"] = 4
     assert L.cama_jpeg_plan(imgs.ctypes.data, 2, 400000, info.ctypes.data) == -1 and b"sampling" in L.cama_last_error()
     imgs[1]["vs"] = 1
-    imgs[1]["stream_off"] = 16
+    imgs[1]["stream_off"] = 399999                           # runs past the stream bytes
     assert L.cama_jpeg_plan(imgs.ctypes.data, 2, 400000, info.ctypes.data) == -1
 
 
