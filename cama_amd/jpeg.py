@@ -346,7 +346,8 @@ class DeviceJpegDecoder:
         base = np.concatenate([[0], np.cumsum(lens)[:-1]])
         stream_bytes = int(lens.sum())
         if L["pinned"] is None or L["pinned"].numel() < stream_bytes:
-            L["pinned"] = torch.empty(max(stream_bytes, 1 << 20), dtype=torch.uint8).pin_memory()
+            # (grown with headroom: lanes are reused across batch sizes, regrowing pinned / device buffers is slow)
+            L["pinned"] = torch.empty(max(stream_bytes * 5 // 4, 1 << 22), dtype=torch.uint8).pin_memory()
         host = L["pinned"].numpy()
         for o, ln, b, h in zip(base.tolist(), lens.tolist(), blobs, headers):
             host[o:o + ln] = np.frombuffer(b, np.uint8, ln, h.scan_start)
@@ -406,7 +407,7 @@ class DeviceJpegDecoder:
         with torch.cuda.stream(st):
             if L["scratch"] is None or L["scratch"].numel() < scratch_bytes:
                 L["scratch"] = None
-                L["scratch"] = torch.empty(scratch_bytes, dtype=torch.uint8, device=self.device)
+                L["scratch"] = torch.empty(scratch_bytes * 5 // 4, dtype=torch.uint8, device=self.device)
             stream_dev = L["pinned"][:stream_bytes].to(self.device, non_blocking=True)
             imgs_dev = torch.from_numpy(imgs.view(np.uint8).reshape(nd, -1)).to(self.device, non_blocking=True)
             status = torch.empty(nd, dtype=torch.int32, device=self.device)
