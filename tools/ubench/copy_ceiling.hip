@@ -83,6 +83,46 @@ __global__ __launch_bounds__(256) void k_copy_mosaic_bands_rowmajor(const u32x4*
         for (int j = 0; j < U; ++j) { unsigned i = base + j * 256; if (i < nchunks) { unsigned r = i / cpr, col = i - r * cpr; __builtin_nontemporal_store(v[j], db + (size_t)r * 3 * cpr + col); } }
     }
 }
+// one workgroup per (frame, camera row, band): 3 x 256 threads, slice k copies camera column k's band, so the
+// workgroup as a whole writes R CONTIGUOUS mosaic rows
+template <int U>
+__global__ __launch_bounds__(768) void k_copy_mosaic_fullrow(const u32x4* __restrict__ s, u32x4* __restrict__ d, int C, int H, int cpr, int R, int NB)
+{
+    unsigned t = blockIdx.x;
+    const unsigned b = t % NB; t /= NB;
+    const unsigned cr = t % 2; const unsigned f = t / 2;
+    const unsigned cc = threadIdx.x >> 8, lt = threadIdx.x & 255u;
+    const unsigned c = cr * 3 + cc, fc = f * C + c;
+    const int y0 = b * R, nrows = min(R, H - y0);
+    const unsigned nchunks = nrows * cpr;
+    const u32x4* sb = s + ((size_t)fc * H + y0) * cpr;
+    u32x4* db = d + ((size_t)f * 2 * H + (size_t)cr * H + y0) * 3 * cpr + (size_t)cc * cpr;
+    for (unsigned base = lt; base < nchunks; base += 256 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) { unsigned i = base + j * 256; if (i < nchunks) v[j] = __builtin_nontemporal_load(sb + i); }
+#pragma unroll
+        for (int j = 0; j < U; ++j) { unsigned i = base + j * 256; if (i < nchunks) { unsigned r = i / cpr, col = i - r * cpr; __builtin_nontemporal_store(v[j], db + (size_t)r * 3 * cpr + col); } }
+    }
+}
+// band split into TX column tiles, one 16-byte chunk per thread (U = 1), order (frame, camera row, band, camera column, tile)
+__global__ __launch_bounds__(256) void k_copy_mosaic_tiles(const u32x4* __restrict__ s, u32x4* __restrict__ d, int C, int H, int cpr, int R, int NB, int TX)
+{
+    unsigned t = blockIdx.x;
+    const unsigned tx = t % TX; t /= TX;
+    const unsigned cc = t % 3; t /= 3;
+    const unsigned b = t % NB; t /= NB;
+    const unsigned cr = t % 2; const unsigned f = t / 2;
+    const unsigned c = cr * 3 + cc, fc = f * C + c;
+    const unsigned cpt = cpr / TX;
+    const int y0 = b * R, nrows = min(R, H - y0);
+    const unsigned r = threadIdx.x / cpt, col = threadIdx.x - r * cpt + tx * cpt;
+    if ((int)r >= nrows) return;
+    const u32x4* sb = s + ((size_t)fc * H + y0) * cpr;
+    u32x4* db = d + ((size_t)f * 2 * H + (size_t)cr * H + y0) * 3 * cpr + (size_t)cc * cpr;
+    u32x4 v = __builtin_nontemporal_load(sb + (size_t)r * cpr + col);
+    __builtin_nontemporal_store(v, db + (size_t)r * 3 * cpr + col);
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 template <typename F> void timeit(const char* name, size_t bytes, F launch)
 {
@@ -117,6 +157,12 @@ int main()
         timeit("mosaic bands R=4 U=5 25KB LDS", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands<5, 25600>), dim3(F * C * 225), dim3(256), 0, 0, s, d, C, H, cpr, 4, 225); });
         timeit("rowmajor bands R=8 U=5", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands_rowmajor<5>), dim3(F * C * 113), dim3(256), 0, 0, s, d, C, H, cpr, 8, 113); });
         timeit("rowmajor bands R=4 U=5", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands_rowmajor<5>), dim3(F * C * 225), dim3(256), 0, 0, s, d, C, H, cpr, 4, 225); });
+        timeit("fullrow 768thr R=4 U=5", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_fullrow<5>), dim3(F * 2 * 225), dim3(768), 0, 0, s, d, C, H, cpr, 4, 225); });
+        timeit("fullrow 768thr R=2 U=3", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_fullrow<3>), dim3(F * 2 * 450), dim3(768), 0, 0, s, d, C, H, cpr, 2, 450); });
+        timeit("fullrow 768thr R=8 U=5", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_fullrow<5>), dim3(F * 2 * 113), dim3(768), 0, 0, s, d, C, H, cpr, 8, 113); });
+        timeit("tiles TX=5 R=4 (240 thr, U=1)", bytes, [&] { hipLaunchKernelGGL(k_copy_mosaic_tiles, dim3(F * C * 225 * 5), dim3(256), 0, 0, s, d, C, H, cpr, 4, 225, 5); });
+        timeit("tiles TX=3 R=2 (200 thr, U=1)", bytes, [&] { hipLaunchKernelGGL(k_copy_mosaic_tiles, dim3(F * C * 450 * 3), dim3(256), 0, 0, s, d, C, H, cpr, 2, 450, 3); });
+        timeit("tiles TX=10 R=8 (240 thr, U=1)", bytes, [&] { hipLaunchKernelGGL(k_copy_mosaic_tiles, dim3(F * C * 113 * 10), dim3(256), 0, 0, s, d, C, H, cpr, 8, 113, 10); });
         timeit("rowmajor bands R=2 U=3", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands_rowmajor<3>), dim3(F * C * 450), dim3(256), 0, 0, s, d, C, H, cpr, 2, 450); });
         timeit("rowmajor bands R=1 U=2", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands_rowmajor<2>), dim3(F * C * 900), dim3(256), 0, 0, s, d, C, H, cpr, 1, 900); });
         timeit("rowmajor bands R=4 U=3", bytes, [&] { hipLaunchKernelGGL((k_copy_mosaic_bands_rowmajor<3>), dim3(F * C * 225), dim3(256), 0, 0, s, d, C, H, cpr, 4, 225); });
