@@ -409,6 +409,28 @@ class PoseTransformer:
             self._tables = hit
         return hit[2:]
 
+    @staticmethod
+    def _seek_many_interior(s, stack, rl, rotvec, q, t_max_diff):
+        """The common case of seek_many in a third of the numpy calls: every query strictly inside the track, none
+        within the exact-hit tolerance of a stamp, no gap above t_max_diff.  Same expressions as the general path
+        (so the same bits); returns None when any query needs the general path."""
+        P = s.shape[0]
+        hi = np.searchsorted(s, q, side="left")
+        if hi.min() < 1 or hi.max() > P - 1:
+            return None
+        lo = hi - 1
+        sl, sh = s[lo], s[hi]
+        tol = _EXACT_ATOL + 1e-20 * np.abs(q)
+        gap = sh - sl
+        if (np.abs(sl - q) <= tol).any() or (np.abs(sh - q) <= tol).any() or (gap > t_max_diff).any():
+            return None
+        ratio = (q - sl) / gap
+        rot = (rl[lo] * Rotation.from_rotvec(rotvec[lo] * ratio[:, None])).as_matrix()
+        r = ratio[:, None, None]
+        T = stack[lo] * (1 - r) + stack[hi] * r
+        T[:, :3, :3] = rot
+        return np.ones(q.shape[0], bool), T
+
     def seek_many(self, query_times, t_max_diff, interpolate=True):
         """Vectorised seek_by_timestamp(interpolate=True) over Q queries.
 
@@ -423,6 +445,9 @@ class PoseTransformer:
         s, stack, rl, rotvec = self._interp_tables()
         q = np.asarray(query_times, np.float64).reshape(-1)
         P = s.shape[0]
+        fast = self._seek_many_interior(s, stack, rl, rotvec, q, t_max_diff) if (P >= 2 and q.shape[0]) else None
+        if fast is not None:
+            return fast
         out = np.zeros((q.shape[0], 4, 4))
         ok = np.zeros(q.shape[0], bool)
         hi = np.searchsorted(s, q, side="left")
