@@ -509,8 +509,13 @@ class Engine:
                 pass
             self._pipe = None
 
-    def max_frames_per_call(self, dmap, rig, budget_bytes=4 << 30):
-        """Largest F whose worst-case stamp scratch fits `budget_bytes` (and 32-bit stamp offsets)."""
+    def max_frames_per_call(self, dmap, rig, budget_bytes=None):
+        """Largest F whose worst-case stamp scratch fits `budget_bytes` (and 32-bit stamp offsets).  Default budget:
+        a quarter of the free HBM, at most 64 GB -- sized for 288 GB parts, so that 4*10^6-vertex site maps still render
+        40 frames per launch (the scratch is worst-case: every vertex visible in every camera)."""
+        if budget_bytes is None:
+            free, _ = _torch().cuda.mem_get_info(self.device)
+            budget_bytes = min(64 << 30, max(1 << 30, free // 4))
         per = max(1, self.lib.cama_render_scratch_bytes(dmap.N, 1, rig.C, rig.H, rig.W, self.radius))
         f_budget = max(1, int(budget_bytes // per))
         f_off = max(1, int(((1 << 32) - 1) // max(1, rig.C * max(1, dmap.N) * 2)))
