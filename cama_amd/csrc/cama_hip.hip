@@ -673,13 +673,17 @@ int cama_build_static_map(const float *verts, const int32_t *seg_v0, const int32
 // ------------------------------------------------------------------------------------------
 // two-stream pipeline context: binning of batch k+1 overlaps the overlay of batch k
 // ------------------------------------------------------------------------------------------
+// Launch k (1-based) uses scratch slot (k - 1) % 2 and records done[k % RING] on s_ov after its overlay.  The ring
+// serves three purposes: (i) launch k's binning waits for done[(k - 2) % RING], the overlay that last read its slot;
+// (ii) cama_pipeline_completed() polls it, so the caller knows which launches' inputs (poses, frames) and outputs may
+// be released -- the internal streams are invisible to the caller's allocator; (iii) it bounds the run-ahead: issuing
+// launch k blocks until launch k - (RING - 2) has completed.
 struct cama_pipeline {
+    static constexpr int RING = 64;
     hipStream_t s_bin = nullptr, s_ov = nullptr;
-    hipEvent_t ready = nullptr, binned[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
-    bool freed_valid[2] = {false, false};
-    int turn = 0;
-    bool any = false;
-    int last = 0;
+    hipEvent_t ready = nullptr, binned[2] = {nullptr, nullptr};
+    hipEvent_t done[RING] = {};
+    uint64_t issued = 0, completed = 0;
 };
 
 int cama_pipeline_create(cama_pipeline **out)
@@ -692,12 +696,10 @@ int cama_pipeline_create(cama_pipeline **out)
     hipError_t e = hipStreamCreateWithFlags(&p->s_bin, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_ov, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready, flags);
-    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-        e = hipEventCreateWithFlags(&p->binned[k], flags);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->freed[k], flags);
-    }
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->binned[k], flags);
+    for (int k = 0; k < cama_pipeline::RING && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->done[k], flags);
     if (e != hipSuccess) {
-        delete p;
+        cama_pipeline_destroy(p);
         return fail(CAMA_EHIP, "cama_pipeline_create -> %s", hipGetErrorString(e));
     }
     *out = p;
@@ -710,12 +712,33 @@ int cama_pipeline_destroy(cama_pipeline *p)
     if (p->s_bin) { (void)hipStreamSynchronize(p->s_bin); (void)hipStreamDestroy(p->s_bin); }
     if (p->s_ov) { (void)hipStreamSynchronize(p->s_ov); (void)hipStreamDestroy(p->s_ov); }
     if (p->ready) (void)hipEventDestroy(p->ready);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 2; ++k)
         if (p->binned[k]) (void)hipEventDestroy(p->binned[k]);
-        if (p->freed[k]) (void)hipEventDestroy(p->freed[k]);
-    }
+    for (int k = 0; k < cama_pipeline::RING; ++k)
+        if (p->done[k]) (void)hipEventDestroy(p->done[k]);
     delete p;
     return CAMA_OK;
+}
+
+// advance `completed` over every launch whose `done` event has fired (launches complete in order: one overlay stream)
+static int pipeline_poll(cama_pipeline *p)
+{
+    while (p->completed < p->issued) {
+        const hipError_t e = hipEventQuery(p->done[(p->completed + 1) % cama_pipeline::RING]);
+        if (e == hipErrorNotReady) break;
+        if (e != hipSuccess) return fail(CAMA_EHIP, "hipEventQuery -> %s", hipGetErrorString(e));
+        ++p->completed;
+    }
+    return CAMA_OK;
+}
+
+int64_t cama_pipeline_issued(cama_pipeline *p) { return p ? (int64_t)p->issued : (int64_t)fail(CAMA_EINVAL, "pipeline is NULL"); }
+
+int64_t cama_pipeline_completed(cama_pipeline *p)
+{
+    if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
+    if (int rc = pipeline_poll(p)) return rc;
+    return (int64_t)p->completed;
 }
 
 int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
@@ -728,12 +751,25 @@ int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const v
 {
     if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
     if (!scratch0 || !scratch1) return fail(CAMA_EINVAL, "two scratch buffers are needed");
-    const int slot = p->turn;
+    constexpr uint64_t RING = cama_pipeline::RING;
+    const uint64_t k = p->issued + 1;                     // this launch
+    const int slot = (int)((k - 1) & 1u);
     void *scratch = slot ? scratch1 : scratch0;
+    // bound the run-ahead (and keep done[k % RING], last used by launch k - RING, free): launch k - (RING - 2) must be over
+    if (k > RING - 2) {
+        HIP_TRY(hipEventSynchronize(p->done[(k - (RING - 2)) % RING]));
+        if (int rc = pipeline_poll(p)) return rc;
+    }
+    // validate before anything is enqueued, so a rejected call leaves the pipeline state untouched
+    {
+        ScratchLayout L;
+        if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+        if (F > 0 && (!src || !mosaic || !palette_bgr || !halfwidth || cols < 1)) return fail(CAMA_EINVAL, "NULL pointer argument");
+    }
     // inputs (w2c upload, frames) are complete on the caller's stream at this point
     HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
     HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
-    if (p->freed_valid[slot]) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->freed[slot], 0));   // overlay that read this slot
+    if (k > 2) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->done[(k - 2) % RING], 0));   // the overlay that read this slot
     if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, N, w2c, F, c2cam, K, C, crop, W, H, radius,
                                  scratch, scratch_bytes, p->s_bin))
         return rc;
@@ -746,19 +782,16 @@ int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const v
     if (int rc = cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
                                      scratch_bytes, so))
         return rc;
-    HIP_TRY(hipEventRecord(p->freed[slot], so));
-    p->freed_valid[slot] = true;
-    p->last = slot;
-    p->any = true;
-    p->turn ^= 1;
+    HIP_TRY(hipEventRecord(p->done[k % RING], so));
+    p->issued = k;
     return CAMA_OK;
 }
 
 int cama_pipeline_join(cama_pipeline *p, void *stream)
 {
     if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
-    for (int k = 0; k < 2; ++k)
-        if (p->freed_valid[k]) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->freed[k], 0));
+    // one overlay stream: the newest launch's event covers every earlier one
+    if (p->issued) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->done[p->issued % cama_pipeline::RING], 0));
     return CAMA_OK;
 }
 

@@ -6,6 +6,7 @@
 // ------------------------------------------------------------------------------------------
 // fp64 k-ordered FMA chains (see header: arithmetic contract)
 // ------------------------------------------------------------------------------------------
+typedef const double __attribute__((address_space(4))) kdouble;   // uniform loads from it are s_load (SGPR operands)
 __device__ __forceinline__ void affine3x4(const double *M, double x, double y, double z,
                                           double &ox, double &oy, double &oz)
 {
@@ -15,8 +16,8 @@ __device__ __forceinline__ void affine3x4(const double *M, double x, double y, d
     a = M[8] * x; a = __builtin_fma(M[9], y, a); a = __builtin_fma(M[10], z, a); a = __builtin_fma(M[11], 1.0, a); oz = a;
 }
 
-__device__ __forceinline__ void linear3x3(const double *K, double x, double y, double z,
-                                          double &o0, double &o1, double &o2)
+template <typename P>
+__device__ __forceinline__ void linear3x3(P K, double x, double y, double z, double &o0, double &o1, double &o2)
 {
     double a;
     a = K[0] * x; a = __builtin_fma(K[1], y, a); a = __builtin_fma(K[2], z, a); o0 = a;
@@ -46,10 +47,12 @@ __device__ __forceinline__ bool pinhole(double h0, double h1, double h2, double 
 //      the third affine row alone (5 fp64 ops instead of ~50 for the half-space behind the camera);
 //  (b) h0 < -h2 or h0 > (W+1)*h2 (same for h1/H) puts the IEEE quotient below 0 / at or above W even after
 //      rounding (one pixel of margin >> 1 ulp), so the two divisions (~28 fp64 ops) are skipped.
-__device__ __forceinline__ bool visible_pixel(const double *m, double cx, double cy, double cz, double Wd, double Hd,
+// m = chassis->camera 3x4 (row-major, 12 values), K = 3x3; P is `const double *` (LDS-staged) or a constant-address-
+// space pointer (wave-uniform scalar loads: the matrices then live in SGPRs and cost no LDS or VMEM issue slots).
+template <typename P>
+__device__ __forceinline__ bool visible_pixel(P m, P K, double cx, double cy, double cz, double Wd, double Hd,
                                               uint32_t &uv)
 {
-    const double *K = m + 12;
     double a;
     a = m[8] * cx; a = __builtin_fma(m[9], cy, a); a = __builtin_fma(m[10], cz, a); a = __builtin_fma(m[11], 1.0, a);
     const double pz = a;
@@ -292,10 +295,12 @@ __device__ __forceinline__ void bin_block(const FrameArgs &a, const int64_t vblo
     }
     // whole workgroup outside the crop box (the common case on site-sized maps): done
     if (!__syncthreads_or((int)in)) return;
+#ifdef CAMA_CAM_LDS
     if (!cams_ready) {
         stage_cameras(s_cam, a.c2cam, a.K, a.C);
         cams_ready = true;
     }
+#endif
     for (int t = threadIdx.x; t < nloc; t += BLOCK) s_cnt[t] = 0u;
     __syncthreads();
 
@@ -313,7 +318,17 @@ __device__ __forceinline__ void bin_block(const FrameArgs &a, const int64_t vblo
                 uint32_t uv = 0xffffffffu;      // packed truncated pixel, or "not visible"
                 if (in) {
                     uint32_t packed;
-                    if (visible_pixel(s_cam + c * CAM_STRIDE, cx, cy, cz, Wd, Hd, packed)) uv = packed;
+#ifdef CAMA_CAM_LDS
+                    if (visible_pixel<const double *>(s_cam + c * CAM_STRIDE, s_cam + c * CAM_STRIDE + 12, cx, cy, cz, Wd, Hd,
+                                                      packed))
+                        uv = packed;
+#else
+                    // the camera's 21 doubles through wave-uniform scalar loads (constant address space): read as LDS
+                    // broadcasts they were ~126 ds_read_b64 per lane and made dense maps LDS-issue bound
+                    if (visible_pixel<kdouble *>((kdouble *)(a.c2cam + (size_t)c * 16), (kdouble *)(a.K + (size_t)c * 9), cx,
+                                                 cy, cz, Wd, Hd, packed))
+                        uv = packed;
+#endif
                 }
                 // A disc is invisible if a LATER point (higher draw index) stamps the very same pixel (same
                 // footprint).  The next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most
@@ -368,7 +383,11 @@ template <int MODE, typename T>
 __global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [C*NB] counts, then (fill) [C*NB] bases
+#ifdef CAMA_CAM_LDS
     __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+#else
+    double *s_cam = nullptr;
+#endif
     bool cams_ready = false;
     bin_block<MODE, T, true>(a, (int64_t)blockIdx.x, (int)blockIdx.y, s_hist, s_cam, cams_ready);
 }
@@ -403,7 +422,11 @@ __global__ __launch_bounds__(BLOCK) void k_frames_bin_list(FrameArgs a, const ui
                                                            uint32_t list_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
+#ifdef CAMA_CAM_LDS
     __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+#else
+    double *s_cam = nullptr;
+#endif
     bool cams_ready = false;
     const uint32_t list = blockIdx.x & 7u;          // gridDim.x is a multiple of 8
     const uint32_t n = work_count[list];

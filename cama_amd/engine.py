@@ -489,16 +489,42 @@ class Engine:
                 rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, src.data_ptr(), out.data_ptr(), cols,
                 self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(),
                 min(s0.numel(), s1.numel()), self._stream()))
-            # the internal streams are invisible to torch's allocator: keep what they read alive until join()
-            P["keep"].append((T, src, out))
-            if len(P["keep"]) > 8:
-                del P["keep"][:-8]
+            # The internal streams are invisible to torch's caching allocator: what launch k reads / writes must stay
+            # allocated until the library reports it complete (cama_pipeline_completed, a hipEventQuery over its ring
+            # of per-launch events) -- however far ahead of the GPU the host is.
+            seq = int(self.lib.cama_pipeline_issued(P["handle"]))
+            P["keep"].append((seq, T, src, out, dmap, rig))
+            self._release_completed(P)
             return out
 
+    def _release_completed(self, P):
+        done = int(self.lib.cama_pipeline_completed(P["handle"]))
+        if done < 0:
+            _lib.check(done)
+        keep = P["keep"]
+        n = 0
+        while n < len(keep) and keep[n][0] <= done:
+            n += 1
+        if n:
+            del keep[:n]
+
     def join(self):
-        """Make the current stream wait for all pipelined overlays issued so far."""
-        if self._pipe is not None:
+        """Make the current stream wait for all pipelined overlays issued so far.  The references kept for them are
+        handed back to torch's allocator with record_stream(current stream): a block is then reused only after work
+        queued behind that wait, on whichever stream it was allocated."""
+        if self._pipe is None:
+            return
+        torch = _torch()
+        with torch.cuda.device(self.device):
             _lib.check(self.lib.cama_pipeline_join(self._pipe["handle"], self._stream()))
+            self._release_completed(self._pipe)
+            cur = torch.cuda.current_stream(self.device)
+            for _, T, src, out, dmap, rig in self._pipe["keep"]:
+                for t in (T, src, out, dmap.soa, dmap.colour, dmap.sorted_soa, dmap.sorted_key,
+                          getattr(dmap, "bounds", None), rig.c2cam, rig.K):
+                    if t is not None:
+                        t.record_stream(cur)
+            self._pipe["keep"].clear()
 
     def __del__(self):
         pipe = getattr(self, "_pipe", None)

@@ -43,16 +43,41 @@ def scene_cost(n_frames, n_verts, W, H, cams=6):
     return float(n_frames) * (13.0 * n_verts + 2.0 * cams * W * H * 3.0)
 
 
-def overlay_hash(mosaic):
-    """Order-independent 128-bit checksum of a uint8 device/host tensor (two 64-bit sums of two views)."""
+_HASH_MULT = 0x9E3779B97F4A7C15                 # odd 64-bit constant (golden ratio)
+
+
+def overlay_hash_np(arr):
+    """numpy twin of overlay_hash (what the oracle side hashes with): (lo, hi) uint64 as Python ints."""
+    b = np.ascontiguousarray(arr).reshape(-1).view(np.uint8)
+    n8 = (b.size // 8) * 8
+    w = b[:n8].view(np.uint64)
+    tail = int(b[n8:].astype(np.uint64).sum())
+    idx = np.arange(w.size, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        lo = int(w.sum(dtype=np.uint64))
+        hi = int((w * ((idx * np.uint64(2) + np.uint64(1)) * np.uint64(_HASH_MULT))).sum(dtype=np.uint64))
+    return (lo + tail) & 0xFFFFFFFFFFFFFFFF, (hi + 31 * tail) & 0xFFFFFFFFFFFFFFFF
+
+
+def overlay_hash(mosaic, chunk_words=1 << 24):
+    """128-bit checksum of a uint8 device/host tensor: lo = sum of its little-endian 64-bit words, hi = sum of
+    word_i * (2 i + 1) * K (both mod 2^64; K odd).  hi is position-weighted: moving, swapping or dropping rows,
+    frames or camera cells changes it, which a plain sum would not notice.  Integer arithmetic only, so the value is
+    the same on every device and equals overlay_hash_np on the same bytes."""
     import torch
     t = mosaic if isinstance(mosaic, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mosaic))
     flat = t.reshape(-1)
     n8 = (flat.numel() // 8) * 8
-    words = flat[:n8].view(torch.int64)
-    lo = int(words.sum().item()) & 0xFFFFFFFFFFFFFFFF
-    hi = int((words >> 7).sum().item() + flat[n8:].to(torch.int64).sum().item()) & 0xFFFFFFFFFFFFFFFF
-    return lo, hi
+    words = flat[:n8].view(torch.int64) if n8 else flat[:0].to(torch.int64)
+    mult = _HASH_MULT - (1 << 64)                   # the same 64 bits as a signed value; int64 products wrap mod 2^64
+    lo = hi = 0
+    for a in range(0, words.numel(), chunk_words):
+        w = words[a:a + chunk_words]
+        idx = torch.arange(a, a + w.numel(), dtype=torch.int64, device=w.device)
+        lo += int(w.sum().item())
+        hi += int((w * ((idx * 2 + 1) * mult)).sum().item())
+    tail = int(flat[n8:].to(torch.int64).sum().item())
+    return (lo + tail) & 0xFFFFFFFFFFFFFFFF, (hi + 31 * tail) & 0xFFFFFFFFFFFFFFFF
 
 
 def gather_records(record, device=None):
@@ -67,6 +92,82 @@ def gather_records(record, device=None):
     out = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)    # flat: accepted by nccl and gloo
     dist.all_gather_into_tensor(out, rec)
     return out.reshape(world, rec.numel()).cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the bench's one collective: per-rank report = float64 metrics + (unit id, hash lo, hash hi) rows, as int64 words
+# ---------------------------------------------------------------------------------------------------------------
+def _to_i64(u):
+    u = int(u) & 0xFFFFFFFFFFFFFFFF
+    return u - (1 << 64) if u >= (1 << 63) else u
+
+
+def pack_report(metrics, hashes, slots):
+    """One rank's report as a flat int64 array: the float64 `metrics` bit-cast to int64, then `slots` rows of
+    (unit id, hash lo, hash hi); unused rows carry id -1.  `hashes` = [(unit id, lo, hi)] of the units (scenes, or
+    sampled frames of a frame-sharded scene) this rank rendered."""
+    assert len(hashes) <= slots, (len(hashes), slots)
+    rows = np.full((slots, 3), -1, np.int64)
+    for k, (uid, lo, hi) in enumerate(hashes):
+        rows[k] = (int(uid), _to_i64(lo), _to_i64(hi))
+    return np.concatenate([np.asarray(metrics, np.float64).view(np.int64), rows.reshape(-1)])
+
+
+def gather_reports(report, device=None):
+    """all_gather of one pack_report() array per rank -> (world, len) int64 numpy array on every rank.  This is the
+    job's only collective (nccl = RCCL over xGMI on the GPU box, gloo in the CPU tests; world 1 needs no group)."""
+    import torch
+    import torch.distributed as dist
+    rec = torch.as_tensor(np.ascontiguousarray(report), dtype=torch.int64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return rec[None].cpu().numpy()
+    world = dist.get_world_size()
+    out = torch.empty(world * rec.numel(), dtype=torch.int64, device=rec.device)
+    dist.all_gather_into_tensor(out, rec)
+    return out.reshape(world, rec.numel()).cpu().numpy()
+
+
+def unpack_reports(reports, n_metrics):
+    """(world, L) int64 -> (metrics float64 (world, n_metrics), {unit id: (lo, hi)}, {unit id: rank})."""
+    r = np.ascontiguousarray(np.asarray(reports, np.int64))
+    metrics = np.ascontiguousarray(r[:, :n_metrics]).view(np.float64)
+    found, owner = {}, {}
+    for rank in range(r.shape[0]):
+        for uid, lo, hi in r[rank, n_metrics:].reshape(-1, 3):
+            if uid >= 0:
+                if int(uid) in found:
+                    raise RuntimeError(f"unit {int(uid)} was rendered by ranks {owner[int(uid)]} and {rank}")
+                found[int(uid)] = (int(lo) & 0xFFFFFFFFFFFFFFFF, int(hi) & 0xFFFFFFFFFFFFFFFF)
+                owner[int(uid)] = rank
+    return metrics, found, owner
+
+
+def verify_hashes(found, golden, expect_units=None):
+    """Compare {unit: (lo, hi)} with the committed golden {unit: (lo, hi)} (oracle-rendered, tests/golden/*.json).
+    Returns {"verified": n, "unverified": [units without a golden entry], "mismatched": [...], "missing": [units
+    that should have been rendered and were not]}."""
+    golden = {int(k): (int(v[0]), int(v[1])) for k, v in golden.items()}
+    out = {"verified": 0, "unverified": [], "mismatched": [], "missing": []}
+    for uid in sorted(found):
+        if uid not in golden:
+            out["unverified"].append(uid)
+        elif golden[uid] == tuple(found[uid]):
+            out["verified"] += 1
+        else:
+            out["mismatched"].append(uid)
+    if expect_units is not None:
+        out["missing"] = sorted(set(int(u) for u in expect_units) - set(found))
+    return out
+
+
+def load_golden_hashes(path, key):
+    """{unit: (lo, hi)} of the golden file's entry `key` (the workload description), or {} when absent."""
+    import json
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return {}
+    return {int(k): (int(v[0], 16), int(v[1], 16)) for k, v in rec.get(key, {}).items()}
 
 
 def reduce_metrics(records):

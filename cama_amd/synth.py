@@ -243,3 +243,39 @@ def make_clip(clip_path, n_frames=5, seed=0, n_lines=6, verts_per_line=5,
                 else:
                     raise ValueError(image_mode)
     return info
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# camera-frame content that is identical on every device
+# ---------------------------------------------------------------------------------------------------------------
+def _pcg_words(counter, seed, xp):
+    """PCG-RXS-M-XS style output of a 32-bit counter hash, in int64 arithmetic that never exceeds 2^62 (so numpy,
+    torch-CPU and torch-GPU agree bit for bit): `counter` int64 array/tensor -> values in [0, 2^32)."""
+    m32 = 0xFFFFFFFF
+    h = (counter * 747796405 + (int(seed) * 2891336453 + 12345) % (1 << 31)) & m32
+    h = (((h >> ((h >> 28) + 4)) ^ h) * 277803737) & m32
+    return ((h >> 22) ^ h) & m32
+
+
+def frame_pattern_np(seed, shape, first=0):
+    """uint8 ndarray of `shape` (byte count a multiple of 4): byte stream = little-endian PCG words of counters
+    first/4, first/4 + 1, ... of stream `seed`.  `first` = byte offset into the stream (a multiple of 4)."""
+    n = int(np.prod(shape))
+    assert n % 4 == 0 and first % 4 == 0
+    c = np.arange(first // 4, first // 4 + n // 4, dtype=np.int64)
+    return _pcg_words(c, seed, np).astype(np.uint32).view(np.uint8).reshape(shape)
+
+
+def frame_pattern(seed, shape, device, chunk_bytes=1 << 28, first=0):
+    """torch twin of frame_pattern_np on any device (filled in chunks: the int64 temporaries are 8x the output)."""
+    import torch
+    n = int(np.prod(shape))
+    assert n % 4 == 0 and first % 4 == 0
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    words = out.view(torch.int32)
+    for lo in range(0, n // 4, chunk_bytes // 4):
+        hi = min(n // 4, lo + chunk_bytes // 4)
+        c = torch.arange(first // 4 + lo, first // 4 + hi, dtype=torch.int64, device=device)
+        w = _pcg_words(c, seed, torch)
+        words[lo:hi] = (w - ((w >> 31) << 32)).to(torch.int32)       # [0, 2^32) -> the int32 with the same bits
+    return out.view(shape)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 5
+#define CAMA_ABI_VERSION 6
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -168,7 +168,14 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
  * binning of batch k+1 overlaps the HBM-bound overlay of batch k; scratch0 / scratch1 (each >=
  * cama_render_scratch_bytes) are used alternately.  Inputs must be complete on `input_stream` when the call is made;
  * outputs are complete after cama_pipeline_join(p, stream) in `stream`'s order.  The context owns two HIP streams and
- * five events (device-scope release, no timing) and no device memory.  One context per thread.
+ * a ring of 64 completion events (device-scope release, no timing) and no device memory.  One context per thread.
+ *
+ * Lifetime of what a launch reads and writes: the internal streams are invisible to the caller's allocator, so every
+ * buffer handed to launch k (w2c, src, mosaic, the map, the calibration) must stay allocated and unmodified until
+ * cama_pipeline_completed(p) >= k (launches are numbered 1, 2, ... = cama_pipeline_issued(p) right after the call)
+ * or until a cama_pipeline_join() has been ordered before its release.  cama_pipeline_completed() never blocks
+ * (hipEventQuery).  At most 62 launches are in flight: issuing launch k blocks the host until launch k - 62 is over.
+ * Both return < 0 on error.
  */
 typedef struct cama_pipeline cama_pipeline;
 int cama_pipeline_create(cama_pipeline **out);
@@ -182,6 +189,8 @@ int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const v
                          int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
                          void *scratch0, void *scratch1, size_t scratch_bytes, void *input_stream);
 int cama_pipeline_join(cama_pipeline *p, void *stream);
+int64_t cama_pipeline_issued(cama_pipeline *p);
+int64_t cama_pipeline_completed(cama_pipeline *p);
 
 /*
  * EXTENSION (no reference semantics; the reference draws opaque discs, cama/reproject.py:253-256): overlay half with

@@ -154,7 +154,7 @@ def test_library_exports_every_declared_symbol(repo_root):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.cama_abi_version() == 5
+    assert L.cama_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define CAMA_ABI_VERSION (\d+)", header).group(1))
     assert _lib.circle_halfwidths(2).tolist() == [2, 1, 0]
     assert L.cama_render_scratch_bytes(10000, 40, 6, 900, 1600, 2) > 0
     # argument validation happens before any device work
