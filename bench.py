@@ -5,23 +5,35 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): one synthetic scene per GPU -- 6 pinhole cameras,
-40 rendered frames at 1600x900, ~1e4 densified map vertices (CAMA-style labels: BEV pixels + height raster),
-pose rows offset from the frame stamps so every frame interpolates.  Camera frames (uint8 BGR) are resident in
-HBM before the timed region; the mosaic output stays in HBM.
+Workloads (every scene: 6 pinhole cameras, 40 rendered frames at 1600x900, ~1e4 densified map
+vertices from CAMA-style labels, pose rows offset from the frame stamps so every frame interpolates; camera frames
+(uint8 BGR, synth.frame_pattern: the same bytes on any device, so the oracle can render them on the CPU) resident
+in HBM before the timed region, mosaics stay in HBM):
 
-One STEP = one pass of the hot path over the scene:
-    ClipManager.render_clip("cama")  =  frame poses for all 40 frames (host: vectorised seek+slerp, float32
-    cast, float32 inverse) -> cama_render_frames (count -> scan -> fill -> overlay, one launch each for all frames).
+  --gpus 1 (default)   BASELINE configs[1]: ONE scene.  A step = one pass of the hot path over its 40 frames.
+  --gpus N > 1         BASELINE configs[2]: the FIXED 73-scene sweep (scene id = seed 0..72), sharded over the ranks by
+                       shard.assign_scenes (longest-processing-time first) => "scaling": "strong".  A step = every rank
+                       renders all of its scenes once.  No data-path collective.  A second, nested measurement
+                       ("stress") is BASELINE configs[4]: ONE scene of 1e6 random vertices x 1000 frames, cut into
+                       contiguous frame ranges (shard.frame_ranges), also fixed total work.
+  --scenes S / --shard-frames / --map ...   the same machinery on other fixed workloads (any N).
+
+One STEP of a scene = ClipManager.render_clip("cama"): frame poses for all frames (host: vectorised seek+slerp,
+float32 cast, float32 inverse) -> cama_pipeline_render (bin -> overlay, one launch each per <= frames-per-call frames).
 value = frames rendered by all ranks / max-over-ranks wall time of the K steps (barrier + synchronize on both sides).
-Scenes are independent, so N GPUs render N scenes (weak scaling, no data-path collective); the only collective is
-one all_gather of an 8-double metric record (frames, seconds, overlay time, bytes, overlay checksum) over RCCL.
+
+Verification (untimed, after the timed region): every scene is rendered once more into its own buffer and hashed
+(shard.overlay_hash); the per-SCENE hashes travel in the job's single all_gather (RCCL) next to the metrics and rank 0
+compares them with tests/golden/scene_hashes.json -- the hashes of the ORACLE's render of the same scenes
+(tests/golden/gen_scene_hashes.py, CPU) -- so a wrong shard, a scene rendered twice or not at all, or wrong pixels
+cannot print a number: the run fails instead.
 
 Extra objects in the JSON line:
   roofline      dominant kernel = k_overlay, HBM-bound.  achieved = algorithmic bytes per launch
                 (13*N + 36*W*H per frame, SURVEY.md 8d, x frames per launch) / its mean duration measured live
-                with hipEvents on the launch stream (cama_profile_*; every 8th launch is timed, a timed event pair
-                is two extra barrier packets).  peak 8000 GB/s.
+                with hipEvents on the launch stream (cama_profile_*; every 8th step is timed, a timed event pair
+                is two extra barrier packets).  peak 8000 GB/s.  `traffic` is a cross-reference to the committed
+                rocprofv3 --pmc run of the same configuration (`traffic_source`), not a measurement of this run.
   cpu_baseline  oracle/cama_oracle.py (numpy port of the reference, per-point circle calls into C) timed on this
                 box's host cores for a bounded number of passes over the same scene; rank 0, N=1 only.
 """
@@ -39,9 +51,13 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+SWEEP_SCENES = 73              # BASELINE configs[2]: nuScenes v1.0-test
+STRESS = dict(verts=1000000, frames=1000)       # BASELINE configs[4]
+N_METRICS = 8
+GOLDEN_SCENES = os.path.join(REPO, "tests", "golden", "scene_hashes.json")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -51,11 +67,11 @@ def parse_args():
     ap.add_argument("--height", type=int, default=900)
     ap.add_argument("--width", type=int, default=1600)
     ap.add_argument("--scenes", type=int, default=0,
-                    help="total number of distinct scenes, sharded over the ranks (default: one per rank). "
-                         "73 = BASELINE configs[2], the v1.0-test sweep; every step renders all scenes of the rank")
+                    help="total number of distinct scenes (seed = scene id), sharded over the ranks.  Default: 1 on one "
+                         "GPU (BASELINE configs[1]), 73 on several (configs[2], the v1.0-test sweep: fixed total work)")
     ap.add_argument("--shard-frames", action="store_true",
                     help="strong scaling of ONE long scene: every rank renders a contiguous range of its --frames "
-                         "(shard.frame_ranges) instead of a scene of its own")
+                         "(shard.frame_ranges) instead of whole scenes")
     ap.add_argument("--map", choices=["lanes", "random", "site"], default="lanes",
                     help="lanes: CAMA-style densified polylines along the drive (configs[1..3]); random: --verts "
                          "uniformly random map vertices over the 600 m map in random order (configs[4] stress); "
@@ -68,27 +84,25 @@ def parse_args():
                     help="with --raw-frames: separate resample kernel + overlay instead of the fused raw-frame overlay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single stream: binning and overlay of consecutive steps do not overlap")
+    ap.add_argument("--no-stress", action="store_true", help="N > 1: skip the nested configs[4] measurement")
+    ap.add_argument("--stress-frames", type=int, default=STRESS["frames"])
+    ap.add_argument("--stress-verts", type=int, default=STRESS["verts"])
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed per-scene hash pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def build_scene(args, seed, device):
-    import torch
-    rank = seed
-    from cama_amd.dataset import ClipManager
-    from cama_amd.frames import DeviceFrameSource
-    from cama_amd.synth import DEFAULT_CAMA_CONFIGS, make_clip
-    H, W = args.height, args.width
-    tmp = tempfile.mkdtemp(prefix=f"cama_bench_r{rank}_")
-    clip = os.path.join(tmp, "clip")
-    n_lines = max(2, round(args.verts / 500)) if args.map == "lanes" else 4
-    # CAMA labels are densified at 0.1 BEV px = 1 cm: a 5 m polyline of 11 vertices gives ~500 points
-    make_clip(clip, n_frames=args.frames + 1, seed=rank, n_lines=n_lines, verts_per_line=11, line_len_m=5.0,
-              raster_size=3000, origin_size=(900, 1600), with_nuscenes=False, extra_labels=False)
-    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W)), clip)
+def workload_key(frames, verts, width, height, map_kind, raw=False):
+    """Name of a workload in the golden hash files (everything the rendered bytes depend on)."""
+    return f"map={map_kind},verts={verts},frames={frames},{width}x{height}" + (",raw1600x900" if raw else "")
+
+
+def replace_map(cm, args, seed):
+    """--map random / site: replace the clip's static map through the reference's public per-clip dict
+    (cama/dataset.py:13-24).  Seeded by the scene id; numpy only, so the oracle side builds the same map."""
     if args.map == "site":
         # site-aggregated map: long polylines with random headings all over the 600 m extent, stored polyline-major
-        rng = np.random.default_rng(2000 + rank)
+        rng = np.random.default_rng(2000 + seed)
         per_line = 5000                                            # 50 m at 1 cm
         n_l = max(1, args.verts // per_line)
         t = (np.arange(per_line) * 0.01)[None, :]
@@ -101,24 +115,48 @@ def build_scene(args, seed, device):
         cls = ["lane_marking", "Road_teeth", "Crosswalk_Line"]
         cm.instance_maps["cama"] = [{"class": cls[i % 3], "points": pts[i]} for i in range(n_l)]
     if args.map == "random":
-        # stress map: uniformly random vertices, no spatial coherence between consecutive draw indices.
-        # instance_maps is the reference's public per-clip dict (cama/dataset.py:13-24): replace the static map.
-        rng = np.random.default_rng(1000 + rank)
+        # stress map: uniformly random vertices, no spatial coherence between consecutive draw indices
+        rng = np.random.default_rng(1000 + seed)
         pts = np.stack([rng.uniform(-300, 300, args.verts), rng.uniform(-300, 300, args.verts),
                         rng.normal(0, 0.05, args.verts)], axis=-1).astype(np.float32)
         half = args.verts // 2
         cm.instance_maps["cama"] = [{"class": "lane_marking", "points": pts[:half]},
                                     {"class": "Road_teeth", "points": pts[half:]}]
-    gen = torch.Generator(device=device)
-    gen.manual_seed(rank)
-    if getattr(args, "raw_frames", False):
+
+
+def write_scene_clip(args, seed, clip):
+    """The synthetic clip directory of scene `seed` (no GPU, no torch): shared by build_scene and the golden scripts."""
+    from cama_amd.synth import make_clip
+    n_lines = max(2, round(args.verts / 500)) if args.map == "lanes" else 4
+    # CAMA labels are densified at 0.1 BEV px = 1 cm: a 5 m polyline of 11 vertices gives ~500 points
+    make_clip(clip, n_frames=args.frames + 1, seed=seed, n_lines=n_lines, verts_per_line=11, line_len_m=5.0,
+              raster_size=3000, origin_size=(900, 1600), with_nuscenes=False, extra_labels=False)
+
+
+def build_scene(args, seed, device, frame_range=None):
+    """ClipManager + HBM-resident frames of scene `seed`.  frame_range = (lo, hi): only the frames of rendered
+    positions lo..hi-1 (image indices lo+1..hi) are made resident (frame-sharded scenes)."""
+    from cama_amd.dataset import ClipManager
+    from cama_amd.frames import DeviceFrameSource
+    from cama_amd.synth import DEFAULT_CAMA_CONFIGS, frame_pattern
+    H, W = args.height, args.width
+    tmp = tempfile.mkdtemp(prefix=f"cama_bench_s{seed}_")
+    clip = os.path.join(tmp, "clip")
+    write_scene_clip(args, seed, clip)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W)), clip)
+    replace_map(cm, args, seed)
+    raw = getattr(args, "raw_frames", False)
+    fh, fw = (900, 1600) if raw else (H, W)
+    per_frame = 6 * fh * fw * 3
+    first_idx, n_idx = (0, args.frames + 1) if frame_range is None else (frame_range[0] + 1, frame_range[1] - frame_range[0])
+    # image index i of scene `seed` = bytes [i * per_frame, (i + 1) * per_frame) of pattern stream `seed`
+    frames = frame_pattern(seed, (n_idx, 6, fh, fw, 3), device, first=first_idx * per_frame)
+    if raw:
         from cama_amd.frames import RawDeviceFrameSource
-        frames = torch.randint(0, 256, (args.frames + 1, 6, 900, 1600, 3), dtype=torch.uint8, device=device,
-                               generator=gen)
+        assert frame_range is None
         cm.set_frame_source(RawDeviceFrameSource(frames, cm.cm_list, fused=not getattr(args, "unfused_resample", False)))
     else:
-        frames = torch.randint(0, 256, (args.frames + 1, 6, H, W, 3), dtype=torch.uint8, device=device, generator=gen)
-        cm.set_frame_source(DeviceFrameSource(frames))
+        cm.set_frame_source(DeviceFrameSource(frames, index_offset=first_idx))
     return cm, frames, clip
 
 
@@ -162,13 +200,118 @@ def cpu_baseline(cm, frames, clip, args, budget_s):
 
 
 def pmc_traffic(config_key):
-    """HBM bytes per overlay launch from a committed rocprofv3 --pmc run (profiles/pmc_traffic.json), else None."""
+    """(HBM bytes per overlay launch, source) from a committed rocprofv3 --pmc run (profiles/pmc_traffic.json) of the
+    same configuration, else (None, None).  A cross-reference, not a measurement of the current run."""
     p = os.path.join(REPO, "profiles", "pmc_traffic.json")
     try:
         rec = json.load(open(p))
-        return rec["bytes_per_launch"] if rec.get("config") == config_key else None
+        if rec.get("config") == config_key:
+            return rec["bytes_per_launch"], "profiles/pmc_traffic.json (" + rec.get("source", "rocprofv3 --pmc") + ")"
     except (OSError, ValueError, KeyError):
-        return None
+        pass
+    return None, None
+
+
+class Job:
+    """One timed workload on this rank: a list of (scene id, ClipManager, frames) and how to step through them."""
+
+    def __init__(self, args, scene_ids, device, frame_range=None):
+        import torch
+        from cama_amd import runtime
+        self.args, self.device, self.frame_range = args, device, frame_range
+        self.scenes = [(sid,) + build_scene(args, sid, device, frame_range) for sid in scene_ids]
+        self.eng = runtime.engine()
+        self.pipelined = not args.no_pipeline and not args.raw_frames
+        self.N = 0
+        self.poses = {}
+        for sid, cm, _, _ in self.scenes:
+            idx, w2c = cm.frame_poses("cama")
+            assert len(idx) == args.frames, (len(idx), args.frames)
+            self.N = max(self.N, cm._static("cama").device().N)
+        lo, hi = frame_range if frame_range is not None else (0, args.frames)
+        self.lo, self.hi, self.F = lo, hi, hi - lo
+        self.out = None
+        if self.scenes and self.F:
+            rig = self.scenes[0][1]._rig()
+            self.out = torch.empty(self.eng.mosaic_shape(rig, self.F), dtype=torch.uint8, device=device)   # shared
+
+    def step(self, out=None):
+        for sid, cm, _, _ in self.scenes:
+            if not self.F:
+                continue
+            poses = None
+            if self.frame_range is not None:                            # this rank's slice of the clip's poses
+                idx_all, w2c_all = cm.frame_poses("cama")
+                poses = (idx_all[self.lo:self.hi], w2c_all[self.lo:self.hi])
+            cm.render_clip("cama", out=self.out if out is None else out, pipelined=self.pipelined, poses=poses)
+
+    def run(self, steps, warmup, sync_all, prof_every):
+        import ctypes
+        from cama_amd import _lib
+        L = _lib.lib()
+        for _ in range(warmup):
+            self.step()
+        self.eng.join()
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            if prof_every > 0:                                          # live hipEvent timing of every n-th overlay
+                L.cama_profile_enable(1 if k % prof_every == 0 else 0)
+            self.step()
+        self.eng.join()
+        sync_all()
+        dt = time.perf_counter() - t0
+        ov_ms, ov_n = ctypes.c_double(0.0), ctypes.c_int32(0)
+        L.cama_profile_collect(ctypes.byref(ov_ms), ctypes.byref(ov_n))
+        L.cama_profile_enable(0)
+        return dt, ov_ms.value, ov_n.value
+
+    def scene_hashes(self, sample_frames=None):
+        """Untimed: render every scene once more (plain single-stream path) and hash it.  Whole-scene jobs: one
+        (scene id, lo, hi) per scene.  Frame-sharded jobs: one (frame position, lo, hi) per sampled frame in range."""
+        import torch
+        from cama_amd import shard
+        out = []
+        for sid, cm, _, _ in self.scenes:
+            if not self.F:
+                continue
+            poses = None
+            if self.frame_range is not None:
+                idx_all, w2c_all = cm.frame_poses("cama")
+                poses = (idx_all[self.lo:self.hi], w2c_all[self.lo:self.hi])
+            self.out.zero_()
+            cm.render_clip("cama", out=self.out, pipelined=False, poses=poses)
+            torch.cuda.synchronize(self.device)
+            if self.frame_range is None:
+                out.append((sid,) + shard.overlay_hash(self.out))
+            else:
+                for f in sample_frames or []:
+                    if self.lo <= f < self.hi:
+                        out.append((f,) + shard.overlay_hash(self.out[f - self.lo]))
+        return out
+
+    def frames_per_launch(self):
+        if not self.scenes or not self.F:
+            return 0.0
+        cm = self.scenes[0][1]
+        per_call = max(1, min(self.F, self.eng.max_frames_per_call(cm._static("cama").device(), cm._rig(),
+                                                                   pipelined=self.pipelined)))
+        return self.F / float(-(-self.F // per_call))                   # render_clip splits big clips into launches
+
+    def free(self):
+        self.scenes, self.out = [], None
+
+
+def stress_sample_frames(n_frames):
+    """Frame positions whose hashes are checked in the frame-sharded stress: first and last frame of every rank's range
+    for 1, 2, 4 and 8 ranks."""
+    from cama_amd import shard
+    s = set()
+    for w in (1, 2, 4, 8):
+        for lo, hi in shard.frame_ranges(n_frames, w):
+            if hi > lo:
+                s.update((lo, hi - 1))
+    return sorted(s)
 
 
 def main():
@@ -193,26 +336,7 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from cama_amd import _lib, runtime, shard
-    n_scenes = args.scenes if args.scenes > 0 else world
-    cost = shard.scene_cost(args.frames, args.verts, args.width, args.height)
-    mine = shard.assign_scenes([cost] * n_scenes, world)[rank]           # scene ids of this rank (seed = scene id)
-    if args.shard_frames:
-        mine = [0]                                                       # the same scene on every rank
-    scenes = [build_scene(args, sid, device) for sid in mine]
-    cm, frames, clip = scenes[0] if scenes else (None, None, None)
-    eng = runtime.engine()
-    F = args.frames
-    N = 0
-    out = None
-    for scm, _, _ in scenes:
-        idx, _ = scm.frame_poses("cama")
-        assert len(idx) == args.frames, (len(idx), args.frames)
-        N = max(N, scm._static("cama").device().N)
-    f_lo, f_hi = shard.frame_ranges(args.frames, world)[rank] if args.shard_frames else (0, args.frames)
-    F = f_hi - f_lo                                                      # frames this rank renders per scene
-    if scenes:
-        out = torch.empty(eng.mosaic_shape(cm._rig(), F), dtype=torch.uint8, device=device)   # shared by the scenes
+    from cama_amd import shard
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -220,80 +344,148 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    pipelined = not args.no_pipeline and not args.raw_frames
-    def step():
-        for scm, _, _ in scenes:
-            poses = None
-            if args.shard_frames:                                        # this rank's slice of the clip's poses
-                idx_all, w2c_all = scm.frame_poses("cama")
-                poses = (idx_all[f_lo:f_hi], w2c_all[f_lo:f_hi])
-            scm.render_clip("cama", out=out, pipelined=pipelined, poses=poses)
-
-    for _ in range(args.warmup):
-        step()
-    eng.join()
-    sync_all()
-    L = _lib.lib()
-    # live hipEvent timing of the overlay kernel: sampled (every `prof_every`-th step) because a timed event pair is
-    # two extra barrier packets on the launch stream
     prof_every = int(os.environ.get("CAMA_BENCH_PROFILE_EVERY", "8"))
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if prof_every > 0:
-            L.cama_profile_enable(1 if k % prof_every == 0 else 0)
-        step()
-    eng.join()
-    sync_all()
-    dt = time.perf_counter() - t0
-    import ctypes
-    ov_ms, ov_n = ctypes.c_double(0.0), ctypes.c_int32(0)
-    L.cama_profile_collect(ctypes.byref(ov_ms), ctypes.byref(ov_n))
-    L.cama_profile_enable(0)
-
     H, W = args.height, args.width
-    h_lo, h_hi = shard.overlay_hash(out) if out is not None else (0, 0)   # checksum of the last mosaics (untimed)
-    rec = [float(F * args.steps * len(scenes)), dt, ov_ms.value, float(ov_n.value), float(N),
-           float(args.steps) * len(scenes) * shard.scene_cost(F, N, W, H), float(h_lo % 2 ** 52), float(h_hi % 2 ** 52)]
-    # the one collective: metric all_gather over RCCL/xGMI
-    allrec = shard.gather_records(rec, device=device if backend == "nccl" else None)
-    agg = shard.reduce_metrics(allrec)
+
+    # ---------------------------------------------------------------- main workload
+    n_scenes = args.scenes if args.scenes > 0 else (1 if (world == 1 or args.shard_frames) else SWEEP_SCENES)
+    if args.shard_frames:
+        n_scenes = 1
+        mine = [0]                                                       # the same scene on every rank
+        frange = shard.frame_ranges(args.frames, world)[rank]
+    else:
+        cost = shard.scene_cost(args.frames, args.verts, W, H)
+        mine = shard.assign_scenes([cost] * n_scenes, world)[rank]       # scene ids of this rank (seed = scene id)
+        frange = None
+    job = Job(args, mine, device, frange)
+    dt, ov_ms, ov_n = job.run(args.steps, args.warmup, sync_all, prof_every)
+    N, F = job.N, job.F
+    key = workload_key(args.frames, args.verts, W, H, args.map, raw=args.raw_frames)
+    samples = stress_sample_frames(args.frames) if args.shard_frames else None
+    hashes = [] if args.no_verify else job.scene_hashes(samples)
+    metrics = [float(F * args.steps * len(job.scenes)), dt, ov_ms, float(ov_n), float(N),
+               float(args.steps) * len(job.scenes) * shard.scene_cost(F, N, W, H), job.frames_per_launch(), 0.0]
+    cm0, frames0, clip0 = (job.scenes[0][1:] if job.scenes else (None, None, None))
+    slots = max(16, -(-n_scenes // world) + 1)
+    report = [shard.pack_report(metrics, hashes, slots)]
+
+    # ---------------------------------------------------------------- nested stress (configs[4]), N > 1 default only
+    do_stress = world > 1 and not args.no_stress and not args.shard_frames and args.scenes == 0 and args.map == "lanes"
+    if do_stress:
+        job.free()
+        cm0 = frames0 = None
+        torch.cuda.empty_cache()
+        sargs = parse_args([])
+        sargs.map, sargs.verts, sargs.frames = "random", args.stress_verts, args.stress_frames
+        sargs.height, sargs.width, sargs.no_pipeline = H, W, args.no_pipeline
+        s_range = shard.frame_ranges(sargs.frames, world)[rank]
+        sjob = Job(sargs, [0], device, s_range)
+        s_steps, s_warm = max(1, args.steps // 4), max(1, args.warmup // 4)
+        sdt, sov_ms, sov_n = sjob.run(s_steps, s_warm, sync_all, prof_every)
+        s_samples = stress_sample_frames(sargs.frames)
+        s_hashes = [] if args.no_verify else sjob.scene_hashes(s_samples)
+        s_metrics = [float(sjob.F * s_steps), sdt, sov_ms, float(sov_n), float(sjob.N),
+                     float(s_steps) * shard.scene_cost(sjob.F, sjob.N, W, H), sjob.frames_per_launch(), float(s_steps)]
+        report.append(shard.pack_report(s_metrics, s_hashes, len(s_samples)))
+        s_key = workload_key(sargs.frames, sargs.verts, W, H, "random")
+
+    # ---------------------------------------------------------------- the one collective: all_gather over RCCL/xGMI
+    sizes = [len(r) for r in report]
+    allrep = shard.gather_reports(np.concatenate(report), device=device if backend == "nccl" else None)
+    rccl_world = dist.get_world_size() if use_dist else 1
 
     if rank == 0:
-        wall = agg["seconds"]
+        failures = []
+
+        def finish(block, n_metrics, golden_key, expect_units, what):
+            m, found, owner = shard.unpack_reports(block, n_metrics)
+            agg = shard.reduce_metrics(m)
+            golden = shard.load_golden_hashes(GOLDEN_SCENES, golden_key)
+            check = None
+            if not args.no_verify:
+                check = shard.verify_hashes(found, golden, expect_units)
+                check["golden"] = f"tests/golden/scene_hashes.json[{golden_key!r}]" if golden else None
+                check["units"] = what
+                if check["mismatched"] or check["missing"]:
+                    failures.append(f"{what} hash check failed for {golden_key}: {check}")
+            return m, agg, found, check
+
+        m, agg, found, check = finish(allrep[:, :sizes[0]], N_METRICS, key,
+                                      samples if args.shard_frames else range(n_scenes),
+                                      "frame positions" if args.shard_frames else "scenes")
         fps = agg["frames_per_s"]
         bytes_per_frame = 13 * N + 36 * W * H
-        launches = max(1.0, float(allrec[0, 3]))
-        ov_avg_ms = float(allrec[0, 2]) / launches
-        per_call = max(1, min(F, eng.max_frames_per_call(cm._static("cama").device(), cm._rig())))
-        frames_per_launch = F / float(-(-F // per_call)) if F else 0.0   # render_clip splits big clips into launches
-        achieved = bytes_per_frame * frames_per_launch / (ov_avg_ms * 1e-3) / 1e9 if ov_avg_ms > 0 else 0.0
-        cfg_key = f"N={N},F={F},{W}x{H}"
+        launches = max(1.0, float(m[0, 3]))
+        ov_avg_ms = float(m[0, 2]) / launches
+        fpl = float(m[0, 6])
+        achieved = bytes_per_frame * fpl / (ov_avg_ms * 1e-3) / 1e9 if ov_avg_ms > 0 else 0.0
+        traffic, traffic_source = pmc_traffic(f"N={N},F={F},{W}x{H}")
+        cfg_no = 4 if args.map == "random" else 3 if args.map == "site" else 2 if n_scenes > 1 else 1
         line = {
             "metric": "6-cam frames/sec (1600x900, ~10k map verts)" if (W, H) == (1600, 900)
                       else f"6-cam frames/sec ({W}x{H})",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if args.shard_frames else "weak",
+            "ms_per_step": agg["seconds"] / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if (world > 1 or args.shard_frames or n_scenes > 1) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: %d scene(s) over %d GPU(s), 6 cams x %d frames, %d densified "
-                                   "verts, %dx%d, frames resident in HBM" % (4 if args.map == "random" else 3 if args.map == "site" else 2 if n_scenes > world else 1,
-                                                                           n_scenes, world, F, N, W, H),
-                       "scenes": n_scenes,
-                       "frames_per_step": F, "verts": N, "width": W, "height": H, "map": args.map,
-                       "sharding": "one scene per rank, no data-path collective",
-                       "streams": "2 (binning of step k+1 overlaps overlay of step k)" if pipelined else "1"},
-            "overlay_hash_per_rank": agg["hash"],
-            "hbm_GBps_whole_step": bytes_per_frame * (float(allrec[0, 0]) / float(allrec[0, 1])) / 1e9,   # rank 0's GPU
-            "hbm_frac_whole_step": bytes_per_frame * (float(allrec[0, 0]) / float(allrec[0, 1])) / 1e9 / HBM_PEAK_GBS,
+            "config": {"workload": "BASELINE configs[%d]: %d scene(s) over %d GPU(s), 6 cams x %d frames each, %d "
+                                   "densified verts, %dx%d, frames resident in HBM; fixed total work"
+                                   % (cfg_no, n_scenes, world, args.frames, N, W, H),
+                       "scenes": n_scenes, "frames_per_scene": args.frames, "verts": N, "width": W, "height": H,
+                       "map": args.map,
+                       "sharding": ("contiguous frame ranges of one scene (shard.frame_ranges)" if args.shard_frames
+                                    else "whole scenes, longest-processing-time first (shard.assign_scenes)")
+                                   + ", no data-path collective",
+                       "streams": "2 (binning of launch k+1 overlaps overlay of launch k)" if job.pipelined else "1"},
+            "rccl_world": rccl_world, "collective": "one all_gather_into_tensor of %d int64 per rank (%s)" % (
+                allrep.shape[1], "RCCL" if (use_dist and backend == "nccl") else backend if use_dist else "no group"),
+            "per_rank_seconds": [float(x) for x in m[:, 1]],
+            "per_rank_frames": [float(x) for x in m[:, 0]],
+            "hash_check": check,
+            "scene_hashes": {str(k): ["%016x" % v[0], "%016x" % v[1]] for k, v in sorted(found.items())}
+                            if len(found) <= 8 else f"{len(found)} units (see hash_check)",
+            "hbm_GBps_whole_step": bytes_per_frame * (float(m[0, 0]) / float(m[0, 1])) / 1e9,   # rank 0's GPU
+            "hbm_frac_whole_step": bytes_per_frame * (float(m[0, 0]) / float(m[0, 1])) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "k_overlay", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(cfg_key),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "avg_launch_ms": ov_avg_ms, "launches": int(launches),
-                         "bytes_per_launch": bytes_per_frame * frames_per_launch},
+                         "bytes_per_launch": bytes_per_frame * fpl},
         }
         if args.raw_frames:
             line["config"]["workload"] += "; raw 1600x900 frames resampled on device each step"
-        if world == 1 and args.cpu_seconds > 0 and not args.raw_frames:
-            line["cpu_baseline"] = cpu_baseline(cm, frames, clip, args, args.cpu_seconds)
+            # this mode's kernel reads the raw frames and writes the resized mosaic: 3*C*(H0*W0 + H*W) bytes per frame
+            raw_bytes = 13 * N + 3 * 6 * (900 * 1600 + H * W)
+            ach = raw_bytes * fpl / (ov_avg_ms * 1e-3) / 1e9 if ov_avg_ms > 0 else 0.0
+            line["roofline"].update(kernel="k_overlay_raw*", achieved=ach, frac=ach / HBM_PEAK_GBS,
+                                    bytes_per_launch=raw_bytes * fpl, traffic=None, traffic_source=None)
+            line["hbm_GBps_whole_step"] = raw_bytes * (float(m[0, 0]) / float(m[0, 1])) / 1e9
+            line["hbm_frac_whole_step"] = line["hbm_GBps_whole_step"] / HBM_PEAK_GBS
+        if do_stress:
+            sm, sagg, sfound, scheck = finish(allrep[:, sizes[0]:], N_METRICS, s_key, s_samples, "frame positions")
+            s_bpf = 13 * int(sm[0, 4]) + 36 * W * H
+            s_l = max(1.0, float(sm[0, 3]))
+            s_ms = float(sm[0, 2]) / s_l
+            s_ach = s_bpf * float(sm[0, 6]) / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
+            line["stress"] = {
+                "workload": "BASELINE configs[4]: 1 scene of %d random verts x 6 cams x %d frames at %dx%d, contiguous "
+                            "frame ranges over %d GPU(s)" % (int(sm[0, 4]), sargs.frames, W, H, world),
+                "value": sagg["frames_per_s"], "unit": "frames/s", "steps": int(sm[0, 7]), "scaling": "strong",
+                "ms_per_step": sagg["seconds"] / max(1.0, float(sm[0, 7])) * 1e3,
+                "per_rank_seconds": [float(x) for x in sm[:, 1]], "per_rank_frames": [float(x) for x in sm[:, 0]],
+                "hash_check": scheck,
+                "roofline": {"bound": "hbm", "kernel": "k_overlay", "achieved": s_ach, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": s_ach / HBM_PEAK_GBS, "avg_launch_ms": s_ms,
+                             "bytes_per_launch": s_bpf * float(sm[0, 6]),
+                             "note": "algorithmic bytes; culled vertex blocks are never read, real traffic is lower"},
+            }
+        if failures:
+            print("\n".join(failures), file=sys.stderr, flush=True)
+            if use_dist:
+                dist.destroy_process_group()
+            sys.exit(3)                                          # a wrong render never prints a throughput line
+        if world == 1 and args.cpu_seconds > 0 and not args.raw_frames and cm0 is not None:
+            line["cpu_baseline"] = cpu_baseline(cm0, frames0, clip0, args, args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = fps / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -380,11 +380,19 @@ class ClipManager:
         assert tuple(out.shape) == shape
         if F == 0:
             return idx, out
-        step = frames_per_launch or eng.max_frames_per_call(dmap, rig)
-        T = eng._mats(w2c)
         crop = self.mm.crop_box()
         src_all = self.frame_source()
         fused_raw = getattr(src_all, "fused", False) and hasattr(src_all, "raw_batch")
+        if frames_per_launch:
+            step = frames_per_launch
+        else:
+            # sources that decode / allocate a batch per call (files on disk) count it against the per-call budget
+            resident = hasattr(src_all, "frames") or hasattr(src_all, "raw")
+            c0 = self.cm_list[0]
+            raw_bytes = rig.C * int(c0.height_origin) * int(c0.width_origin) * 3 if fused_raw else None
+            step = eng.max_frames_per_call(dmap, rig, resident_frames=resident, src_bytes_per_frame=raw_bytes,
+                                           pipelined=pipelined)
+        T = eng._mats(w2c)
         for lo in range(0, F, step):
             hi = min(F, lo + step)
             if fused_raw:      # raw sensor frames: undistort + resize inside the overlay kernel

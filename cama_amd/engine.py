@@ -181,7 +181,17 @@ class Engine:
         with torch.cuda.device(self.device):
             N = int(table["seg_off"][-1])
             S = int(table["seg_num"].shape[0])
-            is64 = bool(lift and bev_height is not None and bev_height.dtype == np.float64)
+            # The raster's dtype decides the vertex dtype: the reference concatenates float32 xy with the gathered
+            # heights (cama/reproject.py:96-103), i.e. numpy promotion of (float32, raster dtype) -- float32 for
+            # float16 / int8 / int16 / uint8 / uint16 rasters, float64 for float64 / int32 / int64 ones.  Normalise the
+            # raster to that type BEFORE anything is sized from it (every such conversion is exact).
+            bev = None
+            if lift:
+                bev = np.asarray(bev_height)
+                assert bev.ndim == 2
+                res = np.result_type(np.float32, bev.dtype)
+                bev = bev.astype(np.float64 if res == np.float64 else np.float32, copy=False)
+            is64 = bool(lift and bev.dtype == np.float64)
             dt = torch.float64 if is64 else torch.float32
             soa = torch.empty((3, N), dtype=dt, device=self.device)
             colour = torch.empty((N,), dtype=torch.uint8, device=self.device)
@@ -196,11 +206,6 @@ class Engine:
             raster = None
             rows = cols = 0
             if lift:
-                bev = np.asarray(bev_height)
-                if bev.dtype not in (np.float32, np.float64):
-                    bev = bev.astype(np.float64)
-                    is64 = True
-                assert bev.ndim == 2
                 rows, cols = int(bev.shape[0]), int(bev.shape[1])
                 raster = up(bev)
             es = soa.element_size()
@@ -535,17 +540,26 @@ class Engine:
                 pass
             self._pipe = None
 
-    def max_frames_per_call(self, dmap, rig, budget_bytes=None):
-        """Largest F whose worst-case stamp scratch fits `budget_bytes` (and 32-bit stamp offsets).  Default budget:
-        a quarter of the free HBM, at most 64 GB -- sized for 288 GB parts, so that 4*10^6-vertex site maps still render
-        40 frames per launch (the scratch is worst-case: every vertex visible in every camera)."""
+    def max_frames_per_call(self, dmap, rig, budget_bytes=None, resident_frames=True, src_bytes_per_frame=None,
+                            pipelined=False):
+        """Largest F whose per-call memory fits `budget_bytes` (and 32-bit stamp offsets).  Per frame: the worst-case
+        stamp scratch (every vertex visible in every camera; two slots when pipelined) and -- unless the source frames
+        and the mosaic are already resident (`resident_frames`, the bench / streaming case) -- the decoded source batch
+        and its mosaic slice, which a disk-backed source allocates per call.  Default budget: a quarter of the free HBM,
+        at most 64 GB -- sized for 288 GB parts, so that 4*10^6-vertex site maps still render 40 frames per launch."""
         if budget_bytes is None:
             free, _ = _torch().cuda.mem_get_info(self.device)
             budget_bytes = min(64 << 30, max(1 << 30, free // 4))
         per = max(1, self.lib.cama_render_scratch_bytes(dmap.N, 1, rig.C, rig.H, rig.W, self.radius))
+        if pipelined:
+            per *= 2
+        if not resident_frames:
+            src = src_bytes_per_frame if src_bytes_per_frame is not None else rig.C * rig.H * rig.W * 3
+            per += int(src) + rig.C * rig.H * rig.W * 3
         f_budget = max(1, int(budget_bytes // per))
         f_off = max(1, int(((1 << 32) - 1) // max(1, rig.C * max(1, dmap.N) * 2)))
-        return min(f_budget, f_off, 65535)
+        cap = 65535 if resident_frames else 512            # a disk-backed batch is decoded and held as a whole
+        return min(f_budget, f_off, cap)
 
     def stamp_points(self, image, vu, colour_id):
         """In-place render_maps on one device image [H,W,3]: points (n,2) (v,u) float64 in draw order."""

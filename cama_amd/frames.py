@@ -71,29 +71,47 @@ def read_bgr(path):
 
 def undistort_rectify_map(K_origin, dist, K_new, W, H):
     """float32 (mapx, mapy), each (H,W): source pixel of every destination pixel -- what
-    cv2.initUndistortRectifyMap(K_origin, dist, None, K_new, (W,H), CV_32FC1) computes (reproject.py:238), in
-    float64 then cast: normalise with K_new^-1, apply the rational + tangential + thin-prism distortion model,
-    project with K_origin.  For zero distortion and K_new = diag(sx, sy, 1) K_origin this is src = dst / scale."""
-    K0 = np.asarray(K_origin, np.float64)
-    ir = np.linalg.inv(np.asarray(K_new, np.float64))
+    cv2.initUndistortRectifyMap(K_origin, dist, None, K_new, (W,H), CV_32FC1) computes (reproject.py:238), following
+    OpenCV's scalar loop operation for operation (imgproc undistort: closed-form 3x3 inverse of K_new, row-incremental
+    _x/_y/_w, w = 1./_w, rational + tangential + thin-prism model, u = fx*xd + u0 with NO skew term), vectorised:
+    the row-incremental sums are np.add.accumulate along the row, which adds in the same order.  Bit-identical to the
+    checker's C restatement (oracle_undistort_map).  For zero distortion and K_new = diag(sx, sy, 1) K_origin this is
+    src = dst / scale.  The tilted-sensor coefficients (dist[12:14]) are not supported and raise."""
+    K0 = np.asarray(K_origin, np.float64).reshape(3, 3)
+    S = [float(v) for v in np.asarray(K_new, np.float64).reshape(9)]
     k = np.zeros(14)
-    d = np.asarray(dist, np.float64).reshape(-1)
+    d = np.asarray([] if dist is None else dist, np.float64).reshape(-1)
     k[:min(14, d.size)] = d[:14]
-    k1, k2, p1, p2, k3, k4, k5, k6, s1, s2, s3, s4 = k[:12]
-    j = np.arange(W, dtype=np.float64)[None, :]
-    i = np.arange(H, dtype=np.float64)[:, None]
-    xw = j * ir[0, 0] + i * ir[0, 1] + ir[0, 2]
-    yw = j * ir[1, 0] + i * ir[1, 1] + ir[1, 2]
-    w = j * ir[2, 0] + i * ir[2, 1] + ir[2, 2]
-    x, y = xw / w, yw / w
+    if k[12] != 0.0 or k[13] != 0.0:
+        raise NotImplementedError("tilted-sensor distortion coefficients (tauX, tauY) are not supported")
+    k1, k2, p1, p2, k3, k4, k5, k6, s1, s2, s3, s4 = (float(v) for v in k[:12])
+    # cv::invert, 3x3 closed form: inverse = adjugate * (1/det)
+    det = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6])
+    if det == 0.0:
+        raise ValueError("singular new camera matrix")
+    dd = 1.0 / det
+    ir = [(S[4] * S[8] - S[5] * S[7]) * dd, (S[2] * S[7] - S[1] * S[8]) * dd, (S[1] * S[5] - S[2] * S[4]) * dd,
+          (S[5] * S[6] - S[3] * S[8]) * dd, (S[0] * S[8] - S[2] * S[6]) * dd, (S[2] * S[3] - S[0] * S[5]) * dd,
+          (S[3] * S[7] - S[4] * S[6]) * dd, (S[1] * S[6] - S[0] * S[7]) * dd, (S[0] * S[4] - S[1] * S[3]) * dd]
+    i = np.arange(H, dtype=np.float64)
+
+    def along_rows(start, step):                     # _v = start_i, then `_v += step` per column
+        a = np.full((H, W), step, np.float64)
+        a[:, 0] = start
+        return np.add.accumulate(a, axis=1)
+    _x = along_rows(i * ir[1] + ir[2], ir[0])
+    _y = along_rows(i * ir[4] + ir[5], ir[3])
+    _w = along_rows(i * ir[7] + ir[8], ir[6])
+    w = 1.0 / _w
+    x, y = _x * w, _y * w
     x2, y2 = x * x, y * y
     r2 = x2 + y2
-    xy2 = 2 * x * y
+    _2xy = 2 * x * y
     kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2)
-    xd = x * kr + p1 * xy2 + p2 * (r2 + 2 * x2) + s1 * r2 + s2 * r2 * r2
-    yd = y * kr + p1 * (r2 + 2 * y2) + p2 * xy2 + s3 * r2 + s4 * r2 * r2
-    u = K0[0, 0] * xd + K0[0, 1] * yd + K0[0, 2]
-    v = K0[1, 1] * yd + K0[1, 2]
+    xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2) + s1 * r2 + s2 * r2 * r2
+    yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy + s3 * r2 + s4 * r2 * r2
+    u = float(K0[0, 0]) * 1.0 * xd + float(K0[0, 2])
+    v = float(K0[1, 1]) * 1.0 * yd + float(K0[1, 2])
     return np.ascontiguousarray(u.astype(np.float32)), np.ascontiguousarray(v.astype(np.float32))
 
 

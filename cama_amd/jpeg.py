@@ -70,13 +70,25 @@ def parse_header(data):
 
 
 def _parse_header(data):
-    """Walk the marker segments up to SOS (T.81 B.2).  Returns a JpegHeader whose `quant` is (3,64) uint16 in natural
-    order, `huff` the raw DHT payloads {(class, id): bytes}, and [scan_start, scan_end) the entropy-coded bytes."""
+    """Walk the marker segments up to SOS (T.81 B.2); anything this decoder does not handle -- including truncated or
+    malformed segments -- raises Unsupported, which sends the image to the host decoder."""
+    try:
+        return _parse_header_strict(data)
+    except Unsupported:
+        raise
+    except (IndexError, ValueError, KeyError) as e:          # truncated DQT / DHT / SOF / SOS payloads
+        raise Unsupported(f"malformed header: {e}") from None
+
+
+def _parse_header_strict(data):
+    """Returns a JpegHeader whose `quant` is (3,64) uint16 in natural order, `huff` the raw DHT payloads
+    {(class, id): bytes}, and [scan_start, scan_end) the entropy-coded bytes."""
     if data[:2] != b"\xff\xd8":
         raise Unsupported("not a JPEG")
     n = len(data)
     i = 2
     qt, huff, frame, dri = {}, {}, None, 0
+    adobe_transform = None
     while i + 4 <= n:
         if data[i] != 0xFF:
             raise Unsupported("marker expected")
@@ -108,6 +120,8 @@ def _parse_header(data):
             raise Unsupported("not baseline sequential DCT")
         elif m == 0xDD:
             dri = (seg[0] << 8) | seg[1]
+        elif m == 0xEE and len(seg) >= 12 and bytes(seg[:5]) == b"Adobe":
+            adobe_transform = seg[11]                        # APP14: 0 = no colour transform (RGB / CMYK), 1 = YCbCr
         elif m == 0xDA:
             if frame is None:
                 raise Unsupported("SOS before SOF")
@@ -125,6 +139,14 @@ def _parse_header(data):
         raise Unsupported("component count / size")
     comps = [(frame[6 + 3 * k], frame[7 + 3 * k] >> 4, frame[7 + 3 * k] & 15, frame[8 + 3 * k]) for k in range(h.ncomp)]
     h.restart_interval = dri
+    if h.ncomp == 3:
+        # libjpeg's colour-space guess (jdapimin.c default_decompress_parms): Adobe transform 0 or component ids
+        # 'R','G','B' mean the samples are RGB already -- this decoder always applies YCbCr -> RGB, so hand those back
+        ids = tuple(c[0] for c in comps)
+        if adobe_transform == 0 or (adobe_transform is None and ids == (0x52, 0x47, 0x42)):
+            raise Unsupported("RGB-coded JPEG (no YCbCr transform)")
+        if adobe_transform not in (None, 0, 1):
+            raise Unsupported("unknown Adobe colour transform")
     if seg[0] != h.ncomp or tuple(seg[1 + 2 * h.ncomp:4 + 2 * h.ncomp]) != (0, 63, 0):
         raise Unsupported("not one interleaved full-spectrum scan")
     h.comp_dc, h.comp_ac = [0, 0, 0], [0, 0, 0]

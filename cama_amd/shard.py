@@ -8,7 +8,7 @@ run (RCCL over xGMI on the GPU box, gloo in the CPU tests).
 """
 import numpy as np
 
-RECORD_FIELDS = ("frames", "seconds", "overlay_ms", "overlay_launches", "verts", "bytes", "hash_lo", "hash_hi")
+RECORD_FIELDS = ("frames", "seconds", "overlay_ms", "overlay_launches", "verts", "bytes", "frames_per_launch", "aux")
 
 
 def assign_scenes(costs, world):
@@ -46,16 +46,19 @@ def scene_cost(n_frames, n_verts, W, H, cams=6):
 _HASH_MULT = 0x9E3779B97F4A7C15                 # odd 64-bit constant (golden ratio)
 
 
-def overlay_hash_np(arr):
+def overlay_hash_np(arr, chunk_words=1 << 22):
     """numpy twin of overlay_hash (what the oracle side hashes with): (lo, hi) uint64 as Python ints."""
     b = np.ascontiguousarray(arr).reshape(-1).view(np.uint8)
     n8 = (b.size // 8) * 8
     w = b[:n8].view(np.uint64)
     tail = int(b[n8:].astype(np.uint64).sum())
-    idx = np.arange(w.size, dtype=np.uint64)
+    lo = hi = 0
     with np.errstate(over="ignore"):
-        lo = int(w.sum(dtype=np.uint64))
-        hi = int((w * ((idx * np.uint64(2) + np.uint64(1)) * np.uint64(_HASH_MULT))).sum(dtype=np.uint64))
+        for a in range(0, w.size, chunk_words):
+            c = w[a:a + chunk_words]
+            idx = np.arange(a, a + c.size, dtype=np.uint64)
+            lo += int(c.sum(dtype=np.uint64))
+            hi += int((c * ((idx * np.uint64(2) + np.uint64(1)) * np.uint64(_HASH_MULT))).sum(dtype=np.uint64))
     return (lo + tail) & 0xFFFFFFFFFFFFFFFF, (hi + 31 * tail) & 0xFFFFFFFFFFFFFFFF
 
 
@@ -175,5 +178,4 @@ def reduce_metrics(records):
     r = np.asarray(records, np.float64)
     frames, seconds = float(r[:, 0].sum()), float(r[:, 1].max())
     return {"frames": frames, "seconds": seconds, "frames_per_s": frames / seconds if seconds > 0 else 0.0,
-            "bytes": float(r[:, 5].sum()), "world": int(r.shape[0]),
-            "hash": [[int(a), int(b)] for a, b in zip(r[:, 6], r[:, 7])]}
+            "bytes": float(r[:, 5].sum()), "world": int(r.shape[0])}

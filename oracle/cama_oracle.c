@@ -227,3 +227,72 @@ void oracle_render_frame_alpha(const uint8_t *src, uint8_t *mosaic, int C, int H
             }
     }
 }
+
+/*
+ * cv2.initUndistortRectifyMap(K_origin, dist, None, K_new, (W,H), CV_32FC1) as called at
+ * cama/reproject.py:238 -- restated from OpenCV's published source (imgproc/src/undistort.dispatch.cpp,
+ * cv::initUndistortRectifyMap, and the scalar loop of initUndistortRectifyMapComputer in undistort.simd.hpp),
+ * operation by operation, in double, stored as float:
+ *
+ *   iR = (K_new * R).inv(DECOMP_LU), R = identity.  cv::invert takes its closed-form 3x3 branch for that method:
+ *        d = 1/det3(A); inverse = adjugate entries, each (a*b - c*d) * d                       [lapack.cpp, n == 3]
+ *   per row i:   _x = i*ir[1] + ir[2], _y = i*ir[4] + ir[5], _w = i*ir[7] + ir[8]
+ *   per column:  w = 1./_w; x = _x*w; y = _y*w;  ... distortion ...;  u = fx*invProj*xd' + u0;  v = fy*invProj*yd' + v0
+ *                then _x += ir[0], _y += ir[3], _w += ir[6]      (ROW-INCREMENTAL: rounding accumulates along the row)
+ *   u uses only fx and u0 of K_origin (no skew term).
+ * Tilt (tauX, tauY = dist[12], dist[13]) is the identity for tau = 0; non-zero tilt is refused (returns -1): the
+ * reference's calibrations carry 8 zero coefficients (dataset/nuscenes2clip.py:510-522).
+ *
+ * What this cannot pin (OpenCV is absent on both boxes, PARITY UNPINNED): OpenCV builds dispatch the row loop to a
+ * SIMD body where the CPU has one (universal intrinsics / AVX2: lanes computed as (_x + k*ir[0]) * (1/(_w + k*ir[6])),
+ * FMA where available), which rounds differently in the last ulp.  For the reference's zero-distortion 0.6 scale the
+ * quantity the remap consumes, cvRound(map*32), is 160*j/3 -- its fraction is 0, 1/3 or 2/3, never near 1/2 -- so
+ * last-ulp differences cannot change a pixel; tests/test_cv2_pins.py checks the real thing wherever cv2 exists.
+ */
+static double det3(const double *m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+int oracle_undistort_map(const double *K_origin, const double *dist, int ndist, const double *K_new, int W, int H,
+                         float *mapx, float *mapy)
+{
+    double k[14] = {0};
+    for (int i = 0; i < ndist && i < 14; ++i) k[i] = dist[i];
+    if (k[12] != 0.0 || k[13] != 0.0) return -1;
+    const double k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3], k3 = k[4], k4 = k[5], k5 = k[6], k6 = k[7];
+    const double s1 = k[8], s2 = k[9], s3 = k[10], s4 = k[11];
+    const double *S = K_new;                         /* Ar.colRange(0,3) * R with R = eye: exact */
+    double d = det3(S);
+    if (d == 0.0) return -2;
+    d = 1. / d;
+    double ir[9];
+    ir[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+    ir[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+    ir[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+    ir[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+    ir[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+    ir[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+    ir[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+    ir[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+    ir[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+    const double u0 = K_origin[2], v0 = K_origin[5], fx = K_origin[0], fy = K_origin[4];
+    for (int i = 0; i < H; ++i) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < W; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            double w = 1. / _w, x = _x * w, y = _y * w;
+            double x2 = x * x, y2 = y * y;
+            double r2 = x2 + y2, _2xy = 2 * x * y;
+            double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+            double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2) + s1 * r2 + s2 * r2 * r2);
+            double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy + s3 * r2 + s4 * r2 * r2);
+            /* matTilt = identity: vecTilt = (xd, yd, 1), invProj = 1./1 */
+            double invProj = 1.;
+            double u = fx * invProj * xd + u0;
+            double v = fy * invProj * yd + v0;
+            mapx[(size_t)i * W + j] = (float)u;
+            mapy[(size_t)i * W + j] = (float)v;
+        }
+    }
+    return 0;
+}

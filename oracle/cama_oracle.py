@@ -56,6 +56,8 @@ def lib():
         L.oracle_render_frame.restype = None
         L.oracle_render_frame_alpha.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, i32, vp, i32, vp]
         L.oracle_render_frame_alpha.restype = None
+        L.oracle_undistort_map.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
+        L.oracle_undistort_map.restype = i32
         _LIB = L
     return _LIB
 
@@ -385,29 +387,21 @@ def circle_halfwidths(radius):
 # --------------------------------------------------------------------------- frame resample (OpenCV restated)
 def undistort_map(K_origin, dist, K_new, W, H):
     """cv2.initUndistortRectifyMap(K_origin, dist, None, K_new, (W,H), CV_32FC1) as called at
-    cama/reproject.py:238, restated from OpenCV's documented model (calib3d/imgproc undistort): per destination
-    pixel normalise with inv(K_new), distort (k1,k2,p1,p2,k3,k4,k5,k6[,s1..s4]), project with K_origin; float64
-    arithmetic, float32 result.  PARITY UNPINNED (OpenCV absent).  Scalar loops on purpose (independent of the
-    product's vectorised builder)."""
-    K0 = np.asarray(K_origin, np.float64)
-    ir = np.linalg.inv(np.asarray(K_new, np.float64))
-    k = np.zeros(14)
-    d = np.asarray(dist, np.float64).reshape(-1)
-    k[:d.size] = d
+    cama/reproject.py:238: oracle_undistort_map (cama_oracle.c) restates OpenCV's published scalar loop operation by
+    operation -- closed-form 3x3 inverse of K_new, row-incremental _x/_y/_w, w = 1./_w, u = fx*invProj*xd + u0 (no
+    skew), float64 arithmetic, float32 result.  PARITY UNPINNED (OpenCV absent; tests/test_cv2_pins.py pins it
+    wherever cv2 is importable).  Non-zero tilt coefficients (dist[12:14]) raise."""
+    K0 = np.ascontiguousarray(np.asarray(K_origin, np.float64).reshape(3, 3))
+    Kn = np.ascontiguousarray(np.asarray(K_new, np.float64).reshape(3, 3))
+    d = np.ascontiguousarray(np.asarray(dist if dist is not None else [], np.float64).reshape(-1))
     mapx = np.zeros((H, W), np.float32)
     mapy = np.zeros((H, W), np.float32)
-    for i in range(H):
-        for j in range(W):
-            w = j * ir[2, 0] + i * ir[2, 1] + ir[2, 2]
-            x = (j * ir[0, 0] + i * ir[0, 1] + ir[0, 2]) / w
-            y = (j * ir[1, 0] + i * ir[1, 1] + ir[1, 2]) / w
-            x2, y2 = x * x, y * y
-            r2 = x2 + y2
-            kr = (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2) / (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2)
-            xd = x * kr + k[2] * 2 * x * y + k[3] * (r2 + 2 * x2) + k[8] * r2 + k[9] * r2 * r2
-            yd = y * kr + k[2] * (r2 + 2 * y2) + k[3] * 2 * x * y + k[10] * r2 + k[11] * r2 * r2
-            mapx[i, j] = K0[0, 0] * xd + K0[0, 1] * yd + K0[0, 2]
-            mapy[i, j] = K0[1, 1] * yd + K0[1, 2]
+    rc = lib().oracle_undistort_map(_ptr(K0), _ptr(d) if d.size else None, int(d.size), _ptr(Kn), int(W), int(H),
+                                    _ptr(mapx), _ptr(mapy))
+    if rc == -1:
+        raise NotImplementedError("tilted-sensor coefficients (tauX, tauY) are not restated")
+    if rc:
+        raise ValueError("singular new camera matrix")
     return mapx, mapy
 
 

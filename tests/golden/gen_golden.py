@@ -189,6 +189,37 @@ def mutate_pose_gaps(clip):
         np.savetxt(p, rows[keep])
 
 
+def mutate_single_point_labels(clip):
+    """Append 2-vertex labels SHORTER than 0.2 units (but >= 0.1): int(len / 0.1) == 1, so each densifies to exactly ONE
+    point (cama/reproject.py:53-63,83-93).  A one-point instance makes every matmul of the per-frame path a
+    (4,4)@(4,1) / (3,3)@(3,1) product, which numpy hands to BLAS gemv instead of gemm -- a different accumulation
+    order than the k-ordered FMA chain all multi-point instances follow."""
+    rng = np.random.default_rng(77)
+    c, s = np.cos(0.3), np.sin(0.3)                 # make_clip: drive from world_anchor (-290, -280) heading 0.3 rad
+    p = os.path.join(clip, "maps", "map_labels.json")
+    if os.path.exists(p):
+        labels = json.load(open(p))
+        for k in range(40):
+            a, l = rng.uniform(2.0, 45.0), rng.uniform(-7.0, 7.0)
+            x, y = -290.0 + a * c - l * s, -280.0 + a * s + l * c
+            px, py = (y + 300.0) / 0.1, (x + 300.0) / 0.1           # BEV pixels (reproject.py:36-40 inverted)
+            ang = rng.uniform(0, 2 * np.pi)
+            L = rng.uniform(0.105, 0.195)
+            labels.append({"attrs": {"type": ["lane_marking", "Road_teeth", "Crosswalk_Line"][k % 3]},
+                           "data": [[px, py], [px + L * np.cos(ang), py + L * np.sin(ang)]], "id": 9100 + k})
+        json.dump(labels, open(p, "w"))
+    p = os.path.join(clip, "maps", "map_nuscenes.json")
+    if os.path.exists(p):
+        labels = json.load(open(p))
+        for k in range(40):
+            x, y = rng.uniform(-25.0, 45.0), rng.uniform(-9.0, 9.0)   # metres, frame of the track's middle pose
+            ang = rng.uniform(0, 2 * np.pi)
+            L = rng.uniform(0.105, 0.195)
+            labels.append({"attrs": {"type": ["Road_teeth", "lane_marking", "Stop_Line"][k % 3]},
+                           "data": [[x, y], [x + L * np.cos(ang), y + L * np.sin(ang)]], "id": 9200 + k})
+        json.dump(labels, open(p, "w"))
+
+
 def run_pose_seek():
     rec = _Recorder()
     install_stubs(rec)
@@ -463,7 +494,9 @@ def main():
         print("reference not present; golden vectors are committed, nothing to do")
         return 0
     sys.path.insert(0, REPO)
-    only = {"pose_eval": run_pose_eval, "dataset_reader": run_dataset_reader}
+    only = {"pose_eval": run_pose_eval, "dataset_reader": run_dataset_reader,
+            "f_single": lambda: run_clip("f_single", dict(n_frames=4, seed=5, n_lines=3, verts_per_line=4, line_len_m=2.0,
+                                                           raster_size=400), mutate=mutate_single_point_labels)}
     if len(sys.argv) > 1 and sys.argv[1] in only:                 # regenerate one fixture only
         only[sys.argv[1]]()
         return 0
@@ -476,6 +509,8 @@ def main():
                                raster_size=300, with_cama=False))
     run_clip("e_crop", dict(n_frames=3, seed=4, n_lines=3, verts_per_line=4, line_len_m=14.0,
                             raster_size=300, with_cama=False))
+    run_clip("f_single", dict(n_frames=4, seed=5, n_lines=3, verts_per_line=4, line_len_m=2.0, raster_size=400),
+             mutate=mutate_single_point_labels)
     run_pose_seek()
     run_mosaic()
     run_pose_eval()

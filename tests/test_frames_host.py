@@ -52,3 +52,35 @@ def test_undistort_map_identity_scale_and_monotonic():
     assert np.array_equal(np.rint(mxi[0] * 32), np.arange(1600) * 32.0)
     mxd, _ = FR.undistort_rectify_map(K0, [-0.2, 0.05, 0, 0, 0, 0, 0, 0], Kn, 960, 540)
     assert not (mxd == mxd[0:1]).all()                                                       # distortion breaks separability
+
+
+def test_undistort_map_bit_identical_to_the_opencv_order_restatement():
+    """The product's vectorised builder against the checker's scalar C restatement of OpenCV's published loop
+    (oracle_undistort_map: closed-form inverse, row-incremental sums, no skew term): same bits, for plain scaling,
+    full rational + tangential + thin-prism distortion, and a K_new with skew and an off-centre principal point."""
+    import pytest
+    from oracle import cama_oracle as O
+    K0 = np.array([[1266.417203, 0.0, 816.2670197], [0.0, 1266.417203, 491.50706579], [0.0, 0.0, 1.0]])
+    Kn = K0.copy()
+    Kn[0] *= 960 / 1600
+    Kn[1] *= 540 / 900
+    Ks = np.array([[700.3, 1.7, 333.1], [0.0, 690.9, 201.7], [0.0, 0.0, 1.0]])
+    cases = [(K0, [0.0] * 8, Kn, 960, 540), (K0, [], K0, 160, 90),
+             (K0, [-0.21, 0.07, 1e-3, -2e-3, 0.01, 0.02, -0.01, 0.003, 1e-3, -1e-3, 2e-3, 5e-4], Kn, 96, 54),
+             (K0, [-0.05, 0.01, 0.0, 0.0, 0.0], Ks, 77, 41)]
+    for K_origin, dist, K_new, W, H in cases:
+        mx, my = FR.undistort_rectify_map(K_origin, dist, K_new, W, H)
+        ox, oy = O.undistort_map(K_origin, dist, K_new, W, H)
+        assert np.array_equal(mx.view(np.uint32), ox.view(np.uint32))
+        assert np.array_equal(my.view(np.uint32), oy.view(np.uint32))
+    # u = fx*xd + u0: a skew entry in K_origin is ignored, like OpenCV does
+    Kskew = K0.copy()
+    Kskew[0, 1] = 3.0
+    a, _ = FR.undistort_rectify_map(Kskew, [-0.1, 0.0, 0.0, 0.0], Kn, 64, 36)
+    b, _ = FR.undistort_rectify_map(K0, [-0.1, 0.0, 0.0, 0.0], Kn, 64, 36)
+    assert np.array_equal(a, b)
+    tilt = [0.0] * 12 + [0.01, 0.0]
+    with pytest.raises(NotImplementedError):
+        FR.undistort_rectify_map(K0, tilt, Kn, 8, 8)
+    with pytest.raises(NotImplementedError):
+        O.undistort_map(K0, tilt, Kn, 8, 8)

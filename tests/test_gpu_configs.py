@@ -1,0 +1,183 @@
+"""-m gpu parity for the multi-scene sweep (BASELINE configs[2]) and the 1e6-vertex stress (configs[4]).
+
+The expected values are oracle renders: tests/golden/scene_hashes.json holds shard.overlay_hash of the ORACLE's mosaics
+for bench.py's seeded scenes (tests/golden/gen_scene_hashes.py, CPU only), and a few scenes / frames are additionally
+compared byte for byte with the oracle here.  The pipelined multi-scene path is exercised the way bench.py --scenes 73
+drives it: many distinct scenes back to back, no join in between, the host far ahead of the GPU."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+
+import bench
+from cama_amd import shard
+from oracle import cama_oracle as O
+from tests.golden import gen_scene_hashes as G
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_hashes.json")
+
+
+def _args(**kw):
+    a = bench.parse_args([])
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def _golden(a):
+    key = bench.workload_key(a.frames, a.verts, a.width, a.height, a.map)
+    g = shard.load_golden_hashes(GOLDEN, key)
+    assert g, f"no golden entry for {key}"
+    return g
+
+
+def _render_pipelined_no_join(scenes, out, rounds):
+    """Every scene into its own slice of `out`, `rounds` times over, pipelined, never joined until the end."""
+    import torch
+    from cama_amd import runtime
+    eng = runtime.engine()
+    for _ in range(rounds):
+        for k, (cm, _, _) in enumerate(scenes):
+            cm.render_clip("cama", out=out[k], pipelined=True)
+    issued = int(eng.lib.cama_pipeline_issued(eng._pipe["handle"]))
+    eng.join()
+    torch.cuda.synchronize()
+    return issued
+
+
+def test_small_sweep_24_distinct_scenes_pipelined_equals_oracle():
+    """24 distinct scenes (own map, calibration, poses, frames), pipelined back to back with no join: every scene's
+    hash equals the oracle's (golden) and its unpipelined render; three scenes byte-equal to the oracle."""
+    import torch
+    from cama_amd import runtime
+    a = _args(frames=6, verts=3000, height=180, width=320)
+    dev = torch.device("cuda:0")
+    golden = _golden(a)
+    scenes = [bench.build_scene(a, s, dev) for s in range(24)]
+    eng = runtime.engine()
+    shape = eng.mosaic_shape(scenes[0][0]._rig(), a.frames)
+    out = torch.zeros((24,) + tuple(shape), dtype=torch.uint8, device=dev)
+    _render_pipelined_no_join(scenes, out, rounds=4)          # 96 launches > the pipeline's 64-event ring
+    for k, (cm, _, _) in enumerate(scenes):
+        assert shard.overlay_hash(out[k]) == golden[k], f"scene {k}: pipelined render differs from the oracle"
+        _, plain = cm.render_clip("cama")
+        torch.cuda.synchronize()
+        assert torch.equal(plain, out[k]), f"scene {k}: pipelined != plain"
+    for k in (0, 11, 23):
+        xyz, col, cams, w2c = G.scene_setup(a, k)
+        got = out[k].cpu().numpy()
+        for pos in range(a.frames):
+            assert np.array_equal(got[pos], G.render_frame(a, k, pos, xyz, col, cams, w2c)), (k, pos)
+
+
+@pytest.fixture(scope="module")
+def sweep_scenes():
+    import torch
+    a = _args()                                               # BASELINE configs[1]/[2] scene: 40 frames, 1600x900
+    dev = torch.device("cuda:0")
+    return a, [bench.build_scene(a, s, dev) for s in range(24)]
+
+
+def test_fullsize_sweep_24_scenes_pipelined_run_ahead(sweep_scenes):
+    """configs[2] at full size, first 24 scenes: the overlay of a launch lasts ~340 us while the host issues one in
+    ~150 us, so the host runs dozens of launches ahead; what a launch reads (its poses!) must survive until that launch
+    has run.  Every scene's hash must equal the oracle's render of that scene (golden), after three un-joined rounds."""
+    import torch
+    from cama_amd import runtime
+    a, scenes = sweep_scenes
+    golden = _golden(a)
+    eng = runtime.engine()
+    dev = torch.device("cuda:0")
+    shape = eng.mosaic_shape(scenes[0][0]._rig(), a.frames)
+    out = torch.zeros((len(scenes),) + tuple(shape), dtype=torch.uint8, device=dev)
+    issued0 = int(eng.lib.cama_pipeline_issued(eng._pipeline()["handle"]))
+    issued = _render_pipelined_no_join(scenes, out, rounds=3)
+    assert issued - issued0 == 3 * len(scenes)
+    assert int(eng.lib.cama_pipeline_completed(eng._pipe["handle"])) == issued
+    assert not eng._pipe["keep"]
+    bad = [k for k in range(len(scenes)) if shard.overlay_hash(out[k]) != golden[k]]
+    assert not bad, f"scenes {bad}: pipelined full-size render differs from the oracle's"
+    # allocator churn between launches must not matter either: interleave fresh allocations with un-joined launches
+    out.zero_()
+    junk = []
+    for k, (cm, _, _) in enumerate(scenes):
+        cm.render_clip("cama", out=out[k], pipelined=True)
+        junk.append(torch.full((4096,), float(k), dtype=torch.float64, device=dev))      # same size class as the poses
+        junk = junk[-2:]
+    eng.join()
+    torch.cuda.synchronize()
+    bad = [k for k in range(len(scenes)) if shard.overlay_hash(out[k]) != golden[k]]
+    assert not bad, f"scenes {bad} after allocator churn"
+
+
+def test_fullsize_scene_byte_equal_to_oracle_frames(sweep_scenes):
+    """Scene 17 of the sweep (never rendered by any other test), sampled frames byte for byte against the oracle."""
+    import torch
+    a, scenes = sweep_scenes
+    cm = scenes[17][0]
+    _, mosaic = cm.render_clip("cama")
+    torch.cuda.synchronize()
+    xyz, col, cams, w2c = G.scene_setup(a, 17)
+    for pos in (0, 13, 39):
+        assert np.array_equal(mosaic[pos].cpu().numpy(), G.render_frame(a, 17, pos, xyz, col, cams, w2c)), pos
+
+
+def test_stress_1e6_random_vertices_125_frames():
+    """configs[4], one rank's share (125 frames) at a reduced image size: 1e6 random vertices (Morton-sorted copy +
+    draw keys + block cull inside).  All frames: every changed pixel lies in a visible point's disc and carries a palette
+    colour, every visible point's centre pixel is stamped, renders are deterministic and pipelined == plain; sampled
+    frames equal the oracle (golden hashes + two frames byte for byte)."""
+    import torch
+    from cama_amd import runtime
+    a = _args(frames=125, verts=1000000, height=180, width=320, map="random")
+    dev = torch.device("cuda:0")
+    golden = _golden(a)
+    cm, frames, _ = bench.build_scene(a, 0, dev)
+    dmap = cm._static("cama").device()
+    assert dmap.N == 1000000 and dmap.sorted_soa is not None
+    idx, mosaic = cm.render_clip("cama")
+    torch.cuda.synchronize()
+    assert len(idx) == 125
+    for pos, want in golden.items():
+        assert shard.overlay_hash(mosaic[pos]) == want, f"frame {pos} differs from the oracle"
+    xyz, col, cams, w2c = G.scene_setup(a, 0)
+    for pos in (1, 93):
+        assert np.array_equal(mosaic[pos].cpu().numpy(), G.render_frame(a, 0, pos, xyz, col, cams, w2c)), pos
+    H, W = a.height, a.width
+    got_all = mosaic.cpu().numpy()
+    src_all = frames.cpu().numpy()
+    grey, gold = np.array([211, 211, 211], np.uint8), np.array([0, 215, 255], np.uint8)
+    stamped = 0
+    for pos in range(125):
+        flat = O.frame_project_flat(xyz, w2c[pos], cams, W, H)
+        for c in range(6):
+            r, q = divmod(c, 3)
+            cell = got_all[pos, r * H:(r + 1) * H, q * W:(q + 1) * W]
+            changed = (cell != src_all[idx[pos], c]).any(axis=-1)
+            vis = flat["vis"][c].astype(bool)
+            p = flat["vu"][c][vis].astype(np.int32)
+            allowed = np.zeros((H, W), bool)
+            for dy in range(-2, 3):
+                hw = [2, 1, 0][abs(dy)]
+                for dx in range(-hw, hw + 1):
+                    y, x = p[:, 0] + dy, p[:, 1] + dx
+                    ok = (y >= 0) & (y < H) & (x >= 0) & (x < W)
+                    allowed[y[ok], x[ok]] = True
+            assert not (changed & ~allowed).any(), (pos, c)
+            px = cell[allowed]                                  # every footprint pixel carries a palette colour
+            assert ((px == grey).all(axis=-1) | (px == gold).all(axis=-1)).all(), (pos, c)
+            stamped += len(p)
+    assert stamped > 125 * 1000
+    h0 = shard.overlay_hash(mosaic)
+    _, again = cm.render_clip("cama")
+    torch.cuda.synchronize()
+    assert shard.overlay_hash(again) == h0
+    out = torch.zeros_like(mosaic)
+    eng = runtime.engine()
+    for lo in range(0, 125, 25):                                # five un-joined pipelined launches of 25 frames
+        cm.render_clip("cama", out=out[lo:lo + 25], pipelined=True, poses=(idx[lo:lo + 25], cm.frame_poses("cama")[1][lo:lo + 25]))
+    eng.join()
+    torch.cuda.synchronize()
+    assert torch.equal(out, mosaic)

@@ -220,6 +220,17 @@ def test_device_static_map_float64_raster_and_edge_pixels(tmp_path):
     d32 = runtime.engine().build_static_map(table, lift=True, bev_height=bev.astype(np.float32))
     assert np.array_equal(d32.soa.cpu().numpy().T, np.concatenate([w["points"] for w in want32]))
     assert d32.colour.cpu().numpy().tolist() == [0] * want[0]["points"].shape[0] + [1] * want[1]["points"].shape[0]
+    # rasters that are neither float32 nor float64 (float16 / integer .npy): the vertex dtype follows numpy's promotion
+    # of (float32, raster dtype) like the reference's np.concatenate, decided BEFORE the vertex buffer is sized (a
+    # float32-sized buffer written with doubles overran by 4*N bytes)
+    import torch
+    for odd, is64 in ((bev.astype(np.float16), 0), ((bev * 100).astype(np.int16), 0), ((bev * 1e6).astype(np.int32), 1)):
+        want_odd = np.concatenate([w["points"] for w in mm.calculate_3d_instance_maps(odd, labels)])
+        assert want_odd.dtype == (np.float64 if is64 else np.float32)
+        d_odd = runtime.engine().build_static_map(table, lift=True, bev_height=odd)
+        assert d_odd.is_f64 == is64 and d_odd.soa.dtype == (torch.float64 if is64 else torch.float32)
+        assert np.array_equal(d_odd.soa.cpu().numpy().T, want_odd)
+        _ = torch.zeros(8, device="cuda").sum().item()          # the device is still healthy (no overrun)
 
 
 def test_fused_raw_frame_overlay_equals_resample_then_overlay(tmp_path):

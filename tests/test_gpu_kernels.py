@@ -74,6 +74,47 @@ def test_project_frames_matches_reference_golden(engine, tag, tmp_path):
                 assert np.array_equal(got2, gold)
 
 
+def test_single_point_instances_measured_deviation_on_device(engine, tmp_path, capsys):
+    """clip_f_single (one-point instances: the reference's matmuls become BLAS gemv): the kernels' FMA chain is
+    bit-exact on every multi-point instance and within 1e-9 px (bar 1e-4) on the one-point ones, no truncated pixel
+    flips; the device result equals the C oracle's bit for bit, and the rendered overlay equals the oracle's."""
+    import torch
+    from tests.helpers import single_point_deviation
+    g = load_golden("f_single")
+    clip = rebuild_clip(g, tmp_path)
+    att = O.read_attribute(clip)
+    cams = [O.camera_model(att, n) for n in CAMERA_NAMES]
+    rig = _rig(engine, cams)
+    W, H = cams[0]["W"], cams[0]["H"]
+    rng = np.random.default_rng(4)
+    for ds, static in _static_maps(clip).items():
+        xyz, col, counts, classes = O.flatten_instances(static)
+        assert int((counts == 1).sum()) >= 30
+        dmap = engine.upload_map(xyz, col)
+        frames = [(idx, w2c) for idx, w2c, _ in O.iter_frames(clip, att, DEFAULT_CAMA_CONFIGS, static, ds)]
+        w2c = np.stack([m for _, m in frames])
+        vu, vis, _ = (t.cpu().numpy() for t in engine.project_frames(dmap, rig, w2c))
+        pos = {idx: k for k, (idx, _) in enumerate(frames)}
+
+        def project(idx):
+            k = pos[idx]
+            return [vu[k, c][vis[k, c].astype(bool)] for c in range(len(cams))]
+        dev_multi, dev_single, n_single, flips = single_point_deviation(g, ds, [i for i, _ in frames], project)
+        with capsys.disabled():
+            print(f"\n[f_single/{ds}] device projector vs reference: multi-point max dev {dev_multi:.3e} px, one-point "
+                  f"max dev {dev_single:.3e} px over {n_single} projections, {flips} pixel flips")
+        assert dev_multi == 0.0 and n_single >= 30 and dev_single <= 1e-9 and flips == 0
+        src = rng.integers(0, 256, (len(frames), len(cams), H, W, 3), dtype=np.uint8)
+        out = engine.render_frames(dmap, rig, w2c, torch.from_numpy(src).to(engine.device)).cpu().numpy()
+        for k, (idx, m) in enumerate(frames):
+            flat = O.frame_project_flat(xyz, m, cams, W, H)
+            assert np.array_equal(vis[k], flat["vis"])
+            for c in range(len(cams)):
+                v = flat["vis"][c].astype(bool)
+                assert np.array_equal(vu[k, c][v], flat["vu"][c][v])
+            assert np.array_equal(out[k], O.frame_render_flat(src[k], flat["vu"], flat["vis"], col))
+
+
 def _random_scene(seed, N, F, W, H, C=6, spread=60.0):
     rng = np.random.default_rng(seed)
     xyz = np.stack([rng.uniform(-spread, spread, N), rng.uniform(-spread * 2, spread * 2, N),

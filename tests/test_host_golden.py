@@ -16,7 +16,7 @@ from tests.helpers import (CAMERA_NAMES, CLIP_TAGS, DEFAULT_CAMA_CONFIGS, GOLDEN
                            golden_instances, load_golden, rebuild_clip)
 
 
-@pytest.mark.parametrize("tag", CLIP_TAGS)
+@pytest.mark.parametrize("tag", CLIP_TAGS + ["f_single"])
 def test_clip_setup_and_frame_poses(tag, tmp_path):
     g = load_golden(tag)
     clip = rebuild_clip(g, tmp_path)

@@ -114,3 +114,27 @@ def test_plan_restart_interval_descriptors():
     assert all(d["plane_w"][0] == 0 for d in imgs[1:]) and [int(d["wg0"]) for d in imgs] == [0, 0, 1, 2]
     imgs[3]["first_block"] = 40                               # would run past the parent's blocks
     assert L.cama_jpeg_plan(imgs.ctypes.data, 4, 2048, info.ctypes.data) == -1 and b"parent" in L.cama_last_error()
+
+
+def test_header_parser_hands_back_what_it_cannot_decode():
+    """RGB-coded files (Adobe APP14 transform 0, or component ids 'R','G','B') and truncated headers raise Unsupported
+    -- the caller then uses the host decoder -- instead of being decoded with the wrong colour transform or crashing."""
+    import io
+    from PIL import Image
+    from cama_amd import jpeg as J
+    img = Image.fromarray(np.random.default_rng(0).integers(0, 256, (16, 16, 3), dtype=np.uint8))
+    b = io.BytesIO()
+    img.save(b, "JPEG", quality=90)
+    data = b.getvalue()
+    assert J._parse_header(data).width == 16
+    sof, sos = data.find(b"\xff\xc0"), data.find(b"\xff\xda")
+    rgb = bytearray(data)
+    for k, cid in enumerate(b"RGB"):
+        rgb[sof + 10 + 3 * k] = cid
+        rgb[sos + 5 + 2 * k] = cid
+    adobe0 = data[:2] + b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00" + data[2:]
+    adobe1 = data[:2] + b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x01" + data[2:]
+    assert J._parse_header(adobe1).width == 16                       # transform 1 = YCbCr: fine
+    for bad in (bytes(rgb), adobe0, data[:sof + 8], data[:sos + 6], data[:data.find(b"\xff\xdb") + 30]):
+        with pytest.raises(J.Unsupported):
+            J._parse_header(bad)

@@ -21,48 +21,105 @@ def test_assign_scenes_lpt_and_ranges():
     assert shard.scene_cost(40, 10000, 1600, 900) == 40 * (13 * 10000 + 36 * 1600 * 900)
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _fake_mosaic(scene):
     import torch
+    return (torch.arange(64 * 48 * 3, dtype=torch.int64) * (scene + 3) % 251).to(torch.uint8)
+
+
+def _worker(rank, world, port, q, corrupt_scene):
+    """What bench.py does after its timed region, on CPU tensors over gloo: hash every scene this rank rendered, pack
+    metrics + per-scene hashes into ONE int64 report, all_gather it, unpack, reduce and verify against golden hashes."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        costs = [shard.scene_cost(40, 10000 + 100 * i, 160, 90) for i in range(5)]
+        n_scenes = 5
+        costs = [shard.scene_cost(40, 10000 + 100 * i, 160, 90) for i in range(n_scenes)]
         mine = shard.assign_scenes(costs, world)[rank]
-        # each rank "renders" its scenes: here a deterministic byte pattern per scene stands in for the mosaic
-        frames, lo, hi = 0, 0, 0
+        # each rank "renders" its scenes: a deterministic byte pattern per scene stands in for the mosaic
+        hashes = []
         for s in mine:
-            m = (torch.arange(64 * 48 * 3, dtype=torch.int64) * (s + 3) % 251).to(torch.uint8)
-            a, b = shard.overlay_hash(m)
-            lo ^= a
-            hi ^= b
-            frames += 40
-        rec = [frames, 0.5 + 0.25 * rank, 1.0, 1.0, 10000, sum(costs[s] for s in mine), float(lo % 2 ** 52), float(hi % 2 ** 52)]
-        allrec = shard.gather_records(rec)
-        q.put((rank, mine, shard.reduce_metrics(allrec)))
+            m = _fake_mosaic(s)
+            if s == corrupt_scene:
+                m[100] ^= 1                                     # one wrong byte in one scene of one rank
+            hashes.append((s,) + shard.overlay_hash(m))
+        metrics = [40.0 * len(mine), 0.5 + 0.25 * rank, 1.0, 1.0, 10000.0, sum(costs[s] for s in mine), 40.0, 0.0]
+        slots = -(-n_scenes // world) + 1
+        allrep = shard.gather_reports(shard.pack_report(metrics, hashes, slots))
+        m, found, owner = shard.unpack_reports(allrep, len(metrics))
+        golden = {s: shard.overlay_hash_np(_fake_mosaic(s).numpy()) for s in range(n_scenes)}
+        check = shard.verify_hashes(found, golden, expect_units=range(n_scenes))
+        q.put((rank, mine, shard.reduce_metrics(m), check, owner, dist.get_world_size()))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_gather_and_reduce():
+def _run_two_ranks(corrupt_scene):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, corrupt_scene)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, s0, m0), (r1, s1, m1) = got
+    return got
+
+
+def test_two_rank_gloo_gather_reduce_and_hash_check():
+    (r0, s0, m0, c0, o0, w0), (r1, s1, m1, c1, o1, w1) = _run_two_ranks(corrupt_scene=-1)
     assert sorted(s0 + s1) == [0, 1, 2, 3, 4] and not set(s0) & set(s1)
-    assert m0 == m1                                         # every rank sees the same aggregate
+    assert m0 == m1 and c0 == c1 and w0 == w1 == 2         # every rank sees the same aggregate and verdict
     assert m0["frames"] == 200 and m0["seconds"] == 0.75 and m0["world"] == 2
     assert m0["frames_per_s"] == pytest.approx(200 / 0.75)
+    assert c0 == {"verified": 5, "unverified": [], "mismatched": [], "missing": []}
+    assert {s: o0[s] for s in s0} == {s: 0 for s in s0} and {s: o0[s] for s in s1} == {s: 1 for s in s1}
+
+
+def test_two_rank_gloo_wrong_scene_is_caught():
+    """A single wrong byte in one scene on one rank: the per-scene comparison with the golden hashes names it."""
+    (_, _, _, c0, _, _), _ = _run_two_ranks(corrupt_scene=3)
+    assert c0["mismatched"] == [3] and c0["verified"] == 4
+
+
+def test_report_roundtrip_and_verdicts():
+    big = (1 << 64) - 1
+    r0 = shard.pack_report([1.5, -2.25], [(3, big, 5), (7, 1, 1 << 63)], 4)
+    r1 = shard.pack_report([0.5, 9.0], [(4, 6, 7)], 4)
+    m, found, owner = shard.unpack_reports(np.stack([r0, r1]), 2)
+    assert m.tolist() == [[1.5, -2.25], [0.5, 9.0]]
+    assert found == {3: (big, 5), 7: (1, 1 << 63), 4: (6, 7)} and owner == {3: 0, 7: 0, 4: 1}
+    v = shard.verify_hashes(found, {3: (big, 5), 4: (6, 8)}, expect_units=[3, 4, 7, 9])
+    assert v == {"verified": 1, "unverified": [7], "mismatched": [4], "missing": [9]}
+    with pytest.raises(RuntimeError):                       # the same scene reported by two ranks
+        shard.unpack_reports(np.stack([r0, shard.pack_report([0.0, 0.0], [(3, 1, 1)], 4)]), 2)
+
+
+def test_committed_golden_hashes_cover_the_bench_workloads(repo_root):
+    import bench
+    path = os.path.join(repo_root, "tests", "golden", "scene_hashes.json")
+    a = bench.parse_args([])
+    sweep = shard.load_golden_hashes(path, bench.workload_key(a.frames, a.verts, a.width, a.height, "lanes"))
+    assert sorted(sweep) == list(range(bench.SWEEP_SCENES))                  # configs[2]: all 73 scenes
+    assert len(set(sweep.values())) == bench.SWEEP_SCENES                     # all distinct
+    stress = shard.load_golden_hashes(path, bench.workload_key(bench.STRESS["frames"], bench.STRESS["verts"], a.width,
+                                                               a.height, "random"))
+    assert sorted(stress) == bench.stress_sample_frames(bench.STRESS["frames"])
+
+
+def test_frame_pattern_is_device_independent():
+    import torch
+    from cama_amd.synth import frame_pattern, frame_pattern_np
+    a = frame_pattern_np(7, (3, 5, 8, 3))
+    assert np.array_equal(a, frame_pattern(7, (3, 5, 8, 3), "cpu", chunk_bytes=64).numpy())
+    assert np.array_equal(frame_pattern_np(7, (2, 5, 8, 3), first=5 * 8 * 3), a[1:])
+    assert np.array_equal(frame_pattern(7, (2, 5, 8, 3), "cpu", first=5 * 8 * 3).numpy(), a[1:])
+    assert not np.array_equal(frame_pattern_np(8, (3, 5, 8, 3)), a)
 
 
 def test_overlay_hash_detects_a_single_byte():
@@ -71,4 +128,8 @@ def test_overlay_hash_detects_a_single_byte():
     b = a.clone()
     b[777] ^= 1
     assert shard.overlay_hash(a) != shard.overlay_hash(b)
-    assert shard.overlay_hash(a) == shard.overlay_hash(a.numpy())
+    assert shard.overlay_hash(a) == shard.overlay_hash(a.numpy()) == shard.overlay_hash_np(a.numpy())
+    # position-weighted: swapping two rows changes the hash although the plain sum stays the same
+    c = a.reshape(125, 8).clone()
+    c[[3, 4]] = c[[4, 3]]
+    assert shard.overlay_hash(c)[0] == shard.overlay_hash(a)[0] and shard.overlay_hash(c)[1] != shard.overlay_hash(a)[1]
