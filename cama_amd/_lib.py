@@ -10,7 +10,7 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _u64 = ctypes.c_uint64
@@ -38,6 +38,10 @@ SIGNATURES = {
     "cama_overlay_frames_alpha": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
     "cama_overlay_frames_raw": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
                                        _vp, _vp, _vp, _sz, _vp]),
+    "cama_bgr_to_i420": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "cama_raw35_plan": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "cama_overlay_frames_raw35": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
+                                         _vp, _vp, _vp, _sz, _vp]),
     "cama_pipeline_create": (_i32, [_vp]),
     "cama_pipeline_destroy": (_i32, [_vp]),
     "cama_pipeline_render": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,

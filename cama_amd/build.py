@@ -7,7 +7,7 @@ _HERE = dirname(abspath(__file__))
 REPO = dirname(_HERE)
 SOURCES = [join(_HERE, "csrc", "cama_hip.hip")]
 DEVICE_HEADERS = [join(_HERE, "csrc", n) for n in ("project_kernels.hpp", "remap_device.hpp", "overlay_kernels.hpp",
-                                                    "resample_kernels.hpp", "map_kernels.hpp", "jpeg_kernels.hpp")]
+                                                    "resample_kernels.hpp", "map_kernels.hpp", "jpeg_kernels.hpp", "raw35_kernels.hpp", "egress_kernels.hpp")]
 HEADER = join(REPO, "include", "cama_hip.h")
 OUT = join(_HERE, "libcama_hip.so")
 # -ffp-contract=off: the fp64 FMA chains are written explicitly; nothing else may be fused

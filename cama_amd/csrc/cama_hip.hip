@@ -25,7 +25,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -101,8 +103,10 @@ struct Palette { uint32_t c[2]; uint32_t alpha256; };  // colours b | g<<8 | r<<
 #include "project_kernels.hpp"
 #include "remap_device.hpp"
 #include "overlay_kernels.hpp"
+#include "raw35_kernels.hpp"
 #include "resample_kernels.hpp"
 #include "map_kernels.hpp"
+#include "egress_kernels.hpp"
 #include "jpeg_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -157,8 +161,10 @@ int log2i(int v)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct ScratchLayout {
-    size_t counts, cursor, work_count, bin_off, fc_total, fc_base, stamps, work, list_cap, total;
+    size_t counts, cursor, work_count, seg_cnt, bin_off, fc_total, fc_base, stamps0, stamps, work, list_cap, total;
+    size_t zero_bytes;              // counts .. seg_cnt: cleared by one memset before the projection pass
     uint64_t capacity;
+    uint32_t nseg;
     int R, NB, bands_per_stamp;
 };
 
@@ -169,13 +175,17 @@ int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLay
     L.bands_per_stamp = radius > 0 ? 2 : 1;  // 2r+1 rows touch <= 2 bands when 2r <= R (checked by the caller)
     const size_t nbins = (size_t)F * C * L.NB, nfc = (size_t)F * C;
     L.capacity = (uint64_t)F * C * (uint64_t)N * L.bands_per_stamp;
+    L.nseg = (uint32_t)((N + BLOCK - 1) / BLOCK) * (BLOCK / SEG);   // one segment per wave of the projection grid
     size_t off = 0;
     L.counts = off;   off = align_up(off + nbins * 4, 256);
     L.cursor = off;   off = align_up(off + nbins * 4, 256);
-    L.work_count = off; off += 256;          // zeroed together with counts and cursor
+    L.work_count = off; off += 256;
+    L.seg_cnt = off;  off = align_up(off + nfc * L.nseg, 256);      // one byte per (frame, camera, segment)
+    L.zero_bytes = off - L.counts;
     L.bin_off = off;  off = align_up(off + nbins * 4, 256);
     L.fc_total = off; off = align_up(off + nfc * 4, 256);
     L.fc_base = off;  off = align_up(off + nfc * 4, 256);
+    L.stamps0 = off;  off = align_up(off + nfc * L.nseg * SEG * 8 + 8, 256);   // compacted per-segment stamps (worst case)
     L.stamps = off;   off = align_up(off + (size_t)L.capacity * 8 + 8, 256);   // >= 1 record: empty bins read stamps[0]
     // work lists of the crop cull: 8 (one per XCD), each up to ceil(vblocks / 8) * F uint32 items
     L.list_cap = (size_t)(((N + BLOCK - 1) / BLOCK + 7) / 8) * (size_t)F;
@@ -397,14 +407,15 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     uint32_t *fc_base = (uint32_t *)(base + L.fc_base);
     const int nfc = F * C;
 
-    // counts, cursor and the work-list counter are adjacent: one memset
-    HIP_TRY(hipMemsetAsync(counts, 0, L.bin_off - L.counts, s));
+    // counts, cursor, the work-list counter and the segment count table are adjacent: one memset
+    HIP_TRY(hipMemsetAsync(counts, 0, L.zero_bytes, s));
 
     FrameArgs a{};
     a.x = x; a.y = y; a.z = z; a.colour = colour_id; a.key = draw_key; a.bounds = block_bounds; a.N = N;
     a.w2c = w2c; a.c2cam = c2cam; a.K = K; a.C = C; a.W = W; a.H = H;
     memcpy(a.crop.v, crop, sizeof(a.crop.v));
     a.band_shift = log2i(L.R); a.NB = L.NB; a.radius = radius;
+    a.nseg = L.nseg; a.seg_cnt = (uint8_t *)(base + L.seg_cnt); a.stamps0 = (uint2 *)(base + L.stamps0);
     a.counts = counts; a.cursor = cursor; a.bin_off = bin_off; a.fc_base = fc_base;
     a.stamps = (uint2 *)(base + L.stamps);
     // XCD-aware mapping: workgroup (x, y) has linear id x + y * gridDim.x and runs on XCD id % 8.  With gridDim.x a
@@ -426,36 +437,26 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
                            w2c, cr, vblocks, (uint32_t)L.list_cap, work_count, work);
         HIP_TRY(hipGetLastError());
         if (xyz_is_f64)
-            hipLaunchKernelGGL((k_frames_bin_list<MODE_COUNT, double>), lgrid, dim3(BLOCK), hist_lds, s, a, work_count, work,
-                               vblocks, (uint32_t)L.list_cap);
+            hipLaunchKernelGGL(k_frames_project_list<double>, lgrid, dim3(BLOCK), hist_lds, s, a, work_count, work, vblocks,
+                               (uint32_t)L.list_cap);
         else
-            hipLaunchKernelGGL((k_frames_bin_list<MODE_COUNT, float>), lgrid, dim3(BLOCK), hist_lds, s, a, work_count, work,
-                               vblocks, (uint32_t)L.list_cap);
+            hipLaunchKernelGGL(k_frames_project_list<float>, lgrid, dim3(BLOCK), hist_lds, s, a, work_count, work, vblocks,
+                               (uint32_t)L.list_cap);
         HIP_TRY(hipGetLastError());
     } else if (N) {
         if (xyz_is_f64)
-            hipLaunchKernelGGL((k_frames_bin<MODE_COUNT, double>), fgrid, dim3(BLOCK), hist_lds, s, a);
+            hipLaunchKernelGGL(k_frames_project<double>, fgrid, dim3(BLOCK), hist_lds, s, a);
         else
-            hipLaunchKernelGGL((k_frames_bin<MODE_COUNT, float>), fgrid, dim3(BLOCK), hist_lds, s, a);
+            hipLaunchKernelGGL(k_frames_project<float>, fgrid, dim3(BLOCK), hist_lds, s, a);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_scan_bands, dim3(nfc), dim3(64), 0, s, counts, bin_off, fc_total, L.NB);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(64), 0, s, fc_total, fc_base, nfc);
     HIP_TRY(hipGetLastError());
-    if (N && use_list) {
-        if (xyz_is_f64)
-            hipLaunchKernelGGL((k_frames_bin_list<MODE_FILL, double>), lgrid, dim3(BLOCK), 2 * hist_lds, s, a, work_count,
-                               work, vblocks, (uint32_t)L.list_cap);
-        else
-            hipLaunchKernelGGL((k_frames_bin_list<MODE_FILL, float>), lgrid, dim3(BLOCK), 2 * hist_lds, s, a, work_count,
-                               work, vblocks, (uint32_t)L.list_cap);
-        HIP_TRY(hipGetLastError());
-    } else if (N) {
-        if (xyz_is_f64)
-            hipLaunchKernelGGL((k_frames_bin<MODE_FILL, double>), fgrid, dim3(BLOCK), 2 * hist_lds, s, a);
-        else
-            hipLaunchKernelGGL((k_frames_bin<MODE_FILL, float>), fgrid, dim3(BLOCK), 2 * hist_lds, s, a);
+    if (N) {
+        const dim3 sgrid((L.nseg + SCATTER_SEGS - 1) / SCATTER_SEGS, (unsigned)nfc);
+        hipLaunchKernelGGL(k_stamps_scatter, sgrid, dim3(BLOCK), align_up((size_t)2 * L.NB * 4, 16), s, a);
         HIP_TRY(hipGetLastError());
     }
     return CAMA_OK;
@@ -602,6 +603,109 @@ int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const fl
                         stream);
 }
 
+// cvRound(v * 32) as cv2.remap's fixed-point path does on float32 maps (round half to even)
+static inline long raw35_q(float v) { return lrintf(v * 32.0f); }
+
+int cama_raw35_plan(const float *mapx, const float *mapy, int32_t C, int32_t H, int32_t W, int32_t H0, int32_t W0,
+                    uint32_t *vrows, int32_t *band_rows, int32_t *max_src_rows)
+{
+    if (!mapx || !mapy || !vrows || !band_rows || !max_src_rows || C < 1 || H < 1 || W < 1 || H0 < 1 || W0 < 1 || H0 > 65535)
+        return fail(CAMA_EINVAL, "bad arguments");
+    *max_src_rows = 0;
+    // 12-pixel units, 16-byte chunk rows on both sides, the last unit's 20 source pixels exist, one unit per thread
+    const int R = band_rows_for(W), NB = (H + R - 1) / R;
+    if (W % 48 != 0 || ((int64_t)W0 * 3) % 16 != 0 || 5l * (W / 3) > W0 || R * (W / 12) > RAW35_MAX_BLOCK) return 0;
+    static const int off[3] = {0, 1, 3}, frac[3] = {0, 21, 11};
+    int most = 0;
+    for (int c = 0; c < C; ++c) {
+        for (int x = 0; x < W; ++x) {
+            const long sx = raw35_q(mapx[(size_t)c * W + x]);
+            const long x0 = sx >> 5, a = sx & 31;
+            if (x0 != 5l * (x / 3) + off[x % 3] || a != frac[x % 3]) return 0;
+            if (x0 < 0 || x0 + (a ? 1 : 0) >= W0) return 0;       // every weighted tap inside the frame
+        }
+        long prev = -1;
+        for (int y = 0; y < H; ++y) {
+            const long sy = raw35_q(mapy[(size_t)c * H + y]);
+            const long yy0 = sy >> 5, bw = sy & 31;
+            const uint32_t wt = (yy0 >= 0 && yy0 < H0) ? 32u - (uint32_t)bw : 0u;
+            const uint32_t wb = (yy0 + 1 >= 0 && yy0 + 1 < H0) ? (uint32_t)bw : 0u;
+            const long r0 = yy0 < 0 ? 0 : yy0 >= H0 ? H0 - 1 : yy0;
+            const long r1 = yy0 + 1 < 0 ? 0 : yy0 + 1 >= H0 ? H0 - 1 : yy0 + 1;
+            if (r0 < prev) return 0;                              // rows must not go backwards (bands stage a range)
+            prev = r0;
+            // a zero-weight bottom tap re-reads the top row instead of touching another source row
+            vrows[((size_t)c * H + y) * 2] = (uint32_t)r0 | ((uint32_t)(wb ? r1 : r0) << 16);
+            vrows[((size_t)c * H + y) * 2 + 1] = wt | (wb << 8);
+        }
+        for (int b = 0; b < NB; ++b) {
+            const int ya = b * R, yb = std::min(H, ya + R) - 1;
+            const uint32_t first = vrows[((size_t)c * H + ya) * 2] & 0xffffu;
+            uint32_t last = first;
+            for (int y = ya; y <= yb; ++y) last = std::max(last, vrows[((size_t)c * H + y) * 2] >> 16);
+            band_rows[((size_t)c * NB + b) * 2] = (int32_t)first;
+            band_rows[((size_t)c * NB + b) * 2 + 1] = (int32_t)(last - first + 1);
+            most = std::max(most, (int)(last - first + 1));
+        }
+    }
+    // the output of a band (R rows of W*3 bytes) is transposed through the staging area
+    if ((size_t)most * W0 < (size_t)R * W) return 0;
+    *max_src_rows = most;
+    return 1;
+}
+
+int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t *vrows, const int32_t *band_rows,
+                              int32_t max_src_rows, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                              int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                              const void *scratch, size_t scratch_bytes, void *stream)
+{
+    ScratchLayout L;
+    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+    if (F == 0) return CAMA_OK;
+    if (cols < 1) return fail(CAMA_EINVAL, "cols=%d", cols);
+    if (!raw || !vrows || !band_rows || !mosaic || !palette_bgr) return fail(CAMA_EINVAL, "NULL pointer argument");
+    const int upr = W / 12;
+    const unsigned items = (unsigned)L.R * (unsigned)upr;
+    if (W % 48 != 0 || ((int64_t)W0 * 3) % 16 != 0 || (uintptr_t)raw % 16 != 0 || (uintptr_t)mosaic % 16 != 0 ||
+        H0 < 1 || H0 > 65535 || 5ll * (W / 3) > W0 || items > RAW35_MAX_BLOCK || max_src_rows < 1 ||
+        (size_t)max_src_rows * W0 < (size_t)L.R * W)
+        return fail(CAMA_EINVAL, "the 3:5 raw overlay needs W %% 48 == 0, 5*W/3 <= W0, 16-byte aligned source rows and "
+                                 "mosaic and a plan from cama_raw35_plan (W=%d, W0=%d, rows=%d)", W, W0, max_src_rows);
+    Disc disc;
+    if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
+    hipStream_t s = (hipStream_t)stream;
+    const char *base = (const char *)scratch;
+    OverlayArgs o{};
+    o.src = raw; o.mosaic = mosaic; o.C = C; o.H = H; o.W = W; o.cols = cols; o.R = L.R; o.NB = L.NB;
+    const int rows = (C + cols - 1) / cols;
+    o.mosaic_row_bytes = (size_t)cols * W * 3;
+    o.mosaic_frame_bytes = (size_t)rows * H * o.mosaic_row_bytes;
+    o.counts = (const uint32_t *)(base + L.counts); o.bin_off = (const uint32_t *)(base + L.bin_off);
+    o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)(base + L.stamps);
+    o.disc = disc; o.pal = make_palette(palette_bgr);
+    o.H0 = H0; o.W0 = W0;
+    const unsigned block = (items + 63u) & ~63u;
+    const size_t lds = (size_t)max_src_rows * W0 * 3 + (size_t)L.R * W * 4;
+    if (lds > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the 3:5 raw overlay's LDS", W);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned nblocks = (unsigned)((size_t)F * rows * cols * L.NB);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_prof.on) {
+        ev0 = prof_event();
+        ev1 = prof_event();
+        if (ev0 && ev1) HIP_TRY(hipEventRecord(ev0, s));
+    }
+    hipLaunchKernelGGL(k_overlay_raw35, dim3(nblocks), dim3(block), lds, s, o, reinterpret_cast<const uint2 *>(vrows),
+                       reinterpret_cast<const int2 *>(band_rows), upr, max_src_rows);
+    HIP_TRY(hipGetLastError());
+    if (ev0 && ev1) {
+        HIP_TRY(hipEventRecord(ev1, s));
+        g_prof.pending.emplace_back(ev0, ev1);
+    }
+    return CAMA_OK;
+}
+
 int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
                        const uint32_t *draw_key, const double *block_bounds, int64_t N, const double *w2c, int32_t F,
                        const double *c2cam, const double *K, int32_t C,
@@ -642,6 +746,24 @@ int cama_resample_frames(const uint8_t *src, int64_t src_stride_bytes, uint8_t *
         hipLaunchKernelGGL(k_resample, dim3((unsigned)(((int64_t)H * W + BLOCK - 1) / BLOCK), (unsigned)n), dim3(BLOCK),
                            0, (hipStream_t)stream, src, src_stride_bytes, dst, dst_stride_bytes, H0, W0, H, W, mapx, mapy,
                            ms);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
+int cama_bgr_to_i420(const uint8_t *bgr, int64_t src_stride_bytes, uint8_t *i420, int64_t dst_stride_bytes, int32_t n,
+                     int32_t H, int32_t W, void *stream)
+{
+    if (n < 0 || n > 65535) return fail(CAMA_EINVAL, "n=%d out of range [0, 65535]", n);
+    if (H < 2 || W < 16 || (H & 1) || (W & 15) || (int64_t)H * W >= (1ll << 31))
+        return fail(CAMA_EINVAL, "bgr->i420 needs an even H and W %% 16 == 0 (got %dx%d)", W, H);
+    if (n == 0) return CAMA_OK;
+    if (!bgr || !i420) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if ((uintptr_t)bgr % 16 || (uintptr_t)i420 % 16 || src_stride_bytes % 16 || dst_stride_bytes % 16 ||
+        src_stride_bytes < (int64_t)H * W * 3 || dst_stride_bytes < (int64_t)H * W * 3 / 2)
+        return fail(CAMA_EINVAL, "bgr->i420 needs 16-byte aligned buffers and strides that hold a frame");
+    const int work = (W >> 4) * (H >> 1);
+    hipLaunchKernelGGL(k_bgr_to_i420, dim3((unsigned)((work + BLOCK - 1) / BLOCK), (unsigned)n), dim3(BLOCK), 0,
+                       (hipStream_t)stream, bgr, i420, H, W, (size_t)src_stride_bytes, (size_t)dst_stride_bytes);
     HIP_TRY(hipGetLastError());
     return CAMA_OK;
 }

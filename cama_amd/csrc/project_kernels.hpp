@@ -140,7 +140,6 @@ __global__ __launch_bounds__(BLOCK) void k_project_points(const double *__restri
 // ------------------------------------------------------------------------------------------
 // fused per-frame kernel
 // ------------------------------------------------------------------------------------------
-enum { MODE_EMIT = 0, MODE_COUNT = 1, MODE_FILL = 2 };
 
 // Conservative "no vertex of this block can be inside the crop box" test on the block's world-space AABB
 // {xlo,xhi,ylo,yhi,zlo,zhi}: the chassis-frame extent of the box along each crop axis is centre +- sum|m_k|*half,
@@ -215,11 +214,14 @@ struct FrameArgs {
     // MODE_EMIT
     double *vu;
     uint8_t *vis, *crop_mask;
-    // MODE_COUNT / MODE_FILL
+    // bin mode
     int band_shift, NB, radius;
+    uint32_t nseg;          // segments (waves) per (frame, camera): ceil(N / BLOCK) * (BLOCK / 64)
+    uint8_t *seg_cnt;       // [F*C*nseg] stamps in each segment (zeroed before k_frames_project)
+    uint2 *stamps0;         // [F*C*nseg*64] compacted per-segment stamps
     uint32_t *counts, *cursor;
     const uint32_t *bin_off, *fc_base;
-    uint2 *stamps;
+    uint2 *stamps;          // band-sorted stamps (k_stamps_scatter)
 };
 
 // Emit mode: materialise (v,u) + visibility for every (frame, camera, vertex).
@@ -256,24 +258,25 @@ __global__ __launch_bounds__(BLOCK) void k_frames_emit(FrameArgs a)
     }
 }
 
-// Bin mode.  Every visible (vertex, camera) pair is a "stamp" {u:16, v:16, key = draw index << 1 | colour}
-// that must reach the 1-2 row bands its disc touches.  Two passes (count -> scan -> fill) with identical
-// arithmetic.  All per-stamp atomics are LDS atomics on a per-workgroup histogram of this frame's
-// C x NB bins (ds_add_rtn gives the rank inside the workgroup); global memory sees one independent
-// atomic per non-empty bin per workgroup, so nothing serialises on HBM/L2 latency.
-constexpr int CAM_GROUP = 8;  // cameras ranked per pass through the workgroup protocol (register-resident entries)
+// Bin mode.  Every visible (vertex, camera) pair is a "stamp" {u:16, v:16, key = draw index << 1 | colour} that must
+// reach the 1-2 row bands its disc touches.  The fp64 chain runs ONCE per (frame, vertex) (the kernel is fp64-VALU
+// bound on dense maps: 74 % VALU-busy, profiles/r02_scalarcam_dense1e6_*; round 1 ran it twice, count + fill):
+//   k_frames_project   projects, writes every wave's surviving stamps COMPACTED into that wave's fixed segment of
+//                      (frame, camera) -- ballot + mbcnt, no atomics, no barrier -- with the count in a byte table,
+//                      and accumulates the per-(frame, camera, band) stamp counts (per-workgroup LDS histogram, one
+//                      global atomic per non-empty bin per workgroup);
+//   k_scan_bands / k_scan_totals   exclusive scans of the counts;
+//   k_stamps_scatter   re-reads only the 8-byte stamps (no geometry) and moves them to their band-sorted places.
+constexpr int SEG = 64;                 // one segment = one wave's 64 vertices of one (frame, camera)
 
-// One (vertex block, frame) work item of the binning passes.  `cams_ready` (workgroup-uniform) lets a persistent
-// workgroup stage the cameras once for all its items.  CULL: test the block's AABB first (grid-per-item launch).
-template <int MODE, typename T, bool CULL>
-__device__ __forceinline__ void bin_block(const FrameArgs &a, const int64_t vblock, const int f, uint32_t *s_hist,
-                                          double *s_cam, bool &cams_ready)
+// One (vertex block, frame) work item.  CULL: test the block's AABB first (grid-per-item launch).
+template <typename T, bool CULL>
+__device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t vblock, const int f, uint32_t *s_cnt)
 {
     const int nloc = a.C * a.NB;
-    uint32_t *s_cnt = s_hist, *s_base = s_hist + nloc;
 
     // world->chassis + crop FIRST, with the frame's matrix read through wave-uniform (scalar) loads: on site-sized
-    // maps ~95 % of the workgroups end here and never pay for staging the cameras or clearing the histogram
+    // maps ~95 % of the workgroups end here and never pay for clearing the histogram
     const double *w2c = a.w2c + (size_t)f * 16;
     const int64_t i = vblock * BLOCK + threadIdx.x;
     // ... and with the map's block AABBs (cama_map_bounds) those workgroups do not even read their vertices
@@ -293,103 +296,135 @@ __device__ __forceinline__ void bin_block(const FrameArgs &a, const int64_t vblo
         // storage index itself
         key = a.key ? a.key[i] : (((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1));
     }
-    // whole workgroup outside the crop box (the common case on site-sized maps): done
+    // whole workgroup outside the crop box (the common case on site-sized maps): done (its segments stay empty: the
+    // count table was zeroed)
     if (!__syncthreads_or((int)in)) return;
-#ifdef CAMA_CAM_LDS
-    if (!cams_ready) {
-        stage_cameras(s_cam, a.c2cam, a.K, a.C);
-        cams_ready = true;
-    }
-#endif
     for (int t = threadIdx.x; t < nloc; t += BLOCK) s_cnt[t] = 0u;
     __syncthreads();
 
     const double Wd = (double)a.W, Hd = (double)a.H;
     const size_t gbin0 = (size_t)f * nloc;
-    for (int c0 = 0; c0 < a.C; c0 += CAM_GROUP) {
-        uint32_t e_uv[CAM_GROUP], e_slot[2 * CAM_GROUP];
-#pragma unroll
-        for (int j = 0; j < CAM_GROUP; ++j) {
-            const int c = c0 + j;
-            e_slot[2 * j] = e_slot[2 * j + 1] = 0xffffffffu;
-            e_uv[j] = 0;
-            // wave-uniform guard: the shuffle below must be executed by every lane
-            if (c < a.C) {
-                uint32_t uv = 0xffffffffu;      // packed truncated pixel, or "not visible"
-                if (in) {
-                    uint32_t packed;
-#ifdef CAMA_CAM_LDS
-                    if (visible_pixel<const double *>(s_cam + c * CAM_STRIDE, s_cam + c * CAM_STRIDE + 12, cx, cy, cz, Wd, Hd,
-                                                      packed))
-                        uv = packed;
-#else
-                    // the camera's 21 doubles through wave-uniform scalar loads (constant address space): read as LDS
-                    // broadcasts they were ~126 ds_read_b64 per lane and made dense maps LDS-issue bound
-                    if (visible_pixel<kdouble *>((kdouble *)(a.c2cam + (size_t)c * 16), (kdouble *)(a.K + (size_t)c * 9), cx,
-                                                 cy, cz, Wd, Hd, packed))
-                        uv = packed;
-#endif
-                }
-                // A disc is invisible if a LATER point (higher draw index) stamps the very same pixel (same
-                // footprint).  The next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most
-                // far-range stamps collapse here, exactly, before they cost atomics, HBM or LDS conflicts.
-                const uint32_t uv_next = __shfl_down(uv, 1, 64);
-                const uint32_t key_next = __shfl_down(key, 1, 64);
-                const bool covered = (__lane_id() != 63u) && (uv_next == uv) && (key_next > key);
-                const bool keep = (uv != 0xffffffffu) && !covered;
-                if (keep) {
-                    const int vi = (int)(uv >> 16);
-                    const int b0 = max(vi - a.radius, 0) >> a.band_shift;
-                    const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;   // b1 <= b0 + 1 (host checks 2r <= R)
-                    const uint32_t l0 = (uint32_t)(c * a.NB + b0);
-                    if (MODE == MODE_COUNT) {
-                        atomicAdd(&s_cnt[l0], 1u);
-                        if (b1 != b0) atomicAdd(&s_cnt[l0 + 1], 1u);
-                    } else {
-                        e_uv[j] = uv;
-                        e_slot[2 * j] = (l0 << 8) | atomicAdd(&s_cnt[l0], 1u);
-                        if (b1 != b0) e_slot[2 * j + 1] = ((l0 + 1) << 8) | atomicAdd(&s_cnt[l0 + 1], 1u);
-                    }
-                }
-            }
+    const uint32_t seg = (uint32_t)vblock * (BLOCK / SEG) + (threadIdx.x >> 6);
+    const uint32_t lane = __lane_id();
+    for (int c = 0; c < a.C; ++c) {
+        uint32_t uv = 0xffffffffu;      // packed truncated pixel, or "not visible"
+        if (in) {
+            uint32_t packed;
+            // the camera's 21 doubles through wave-uniform scalar loads (constant address space): read as LDS
+            // broadcasts they were ~126 ds_read_b64 per lane and made dense maps LDS-issue bound
+            if (visible_pixel<kdouble *>((kdouble *)(a.c2cam + (size_t)c * 16), (kdouble *)(a.K + (size_t)c * 9), cx, cy,
+                                         cz, Wd, Hd, packed))
+                uv = packed;
         }
-        if (MODE == MODE_FILL) {
-            __syncthreads();
-            const int cend = min(c0 + CAM_GROUP, a.C);
-            for (int t = c0 * a.NB + threadIdx.x; t < cend * a.NB; t += BLOCK) {
-                const uint32_t n = s_cnt[t];
-                uint32_t base = 0;
-                if (n) base = atomicAdd(&a.cursor[gbin0 + t], n) + a.bin_off[gbin0 + t] + a.fc_base[f * a.C + t / a.NB];
-                s_base[t] = base;
+        // A disc is invisible if a LATER point (higher draw index) stamps the very same pixel (same footprint).  The
+        // next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most far-range stamps collapse
+        // here, exactly, before they cost HBM or LDS traffic.  (executed by every lane: shuffles)
+        const uint32_t uv_next = __shfl_down(uv, 1, 64);
+        const uint32_t key_next = __shfl_down(key, 1, 64);
+        const bool covered = (lane != 63u) && (uv_next == uv) && (key_next > key);
+        const bool keep = (uv != 0xffffffffu) && !covered;
+        const uint64_t m = __ballot(keep);
+        if (m) {                        // wave-uniform
+            const size_t fcseg = ((size_t)f * a.C + c) * a.nseg + seg;
+            if (keep) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                a.stamps0[fcseg * SEG + rank] = make_uint2(uv, key);
+                const int vi = (int)(uv >> 16);
+                const int b0 = max(vi - a.radius, 0) >> a.band_shift;
+                const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;   // b1 <= b0 + 1 (host checks 2r <= R)
+                const uint32_t l0 = (uint32_t)(c * a.NB + b0);
+                atomicAdd(&s_cnt[l0], 1u);
+                if (b1 != b0) atomicAdd(&s_cnt[l0 + 1], 1u);
             }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 2 * CAM_GROUP; ++j) {
-                if (e_slot[j] != 0xffffffffu)
-                    a.stamps[(size_t)s_base[e_slot[j] >> 8] + (e_slot[j] & 0xffu)] = make_uint2(e_uv[j >> 1], key);
-            }
+            if (lane == 0u) a.seg_cnt[fcseg] = (uint8_t)__popcll(m);
         }
     }
-    if (MODE == MODE_COUNT) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < nloc; t += BLOCK) {
-            const uint32_t n = s_cnt[t];
-            if (n) atomicAdd(&a.counts[gbin0 + t], n);
-        }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nloc; t += BLOCK) {
+        const uint32_t n = s_cnt[t];
+        if (n) atomicAdd(&a.counts[gbin0 + t], n);
     }
 }
 
-template <int MODE, typename T>
-__global__ __launch_bounds__(BLOCK) void k_frames_bin(FrameArgs a)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_frames_project(FrameArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [C*NB] counts, then (fill) [C*NB] bases
-#ifdef CAMA_CAM_LDS
-    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
-#else
-    double *s_cam = nullptr;
-#endif
-    bool cams_ready = false;
-    bin_block<MODE, T, true>(a, (int64_t)blockIdx.x, (int)blockIdx.y, s_hist, s_cam, cams_ready);
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [C*NB] stamp counts of this workgroup
+    project_block<T, true>(a, (int64_t)blockIdx.x, (int)blockIdx.y, s_hist);
+}
+
+// Band sort of the compacted stamps: one workgroup per SCATTER_SEGS consecutive segments of one (frame, camera).  Work
+// is proportional to the stamps that exist (a prefix sum of the segment counts maps thread -> stamp), every stamp is
+// ranked inside the workgroup with an LDS atomic on its band's counter, the workgroup reserves its share of each
+// non-empty band with one global atomic, and the stamps go to bin_off + reserved base + rank.
+constexpr int SCATTER_SEGS = 64;
+constexpr int SCATTER_K = 4;            // stamps per thread per round (register-resident between rank and write)
+
+__global__ __launch_bounds__(BLOCK) void k_stamps_scatter(FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [NB] counts | [NB] bases
+    __shared__ uint32_t s_off[SCATTER_SEGS + 1];
+    const uint32_t fc = blockIdx.y, seg0 = blockIdx.x * SCATTER_SEGS;
+    const int NB = a.NB;
+    uint32_t *s_cnt = s_hist, *s_base = s_hist + NB;
+    if (threadIdx.x < SCATTER_SEGS) {
+        const uint32_t sg = seg0 + threadIdx.x;
+        const uint32_t v = sg < a.nseg ? (uint32_t)a.seg_cnt[(size_t)fc * a.nseg + sg] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(x, d, 64);
+            if ((int)threadIdx.x >= d) x += t;
+        }
+        s_off[threadIdx.x + 1] = x;
+        if (threadIdx.x == 0) s_off[0] = 0u;
+    }
+    for (int t = threadIdx.x; t < NB; t += BLOCK) s_cnt[t] = 0u;
+    __syncthreads();
+    const uint32_t total = s_off[SCATTER_SEGS];
+    if (!total) return;
+    const uint2 *segs = a.stamps0 + ((size_t)fc * a.nseg + seg0) * SEG;
+    const size_t gbin0 = (size_t)fc * NB;
+    const uint32_t fcb = a.fc_base[fc];
+    for (uint32_t base = 0; base < total; base += BLOCK * SCATTER_K) {
+        uint32_t e_uv[SCATTER_K], e_key[SCATTER_K], e_slot[2 * SCATTER_K];
+#pragma unroll
+        for (int j = 0; j < SCATTER_K; ++j) {
+            e_slot[2 * j] = e_slot[2 * j + 1] = 0xffffffffu;
+            e_uv[j] = e_key[j] = 0u;
+            const uint32_t t = base + j * BLOCK + threadIdx.x;
+            if (t < total) {
+                uint32_t lo = 0;        // the segment that holds stamp t: largest lo with s_off[lo] <= t
+#pragma unroll
+                for (uint32_t step = SCATTER_SEGS / 2; step; step >>= 1)
+                    if (s_off[lo + step] <= t) lo += step;
+                const uint2 r = segs[(size_t)lo * SEG + (t - s_off[lo])];
+                const int vi = (int)(r.x >> 16);
+                const int b0 = max(vi - a.radius, 0) >> a.band_shift;
+                const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;
+                e_uv[j] = r.x;
+                e_key[j] = r.y;
+                e_slot[2 * j] = ((uint32_t)b0 << 12) | atomicAdd(&s_cnt[b0], 1u);         // rank < BLOCK * K * 2 <= 4096
+                if (b1 != b0) e_slot[2 * j + 1] = ((uint32_t)b1 << 12) | atomicAdd(&s_cnt[b1], 1u);
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < NB; t += BLOCK) {
+            const uint32_t n = s_cnt[t];
+            uint32_t bs = 0;
+            if (n) {
+                bs = atomicAdd(&a.cursor[gbin0 + t], n) + a.bin_off[gbin0 + t] + fcb;
+                s_cnt[t] = 0u;
+            }
+            s_base[t] = bs;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2 * SCATTER_K; ++j)
+            if (e_slot[j] != 0xffffffffu)
+                a.stamps[(size_t)s_base[e_slot[j] >> 12] + (e_slot[j] & 0xfffu)] = make_uint2(e_uv[j >> 1], e_key[j >> 1]);
+        __syncthreads();                 // s_base / s_cnt are rewritten by the next round
+    }
 }
 
 // Site-sized maps: F * ceil(N/BLOCK) work items, ~95 % of them outside the crop box.  Even an empty workgroup costs
@@ -416,25 +451,19 @@ __global__ __launch_bounds__(BLOCK) void k_cull_blocks(const double *__restrict_
         work[(size_t)(lane & 7u) * list_cap + base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = f * vblocks + b;
 }
 
-template <int MODE, typename T>
-__global__ __launch_bounds__(BLOCK) void k_frames_bin_list(FrameArgs a, const uint32_t *__restrict__ work_count,
-                                                           const uint32_t *__restrict__ work, uint32_t vblocks,
-                                                           uint32_t list_cap)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_frames_project_list(FrameArgs a, const uint32_t *__restrict__ work_count,
+                                                               const uint32_t *__restrict__ work, uint32_t vblocks,
+                                                               uint32_t list_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
-#ifdef CAMA_CAM_LDS
-    __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
-#else
-    double *s_cam = nullptr;
-#endif
-    bool cams_ready = false;
     const uint32_t list = blockIdx.x & 7u;          // gridDim.x is a multiple of 8
     const uint32_t n = work_count[list];
     work += (size_t)list * list_cap;
     for (uint32_t w = blockIdx.x >> 3; w < n; w += gridDim.x >> 3) {
         const uint32_t item = work[w];
-        // the barrier at the top of bin_block (__syncthreads_or) also fences the previous item's LDS reads
-        bin_block<MODE, T, false>(a, (int64_t)(item % vblocks), (int)(item / vblocks), s_hist, s_cam, cams_ready);
+        // the barrier at the top of project_block (__syncthreads_or) also fences the previous item's LDS reads
+        project_block<T, false>(a, (int64_t)(item % vblocks), (int)(item / vblocks), s_hist);
     }
 }
 

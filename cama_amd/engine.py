@@ -416,9 +416,29 @@ class Engine:
                     tb[:, :, 1] = max_tile                      # one LDS row stride for every tile (clamped below)
                     tb[:, :, 0] = np.minimum(tb[:, :, 0], W0 * 3 - max_tile)
                     tiles = torch.from_numpy(tb).to(self.device)
+            # rational 3:5 scale (the reference default 1600x900 -> 960x540): the library verifies the tap pattern and
+            # builds the per-row vertical taps for its gather-free kernel (cama_raw35_plan)
+            vrows = None
+            if sep and not os.environ.get("CAMA_NO_RAW35"):
+                Cn, Hd, Wd = len(cm_list), int(cm_list[0].height), int(cm_list[0].width)
+                mxh = np.ascontiguousarray(mx, np.float32)
+                myh = np.ascontiguousarray(my, np.float32)
+                table = np.zeros((Cn, Hd, 2), np.uint32)
+                R35 = self.lib.cama_overlay_band_rows(Wd)
+                brows = np.zeros((Cn, (Hd + R35 - 1) // R35, 2), np.int32)
+                import ctypes
+                most = ctypes.c_int32(0)
+                rc = self.lib.cama_raw35_plan(mxh.ctypes.data, myh.ctypes.data, Cn, Hd, Wd,
+                                              int(cm_list[0].height_origin), int(cm_list[0].width_origin), table.ctypes.data,
+                                              brows.ctypes.data, ctypes.byref(most))
+                if rc < 0:
+                    _lib.check(rc)
+                if rc == 1:
+                    vrows = (torch.from_numpy(table.view(np.int32)).to(self.device), torch.from_numpy(brows).to(self.device),
+                             int(most.value))
             hit = (key, torch.from_numpy(np.ascontiguousarray(mx)).to(self.device),
                    torch.from_numpy(np.ascontiguousarray(my)).to(self.device), int(sep), band_rows, max_rows,
-                   tiles, tiles_x, max_tile)
+                   tiles, tiles_x, max_tile, vrows)
             self._rig_maps = hit
         return hit[1:]
 
@@ -438,7 +458,7 @@ class Engine:
             if out is None:
                 out = torch.empty(shape, dtype=torch.uint8, device=self.device)
             assert tuple(out.shape) == shape and out.is_contiguous()
-            mapx, mapy, sep, band_rows, max_rows, tiles, tiles_x, max_tile = self.rig_maps(cm_list)
+            mapx, mapy, sep, band_rows, max_rows, tiles, tiles_x, max_tile, vrows = self.rig_maps(cm_list)
             need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
             scratch = self._scratch_buf(need)
             x, y, z, col, key, bnd = dmap.render_ptrs(cropa)
@@ -446,6 +466,13 @@ class Engine:
             _lib.check(self.lib.cama_bin_frames(
                 x, y, z, dmap.is_f64, col, key, bnd, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
                 cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(), st))
+            if vrows is not None:
+                _lib.check(self.lib.cama_overlay_frames_raw35(
+                    raw.data_ptr(), H0, W0, vrows[0].data_ptr(), vrows[1].data_ptr(), vrows[2], out.data_ptr(), dmap.N, F,
+                    rig.C, rig.H, rig.W, cols,
+                    self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, scratch.data_ptr(),
+                    scratch.numel(), st))
+                return out
             _lib.check(self.lib.cama_overlay_frames_raw(
                 raw.data_ptr(), H0, W0, mapx.data_ptr(), mapy.data_ptr(), sep,
                 None if band_rows is None else band_rows.data_ptr(), max_rows,

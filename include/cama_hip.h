@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 6
+#define CAMA_ABI_VERSION 7
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -201,6 +201,45 @@ int cama_overlay_frames_alpha(const uint8_t *src, uint8_t *mosaic, int64_t N, in
                               int32_t H, int32_t W, int32_t cols,
                               int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
                               int32_t alpha256, const void *scratch, size_t scratch_bytes, void *stream);
+
+/*
+ * Mosaic egress: n BGR24 frames [H,W,3] -> planar YUV 4:2:0 (I420: Y plane H*W, then U and V planes (H/2)*(W/2)), so
+ * that what is downloaded and piped to the encoder is 1.5 bytes per pixel and already in the encoder's pixel format.
+ * Replaces the colour conversion libswscale performs behind VideoGenerator's bgr24 pipe (cama/tools.py:13-20,27-32:
+ * rawvideo bgr24 in, -pix_fmt yuv420p libx264 out).  Arithmetic = libswscale's unscaled C path for BGR24 -> YUV420P
+ * (rgb24toyv12_c with the BT.601 limited-range table, 15-bit fixed point; chroma from the first pixel of the first
+ * line of each 2x2 block), restated in oracle/cama_oracle.py:bgr_to_i420.  PARITY UNPINNED (no ffmpeg on either box).
+ *   bgr  [n] frames at bgr + k*src_stride_bytes     i420 [n] frames at i420 + k*dst_stride_bytes
+ *   H even, W % 16 == 0, buffers and strides 16-byte aligned.
+ */
+int cama_bgr_to_i420(const uint8_t *bgr, int64_t src_stride_bytes, uint8_t *i420, int64_t dst_stride_bytes, int32_t n,
+                     int32_t H, int32_t W, void *stream);
+
+/*
+ * Raw-frame overlay for rational 3:5 scaling without lens distortion -- the reference's default pipeline, 1600x900
+ * sensor frames -> 960x540 tiles (CameraManager(output_size=(540, 960)), cama/reproject.py:164,176-182,232-240).  There
+ * cv2.remap's fixed-point taps repeat with period 3 destination / 5 source pixels (offsets 0,1,3; left/right weights
+ * 32/0, 11/21, 21/11 of 32), so 12 destination pixels come from exactly 20 source pixels and every tap is a constant
+ * byte offset: a band's source rows are streamed into LDS as one contiguous range, one thread per 12-pixel unit reads its
+ * 2 x 60 bytes at a conflict-free odd dword stride.  Same bytes as cama_overlay_frames_raw / cama_resample_frames +
+ * cama_overlay_frames.
+ *   cama_raw35_plan      HOST pointers: mapx [C,W], mapy [C,H] (the separable float32 maps); out: vrows [C,H,2] uint32
+ *                        ({top row | bottom row << 16, top weight | bottom weight << 8} per destination row; rows are
+ *                        general, only the columns must follow the 3:5 pattern), band_rows [C,NB,2] int32 ({first
+ *                        source row, number of source rows} of every band of R = cama_overlay_band_rows(W) rows; a band's
+ *                        source rows are one contiguous range) and *max_src_rows.  Returns 1 when the kernel applies
+ *                        (pattern verified for every column, W % 48 == 0, W0*3 % 16 == 0, all weighted taps inside the
+ *                        frame, one 12-pixel unit per thread fits a workgroup), 0 when it does not (use
+ *                        cama_overlay_frames_raw), < 0 on bad arguments.
+ *   cama_overlay_frames_raw35   raw [F,C,H0,W0,3] uint8 (16-byte aligned), vrows / band_rows = the plan's tables on the
+ *                        DEVICE; other arguments as cama_overlay_frames.
+ */
+int cama_raw35_plan(const float *mapx, const float *mapy, int32_t C, int32_t H, int32_t W, int32_t H0, int32_t W0,
+                    uint32_t *vrows, int32_t *band_rows, int32_t *max_src_rows);
+int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t *vrows, const int32_t *band_rows,
+                              int32_t max_src_rows, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                              int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                              const void *scratch, size_t scratch_bytes, void *stream);
 
 /*
  * Overlay half that reads RAW sensor frames: undistort + resize (the cv2.initUndistortRectifyMap + cv2.remap of

@@ -432,6 +432,29 @@ def remap_bilinear(image, mapx, mapy):
     return np.clip(acc, 0, 255).astype(np.uint8)
 
 
+# --------------------------------------------------------------------------- mosaic egress (libswscale restated)
+I420_COEFFS = dict(ry=8414, gy=16519, by=3208, ru=-4865, gu=-9528, bu=14392, rv=14392, gv=-12061, bv=-2332)
+
+
+def bgr_to_i420(image):
+    """What the encoder ends up with for a bgr24 frame: VideoGenerator pipes raw bgr24 into ffmpeg with `-pix_fmt yuv420p`
+    (cama/tools.py:13-20), i.e. libswscale converts BGR24 -> YUV420P.  Restated from libswscale's unscaled C converter
+    (rgb2rgb_template.c rgb24toyv12_c, reached through bgr24ToYv12Wrapper for even widths without SWS_ACCURATE_RND):
+    BT.601 limited range, coefficients int(c * 219|224 / 255 * 2^15 + 0.5), Y = ((ry*r + gy*g + by*b) >> 15) + 16 for
+    every pixel, U / V = ((..) >> 15) + 128 (arithmetic shift) from the FIRST pixel of the FIRST line of each 2x2 block.
+    Returns the planar I420 bytes (Y, U, V) as one uint8 vector.  PARITY UNPINNED: ffmpeg is absent on both boxes, and
+    x86 builds may run a SIMD body that averages chroma instead."""
+    H, W = image.shape[:2]
+    assert H % 2 == 0 and W % 2 == 0 and image.dtype == np.uint8 and image.shape[2] == 3
+    c = I420_COEFFS
+    b, g, r = (image[..., k].astype(np.int64) for k in range(3))
+    y = ((c["ry"] * r + c["gy"] * g + c["by"] * b) >> 15) + 16
+    b0, g0, r0 = b[0::2, 0::2], g[0::2, 0::2], r[0::2, 0::2]
+    u = ((c["ru"] * r0 + c["gu"] * g0 + c["bu"] * b0) >> 15) + 128
+    v = ((c["rv"] * r0 + c["gv"] * g0 + c["bv"] * b0) >> 15) + 128
+    return np.concatenate([y.astype(np.uint8).reshape(-1), u.astype(np.uint8).reshape(-1), v.astype(np.uint8).reshape(-1)])
+
+
 # --------------------------------------------------------------------------- flat (C) frame path
 def flatten_instances(instances):
     """-> (xyz (N,3) contiguous, colour_id (N,) uint8, counts, classes)."""

@@ -269,6 +269,60 @@ def test_fused_raw_frame_overlay_equals_resample_then_overlay(tmp_path):
         assert np.array_equal(outs[0][1].cpu().numpy(), O.frame_render_flat(small, flat["vu"], flat["vis"], col))
 
 
+def _raw_pipeline_vs_oracle(tmp_path, origin, out_size, seed, n_frames=4, check_frames=(1,)):
+    """Fused raw overlay of a zero-distortion clip == resample->overlay == the oracle's restated remap + circles.
+    Returns which kernel family the engine selected: "raw35" (3:5 rational pattern), "lds" or "gather"."""
+    import torch
+    from cama_amd import runtime
+    from cama_amd.dataset import ClipManager
+    from cama_amd.frames import RawDeviceFrameSource
+    from cama_amd.synth import frame_pattern, make_clip
+    clip = str(tmp_path / f"clip_{origin[1]}_{out_size[1]}")
+    make_clip(clip, n_frames=n_frames, seed=seed, n_lines=12, verts_per_line=5, line_len_m=3.0, raster_size=400,
+              origin_size=origin, with_nuscenes=False)
+    H, W = out_size
+    raw = frame_pattern(seed, (n_frames, 6, origin[0], origin[1], 3), "cuda")
+    outs = []
+    for fused in (True, False):
+        cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W)), clip)
+        cm.set_frame_source(RawDeviceFrameSource(raw, cm.cm_list, fused=fused))
+        idx, mosaic = cm.render_clip("cama")
+        torch.cuda.synchronize()
+        outs.append(mosaic.clone())
+        if fused:
+            maps = runtime.engine().rig_maps(cm.cm_list)
+            kind = "raw35" if maps[-1] is not None else "lds" if (maps[2] and maps[3] is not None) else "gather"
+    assert torch.equal(outs[0], outs[1])
+    att = O.read_attribute(clip)
+    cams = [O.camera_model(att, n, output_size=(H, W)) for n in CAMERA_NAMES]
+    xyz, col, _, _ = O.flatten_instances(cm.instance_maps["cama"])
+    _, w2c = cm.frame_poses("cama")
+    rawh = raw.cpu().numpy()
+    stamped = 0
+    for k in check_frames:
+        small = np.stack([O.remap_bilinear(rawh[idx[k], c], *O.undistort_map(cam["K_origin"], cam["d_origin"], cam["K"], W, H))
+                          for c, cam in enumerate(cams)])
+        flat = O.frame_project_flat(xyz, w2c[k], cams, W, H)
+        stamped += int(flat["vis"].sum())
+        assert np.array_equal(outs[0][k].cpu().numpy(), O.frame_render_flat(small, flat["vu"], flat["vis"], col)), k
+    assert stamped > 100
+    return kind
+
+
+def test_raw_overlay_kernel_families(tmp_path):
+    """The three raw-frame overlays on zero-distortion clips: 160x90 -> 96x54 and 320x180 -> 192x108 are the reference's
+    3:5 scale (gather-free k_overlay_raw35, several units per row, bands with and without stamps); 160x90 -> 80x45
+    (1:2) is separable but not 3:5 (LDS-staged k_overlay_rawlds); every result equals the oracle."""
+    assert _raw_pipeline_vs_oracle(tmp_path, (90, 160), (54, 96), seed=31, check_frames=(0, 1, 2)) == "raw35"
+    assert _raw_pipeline_vs_oracle(tmp_path, (180, 320), (108, 192), seed=32) == "raw35"
+    assert _raw_pipeline_vs_oracle(tmp_path, (90, 160), (45, 80), seed=33) == "lds"
+
+
+def test_raw_overlay_reference_default_size(tmp_path):
+    """The reference's default pipeline at full size: raw 1600x900 frames -> 960x540 tiles -> 2880x1080 mosaic."""
+    assert _raw_pipeline_vs_oracle(tmp_path, (900, 1600), (540, 960), seed=34, n_frames=3, check_frames=(1,)) == "raw35"
+
+
 def test_integration_md_binding_example_runs(repo_root):
     """The ctypes stub shown in INTEGRATION.md (what a maintainer of the reference would add) is real code: extract
     it, point it at the built library, render with it and compare with the engine."""
