@@ -221,7 +221,7 @@ class Job:
         self.args, self.device, self.frame_range = args, device, frame_range
         self.scenes = [(sid,) + build_scene(args, sid, device, frame_range) for sid in scene_ids]
         self.eng = runtime.engine()
-        self.pipelined = not args.no_pipeline and not args.raw_frames
+        self.pipelined = not args.no_pipeline and not (args.raw_frames and args.unfused_resample)
         self.N = 0
         self.poses = {}
         for sid, cm, _, _ in self.scenes:

@@ -10,7 +10,8 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 7
+ABI_VERSION = 8
+BIN_WORKLIST = 1
 
 _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _u64 = ctypes.c_uint64
@@ -27,9 +28,9 @@ SIGNATURES = {
     "cama_render_scratch_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _i32]),
     "cama_map_bounds_block": (_i32, []),
     "cama_map_bounds": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _vp]),
-    "cama_render_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
+    "cama_render_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
                                   _vp, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
-    "cama_bin_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32,
+    "cama_bin_frames": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32,
                                _vp, _sz, _vp]),
     "cama_overlay_frames": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_build_static_map": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32, _i32, _i32,
@@ -44,8 +45,10 @@ SIGNATURES = {
                                          _vp, _vp, _vp, _sz, _vp]),
     "cama_pipeline_create": (_i32, [_vp]),
     "cama_pipeline_destroy": (_i32, [_vp]),
-    "cama_pipeline_render": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
+    "cama_pipeline_render": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32,
                                     _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cama_pipeline_render_raw35": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32,
+                                          _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cama_pipeline_join": (_i32, [_vp, _vp]),
     "cama_pipeline_issued": (_i64, [_vp]),
     "cama_pipeline_completed": (_i64, [_vp]),

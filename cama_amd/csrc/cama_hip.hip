@@ -21,6 +21,7 @@
 //     pixel has an owner.  No pixel is read or written twice.
 //   * 64-wide wavefronts throughout (ballots are 64-bit, scans step to 32).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -161,7 +162,7 @@ int log2i(int v)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct ScratchLayout {
-    size_t counts, cursor, work_count, seg_cnt, bin_off, fc_total, fc_base, stamps0, stamps, work, list_cap, total;
+    size_t counts, cursor, work_count, seg_cnt, bin_off, fc_total, fc_base, cam_mask, stamps0, stamps, work, list_cap, total;
     size_t zero_bytes;              // counts .. seg_cnt: cleared by one memset before the projection pass
     uint64_t capacity;
     uint32_t nseg;
@@ -185,6 +186,7 @@ int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLay
     L.bin_off = off;  off = align_up(off + nbins * 4, 256);
     L.fc_total = off; off = align_up(off + nfc * 4, 256);
     L.fc_base = off;  off = align_up(off + nfc * 4, 256);
+    L.cam_mask = off; off = align_up(off + (size_t)F * ((N + BLOCK - 1) / BLOCK) * 2, 256);   // per (frame, vertex block)
     L.stamps0 = off;  off = align_up(off + nfc * L.nseg * SEG * 8 + 8, 256);   // compacted per-segment stamps (worst case)
     L.stamps = off;   off = align_up(off + (size_t)L.capacity * 8 + 8, 256);   // >= 1 record: empty bins read stamps[0]
     // work lists of the crop cull: 8 (one per XCD), each up to ceil(vblocks / 8) * F uint32 items
@@ -388,8 +390,19 @@ int cama_map_bounds(const void *x, const void *y, const void *z, int32_t xyz_is_
     return CAMA_OK;
 }
 
+// Completion events attached to the NEXT overlay / scatter launch itself (hipExtLaunchKernelGGL stop event) instead of a
+// separate hipEventRecord marker packet behind it: one packet less between consecutive overlays on the pipeline's
+// stream.  Set by cama_pipeline_render, consumed (and cleared) by the launch.
+thread_local hipEvent_t g_overlay_stop_event = nullptr;
+thread_local hipEvent_t g_scatter_stop_event = nullptr;
+static bool ext_events()
+{
+    static const bool v = !getenv("CAMA_NO_EXT_EVENTS");
+    return v;
+}   // consumed by the next overlay launch (cama_overlay_frames_alpha)
+
 int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
-                    const uint32_t *draw_key, const double *block_bounds, int64_t N, const double *w2c, int32_t F,
+                    const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N, const double *w2c, int32_t F,
                     const double *c2cam, const double *K, int32_t C,
                     const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch, size_t scratch_bytes,
                     void *stream)
@@ -425,17 +438,29 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     const unsigned vblocks = (unsigned)((N + BLOCK - 1) / BLOCK);
     const dim3 fgrid(getenv("CAMA_NO_XCD_PAD") ? vblocks : ((vblocks + 7u) & ~7u), (unsigned)F);
     const size_t hist_lds = align_up((size_t)C * L.NB * 4, 16);
-    // Many (block, frame) items and a spatial index: cull them one thread per item into a work list and let persistent
-    // workgroups walk the survivors (an empty workgroup still costs ~0.8 ns of dispatch; 1.25 M of them = 1 ms).
-    const bool use_list = block_bounds && (uint64_t)vblocks * (uint64_t)F >= cull_list_threshold();
+    // With the map's spatial index (block AABBs) a one-thread-per-(block, frame) pre-pass decides which cameras can see
+    // each block at all (k_block_cameras); the projection skips the others.  Site-sized maps (CAMA_BIN_WORKLIST: most
+    // blocks are outside the crop box on any frame) additionally go through work lists + persistent workgroups: an empty
+    // workgroup still costs ~0.8 ns of dispatch, 1.25 M of them = 1 ms.
+    const bool use_list = block_bounds && (flags & CAMA_BIN_WORKLIST) && (uint64_t)vblocks * (uint64_t)F >= cull_list_threshold();
     uint32_t *work_count = (uint32_t *)(base + L.work_count), *work = (uint32_t *)(base + L.work);
     const dim3 lgrid(persistent_workgroups());
-    if (N && use_list) {
+    if (N && block_bounds && !getenv("CAMA_NO_CAM_MASK")) {
         Crop cr;
         memcpy(cr.v, crop, sizeof(cr.v));
-        hipLaunchKernelGGL(k_cull_blocks, dim3((vblocks + BLOCK - 1) / BLOCK, (unsigned)F), dim3(BLOCK), 0, s, block_bounds,
-                           w2c, cr, vblocks, (uint32_t)L.list_cap, work_count, work);
+        uint16_t *cam_mask = (uint16_t *)(base + L.cam_mask);
+        const dim3 cgrid((vblocks + BLOCK - 1) / BLOCK, (unsigned)F);
+        if (use_list)
+            hipLaunchKernelGGL(k_block_cameras<true>, cgrid, dim3(BLOCK), 0, s, block_bounds, w2c, c2cam, K, C, W, H, cr,
+                               vblocks, cam_mask, (uint32_t)L.list_cap, work_count, work);
+        else
+            hipLaunchKernelGGL(k_block_cameras<false>, cgrid, dim3(BLOCK), 0, s, block_bounds, w2c, c2cam, K, C, W, H, cr,
+                               vblocks, cam_mask, (uint32_t)L.list_cap, work_count, work);
         HIP_TRY(hipGetLastError());
+        a.cam_mask = cam_mask;
+        a.vblocks = vblocks;
+    }
+    if (N && use_list && a.cam_mask) {
         if (xyz_is_f64)
             hipLaunchKernelGGL(k_frames_project_list<double>, lgrid, dim3(BLOCK), hist_lds, s, a, work_count, work, vblocks,
                                (uint32_t)L.list_cap);
@@ -456,14 +481,18 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     HIP_TRY(hipGetLastError());
     if (N) {
         const dim3 sgrid((L.nseg + SCATTER_SEGS - 1) / SCATTER_SEGS, (unsigned)nfc);
-        hipLaunchKernelGGL(k_stamps_scatter, sgrid, dim3(BLOCK), align_up((size_t)2 * L.NB * 4, 16), s, a);
+        if (g_scatter_stop_event) {
+            hipExtLaunchKernelGGL(k_stamps_scatter, sgrid, dim3(BLOCK), (uint32_t)align_up((size_t)2 * L.NB * 4, 16), s,
+                                  nullptr, g_scatter_stop_event, 0u, a);
+            g_scatter_stop_event = nullptr;
+        } else
+            hipLaunchKernelGGL(k_stamps_scatter, sgrid, dim3(BLOCK), align_up((size_t)2 * L.NB * 4, 16), s, a);
         HIP_TRY(hipGetLastError());
     }
     return CAMA_OK;
 }
 
-thread_local uint32_t g_next_alpha256 = 256u;   // consumed by the next overlay launch (cama_overlay_frames_alpha)
-
+thread_local uint32_t g_next_alpha256 = 256u;
 struct RawSource {
     int H0, W0;
     const float *mapx, *mapy;
@@ -485,7 +514,9 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     if (!src || !mosaic || !palette_bgr) return fail(CAMA_EINVAL, "NULL pointer argument");
     Disc disc;
     if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
-    const size_t lds = align_up((size_t)L.R * W * 4, 16);
+    // (A/B knob: CAMA_OVERLAY_LDS_PAD=bytes inflates the allocation, i.e. lowers the overlay's workgroups per CU)
+    static const size_t lds_pad = getenv("CAMA_OVERLAY_LDS_PAD") ? (size_t)atol(getenv("CAMA_OVERLAY_LDS_PAD")) : 0;
+    const size_t lds = align_up((size_t)L.R * W * 4, 16) + lds_pad;
     hipStream_t s = (hipStream_t)stream;
     const char *base = (const char *)scratch;
 #ifdef OVERLAY_ORDER_FCB
@@ -559,9 +590,14 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
             hipLaunchKernelGGL((k_overlay<true, false, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
         else
             hipLaunchKernelGGL((k_overlay<false, false, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
-    } else if (vec)
-        hipLaunchKernelGGL((k_overlay<true, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
-    else
+    } else if (vec) {
+        if (g_overlay_stop_event) {
+            hipExtLaunchKernelGGL((k_overlay<true, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), (uint32_t)lds, s, nullptr,
+                                  g_overlay_stop_event, 0u, o);
+            g_overlay_stop_event = nullptr;
+        } else
+            hipLaunchKernelGGL((k_overlay<true, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+    } else
         hipLaunchKernelGGL((k_overlay<false, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) {
@@ -696,8 +732,14 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
         ev1 = prof_event();
         if (ev0 && ev1) HIP_TRY(hipEventRecord(ev0, s));
     }
-    hipLaunchKernelGGL(k_overlay_raw35, dim3(nblocks), dim3(block), lds, s, o, reinterpret_cast<const uint2 *>(vrows),
-                       reinterpret_cast<const int2 *>(band_rows), upr, max_src_rows);
+    if (g_overlay_stop_event) {
+        hipExtLaunchKernelGGL(k_overlay_raw35, dim3(nblocks), dim3(block), (uint32_t)lds, s, nullptr, g_overlay_stop_event,
+                              0u, o, reinterpret_cast<const uint2 *>(vrows), reinterpret_cast<const int2 *>(band_rows), upr,
+                              max_src_rows);
+        g_overlay_stop_event = nullptr;
+    } else
+        hipLaunchKernelGGL(k_overlay_raw35, dim3(nblocks), dim3(block), lds, s, o, reinterpret_cast<const uint2 *>(vrows),
+                           reinterpret_cast<const int2 *>(band_rows), upr, max_src_rows);
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) {
         HIP_TRY(hipEventRecord(ev1, s));
@@ -707,7 +749,7 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
 }
 
 int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
-                       const uint32_t *draw_key, const double *block_bounds, int64_t N, const double *w2c, int32_t F,
+                       const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N, const double *w2c, int32_t F,
                        const double *c2cam, const double *K, int32_t C,
                        const double *crop, int32_t W, int32_t H, const uint8_t *src, uint8_t *mosaic, int32_t cols,
                        int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
@@ -716,7 +758,7 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
     // validate the overlay half first so that nothing is enqueued when it would be rejected
     if (F > 0 && (!src || !mosaic || !palette_bgr || !halfwidth || cols < 1))
         return check_common(N, F, C, W, H) ? CAMA_EINVAL : fail(CAMA_EINVAL, "NULL pointer argument");
-    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, N, w2c, F, c2cam, K, C, crop, W, H, radius, scratch,
+    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H, radius, scratch,
                                  scratch_bytes, stream))
         return rc;
     return cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch, scratch_bytes,
@@ -815,7 +857,13 @@ int cama_pipeline_create(cama_pipeline **out)
     // device-scope release, no timing: a default event makes the recording stream do a system-scope release after
     // an overlay that wrote ~1 GB, which showed up as ~20 us between consecutive overlays
     const unsigned flags = hipEventDisableTiming | hipEventReleaseToDevice;
-    hipError_t e = hipStreamCreateWithFlags(&p->s_bin, hipStreamNonBlocking);
+    // A/B knob: CAMA_BIN_PRIORITY=high|low gives the binning stream another priority than the overlay stream
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least urgent (numerically greatest)
+    const char *pe = getenv("CAMA_BIN_PRIORITY");
+    const int bin_prio = pe && !strcmp(pe, "high") ? hi : pe && !strcmp(pe, "low") ? lo : (lo + hi) / 2;
+    hipError_t e = pe ? hipStreamCreateWithPriority(&p->s_bin, hipStreamNonBlocking, bin_prio)
+                      : hipStreamCreateWithFlags(&p->s_bin, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_ov, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready, flags);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->binned[k], flags);
@@ -863,13 +911,15 @@ int64_t cama_pipeline_completed(cama_pipeline *p)
     return (int64_t)p->completed;
 }
 
-int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                         const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int64_t N,
-                         const double *w2c, int32_t F,
-                         const double *c2cam, const double *K, int32_t C, const double *crop, int32_t W, int32_t H,
-                         const uint8_t *src, uint8_t *mosaic, int32_t cols, int32_t radius, const int32_t *halfwidth,
-                         const uint8_t *palette_bgr, void *scratch0, void *scratch1, size_t scratch_bytes,
-                         void *input_stream)
+}  // extern "C"
+
+// shared body of the pipelined renders: bin on s_bin, then `overlay(scratch, stream)` on s_ov
+template <typename Overlay>
+static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
+                                const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
+                                const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                                const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch0, void *scratch1,
+                                size_t scratch_bytes, void *input_stream, bool overlay_takes_stop_event, Overlay overlay)
 {
     if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
     if (!scratch0 || !scratch1) return fail(CAMA_EINVAL, "two scratch buffers are needed");
@@ -886,27 +936,74 @@ int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const v
     {
         ScratchLayout L;
         if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
-        if (F > 0 && (!src || !mosaic || !palette_bgr || !halfwidth || cols < 1)) return fail(CAMA_EINVAL, "NULL pointer argument");
     }
     // inputs (w2c upload, frames) are complete on the caller's stream at this point
     HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
     HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
     if (k > 2) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->done[(k - 2) % RING], 0));   // the overlay that read this slot
-    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, N, w2c, F, c2cam, K, C, crop, W, H, radius,
-                                 scratch, scratch_bytes, p->s_bin))
+    // the chain's last kernel (k_stamps_scatter, launched whenever N > 0) carries `binned` as its own stop event
+    const bool ext = ext_events() && N > 0;
+    g_scatter_stop_event = ext ? p->binned[slot] : nullptr;
+    if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H, radius,
+                                 scratch, scratch_bytes, p->s_bin)) {
+        g_scatter_stop_event = nullptr;
         return rc;
-    HIP_TRY(hipEventRecord(p->binned[slot], p->s_bin));
+    }
+    if (!ext || g_scatter_stop_event) HIP_TRY(hipEventRecord(p->binned[slot], p->s_bin));
+    g_scatter_stop_event = nullptr;
     // (overlays stay on ONE stream: two overlays in flight at once interleave their streams in DRAM -- measured
     // 106.8 k vs 109.9 k frames/s)
     hipStream_t so = p->s_ov;
     // `binned` also carries `ready` (s_bin waited for it above): one barrier packet between overlays, not two
     HIP_TRY(hipStreamWaitEvent(so, p->binned[slot], 0));
-    if (int rc = cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
-                                     scratch_bytes, so))
+    g_overlay_stop_event = (overlay_takes_stop_event && ext_events()) ? p->done[k % RING] : nullptr;
+    if (int rc = overlay(scratch, (void *)so)) {
+        g_overlay_stop_event = nullptr;
         return rc;
-    HIP_TRY(hipEventRecord(p->done[k % RING], so));
+    }
+    if (!(overlay_takes_stop_event && ext_events()) || g_overlay_stop_event)
+        HIP_TRY(hipEventRecord(p->done[k % RING], so));      // the launch did not take the event: record it behind
+    g_overlay_stop_event = nullptr;
     p->issued = k;
     return CAMA_OK;
+}
+
+extern "C" {
+
+int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
+                         const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
+                         const double *w2c, int32_t F,
+                         const double *c2cam, const double *K, int32_t C, const double *crop, int32_t W, int32_t H,
+                         const uint8_t *src, uint8_t *mosaic, int32_t cols, int32_t radius, const int32_t *halfwidth,
+                         const uint8_t *palette_bgr, void *scratch0, void *scratch1, size_t scratch_bytes,
+                         void *input_stream)
+{
+    if (F > 0 && (!src || !mosaic || !palette_bgr || !halfwidth || cols < 1)) return fail(CAMA_EINVAL, "NULL pointer argument");
+    return pipeline_render_impl(p, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H,
+                                radius, scratch0, scratch1, scratch_bytes, input_stream, true,
+                                [&](void *scratch, void *so) {
+                                    return cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth,
+                                                               palette_bgr, scratch, scratch_bytes, so);
+                                });
+}
+
+int cama_pipeline_render_raw35(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
+                               const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
+                               const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                               const double *crop, int32_t W, int32_t H, const uint8_t *raw, int32_t H0, int32_t W0,
+                               const uint32_t *vrows, const int32_t *band_rows, int32_t max_src_rows, uint8_t *mosaic,
+                               int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                               void *scratch0, void *scratch1, size_t scratch_bytes, void *input_stream)
+{
+    if (F > 0 && (!raw || !vrows || !band_rows || !mosaic || !palette_bgr || !halfwidth || cols < 1))
+        return fail(CAMA_EINVAL, "NULL pointer argument");
+    return pipeline_render_impl(p, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H,
+                                radius, scratch0, scratch1, scratch_bytes, input_stream, true,
+                                [&](void *scratch, void *so) {
+                                    return cama_overlay_frames_raw35(raw, H0, W0, vrows, band_rows, max_src_rows, mosaic, N,
+                                                                     F, C, H, W, cols, radius, halfwidth, palette_bgr,
+                                                                     scratch, scratch_bytes, so);
+                                });
 }
 
 int cama_pipeline_join(cama_pipeline *p, void *stream)

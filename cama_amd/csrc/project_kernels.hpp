@@ -207,6 +207,8 @@ struct FrameArgs {
     const uint8_t *colour;
     const uint32_t *key;    // optional [N]: draw index << 1 | colour (maps stored in a different order than drawn)
     const double *bounds;   // optional [ceil(N/BLOCK),6]: per-vertex-block AABB (k_block_bounds), for the crop cull
+    const uint16_t *cam_mask;   // optional [F, vblocks]: cameras that may see a block (k_block_cameras); 0 = outside crop
+    uint32_t vblocks;
     int64_t N;
     const double *w2c, *c2cam, *K;
     int C, W, H;
@@ -279,10 +281,13 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
     // maps ~95 % of the workgroups end here and never pay for clearing the histogram
     const double *w2c = a.w2c + (size_t)f * 16;
     const int64_t i = vblock * BLOCK + threadIdx.x;
-    // ... and with the map's block AABBs (cama_map_bounds) those workgroups do not even read their vertices
-    if (CULL && a.bounds) {
+    // ... and with the map's block AABBs (cama_map_bounds -> k_block_cameras) those workgroups do not even read their
+    // vertices; the surviving ones know which cameras can see the block at all
+    uint32_t cams = 0xffffu;
+    if (a.cam_mask) {
         if (vblock * BLOCK >= a.N) return;
-        if (block_outside_crop(w2c, a.bounds + (size_t)vblock * 6, a.crop)) return;
+        cams = a.cam_mask[(size_t)f * a.vblocks + (size_t)vblock];       // wave-uniform (scalar) load
+        if (CULL && !cams) return;
     }
     double cx = 0, cy = 0, cz = 0;
     bool in = false;
@@ -307,6 +312,7 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
     const uint32_t seg = (uint32_t)vblock * (BLOCK / SEG) + (threadIdx.x >> 6);
     const uint32_t lane = __lane_id();
     for (int c = 0; c < a.C; ++c) {
+        if (!((cams >> c) & 1u)) continue;                               // wave-uniform: no vertex of the block in view
         uint32_t uv = 0xffffffffu;      // packed truncated pixel, or "not visible"
         if (in) {
             uint32_t packed;
@@ -427,23 +433,94 @@ __global__ __launch_bounds__(BLOCK) void k_stamps_scatter(FrameArgs a)
     }
 }
 
-// Site-sized maps: F * ceil(N/BLOCK) work items, ~95 % of them outside the crop box.  Even an empty workgroup costs
-// ~0.8 ns of dispatch (measured: 1.25 M workgroups / ms), so the items are culled first, one THREAD per item, into
-// work lists (k_cull_blocks), and persistent workgroups walk the survivors.  There is one list per XCD: vertex block b
-// always goes to list b % 8 and list l is walked by the workgroups with blockIdx.x % 8 == l, i.e. (round-robin
-// dispatch) by XCD l, so every XCD's L2 keeps its eighth of the live vertex blocks across all frames.
-__global__ __launch_bounds__(BLOCK) void k_cull_blocks(const double *__restrict__ bounds, const double *__restrict__ w2c,
-                                                       Crop crop, uint32_t vblocks, uint32_t list_cap,
-                                                       uint32_t *__restrict__ work_count, uint32_t *__restrict__ work)
+// Which cameras can a vertex block reach?  One THREAD per (vertex block, frame): the block's world AABB becomes a
+// conservative chassis-frame box (centre +- sum |m_k| * half extent, as in block_outside_crop), clipped to the crop box
+// (vertices outside it are dropped before projection), and that box is tested against the five half-spaces every visible
+// point satisfies in homogeneous image coordinates h = K (R p + t):
+//     h2 > 0,   h0 >= 0,   h0 - W h2 < 0,   h1 >= 0,   h1 - H h2 < 0
+// (each a linear functional of the chassis point; a box wholly on the wrong side of any one of them has no visible point in
+// that camera -- for points with h2 <= 0 nothing is visible anyway, so the sign arguments only need h2 > 0).  Margins of
+// 1e-9 relative + 1e-9 absolute are >= 6 orders above fp64 rounding of the exact chain, and every comparison is false on
+// NaN, i.e. "may be visible": the mask never removes a stamp, the output is bit-identical with and without it.
+// Bit c of cam_mask[f * vblocks + b] = camera c may see block b in frame f; 0 = the block is outside the crop box too.
+// The projection kernel then skips the whole fp64 chain of the other cameras (wave-uniform branch): on dense lane maps a
+// block is in view of 1-2 of the 6 cameras.  With WORKLIST the surviving (block, frame) items are also appended to 8
+// per-XCD work lists for persistent workgroups (site-sized maps: ~95 % of the items are outside the crop box, and even an
+// empty workgroup costs ~0.8 ns of dispatch): vertex block b always goes to list b % 8 and list l is walked by the
+// workgroups with blockIdx.x % 8 == l, i.e. by XCD l, whose L2 keeps its eighth of the live vertex blocks.
+__device__ __forceinline__ bool box_beyond(const double n0, const double n1, const double n2, const double d,
+                                           const double *mid, const double *rad, const bool want_positive)
+{
+    // functional L(p) = n.p + d over the box mid +- rad: returns true iff L < 0 on the whole box (want_positive: the
+    // visible side is L >= 0 / L > 0) or L > 0 on the whole box (!want_positive: the visible side is L < 0), with margin
+    const double v = n0 * mid[0] + n1 * mid[1] + n2 * mid[2] + d;
+    const double s = fabs(n0) * rad[0] + fabs(n1) * rad[1] + fabs(n2) * rad[2];
+    const double mag = fabs(n0) * (fabs(mid[0]) + rad[0]) + fabs(n1) * (fabs(mid[1]) + rad[1]) +
+                       fabs(n2) * (fabs(mid[2]) + rad[2]) + fabs(d);
+    const double margin = 1e-9 + 1e-9 * mag;
+    return want_positive ? (v + s + margin < 0.0) : (v - s - margin > 0.0);
+}
+
+template <bool WORKLIST>
+__global__ __launch_bounds__(BLOCK) void k_block_cameras(const double *__restrict__ bounds, const double *__restrict__ w2c,
+                                                         const double *__restrict__ c2cam, const double *__restrict__ K,
+                                                         int C, int W, int H, Crop crop, uint32_t vblocks,
+                                                         uint16_t *__restrict__ cam_mask, uint32_t list_cap,
+                                                         uint32_t *__restrict__ work_count, uint32_t *__restrict__ work)
 {
     const uint32_t b = blockIdx.x * BLOCK + threadIdx.x, f = blockIdx.y;   // b % 8 == lane % 8
-    bool keep = false;
-    if (b < vblocks) keep = !block_outside_crop(w2c + (size_t)f * 16, bounds + (size_t)b * 6, crop);
-    const uint64_t m = __ballot(keep);
-    if (!m) return;
+    uint32_t mask = 0;
+    if (b < vblocks) {
+        const double *m = w2c + (size_t)f * 16, *bx = bounds + (size_t)b * 6;
+        const double wx = 0.5 * (bx[0] + bx[1]), wy = 0.5 * (bx[2] + bx[3]), wz = 0.5 * (bx[4] + bx[5]);
+        const double ex = 0.5 * (bx[1] - bx[0]), ey = 0.5 * (bx[3] - bx[2]), ez = 0.5 * (bx[5] - bx[4]);
+        double mid[3], rad[3];
+        bool outside = false, finite = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double c0 = m[4 * r], c1 = m[4 * r + 1], c2 = m[4 * r + 2], c3 = m[4 * r + 3];
+            const double ctr = c0 * wx + c1 * wy + c2 * wz + c3;
+            const double rd = fabs(c0) * ex + fabs(c1) * ey + fabs(c2) * ez;
+            const double mag = fabs(c0 * wx) + fabs(c1 * wy) + fabs(c2 * wz) + fabs(c3) + rd;
+            const double margin = 1e-6 + 1e-9 * mag;
+            double lo = ctr - rd - margin, hi = ctr + rd + margin;
+            outside |= (hi < crop.v[2 * r]) | (lo > crop.v[2 * r + 1]);
+            finite &= (lo == lo) & (hi == hi) & (fabs(lo) < 1e300) & (fabs(hi) < 1e300);
+            lo = fmax(lo, crop.v[2 * r]);                   // clip to the crop box: only in-crop vertices are projected
+            hi = fmin(hi, crop.v[2 * r + 1]);
+            mid[r] = 0.5 * (lo + hi);
+            rad[r] = 0.5 * (hi - lo);
+        }
+        if (!finite) {
+            mask = (1u << C) - 1u;                          // NaN / inf anywhere: no claim, keep every camera
+        } else if (!outside) {
+            for (int c = 0; c < C; ++c) {
+                const double *M = c2cam + (size_t)c * 16, *Kc = K + (size_t)c * 9;
+                double P[3][4];                             // K * [R | t]
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) P[i][j] = Kc[3 * i] * M[j] + Kc[3 * i + 1] * M[4 + j] + Kc[3 * i + 2] * M[8 + j];
+                const double Wd = (double)W, Hd = (double)H;
+                bool gone = box_beyond(P[2][0], P[2][1], P[2][2], P[2][3], mid, rad, true);                     // h2 > 0
+                gone |= box_beyond(P[0][0], P[0][1], P[0][2], P[0][3], mid, rad, true);                         // h0 >= 0
+                gone |= box_beyond(P[1][0], P[1][1], P[1][2], P[1][3], mid, rad, true);                         // h1 >= 0
+                gone |= box_beyond(P[0][0] - Wd * P[2][0], P[0][1] - Wd * P[2][1], P[0][2] - Wd * P[2][2],
+                                   P[0][3] - Wd * P[2][3], mid, rad, false);                                    // h0 < W h2
+                gone |= box_beyond(P[1][0] - Hd * P[2][0], P[1][1] - Hd * P[2][1], P[1][2] - Hd * P[2][2],
+                                   P[1][3] - Hd * P[2][3], mid, rad, false);                                    // h1 < H h2
+                if (!gone) mask |= 1u << c;
+            }
+        }
+        cam_mask[(size_t)f * vblocks + b] = (uint16_t)mask;
+    }
+    if (!WORKLIST) return;
+    const bool keep = mask != 0u;
+    const uint64_t mk = __ballot(keep);
+    if (!mk) return;
     // one atomic per (wave, list): lane l < 8 reserves for list l, whose members are the lanes = l (mod 8)
     const uint32_t lane = __lane_id();
-    const uint64_t mine = m & (0x0101010101010101ull << (lane & 7u));
+    const uint64_t mine = mk & (0x0101010101010101ull << (lane & 7u));
     uint32_t base = 0;
     if (lane < 8u && mine) base = atomicAdd(&work_count[lane], (uint32_t)__popcll(mine));
     base = __shfl(base, (int)(lane & 7u), 64);

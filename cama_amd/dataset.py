@@ -157,10 +157,12 @@ class ProjectedMaps(Mapping):
 
 class RenderedFrame(Mapping):
     """What render_vectors returns on the fused path: camera name -> (H,W,3) uint8 BGR ndarray
-    (cama/dataset.py:119-126), backed by the mosaic the overlay kernel wrote in HBM."""
+    (cama/dataset.py:119-126), backed by the mosaic the overlay kernel wrote in HBM.  `batch` / `j`: the render-ahead
+    batch the frame belongs to (cama_amd/egress.py), which VideoGenerator uses for the device-side egress."""
 
-    def __init__(self, names, mosaic_dev, H, W, cols=3):
+    def __init__(self, names, mosaic_dev, H, W, cols=3, batch=None, j=0):
         self.names, self.mosaic_device, self.H, self.W, self.cols = list(names), mosaic_dev, H, W, cols
+        self.batch, self.j = batch, j
         self._host = None
 
     def _mosaic_host(self):
@@ -173,6 +175,14 @@ class RenderedFrame(Mapping):
         if order is not None and list(order) != self.names:
             return None
         return self._mosaic_host()
+
+    def mosaic_handle(self, order=None):
+        """The mosaic without leaving HBM (egress.DeviceMosaic) when the frame came out of a render batch and the
+        camera order matches the kernel's cell layout, else None."""
+        if self.batch is None or (order is not None and list(order) != self.names):
+            return None
+        from .egress import DeviceMosaic
+        return DeviceMosaic(self.batch, self.j)
 
     def __getitem__(self, name):
         c = self.names.index(name)
@@ -341,24 +351,60 @@ class ClipManager:
         if isinstance(maps_2d_dict, ProjectedMaps) and maps_2d_dict.frame.owner is self \
                 and maps_2d_dict._items is None and maps_2d_dict.frame.image_idx == image_idx:
             fr = maps_2d_dict.frame
-            eng = runtime.engine()
             rig = self._rig()
-            source = self.frame_source()
-            dmap = self._static(fr.dataset).device()
-            if getattr(source, "fused", False) and hasattr(source, "raw_batch"):
-                # raw sensor frames: undistort + resize happens inside the overlay kernel
-                mosaic = eng.render_frames_raw(dmap, rig, fr.world2chassis[None], source.raw_batch([image_idx]),
-                                               self.cm_list, crop=self.mm.crop_box())
-            else:
-                mosaic = eng.render_frames(dmap, rig, fr.world2chassis[None], source.batch([image_idx]),
-                                           crop=self.mm.crop_box())
-            return RenderedFrame(rig.names, mosaic[0], rig.H, rig.W)
+            batch, j = self._render_ahead(fr)
+            return RenderedFrame(rig.names, batch.mosaic[j], rig.H, rig.W, batch=batch, j=j)
         # generic path: caller-supplied 2D instances, one image at a time like the reference
         out = {}
         for cm in self.cm_list:
             image = cm.read_resized_image_by_index(image_idx)
             out[cm.camera_name] = cm.render_maps(image, maps_2d_dict[cm.camera_name])
         return out
+
+    def _render_batch(self, dataset, image_ids, w2c):
+        """One fused launch for the frames `image_ids` (consecutive entries of the pass) -> egress.RenderBatch."""
+        from .egress import RenderBatch
+        eng = runtime.engine()
+        rig = self._rig()
+        source = self.frame_source()
+        dmap = self._static(dataset).device()
+        if getattr(source, "fused", False) and hasattr(source, "raw_batch"):
+            # raw sensor frames: undistort + resize happens inside the overlay kernel
+            mosaic = eng.render_frames_raw(dmap, rig, w2c, source.raw_batch(image_ids), self.cm_list, crop=self.mm.crop_box())
+        else:
+            mosaic = eng.render_frames(dmap, rig, w2c, source.batch(image_ids), crop=self.mm.crop_box())
+        batch = RenderBatch(eng, image_ids, mosaic)
+        if runtime.egress_mode() == "i420":
+            batch.start_egress()
+        return batch
+
+    def _render_ahead(self, fr):
+        """(batch, position) holding frame `fr` of a yield_frame pass.  The loop in main.py asks frame by frame, but
+        all poses of a pass are known up front (frame_poses), so the frames are rendered `render_ahead` at a time
+        (configs["render_ahead"], default 16; 1 = one launch per frame) the first time one of a batch is asked for, and
+        the following batch is issued right away so that it runs while this one is consumed.  Same kernels, same
+        arguments per frame as a one-frame launch: only the batching differs."""
+        B = max(1, int(self.configs.get("render_ahead", 16)))
+        crop = tuple(float(v) for v in np.asarray(self.mm.crop_box()).reshape(-1))
+        key = (fr.dataset, id(self.instance_maps[fr.dataset]), crop, id(self._frame_source), B)
+        ra = getattr(self, "_ahead", None)
+        if ra is None or ra["key"] != key:
+            idx, w2c = self.frame_poses(fr.dataset)
+            ra = self._ahead = {"key": key, "idx": idx, "w2c": w2c, "pos": {int(i): k for k, i in enumerate(idx)},
+                                "batches": {}}
+        k = ra["pos"].get(int(fr.image_idx))
+        if k is None or B == 1 or not np.array_equal(ra["w2c"][k], fr.world2chassis):
+            return self._render_batch(fr.dataset, [int(fr.image_idx)], np.asarray(fr.world2chassis)[None]), 0
+        b = k // B
+        batches = ra["batches"]
+        for nb in (b, b + 1):                       # this batch now, the next one a batch early
+            lo = nb * B
+            if nb not in batches and lo < len(ra["idx"]):
+                hi = min(len(ra["idx"]), lo + B)
+                batches[nb] = self._render_batch(fr.dataset, [int(i) for i in ra["idx"][lo:hi]], ra["w2c"][lo:hi])
+        for old in [n for n in batches if n < b - 1]:
+            del batches[old]
+        return batches[b], k - b * B
 
     # ------------------------------------------------------------------ whole-clip fused path
     def render_clip(self, dataset, out=None, frames_per_launch=None, poses=None, pipelined=False):
@@ -397,7 +443,7 @@ class ClipManager:
             hi = min(F, lo + step)
             if fused_raw:      # raw sensor frames: undistort + resize inside the overlay kernel
                 eng.render_frames_raw(dmap, rig, T[lo:hi], src_all.raw_batch([int(i) for i in idx[lo:hi]]),
-                                      self.cm_list, out=out[lo:hi], crop=crop)
+                                      self.cm_list, out=out[lo:hi], crop=crop, pipelined=pipelined)
                 continue
             src = src_all.batch([int(i) for i in idx[lo:hi]])
             if pipelined:

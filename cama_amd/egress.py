@@ -1,0 +1,147 @@
+"""Render-ahead batches and mosaic egress for the reference's frame-by-frame loop (main.py:57-61).
+
+The loop asks for one frame at a time; on the device one frame is ~10 us of work behind ~150 us of host issue cost, and
+what leaves the GPU per frame is a 9.3 MB BGR mosaic that the encoder's front end immediately converts to yuv420p
+(cama/tools.py:13-20).  So the drop-in classes work in batches behind the unchanged per-frame surface:
+
+  * ClipManager.render_vectors renders `render_ahead` consecutive frames of the pass in ONE launch the first time a frame
+    of the batch is asked for (all poses of a pass are known up front) and hands out slices afterwards; the next batch
+    is issued one batch early, so the GPU works while the host consumes.
+  * when a VideoGenerator is listening (runtime.egress_mode() == "i420") every batch is converted to planar YUV 4:2:0 on
+    the device (cama_bgr_to_i420) and copied to pinned host memory asynchronously, right behind its render: the
+    per-frame add_frame() is then a wait on an already finished copy plus a 4.7 MB pipe write.
+"""
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class PinnedPool:
+    """Pinned host buffers are expensive to create (hipHostMalloc): recycle them by size."""
+
+    def __init__(self):
+        self.free = {}
+
+    def take(self, nbytes):
+        lst = self.free.get(nbytes)
+        if lst:
+            return lst.pop()
+        return _torch().empty(nbytes, dtype=_torch().uint8, pin_memory=True)
+
+    def give(self, buf):
+        lst = self.free.setdefault(buf.numel(), [])
+        if len(lst) < 4:
+            lst.append(buf)
+
+
+_POOL = PinnedPool()
+
+
+class RenderBatch:
+    """B consecutive frames rendered in one launch: `mosaic` [B, rows*H, cols*W, 3] uint8 in HBM (complete on the
+    stream it was rendered on), plus -- after start_egress() -- their I420 planes on their way to pinned host memory."""
+
+    def __init__(self, engine, image_ids, mosaic):
+        self.engine, self.ids, self.mosaic = engine, [int(i) for i in image_ids], mosaic
+        self._host = self._event = self._i420_dev = None
+        self._host_np = None
+
+    def start_egress(self):
+        """Enqueue BGR -> I420 and the download behind the render (same stream).  False when the mosaic shape does not
+        fit the converter (odd height, width not a multiple of 16): the caller then falls back to BGR downloads."""
+        torch = _torch()
+        B, H2, W2 = (int(v) for v in self.mosaic.shape[:3])
+        per = H2 * W2 * 3 // 2
+        if self._event is not None:
+            return True
+        if H2 % 2 or W2 % 16 or per % 16 or not self.mosaic.is_contiguous():
+            return False
+        eng = self.engine
+        with torch.cuda.device(eng.device):
+            self._i420_dev = torch.empty((B, per), dtype=torch.uint8, device=eng.device)
+            _lib.check(eng.lib.cama_bgr_to_i420(self.mosaic.data_ptr(), H2 * W2 * 3, self._i420_dev.data_ptr(), per, B, H2,
+                                                W2, eng._stream()))
+            self._host = _POOL.take(B * per)
+            self._host.view(B, per).copy_(self._i420_dev, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record(torch.cuda.current_stream(eng.device))
+        return True
+
+    def i420(self, j):
+        """The I420 bytes of frame j as a uint8 ndarray view of the pinned buffer (valid while the batch lives)."""
+        if self._event is None and not self.start_egress():
+            return None
+        if self._host_np is None:
+            self._event.synchronize()
+            B = int(self.mosaic.shape[0])
+            self._host_np = self._host.numpy().reshape(B, -1)
+            self._i420_dev = None
+        return self._host_np[j]
+
+    def bgr(self, j):
+        return self.mosaic[j].cpu().numpy()
+
+    def __del__(self):
+        host = getattr(self, "_host", None)
+        if host is not None:
+            ev = getattr(self, "_event", None)
+            try:
+                if ev is not None:
+                    ev.synchronize()            # the copy into it must be over before someone else reuses it
+                _POOL.give(host)
+            except Exception:
+                pass
+
+
+class DeviceMosaic:
+    """What VideoGenerator.concate_image returns on the fused path: the (2H, 3W, 3) uint8 BGR mosaic, still in HBM.
+    Behaves like the ndarray the reference returns when touched (np.asarray / astype / tobytes / indexing download it
+    once); VideoGenerator.add_frame takes the I420 shortcut instead."""
+
+    def __init__(self, batch, j):
+        self.batch, self.j = batch, j
+        self.shape = tuple(int(v) for v in batch.mosaic.shape[1:])
+        self.dtype = np.dtype(np.uint8)
+        self.ndim = 3
+        self._bgr = None
+
+    def __array__(self, dtype=None, copy=None):
+        if self._bgr is None:
+            self._bgr = self.batch.bgr(self.j)
+        return self._bgr if dtype is None else self._bgr.astype(dtype, copy=False)
+
+    def astype(self, dtype, **kw):
+        return np.asarray(self).astype(dtype, **kw)
+
+    def tobytes(self):
+        return np.asarray(self).tobytes()
+
+    def __getitem__(self, k):
+        return np.asarray(self)[k]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def i420(self):
+        return self.batch.i420(self.j)
+
+
+def bgr_to_i420_host(image):
+    """Host twin of cama_bgr_to_i420 for frames that reach an I420-mode VideoGenerator as plain ndarrays: libswscale's
+    unscaled BGR24 -> YUV420P C arithmetic (BT.601 limited range, 15-bit fixed point, chroma from the first pixel of
+    each 2x2 block).  Returns the planar bytes as one uint8 vector."""
+    img = np.asarray(image, np.uint8)
+    H, W = img.shape[:2]
+    if H % 2 or W % 2:
+        raise ValueError("yuv420p needs even frame sizes")
+    b, g, r = (img[..., k].astype(np.int32) for k in range(3))
+    y = ((8414 * r + 16519 * g + 3208 * b) >> 15) + 16
+    b0, g0, r0 = b[0::2, 0::2], g[0::2, 0::2], r[0::2, 0::2]
+    u = ((-4865 * r0 - 9528 * g0 + 14392 * b0) >> 15) + 128
+    v = ((14392 * r0 - 12061 * g0 - 2332 * b0) >> 15) + 128
+    return np.concatenate([y.astype(np.uint8).reshape(-1), u.astype(np.uint8).reshape(-1), v.astype(np.uint8).reshape(-1)])

@@ -122,17 +122,20 @@ class DeviceMap:
         return base, base + self.N * es, base + 2 * self.N * es
 
     def render_ptrs(self, crop=None):
-        """(x, y, z, colour, key, block bounds) device pointers for the fused render: the sorted copy when there is
-        one; the bounds only for maps that are site-sized against `crop`."""
-        bounds = None
-        if crop is not None and getattr(self, "bounds", None) is not None and self.site_sized(crop):
+        """(x, y, z, colour, key, block bounds, bin flags) for the fused render: the sorted copy when there is one; the
+        block bounds (per-camera / crop culling of whole vertex blocks) whenever the map has an index and is big enough
+        for the one-thread-per-block pre-pass to pay; the work-list flag only for maps that are site-sized against `crop`."""
+        bounds, flags = None, 0
+        if crop is not None and getattr(self, "bounds", None) is not None and self.N >= 65536:
             bounds = self.bounds.data_ptr()
+            if self.site_sized(crop):
+                flags = _lib.BIN_WORKLIST
         if self.sorted_soa is None:
-            return self.ptrs() + (self.colour.data_ptr(), None, bounds)
+            return self.ptrs() + (self.colour.data_ptr(), None, bounds, flags)
         es = self.sorted_soa.element_size()
         base = self.sorted_soa.data_ptr()
         return (base, base + self.N * es, base + 2 * self.N * es, self.colour.data_ptr(), self.sorted_key.data_ptr(),
-                bounds)
+                bounds, flags)
 
 
 class Engine:
@@ -318,10 +321,10 @@ class Engine:
             assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.uint8
             need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
             scratch = self._scratch_buf(need)
-            x, y, z, col, key, bnd = dmap.render_ptrs(cropa)
+            x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
             if self.alpha256 != 256:        # extension path: binning + translucent overlay
                 _lib.check(self.lib.cama_bin_frames(
-                    x, y, z, dmap.is_f64, col, key, bnd, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(),
+                    x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(),
                     rig.C, cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(),
                     self._stream()))
                 _lib.check(self.lib.cama_overlay_frames_alpha(
@@ -330,7 +333,7 @@ class Engine:
                     scratch.numel(), self._stream()))
                 return out
             _lib.check(self.lib.cama_render_frames(
-                x, y, z, dmap.is_f64, col, key, bnd, dmap.N, T.data_ptr(), F,
+                x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T.data_ptr(), F,
                 rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H,
                 src.data_ptr(), out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
                 self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), self._stream()))
@@ -442,9 +445,11 @@ class Engine:
             self._rig_maps = hit
         return hit[1:]
 
-    def render_frames_raw(self, dmap, rig, w2c, raw, cm_list, out=None, cols=3, crop=None):
+    def render_frames_raw(self, dmap, rig, w2c, raw, cm_list, out=None, cols=3, crop=None, pipelined=False):
         """Like render_frames, but `raw` [F,C,H0,W0,3] holds RAW sensor frames: undistort + resize to the rig's
-        output size happens inside the overlay kernel's source read (cama_overlay_frames_raw)."""
+        output size happens inside the overlay kernel's source read (cama_overlay_frames_raw35 for the reference's
+        3:5 scale, else cama_overlay_frames_raw).  pipelined=True (3:5 scale only; otherwise ignored) goes through the
+        two-stream pipeline like render_frames_pipelined: `out` is complete after join()."""
         torch = _torch()
         cropa = self._crop(crop)
         with torch.cuda.device(self.device):
@@ -461,10 +466,28 @@ class Engine:
             mapx, mapy, sep, band_rows, max_rows, tiles, tiles_x, max_tile, vrows = self.rig_maps(cm_list)
             need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
             scratch = self._scratch_buf(need)
-            x, y, z, col, key, bnd = dmap.render_ptrs(cropa)
+            x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
             st = self._stream()
+            if pipelined and vrows is not None:
+                P = self._pipeline()
+                for k in range(2):
+                    if P["scratch"][k] is None or P["scratch"][k].numel() < need:
+                        if P["scratch"][k] is not None:
+                            self.join()
+                            torch.cuda.current_stream(self.device).synchronize()
+                        P["scratch"][k] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+                s0, s1 = P["scratch"]
+                _lib.check(self.lib.cama_pipeline_render_raw35(
+                    P["handle"], x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
+                    rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, raw.data_ptr(), H0, W0, vrows[0].data_ptr(),
+                    vrows[1].data_ptr(), vrows[2], out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
+                    self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(), min(s0.numel(), s1.numel()), st))
+                seq = int(self.lib.cama_pipeline_issued(P["handle"]))
+                P["keep"].append((seq, T, raw, out, dmap, rig))
+                self._release_completed(P)
+                return out
             _lib.check(self.lib.cama_bin_frames(
-                x, y, z, dmap.is_f64, col, key, bnd, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
+                x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
                 cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(), st))
             if vrows is not None:
                 _lib.check(self.lib.cama_overlay_frames_raw35(
@@ -515,9 +538,9 @@ class Engine:
                         torch.cuda.current_stream(self.device).synchronize()     # old buffer may still be in use
                     P["scratch"][k] = torch.empty(need, dtype=torch.uint8, device=self.device)
             s0, s1 = P["scratch"]
-            x, y, z, col, key, bnd = dmap.render_ptrs(cropa)
+            x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
             _lib.check(self.lib.cama_pipeline_render(
-                P["handle"], x, y, z, dmap.is_f64, col, key, bnd, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
+                P["handle"], x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
                 rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, src.data_ptr(), out.data_ptr(), cols,
                 self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(),
                 min(s0.numel(), s1.numel()), self._stream()))

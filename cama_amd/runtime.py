@@ -23,3 +23,19 @@ def engine():
 def set_engine(e):
     global _engine
     _engine = e
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# egress: a VideoGenerator that can take planar YUV 4:2:0 announces itself here, and the render path then prepares
+# every batch's I420 planes + download right behind its render (cama_amd/egress.py)
+_egress = None
+
+
+def request_egress(mode):
+    """mode: "i420" or None."""
+    global _egress
+    _egress = mode
+
+
+def egress_mode():
+    return _egress

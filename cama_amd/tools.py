@@ -10,6 +10,7 @@ quiet -- is a plain subprocess of the `ffmpeg` binary, started lazily so that im
 mosaics works on machines without ffmpeg.  `self.writer` keeps the `.stdin` / `.wait()` interface callers use.
 """
 import json
+import os
 import shutil
 import subprocess
 
@@ -25,34 +26,98 @@ def load_json(filename):
         return json.load(f)
 
 
-def _encoder_command(path, width, height, fps=VIDEO_FPS):
+def _encoder_command(path, width, height, fps=VIDEO_FPS, pix_fmt="bgr24"):
     return ["ffmpeg", "-loglevel", "quiet", "-y",
-            "-f", "rawvideo", "-pix_fmt", "bgr24", "-s", f"{width}x{height}", "-i", "pipe:",
+            "-f", "rawvideo", "-pix_fmt", pix_fmt, "-s", f"{width}x{height}", "-i", "pipe:",
             "-pix_fmt", "yuv420p", "-vcodec", "libx264", "-r", str(fps), path]
 
 
+class _Sink:
+    """Stands in for the encoder process when there is no ffmpeg (neither box has one) or a test wants the stream:
+    `.stdin.write` goes to a file object, `.wait()` is a no-op."""
+
+    def __init__(self, fileobj, close):
+        self.stdin, self._close = fileobj, close
+
+    def wait(self):
+        return 0
+
+
 class VideoGenerator:
-    def __init__(self, output_video_path, output_shape=(2880, 1080)):
+    """cama/tools.py:12-40.  Same constructor, concate_image, add_frame.  The encoder (ffmpeg: rawvideo in -> libx264
+    yuv420p out, 10 fps, overwrite, quiet) is started at the first add_frame, because only then it is known what
+    crosses the pipe:
+
+      * frames that come out of ClipManager.render_vectors as device mosaics leave the GPU as planar YUV 4:2:0 (the
+        encoder's own pixel format: cama_bgr_to_i420 + a pinned, asynchronous download prepared per render batch), so the
+        pipe carries `-pix_fmt yuv420p` rawvideo: half the bytes, no libswscale pass in ffmpeg;
+      * plain ndarrays (the reference's path) are piped as bgr24, exactly the reference's bytes.  CAMA_EGRESS=bgr24 forces
+        this mode for device mosaics too.
+
+    `sink`: a binary file object that receives the raw stream instead of an encoder (tests; CAMA_VIDEO_SINK=null or a file
+    path does the same for an unchanged main.py on a machine without ffmpeg)."""
+
+    def __init__(self, output_video_path, output_shape=(2880, 1080), sink=None):
         self.output_video_path = output_video_path
         self.output_shape = tuple(output_shape)         # (width, height) of the mosaic
-        if shutil.which("ffmpeg") is None:
+        self.writer = None
+        self.pix_fmt = None                             # decided by the first frame
+        self._sink = sink
+        env = os.environ.get("CAMA_VIDEO_SINK")
+        if sink is None and env:
+            self._sink = open(os.devnull if env == "null" else env, "wb")
+            self._own_sink = True
+        else:
+            self._own_sink = False
+        if self._sink is None and shutil.which("ffmpeg") is None:
             raise FileNotFoundError("the `ffmpeg` binary is needed to encode the reprojection video")
-        self.writer = subprocess.Popen(_encoder_command(output_video_path, *self.output_shape),
-                                       stdin=subprocess.PIPE)
+        if os.environ.get("CAMA_EGRESS", "i420") != "bgr24":
+            from . import runtime
+            runtime.request_egress("i420")              # render batches prepare their I420 planes from now on
+
+    def _start(self, pix_fmt):
+        self.pix_fmt = pix_fmt
+        if self._sink is not None:
+            self.writer = _Sink(self._sink, self._own_sink)
+        else:
+            self.writer = subprocess.Popen(_encoder_command(self.output_video_path, *self.output_shape, pix_fmt=pix_fmt),
+                                           stdin=subprocess.PIPE)
 
     def concate_image(self, image_dict):
         """camera name -> (H,W,3) images => (2H,3W,3): front_left | front | front_right over the three rear cameras."""
+        handle = getattr(image_dict, "mosaic_handle", None)
+        if callable(handle):
+            dev = handle(MOSAIC_ORDER)                 # already assembled in HBM by the overlay kernel: stays there
+            if dev is not None:
+                return dev
         mosaic = getattr(image_dict, "mosaic", None)
         if callable(mosaic):
-            ready = mosaic(MOSAIC_ORDER)               # already assembled in HBM by the overlay kernel
+            ready = mosaic(MOSAIC_ORDER)
             if ready is not None:
                 return ready
         rows = [np.concatenate([image_dict[name] for name in MOSAIC_ORDER[r:r + 3]], axis=1) for r in (0, 3)]
         return np.concatenate(rows, axis=0)
 
     def add_frame(self, image):
-        """Raw BGR24 bytes of the mosaic into the encoder's pipe (tools.py:28-32 writes image.astype(uint8).tobytes():
-        the same bytes; a contiguous uint8 array goes out through the buffer protocol without the two 9 MB copies)."""
+        """One mosaic into the encoder's pipe (tools.py:28-32 writes image.astype(uint8).tobytes())."""
+        pix_fmt = getattr(self, "pix_fmt", None) or ("bgr24" if getattr(self, "writer", None) is not None else None)
+        i420 = getattr(image, "i420", None)
+        planes = None
+        if callable(i420) and pix_fmt in (None, "yuv420p") and os.environ.get("CAMA_EGRESS", "i420") != "bgr24":
+            planes = i420()                             # pinned host bytes prepared behind the render; None = cannot
+        if planes is not None:
+            if self.writer is None:
+                self._start("yuv420p")
+            self.writer.stdin.write(memoryview(planes).cast("B"))
+            return
+        if getattr(self, "writer", None) is None:
+            self._start("bgr24")
+            pix_fmt = "bgr24"
+        if pix_fmt == "yuv420p":                        # a plain array in an I420 stream: convert on the host
+            from .egress import bgr_to_i420_host
+            self.writer.stdin.write(memoryview(bgr_to_i420_host(np.asarray(image))).cast("B"))
+            return
+        # the same bytes as the reference; a contiguous uint8 array goes out through the buffer protocol
         self.writer.stdin.write(memoryview(np.ascontiguousarray(image, dtype=np.uint8)).cast("B"))
 
     def add_frame_from_dict(self, image_dict):
@@ -62,8 +127,17 @@ class VideoGenerator:
         writer = getattr(self, "writer", None)
         if writer is not None:
             self.writer = None
-            writer.stdin.close()
-            writer.wait()
+            if not isinstance(writer, _Sink):
+                writer.stdin.close()
+                writer.wait()
+            elif writer._close:
+                writer.stdin.close()
+        elif getattr(self, "_own_sink", False) and self._sink is not None:
+            self._sink.close()
+        self._sink = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass

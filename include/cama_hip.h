@@ -39,12 +39,13 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 7
+#define CAMA_ABI_VERSION 8
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
 #define CAMA_MAX_CAMERAS 16
 #define CAMA_MAX_RADIUS  15
+#define CAMA_BIN_WORKLIST 1   /* flags of the bin / render entries */
 
 int cama_abi_version(void);
 const char *cama_last_error(void);
@@ -111,9 +112,14 @@ int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz
  *   draw_key   NULL, or [N] uint32 = (draw index << 1) | colour for vertex buffers stored in another order than
  *              they are drawn (e.g. spatially sorted): "last writer wins" follows the draw index, not storage
  *              order; colour_id is ignored when draw_key is given
- *   block_bounds NULL, or the map's per-block AABBs from cama_map_bounds(): vertex blocks that cannot reach the crop
- *              box are skipped without reading their vertices (site-sized maps: ~95 % of them).  Conservative, so
- *              the output is bit-identical with and without it
+ *   block_bounds NULL, or the map's per-block AABBs from cama_map_bounds().  A pre-pass then decides per (vertex block,
+ *              frame) which cameras can see the block at all (conservative box-vs-frustum and box-vs-crop tests): blocks
+ *              outside the crop box are skipped without reading their vertices, and for the others the fp64 projection
+ *              chain runs only for the cameras that may see them (dense lane maps: 1-2 of 6).  Conservative, so the
+ *              output is bit-identical with and without it
+ *   flags      0, or CAMA_BIN_WORKLIST (needs block_bounds): the surviving (block, frame) items go through work lists walked
+ *              by persistent workgroups instead of one workgroup per item -- for site-sized maps, where ~95 % of the
+ *              blocks are outside the crop box on any frame
  *   w2c        [F,16]             c2cam [C,16]   K [C,9]   crop host[6]
  *   src        [F,C,H,W,3] uint8 BGR frames (already at output size)
  *   mosaic     [F, rows*H, cols*W, 3] uint8, rows = ceil(C/cols); camera c goes to cell
@@ -136,7 +142,7 @@ int cama_map_bounds_block(void);
 int cama_map_bounds(const void *x, const void *y, const void *z, int32_t xyz_is_f64, int64_t N, double *bounds,
                     void *stream);
 int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                       const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int64_t N,
+                       const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
                        const double *w2c, int32_t F,
                        const double *c2cam, const double *K, int32_t C,
                        const double *crop, int32_t W, int32_t H,
@@ -152,7 +158,7 @@ int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_
  * orders the overlay after its own binning (stream order or an event).  Arguments as above.
  */
 int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                    const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int64_t N,
+                    const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
                     const double *w2c, int32_t F,
                     const double *c2cam, const double *K, int32_t C,
                     const double *crop, int32_t W, int32_t H, int32_t radius,
@@ -181,13 +187,21 @@ typedef struct cama_pipeline cama_pipeline;
 int cama_pipeline_create(cama_pipeline **out);
 int cama_pipeline_destroy(cama_pipeline *p);
 int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                         const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int64_t N,
+                         const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
                          const double *w2c, int32_t F,
                          const double *c2cam, const double *K, int32_t C,
                          const double *crop, int32_t W, int32_t H,
                          const uint8_t *src, uint8_t *mosaic, int32_t cols,
                          int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
                          void *scratch0, void *scratch1, size_t scratch_bytes, void *input_stream);
+/* The same pipeline with the 3:5 raw-frame overlay (cama_overlay_frames_raw35) as its overlay half. */
+int cama_pipeline_render_raw35(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
+                               const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
+                               const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                               const double *crop, int32_t W, int32_t H, const uint8_t *raw, int32_t H0, int32_t W0,
+                               const uint32_t *vrows, const int32_t *band_rows, int32_t max_src_rows, uint8_t *mosaic,
+                               int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                               void *scratch0, void *scratch1, size_t scratch_bytes, void *input_stream);
 int cama_pipeline_join(cama_pipeline *p, void *stream);
 int64_t cama_pipeline_issued(cama_pipeline *p);
 int64_t cama_pipeline_completed(cama_pipeline *p);

@@ -84,6 +84,82 @@ def test_main_loop_renders_like_the_oracle(tmp_path):
         assert n == len(want) == 3
 
 
+def test_bgr_to_i420_matches_the_swscale_restatement():
+    """cama_bgr_to_i420 (mosaic egress) == the oracle's restatement of libswscale's unscaled BGR24 -> YUV420P C path, byte
+    for byte: random frames, the 2880x1080 mosaic size, a strided batch, and the extreme colours."""
+    import torch
+    from cama_amd import _lib, runtime
+    eng = runtime.engine()
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for n, H, W in ((3, 8, 32), (2, 1080, 2880), (1, 90, 160)):
+        src = torch.randint(0, 256, (n, H, W, 3), dtype=torch.uint8, device=eng.device)
+        if (n, H, W) == (3, 8, 32):
+            src[0, :, :16] = 255
+            src[0, :, 16:] = 0
+            src[1, ..., 0], src[1, ..., 1], src[1, ..., 2] = 255, 0, 0
+        per = H * W * 3 // 2
+        dst = torch.zeros((n, per + 16), dtype=torch.uint8, device=eng.device)       # strided destination
+        _lib.check(L.cama_bgr_to_i420(src.data_ptr(), H * W * 3, dst.data_ptr(), per + 16, n, H, W, st))
+        torch.cuda.synchronize()
+        got, host = dst.cpu().numpy(), src.cpu().numpy()
+        for k in range(n):
+            assert np.array_equal(got[k, :per], O.bgr_to_i420(host[k])), (n, H, W, k)
+            assert not got[k, per:].any()
+    assert L.cama_bgr_to_i420(src.data_ptr(), 90 * 160 * 3, dst.data_ptr(), 90 * 160 * 3 // 2, 1, 91, 160, st) == -1   # odd H
+    assert L.cama_bgr_to_i420(src.data_ptr(), 90 * 160 * 3, dst.data_ptr(), 90 * 160 * 3 // 2, 1, 90, 150, st) == -1   # W % 16
+
+
+def test_main_loop_with_video_generator_streams_i420(tmp_path):
+    """main.py:56-61 verbatim INCLUDING the VideoGenerator (writing to a sink: no ffmpeg on the boxes).  Frames are
+    rendered ahead in batches behind the per-frame surface and leave the GPU as planar YUV 4:2:0; the stream must be,
+    frame by frame, the libswscale-restated conversion of the oracle's mosaic -- for every render_ahead setting."""
+    import io
+    from cama.dataset import ClipManager
+    from cama.tools import VideoGenerator
+    from cama_amd import runtime
+    from cama_amd.egress import DeviceMosaic
+    from cama_amd.synth import make_clip
+    H, W = 96, 160
+    clip = str(tmp_path / "clip")
+    make_clip(clip, n_frames=11, seed=6, n_lines=8, verts_per_line=5, line_len_m=3.0, raster_size=400,
+              image_mode="npy", image_size=(H, W), origin_size=(H, W), with_nuscenes=False)
+    att = O.read_attribute(clip)
+    cams = [O.camera_model(att, n, output_size=(H, W)) for n in CAMERA_NAMES]
+    streams = {}
+    try:
+        for ahead in (4, 1, 16):
+            configs = dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W), render_ahead=ahead)
+            cm = ClipManager(configs, clip)
+            sink = io.BytesIO()
+            vg = VideoGenerator(str(tmp_path / "out.mp4"), (3 * W, 2 * H), sink=sink)
+            n = 0
+            for image_idx, instance_map in cm.yield_frame(dataset="cama"):
+                maps_2d_dict = cm.project_all_camera(instance_map)
+                image_dict = cm.render_vectors(maps_2d_dict, image_idx)
+                image = vg.concate_image(image_dict)
+                assert isinstance(image, DeviceMosaic) and image.shape == (2 * H, 3 * W, 3)
+                vg.add_frame(image)
+                n += 1
+            vg.close()
+            assert n == 10 and vg.pix_fmt == "yuv420p"
+            streams[ahead] = sink.getvalue()
+        per = 2 * H * 3 * W * 3 // 2
+        assert len(streams[4]) == 10 * per and streams[4] == streams[1] == streams[16]
+        want = {i: m2 for i, _, _, m2 in _oracle_frames(clip, configs, "cama", cm.instance_maps["cama"], cams)}
+        for k, image_idx in enumerate(sorted(want)):
+            imgs = {}
+            for c in cams:
+                img = np.load(f"{clip}/{c['name']}/{att['sync'][c['name']][image_idx]}.npy")
+                imgs[c["name"]] = O.render_instances(img.copy(), want[image_idx][c["name"]])
+            ref = O.bgr_to_i420(O.mosaic(imgs))
+            assert streams[4][k * per:(k + 1) * per] == ref.tobytes(), image_idx
+        # touching the lazy mosaic gives the reference's BGR array
+        assert np.array_equal(np.asarray(image), O.mosaic(imgs)) and image.astype(np.uint8).tobytes() == O.mosaic(imgs).tobytes()
+    finally:
+        runtime.request_egress(None)
+
+
 def test_render_clip_batched_equals_per_frame_and_device_source(tmp_path):
     import torch
     from cama_amd.dataset import ClipManager

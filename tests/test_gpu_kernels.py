@@ -242,7 +242,7 @@ def test_bad_arguments_fail_loudly(engine):
     L = _lib.lib()
     assert L.cama_project_points(None, 10, None, None, 6, 10, 10, None, None, None) == -1
     assert b"NULL" in L.cama_last_error()
-    assert L.cama_render_frames(None, None, None, 0, None, None, None, 0, None, 1, None, None, 99, None, 10, 10, None, None, 3, 2,
+    assert L.cama_render_frames(None, None, None, 0, None, None, None, 0, 0, None, 1, None, None, 99, None, 10, 10, None, None, 3, 2,
                                 None, None, None, 0, None) == -1
     assert b"C=99" in L.cama_last_error()
 

@@ -252,3 +252,44 @@ def test_add_frame_pipes_the_reference_bytes():
         want += img.astype(np.uint8).tobytes()
     assert _Writer.stdin.data == want
     vg.writer = None
+
+
+def test_video_generator_sink_and_i420_stream(tmp_path):
+    """A VideoGenerator writing to a sink: plain arrays first -> a bgr24 stream (the reference's bytes); an object that
+    offers I420 planes first -> a yuv420p stream, into which later plain arrays are converted on the host with the same
+    arithmetic as the oracle's libswscale restatement."""
+    import io
+    from oracle import cama_oracle as O
+    from cama_amd import runtime
+    from cama_amd.egress import bgr_to_i420_host
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (8, 32, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (8, 32, 3), dtype=np.uint8)
+    assert np.array_equal(bgr_to_i420_host(a), O.bgr_to_i420(a))
+    extremes = np.array([[[0, 0, 0], [255, 255, 255]], [[255, 0, 0], [0, 0, 255]]], np.uint8).repeat(2, 0).repeat(8, 1)
+    assert np.array_equal(bgr_to_i420_host(extremes), O.bgr_to_i420(extremes))
+    buf = io.BytesIO()
+    vg = VideoGenerator(str(tmp_path / "x.mp4"), (32, 8), sink=buf)
+    assert runtime.egress_mode() == "i420"              # announced itself to the render path
+    vg.add_frame(a)
+    assert vg.pix_fmt == "bgr24" and buf.getvalue() == a.tobytes()
+    vg.close()
+
+    class Planes:                                        # stands in for egress.DeviceMosaic
+        shape, dtype = a.shape, a.dtype
+
+        def i420(self):
+            return O.bgr_to_i420(a)
+
+        def __array__(self, dtype=None, copy=None):
+            return a
+
+    buf = io.BytesIO()
+    vg = VideoGenerator(str(tmp_path / "y.mp4"), (32, 8), sink=buf)
+    vg.add_frame(Planes())
+    vg.add_frame(b)
+    assert vg.pix_fmt == "yuv420p"
+    assert buf.getvalue() == O.bgr_to_i420(a).tobytes() + O.bgr_to_i420(b).tobytes()
+    assert len(buf.getvalue()) == 2 * 8 * 32 * 3 // 2
+    vg.close()
+    runtime.request_egress(None)

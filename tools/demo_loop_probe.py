@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""The reference's main.py loop (main.py:56-61), verbatim, on a synthetic clip with 1600x900 JPEG frames, VideoGenerator
+included: frames/s end to end (files -> device JPEG decode -> fused raw overlay -> device I420 -> pinned download -> sink).
+
+    CAMA_VIDEO_SINK=null python tools/demo_loop_probe.py [--frames 240] [--content photo|noise]
+"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=240)
+    ap.add_argument("--content", choices=["noise", "photo"], default="photo")
+    args = ap.parse_args()
+    import torch
+    from cama.dataset import ClipManager
+    from cama.tools import VideoGenerator
+    from cama_amd.synth import DEFAULT_CAMA_CONFIGS, make_clip
+    root = tempfile.mkdtemp(prefix="cama_demo_")
+    clip = os.path.join(root, "clip")
+    t = time.perf_counter()
+    make_clip(clip, n_frames=args.frames + 1, seed=0, n_lines=20, verts_per_line=11, line_len_m=5.0, raster_size=3000,
+              image_mode="jpg" if args.content == "noise" else "jpg_photo", image_size=(900, 1600), with_nuscenes=False,
+              extra_labels=False)
+    print(f"clip with {6 * (args.frames + 1)} JPEGs written in {time.perf_counter() - t:.1f} s")
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)          # reference default output size (540, 960)
+    for label in ("first pass (one-off setup)", "steady state", "steady state"):
+        vg = VideoGenerator(os.path.join(root, "out.mp4"), (2880, 1080))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        # ---- main.py:57-61 ----
+        for image_idx, instance_map in cm.yield_frame(dataset="cama"):
+            maps_2d_dict = cm.project_all_camera(instance_map)
+            image_dict = cm.render_vectors(maps_2d_dict, image_idx)
+            image = vg.concate_image(image_dict)
+            vg.add_frame(image)
+            n += 1
+        # ------------------------
+        vg.close()
+        dt = time.perf_counter() - t0
+        print(f"main.py loop, {label}: {n} frames in {dt:.3f} s = {n / dt:.1f} frames/s (stream: {vg.pix_fmt}, "
+              f"mosaic {tuple(image.shape)})")
+
+
+if __name__ == "__main__":
+    main()
