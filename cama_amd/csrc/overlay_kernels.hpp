@@ -38,11 +38,21 @@ __device__ __forceinline__ void rasterise_one(uint32_t *s_owner, const uint2 r, 
     }
 }
 
-template <int THREADS = OVERLAY_BLOCK>
-__device__ __forceinline__ void rasterise_stamps(uint32_t *s_owner, const uint2 *st, uint32_t n,
-                                                 int y0, int nrows, int W, const Disc &disc)
+// Stamps `first`, first + stride, ... < n of a band's list, four record loads in flight per thread: on bands that
+// collect tens of thousands of stamps (dense maps: every far lane converges on a few horizon rows) the loop is a chain of
+// global-load latencies, and such a band's workgroup is the kernel's straggler.  Loads are unconditional (clamped index):
+// a load under a divergent guard is waited for at the end of the guard.
+__device__ __forceinline__ void rasterise_rest(uint32_t *s_owner, const uint2 *st, uint32_t first, uint32_t stride, uint32_t n,
+                                               int y0, int nrows, int W, const Disc &disc)
 {
-    for (uint32_t s = threadIdx.x; s < n; s += THREADS) rasterise_one(s_owner, st[s], y0, nrows, W, disc);
+    for (uint32_t s = first; s < n; s += 4u * stride) {
+        const uint2 r0 = st[s], r1 = st[min(s + stride, n - 1u)], r2 = st[min(s + 2u * stride, n - 1u)],
+                    r3 = st[min(s + 3u * stride, n - 1u)];
+        rasterise_one(s_owner, r0, y0, nrows, W, disc);
+        if (s + stride < n) rasterise_one(s_owner, r1, y0, nrows, W, disc);
+        if (s + 2u * stride < n) rasterise_one(s_owner, r2, y0, nrows, W, disc);
+        if (s + 3u * stride < n) rasterise_one(s_owner, r3, y0, nrows, W, disc);
+    }
 }
 
 // per-byte (colour*a + source*(256-a) + 128) >> 8 on four packed bytes: even and odd bytes as two 16-bit lanes each
@@ -170,8 +180,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
         for (int j = threadIdx.x; j < n4; j += OVERLAY_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
         lds_barrier();
         if (threadIdx.x < n) rasterise_one(s_owner, first, y0, nrows, W, a.disc);
-        for (uint32_t s = threadIdx.x + OVERLAY_BLOCK; s < n; s += OVERLAY_BLOCK)
-            rasterise_one(s_owner, st[s], y0, nrows, W, a.disc);
+        rasterise_rest(s_owner, st, threadIdx.x + OVERLAY_BLOCK, OVERLAY_BLOCK, n, y0, nrows, W, a.disc);
         lds_barrier();
     }
 

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
         for (int j = threadIdx.x; j < n4; j += blockDim.x) o4[j] = make_uint4(0, 0, 0, 0);
         lds_barrier();
         if (threadIdx.x < n) rasterise_one(s_owner, first, y0, nrows, W, a.disc);
-        for (uint32_t s = threadIdx.x + blockDim.x; s < n; s += blockDim.x) rasterise_one(s_owner, st[s], y0, nrows, W, a.disc);
+        rasterise_rest(s_owner, st, threadIdx.x + blockDim.x, blockDim.x, n, y0, nrows, W, a.disc);
     }
     u32x4 *s16 = reinterpret_cast<u32x4 *>(s_stage);
 #pragma unroll

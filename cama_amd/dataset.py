@@ -438,14 +438,17 @@ class ClipManager:
             raw_bytes = rig.C * int(c0.height_origin) * int(c0.width_origin) * 3 if fused_raw else None
             step = eng.max_frames_per_call(dmap, rig, resident_frames=resident, src_bytes_per_frame=raw_bytes,
                                            pipelined=pipelined)
-        T = eng._mats(w2c)
+        # pipelined launches take the host float32 poses as they are (staged by the library); the others one upload
+        host_poses = pipelined and isinstance(w2c, np.ndarray) and w2c.dtype == np.float32
+        T = w2c if host_poses else eng._mats(w2c)
+        ids = idx.tolist()
         for lo in range(0, F, step):
             hi = min(F, lo + step)
             if fused_raw:      # raw sensor frames: undistort + resize inside the overlay kernel
-                eng.render_frames_raw(dmap, rig, T[lo:hi], src_all.raw_batch([int(i) for i in idx[lo:hi]]),
+                eng.render_frames_raw(dmap, rig, T[lo:hi], src_all.raw_batch(ids[lo:hi]),
                                       self.cm_list, out=out[lo:hi], crop=crop, pipelined=pipelined)
                 continue
-            src = src_all.batch([int(i) for i in idx[lo:hi]])
+            src = src_all.batch(ids[lo:hi])
             if pipelined:
                 eng.render_frames_pipelined(dmap, rig, T[lo:hi], src, out[lo:hi], crop=crop)
             else:

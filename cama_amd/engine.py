@@ -453,9 +453,13 @@ class Engine:
         torch = _torch()
         cropa = self._crop(crop)
         with torch.cuda.device(self.device):
-            T = w2c if (isinstance(w2c, torch.Tensor) and w2c.dtype == torch.float64 and w2c.is_cuda
-                        and w2c.dim() == 2) else self._mats(w2c)
-            F = T.shape[0]
+            host32 = pipelined and isinstance(w2c, np.ndarray) and w2c.dtype == np.float32      # staged by the pipeline
+            if host32:
+                T, F = None, int(w2c.reshape(-1, 16).shape[0])
+            else:
+                T = w2c if (isinstance(w2c, torch.Tensor) and w2c.dtype == torch.float64 and w2c.is_cuda
+                            and w2c.dim() == 2) else self._mats(w2c)
+                F = T.shape[0]
             assert raw.is_cuda and raw.dtype == torch.uint8 and raw.is_contiguous() and raw.dim() == 5
             assert raw.shape[0] == F and raw.shape[1] == rig.C and raw.shape[4] == 3
             H0, W0 = int(raw.shape[2]), int(raw.shape[3])
@@ -470,15 +474,11 @@ class Engine:
             st = self._stream()
             if pipelined and vrows is not None:
                 P = self._pipeline()
-                for k in range(2):
-                    if P["scratch"][k] is None or P["scratch"][k].numel() < need:
-                        if P["scratch"][k] is not None:
-                            self.join()
-                            torch.cuda.current_stream(self.device).synchronize()
-                        P["scratch"][k] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
-                s0, s1 = P["scratch"]
+                s0, s1 = self._pipe_scratch(P, need)
+                staged = self._stage_poses(P, w2c)
+                T_ptr = staged[0] if staged is not None else T.data_ptr()
                 _lib.check(self.lib.cama_pipeline_render_raw35(
-                    P["handle"], x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
+                    P["handle"], x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T_ptr, F, rig.c2cam.data_ptr(),
                     rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, raw.data_ptr(), H0, W0, vrows[0].data_ptr(),
                     vrows[1].data_ptr(), vrows[2], out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
                     self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(), min(s0.numel(), s1.numel()), st))
@@ -486,6 +486,8 @@ class Engine:
                 P["keep"].append((seq, T, raw, out, dmap, rig))
                 self._release_completed(P)
                 return out
+            if T is None:
+                T = self._mats(w2c)
             _lib.check(self.lib.cama_bin_frames(
                 x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
                 cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(), st))
@@ -514,33 +516,62 @@ class Engine:
             self._pipe = {"handle": handle, "scratch": [None, None], "keep": []}
         return self._pipe
 
+    def _pipe_scratch(self, P, need):
+        torch = _torch()
+        for k in range(2):
+            if P["scratch"][k] is None or P["scratch"][k].numel() < need:
+                if P["scratch"][k] is not None:
+                    self.join()
+                    torch.cuda.current_stream(self.device).synchronize()     # old buffer may still be in use
+                P["scratch"][k] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return P["scratch"]
+
+    def _scratch_need(self, N, F, rig):
+        key = (N, F, rig.C, rig.H, rig.W, self.radius)
+        memo = self.__dict__.setdefault("_need_memo", {})
+        need = memo.get(key)
+        if need is None:
+            need = memo[key] = int(self.lib.cama_render_scratch_bytes(N, F, rig.C, rig.H, rig.W, self.radius))
+        return need
+
+    def _stage_poses(self, P, w2c):
+        """Host float32 matrices (the np.linalg.inv result, cama/dataset.py:99) -> the pipeline's pose slot of the next
+        launch (cama_pipeline_stage_poses): no torch tensor, no allocator traffic, and a device address that is fixed
+        per slot, which lets the library replay the binning chain as one hipGraph.  Returns (device pointer, F) or None
+        when `w2c` is not a host float32 array."""
+        if not (isinstance(w2c, np.ndarray) and w2c.dtype == np.float32):
+            return None
+        import ctypes
+        a = np.ascontiguousarray(w2c).reshape(-1, 16)
+        ptr = ctypes.c_void_p()
+        _lib.check(self.lib.cama_pipeline_stage_poses(P["handle"], a.ctypes.data, a.shape[0], ctypes.byref(ptr)))
+        return ptr.value, a.shape[0]
+
     def render_frames_pipelined(self, dmap, rig, w2c, src, out, cols=3, crop=None):
         """Like render_frames, but through the library's two-stream pipeline (cama_pipeline_render): the binning half
         runs on one internal stream and the overlay half on another with double-buffered scratch, so call k+1's
         binning overlaps call k's overlay (HBM-bound) instead of queueing behind it.  `src` / `w2c` must be complete
         on the CURRENT stream at call time; `out` is complete only after join() (which makes the current stream wait
-        for every overlay issued so far)."""
+        for every overlay issued so far).  Host float32 `w2c` (what frame_poses returns) takes the staged-pose path:
+        no per-call tensor, and the binning chain is replayed as a captured hipGraph."""
         torch = _torch()
         cropa = self._crop(crop)
         P = self._pipeline()
         with torch.cuda.device(self.device):
-            T = w2c if (isinstance(w2c, torch.Tensor) and w2c.dtype == torch.float64 and w2c.is_cuda
-                        and w2c.dim() == 2) else self._mats(w2c)
-            F = T.shape[0]
+            staged = self._stage_poses(P, w2c)
+            if staged is not None:
+                T, (T_ptr, F) = None, staged
+            else:
+                T = w2c if (isinstance(w2c, torch.Tensor) and w2c.dtype == torch.float64 and w2c.is_cuda
+                            and w2c.dim() == 2) else self._mats(w2c)
+                T_ptr, F = T.data_ptr(), T.shape[0]
             assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
             assert tuple(src.shape) == (F, rig.C, rig.H, rig.W, 3)
             assert tuple(out.shape) == self.mosaic_shape(rig, F, cols) and out.is_contiguous()
-            need = int(self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius))
-            for k in range(2):
-                if P["scratch"][k] is None or P["scratch"][k].numel() < need:
-                    if P["scratch"][k] is not None:
-                        self.join()
-                        torch.cuda.current_stream(self.device).synchronize()     # old buffer may still be in use
-                    P["scratch"][k] = torch.empty(need, dtype=torch.uint8, device=self.device)
-            s0, s1 = P["scratch"]
+            s0, s1 = self._pipe_scratch(P, self._scratch_need(dmap.N, F, rig))
             x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
             _lib.check(self.lib.cama_pipeline_render(
-                P["handle"], x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(),
+                P["handle"], x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T_ptr, F, rig.c2cam.data_ptr(),
                 rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, src.data_ptr(), out.data_ptr(), cols,
                 self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(),
                 min(s0.numel(), s1.numel()), self._stream()))
@@ -597,6 +628,10 @@ class Engine:
         and the mosaic are already resident (`resident_frames`, the bench / streaming case) -- the decoded source batch
         and its mosaic slice, which a disk-backed source allocates per call.  Default budget: a quarter of the free HBM,
         at most 64 GB -- sized for 288 GB parts, so that 4*10^6-vertex site maps still render 40 frames per launch."""
+        memo_key = (dmap.N, rig.C, rig.H, rig.W, budget_bytes, resident_frames, src_bytes_per_frame, pipelined)
+        memo = self.__dict__.setdefault("_fpc_memo", {})
+        if memo_key in memo:                    # (the free-memory probe is a driver call: once per shape is enough)
+            return memo[memo_key]
         if budget_bytes is None:
             free, _ = _torch().cuda.mem_get_info(self.device)
             budget_bytes = min(64 << 30, max(1 << 30, free // 4))
@@ -609,7 +644,8 @@ class Engine:
         f_budget = max(1, int(budget_bytes // per))
         f_off = max(1, int(((1 << 32) - 1) // max(1, rig.C * max(1, dmap.N) * 2)))
         cap = 65535 if resident_frames else 512            # a disk-backed batch is decoded and held as a whole
-        return min(f_budget, f_off, cap)
+        memo[memo_key] = min(f_budget, f_off, cap)
+        return memo[memo_key]
 
     def stamp_points(self, image, vu, colour_id):
         """In-place render_maps on one device image [H,W,3]: points (n,2) (v,u) float64 in draw order."""

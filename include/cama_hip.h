@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 8
+#define CAMA_ABI_VERSION 9
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -194,6 +194,16 @@ int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const v
                          const uint8_t *src, uint8_t *mosaic, int32_t cols,
                          int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
                          void *scratch0, void *scratch1, size_t scratch_bytes, void *input_stream);
+/*
+ * Host poses for the next launch: copies F world->chassis matrices from HOST memory (float32 [F,16], the np.linalg.inv
+ * result of cama/dataset.py:99; promoted to double exactly) into the context's pinned ring, enqueues the upload on the
+ * binning stream and returns the DEVICE address to pass as `w2c` to the next cama_pipeline_render*: no device allocation
+ * or caller-side upload per launch.  The address is fixed per scratch slot; with CAMA_GRAPH=1 in the environment the
+ * context additionally replays that launch's binning chain (one memset + 4-5 kernels) as a single captured hipGraph
+ * (experimental, off by default).  The context allocates these two small pose buffers and the pinned ring itself
+ * (64 x max F x 128 bytes); everything else stays caller-owned.
+ */
+int cama_pipeline_stage_poses(cama_pipeline *p, const float *w2c_host_f32, int32_t F, const double **w2c_dev);
 /* The same pipeline with the 3:5 raw-frame overlay (cama_overlay_frames_raw35) as its overlay half. */
 int cama_pipeline_render_raw35(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
                                const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
