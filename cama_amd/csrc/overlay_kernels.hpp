@@ -34,6 +34,9 @@ __device__ __forceinline__ void rasterise_one(uint32_t *s_owner, const uint2 r, 
         if (hw < 0) continue;
         const int xlo = max(u - hw, 0), xhi = min(u + hw, W - 1);
         uint32_t *row = s_owner + (y - y0) * W;
+        // (tried: a plain read first and the atomic only where the key would grow -- owners are monotone, so that is
+        // exact, and on dense maps ~9 of 10 atomics would go away -- but the dependent read costs more than the
+        // fire-and-forget ds_max it saves: dense 10^6 overlay 441 -> 498 us)
         for (int x = xlo; x <= xhi; ++x) atomicMax(&row[x], val);
     }
 }
