@@ -92,9 +92,11 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def workload_key(frames, verts, width, height, map_kind, raw=False):
-    """Name of a workload in the golden hash files (everything the rendered bytes depend on)."""
-    return f"map={map_kind},verts={verts},frames={frames},{width}x{height}" + (",raw1600x900" if raw else "")
+def workload_key(frames, verts, width, height, map_kind, raw=False, unit="scene"):
+    """Name of a workload in the golden hash files: everything the rendered bytes depend on, plus what one hashed unit
+    is -- a whole scene (all its frames' mosaics) or one frame position of a frame-sharded scene."""
+    return (f"map={map_kind},verts={verts},frames={frames},{width}x{height}" + (",raw1600x900" if raw else "") +
+            (",per-frame" if unit == "frame" else ""))
 
 
 def replace_map(cm, args, seed):
@@ -360,7 +362,8 @@ def main():
     job = Job(args, mine, device, frange)
     dt, ov_ms, ov_n = job.run(args.steps, args.warmup, sync_all, prof_every)
     N, F = job.N, job.F
-    key = workload_key(args.frames, args.verts, W, H, args.map, raw=args.raw_frames)
+    key = workload_key(args.frames, args.verts, W, H, args.map, raw=args.raw_frames,
+                       unit="frame" if args.shard_frames else "scene")
     samples = stress_sample_frames(args.frames) if args.shard_frames else None
     hashes = [] if args.no_verify else job.scene_hashes(samples)
     metrics = [float(F * args.steps * len(job.scenes)), dt, ov_ms, float(ov_n), float(N),
@@ -387,7 +390,7 @@ def main():
         s_metrics = [float(sjob.F * s_steps), sdt, sov_ms, float(sov_n), float(sjob.N),
                      float(s_steps) * shard.scene_cost(sjob.F, sjob.N, W, H), sjob.frames_per_launch(), float(s_steps)]
         report.append(shard.pack_report(s_metrics, s_hashes, len(s_samples)))
-        s_key = workload_key(sargs.frames, sargs.verts, W, H, "random")
+        s_key = workload_key(sargs.frames, sargs.verts, W, H, "random", unit="frame")
 
     # ---------------------------------------------------------------- the one collective: all_gather over RCCL/xGMI
     sizes = [len(r) for r in report]

@@ -117,7 +117,7 @@ def main():
         bargs = bench.parse_args([])
         bargs.map, bargs.verts, bargs.frames = "random", bench.STRESS["verts"], bench.STRESS["frames"]
         units = frame_hashes(bargs, 0, bench.stress_sample_frames(bargs.frames))
-        update(bench.workload_key(bargs.frames, bargs.verts, bargs.width, bargs.height, "random"), units)
+        update(bench.workload_key(bargs.frames, bargs.verts, bargs.width, bargs.height, "random", unit="frame"), units)
     else:
         # reduced-size twins used by tests/test_gpu_configs.py: 24 small scenes; a 1e6-vertex random map at 320x180
         bargs = bench.parse_args(["--frames", "6", "--verts", "3000", "--height", "180", "--width", "320"])
@@ -126,7 +126,7 @@ def main():
         update(bench.workload_key(6, 3000, 320, 180, "lanes"), {str(s): [lo, hi] for s, lo, hi in res})
         bargs = bench.parse_args(["--frames", "125", "--verts", "1000000", "--height", "180", "--width", "320", "--map", "random"])
         units = frame_hashes(bargs, 0, [0, 1, 31, 62, 93, 124])
-        update(bench.workload_key(125, 1000000, 320, 180, "random"), units)
+        update(bench.workload_key(125, 1000000, 320, 180, "random", unit="frame"), units)
 
 
 if __name__ == "__main__":

@@ -26,8 +26,8 @@ def _args(**kw):
     return a
 
 
-def _golden(a):
-    key = bench.workload_key(a.frames, a.verts, a.width, a.height, a.map)
+def _golden(a, unit="scene"):
+    key = bench.workload_key(a.frames, a.verts, a.width, a.height, a.map, unit=unit)
     g = shard.load_golden_hashes(GOLDEN, key)
     assert g, f"no golden entry for {key}"
     return g
@@ -133,7 +133,7 @@ def test_stress_1e6_random_vertices_125_frames():
     from cama_amd import runtime
     a = _args(frames=125, verts=1000000, height=180, width=320, map="random")
     dev = torch.device("cuda:0")
-    golden = _golden(a)
+    golden = _golden(a, unit="frame")
     cm, frames, _ = bench.build_scene(a, 0, dev)
     dmap = cm._static("cama").device()
     assert dmap.N == 1000000 and dmap.sorted_soa is not None

@@ -108,7 +108,7 @@ def test_committed_golden_hashes_cover_the_bench_workloads(repo_root):
     assert sorted(sweep) == list(range(bench.SWEEP_SCENES))                  # configs[2]: all 73 scenes
     assert len(set(sweep.values())) == bench.SWEEP_SCENES                     # all distinct
     stress = shard.load_golden_hashes(path, bench.workload_key(bench.STRESS["frames"], bench.STRESS["verts"], a.width,
-                                                               a.height, "random"))
+                                                               a.height, "random", unit="frame"))
     assert sorted(stress) == bench.stress_sample_frames(bench.STRESS["frames"])
 
 

@@ -62,8 +62,9 @@ def main(tag):
             wr.writerows(rows)
         # calibration: the big device copies (the runtime's copy kernel), known byte count each way
         ck = [k for k in fs if "copyBuffer" in k]
-        big_f = [v for k in ck for v in fs[k] if v * 1024 > 0.2 * calib_bytes]
-        big_w = [v for k in ck for v in ws.get(k, []) if v * 1024 > 0.2 * calib_bytes]
+        # (only the calibration copies themselves: other device copies of other sizes share the kernel name)
+        big_f = [v for k in ck for v in fs[k] if 0.4 * calib_bytes < v * 1024 < 1.2 * calib_bytes]
+        big_w = [v for k in ck for v in ws.get(k, []) if 0.8 * calib_bytes < v * 1024 < 1.2 * calib_bytes]
         cal = {"calib_bytes_each_way": calib_bytes,
                "FETCH_SIZE_ratio": (sum(big_f) / len(big_f)) * 1024 / calib_bytes if big_f else None,
                "WRITE_SIZE_ratio": (sum(big_w) / len(big_w)) * 1024 / calib_bytes if big_w else None}
