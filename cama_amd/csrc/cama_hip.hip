@@ -369,7 +369,7 @@ static int check_render(int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, i
         return fail(CAMA_EINVAL, "radius %d too large for the fused path (needs 2r <= band rows = %d)", radius, L.R);
     if ((size_t)C * L.NB * 8 > 64 * 1024)
         return fail(CAMA_EINVAL, "C*bands = %d*%d exceeds the per-workgroup LDS histogram", C, L.NB);
-    if (align_up((size_t)L.R * W * 4, 16) > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the LDS owner table", W);
+    if (align_up((size_t)L.R * (W + 2 * radius) * 4, 16) > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the LDS owner table", W);
     return CAMA_OK;
 }
 
@@ -516,7 +516,10 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
     // (A/B knob: CAMA_OVERLAY_LDS_PAD=bytes inflates the allocation, i.e. lowers the overlay's workgroups per CU)
     static const size_t lds_pad = getenv("CAMA_OVERLAY_LDS_PAD") ? (size_t)atol(getenv("CAMA_OVERLAY_LDS_PAD")) : 0;
-    const size_t lds = align_up((size_t)L.R * W * 4, 16) + lds_pad;
+    // k_overlay's owner table carries `radius` spare cells on either side of every row (rasterise_one_padded: 4-bit half
+    // widths of 8 rows in one register => radius <= 7 on this path; the generic cama_stamp_points has no such limit)
+    if (radius > 7) return fail(CAMA_EINVAL, "radius %d: the fused overlay supports radius <= 7", radius);
+    const size_t lds = align_up((size_t)L.R * (W + 2 * radius) * 4, 16) + lds_pad;
     hipStream_t s = (hipStream_t)stream;
     const char *base = (const char *)scratch;
 #ifdef OVERLAY_ORDER_FCB

@@ -41,10 +41,49 @@ __device__ __forceinline__ void rasterise_one(uint32_t *s_owner, const uint2 r, 
     }
 }
 
+// The same on a table whose rows carry `radius` spare cells on either side (row stride Wp = W + 2 * radius, pixel x at
+// cell x + radius): spans never need clamping, and a row's span is the centre plus symmetric pairs.  The rasteriser is
+// instruction-bound on maps that stack hundreds of thousands of stamps per frame (ablation on the dense 10^6 map: the
+// stamp loop is ALL of the 108 us that separate its overlay from a stamp-free copy), and this form has about half the
+// instructions per (stamp, row): no x clamps, no per-pixel loop counter, one table lookup from a 32-bit packed register.
+// hw8 = half widths of rows |dy| = 0..7, 4 bits each (radius <= 7); rowmask bit k = row |dy| = k is drawn.
+__device__ __forceinline__ void rasterise_one_padded(uint32_t *s_owner, const uint2 r, int y0, int nrows, int Wp, int radius,
+                                                     uint32_t hw8, uint32_t rowmask)
+{
+    const int u = (int)(r.x & 0xffffu), v = (int)(r.x >> 16);
+    const uint32_t val = r.y + 1u;
+    const int ylo = max(v - radius, y0), yhi = min(v + radius, y0 + nrows - 1);
+    uint32_t *cell = s_owner + (ylo - y0) * Wp + u + radius;           // centre column of row ylo
+    for (int y = ylo; y <= yhi; ++y, cell += Wp) {
+        const uint32_t k = (uint32_t)abs(y - v);
+        if (!((rowmask >> k) & 1u)) continue;
+        const int hw = (int)((hw8 >> (4u * k)) & 15u);
+        atomicMax(cell, val);
+        for (int d = 1; d <= hw; ++d) {
+            atomicMax(cell - d, val);
+            atomicMax(cell + d, val);
+        }
+    }
+}
+
 // Stamps `first`, first + stride, ... < n of a band's list, four record loads in flight per thread: on bands that
 // collect tens of thousands of stamps (dense maps: every far lane converges on a few horizon rows) the loop is a chain of
 // global-load latencies, and such a band's workgroup is the kernel's straggler.  Loads are unconditional (clamped index):
 // a load under a divergent guard is waited for at the end of the guard.
+__device__ __forceinline__ void rasterise_rest_padded(uint32_t *s_owner, const uint2 *st, uint32_t first, uint32_t stride,
+                                                      uint32_t n, int y0, int nrows, int Wp, int radius, uint32_t hw8,
+                                                      uint32_t rowmask)
+{
+    for (uint32_t s = first; s < n; s += 4u * stride) {
+        const uint2 r0 = st[s], r1 = st[min(s + stride, n - 1u)], r2 = st[min(s + 2u * stride, n - 1u)],
+                    r3 = st[min(s + 3u * stride, n - 1u)];
+        rasterise_one_padded(s_owner, r0, y0, nrows, Wp, radius, hw8, rowmask);
+        if (s + stride < n) rasterise_one_padded(s_owner, r1, y0, nrows, Wp, radius, hw8, rowmask);
+        if (s + 2u * stride < n) rasterise_one_padded(s_owner, r2, y0, nrows, Wp, radius, hw8, rowmask);
+        if (s + 3u * stride < n) rasterise_one_padded(s_owner, r3, y0, nrows, Wp, radius, hw8, rowmask);
+    }
+}
+
 __device__ __forceinline__ void rasterise_rest(uint32_t *s_owner, const uint2 *st, uint32_t first, uint32_t stride, uint32_t n,
                                                int y0, int nrows, int W, const Disc &disc)
 {
@@ -153,7 +192,11 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
     const int y0 = (int)b * a.R;
     const int nrows = min(a.R, a.H - y0);
     const int W = a.W;
+#ifdef ABL_NO_STAMPS
+    const uint32_t n = 0u * a.counts[bin];
+#else
     const uint32_t n = a.counts[bin];
+#endif
 
     // A stamped band fetches this thread's first stamp record and THEN issues its (first, normally only) batch of
     // 16-byte source loads, all before clearing / rasterising: the source chunks do not depend on the owner table, so
@@ -177,13 +220,18 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
         for (int j = 0; j < U; ++j) v[j] = OVERLAY_LOAD(s16 + min(threadIdx.x + j * OVERLAY_BLOCK, nchunks - 1u));
     }
 
+    // owner table: rows of Wp = W + 2 * radius cells, pixel x at cell x + radius (see rasterise_one_padded)
+    const int rad = a.disc.radius, Wp = W + 2 * rad;
     if (n) {
         uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
-        const int n4 = (nrows * W + 3) >> 2;
+        const int n4 = (nrows * Wp + 3) >> 2;
         for (int j = threadIdx.x; j < n4; j += OVERLAY_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
         lds_barrier();
-        if (threadIdx.x < n) rasterise_one(s_owner, first, y0, nrows, W, a.disc);
-        rasterise_rest(s_owner, st, threadIdx.x + OVERLAY_BLOCK, OVERLAY_BLOCK, n, y0, nrows, W, a.disc);
+#ifndef ABL_NO_RASTER
+        const uint32_t hw8 = (uint32_t)a.disc.hw4, rowmask = a.disc.rows;      // radius <= 7 (host-checked for this kernel)
+        if (threadIdx.x < n) rasterise_one_padded(s_owner, first, y0, nrows, Wp, rad, hw8, rowmask);
+        rasterise_rest_padded(s_owner, st, threadIdx.x + OVERLAY_BLOCK, OVERLAY_BLOCK, n, y0, nrows, Wp, rad, hw8, rowmask);
+#endif
         lds_barrier();
     }
 
@@ -216,7 +264,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 #pragma unroll
             for (int k = 0; k < 6; ++k) px[k] = remap_pixel(raw, raw_frame, a.H0, a.W0, mx[k], my[k]);
             u32x4 v = chunk_from_pixels(px, ph);
-            if (n) patch_chunk(v, s_owner + row * W, col, a.pal);
+            if (n) patch_chunk(v, s_owner + row * Wp + rad, col, a.pal);
             u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
             OVERLAY_STORE(v, drow + col);
         }
@@ -236,7 +284,9 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
                 if (idx < nchunks) {
                     const uint32_t row = __umulhi(idx, a.cpr_magic);
                     const uint32_t col = idx - row * a.cpr;
-                    if (n) patch_chunk<ALPHA>(v[j], s_owner + row * W, col, a.pal);
+#ifndef ABL_NO_PATCH
+                    if (n) patch_chunk<ALPHA>(v[j], s_owner + row * Wp + rad, col, a.pal);
+#endif
                     u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
                     OVERLAY_STORE(v[j], drow + col);
                 }
@@ -250,7 +300,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
             const uint8_t *s = sband + (size_t)p * 3;
             uint8_t b0 = s[0], b1 = s[1], b2 = s[2];
             if (n) {
-                const uint32_t o = s_owner[p];
+                const uint32_t o = s_owner[row * Wp + rad + x];
                 if (o) {
                     const uint32_t col = ((o - 1u) & 1u) ? a.pal.c[1] : a.pal.c[0];
                     const uint32_t srcw = (uint32_t)b0 | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16);

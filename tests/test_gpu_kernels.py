@@ -223,10 +223,17 @@ def test_stamp_points_generic_render_maps(engine):
 
 
 def test_radius_variants(engine):
-    """Radius is a parameter (table-driven footprint); r = 1 and r = 3 against the oracle's circle."""
+    """Radius is a parameter (table-driven footprint); r = 0, 1, 3, 5, 7 against the oracle's circle (7 = the widest
+    footprint of the fused overlay's padded owner table); a larger radius is refused, not mis-drawn."""
     import torch
+    from cama_amd import _lib
     from cama_amd.engine import Engine
-    for r in (1, 3):
+    with pytest.raises(_lib.CamaHipError):
+        e8 = Engine("cuda:0", radius=8)
+        xyz, col, cams, w2c = _random_scene(38, 200, 1, 160, 96)
+        e8.render_frames(e8.upload_map(xyz, col), _rig(e8, cams), w2c,
+                         torch.zeros((1, 6, 96, 160, 3), dtype=torch.uint8, device="cuda"))
+    for r in (0, 1, 3, 5, 7):
         e = Engine("cuda:0", radius=r)
         xyz, col, cams, w2c = _random_scene(30 + r, 1500, 1, 160, 96)
         rig = _rig(e, cams)
