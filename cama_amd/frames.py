@@ -42,6 +42,19 @@ def _read_jpeg_bytes_or_array(path):
     return read_rgb_or_bgr(path)
 
 
+def _read_into(blob, path):
+    """Fill an ArenaBlob (pinned memory) with the file's bytes; (blob, False) like the other fetchers."""
+    view = memoryview(blob.view())
+    with open(path, "rb", buffering=0) as f:
+        got = 0
+        while got < blob.n:
+            k = f.readinto(view[got:])
+            if not k:
+                raise IOError(f"{path}: short read ({got} of {blob.n} bytes)")
+            got += k
+    return blob, False
+
+
 def _decode_bytes(data):
     import io
     from PIL import Image
@@ -182,12 +195,42 @@ class ClipFrameSource:
             self._pool = ThreadPoolExecutor(max_workers=self._workers, thread_name_prefix="cama-decode")
         return self._pool
 
+    def _decoder(self):
+        if self._jpeg is None:
+            from .jpeg import DeviceJpegDecoder
+            self._jpeg = DeviceJpegDecoder(self.device)
+        return self._jpeg
+
     def _submit(self, idx):
-        if idx not in self._pending:
-            ex = self._executor()
-            fetch = _read_jpeg_bytes_or_array if self.decoder == "device" else read_rgb_or_bgr
-            self._pending[idx] = [ex.submit(fetch, cm.get_image_path(idx, True)) for cm in self.cm_list]
-        return self._pending[idx]
+        """Start reading the C camera files of sync index `idx`.  Device decoder: JPEG files are read by the workers
+        STRAIGHT INTO pinned memory (a slice of the decoder's current arena, sized from os.stat), so the compressed
+        bytes are copied once (page cache -> pinned) and uploaded from where they are; anything else (.npy twins,
+        host decoder) goes through the old fetchers."""
+        if idx in self._pending:
+            return self._pending[idx]
+        ex = self._executor()
+        paths = [cm.get_image_path(idx, True) for cm in self.cm_list]
+        if self.decoder != "device":
+            self._pending[idx] = [ex.submit(read_rgb_or_bgr, p) for p in paths]
+            return self._pending[idx]
+        sizes = []
+        for p in paths:
+            try:
+                sizes.append(os.stat(p).st_size if p.lower().endswith((".jpg", ".jpeg")) else -1)
+            except OSError:
+                sizes.append(-1)
+        futs = []
+        if min(sizes) > 0:
+            need = sum(sz + 16 for sz in sizes)
+            a = getattr(self, "_arena", None)
+            if a is None or a.size - a.used < need:
+                a = self._arena = self._decoder().arena(max(need, 96 << 20))
+            for p, sz in zip(paths, sizes):
+                futs.append(ex.submit(_read_into, a.take(sz), p))
+        else:
+            futs = [ex.submit(_read_jpeg_bytes_or_array, p) for p in paths]
+        self._pending[idx] = futs
+        return futs
 
     def _n_frames(self):
         return len(self.cm_list[0].dr.attribute["sync"][self.cm_list[0].camera_name])
@@ -214,7 +257,8 @@ class ClipFrameSource:
         """host uint8 BGR array [F,C,H0,W0,3] of the requested frames."""
         items = self._collect(image_indices)
         F = len(list(image_indices))
-        items = [(k, c, _decode_bytes(arr), True) if isinstance(arr, (bytes, bytearray)) else (k, c, arr, is_rgb)
+        from .jpeg import as_bytes, is_blob
+        items = [(k, c, _decode_bytes(as_bytes(arr)), True) if is_blob(arr) else (k, c, arr, is_rgb)
                  for k, c, arr, is_rgb in items]
         first = items[0][2]
         host = np.empty((F, len(self.cm_list)) + first.shape, np.uint8)
@@ -233,13 +277,14 @@ class ClipFrameSource:
             flat = ahead.result()
             self._decode_ahead(image_indices)
             return flat.view((F, len(self.cm_list)) + tuple(flat.shape[1:]))
+        from .jpeg import as_bytes, is_blob
         items = self._collect(image_indices)
-        if all(isinstance(arr, (bytes, bytearray)) for _, _, arr, _ in items):
+        if all(is_blob(arr) for _, _, arr, _ in items):
             # compressed bytes straight to the device decoder: one upload + one decode for the whole batch, BGR out
             flat = self._device_decode(image_indices, items)
             return flat.view((F, len(self.cm_list)) + tuple(flat.shape[1:]))
-        items = [(k, c, _decode_bytes(arr) if isinstance(arr, (bytes, bytearray)) else arr,
-                  True if isinstance(arr, (bytes, bytearray)) else is_rgb) for k, c, arr, is_rgb in items]
+        items = [(k, c, _decode_bytes(as_bytes(arr)) if is_blob(arr) else arr,
+                  True if is_blob(arr) else is_rgb) for k, c, arr, is_rgb in items]
         shape = items[0][2].shape
         dev = torch.empty((F, len(self.cm_list)) + tuple(shape), dtype=torch.uint8, device=self.device)
         rgb = torch.zeros((F, len(self.cm_list)), dtype=torch.bool)
@@ -254,10 +299,7 @@ class ClipFrameSource:
         return dev
 
     def _device_decode(self, image_indices, items):
-        if self._jpeg is None:
-            from .jpeg import DeviceJpegDecoder
-            self._jpeg = DeviceJpegDecoder(self.device)
-        flat = self._jpeg.decode([arr for _, _, arr, _ in items], bgr=True)
+        flat = self._decoder().decode([arr for _, _, arr, _ in items], bgr=True)
         self._decode_ahead(image_indices)
         return flat
 
@@ -279,9 +321,10 @@ class ClipFrameSource:
         for key in wanted:
             if key in self._ahead:
                 continue
+            from .jpeg import is_blob
             items = self._collect(list(key))
-            if all(isinstance(arr, (bytes, bytearray)) for _, _, arr, _ in items):
-                self._ahead[key] = self._jpeg.decode_async([arr for _, _, arr, _ in items], bgr=True)
+            if all(is_blob(arr) for _, _, arr, _ in items):
+                self._ahead[key] = self._decoder().decode_async([arr for _, _, arr, _ in items], bgr=True)
             else:                                                        # mixed sources: leave them to the normal path
                 self._requeue(list(key), items)
                 break

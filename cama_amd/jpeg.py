@@ -47,6 +47,74 @@ class JpegHeader:
 _HEADER_CACHE = {}
 
 
+class PinnedArena:
+    """A pinned host buffer that compressed files are read INTO (file -> pinned memory, one copy), so that a batch's
+    entropy data goes to the device with one asynchronous copy of a contiguous span instead of being packed into a
+    staging buffer first (a Python-side memcpy of ~75 MB per 240 photo-like frames: it was 90 % of a batch's host time
+    and made the decoder host-bound at 31 k images/s).  Bump allocation, 16-byte aligned slices."""
+
+    def __init__(self, nbytes, pool=None):
+        import torch
+        self.buf = torch.empty(int(nbytes), dtype=torch.uint8).pin_memory()
+        self.np = self.buf.numpy()
+        self.size, self.used, self._pool = int(nbytes), 0, pool
+
+    def take(self, n):
+        """An ArenaBlob of n bytes, or None when the arena is full."""
+        off = (self.used + 15) & ~15
+        if off + n > self.size:
+            return None
+        self.used = off + n
+        return ArenaBlob(self, off, n)
+
+
+class ArenaBlob:
+    """n bytes of a PinnedArena holding one compressed file (filled by the reader)."""
+    __slots__ = ("arena", "off", "n")
+
+    def __init__(self, arena, off, n):
+        self.arena, self.off, self.n = arena, off, n
+
+    def view(self):
+        return self.arena.np[self.off:self.off + self.n]
+
+    def tobytes(self):
+        return self.view().tobytes()
+
+    def __len__(self):
+        return self.n
+
+
+def is_blob(x):
+    return isinstance(x, (bytes, bytearray, ArenaBlob))
+
+
+def as_bytes(x):
+    return x.tobytes() if isinstance(x, ArenaBlob) else x
+
+
+def parse_header_blob(blob):
+    """parse_header for an ArenaBlob without copying the file: the header is looked up on its first bytes, the scan's end
+    on its last bytes (EOI is the file's tail); only unusual layouts fall back to a full copy."""
+    v = blob.view()
+    n = len(v)
+    head = v[:min(n, 8192)].tobytes()
+    sos = head.find(b"\xff\xda")
+    if sos > 0 and sos + 4 <= len(head):
+        key = head[:sos + 2 + ((head[sos + 2] << 8) | head[sos + 3])]
+        hit = _HEADER_CACHE.get(key)
+        if hit is not None and len(key) <= len(head):
+            tail0 = max(0, n - 64)
+            e = v[tail0:].tobytes().rfind(b"\xff\xd9")
+            if e >= 0 and tail0 + e >= hit.scan_start:
+                h = JpegHeader()
+                for name in JpegHeader.__slots__:
+                    setattr(h, name, getattr(hit, name))
+                h.scan_end = tail0 + e
+                return h
+    return parse_header(v.tobytes())
+
+
 def parse_header(data):
     """Header of a JPEG file; the frames of one camera share every byte up to the scan, so the parsed header is cached
     on those bytes and only the scan's end is looked up per file."""
@@ -259,6 +327,34 @@ class DeviceJpegDecoder:
         self._templates = {}
         self.stats = {"device": 0, "host_unsupported": 0, "host_flagged": 0}
 
+    # ------------------------------------------------------------------ pinned arenas for the readers
+    def arena(self, nbytes):
+        """A PinnedArena of at least `nbytes`: recycled from the pool when nobody references an old one any more (blobs,
+        pending decodes and tickets hold references; a ticket lives until its decode has been waited for)."""
+        import sys
+        pool = self.__dict__.setdefault("_arenas", [])
+        for a in pool:
+            if a.size >= nbytes and sys.getrefcount(a) <= 3:       # the pool's list, `a`, getrefcount's argument
+                a.used = 0
+                return a
+        a = PinnedArena(max(int(nbytes), 64 << 20))
+        pool.append(a)
+        if len(pool) > 8:
+            pool[:] = [x for x in pool if sys.getrefcount(x) > 3 or x is a][-8:]
+        return a
+
+    def stage(self, datas):
+        """bytes-like objects -> ArenaBlobs in one arena (for callers that hold files in memory; readers that can should
+        read straight into `arena(...).take(n).view()`)."""
+        total = sum(len(d) + 16 for d in datas)
+        a = self.arena(total)
+        out = []
+        for d in datas:
+            b = a.take(len(d))
+            b.view()[:] = np.frombuffer(d, np.uint8)
+            out.append(b)
+        return out
+
     # ------------------------------------------------------------------ table caches (device copies grow on demand)
     def _huff_id(self, huff):
         key = tuple(sorted((k, v) for k, v in huff.items() if k[1] <= 1))
@@ -316,7 +412,7 @@ class DeviceJpegDecoder:
         headers = []
         for b in blobs:
             try:
-                headers.append(parse_header(b))
+                headers.append(parse_header_blob(b) if isinstance(b, ArenaBlob) else parse_header(b))
             except Unsupported:
                 headers.append(None)
         size = None
@@ -325,7 +421,7 @@ class DeviceJpegDecoder:
                 size = (h.height, h.width)
                 break
         if size is None:                                             # nothing for the device: all on the host
-            size = _host_decode(blobs[0], bgr).shape[:2]
+            size = _host_decode(as_bytes(blobs[0]), bgr).shape[:2]
         H, W = size
         ok = [i for i, h in enumerate(headers) if h is not None and (h.height, h.width) == (H, W)]
         with torch.cuda.device(self.device):
@@ -365,14 +461,26 @@ class DeviceJpegDecoder:
         # the scans go into the staging buffer back to back (no alignment needed: descriptors point into it, the
         # library lays out its own aligned unstuffed copies)
         lens = np.array([h.scan_end - h.scan_start for h in headers], dtype=np.int64)
-        base = np.concatenate([[0], np.cumsum(lens)[:-1]])
-        stream_bytes = int(lens.sum())
-        if L["pinned"] is None or L["pinned"].numel() < stream_bytes:
-            # (grown with headroom: lanes are reused across batch sizes, regrowing pinned / device buffers is slow)
-            L["pinned"] = torch.empty(max(stream_bytes * 5 // 4, 1 << 22), dtype=torch.uint8).pin_memory()
-        host = L["pinned"].numpy()
-        for o, ln, b, h in zip(base.tolist(), lens.tolist(), blobs, headers):
-            host[o:o + ln] = np.frombuffer(b, np.uint8, ln, h.scan_start)
+        arena = blobs[0].arena if isinstance(blobs[0], ArenaBlob) else None
+        if arena is not None and all(isinstance(b, ArenaBlob) and b.arena is arena for b in blobs) and \
+                all(blobs[k].off < blobs[k + 1].off for k in range(n - 1)):
+            # the files already sit in pinned memory, in order: upload the span they occupy as it is (headers included,
+            # ~0.2 % of the bytes) and point the descriptors into it -- no packing copy
+            span_lo, span_hi = blobs[0].off, blobs[-1].off + blobs[-1].n
+            base = np.array([b.off - span_lo + h.scan_start for b, h in zip(blobs, headers)], dtype=np.int64)
+            stream_bytes = int(span_hi - span_lo)
+            pinned_src = arena.buf[span_lo:span_hi]
+        else:
+            arena = None
+            base = np.concatenate([[0], np.cumsum(lens)[:-1]])
+            stream_bytes = int(lens.sum())
+            if L["pinned"] is None or L["pinned"].numel() < stream_bytes:
+                # (grown with headroom: lanes are reused across batch sizes, regrowing pinned / device buffers is slow)
+                L["pinned"] = torch.empty(max(stream_bytes * 5 // 4, 1 << 22), dtype=torch.uint8).pin_memory()
+            host = L["pinned"].numpy()
+            for o, ln, b, h in zip(base.tolist(), lens.tolist(), blobs, headers):
+                host[o:o + ln] = np.frombuffer(as_bytes(b), np.uint8, ln, h.scan_start)
+            pinned_src = L["pinned"][:stream_bytes]
         # descriptors: images without restart intervals first, as one vectorised block
         whole = [i for i, h in enumerate(headers) if not h.restart_interval]
         if whole:
@@ -393,7 +501,7 @@ class DeviceJpegDecoder:
                 continue
             rec = self._template(h).copy()
             rec["out_slot"] = i
-            segs = restart_segments(b, h)
+            segs = restart_segments(as_bytes(b), h)
             rec["kind"] = KIND_PIXELS
             if segs is None:
                 broken.append(i)                                   # marker count does not match: host decoder
@@ -430,7 +538,7 @@ class DeviceJpegDecoder:
             if L["scratch"] is None or L["scratch"].numel() < scratch_bytes:
                 L["scratch"] = None
                 L["scratch"] = torch.empty(scratch_bytes * 5 // 4, dtype=torch.uint8, device=self.device)
-            stream_dev = L["pinned"][:stream_bytes].to(self.device, non_blocking=True)
+            stream_dev = pinned_src.to(self.device, non_blocking=True)
             imgs_dev = torch.from_numpy(imgs.view(np.uint8).reshape(nd, -1)).to(self.device, non_blocking=True)
             status = torch.empty(nd, dtype=torch.int32, device=self.device)
             target = out[slots[0]:slots[0] + n] if contiguous else \
@@ -446,7 +554,7 @@ class DeviceJpegDecoder:
             L["status"][:nd].copy_(status, non_blocking=True)
         # (no record_stream on `out`: _finish synchronises every lane before decode() returns)
         return {"lane": L, "slots": slots, "n": nd, "owner": owner, "broken": broken,
-                "keep": (stream_dev, imgs_dev, status, target, imgs)}
+                "keep": (stream_dev, imgs_dev, status, target, imgs, arena)}
 
     def _finish(self, ticket, out, cur):
         """Wait for a group; returns the slots the device flagged as inconsistent (to be decoded on the host)."""
@@ -480,7 +588,7 @@ class PendingDecode:
             dec.stats["host_unsupported"] += n - len(self.ok)
             dec.stats["host_flagged"] += len(flagged)
             for i in host:
-                arr = _host_decode(self.blobs[i], self.bgr)
+                arr = _host_decode(as_bytes(self.blobs[i]), self.bgr)
                 if tuple(arr.shape[:2]) != tuple(out.shape[1:3]):
                     raise ValueError(f"image {i} is {arr.shape[1]}x{arr.shape[0]}, the batch is {out.shape[2]}x{out.shape[1]}")
                 out[i].copy_(torch.from_numpy(np.ascontiguousarray(arr)))

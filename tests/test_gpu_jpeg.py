@@ -127,6 +127,36 @@ def test_clip_frame_source_device_decode_equals_host_decode(tmp_path):
     b = host.raw_batch([1, 2, 3]).cpu().numpy()
     assert a.shape == b.shape == (3, 6, 180, 320, 3) and np.array_equal(a, b)
     assert dev._jpeg.stats["device"] == 18 and dev._jpeg.stats["host_flagged"] == 0
+    # the device path read the files straight into a pinned arena (no packing copy on the submitting thread)
+    from cama_amd.jpeg import ArenaBlob
+    blobs = [f.result()[0] for f in dev._submit(2)]
+    assert all(isinstance(x, ArenaBlob) for x in blobs) and len({id(x.arena) for x in blobs}) == 1
+    assert [x.off for x in blobs] == sorted(x.off for x in blobs)
+    for x, cmgr in zip(blobs, cm.cm_list):
+        assert x.tobytes() == open(cmgr.get_image_path(2, True), "rb").read()
+
+
+def test_arena_staged_blobs_decode_like_bytes(dec):
+    """decode() of files staged in a pinned arena (span upload, descriptors pointing into it) == decode() of the same
+    bytes objects (packed per call) == Pillow; mixed with a file the device hands back to the host decoder, and with a
+    batch that straddles two arenas (falls back to the packing path)."""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(12)
+    imgs = [rng.integers(0, 256, (120, 200, 3), dtype=np.uint8) for _ in range(30)]
+    blobs = []
+    for k, im in enumerate(imgs):
+        b = io.BytesIO()
+        Image.fromarray(im).save(b, "JPEG", quality=60 + k, progressive=(k == 7))     # one progressive: host fallback
+        blobs.append(b.getvalue())
+    want = np.stack([np.array(Image.open(io.BytesIO(b)).convert("RGB"))[:, :, ::-1] for b in blobs])
+    staged = dec.stage(blobs)
+    assert np.array_equal(dec.decode(staged).cpu().numpy(), want)
+    assert np.array_equal(dec.decode(blobs).cpu().numpy(), want)
+    other = dec.stage(blobs[10:13])                                    # another arena: the batch is no longer one span
+    assert other[0].arena is not staged[0].arena
+    mixed = staged[:10] + other + staged[13:]
+    assert np.array_equal(dec.decode(mixed).cpu().numpy(), want)
 
 
 def test_fuzz_random_images_sizes_and_encoder_settings(dec):
