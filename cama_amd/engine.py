@@ -15,6 +15,9 @@ from . import _lib
 CROP_BOX = (-50.0, 50.0, -100.0, 100.0, -200.0, 200.0)        # cama/reproject.py:28-34
 PALETTE_BGR = ((211, 211, 211), (0, 215, 255))                # grey lane_marking, gold everything else
 RADIUS = 2                                                    # cama/reproject.py:256
+# maps with at least this many vertices hand their block index (per-block AABBs) to the render: below, the
+# one-thread-per-block pre-pass costs a launch for nothing.  CAMA_BOUNDS_MIN_VERTS=1 forces it (tests).
+BOUNDS_MIN_VERTS = int(os.environ.get("CAMA_BOUNDS_MIN_VERTS", "65536"))
 
 
 def _torch():
@@ -126,7 +129,7 @@ class DeviceMap:
         block bounds (per-camera / crop culling of whole vertex blocks) whenever the map has an index and is big enough
         for the one-thread-per-block pre-pass to pay; the work-list flag only for maps that are site-sized against `crop`."""
         bounds, flags = None, 0
-        if crop is not None and getattr(self, "bounds", None) is not None and self.N >= 65536:
+        if crop is not None and getattr(self, "bounds", None) is not None and self.N >= BOUNDS_MIN_VERTS:
             bounds = self.bounds.data_ptr()
             if self.site_sized(crop):
                 flags = _lib.BIN_WORKLIST

@@ -63,17 +63,27 @@ def _case(rng):
                 sort=bool(rng.random() < 0.3), kind=str(kind))
 
 
-def test_fuzz_work_list_path():
-    """Same fuzz in a child process with CAMA_CULL_LIST_MIN=1: every render that carries block bounds goes through
-    k_cull_blocks + the persistent k_frames_bin_list instead of the grid launch."""
+def _fuzz_child(extra_env):
     import subprocess
     import sys
-    env = dict(os.environ, CAMA_CULL_LIST_MIN="1", CAMA_FUZZ_ITERS=os.environ.get("CAMA_FUZZ_ITERS", "40"),
-               CAMA_FUZZ_SEED="77")
+    env = dict(os.environ, CAMA_FUZZ_ITERS=os.environ.get("CAMA_FUZZ_ITERS", "40"), **extra_env)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
                         __file__ + "::test_fuzz_against_oracle"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_fuzz_block_index_and_camera_masks():
+    """Same fuzz in a child process with CAMA_BOUNDS_MIN_VERTS=1: every map hands its block AABBs to the render, so
+    k_block_cameras runs for all of these rigs -- skewed K, projective last rows, flipped depth signs, odd crop boxes --
+    and the projection skips cameras / blocks by its masks; the output must not change by a byte."""
+    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_FUZZ_SEED": "4242"})
+
+
+def test_fuzz_work_list_path():
+    """... and with CAMA_CULL_LIST_MIN=1 on top: every site-sized map additionally goes through the work lists and the
+    persistent k_frames_project_list instead of the grid launch."""
+    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "77"})
 
 
 def test_fuzz_against_oracle():
