@@ -71,9 +71,11 @@ class VideoGenerator:
             self._own_sink = False
         if self._sink is None and shutil.which("ffmpeg") is None:
             raise FileNotFoundError("the `ffmpeg` binary is needed to encode the reprojection video")
+        self._asked_egress = False
         if os.environ.get("CAMA_EGRESS", "i420") != "bgr24":
             from . import runtime
             runtime.request_egress("i420")              # render batches prepare their I420 planes from now on
+            self._asked_egress = True
 
     def _start(self, pix_fmt):
         self.pix_fmt = pix_fmt
@@ -124,6 +126,10 @@ class VideoGenerator:
         self.add_frame(self.concate_image(image_dict))
 
     def close(self):
+        if getattr(self, "_asked_egress", False):       # nobody is listening any more
+            self._asked_egress = False
+            from . import runtime
+            runtime.request_egress(None)
         writer = getattr(self, "writer", None)
         if writer is not None:
             self.writer = None

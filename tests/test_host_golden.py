@@ -291,5 +291,6 @@ def test_video_generator_sink_and_i420_stream(tmp_path):
     assert vg.pix_fmt == "yuv420p"
     assert buf.getvalue() == O.bgr_to_i420(a).tobytes() + O.bgr_to_i420(b).tobytes()
     assert len(buf.getvalue()) == 2 * 8 * 32 * 3 // 2
+    assert runtime.egress_mode() == "i420"
     vg.close()
-    runtime.request_egress(None)
+    assert runtime.egress_mode() is None                # the render path stops preparing I420 once the sink is closed
