@@ -363,26 +363,36 @@ __global__ __launch_bounds__(BLOCK) void k_frames_project(FrameArgs a)
 // is proportional to the stamps that exist (a prefix sum of the segment counts maps thread -> stamp), every stamp is
 // ranked inside the workgroup with an LDS atomic on its band's counter, the workgroup reserves its share of each
 // non-empty band with one global atomic, and the stamps go to bin_off + reserved base + rank.
-constexpr int SCATTER_SEGS = 64;
+#ifndef SCATTER_SEGS_N
+#define SCATTER_SEGS_N 256
+#endif
+constexpr int SCATTER_SEGS = SCATTER_SEGS_N;   // 64, 128 or 256 (<= BLOCK): fewer, fatter workgroups = fewer reservations
 constexpr int SCATTER_K = 4;            // stamps per thread per round (register-resident between rank and write)
+static_assert(SCATTER_SEGS <= BLOCK && (SCATTER_SEGS & (SCATTER_SEGS - 1)) == 0 && SCATTER_SEGS >= 64, "SCATTER_SEGS");
 
 __global__ __launch_bounds__(BLOCK) void k_stamps_scatter(FrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [NB] counts | [NB] bases
     __shared__ uint32_t s_off[SCATTER_SEGS + 1];
+    __shared__ uint32_t s_wave[BLOCK / 64];
     const uint32_t fc = blockIdx.y, seg0 = blockIdx.x * SCATTER_SEGS;
     const int NB = a.NB;
     uint32_t *s_cnt = s_hist, *s_base = s_hist + NB;
-    if (threadIdx.x < SCATTER_SEGS) {
+    {
+        // inclusive scan of the SCATTER_SEGS segment counts: inside each wave by shuffles, across waves through LDS
         const uint32_t sg = seg0 + threadIdx.x;
-        const uint32_t v = sg < a.nseg ? (uint32_t)a.seg_cnt[(size_t)fc * a.nseg + sg] : 0u;
+        const uint32_t v = (threadIdx.x < SCATTER_SEGS && sg < a.nseg) ? (uint32_t)a.seg_cnt[(size_t)fc * a.nseg + sg] : 0u;
         uint32_t x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t t = __shfl_up(x, d, 64);
-            if ((int)threadIdx.x >= d) x += t;
+            if ((int)(threadIdx.x & 63) >= d) x += t;
         }
-        s_off[threadIdx.x + 1] = x;
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = x;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += s_wave[w];
+        if (threadIdx.x < SCATTER_SEGS) s_off[threadIdx.x + 1] = before + x;
         if (threadIdx.x == 0) s_off[0] = 0u;
     }
     for (int t = threadIdx.x; t < NB; t += BLOCK) s_cnt[t] = 0u;
