@@ -442,15 +442,26 @@ class ClipManager:
         host_poses = pipelined and isinstance(w2c, np.ndarray) and w2c.dtype == np.float32
         T = w2c if host_poses else eng._mats(w2c)
         ids = idx.tolist()
-        for lo in range(0, F, step):
+        lo = 0
+        while lo < F:
             hi = min(F, lo + step)
-            if fused_raw:      # raw sensor frames: undistort + resize inside the overlay kernel
-                eng.render_frames_raw(dmap, rig, T[lo:hi], src_all.raw_batch(ids[lo:hi]),
-                                      self.cm_list, out=out[lo:hi], crop=crop, pipelined=pipelined)
+            try:
+                if fused_raw:      # raw sensor frames: undistort + resize inside the overlay kernel
+                    eng.render_frames_raw(dmap, rig, T[lo:hi], src_all.raw_batch(ids[lo:hi]),
+                                          self.cm_list, out=out[lo:hi], crop=crop, pipelined=pipelined)
+                else:
+                    src = src_all.batch(ids[lo:hi])
+                    if pipelined:
+                        eng.render_frames_pipelined(dmap, rig, T[lo:hi], src, out[lo:hi], crop=crop)
+                    else:
+                        eng.render_frames(dmap, rig, T[lo:hi], src, out=out[lo:hi], crop=crop)
+            except torch.OutOfMemoryError:
+                # the per-call scratch is a worst case (every vertex visible in every camera) sized from the memory that
+                # was free when the shape was first seen; if the device has filled up since, render fewer frames per call
+                if frames_per_launch or step <= 1:
+                    raise
+                eng.shrink_frames_per_call()
+                step = max(1, step // 2)
                 continue
-            src = src_all.batch(ids[lo:hi])
-            if pipelined:
-                eng.render_frames_pipelined(dmap, rig, T[lo:hi], src, out[lo:hi], crop=crop)
-            else:
-                eng.render_frames(dmap, rig, T[lo:hi], src, out=out[lo:hi], crop=crop)
+            lo = hi
         return idx, out

@@ -650,6 +650,18 @@ class Engine:
         memo[memo_key] = min(f_budget, f_off, cap)
         return memo[memo_key]
 
+    def shrink_frames_per_call(self):
+        """After an out-of-memory error: forget the memoised per-call sizes and the scratch buffers (so that a smaller
+        call can allocate), wait for what is in flight."""
+        torch = _torch()
+        self.__dict__.pop("_fpc_memo", None)
+        if self._pipe is not None:
+            self.join()
+            torch.cuda.current_stream(self.device).synchronize()
+            self._pipe["scratch"] = [None, None]
+        self._scratch = None
+        torch.cuda.empty_cache()
+
     def stamp_points(self, image, vu, colour_id):
         """In-place render_maps on one device image [H,W,3]: points (n,2) (v,u) float64 in draw order."""
         torch = _torch()
