@@ -9,9 +9,14 @@ bench.py's cpu_baseline leg may import this module; cama_amd/ never does.
 
 Pinned against tests/golden/*.npz, which were produced by importing the real
 reference in the build container (tests/golden/gen_golden.py).
-PARITY UNPINNED beyond the OpenCV boundary: the filled-circle footprint
-(oracle_circle_fill in cama_oracle.c), cv2.remap and cv2.imread have no golden
-vectors because OpenCV is installed on neither box.
+PARITY UNPINNED beyond the third-party boundaries, because neither OpenCV nor
+ffmpeg is installed on either box: the filled-circle footprint
+(oracle_circle_fill in cama_oracle.c), cv2.initUndistortRectifyMap
+(oracle_undistort_map: OpenCV's published scalar loop, operation by operation),
+cv2.remap (remap_bilinear) and libswscale's bgr24 -> yuv420p (bgr_to_i420) are
+restated from the published algorithms.  tests/test_cv2_pins.py pins the three
+OpenCV ones against the real library wherever `import cv2` works; cv2.imread's
+decode IS pinned (oracle/jpeg_oracle.py == libjpeg-turbo through Pillow).
 
 Each function cites the reference lines it follows (paths under /root/reference).
 """
