@@ -162,7 +162,7 @@ int log2i(int v)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct ScratchLayout {
-    size_t counts, cursor, work_count, seg_cnt, bin_off, fc_total, fc_base, cam_mask, stamps0, stamps, work, list_cap, total;
+    size_t counts, cursor, work_count, seg_cnt, bin_off, fc_total, fc_base, cam_mask, cam_fn, stamps0, stamps, work, list_cap, total;
     size_t zero_bytes;              // counts .. seg_cnt: cleared by one memset before the projection pass
     uint64_t capacity;
     uint32_t nseg;
@@ -186,7 +186,8 @@ int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLay
     L.bin_off = off;  off = align_up(off + nbins * 4, 256);
     L.fc_total = off; off = align_up(off + nfc * 4, 256);
     L.fc_base = off;  off = align_up(off + nfc * 4, 256);
-    L.cam_mask = off; off = align_up(off + (size_t)F * ((N + BLOCK - 1) / BLOCK) * 2, 256);   // per (frame, vertex block)
+    L.cam_mask = off; off = align_up(off + (size_t)F * ((N + BLOCK - 1) / BLOCK) * 8, 256);   // per (frame, vertex block): 4 x u16
+    L.cam_fn = off; off = align_up(off + (size_t)CAMA_MAX_CAMERAS * 20 * 8, 256);
     L.stamps0 = off;  off = align_up(off + nfc * L.nseg * SEG * 8 + 8, 256);   // compacted per-segment stamps (worst case)
     L.stamps = off;   off = align_up(off + (size_t)L.capacity * 8 + 8, 256);   // >= 1 record: empty bins read stamps[0]
     // work lists of the crop cull: 8 (one per XCD), each up to ceil(vblocks / 8) * F uint32 items
@@ -203,6 +204,16 @@ uint64_t cull_list_threshold()
     static const uint64_t v = getenv("CAMA_CULL_LIST_MIN") ? strtoull(getenv("CAMA_CULL_LIST_MIN"), nullptr, 10) : 16384ull;
     return v;
 }
+// vertex blocks one projection workgroup runs: 1 until the launch has >= 16 k (block, frame) items, then as many as keep
+// ~16 k workgroups (64 per CU), at most 8.  CAMA_PROJECT_VB overrides (A/B).
+int project_blocks_per_workgroup(uint64_t items)
+{
+    static const int forced = getenv("CAMA_PROJECT_VB") ? atoi(getenv("CAMA_PROJECT_VB")) : 0;
+    if (forced > 0) return forced;
+    const uint64_t vb = items / 16384ull;
+    return vb < 1 ? 1 : (vb > 8 ? 8 : (int)vb);
+}
+
 unsigned persistent_workgroups()
 {
     static const unsigned v = getenv("CAMA_PERSISTENT_WGS") ? (unsigned)atoi(getenv("CAMA_PERSISTENT_WGS")) : 2048u;
@@ -373,7 +384,7 @@ static int check_render(int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, i
     return CAMA_OK;
 }
 
-int cama_map_bounds_block(void) { return BLOCK; }
+int cama_map_bounds_block(void) { return 64; }      // one box per wave of the projection kernel
 
 int cama_map_bounds(const void *x, const void *y, const void *z, int32_t xyz_is_f64, int64_t N, double *bounds,
                     void *stream)
@@ -436,7 +447,11 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     // keeps its 1/8 of the vertex buffer across all frames instead of re-fetching it per frame (padding workgroups
     // exit at once: no vertex, no survivor).
     const unsigned vblocks = (unsigned)((N + BLOCK - 1) / BLOCK);
-    const dim3 fgrid(getenv("CAMA_NO_XCD_PAD") ? vblocks : ((vblocks + 7u) & ~7u), (unsigned)F);
+    // ... and a workgroup runs several consecutive vertex blocks of its frame once there are enough workgroups to fill the
+    // chip anyway (launch + histogram clear / flush per 256 vertices made big maps dispatch-bound)
+    const int vb_per_wg = project_blocks_per_workgroup((uint64_t)vblocks * (uint64_t)F);
+    const unsigned vchunks = (vblocks + vb_per_wg - 1) / vb_per_wg;
+    const dim3 fgrid(getenv("CAMA_NO_XCD_PAD") ? vchunks : ((vchunks + 7u) & ~7u), (unsigned)F);
     const size_t hist_lds = align_up((size_t)C * L.NB * 4, 16);
     // With the map's spatial index (block AABBs) a one-thread-per-(block, frame) pre-pass decides which cameras can see
     // each block at all (k_block_cameras); the projection skips the others.  Site-sized maps (CAMA_BIN_WORKLIST: most
@@ -449,16 +464,31 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
         Crop cr;
         memcpy(cr.v, crop, sizeof(cr.v));
         uint16_t *cam_mask = (uint16_t *)(base + L.cam_mask);
-        const dim3 cgrid((vblocks + BLOCK - 1) / BLOCK, (unsigned)F);
+        const uint32_t nsub = (uint32_t)((N + 63) / 64);
+        const dim3 cgrid((4 * vblocks + BLOCK - 1) / BLOCK, (unsigned)F);
+        double *cam_fn = (double *)(base + L.cam_fn);
+        hipLaunchKernelGGL(k_camera_functionals, dim3(1), dim3(CAMA_MAX_CAMERAS * 20 <= 256 ? 256 : 512), 0, s, c2cam, K, C, W, H,
+                           cam_fn);
         if (use_list)
-            hipLaunchKernelGGL(k_block_cameras<true>, cgrid, dim3(BLOCK), 0, s, block_bounds, w2c, c2cam, K, C, W, H, cr,
-                               vblocks, cam_mask, (uint32_t)L.list_cap, work_count, work);
+            hipLaunchKernelGGL(k_block_cameras<true>, cgrid, dim3(BLOCK), 0, s, block_bounds, w2c, cam_fn, C, cr, vblocks, nsub,
+                               cam_mask, (uint32_t)L.list_cap, work_count, work);
         else
-            hipLaunchKernelGGL(k_block_cameras<false>, cgrid, dim3(BLOCK), 0, s, block_bounds, w2c, c2cam, K, C, W, H, cr,
-                               vblocks, cam_mask, (uint32_t)L.list_cap, work_count, work);
+            hipLaunchKernelGGL(k_block_cameras<false>, cgrid, dim3(BLOCK), 0, s, block_bounds, w2c, cam_fn, C, cr, vblocks, nsub,
+                               cam_mask, (uint32_t)L.list_cap, work_count, work);
         HIP_TRY(hipGetLastError());
-        a.cam_mask = cam_mask;
+        a.cam_mask = (const uint64_t *)cam_mask;
         a.vblocks = vblocks;
+#ifdef ABL_MASK_STATS
+        {
+            std::vector<uint64_t> hm((size_t)vblocks * F);
+            hipStreamSynchronize(s);
+            hipMemcpy(hm.data(), (const void *)cam_mask, hm.size() * 8, hipMemcpyDeviceToHost);
+            uint64_t bits = 0, zero = 0;
+            for (uint64_t m : hm) { bits += __builtin_popcountll(m); zero += m == 0; }
+            fprintf(stderr, "[mask stats] %zu (block, frame) items: %.3f cameras per wave, %.3f of the blocks empty\n", hm.size(),
+                    (double)bits / hm.size() / 4, (double)zero / hm.size());
+        }
+#endif
     }
     if (N && use_list && a.cam_mask) {
         if (xyz_is_f64)
@@ -470,9 +500,9 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
         HIP_TRY(hipGetLastError());
     } else if (N) {
         if (xyz_is_f64)
-            hipLaunchKernelGGL(k_frames_project<double>, fgrid, dim3(BLOCK), hist_lds, s, a);
+            hipLaunchKernelGGL(k_frames_project<double>, fgrid, dim3(BLOCK), hist_lds, s, a, vb_per_wg);
         else
-            hipLaunchKernelGGL(k_frames_project<float>, fgrid, dim3(BLOCK), hist_lds, s, a);
+            hipLaunchKernelGGL(k_frames_project<float>, fgrid, dim3(BLOCK), hist_lds, s, a, vb_per_wg);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_scan_bands, dim3(nfc), dim3(64), 0, s, counts, bin_off, fc_total, L.NB);
@@ -1279,6 +1309,22 @@ extern "C" int cama_jpeg_plan(cama_jpeg_image *imgs, int32_t n, uint64_t stream_
     return CAMA_OK;
 }
 
+extern "C" int cama_jpeg_find_restarts(const uint8_t *stream, uint64_t stream_bytes, uint32_t *positions,
+                                       uint32_t capacity, uint32_t *count, void *stream_handle)
+{
+    if (!stream || !positions || !count) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (stream_bytes < 1 || stream_bytes > 0xffffffffull)
+        return fail(CAMA_EINVAL, "stream_bytes=%llu out of range [1, 2^32)", (unsigned long long)stream_bytes);
+    if ((uintptr_t)stream % 16) return fail(CAMA_EINVAL, "stream must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream_handle;
+    HIP_TRY(hipMemsetAsync(count, 0, 4, s));
+    const uint64_t threads = (stream_bytes + 15) / 16;
+    hipLaunchKernelGGL(k_jpeg_find_restarts, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, stream, stream_bytes,
+                       positions, capacity, count);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
 extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, const cama_jpeg_image *imgs,
                                 const cama_jpeg_image *imgs_dev, int32_t n, const void *huff_sets, int32_t n_huff_sets,
                                 const uint16_t *quant_sets, int32_t n_quant_sets, uint8_t *out, uint64_t out_stride,
@@ -1290,6 +1336,13 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
     if (int rc = jpeg_layout(nullptr, imgs, n, stream_bytes, false, L)) return rc;
     if (scratch_bytes < L.total) return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", scratch_bytes, L.total);
     uint32_t maxw = 0, maxh = 0;
+    // the pixel stages (IDCT, colour) run over the descriptors that own pixels; restart-interval segments do not, and
+    // there are ~60 of them per image: when they all come after the pixel owners (as cama_amd/jpeg.py lays them out)
+    // the grids stop at the first one instead of launching a million workgroups that return at once
+    int npix = 0;
+    while (npix < n && imgs[npix].kind != CAMA_JPEG_SEGMENT) ++npix;
+    for (int i = npix; i < n; ++i)
+        if (imgs[i].kind != CAMA_JPEG_SEGMENT) { npix = n; break; }
     for (int i = 0; i < n; ++i) {
         if ((int32_t)imgs[i].huff_set >= n_huff_sets || (int32_t)imgs[i].quant_set >= n_quant_sets)
             return fail(CAMA_EINVAL, "image %d: table set index out of range", i);
@@ -1325,9 +1378,12 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
         hipLaunchKernelGGL(k_jpeg_write, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
     }
     hipLaunchKernelGGL(k_jpeg_dc, dim3((unsigned)n, 3), dim3(JPEG_DC_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_jpeg_idct, dim3((L.max_blocks + 31) / 32, (unsigned)n), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_jpeg_colour, dim3((maxw + 2047) / 2048, (maxh + JPEG_COLOUR_ROWS - 1) / JPEG_COLOUR_ROWS, (unsigned)n),
-                       dim3(256), 0, s, a);
+    if (npix) {
+        hipLaunchKernelGGL(k_jpeg_idct, dim3((L.max_blocks + 31) / 32, (unsigned)npix), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_jpeg_colour,
+                           dim3((maxw + 2047) / 2048, (maxh + JPEG_COLOUR_ROWS - 1) / JPEG_COLOUR_ROWS, (unsigned)npix),
+                           dim3(256), 0, s, a);
+    }
     HIP_TRY(hipGetLastError());
     return CAMA_OK;
 }

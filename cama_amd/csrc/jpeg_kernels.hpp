@@ -18,10 +18,17 @@
 //   k_jpeg_dc        per component prefix sum of the DC differences
 //   k_jpeg_idct      dequantise + islow IDCT, 8 lanes per block, column pass -> LDS -> row pass -> component planes
 //   k_jpeg_colour    fancy upsampling + colour conversion, one thread per output pixel, BGR or RGB
+//   k_jpeg_find_restarts   (DRI files, before the descriptors exist) positions of every RSTn marker in the uploaded bytes
 
-constexpr int JPEG_SUB_WORDS = 32;                 // subsequence: 32 dwords = 1024 bits
+#ifndef JPEG_SUB_SHIFT
+#define JPEG_SUB_SHIFT 5
+#endif
+constexpr int JPEG_SUB_WORDS = 1 << JPEG_SUB_SHIFT; // subsequence: 32 dwords = 1024 bits
 constexpr int JPEG_SUB_BITS = JPEG_SUB_WORDS * 32;
-constexpr int JPEG_WG = 256;                       // subsequences (threads) per workgroup
+#ifndef JPEG_WG_N
+#define JPEG_WG_N 256
+#endif
+constexpr int JPEG_WG = JPEG_WG_N;                 // subsequences (threads) per workgroup
 constexpr int JPEG_TILE = 1024;                    // unstuff tile, bytes (4 per thread)
 constexpr int JPEG_LUT_BITS = 10;
 
@@ -196,7 +203,7 @@ __device__ __forceinline__ uint32_t jpeg_word(const JpegWgCtx &c, uint32_t w)
 #ifdef JPEG_WORDS_GLOBAL
     return w < c.nwords ? __builtin_bswap32(c.words[w]) : 0u;
 #else
-    return c.words[w + (w >> 5)];
+    return c.words[w + (w >> JPEG_SUB_SHIFT)];
 #endif
 }
 
@@ -333,7 +340,7 @@ __device__ __forceinline__ uint32_t jpeg_decode_span_wave(const JpegWgCtx &c, Jp
 struct JpegWgShared {
     JpegHuffSet H;
 #ifndef JPEG_WORDS_GLOBAL
-    uint32_t words[JPEG_WG * JPEG_SUB_WORDS + JPEG_WG + 40];
+    uint32_t words[JPEG_WG * JPEG_SUB_WORDS + JPEG_WG + 40];   // one pad word per subsequence: lane stride odd
 #endif
     uint64_t E[JPEG_WG];
     uint32_t nb[JPEG_WG];
@@ -361,7 +368,7 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
     const uint32_t w0 = lw * JPEG_WG * JPEG_SUB_WORDS;
     for (uint32_t i = threadIdx.x; i < JPEG_WG * JPEG_SUB_WORDS + 8; i += JPEG_WG) {
         const uint32_t w = w0 + i;
-        S.words[i + (i >> 5)] = w < nwords_img ? __builtin_bswap32(g[w]) : 0u;
+        S.words[i + (i >> JPEG_SUB_SHIFT)] = w < nwords_img ? __builtin_bswap32(g[w]) : 0u;
     }
     c.words = S.words;
     c.word0 = w0;
@@ -793,5 +800,56 @@ __global__ __launch_bounds__(256) void k_jpeg_colour(JpegArgs a)
                 o[3 * k + 2] = (uint8_t)(px[k] >> 16);
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ restart markers
+// Positions of every 0xFF 0xD0..0xD7 pair in bytes [0, n) (T.81 B.2.1: inside entropy-coded data 0xFF is always
+// followed by 0x00, so such a pair IS a restart marker; hits in file headers between the scans are filtered by the
+// caller, who knows the scan ranges).  16 bytes per thread, one counter reservation per wave; the list is unordered
+// across waves (the caller sorts it: it is ~1 entry per 5 KB).  *count is the number found, even beyond `capacity`.
+__global__ __launch_bounds__(256) void k_jpeg_find_restarts(const uint8_t *bytes, uint64_t n, uint32_t *positions,
+                                                            uint32_t capacity, uint32_t *count)
+{
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    uint32_t hits = 0;                                  // bit k: marker starts at byte i0 + k
+    if (i0 < n) {
+        uint32_t w[5];
+        if (i0 + 16 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bytes + i0);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            for (int q = 0; q < 4; ++q) {
+                w[q] = 0;
+                for (int b = 0; b < 4; ++b)
+                    if (i0 + q * 4 + b < n) w[q] |= (uint32_t)bytes[i0 + q * 4 + b] << (8 * b);
+            }
+        }
+        w[4] = i0 + 16 < n ? bytes[i0 + 16] : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t b0 = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+            const uint32_t b1 = (w[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 255u;
+            if (b0 == 0xFFu && (b1 & 0xF8u) == 0xD0u) hits |= 1u << k;
+        }
+    }
+    const uint32_t mine = __popc(hits);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total == 0u) return;                            // wave-uniform: almost every wave
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 63) base = atomicAdd(count, total);
+    base = __shfl(base, 63, 64);
+    uint32_t at = base + incl - mine;
+    while (hits) {
+        const int k = __ffs(hits) - 1;
+        hits &= hits - 1u;
+        if (at < capacity) positions[at] = (uint32_t)(i0 + k);
+        ++at;
     }
 }

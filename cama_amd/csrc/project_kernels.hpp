@@ -169,7 +169,6 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_block_bounds(const void *x, const void *y, const void *z, int64_t N,
                                                         double *__restrict__ bounds)
 {
-    __shared__ double s_part[BLOCK / 64][6];
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const double inf = __builtin_huge_val();
     double v[6] = {inf, -inf, inf, -inf, inf, -inf};
@@ -189,16 +188,12 @@ __global__ __launch_bounds__(BLOCK) void k_block_bounds(const void *x, const voi
             v[k + 1] = fmax(v[k + 1], __shfl_xor(v[k + 1], off, 64));
         }
     }
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s_part[threadIdx.x >> 6][k] = v[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        double r = s_part[0][threadIdx.x];
-        for (int w = 1; w < BLOCK / 64; ++w)
-            r = (threadIdx.x & 1) ? fmax(r, s_part[w][threadIdx.x]) : fmin(r, s_part[w][threadIdx.x]);
-        bounds[(size_t)blockIdx.x * 6 + threadIdx.x] = r;
+    // one box per wave (64 consecutive vertices): lane k < 6 writes component k
+    const int64_t sub = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (sub * 64 < N) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const double r = lane == 0 ? v[0] : lane == 1 ? v[1] : lane == 2 ? v[2] : lane == 3 ? v[3] : lane == 4 ? v[4] : v[5];
+        if (lane < 6u) bounds[(size_t)sub * 6 + lane] = r;
     }
 }
 
@@ -206,8 +201,9 @@ struct FrameArgs {
     const void *x, *y, *z;  // [N] each, float or double (template parameter T)
     const uint8_t *colour;
     const uint32_t *key;    // optional [N]: draw index << 1 | colour (maps stored in a different order than drawn)
-    const double *bounds;   // optional [ceil(N/BLOCK),6]: per-vertex-block AABB (k_block_bounds), for the crop cull
-    const uint16_t *cam_mask;   // optional [F, vblocks]: cameras that may see a block (k_block_cameras); 0 = outside crop
+    const double *bounds;   // optional [ceil(N/64),6]: AABB of every 64 consecutive vertices (k_block_bounds)
+    const uint64_t *cam_mask;   // optional [F, vblocks]: 4 x 16 bits, cameras that may see wave w's 64 vertices of the
+                                // block (k_block_cameras); 0 = outside the crop box / every frustum
     uint32_t vblocks;
     int64_t N;
     const double *w2c, *c2cam, *K;
@@ -271,24 +267,21 @@ __global__ __launch_bounds__(BLOCK) void k_frames_emit(FrameArgs a)
 //   k_stamps_scatter   re-reads only the 8-byte stamps (no geometry) and moves them to their band-sorted places.
 constexpr int SEG = 64;                 // one segment = one wave's 64 vertices of one (frame, camera)
 
-// One (vertex block, frame) work item.  CULL: test the block's AABB first (grid-per-item launch).
-template <typename T, bool CULL>
-__device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t vblock, const int f, uint32_t *s_cnt)
+// Vertex block `vblock` of frame f: every wave projects its 64 vertices, compacts the surviving stamps into its segments
+// and adds their bands to the workgroup's LDS histogram s_cnt [C*NB] (zeroed by the caller).  No barrier inside: the
+// waves of a workgroup run through their blocks independently; the caller flushes s_cnt after a barrier.
+template <typename T>
+__device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t vblock, const int f, const uint64_t cams4,
+                                              uint32_t *s_cnt)
 {
-    const int nloc = a.C * a.NB;
-
+    // this wave's 16 camera bits (wave-uniform: kept in an SGPR)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t cams = (uint32_t)(cams4 >> (16u * wave)) & 0xffffu;
+    if (!cams) return;
     // world->chassis + crop FIRST, with the frame's matrix read through wave-uniform (scalar) loads: on site-sized
-    // maps ~95 % of the workgroups end here and never pay for clearing the histogram
+    // maps ~95 % of the waves end here
     const double *w2c = a.w2c + (size_t)f * 16;
     const int64_t i = vblock * BLOCK + threadIdx.x;
-    // ... and with the map's block AABBs (cama_map_bounds -> k_block_cameras) those workgroups do not even read their
-    // vertices; the surviving ones know which cameras can see the block at all
-    uint32_t cams = 0xffffu;
-    if (a.cam_mask) {
-        if (vblock * BLOCK >= a.N) return;
-        cams = a.cam_mask[(size_t)f * a.vblocks + (size_t)vblock];       // wave-uniform (scalar) load
-        if (CULL && !cams) return;
-    }
     double cx = 0, cy = 0, cz = 0;
     bool in = false;
     uint32_t key = 0;
@@ -301,16 +294,16 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
         // storage index itself
         key = a.key ? a.key[i] : (((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1));
     }
-    // whole workgroup outside the crop box (the common case on site-sized maps): done (its segments stay empty: the
-    // count table was zeroed)
-    if (!__syncthreads_or((int)in)) return;
-    for (int t = threadIdx.x; t < nloc; t += BLOCK) s_cnt[t] = 0u;
-    __syncthreads();
+    // whole wave outside the crop box: done (its segments stay empty: the count table was zeroed)
+    if (!__ballot(in)) return;
 
     const double Wd = (double)a.W, Hd = (double)a.H;
-    const size_t gbin0 = (size_t)f * nloc;
     const uint32_t seg = (uint32_t)vblock * (BLOCK / SEG) + (threadIdx.x >> 6);
     const uint32_t lane = __lane_id();
+#ifdef ABL_PROJ_NO_OUT
+    uint32_t sink = 0;
+#endif
+#ifndef ABL_PROJ_NO_CAMS
     for (int c = 0; c < a.C; ++c) {
         if (!((cams >> c) & 1u)) continue;                               // wave-uniform: no vertex of the block in view
         uint32_t uv = 0xffffffffu;      // packed truncated pixel, or "not visible"
@@ -322,6 +315,10 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
                                          cz, Wd, Hd, packed))
                 uv = packed;
         }
+#ifdef ABL_PROJ_NO_OUT
+        sink ^= uv;
+        continue;
+#endif
         // A disc is invisible if a LATER point (higher draw index) stamps the very same pixel (same footprint).  The
         // next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most far-range stamps collapse
         // here, exactly, before they cost HBM or LDS traffic.  (executed by every lane: shuffles)
@@ -332,31 +329,66 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
         const uint64_t m = __ballot(keep);
         if (m) {                        // wave-uniform
             const size_t fcseg = ((size_t)f * a.C + c) * a.nseg + seg;
+            const int vi = (int)(uv >> 16);
+            const int b0 = max(vi - a.radius, 0) >> a.band_shift;
+            const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;       // b1 <= b0 + 1 (host checks 2r <= R)
             if (keep) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 a.stamps0[fcseg * SEG + rank] = make_uint2(uv, key);
-                const int vi = (int)(uv >> 16);
-                const int b0 = max(vi - a.radius, 0) >> a.band_shift;
-                const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;   // b1 <= b0 + 1 (host checks 2r <= R)
+            }
+            if (lane == 0u) a.seg_cnt[fcseg] = (uint8_t)__popcll(m);
+            // band histogram: per-lane LDS atomics (counting the wave's stamps per distinct band by ballot first was
+            // measured slower on the dense map, 475 -> 527 us: same-address ds_add is cheaper than the leader loop)
+            if (keep) {
                 const uint32_t l0 = (uint32_t)(c * a.NB + b0);
                 atomicAdd(&s_cnt[l0], 1u);
                 if (b1 != b0) atomicAdd(&s_cnt[l0 + 1], 1u);
             }
-            if (lane == 0u) a.seg_cnt[fcseg] = (uint8_t)__popcll(m);
         }
     }
+#endif
+#ifdef ABL_PROJ_NO_OUT
+    if (sink == 0x12345678u) a.seg_cnt[0] = 1;
+#endif
+}
+
+// workgroup-level frame of project_block: zero the histogram, run `body`, add the non-empty bins to the frame's counts
+__device__ __forceinline__ void hist_clear(const FrameArgs &a, uint32_t *s_cnt)
+{
+    for (int t = threadIdx.x; t < a.C * a.NB; t += BLOCK) s_cnt[t] = 0u;
+    __syncthreads();
+}
+__device__ __forceinline__ void hist_flush(const FrameArgs &a, const int f, const uint32_t *s_cnt)
+{
+    const int nloc = a.C * a.NB;
     __syncthreads();
     for (int t = threadIdx.x; t < nloc; t += BLOCK) {
         const uint32_t n = s_cnt[t];
-        if (n) atomicAdd(&a.counts[gbin0 + t], n);
+        if (n) atomicAdd(&a.counts[(size_t)f * nloc + t], n);
     }
 }
 
+// grid (ceil(vblocks / vb_per_wg) padded to a multiple of 8, F): a workgroup runs vb_per_wg consecutive vertex blocks of
+// one frame.  One block per workgroup made big maps dispatch-bound: on the dense 1e6-vertex map (156 k workgroups per
+// launch) an ablation with the camera loop removed still took 278 of 534 us -- workgroup launch, histogram clear /
+// flush and two barriers per 256 vertices (profiles/r02_project_ablation.txt).
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_frames_project(FrameArgs a)
+__global__ __launch_bounds__(BLOCK) void k_frames_project(FrameArgs a, const int vb_per_wg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [C*NB] stamp counts of this workgroup
-    project_block<T, true>(a, (int64_t)blockIdx.x, (int)blockIdx.y, s_hist);
+    const int f = blockIdx.y;
+    const int64_t vb0 = (int64_t)blockIdx.x * vb_per_wg;
+    if (vb0 * BLOCK >= a.N) return;
+    hist_clear(a, s_hist);
+    for (int b = 0; b < vb_per_wg; ++b) {
+        const int64_t vb = vb0 + b;
+        if (vb * BLOCK >= a.N) break;
+        // with the map's block AABBs (cama_map_bounds -> k_block_cameras) a block outside the crop box or every frustum
+        // is not even read; the others know which cameras can see them at all
+        const uint64_t cams = a.cam_mask ? a.cam_mask[(size_t)f * a.vblocks + (size_t)vb] : ~0ull;   // scalar load
+        if (cams) project_block<T>(a, vb, f, cams, s_hist);
+    }
+    hist_flush(a, f, s_hist);
 }
 
 // Band sort of the compacted stamps: one workgroup per SCATTER_SEGS consecutive segments of one (frame, camera).  Work
@@ -443,7 +475,9 @@ __global__ __launch_bounds__(BLOCK) void k_stamps_scatter(FrameArgs a)
     }
 }
 
-// Which cameras can a vertex block reach?  One THREAD per (vertex block, frame): the block's world AABB becomes a
+// Which cameras can a vertex block reach?  One THREAD per (box, frame), one box per WAVE of a vertex block (64
+// consecutive vertices: on the dense 1e6-vertex lane map a 256-vertex box left 2.14 cameras per block where 0.98 have a
+// visible vertex -- close to the car a 2.5 m box spans two or three frusta): each world AABB becomes a
 // conservative chassis-frame box (centre +- sum |m_k| * half extent, as in block_outside_crop), clipped to the crop box
 // (vertices outside it are dropped before projection), and that box is tested against the five half-spaces every visible
 // point satisfies in homogeneous image coordinates h = K (R p + t):
@@ -452,7 +486,8 @@ __global__ __launch_bounds__(BLOCK) void k_stamps_scatter(FrameArgs a)
 // that camera -- for points with h2 <= 0 nothing is visible anyway, so the sign arguments only need h2 > 0).  Margins of
 // 1e-9 relative + 1e-9 absolute are >= 6 orders above fp64 rounding of the exact chain, and every comparison is false on
 // NaN, i.e. "may be visible": the mask never removes a stamp, the output is bit-identical with and without it.
-// Bit c of cam_mask[f * vblocks + b] = camera c may see block b in frame f; 0 = the block is outside the crop box too.
+// Bit 16 w + c of cam_mask[f * vblocks + b] = camera c may see wave w's vertices of block b in frame f; 0 = the block is
+// outside the crop box too.
 // The projection kernel then skips the whole fp64 chain of the other cameras (wave-uniform branch): on dense lane maps a
 // block is in view of 1-2 of the 6 cameras.  With WORKLIST the surviving (block, frame) items are also appended to 8
 // per-XCD work lists for persistent workgroups (site-sized maps: ~95 % of the items are outside the crop box, and even an
@@ -471,17 +506,30 @@ __device__ __forceinline__ bool box_beyond(const double n0, const double n1, con
     return want_positive ? (v + s + margin < 0.0) : (v - s - margin > 0.0);
 }
 
+// The five functionals of every camera, once per launch: rows h0, h1, h2 of K [R | t], then h0 - W h2, h1 - H h2.
+// fn [C][5][4]; k_block_cameras reads them through scalar loads (as LDS broadcasts they were 120 ds_read_b64 per thread).
+__global__ void k_camera_functionals(const double *__restrict__ c2cam, const double *__restrict__ K, int C, int W, int H,
+                                     double *__restrict__ fn)
+{
+    if ((int)threadIdx.x >= C * 20) return;
+    const int c = threadIdx.x / 20, i = (threadIdx.x % 20) / 4, j = threadIdx.x % 4;
+    const double *M = c2cam + (size_t)c * 16, *Kc = K + (size_t)c * 9;
+    const auto row = [&](int r) { return Kc[3 * r] * M[j] + Kc[3 * r + 1] * M[4 + j] + Kc[3 * r + 2] * M[8 + j]; };
+    fn[threadIdx.x] = i < 3 ? row(i) : row(i - 3) - (i == 3 ? (double)W : (double)H) * row(2);
+}
+
+// grid (ceil(4 * vblocks / BLOCK), F): one thread per (box, frame); the four boxes of a vertex block sit in adjacent lanes.
 template <bool WORKLIST>
 __global__ __launch_bounds__(BLOCK) void k_block_cameras(const double *__restrict__ bounds, const double *__restrict__ w2c,
-                                                         const double *__restrict__ c2cam, const double *__restrict__ K,
-                                                         int C, int W, int H, Crop crop, uint32_t vblocks,
+                                                         const double *fn, int C, Crop crop, uint32_t vblocks, uint32_t nsub,
                                                          uint16_t *__restrict__ cam_mask, uint32_t list_cap,
                                                          uint32_t *__restrict__ work_count, uint32_t *__restrict__ work)
 {
-    const uint32_t b = blockIdx.x * BLOCK + threadIdx.x, f = blockIdx.y;   // b % 8 == lane % 8
+    const uint32_t sb = blockIdx.x * BLOCK + threadIdx.x, f = blockIdx.y;     // box; vertex block b = sb / 4
+    const uint32_t b = sb >> 2;
     uint32_t mask = 0;
-    if (b < vblocks) {
-        const double *m = w2c + (size_t)f * 16, *bx = bounds + (size_t)b * 6;
+    if (sb < nsub) {
+        const double *m = w2c + (size_t)f * 16, *bx = bounds + (size_t)sb * 6;
         const double wx = 0.5 * (bx[0] + bx[1]), wy = 0.5 * (bx[2] + bx[3]), wz = 0.5 * (bx[4] + bx[5]);
         const double ex = 0.5 * (bx[1] - bx[0]), ey = 0.5 * (bx[3] - bx[2]), ez = 0.5 * (bx[5] - bx[4]);
         double mid[3], rad[3];
@@ -505,37 +553,38 @@ __global__ __launch_bounds__(BLOCK) void k_block_cameras(const double *__restric
             mask = (1u << C) - 1u;                          // NaN / inf anywhere: no claim, keep every camera
         } else if (!outside) {
             for (int c = 0; c < C; ++c) {
-                const double *M = c2cam + (size_t)c * 16, *Kc = K + (size_t)c * 9;
-                double P[3][4];                             // K * [R | t]
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) P[i][j] = Kc[3 * i] * M[j] + Kc[3 * i + 1] * M[4 + j] + Kc[3 * i + 2] * M[8 + j];
-                const double Wd = (double)W, Hd = (double)H;
-                bool gone = box_beyond(P[2][0], P[2][1], P[2][2], P[2][3], mid, rad, true);                     // h2 > 0
-                gone |= box_beyond(P[0][0], P[0][1], P[0][2], P[0][3], mid, rad, true);                         // h0 >= 0
-                gone |= box_beyond(P[1][0], P[1][1], P[1][2], P[1][3], mid, rad, true);                         // h1 >= 0
-                gone |= box_beyond(P[0][0] - Wd * P[2][0], P[0][1] - Wd * P[2][1], P[0][2] - Wd * P[2][2],
-                                   P[0][3] - Wd * P[2][3], mid, rad, false);                                    // h0 < W h2
-                gone |= box_beyond(P[1][0] - Hd * P[2][0], P[1][1] - Hd * P[2][1], P[1][2] - Hd * P[2][2],
-                                   P[1][3] - Hd * P[2][3], mid, rad, false);                                    // h1 < H h2
+                kdouble *P = (kdouble *)(fn + (size_t)c * 20);      // wave-uniform: scalar loads
+                bool gone = box_beyond(P[8], P[9], P[10], P[11], mid, rad, true);                               // h2 > 0
+                gone |= box_beyond(P[0], P[1], P[2], P[3], mid, rad, true);                                     // h0 >= 0
+                gone |= box_beyond(P[4], P[5], P[6], P[7], mid, rad, true);                                     // h1 >= 0
+                gone |= box_beyond(P[12], P[13], P[14], P[15], mid, rad, false);                                // h0 < W h2
+                gone |= box_beyond(P[16], P[17], P[18], P[19], mid, rad, false);                                // h1 < H h2
                 if (!gone) mask |= 1u << c;
             }
         }
-        cam_mask[(size_t)f * vblocks + b] = (uint16_t)mask;
     }
+    // [F, vblocks] x 4 x u16 = the u64 per block the projection reads (boxes past the last vertex: 0)
+    if (b < vblocks) cam_mask[((size_t)f * vblocks + b) * 4 + (sb & 3u)] = (uint16_t)mask;
     if (!WORKLIST) return;
-    const bool keep = mask != 0u;
+    // a block goes on if any of its four boxes does; its first lane (lane % 4 == 0) appends it
+    uint32_t any = mask | (uint32_t)__shfl_xor((int)mask, 1, 64);
+    any |= (uint32_t)__shfl_xor((int)any, 2, 64);
+    const uint32_t lane = __lane_id();
+    const bool keep = any != 0u && (lane & 3u) == 0u && b < vblocks;
     const uint64_t mk = __ballot(keep);
     if (!mk) return;
-    // one atomic per (wave, list): lane l < 8 reserves for list l, whose members are the lanes = l (mod 8)
-    const uint32_t lane = __lane_id();
-    const uint64_t mine = mk & (0x0101010101010101ull << (lane & 7u));
+    // one atomic per (wave, list): a wave holds 16 consecutive blocks, b % 8 == (lane / 4) % 8, so list l's members are
+    // lanes 4 l and 4 l + 32; lane l < 8 reserves for list l
+    const uint64_t pair = 0x0000000100000001ull;
+    const uint64_t res = mk & (pair << (4u * (lane & 7u)));
     uint32_t base = 0;
-    if (lane < 8u && mine) base = atomicAdd(&work_count[lane], (uint32_t)__popcll(mine));
-    base = __shfl(base, (int)(lane & 7u), 64);
-    if (keep)
-        work[(size_t)(lane & 7u) * list_cap + base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = f * vblocks + b;
+    if (lane < 8u && res) base = atomicAdd(&work_count[lane], (uint32_t)__popcll(res));
+    const uint32_t l = (lane >> 2) & 7u;
+    base = __shfl(base, (int)l, 64);
+    if (keep) {
+        const uint64_t mine = mk & (pair << (4u * l));
+        work[(size_t)l * list_cap + base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = f * vblocks + b;
+    }
 }
 
 template <typename T>
@@ -549,8 +598,12 @@ __global__ __launch_bounds__(BLOCK) void k_frames_project_list(FrameArgs a, cons
     work += (size_t)list * list_cap;
     for (uint32_t w = blockIdx.x >> 3; w < n; w += gridDim.x >> 3) {
         const uint32_t item = work[w];
-        // the barrier at the top of project_block (__syncthreads_or) also fences the previous item's LDS reads
-        project_block<T, false>(a, (int64_t)(item % vblocks), (int)(item / vblocks), s_hist);
+        const int64_t vb = (int64_t)(item % vblocks);
+        const int f = (int)(item / vblocks);
+        hist_clear(a, s_hist);
+        project_block<T>(a, vb, f, a.cam_mask[(size_t)f * a.vblocks + (size_t)vb], s_hist);
+        hist_flush(a, f, s_hist);
+        __syncthreads();                            // the next item's clear must not overtake this flush
     }
 }
 

@@ -297,6 +297,37 @@ def restart_segments(data, h):
     return segs
 
 
+def segments_from_markers(pos, host_bytes, lo, hi, nseg, good):
+    """Restart intervals of several scans from the sorted positions `pos` of every 0xFF 0xDk pair in `host_bytes`
+    (the device's search, cama_jpeg_find_restarts): scan j occupies bytes [lo[j], hi[j]) and must hold nseg[j]
+    intervals.  Clears good[j] (in place) for a scan whose markers are not exactly nseg[j] - 1, do not cycle
+    RST0..RST7, or leave an interval empty (T.81 B.2.1, E.2.4): those go to the host decoder.  Returns (g, ns, k, starts,
+    ends): the surviving scans, their interval counts, and per interval its number inside the scan and its byte range.
+    Same segmentation as restart_segments(), for a whole group at once."""
+    A = np.searchsorted(pos, lo, "left")
+    B = np.searchsorted(pos, hi - 1, "left")                       # a marker is two bytes: pos + 2 <= hi
+    good &= (B - A) == nseg - 1
+    for _ in range(2):                                             # second pass: without the scans the checks dropped
+        g = np.flatnonzero(good)
+        ns = nseg[g]
+        total = int(ns.sum())
+        first = np.cumsum(ns) - ns                                 # index of every scan's first interval
+        M = np.concatenate([pos[a:b] for a, b in zip(A[g], B[g])]) if len(g) else np.zeros(0, np.int64)
+        k = np.arange(total) - np.repeat(first, ns)                # interval number inside its scan
+        starts, ends = np.empty(total, np.int64), np.empty(total, np.int64)
+        starts[first] = lo[g]
+        ends[first + ns - 1] = hi[g]
+        not_first, not_last = k > 0, k < np.repeat(ns, ns) - 1
+        starts[not_first] = M + 2
+        ends[not_last] = M
+        bad = ends <= starts
+        bad[not_last] |= (host_bytes[M + 1] & 7) != (k[not_last] & 7)
+        if not bad.any():
+            break
+        good[g[np.add.reduceat(bad.astype(np.int64), first) > 0]] = False
+    return g, ns, k, starts, ends
+
+
 def _host_decode(data, bgr):
     from PIL import Image
     with Image.open(io.BytesIO(data)) as im:
@@ -449,6 +480,67 @@ class DeviceJpegDecoder:
         self._lane = [x for x in self._lane if x is not None] + [L]
         return L
 
+    @staticmethod
+    def _repeat_templates(tmpl, counts):
+        """Descriptor block: template k repeated counts[k] times."""
+        if all(t is tmpl[0] for t in tmpl):                      # one camera model: the usual case
+            return np.repeat(tmpl[0], int(counts.sum()))
+        blk = np.empty(int(counts.sum()), IMAGE_DTYPE)           # (np.concatenate on structured arrays is slow)
+        at = 0
+        for t, c in zip(tmpl, counts.tolist()):
+            blk[at:at + c] = t[0]
+            at += c
+        return blk
+
+    def _restart_descriptors(self, L, stream_dev, stream_bytes, host_bytes, headers, dri, base, lens, nd0):
+        """Descriptors of the restart-interval images `dri` of a group: (parents [len(dri)], segments, the image of every
+        segment, images to hand to the host decoder).  The RSTn markers are located by the device in the bytes already
+        uploaded (one small readback per group); an image whose markers do not cycle RST0..RST7 in the number its frame
+        needs, or with an empty interval, is left to the host decoder (T.81 B.2.1, E.2.4)."""
+        import torch
+        H = [headers[i] for i in dri]
+        lo = base[dri].astype(np.int64)
+        hi = lo + lens[dri]
+        mcus = np.array([-(-h.width // (8 * h.hs)) * -(-h.height // (8 * h.vs)) for h in H], dtype=np.int64)
+        ri = np.array([h.restart_interval for h in H], dtype=np.int64)
+        bpm = np.array([1 if h.ncomp == 1 else h.hs * h.vs + 2 for h in H], dtype=np.int64)
+        nseg = -(-mcus // ri)
+        # the descriptor array holds at most 65535 entries: images past that budget go to the host decoder
+        good = nd0 + len(dri) + np.cumsum(nseg) <= 65535
+        capacity = int(nseg[good].sum()) + 4096                    # + strays in file headers inside the uploaded span
+        st = L["stream"]
+        with torch.cuda.stream(st):
+            if L.get("rst") is None or L["rst"][0].numel() < capacity + 1:
+                L["rst"] = (torch.empty(capacity * 5 // 4 + 1, dtype=torch.int32, device=self.device),
+                            torch.empty(capacity * 5 // 4 + 1, dtype=torch.int32).pin_memory())
+            dev, pin = L["rst"]
+            _lib.check(self.lib.cama_jpeg_find_restarts(stream_dev.data_ptr(), stream_bytes, dev.data_ptr() + 4,
+                                                        capacity, dev.data_ptr(), st.cuda_stream))
+            pin[:capacity + 1].copy_(dev[:capacity + 1], non_blocking=True)
+        st.synchronize()
+        got = pin.numpy().view(np.uint32)
+        found = int(got[0])
+        if found > capacity:                                       # not JPEG entropy data: nothing to trust
+            good[:] = False
+            found = 0
+        pos = np.sort(got[1:1 + found].astype(np.int64))
+        g, ns, k, starts, ends = segments_from_markers(pos, host_bytes, lo, hi, nseg, good)
+        tmpl = [self._template(h) for h in H]
+        parents = self._repeat_templates(tmpl, np.ones(len(dri), np.int64))
+        parents["kind"], parents["out_slot"] = KIND_PIXELS, dri
+        if not len(g):
+            return parents, np.empty(0, IMAGE_DTYPE), np.zeros(0, np.int64), [int(i) for i in dri]
+        segs = self._repeat_templates([tmpl[j] for j in g], ns)
+        rg = np.repeat(np.arange(len(g)), ns)
+        segs["kind"], segs["parent"], segs["out_slot"] = KIND_SEGMENT, nd0 + np.repeat(g, ns), 0
+        segs["first_block"] = k * ri[g][rg] * bpm[g][rg]
+        nmcu = np.minimum(ri[g][rg], mcus[g][rg] - k * ri[g][rg])
+        segs["width"] = nmcu * 8 * np.array([H[j].hs for j in g], dtype=np.int64)[rg]
+        segs["height"] = 8 * np.array([H[j].vs for j in g], dtype=np.int64)[rg]
+        segs["stream_off"], segs["stream_len"] = starts, ends - starts
+        dri = np.asarray(dri)
+        return parents, segs, dri[g][rg], [int(i) for i in dri[~good]]
+
     def _submit(self, blobs, headers, slots, out, bgr, cur):
         """Pack, upload and launch the decode of one group on a free lane's stream; returns a ticket for _finish."""
         import torch
@@ -481,43 +573,29 @@ class DeviceJpegDecoder:
             for o, ln, b, h in zip(base.tolist(), lens.tolist(), blobs, headers):
                 host[o:o + ln] = np.frombuffer(as_bytes(b), np.uint8, ln, h.scan_start)
             pinned_src = L["pinned"][:stream_bytes]
+        host_bytes = arena.np[span_lo:span_hi] if arena is not None else host[:stream_bytes]
+        st = L["stream"]
+        st.wait_stream(cur)                                # `out`, the tables and earlier work of the caller
+        with torch.cuda.stream(st):
+            stream_dev = pinned_src.to(self.device, non_blocking=True)
         # descriptors: images without restart intervals first, as one vectorised block
         whole = [i for i, h in enumerate(headers) if not h.restart_interval]
         if whole:
             tmpl = [self._template(headers[i]) for i in whole]
-            if all(t is tmpl[0] for t in tmpl):                  # one camera model: the usual case
-                blk = np.repeat(tmpl[0], len(whole))
-            else:                                                # (np.concatenate on structured arrays is slow)
-                blk = np.empty(len(whole), IMAGE_DTYPE)
-                for k, t in enumerate(tmpl):
-                    blk[k] = t[0]
+            blk = self._repeat_templates(tmpl, np.ones(len(whole), np.int64))
             blk["kind"], blk["out_slot"], blk["stream_off"], blk["stream_len"] = KIND_WHOLE, whole, base[whole], lens[whole]
             parts.append(blk)
             owner.append(np.asarray(whole))
             nd = len(whole)
-        # restart intervals: a pixels-only parent + one entropy segment per interval, all pointing into the one scan copy
-        for i, (b, h) in enumerate(zip(blobs, headers)):
-            if not h.restart_interval:
-                continue
-            rec = self._template(h).copy()
-            rec["out_slot"] = i
-            segs = restart_segments(as_bytes(b), h)
-            rec["kind"] = KIND_PIXELS
-            if segs is None:
-                broken.append(i)                                   # marker count does not match: host decoder
-                parts.append(rec)
-                owner.append(np.full(1, i))
-                nd += 1
-                continue
-            s0, e0, mcu0, nmcu = (np.array(col, dtype=np.int64) for col in zip(*segs))
-            seg = np.repeat(rec, len(segs))
-            seg["kind"], seg["parent"], seg["out_slot"] = KIND_SEGMENT, nd, 0
-            seg["first_block"] = mcu0 * (1 if h.ncomp == 1 else h.hs * h.vs + 2)
-            seg["width"], seg["height"] = nmcu * 8 * h.hs, 8 * h.vs
-            seg["stream_off"], seg["stream_len"] = int(base[i]) + (s0 - h.scan_start), e0 - s0
-            parts += [rec, seg]
-            owner.append(np.full(1 + len(segs), i))
-            nd += 1 + len(segs)
+        # restart intervals: a pixels-only parent + one entropy segment per interval, all pointing into the one upload;
+        # the markers between them are found on the device (cama_jpeg_find_restarts)
+        dri = [i for i, h in enumerate(headers) if h.restart_interval]
+        if dri:
+            parents, segs, seg_owner, broken = self._restart_descriptors(L, stream_dev, stream_bytes, host_bytes, headers,
+                                                                         dri, base, lens, nd)
+            parts += [parents, segs]
+            owner += [np.asarray(dri), seg_owner]
+            nd += len(parents) + len(segs)
         if len(parts) == 1:
             imgs = parts[0]
         else:
@@ -530,15 +608,13 @@ class DeviceJpegDecoder:
         info = np.zeros(3, np.uint64)                      # cama_jpeg_plan_info: u64 scratch_bytes + 4 x u32
         _lib.check(self.lib.cama_jpeg_plan(imgs.ctypes.data, nd, stream_bytes, info.ctypes.data))
         scratch_bytes = int(info[0])
-        huff_dev, quant_dev = self._tables()               # (on the caller's stream: the lane waits for it below)
+        huff_dev, quant_dev = self._tables()               # (uploaded on the caller's stream when a new table set appeared)
+        st.wait_stream(cur)
         contiguous = slots == list(range(slots[0], slots[0] + n))
-        st = L["stream"]
-        st.wait_stream(cur)                                # `out`, the tables and earlier work of the caller
         with torch.cuda.stream(st):
             if L["scratch"] is None or L["scratch"].numel() < scratch_bytes:
                 L["scratch"] = None
                 L["scratch"] = torch.empty(scratch_bytes * 5 // 4, dtype=torch.uint8, device=self.device)
-            stream_dev = pinned_src.to(self.device, non_blocking=True)
             imgs_dev = torch.from_numpy(imgs.view(np.uint8).reshape(nd, -1)).to(self.device, non_blocking=True)
             status = torch.empty(nd, dtype=torch.int32, device=self.device)
             target = out[slots[0]:slots[0] + n] if contiguous else \

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 9
+#define CAMA_ABI_VERSION 10
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -402,6 +402,16 @@ size_t cama_jpeg_image_bytes(void);       /* sizeof(cama_jpeg_image), for bindin
 size_t cama_jpeg_huff_set_bytes(void);    /* bytes of one Huffman table set in device layout */
 int cama_jpeg_plan(cama_jpeg_image *imgs /* host, in/out */, int32_t n, uint64_t stream_bytes,
                    cama_jpeg_plan_info *info /* host, out */);
+/*
+ * Restart-interval files (DRI): the byte positions of every RSTn marker (0xFF 0xD0..0xD7) in the uploaded bytes
+ * [0, stream_bytes), found on the device before the descriptors exist (the reference's libjpeg walks them serially;
+ * a Python-side search was 0.18 ms per 1600x900 image).  positions [capacity] uint32 and count [1] uint32 are device
+ * memory; the list is UNORDERED, *count is the number of markers found even when it exceeds capacity (then only the
+ * first `capacity` reservations were stored).  Hits outside the scans (file headers inside an uploaded span) are the
+ * caller's to drop: it knows the scan ranges.  stream must be 16-byte aligned, stream_bytes < 2^32.
+ */
+int cama_jpeg_find_restarts(const uint8_t *stream, uint64_t stream_bytes, uint32_t *positions, uint32_t capacity,
+                            uint32_t *count, void *stream_handle);
 int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, const cama_jpeg_image *imgs /* host, planned */,
                      const cama_jpeg_image *imgs_dev, int32_t n, const void *huff_sets, int32_t n_huff_sets,
                      const uint16_t *quant_sets, int32_t n_quant_sets, uint8_t *out, uint64_t out_stride, int32_t bgr,

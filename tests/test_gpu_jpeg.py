@@ -68,6 +68,85 @@ def test_restart_intervals_decode_on_the_device(dec):
     assert np.array_equal(got[0], pillow_rgb(big)) and dec.stats["host_flagged"] == before["host_flagged"]
 
 
+def test_device_restart_marker_search_equals_numpy(dec):
+    """cama_jpeg_find_restarts == a numpy search for every 0xFF 0xD0..0xD7 pair: random bytes (1/256 of them 0xFF),
+    markers planted across the 16-byte thread, 1 KB wave and 4 KB workgroup boundaries and at both ends, ragged
+    lengths, and a capacity smaller than the number found (count still exact, nothing written past the capacity)."""
+    import torch
+    from cama_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 15, 16, 17, 4095, 4096, 4097, 123457, 3_000_001):
+        buf = rng.integers(0, 256, n, dtype=np.uint8)
+        for at in (0, 14, 15, 16, 1023, 1024, 4094, 4095, 4096, n - 2, n - 1):
+            if 0 <= at < n:
+                buf[at] = 0xFF
+                if at + 1 < n:
+                    buf[at + 1] = 0xD0 + (at & 7)
+        idx = np.flatnonzero(buf[:-1] == 0xFF)
+        want = idx[(buf[idx + 1] & 0xF8) == 0xD0]
+        dev = torch.from_numpy(buf).cuda()
+        for cap in (len(want) + 8, max(len(want) // 2, 1)):
+            out = torch.full((cap + 9,), -1, dtype=torch.int32, device="cuda")
+            _lib.check(L.cama_jpeg_find_restarts(dev.data_ptr(), n, out.data_ptr() + 4, cap, out.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream))
+            got = out.cpu().numpy()
+            assert got[0] == len(want), (n, cap)
+            stored = got[1:1 + min(cap, len(want))]
+            assert (got[1 + cap:] == -1).all()
+            if cap >= len(want):
+                assert np.array_equal(np.sort(stored), want), (n, cap)
+            else:
+                assert len(set(stored.tolist())) == cap and set(stored.tolist()) <= set(want.tolist())
+    assert L.cama_jpeg_find_restarts(dev.data_ptr() + 1, 100, out.data_ptr() + 4, 4, out.data_ptr(), 0) == -1   # alignment
+
+
+def test_restart_files_with_broken_marker_sequences_go_to_the_host(dec):
+    """A group of DRI files, staged in an arena (headers inside the uploaded span), four of them with a missing / out of
+    cycle / doubled / surplus RSTn: exactly those are handed to the host decoder, every image equals Pillow's decode."""
+    from cama_amd import jpeg as PJ
+    rng = np.random.default_rng(21)
+    files = []
+    for k in range(24):
+        img = synth_image(120, 200, "noise", seed=k)
+        img[:, :100] = synth_image(120, 100, "smooth")
+        kw = [dict(restart_marker_blocks=1), dict(restart_marker_blocks=7), dict(restart_marker_rows=1), {}][k % 4]
+        files.append(encode(img, quality=int(rng.integers(40, 98)), subsampling=k % 3, **kw))
+    broken = {}
+    for kind, j in (("missing", 1), ("cycle", 5), ("empty", 9), ("extra", 13)):
+        data, hd = bytearray(files[j]), PJ.parse_header(files[j])
+        segs = PJ.restart_segments(bytes(data), hd)
+        m = segs[1][1]
+        if kind == "missing":
+            data[m:m + 2] = b"\x12\x34"
+        elif kind == "cycle":
+            data[m + 1] = 0xD0 | ((data[m + 1] + 3) & 7)
+        elif kind == "empty":
+            data[m + 2:m + 2] = bytes((0xFF, 0xD0 | ((data[m + 1] + 1) & 7)))
+        else:
+            data[segs[-1][0] + 1:segs[-1][0] + 1] = b"\xff\xd3"
+        files[j] = bytes(data)
+        broken[j] = kind
+    want = []
+    for j, f in enumerate(files):
+        try:
+            want.append(pillow_rgb(f))
+        except Exception:
+            want.append(None)
+    assert all(w is not None for j, w in enumerate(want) if j not in broken)
+    for blobs in (dec.stage(files), files):
+        before = dict(dec.stats)
+        try:
+            got = dec.decode(blobs, bgr=False).cpu().numpy()
+        except Exception:
+            assert any(want[j] is None for j in broken)            # Pillow refused one of the damaged files
+            continue
+        assert dec.stats["host_flagged"] - before["host_flagged"] == len(broken), dec.stats
+        for j, w in enumerate(want):
+            if w is not None:
+                assert np.array_equal(got[j], w), (j, broken.get(j))
+
+
 def test_files_outside_the_device_scope_fall_back_to_the_host(dec):
     img = synth_image(64, 96, "smooth")
     cmyk = io.BytesIO()

@@ -67,6 +67,64 @@ def test_scope_checks():
     assert joined == ref_scan and all(ref_scan[b - h.scan_start] == 0xFF for (_, b, _, _) in segs[:-1])
 
 
+def _marker_positions(buf):
+    """What cama_jpeg_find_restarts returns (sorted): every 0xFF 0xD0..0xD7 pair."""
+    idx = np.flatnonzero(buf[:-1] == 0xFF)
+    return idx[(buf[idx + 1] & 0xF8) == 0xD0].astype(np.int64)
+
+
+def test_batched_restart_segmentation_equals_the_per_file_walk():
+    """segments_from_markers (the group-at-once route fed by the device's marker search) == restart_segments (the
+    per-file walk) on whole files laid end to end -- headers in between included, as in an arena upload -- and drops
+    exactly the scans whose markers are missing, out of cycle, or adjacent (empty interval)."""
+    rng = np.random.default_rng(11)
+    files = []
+    for (h, w) in [(64, 96), (203, 317), (33, 47), (120, 200)]:
+        img = synth_image(h, w, "noise", seed=h)
+        for sub in (0, 1, 2):
+            for kw in (dict(restart_marker_blocks=1), dict(restart_marker_blocks=7), dict(restart_marker_rows=1)):
+                files.append(encode(img, quality=int(rng.integers(30, 100)), subsampling=sub, **kw))
+    files.append(encode(synth_image(40, 40, "smooth"), restart_marker_blocks=10000))       # one interval, no marker
+    corrupt = {}
+    for kind, j in (("missing", 3), ("cycle", 8), ("empty", 14), ("extra", 20)):
+        data, hd = bytearray(files[j]), PJ.parse_header(files[j])
+        segs = PJ.restart_segments(bytes(data), hd)
+        m = segs[1][1]                                                # second marker
+        if kind == "missing":
+            data[m:m + 2] = b"\x12\x34"
+        elif kind == "cycle":
+            data[m + 1] = 0xD0 | ((data[m + 1] + 3) & 7)
+        elif kind == "empty":
+            data[m + 2:m + 2] = bytes((0xFF, 0xD0 | ((data[m + 1] + 1) & 7)))        # two markers back to back
+        else:
+            data[segs[-1][0] + 1:segs[-1][0] + 1] = b"\xff\xd3"                        # one marker too many
+        files[j] = bytes(data)
+        corrupt[j] = kind
+    headers = [PJ.parse_header(f) for f in files]
+    offs = np.concatenate([[0], np.cumsum([len(f) + 16 for f in files])[:-1]])
+    buf = np.zeros(int(offs[-1]) + len(files[-1]) + 16, np.uint8)
+    for o, f in zip(offs, files):
+        buf[o:o + len(f)] = np.frombuffer(f, np.uint8)
+    lo = np.array([o + h.scan_start for o, h in zip(offs, headers)], dtype=np.int64)
+    hi = np.array([o + h.scan_end for o, h in zip(offs, headers)], dtype=np.int64)
+    mcus = np.array([-(-h.width // (8 * h.hs)) * -(-h.height // (8 * h.vs)) for h in headers])
+    nseg = -(-mcus // np.array([h.restart_interval for h in headers]))
+    good = np.ones(len(files), bool)
+    g, ns, k, starts, ends = PJ.segments_from_markers(_marker_positions(buf), buf, lo, hi, nseg, good)
+    assert sorted(np.flatnonzero(~good).tolist()) == sorted(corrupt), (np.flatnonzero(~good), corrupt)
+    at = 0
+    for j, n in zip(g.tolist(), ns.tolist()):
+        want = PJ.restart_segments(files[j], headers[j])
+        assert want is not None and len(want) == n
+        assert [(int(a) - offs[j], int(b) - offs[j]) for a, b in zip(starts[at:at + n], ends[at:at + n])] == \
+            [(a, b) for a, b, _, _ in want], j
+        assert k[at:at + n].tolist() == list(range(n))
+        at += n
+    assert at == len(k)
+    for j in corrupt:                                                 # the per-file walk refuses them too
+        assert PJ.restart_segments(files[j], headers[j]) is None or corrupt[j] == "cycle", corrupt[j]
+
+
 def test_descriptor_layout_and_plan():
     L = _lib.lib()
     assert PJ.IMAGE_DTYPE.itemsize == L.cama_jpeg_image_bytes() == 176
