@@ -7,8 +7,8 @@
 // fp64 k-ordered FMA chains (see header: arithmetic contract)
 // ------------------------------------------------------------------------------------------
 typedef const double __attribute__((address_space(4))) kdouble;   // uniform loads from it are s_load (SGPR operands)
-__device__ __forceinline__ void affine3x4(const double *M, double x, double y, double z,
-                                          double &ox, double &oy, double &oz)
+template <typename P>
+__device__ __forceinline__ void affine3x4(P M, double x, double y, double z, double &ox, double &oy, double &oz)
 {
     double a;
     a = M[0] * x; a = __builtin_fma(M[1], y, a); a = __builtin_fma(M[2], z, a);  a = __builtin_fma(M[3], 1.0, a);  ox = a;
@@ -267,6 +267,73 @@ __global__ __launch_bounds__(BLOCK) void k_frames_emit(FrameArgs a)
 //   k_stamps_scatter   re-reads only the 8-byte stamps (no geometry) and moves them to their band-sorted places.
 constexpr int SEG = 64;                 // one segment = one wave's 64 vertices of one (frame, camera)
 
+// One wave's share (64 consecutive vertices) of a vertex block in one frame: chassis-frame point, crop flag, draw key.
+struct WaveVerts {
+    double cx, cy, cz;
+    uint32_t key;
+    bool in;
+    uint32_t cams;          // cameras that may see these 64 vertices (wave-uniform); 0 = nothing to do
+    uint32_t seg;           // segment index inside (frame, camera)
+};
+
+template <typename T>
+__device__ __forceinline__ WaveVerts load_wave_verts(const FrameArgs &a, const int64_t vblock, const int f, const uint64_t cams4)
+{
+    WaveVerts v{0.0, 0.0, 0.0, 0u, false, 0u, 0u};
+    // this wave's 16 camera bits (wave-uniform: kept in an SGPR)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    v.cams = (uint32_t)(cams4 >> (16u * wave)) & 0xffffu;
+    v.seg = (uint32_t)vblock * (BLOCK / SEG) + wave;
+    if (!v.cams) return v;
+    // world->chassis + crop FIRST, with the frame's matrix read through wave-uniform (scalar) loads: on site-sized
+    // maps ~95 % of the waves end here
+    const double *w2c = a.w2c + (size_t)f * 16;
+    const int64_t i = vblock * BLOCK + threadIdx.x;
+    if (i < a.N) {
+        const double x = (double)static_cast<const T *>(a.x)[i], y = (double)static_cast<const T *>(a.y)[i],
+                     z = (double)static_cast<const T *>(a.z)[i];
+        affine3x4(w2c, x, y, z, v.cx, v.cy, v.cz);
+        v.in = in_crop(a.crop, v.cx, v.cy, v.cz);
+        // draw index << 1 | colour.  Spatially re-ordered maps carry it per vertex (a.key), otherwise it is the
+        // storage index itself
+        v.key = a.key ? a.key[i] : (((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1));
+    }
+    // whole wave outside the crop box: done (its segments stay empty: the count table was zeroed)
+    if (!__ballot(v.in)) v.cams = 0;
+    return v;
+}
+
+// The wave's stamps of camera c (uv = packed truncated pixel or 0xffffffff): drop same-pixel predecessors, compact into the
+// wave's segment, count, add the bands to the LDS histogram.
+__device__ __forceinline__ void emit_wave_stamps(const FrameArgs &a, const int f, const int c, const WaveVerts &v,
+                                                 const uint32_t uv, uint32_t *s_cnt)
+{
+    const uint32_t lane = __lane_id();
+    // A disc is invisible if a LATER point (higher draw index) stamps the very same pixel (same footprint).  The
+    // next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most far-range stamps collapse
+    // here, exactly, before they cost HBM or LDS traffic.  (executed by every lane: shuffles)
+    const uint32_t uv_next = __shfl_down(uv, 1, 64);
+    const uint32_t key_next = __shfl_down(v.key, 1, 64);
+    const bool covered = (lane != 63u) && (uv_next == uv) && (key_next > v.key);
+    const bool keep = (uv != 0xffffffffu) && !covered;
+    const uint64_t m = __ballot(keep);
+    if (!m) return;                     // wave-uniform
+    const size_t fcseg = ((size_t)f * a.C + c) * a.nseg + v.seg;
+    if (keep) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        a.stamps0[fcseg * SEG + rank] = make_uint2(uv, v.key);
+        // band histogram: per-lane LDS atomics (counting the wave's stamps per distinct band by ballot first was
+        // measured slower on the dense map, 475 -> 527 us: same-address ds_add is cheaper than the leader loop)
+        const int vi = (int)(uv >> 16);
+        const int b0 = max(vi - a.radius, 0) >> a.band_shift;
+        const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;       // b1 <= b0 + 1 (host checks 2r <= R)
+        const uint32_t l0 = (uint32_t)(c * a.NB + b0);
+        atomicAdd(&s_cnt[l0], 1u);
+        if (b1 != b0) atomicAdd(&s_cnt[l0 + 1], 1u);
+    }
+    if (lane == 0u) a.seg_cnt[fcseg] = (uint8_t)__popcll(m);
+}
+
 // Vertex block `vblock` of frame f: every wave projects its 64 vertices, compacts the surviving stamps into its segments
 // and adds their bands to the workgroup's LDS histogram s_cnt [C*NB] (zeroed by the caller).  No barrier inside: the
 // waves of a workgroup run through their blocks independently; the caller flushes s_cnt after a barrier.
@@ -274,81 +341,25 @@ template <typename T>
 __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t vblock, const int f, const uint64_t cams4,
                                               uint32_t *s_cnt)
 {
-    // this wave's 16 camera bits (wave-uniform: kept in an SGPR)
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t cams = (uint32_t)(cams4 >> (16u * wave)) & 0xffffu;
-    if (!cams) return;
-    // world->chassis + crop FIRST, with the frame's matrix read through wave-uniform (scalar) loads: on site-sized
-    // maps ~95 % of the waves end here
-    const double *w2c = a.w2c + (size_t)f * 16;
-    const int64_t i = vblock * BLOCK + threadIdx.x;
-    double cx = 0, cy = 0, cz = 0;
-    bool in = false;
-    uint32_t key = 0;
-    if (i < a.N) {
-        const double x = (double)static_cast<const T *>(a.x)[i], y = (double)static_cast<const T *>(a.y)[i],
-                     z = (double)static_cast<const T *>(a.z)[i];
-        affine3x4(w2c, x, y, z, cx, cy, cz);
-        in = in_crop(a.crop, cx, cy, cz);
-        // draw index << 1 | colour.  Spatially re-ordered maps carry it per vertex (a.key), otherwise it is the
-        // storage index itself
-        key = a.key ? a.key[i] : (((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1));
-    }
-    // whole wave outside the crop box: done (its segments stay empty: the count table was zeroed)
-    if (!__ballot(in)) return;
-
+    const WaveVerts v = load_wave_verts<T>(a, vblock, f, cams4);
+    if (!v.cams) return;
     const double Wd = (double)a.W, Hd = (double)a.H;
-    const uint32_t seg = (uint32_t)vblock * (BLOCK / SEG) + (threadIdx.x >> 6);
-    const uint32_t lane = __lane_id();
-#ifdef ABL_PROJ_NO_OUT
-    uint32_t sink = 0;
-#endif
 #ifndef ABL_PROJ_NO_CAMS
-    for (int c = 0; c < a.C; ++c) {
-        if (!((cams >> c) & 1u)) continue;                               // wave-uniform: no vertex of the block in view
+    // only the cameras the wave's mask lets through (wave-uniform scalar loop: the kernel issues as many SALU as VALU
+    // instructions, PMC: profiles/r02_project_dense1e6_pmc_sq.csv)
+    for (uint32_t todo = v.cams & ((1u << a.C) - 1u); todo; todo &= todo - 1u) {
+        const int c = __builtin_ctz(todo);
         uint32_t uv = 0xffffffffu;      // packed truncated pixel, or "not visible"
-        if (in) {
+        if (v.in) {
             uint32_t packed;
             // the camera's 21 doubles through wave-uniform scalar loads (constant address space): read as LDS
             // broadcasts they were ~126 ds_read_b64 per lane and made dense maps LDS-issue bound
-            if (visible_pixel<kdouble *>((kdouble *)(a.c2cam + (size_t)c * 16), (kdouble *)(a.K + (size_t)c * 9), cx, cy,
-                                         cz, Wd, Hd, packed))
+            if (visible_pixel<kdouble *>((kdouble *)(a.c2cam + (size_t)c * 16), (kdouble *)(a.K + (size_t)c * 9), v.cx,
+                                         v.cy, v.cz, Wd, Hd, packed))
                 uv = packed;
         }
-#ifdef ABL_PROJ_NO_OUT
-        sink ^= uv;
-        continue;
-#endif
-        // A disc is invisible if a LATER point (higher draw index) stamps the very same pixel (same footprint).  The
-        // next lane is the next vertex of the polyline, so on dense maps (1 cm spacing) most far-range stamps collapse
-        // here, exactly, before they cost HBM or LDS traffic.  (executed by every lane: shuffles)
-        const uint32_t uv_next = __shfl_down(uv, 1, 64);
-        const uint32_t key_next = __shfl_down(key, 1, 64);
-        const bool covered = (lane != 63u) && (uv_next == uv) && (key_next > key);
-        const bool keep = (uv != 0xffffffffu) && !covered;
-        const uint64_t m = __ballot(keep);
-        if (m) {                        // wave-uniform
-            const size_t fcseg = ((size_t)f * a.C + c) * a.nseg + seg;
-            const int vi = (int)(uv >> 16);
-            const int b0 = max(vi - a.radius, 0) >> a.band_shift;
-            const int b1 = min(vi + a.radius, a.H - 1) >> a.band_shift;       // b1 <= b0 + 1 (host checks 2r <= R)
-            if (keep) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                a.stamps0[fcseg * SEG + rank] = make_uint2(uv, key);
-            }
-            if (lane == 0u) a.seg_cnt[fcseg] = (uint8_t)__popcll(m);
-            // band histogram: per-lane LDS atomics (counting the wave's stamps per distinct band by ballot first was
-            // measured slower on the dense map, 475 -> 527 us: same-address ds_add is cheaper than the leader loop)
-            if (keep) {
-                const uint32_t l0 = (uint32_t)(c * a.NB + b0);
-                atomicAdd(&s_cnt[l0], 1u);
-                if (b1 != b0) atomicAdd(&s_cnt[l0 + 1], 1u);
-            }
-        }
+        emit_wave_stamps(a, f, c, v, uv, s_cnt);
     }
-#endif
-#ifdef ABL_PROJ_NO_OUT
-    if (sink == 0x12345678u) a.seg_cnt[0] = 1;
 #endif
 }
 
@@ -380,12 +391,14 @@ __global__ __launch_bounds__(BLOCK) void k_frames_project(FrameArgs a, const int
     const int64_t vb0 = (int64_t)blockIdx.x * vb_per_wg;
     if (vb0 * BLOCK >= a.N) return;
     hist_clear(a, s_hist);
+    // with the map's block AABBs (cama_map_bounds -> k_block_cameras) a block outside the crop box or every frustum is
+    // not even read; the others know, per wave, which cameras can see them at all
+    const uint64_t *cm = a.cam_mask ? a.cam_mask + (size_t)f * a.vblocks : nullptr;
+    // (two blocks per iteration -- two independent fp64 chains per lane -- was measured: 266 -> 280 us, no gain from ILP)
     for (int b = 0; b < vb_per_wg; ++b) {
         const int64_t vb = vb0 + b;
         if (vb * BLOCK >= a.N) break;
-        // with the map's block AABBs (cama_map_bounds -> k_block_cameras) a block outside the crop box or every frustum
-        // is not even read; the others know which cameras can see them at all
-        const uint64_t cams = a.cam_mask ? a.cam_mask[(size_t)f * a.vblocks + (size_t)vb] : ~0ull;   // scalar load
+        const uint64_t cams = cm ? cm[vb] : ~0ull;                           // scalar load
         if (cams) project_block<T>(a, vb, f, cams, s_hist);
     }
     hist_flush(a, f, s_hist);

@@ -375,7 +375,7 @@ def test_spatially_sorted_map_renders_identically(engine):
 
 
 def test_block_bounds_match_numpy(engine):
-    """cama_map_bounds: per-256-vertex AABBs, ragged tail, NaNs ignored, all-NaN block = empty box."""
+    """cama_map_bounds: per-wave (cama_map_bounds_block() = 64 vertices) AABBs, ragged tail, NaNs ignored, all-NaN block = empty box."""
     import torch
     from cama_amd import _lib
     L = _lib.lib()

@@ -1,0 +1,15 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+ulimit -c 0
+O=$PWD/gpurun_out
+R=$PWD
+timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fuzz.py tests/test_gpu_configs.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -2
+for mode in "" "--no-pipeline"; do
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_pp -o run -- python $R/bench.py --verts 1000000 --steps 10 --warmup 2 --cpu-seconds 0 $mode > $O/r02_pp.json 2>$O/r02_pp.err)
+    echo "== $mode $(python -c "import json;d=json.loads([l for l in open('$O/r02_pp.json') if l.startswith('{')][0]);print(round(d['value']), d['ms_per_step'])")"
+    grep -h "k_frames_project\|k_stamps_scatter\|k_overlay\|k_block_cameras" $O/r02_pp/run_kernel_stats.csv | python -c "
+import sys,csv
+for r in csv.reader(sys.stdin): print('  ', r[0].split(chr(40))[0][-45:], r[1], round(float(r[3])/1e3,1))"
+done
+for m in lanes random site; do python bench.py --verts 1000000 --map $m --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | python -c "import json,sys;d=json.loads([l for l in sys.stdin if l.startswith('{')][0]);print('$m', round(d['value']), d['ms_per_step'])"; done

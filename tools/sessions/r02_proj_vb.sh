@@ -16,3 +16,7 @@ done
 for m in random site; do env python bench.py --verts 1000000 --map $m --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | python -c "import json,sys;d=json.loads([l for l in sys.stdin if l.startswith('{')][0]);print('$m', round(d['value']), d['ms_per_step'])"; done
 python bench.py --verts 1000000 --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | python -c "import json,sys;d=json.loads([l for l in sys.stdin if l.startswith('{')][0]);print('dense', round(d['value']), d['ms_per_step'])"
 python bench.py --cpu-seconds 0 2>/dev/null | python -c "import json,sys;d=json.loads([l for l in sys.stdin if l.startswith('{')][0]);print('headline', round(d['value']), d['ms_per_step'], d['hash_check']['verified'])"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_proj_alone -o run -- python $R/bench.py --verts 1000000 --steps 10 --warmup 2 --cpu-seconds 0 --no-pipeline > /dev/null 2>&1)
+echo "== standalone"; grep -h "k_frames_project\|k_stamps_scatter\|k_overlay\|k_block_cameras" $O/r02_proj_alone/run_kernel_stats.csv | python -c "
+import sys,csv
+for r in csv.reader(sys.stdin): print('  ', r[0].split(chr(40))[0][-45:], r[1], round(float(r[3])/1e3,1))"
