@@ -85,6 +85,28 @@ __device__ __forceinline__ void stage_cameras(double *s_cam, const double *c2cam
 // ------------------------------------------------------------------------------------------
 // API kernels (materialise coordinates)
 // ------------------------------------------------------------------------------------------
+// A workgroup's BLOCK points are 3 * BLOCK consecutive values of an [n, 3] array: moved with unit-stride loads / stores
+// through LDS (a thread reading xyz[3 i], xyz[3 i + 1], xyz[3 i + 2] itself issues three stride-3 accesses).
+template <typename T>
+__device__ __forceinline__ void stage_points_in(const T *__restrict__ pts, int64_t i0, int64_t n, double *s_pts)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int64_t g = 3 * i0 + k * BLOCK + threadIdx.x;
+        if (g < 3 * n) s_pts[k * BLOCK + threadIdx.x] = (double)pts[g];
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void stage_points_out(double *__restrict__ out, int64_t i0, int64_t n, const double *s_pts)
+{
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int64_t g = 3 * i0 + k * BLOCK + threadIdx.x;
+        if (g < 3 * n) out[g] = s_pts[k * BLOCK + threadIdx.x];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_transform_points(const T *__restrict__ xyz, int64_t N,
                                                             const double *__restrict__ Tm, Crop crop,
@@ -92,26 +114,29 @@ __global__ __launch_bounds__(BLOCK) void k_transform_points(const T *__restrict_
                                                             uint8_t *__restrict__ mask)
 {
     __shared__ double s_m[12];
+    __shared__ double s_pts[3 * BLOCK];
     const int f = blockIdx.y;
     if (threadIdx.x < 12) s_m[threadIdx.x] = Tm[(size_t)f * 16 + threadIdx.x];
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= N) return;
-    const double x = (double)xyz[3 * i], y = (double)xyz[3 * i + 1], z = (double)xyz[3 * i + 2];
-    double ox, oy, oz;
-    affine3x4(s_m, x, y, z, ox, oy, oz);
-    if (out) {
-        double *o = out + ((size_t)f * N + i) * 3;
-        o[0] = ox; o[1] = oy; o[2] = oz;
+    const int64_t i0 = (int64_t)blockIdx.x * BLOCK, i = i0 + threadIdx.x;
+    stage_points_in(xyz, i0, N, s_pts);
+    double ox = 0, oy = 0, oz = 0;
+    if (i < N) {
+        affine3x4((const double *)s_m, s_pts[3 * threadIdx.x], s_pts[3 * threadIdx.x + 1], s_pts[3 * threadIdx.x + 2], ox, oy, oz);
+        if (mask) mask[(size_t)f * N + i] = has_crop ? (uint8_t)in_crop(crop, ox, oy, oz) : (uint8_t)1;
     }
-    if (mask) mask[(size_t)f * N + i] = has_crop ? (uint8_t)in_crop(crop, ox, oy, oz) : (uint8_t)1;
+    if (out) {                                              // (uniform; every thread rewrites the three values it read)
+        s_pts[3 * threadIdx.x] = ox; s_pts[3 * threadIdx.x + 1] = oy; s_pts[3 * threadIdx.x + 2] = oz;
+        stage_points_out(out + (size_t)f * N * 3, i0, N, s_pts);
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_crop_points(const double *__restrict__ pts, int64_t n, Crop crop,
                                                        uint8_t *__restrict__ mask)
 {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) mask[i] = (uint8_t)in_crop(crop, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    __shared__ double s_pts[3 * BLOCK];
+    const int64_t i0 = (int64_t)blockIdx.x * BLOCK, i = i0 + threadIdx.x;
+    stage_points_in(pts, i0, n, s_pts);
+    if (i < n) mask[i] = (uint8_t)in_crop(crop, s_pts[3 * threadIdx.x], s_pts[3 * threadIdx.x + 1], s_pts[3 * threadIdx.x + 2]);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_project_points(const double *__restrict__ pts, int64_t n,
@@ -120,11 +145,12 @@ __global__ __launch_bounds__(BLOCK) void k_project_points(const double *__restri
                                                           double *__restrict__ vu, uint8_t *__restrict__ vis)
 {
     __shared__ double s_cam[CAMA_MAX_CAMERAS * CAM_STRIDE];
+    __shared__ double s_pts[3 * BLOCK];
     stage_cameras(s_cam, c2cam, K, C);
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * BLOCK, i = i0 + threadIdx.x;
+    stage_points_in(pts, i0, n, s_pts);
     if (i >= n) return;
-    const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    const double x = s_pts[3 * threadIdx.x], y = s_pts[3 * threadIdx.x + 1], z = s_pts[3 * threadIdx.x + 2];
     const double Wd = (double)W, Hd = (double)H;
     for (int c = 0; c < C; ++c) {
         const double *m = s_cam + c * CAM_STRIDE;
@@ -141,30 +167,8 @@ __global__ __launch_bounds__(BLOCK) void k_project_points(const double *__restri
 // fused per-frame kernel
 // ------------------------------------------------------------------------------------------
 
-// Conservative "no vertex of this block can be inside the crop box" test on the block's world-space AABB
-// {xlo,xhi,ylo,yhi,zlo,zhi}: the chassis-frame extent of the box along each crop axis is centre +- sum|m_k|*half,
-// widened by a margin 7 orders above fp64 rounding, so a block is skipped only when in_crop() is false for every
-// vertex in it -- the result is bit-identical with and without the cull.  Every comparison is false on NaN/inf, i.e.
-// "not culled".
-__device__ __forceinline__ bool block_outside_crop(const double *m, const double *b, const Crop &crop)
-{
-    const double mx = 0.5 * (b[0] + b[1]), my = 0.5 * (b[2] + b[3]), mz = 0.5 * (b[4] + b[5]);
-    const double ex = 0.5 * (b[1] - b[0]), ey = 0.5 * (b[3] - b[2]), ez = 0.5 * (b[5] - b[4]);
-    bool out = false;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const double c0 = m[4 * r], c1 = m[4 * r + 1], c2 = m[4 * r + 2], c3 = m[4 * r + 3];
-        const double mid = c0 * mx + c1 * my + c2 * mz + c3;
-        const double rad = fabs(c0) * ex + fabs(c1) * ey + fabs(c2) * ez;
-        const double mag = fabs(c0 * mx) + fabs(c1 * my) + fabs(c2 * mz) + fabs(c3) + rad;
-        const double margin = 1e-6 + 1e-9 * mag;
-        out |= (mid + rad + margin < crop.v[2 * r]) | (mid - rad - margin > crop.v[2 * r + 1]);
-    }
-    return out;
-}
-
-// Per-block AABB of the vertex buffer (block = the BLOCK vertices one k_frames_bin workgroup owns).  NaN coordinates
-// are ignored by fmin/fmax (such a vertex is never inside the crop box); an all-NaN block yields an empty box.
+// AABB of every 64 consecutive vertices (= what one wave of k_frames_project owns; cama_map_bounds).  NaN coordinates
+// are ignored by fmin/fmax (such a vertex is never inside the crop box); an all-NaN run yields an empty box.
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_block_bounds(const void *x, const void *y, const void *z, int64_t N,
                                                         double *__restrict__ bounds)
@@ -491,7 +495,8 @@ __global__ __launch_bounds__(BLOCK) void k_stamps_scatter(FrameArgs a)
 // Which cameras can a vertex block reach?  One THREAD per (box, frame), one box per WAVE of a vertex block (64
 // consecutive vertices: on the dense 1e6-vertex lane map a 256-vertex box left 2.14 cameras per block where 0.98 have a
 // visible vertex -- close to the car a 2.5 m box spans two or three frusta): each world AABB becomes a
-// conservative chassis-frame box (centre +- sum |m_k| * half extent, as in block_outside_crop), clipped to the crop box
+// conservative chassis-frame box (centre +- sum |m_k| * half extent, widened by a margin 7 orders above fp64 rounding),
+// clipped to the crop box
 // (vertices outside it are dropped before projection), and that box is tested against the five half-spaces every visible
 // point satisfies in homogeneous image coordinates h = K (R p + t):
 //     h2 > 0,   h0 >= 0,   h0 - W h2 < 0,   h1 >= 0,   h1 - H h2 < 0

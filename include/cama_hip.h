@@ -112,11 +112,11 @@ int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz
  *   draw_key   NULL, or [N] uint32 = (draw index << 1) | colour for vertex buffers stored in another order than
  *              they are drawn (e.g. spatially sorted): "last writer wins" follows the draw index, not storage
  *              order; colour_id is ignored when draw_key is given
- *   block_bounds NULL, or the map's per-block AABBs from cama_map_bounds().  A pre-pass then decides per (vertex block,
- *              frame) which cameras can see the block at all (conservative box-vs-frustum and box-vs-crop tests): blocks
- *              outside the crop box are skipped without reading their vertices, and for the others the fp64 projection
- *              chain runs only for the cameras that may see them (dense lane maps: 1-2 of 6).  Conservative, so the
- *              output is bit-identical with and without it
+ *   block_bounds NULL, or the map's AABBs (one per cama_map_bounds_block() = 64 consecutive vertices, what one wave
+ *              projects) from cama_map_bounds().  A pre-pass then decides per (box, frame) which cameras can see it at all
+ *              (conservative box-vs-frustum and box-vs-crop tests): vertices outside the crop box are skipped without
+ *              being read, and for the others the fp64 projection chain runs only for the cameras that may see them
+ *              (dense lane maps: 1.1 of 6 per wave).  Conservative, so the output is bit-identical with and without it
  *   flags      0, or CAMA_BIN_WORKLIST (needs block_bounds): the surviving (block, frame) items go through work lists walked
  *              by persistent workgroups instead of one workgroup per item -- for site-sized maps, where ~95 % of the
  *              blocks are outside the crop box on any frame
@@ -135,7 +135,7 @@ size_t cama_render_scratch_bytes(int64_t N, int32_t F, int32_t C, int32_t H, int
 /*
  * Spatial index of a static map for the crop step (MapManager.crop_3d_instance_maps, cama/reproject.py:118-131, which
  * the reference evaluates for every vertex of the site map on every frame): bounds[b] = {xlo,xhi,ylo,yhi,zlo,zhi} of
- * vertices [b*B, (b+1)*B), B = cama_map_bounds_block(); bounds is device double[ceil(N/B)*6].  Computed once per
+ * vertices [b*B, (b+1)*B), B = cama_map_bounds_block() (64); bounds is device double[ceil(N/B)*6].  Computed once per
  * map (or per spatially sorted copy), passed as `block_bounds` to the render entries.
  */
 int cama_map_bounds_block(void);

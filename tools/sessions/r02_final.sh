@@ -26,6 +26,16 @@ CAMA_BENCH_SHARE_GPU=1 CAMA_BENCH_BACKEND=gloo timeout 1200 python -m torch.dist
 (cd /tmp && timeout 300 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/${T}_raw_pmc_write -- python $R/bench.py --raw-frames --height 540 --width 960 --steps 4 --warmup 1 $B --no-verify > /dev/null 2>&1)
 timeout 300 python tools/jpeg_probe.py --batch 240 --reps 10 > $O/${T}_jpeg_probe.txt 2>&1
 timeout 300 python tools/jpeg_probe.py --batch 6 --reps 20 >> $O/${T}_jpeg_probe.txt 2>&1
+timeout 300 python tools/jpeg_probe.py --batch 240 --reps 10 --restart-rows 1 2>&1 | grep -v amdgpu.ids > $O/${T}_jpeg_probe_dri.txt
+# dense 1e6-vertex map: the binning chain on its own (--no-pipeline: nothing runs beside it), kernel stats + SQ counters
+(cd /tmp && timeout 300 rocprofv3 --output-format csv --kernel-trace --stats -d $O/${T}_dense_alone -o run -- python $R/bench.py --verts 1000000 --steps 10 --warmup 2 $B --no-pipeline > /dev/null 2>&1)
+cp $O/${T}_dense_alone/run_kernel_stats.csv $O/${T}_dense1e6_standalone_kernel_stats.csv
+i=0
+for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
+  i=$((i+1))
+  (cd /tmp && timeout 300 rocprofv3 --output-format csv --kernel-trace --pmc $PMC -d $O/${T}_dense_pmc_$i -- python $R/bench.py --verts 1000000 --steps 3 --warmup 1 $B --no-pipeline > /dev/null 2>&1)
+  python tools/pmc_summary.py $O/${T}_dense_pmc_$i k_frames_project k_stamps_scatter k_block_cameras k_overlay
+done > $O/${T}_project_dense1e6_pmc_sq.csv
 CAMA_VIDEO_SINK=null timeout 600 python tools/demo_loop_probe.py --frames 120 > $O/${T}_demo_loop.txt 2>&1
 timeout 300 python tools/clip_from_jpeg_probe.py > $O/${T}_clip_from_jpeg.txt 2>&1
 for f in $O/${T}_bench_*.json; do echo "== $f"; python - "$f" <<'PY'
