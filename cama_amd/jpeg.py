@@ -339,7 +339,10 @@ class DeviceJpegDecoder:
     """Batch decoder bound to one GPU.  decode(list of JPEG byte strings) -> uint8 tensor [n, H, W, 3] on the device
     (all images of a batch must share one size; BGR by default = cv2.imread's order)."""
 
-    def __init__(self, device, lanes=4, min_group=24):
+    # decode workgroup: 256 subsequences of 1024 bits (jpeg_kernels.hpp: JPEG_WG, JPEG_SUB_BITS), 47 KB of LDS = 3 per CU
+    WG_BYTES, WGS_PER_CU = 256 * 1024 // 8, 3
+
+    def __init__(self, device, lanes=None, min_group=8):
         import torch
         self.lib = _lib.lib()
         if not torch.cuda.is_available():
@@ -350,10 +353,15 @@ class DeviceJpegDecoder:
         self._huff_index, self._huff_host, self._huff_dev = {}, [], None
         self._quant_index, self._quant_host, self._quant_dev = {}, [], None
         # The decode kernels last as long as their slowest workgroup (the longest re-synchronisation chain), not as
-        # long as their work: independent groups of images on separate streams overlap almost perfectly, so a batch
-        # is split over up to `lanes` streams, each with its own staging buffer and scratch.
-        self.lanes = int(lanes)
+        # long as their work, so a batch is split into groups of images on separate streams ("lanes", each with its own
+        # staging buffer and scratch) whose kernels run side by side.  How many: a group whose entropy stages need about
+        # HALF of the chip's decode-workgroup slots (3 per CU: LDS) lets two groups tile the chip while the next ones
+        # upload -- 240 photo-like 1600x900 frames (10 workgroups each): 7 groups 42-43 k images/s, 4 groups 36 k, 8 groups
+        # 37 k, 1 group 33 k (profiles/r02_jpeg_lanes.txt).  `lanes` fixes the number of groups instead (A/B).
+        self.lanes = None if lanes is None else int(lanes)
         self.min_group = int(min_group)
+        self.group_wgs = self.WGS_PER_CU * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
+        self.max_lanes = 16
         self._lane = []
         self._templates = {}
         self.stats = {"device": 0, "host_unsupported": 0, "host_flagged": 0}
@@ -461,8 +469,17 @@ class DeviceJpegDecoder:
             assert tuple(out.shape) == (n, H, W, 3) and out.is_contiguous() and out.dtype == torch.uint8
             tickets = []
             if ok:
-                groups = max(1, min(self.lanes, len(ok) // self.min_group))
-                bounds = [len(ok) * g // groups for g in range(groups + 1)]
+                # decode workgroups per image (from the stuffed length: a slight over-estimate), groups of ~group_wgs
+                wgs = np.array([-(-(headers[i].scan_end - headers[i].scan_start) // self.WG_BYTES) for i in ok])
+                cum = np.concatenate([[0], np.cumsum(wgs)])
+                if self.lanes is not None:
+                    groups = max(1, min(self.lanes, len(ok) // self.min_group))
+                else:
+                    groups = max(1, min(self.max_lanes, len(ok) // self.min_group, -(-int(cum[-1]) // self.group_wgs)))
+                # equal shares of the workgroups, not of the images
+                bounds = [0] + [int(np.searchsorted(cum, cum[-1] * g / groups, "left")) for g in range(1, groups)] + [len(ok)]
+                bounds = sorted(set(bounds))
+                groups = len(bounds) - 1
                 cur = torch.cuda.current_stream(self.device)
                 tickets = [self._submit([blobs[i] for i in ok[bounds[g]:bounds[g + 1]]],
                                         [headers[i] for i in ok[bounds[g]:bounds[g + 1]]], ok[bounds[g]:bounds[g + 1]],

@@ -66,6 +66,42 @@ def test_restart_intervals_decode_on_the_device(dec):
     big = encode(synth_image(900, 1600, "noise", seed=1), quality=90, restart_marker_rows=1)
     got = dec.decode([big], bgr=False).cpu().numpy()
     assert np.array_equal(got[0], pillow_rgb(big)) and dec.stats["host_flagged"] == before["host_flagged"]
+    # long intervals (a noise frame with a marker every 4 MCU rows: ~90 KB each, several decode workgroups per interval)
+    # mixed with short-interval and marker-free files
+    from cama_amd.jpeg import parse_header, restart_segments
+    long_iv = encode(synth_image(900, 1600, "noise", seed=2), quality=92, restart_marker_rows=4)
+    assert max(e - s for s, e, _, _ in restart_segments(long_iv, parse_header(long_iv))) > (1 << 16)
+    group = [long_iv, big, encode(synth_image(900, 1600, "smooth"), quality=85),
+             encode(synth_image(900, 1600, "edges"), quality=70, restart_marker_blocks=3, subsampling=0)]
+    got = dec.decode(group, bgr=False).cpu().numpy()
+    for k, b in enumerate(group):
+        assert np.array_equal(got[k], pillow_rgb(b)), k
+    assert dec.stats["host_flagged"] == before["host_flagged"]
+
+
+def test_damaged_restart_interval_is_flagged(dec):
+    """Bytes changed INSIDE one restart interval (markers intact): that interval ends with the wrong block count or an
+    inconsistent state, the device flags it, and the image is decoded again on the host -- the others stay on the device."""
+    from cama_amd.jpeg import parse_header, restart_segments
+    rng = np.random.default_rng(8)
+    files = [encode(synth_image(120, 200, "noise", seed=k), quality=90, restart_marker_rows=1, subsampling=k % 3) for k in range(6)]
+    data = bytearray(files[2])
+    segs = restart_segments(files[2], parse_header(files[2]))
+    s0, e0 = segs[3][0], segs[3][1]
+    for p in range(s0 + 4, min(e0 - 2, s0 + 40)):
+        b = int(rng.integers(0, 255))
+        data[p] = b if b != 0xFF else 0x7F                       # (no new markers, no new stuffing)
+    files[2] = bytes(data)
+    before = dict(dec.stats)
+    try:
+        got = dec.decode(files, bgr=False).cpu().numpy()
+    except Exception:
+        got = None                                               # Pillow may refuse the damaged file
+    assert dec.stats["host_flagged"] - before["host_flagged"] == 1, dec.stats
+    if got is not None:
+        for k, b in enumerate(files):
+            if k != 2:
+                assert np.array_equal(got[k], pillow_rgb(b)), k
 
 
 def test_device_restart_marker_search_equals_numpy(dec):
