@@ -11,6 +11,7 @@ interleaved scan, with or without restart intervals (every interval becomes its 
 by Pillow on the host and uploaded, so `decode()` always returns every image.
 """
 import io
+import os
 
 import numpy as np
 
@@ -360,7 +361,8 @@ class DeviceJpegDecoder:
         # 37 k, 1 group 33 k (profiles/r02_jpeg_lanes.txt).  `lanes` fixes the number of groups instead (A/B).
         self.lanes = None if lanes is None else int(lanes)
         self.min_group = int(min_group)
-        self.group_wgs = self.WGS_PER_CU * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
+        self.group_wgs = int(os.environ.get("CAMA_JPEG_GROUP_WGS", 0)) or \
+            self.WGS_PER_CU * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
         self.max_lanes = 16
         self._lane = []
         self._templates = {}
@@ -476,7 +478,8 @@ class DeviceJpegDecoder:
                     groups = max(1, min(self.lanes, len(ok) // self.min_group))
                 else:
                     groups = max(1, min(self.max_lanes, len(ok) // self.min_group, -(-int(cum[-1]) // self.group_wgs)))
-                # equal shares of the workgroups, not of the images
+                # equal shares of the workgroups, not of the images (filling every group to group_wgs and leaving a small
+                # last one measures the same)
                 bounds = [0] + [int(np.searchsorted(cum, cum[-1] * g / groups, "left")) for g in range(1, groups)] + [len(ok)]
                 bounds = sorted(set(bounds))
                 groups = len(bounds) - 1
