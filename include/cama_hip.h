@@ -361,7 +361,8 @@ int cama_profile_collect(double *total_ms /* host */, int32_t *launches /* host 
  * Scope: SOF0, 8 bit, 1 or 3 components in one interleaved scan, luma sampling 1x1 / 2x1 / 2x2 with 1x1 chroma,
  * restart intervals through per-interval descriptors.  Everything else is the caller's host fallback.
  *   cama_jpeg_plan    fills the derived descriptor fields and reports grid sizes and scratch bytes (host only)
- *   cama_jpeg_decode  imgs_dev = device copy of the PLANNED descriptors; out: image `out_slot` of height*width*3 bytes,
+ *   cama_jpeg_decode  stream: readable up to the next multiple of 4 bytes (it is read with aligned dword loads);
+ *                     imgs_dev = device copy of the PLANNED descriptors; out: image `out_slot` of height*width*3 bytes,
  *                     out_stride bytes apart, BGR (bgr != 0: OpenCV order) or RGB; status [n] int32 on the device:
  *                     0 ok, != 0 the stream did not decode consistently (corrupt or unsupported): use the host
  *                     decoder for that image

@@ -2,7 +2,9 @@
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 O=$PWD/gpurun_out
-for g in 300 330 350 370 380 384 400 440 500; do echo "group_wgs $g: $(CAMA_JPEG_GROUP_WGS=$g timeout 300 python tools/jpeg_probe.py --batch 240 2>&1 | grep '^photo: 315' | cut -c1-75)"; done
-echo "equal 384: $(CAMA_JPEG_SPLIT=equal timeout 300 python tools/jpeg_probe.py --batch 240 2>&1 | grep '^photo: 315' | cut -c1-75)"
-timeout 300 python tools/jpeg_probe.py --batch 240 2>&1 | grep '^noise: 1298' | cut -c1-75
+R=$PWD
 timeout 600 python -m pytest tests/test_gpu_jpeg.py -x -q 2>&1 | tail -2
+timeout 300 python tools/jpeg_probe.py --batch 240 --reps 10 2>&1 | grep -v amdgpu.ids | cut -c1-100
+timeout 300 python tools/jpeg_probe.py --batch 240 --reps 10 --restart-rows 1 2>&1 | grep "^photo: 315" | cut -c1-100
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_jpeg_prof -o run -- python $R/tools/jpeg_probe.py --batch 240 > /dev/null 2>&1)
+head -12 $O/r02_jpeg_prof/run_kernel_stats.csv | cut -d, -f1-4 | cut -c1-120
