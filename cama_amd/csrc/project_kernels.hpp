@@ -348,6 +348,10 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
     const WaveVerts v = load_wave_verts<T>(a, vblock, f, cams4);
     if (!v.cams) return;
     const double Wd = (double)a.W, Hd = (double)a.H;
+    // -DABL_PROJ_NO_CAMS / -DABL_PROJ_NO_OUT: ablation builds behind profiles/r02_project_ablation.txt
+#ifdef ABL_PROJ_NO_OUT
+    uint32_t sink = 0;
+#endif
 #ifndef ABL_PROJ_NO_CAMS
     // only the cameras the wave's mask lets through (wave-uniform scalar loop: the kernel issues as many SALU as VALU
     // instructions, PMC: profiles/r02_project_dense1e6_pmc_sq.csv)
@@ -362,8 +366,15 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
                                          v.cy, v.cz, Wd, Hd, packed))
                 uv = packed;
         }
+#ifdef ABL_PROJ_NO_OUT
+        sink ^= uv;                     // (ablation: the chains run, nothing is emitted)
+#else
         emit_wave_stamps(a, f, c, v, uv, s_cnt);
+#endif
     }
+#endif
+#ifdef ABL_PROJ_NO_OUT
+    if (sink == 0x12345678u) a.seg_cnt[0] = 1;
 #endif
 }
 
