@@ -520,7 +520,6 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
 __global__ __launch_bounds__(JPEG_WG) void k_jpeg_write(JpegArgs a)
 {
     __shared__ JpegWgShared S;
-    __shared__ uint32_t s_scan[JPEG_WG];
     const int img = jpeg_find_image(a.imgs, a.n, blockIdx.x, false);
     const cama_jpeg_image &D = a.imgs[img];
     const uint32_t lw = blockIdx.x - D.wg0;
@@ -535,36 +534,37 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_write(JpegArgs a)
     const bool active = threadIdx.x <= last;
     const uint32_t lo = t * JPEG_SUB_BITS, hi = min(lo + JPEG_SUB_BITS, nbits);
     const size_t gsub = (size_t)D.wg0 * JPEG_WG + (size_t)lw * JPEG_WG + threadIdx.x;
-    // blocks completed before this workgroup, then before this subsequence
+    // blocks completed before this workgroup, then before this subsequence: a reduction and an exclusive scan over the
+    // workgroup, by wave shuffles + one LDS hop across the waves (thread 0 walking 256 LDS entries twice cost ~20 us of
+    // latency per workgroup)
     uint32_t before = 0;
     for (uint32_t w = threadIdx.x; w < lw; w += JPEG_WG) before += a.wg_total[D.wg0 + w];
     const uint32_t mine = active ? a.nb[gsub] : 0u;
-    s_scan[threadIdx.x] = before;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int k = 0; k < JPEG_WG; ++k) tot += s_scan[k];
-        S.nb[0] = tot;                                   // reuse: base of the workgroup
+    uint32_t red = before, incl = mine;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) red += __shfl_xor(red, off, 64);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += v;
     }
-    __syncthreads();
-    const uint32_t base = S.nb[0];
-    __syncthreads();
-    s_scan[threadIdx.x] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = base;
-        for (int k = 0; k < JPEG_WG; ++k) {
-            const uint32_t v = s_scan[k];
-            s_scan[k] = run;
-            run += v;
-        }
+    __shared__ uint32_t s_red[JPEG_WG / 64], s_inc[JPEG_WG / 64];
+    if ((threadIdx.x & 63) == 63) {
+        s_red[threadIdx.x >> 6] = red;
+        s_inc[threadIdx.x >> 6] = incl;
     }
-    __syncthreads();
+    __syncthreads();                                    // (also: the stream words and tables of jpeg_wg_setup)
+    uint32_t first_block = incl - mine;                 // exclusive prefix inside the wave ...
+#pragma unroll
+    for (int w = 0; w < JPEG_WG / 64; ++w) {
+        first_block += s_red[w];                         // ... + everything before the workgroup
+        if (w < (int)(threadIdx.x >> 6)) first_block += s_inc[w];   // ... + the waves before this one
+    }
     if (!active) return;
     JpegState s = (t == 0) ? JpegState{0u, 0u, 0u} : jpeg_unpack(a.E[gsub - 1]);
-    const uint32_t nb = jpeg_decode_span<true>(c, s, hi, a.coef + D.coef_off, s_scan[threadIdx.x], D.total_blocks);
+    const uint32_t nb = jpeg_decode_span<true>(c, s, hi, a.coef + D.coef_off, first_block, D.total_blocks);
     int bad = (jpeg_pack(s) != a.E[gsub]) || (nb != mine);
-    if (t == nsub_img - 1u && s_scan[threadIdx.x] + nb != D.total_blocks) bad |= 2;
+    if (t == nsub_img - 1u && first_block + nb != D.total_blocks) bad |= 2;
     if (bad) atomicOr(&a.status[img], bad);
 }
 
