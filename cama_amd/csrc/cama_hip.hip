@@ -761,7 +761,11 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     o.disc = disc; o.pal = make_palette(palette_bgr);
     o.H0 = H0; o.W0 = W0;
     const unsigned block = (items + 63u) & ~63u;
-    const size_t lds = (size_t)max_src_rows * W0 * 3 + (size_t)L.R * W * 4;
+    // the owner table of a stamped band goes INTO the staging area (behind the band's output rows) when that is big enough
+    const size_t staging_dw = (size_t)max_src_rows * W0 * 3 / 4, out_dw = (size_t)L.R * W * 3 / 4, owner_dw = (size_t)L.R * W;
+    const bool alias_owner = staging_dw >= out_dw + owner_dw && !getenv("CAMA_RAW35_NO_ALIAS");
+    const size_t owner_off = alias_owner ? out_dw : staging_dw;
+    const size_t lds = alias_owner ? staging_dw * 4 : (staging_dw + owner_dw) * 4;
     if (lds > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the 3:5 raw overlay's LDS", W);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -774,15 +778,15 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     if (ev0 && ev1) {
         hipExtLaunchKernelGGL(k_overlay_raw35, dim3(nblocks), dim3(block), (uint32_t)lds, s, ev0, ev1, 0u, o,
                               reinterpret_cast<const uint2 *>(vrows), reinterpret_cast<const int2 *>(band_rows), upr,
-                              max_src_rows);
+                              max_src_rows, (int)owner_off);
     } else if (g_overlay_stop_event) {
         hipExtLaunchKernelGGL(k_overlay_raw35, dim3(nblocks), dim3(block), (uint32_t)lds, s, nullptr, g_overlay_stop_event,
                               0u, o, reinterpret_cast<const uint2 *>(vrows), reinterpret_cast<const int2 *>(band_rows), upr,
-                              max_src_rows);
+                              max_src_rows, (int)owner_off);
         g_overlay_stop_event = nullptr;
     } else
         hipLaunchKernelGGL(k_overlay_raw35, dim3(nblocks), dim3(block), lds, s, o, reinterpret_cast<const uint2 *>(vrows),
-                           reinterpret_cast<const int2 *>(band_rows), upr, max_src_rows);
+                           reinterpret_cast<const int2 *>(band_rows), upr, max_src_rows, (int)owner_off);
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) g_prof.pending.emplace_back(ev0, ev1);
     return CAMA_OK;

@@ -68,9 +68,14 @@ __device__ __forceinline__ void raw35_unit(const uint32_t (&d0)[15], const uint3
     ((px[K] = raw35_pixel<K>(d0, d1, wt, wb)), ...);
 }
 
+// owner_off (dwords into the dynamic LDS) = where a stamped band's owner table lives: behind the staging area, or -- when
+// the staging area is big enough for the band's output rows AND the table (it is at 1600 -> 960: 9 600 >= 2 880 + 3 840
+// dwords) -- INSIDE it, right behind the output rows: the table is then built after every unit has read its taps, a
+// stamped band pays two more barriers and loses the overlap of its rasterisation with the source loads, and every
+// workgroup needs 38 KB of LDS instead of 54 KB: 4 instead of 3 workgroups per CU (0.260 -> 0.24x ms at N = 10^4).
 __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a, const uint2 *__restrict__ vrows,
                                                                    const int2 *__restrict__ band_rows, int upr,
-                                                                   int max_src_rows)
+                                                                   int max_src_rows, int owner_off)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     // same workgroup order as k_overlay: (frame, mosaic row of cameras, band, camera column)
@@ -92,7 +97,8 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     const uint32_t row_dwords = (uint32_t)W * 3u / 4u;                 // W % 48 == 0 (host-checked): multiple of 36
     const uint32_t src_row_dwords = (uint32_t)a.W0 * 3u / 4u;          // W0 * 3 % 16 == 0 (host-checked)
     uint32_t *s_stage = s_dyn;                                         // [max_src_rows * src_row_dwords], later the output
-    uint32_t *s_owner = s_dyn + (size_t)max_src_rows * src_row_dwords; // [R * W], stamped bands only
+    uint32_t *s_owner = s_dyn + owner_off;                             // [R * W], stamped bands only
+    const bool aliased = (uint32_t)owner_off < (uint32_t)max_src_rows * src_row_dwords;
 
     // the band's first stamp record before the source loads (VMEM returns in order; see k_overlay)
     const uint2 *st = a.stamps + (n ? (size_t)a.fc_base[fc] + a.bin_off[bin] : (size_t)0);
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
 #pragma unroll
     for (int j = 0; j < U; ++j) v[j] = OVERLAY_LOAD(g + min(threadIdx.x + j * blockDim.x, nsrc - 1u));
 
-    if (n) {                                                           // owner table: its own LDS region
+    if (n && !aliased) {                                               // owner table in its own LDS region
         uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
         const int n4 = (nrows * W + 3) >> 2;
         for (int j = threadIdx.x; j < n4; j += blockDim.x) o4[j] = make_uint4(0, 0, 0, 0);
@@ -140,6 +146,16 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     for (int k = 0; k < 15; ++k) d0[k] = p0[k];
 #pragma unroll
     for (int k = 0; k < 15; ++k) d1[k] = p1[k];
+    if (n && aliased) {                                                // (workgroup-uniform)
+        __syncthreads();                                               // every unit holds its taps: staging is dead
+        uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
+        const int n4 = (nrows * W + 3) >> 2;
+        for (int j = threadIdx.x; j < n4; j += blockDim.x) o4[j] = make_uint4(0, 0, 0, 0);
+        lds_barrier();
+        if (threadIdx.x < n) rasterise_one(s_owner, first, y0, nrows, W, a.disc);
+        rasterise_rest(s_owner, st, threadIdx.x + blockDim.x, blockDim.x, n, y0, nrows, W, a.disc);
+        __syncthreads();
+    }
     uint32_t px[12];
     raw35_unit(d0, d1, wt, wb, px, std::make_integer_sequence<int, 12>{});
     if (n) {
