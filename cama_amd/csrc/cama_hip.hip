@@ -761,11 +761,11 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     o.disc = disc; o.pal = make_palette(palette_bgr);
     o.H0 = H0; o.W0 = W0;
     const unsigned block = (items + 63u) & ~63u;
-    // the owner table of a stamped band goes INTO the staging area (behind the band's output rows) when that is big enough
-    const size_t staging_dw = (size_t)max_src_rows * W0 * 3 / 4, out_dw = (size_t)L.R * W * 3 / 4, owner_dw = (size_t)L.R * W;
-    const bool alias_owner = staging_dw >= out_dw + owner_dw && !getenv("CAMA_RAW35_NO_ALIAS");
-    const size_t owner_off = alias_owner ? out_dw : staging_dw;
-    const size_t lds = alias_owner ? staging_dw * 4 : (staging_dw + owner_dw) * 4;
+    // the owner table of a stamped band goes INTO the staging area, behind the band's output rows (raw35_kernels.hpp)
+    const size_t staging_dw = (size_t)max_src_rows * W0 * 3 / 4, owner_off = (size_t)L.R * W * 3 / 4, owner_dw = (size_t)L.R * W;
+    if (staging_dw < owner_off + owner_dw)
+        return fail(CAMA_EINVAL, "the plan's %d source rows leave no room for the owner table (W=%d, W0=%d)", max_src_rows, W, W0);
+    const size_t lds = staging_dw * 4;
     if (lds > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the 3:5 raw overlay's LDS", W);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

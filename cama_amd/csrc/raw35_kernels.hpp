@@ -68,11 +68,11 @@ __device__ __forceinline__ void raw35_unit(const uint32_t (&d0)[15], const uint3
     ((px[K] = raw35_pixel<K>(d0, d1, wt, wb)), ...);
 }
 
-// owner_off (dwords into the dynamic LDS) = where a stamped band's owner table lives: behind the staging area, or -- when
-// the staging area is big enough for the band's output rows AND the table (it is at 1600 -> 960: 9 600 >= 2 880 + 3 840
-// dwords) -- INSIDE it, right behind the output rows: the table is then built after every unit has read its taps, a
-// stamped band pays two more barriers and loses the overlap of its rasterisation with the source loads, and every
-// workgroup needs 38 KB of LDS instead of 54 KB: 4 instead of 3 workgroups per CU (0.260 -> 0.24x ms at N = 10^4).
+// A stamped band's owner table lives INSIDE the staging area, right behind the band's output rows (owner_off dwords; the
+// staging area is always big enough at a 3:5 scale: rows * 1.25 W >= R * 1.75 W dwords, host-checked): it is built after
+// every unit has read its taps, so a stamped band pays two more barriers and its rasterisation no longer overlaps the
+// source loads, but every workgroup needs 38 KB of LDS instead of 54 KB -- 4 instead of 3 per CU: 140.0 -> 145.5 k
+// frames/s at N = 10^4, 117.7 -> 123.5 k at N = 10^5 (same box).
 __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a, const uint2 *__restrict__ vrows,
                                                                    const int2 *__restrict__ band_rows, int upr,
                                                                    int max_src_rows, int owner_off)
@@ -98,7 +98,6 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     const uint32_t src_row_dwords = (uint32_t)a.W0 * 3u / 4u;          // W0 * 3 % 16 == 0 (host-checked)
     uint32_t *s_stage = s_dyn;                                         // [max_src_rows * src_row_dwords], later the output
     uint32_t *s_owner = s_dyn + owner_off;                             // [R * W], stamped bands only
-    const bool aliased = (uint32_t)owner_off < (uint32_t)max_src_rows * src_row_dwords;
 
     // the band's first stamp record before the source loads (VMEM returns in order; see k_overlay)
     const uint2 *st = a.stamps + (n ? (size_t)a.fc_base[fc] + a.bin_off[bin] : (size_t)0);
@@ -114,14 +113,6 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
 #pragma unroll
     for (int j = 0; j < U; ++j) v[j] = OVERLAY_LOAD(g + min(threadIdx.x + j * blockDim.x, nsrc - 1u));
 
-    if (n && !aliased) {                                               // owner table in its own LDS region
-        uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
-        const int n4 = (nrows * W + 3) >> 2;
-        for (int j = threadIdx.x; j < n4; j += blockDim.x) o4[j] = make_uint4(0, 0, 0, 0);
-        lds_barrier();
-        if (threadIdx.x < n) rasterise_one(s_owner, first, y0, nrows, W, a.disc);
-        rasterise_rest(s_owner, st, threadIdx.x + blockDim.x, blockDim.x, n, y0, nrows, W, a.disc);
-    }
     u32x4 *s16 = reinterpret_cast<u32x4 *>(s_stage);
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -146,7 +137,7 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     for (int k = 0; k < 15; ++k) d0[k] = p0[k];
 #pragma unroll
     for (int k = 0; k < 15; ++k) d1[k] = p1[k];
-    if (n && aliased) {                                                // (workgroup-uniform)
+    if (n) {                                                           // (workgroup-uniform)
         __syncthreads();                                               // every unit holds its taps: staging is dead
         uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
         const int n4 = (nrows * W + 3) >> 2;
@@ -184,9 +175,13 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
                      ((size_t)(c / cols) * a.H + y0) * a.mosaic_row_bytes + (size_t)(c % cols) * W * 3;
     const uint32_t cpr = row_dwords >> 2;                               // 16-byte chunks per destination row
     const uint32_t nchunks = (uint32_t)nrows * cpr;
+    uint32_t r = threadIdx.x / cpr, col = threadIdx.x - r * cpr;        // one division, then (row, chunk) advance by blockDim
+    const uint32_t dr = blockDim.x / cpr, dc = blockDim.x - dr * cpr;
     for (uint32_t idx = threadIdx.x; idx < nchunks; idx += blockDim.x) {
-        const uint32_t r = idx / cpr, col = idx - r * cpr;
         const u32x4 w = reinterpret_cast<const u32x4 *>(s_stage + r * row_dwords)[col];
         OVERLAY_STORE(w, reinterpret_cast<u32x4 *>(dcell + (size_t)r * a.mosaic_row_bytes) + col);
+        r += dr;
+        col += dc;
+        if (col >= cpr) { col -= cpr; ++r; }
     }
 }
