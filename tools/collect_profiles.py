@@ -21,8 +21,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def first(pattern):
-    hits = sorted(glob.glob(os.path.join(REPO, "gpurun_out", pattern)))
-    return hits[0] if hits else None
+    """The NEWEST match: gpurun merges every session's outputs into gpurun_out/, rocprofv3 names them by process id."""
+    hits = glob.glob(os.path.join(REPO, "gpurun_out", pattern))
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def counters(path, name):

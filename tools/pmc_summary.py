@@ -14,7 +14,8 @@ import sys
 def main():
     run = sys.argv[1]
     pats = sys.argv[2:] or ["k_"]
-    path = (glob.glob(os.path.join(run, "*", "*counter_collection.csv")) + glob.glob(os.path.join(run, "*counter_collection.csv")))[0]
+    path = max(glob.glob(os.path.join(run, "*", "*counter_collection.csv")) + glob.glob(os.path.join(run, "*counter_collection.csv")),
+               key=os.path.getmtime)                   # the newest run (gpurun merges sessions into one directory)
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
