@@ -50,9 +50,32 @@ def _read_into(blob, path):
         while got < blob.n:
             k = f.readinto(view[got:])
             if not k:
-                raise IOError(f"{path}: short read ({got} of {blob.n} bytes)")
+                break
             got += k
-    return blob, False
+        # the slice was sized from a directory scan: a file that changed since then is read again, whole, the plain way
+        if got == blob.n and not f.read(1):
+            return blob, False
+    return _read_jpeg_bytes_or_array(path)
+
+
+def _read_frame(items):
+    """The camera files of one frame, one after the other (one pool task per frame instead of one per file: the pool's
+    per-task cost on the submitting thread was the largest item of the main.py loop's host profile)."""
+    return [_read_into(blob, path) for blob, path in items]
+
+
+class _Part:
+    """Camera c's share of a _read_frame task, with the two Future methods the consumers use."""
+    __slots__ = ("fut", "c")
+
+    def __init__(self, fut, c):
+        self.fut, self.c = fut, c
+
+    def result(self):
+        return self.fut.result()[self.c]
+
+    def cancel(self):
+        return self.fut.cancel()
 
 
 def _decode_bytes(data):
@@ -185,9 +208,11 @@ class ClipFrameSource:
         self._pool = None
         # host decode: 12 threads peak (~500 images/s; the GIL beyond that).  Device decode: the workers only read
         # files, a few are enough (more just burn the container's CPU quota)
-        self._workers = workers or (4 if self.decoder == "device" else min(12, (os.cpu_count() or 4)))
+        self._workers = workers or int(os.environ.get("CAMA_READ_WORKERS", 0)) or \
+            (4 if self.decoder == "device" else min(12, (os.cpu_count() or 4)))
         self._prefetch = prefetch
         self._pending = {}                                            # image index -> list of futures
+        self._dir_sizes = {}                                          # directory -> {file name: bytes} (one scan each)
 
     def _executor(self):
         if self._pool is None:
@@ -213,24 +238,43 @@ class ClipFrameSource:
         if self.decoder != "device":
             self._pending[idx] = [ex.submit(read_rgb_or_bgr, p) for p in paths]
             return self._pending[idx]
-        sizes = []
-        for p in paths:
-            try:
-                sizes.append(os.stat(p).st_size if p.lower().endswith((".jpg", ".jpeg")) else -1)
-            except OSError:
-                sizes.append(-1)
+        sizes = [self._file_size(p) if p.lower().endswith((".jpg", ".jpeg")) else -1 for p in paths]
         futs = []
         if min(sizes) > 0:
             need = sum(sz + 16 for sz in sizes)
             a = getattr(self, "_arena", None)
             if a is None or a.size - a.used < need:
                 a = self._arena = self._decoder().arena(max(need, 96 << 20))
-            for p, sz in zip(paths, sizes):
-                futs.append(ex.submit(_read_into, a.take(sz), p))
+            fut = ex.submit(_read_frame, [(a.take(sz), p) for p, sz in zip(paths, sizes)])
+            futs = [_Part(fut, c) for c in range(len(paths))]
         else:
             futs = [ex.submit(_read_jpeg_bytes_or_array, p) for p in paths]
         self._pending[idx] = futs
         return futs
+
+    def _file_size(self, path):
+        """Size of a camera file from one scan of its directory (an os.stat per file was 8.5 us x 6 cameras x every frame
+        on the submitting thread: 12 % of the main.py loop); -1 when it cannot be had.  _read_into re-checks the length."""
+        d, name = os.path.split(path)
+        tab = self._dir_sizes.get(d)
+        if tab is None:
+            tab = self._dir_sizes[d] = {}
+            try:
+                with os.scandir(d) as it:
+                    for e in it:
+                        try:
+                            tab[e.name] = e.stat().st_size
+                        except OSError:
+                            pass
+            except OSError:
+                pass
+        sz = tab.get(name)
+        if sz is None:
+            try:
+                sz = tab[name] = os.stat(path).st_size
+            except OSError:
+                sz = -1
+        return sz
 
     def _n_frames(self):
         return len(self.cm_list[0].dr.attribute["sync"][self.cm_list[0].camera_name])

@@ -36,7 +36,7 @@ for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   (cd /tmp && timeout 300 rocprofv3 --output-format csv --kernel-trace --pmc $PMC -d $O/${T}_dense_pmc_$i -- python $R/bench.py --verts 1000000 --steps 3 --warmup 1 $B --no-pipeline > /dev/null 2>&1)
   python tools/pmc_summary.py $O/${T}_dense_pmc_$i k_frames_project k_stamps_scatter k_block_cameras k_overlay
 done > $O/${T}_project_dense1e6_pmc_sq.csv
-CAMA_VIDEO_SINK=null timeout 600 python tools/demo_loop_probe.py --frames 120 > $O/${T}_demo_loop.txt 2>&1
+CAMA_VIDEO_SINK=null timeout 600 python tools/demo_loop_probe.py --frames 240 > $O/${T}_demo_loop.txt 2>&1
 timeout 300 python tools/clip_from_jpeg_probe.py > $O/${T}_clip_from_jpeg.txt 2>&1
 for f in $O/${T}_bench_*.json; do echo "== $f"; python - "$f" <<'PY'
 import sys, json
