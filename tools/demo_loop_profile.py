@@ -13,6 +13,14 @@ make_clip(clip, n_frames=N + 1, seed=0, n_lines=20, verts_per_line=11, line_len_
           image_mode="jpg_photo", image_size=(900, 1600), with_nuscenes=False, extra_labels=False)
 cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)
 
+
+def set_render_ahead(n):
+    global cm
+    cfg = dict(DEFAULT_CAMA_CONFIGS)
+    cfg["render_ahead"] = n
+    cm = ClipManager(cfg, clip)
+
+
 def one_pass():
     vg = VideoGenerator(os.path.join(root, "out.mp4"), (2880, 1080))
     n = 0
@@ -25,10 +33,12 @@ def one_pass():
     vg.close()
     return n
 
-one_pass(); one_pass()
-torch.cuda.synchronize()
-for _ in range(3):
-    t = time.perf_counter(); n = one_pass(); dt = time.perf_counter() - t
-    print(f"{n} frames in {dt*1e3:.1f} ms = {n/dt:.0f} frames/s")
+for ra in [int(x) for x in os.environ.get("RENDER_AHEAD", "16").split(",")]:
+    set_render_ahead(ra)
+    one_pass(); one_pass()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        t = time.perf_counter(); n = one_pass(); dt = time.perf_counter() - t
+        print(f"render_ahead {ra}: {n} frames in {dt*1e3:.1f} ms = {n/dt:.0f} frames/s")
 pr = cProfile.Profile(); pr.enable(); one_pass(); pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(28)
