@@ -86,6 +86,13 @@ def test_fuzz_work_list_path():
     _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "77"})
 
 
+def test_fuzz_several_vertex_blocks_per_workgroup():
+    """... and with CAMA_PROJECT_VB forced: the projection runs 3 (ragged last chunk) / 8 vertex blocks per workgroup as it
+    does on launches with >= 16 k (block, frame) items, with the per-wave camera masks and without any."""
+    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_PROJECT_VB": "3", "CAMA_FUZZ_SEED": "31"})
+    _fuzz_child({"CAMA_NO_BOUNDS": "1", "CAMA_PROJECT_VB": "8", "CAMA_FUZZ_SEED": "32"})
+
+
 def test_fuzz_against_oracle():
     import torch
     from cama_amd.engine import Engine
