@@ -886,20 +886,6 @@ int cama_build_static_map(const float *verts, const int32_t *seg_v0, const int32
 // (ii) cama_pipeline_completed() polls it, so the caller knows which launches' inputs (poses, frames) and outputs may
 // be released -- the internal streams are invisible to the caller's allocator; (iii) it bounds the run-ahead: issuing
 // launch k blocks until launch k - (RING - 2) has completed.
-// Key of a captured binning chain: everything cama_bin_frames' launches depend on.
-struct BinKey {
-    const void *x, *y, *z, *colour, *key, *bounds, *w2c, *c2cam, *K, *scratch;
-    int64_t N;
-    size_t scratch_bytes;
-    double crop[6];
-    int32_t is64, flags, F, C, W, H, radius, pad;
-};
-struct BinGraph {
-    BinKey key;
-    hipGraphExec_t exec;
-    uint64_t last_use;
-};
-
 struct cama_pipeline {
     static constexpr int RING = 64;
     hipStream_t s_bin = nullptr, s_ov = nullptr;
@@ -907,13 +893,9 @@ struct cama_pipeline {
     hipEvent_t done[RING] = {};
     uint64_t issued = 0, completed = 0;
     // staged poses (cama_pipeline_stage_poses): a pinned host ring (one slot per in-flight launch) and one device pose
-    // buffer per scratch slot, so that the binning chain of a slot always reads the same device address ...
+    // buffer per scratch slot: no per-call pose tensor on the caller's side, the upload rides on the binning stream
     double *pose_host = nullptr, *pose_dev[2] = {nullptr, nullptr};
     size_t pose_cap = 0;                        // doubles per slot
-    const double *staged = nullptr;             // device poses staged for the next launch (or nullptr)
-    // ... which makes the chain (memset + 4-5 kernels) replayable as ONE hipGraph launch instead of 6-7 launches
-    std::vector<BinGraph> graphs;
-    uint64_t tick = 0;
 };
 
 int cama_pipeline_create(cama_pipeline **out)
@@ -952,7 +934,6 @@ int cama_pipeline_destroy(cama_pipeline *p)
         if (p->binned[k]) (void)hipEventDestroy(p->binned[k]);
     for (int k = 0; k < cama_pipeline::RING; ++k)
         if (p->done[k]) (void)hipEventDestroy(p->done[k]);
-    for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->pose_host) (void)hipHostFree(p->pose_host);
     for (int k = 0; k < 2; ++k)
         if (p->pose_dev[k]) (void)hipFree(p->pose_dev[k]);
@@ -981,8 +962,6 @@ int cama_pipeline_stage_poses(cama_pipeline *p, const float *w2c_host_f32, int32
         p->pose_host = nullptr;
         p->pose_dev[0] = p->pose_dev[1] = nullptr;
         p->pose_cap = 0;
-        for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);     // they captured the old addresses
-        p->graphs.clear();
         HIP_TRY(hipHostMalloc((void **)&p->pose_host, RING * cap * sizeof(double), hipHostMallocDefault));
         for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void **)&p->pose_dev[k], cap * sizeof(double)));
         p->pose_cap = cap;
@@ -995,7 +974,6 @@ int cama_pipeline_stage_poses(cama_pipeline *p, const float *w2c_host_f32, int32
     for (size_t i = 0; i < (size_t)F * 16; ++i) h[i] = (double)w2c_host_f32[i];
     double *d = p->pose_dev[(k - 1) & 1u];
     if (F) HIP_TRY(hipMemcpyAsync(d, h, (size_t)F * 16 * sizeof(double), hipMemcpyHostToDevice, p->s_bin));
-    p->staged = d;
     *w2c_dev = d;
     return CAMA_OK;
 }
@@ -1051,53 +1029,7 @@ static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, 
     HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
     HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
     if (k > 2) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->done[(k - 2) % RING], 0));   // the overlay that read this slot
-    // Staged poses live at a fixed device address per slot: the whole chain (one memset + 4-5 kernels) is then a
-    // function of BinKey only and is replayed as ONE captured hipGraph launch (6-7 launch calls -> 1 on the host).
-    // OPT-IN (CAMA_GRAPH=1): measured +2 % at 960x540 (host-bound) and nothing at 1600x900, and one GPU test -- 24
-    // full-size scenes replayed from the cache while the caller allocates between launches -- aborted inside the HIP
-    // runtime at the next device synchronisation (no fault message; the un-graphed path passes), so it stays off.
-    static const bool use_graphs = getenv("CAMA_GRAPH") != nullptr;
-    const bool staged = use_graphs && N > 0 && F > 0 && w2c && w2c == p->staged && w2c == p->pose_dev[slot];
-    p->staged = nullptr;
-    if (staged) {
-        BinKey key;
-        memset(&key, 0, sizeof(key));
-        key.x = x; key.y = y; key.z = z; key.colour = colour_id; key.key = draw_key; key.bounds = block_bounds; key.w2c = w2c;
-        key.c2cam = c2cam; key.K = K; key.scratch = scratch; key.N = N; key.scratch_bytes = scratch_bytes;
-        memcpy(key.crop, crop, sizeof(key.crop));
-        key.is64 = xyz_is_f64; key.flags = flags; key.F = F; key.C = C; key.W = W; key.H = H; key.radius = radius;
-        BinGraph *hit = nullptr;
-        for (auto &g : p->graphs)
-            if (!memcmp(&g.key, &key, sizeof(key))) { hit = &g; break; }
-        if (!hit) {
-            hipGraph_t graph = nullptr;
-            HIP_TRY(hipStreamBeginCapture(p->s_bin, hipStreamCaptureModeThreadLocal));
-            g_scatter_stop_event = nullptr;
-            const int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C,
-                                           crop, W, H, radius, scratch, scratch_bytes, p->s_bin);
-            const hipError_t e = hipStreamEndCapture(p->s_bin, &graph);
-            if (rc || e != hipSuccess || !graph) {
-                if (graph) (void)hipGraphDestroy(graph);
-                return rc ? rc : fail(CAMA_EHIP, "hipStreamEndCapture -> %s", hipGetErrorString(e));
-            }
-            hipGraphExec_t exec = nullptr;
-            const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (ei != hipSuccess) return fail(CAMA_EHIP, "hipGraphInstantiate -> %s", hipGetErrorString(ei));
-            if (p->graphs.size() >= 256) {                  // evict the least recently used
-                size_t lru = 0;
-                for (size_t i = 1; i < p->graphs.size(); ++i)
-                    if (p->graphs[i].last_use < p->graphs[lru].last_use) lru = i;
-                (void)hipGraphExecDestroy(p->graphs[lru].exec);
-                p->graphs.erase(p->graphs.begin() + (long)lru);
-            }
-            p->graphs.push_back(BinGraph{key, exec, 0});
-            hit = &p->graphs.back();
-        }
-        hit->last_use = ++p->tick;
-        HIP_TRY(hipGraphLaunch(hit->exec, p->s_bin));
-        HIP_TRY(hipEventRecord(p->binned[slot], p->s_bin));
-    } else {
+    {
         // the chain's last kernel (k_stamps_scatter, launched whenever N > 0) carries `binned` as its own stop event
         const bool ext = ext_events() && N > 0;
         g_scatter_stop_event = ext ? p->binned[slot] : nullptr;

@@ -539,8 +539,8 @@ class Engine:
 
     def _stage_poses(self, P, w2c):
         """Host float32 matrices (the np.linalg.inv result, cama/dataset.py:99) -> the pipeline's pose slot of the next
-        launch (cama_pipeline_stage_poses): no torch tensor, no allocator traffic, and a device address that is fixed
-        per slot, which lets the library replay the binning chain as one hipGraph.  Returns (device pointer, F) or None
+        launch (cama_pipeline_stage_poses): no torch tensor, no allocator traffic, a device address that is fixed per
+        slot.  Returns (device pointer, F) or None
         when `w2c` is not a host float32 array."""
         if not (isinstance(w2c, np.ndarray) and w2c.dtype == np.float32):
             return None
@@ -556,7 +556,7 @@ class Engine:
         binning overlaps call k's overlay (HBM-bound) instead of queueing behind it.  `src` / `w2c` must be complete
         on the CURRENT stream at call time; `out` is complete only after join() (which makes the current stream wait
         for every overlay issued so far).  Host float32 `w2c` (what frame_poses returns) takes the staged-pose path:
-        no per-call tensor, and the binning chain is replayed as a captured hipGraph."""
+        no per-call tensor."""
         torch = _torch()
         cropa = self._crop(crop)
         P = self._pipeline()

@@ -198,9 +198,8 @@ int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const v
  * Host poses for the next launch: copies F world->chassis matrices from HOST memory (float32 [F,16], the np.linalg.inv
  * result of cama/dataset.py:99; promoted to double exactly) into the context's pinned ring, enqueues the upload on the
  * binning stream and returns the DEVICE address to pass as `w2c` to the next cama_pipeline_render*: no device allocation
- * or caller-side upload per launch.  The address is fixed per scratch slot; with CAMA_GRAPH=1 in the environment the
- * context additionally replays that launch's binning chain (one memset + 4-5 kernels) as a single captured hipGraph
- * (experimental, off by default).  The context allocates these two small pose buffers and the pinned ring itself
+ * or caller-side upload per launch.  The address is fixed per scratch slot.  The context allocates these two small pose
+ * buffers and the pinned ring itself
  * (64 x max F x 128 bytes); everything else stays caller-owned.
  */
 int cama_pipeline_stage_poses(cama_pipeline *p, const float *w2c_host_f32, int32_t F, const double **w2c_dev);
