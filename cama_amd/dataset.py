@@ -397,6 +397,9 @@ class ClipManager:
             return self._render_batch(fr.dataset, [int(fr.image_idx)], np.asarray(fr.world2chassis)[None]), 0
         b = k // B
         batches = ra["batches"]
+        if k < ra.get("last", -1):                  # a new pass over the clip: render it again (files may have changed)
+            batches.clear()
+        ra["last"] = k
         for nb in (b, b + 1):                       # this batch now, the next one a batch early
             lo = nb * B
             if nb not in batches and lo < len(ra["idx"]):

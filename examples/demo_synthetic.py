@@ -52,8 +52,9 @@ def main():
             image_dict = cm.render_vectors(maps_2d_dict, image_idx)
             image = vg.concate_image(image_dict)
             n += 1
+        torch.cuda.synchronize()                                 # the mosaics stay on the device here (no encoder)
         dt = time.perf_counter() - t0
-        print(f"main.py loop, {label}: {n} frames in {dt:.2f} s = {n / dt:.1f} frames/s, mosaic {image.shape}")
+        print(f"main.py loop, {label}: {n} frames in {dt:.3f} s = {n / dt:.1f} frames/s, mosaic {image.shape}")
     # 2) stage clock
     idx, w2c = cm.frame_poses("cama")
     t_dec = t_up = t_gpu = t_down = 0.0
