@@ -200,6 +200,33 @@ def test_render_clip_batched_equals_per_frame_and_device_source(tmp_path):
         assert np.array_equal(mosaic[k].cpu().numpy(), O.frame_render_flat(src[i], flat["vu"], flat["vis"], col))
 
 
+def test_second_pass_over_a_clip_renders_again(tmp_path):
+    """The per-frame loop renders `render_ahead` frames per launch and keeps the batches of the current pass; a NEW pass
+    (the frame index goes back) must not hand out what the previous pass rendered: the frames may have changed."""
+    import torch
+    from cama_amd.dataset import ClipManager
+    from cama_amd.frames import DeviceFrameSource
+    from cama_amd.synth import make_clip
+    H, W = 64, 112
+    clip = str(tmp_path / "clip")
+    make_clip(clip, n_frames=9, seed=5, n_lines=10, verts_per_line=4, line_len_m=2.0, raster_size=400,
+              origin_size=(H, W), with_nuscenes=False)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W), render_ahead=3), clip)
+    frames = torch.randint(0, 256, (9, 6, H, W, 3), dtype=torch.uint8, device="cuda")
+    cm.set_frame_source(DeviceFrameSource(frames))
+
+    def one_pass():
+        return np.stack([cm.render_vectors(cm.project_all_camera(m), i).mosaic() for i, m in cm.yield_frame("cama")])
+
+    first = one_pass()
+    assert np.array_equal(first, one_pass())
+    frames.copy_(255 - frames)                                   # same tensor, same source object, new content
+    second = one_pass()
+    assert not np.array_equal(first, second)
+    _, want = cm.render_clip("cama")
+    assert np.array_equal(second, want.cpu().numpy())
+
+
 def test_crop_dict_override_is_honoured(tmp_path):
     from cama_amd.dataset import ClipManager
     g = load_golden("e_crop")
