@@ -31,8 +31,8 @@ cannot print a number: the run fails instead.
 Extra objects in the JSON line:
   roofline      dominant kernel = k_overlay, HBM-bound.  achieved = algorithmic bytes per launch
                 (13*N + 36*W*H per frame, SURVEY.md 8d, x frames per launch) / its mean duration measured live
-                with hipEvents on the launch stream (cama_profile_*; every 8th step is timed, a timed event pair
-                is two extra barrier packets).  peak 8000 GB/s.  `traffic` is a cross-reference to the committed
+                with hipEvents on the launch stream (cama_profile_*; every 8th step is timed: the launch takes the
+                event pair as the kernel's own start / stop events, hipExtLaunchKernelGGL).  peak 8000 GB/s.  `traffic` is a cross-reference to the committed
                 rocprofv3 --pmc run of the same configuration (`traffic_source`), not a measurement of this run.
   cpu_baseline  oracle/cama_oracle.py (numpy port of the reference, per-point circle calls into C) timed on this
                 box's host cores for a bounded number of passes over the same scene; rank 0, N=1 only.
