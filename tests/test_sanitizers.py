@@ -69,6 +69,12 @@ info = Info()
 L.cama_jpeg_plan.argtypes = [vp, i32, ctypes.c_uint64, vp]
 assert L.cama_jpeg_plan(buf.ctypes.data, n, 1000, ctypes.byref(info)) == -1        # zeroed descriptors: rejected
 assert L.cama_jpeg_plan(buf.ctypes.data, 0, 1000, ctypes.byref(info)) == -1
+# restart-marker search: arguments are checked before any HIP call
+L.cama_jpeg_find_restarts.argtypes = [vp, ctypes.c_uint64, vp, ctypes.c_uint32, vp, vp]
+assert L.cama_jpeg_find_restarts(None, 16, None, 0, None, None) == -1
+assert L.cama_jpeg_find_restarts(16, 0, 16, 4, 16, None) == -1 and b"stream_bytes" in L.cama_last_error()
+assert L.cama_jpeg_find_restarts(17, 64, 16, 4, 16, None) == -1 and b"aligned" in L.cama_last_error()
+assert L.cama_jpeg_find_restarts(16, 1 << 33, 16, 4, 16, None) == -1
 print("sanitizer driver ok")
 '''
 
