@@ -2,6 +2,7 @@
 bundled libjpeg-turbo, byte for byte -- sizes off the MCU grid, all supported subsamplings, qualities, grey, optimised
 Huffman tables, mixed batches, host fallback for files outside the device scope, and a full-size 1600x900 rig."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -249,6 +250,32 @@ def test_clip_frame_source_device_decode_equals_host_decode(tmp_path):
     assert [x.off for x in blobs] == sorted(x.off for x in blobs)
     for x, cmgr in zip(blobs, cm.cm_list):
         assert x.tobytes() == open(cmgr.get_image_path(2, True), "rb").read()
+
+
+def test_clip_frame_source_survives_files_that_change_size(tmp_path):
+    """The pinned slices are sized from ONE directory scan per camera; a file rewritten with another length afterwards
+    (longer: the slice is too short, shorter: a short read) is read again the plain way and still decodes to what is on disk."""
+    import torch
+    from cama_amd import frames as FR
+    from cama_amd.dataset import ClipManager
+    from cama_amd.synth import DEFAULT_CAMA_CONFIGS, make_clip
+    clip = str(tmp_path / "clip")
+    make_clip(clip, n_frames=16, seed=3, n_lines=4, verts_per_line=4, line_len_m=2.0, raster_size=300,
+              image_mode="jpg", image_size=(180, 320), with_nuscenes=False, extra_labels=False)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)
+    src = FR.ClipFrameSource(cm.cm_list, torch.device("cuda:0"), decoder="device")
+    first = src.raw_batch([1]).cpu().numpy()                    # fills the size tables
+    assert src._dir_sizes
+    img = synth_image(180, 320, "edges", seed=77)
+    longer, shorter = cm.cm_list[0].get_image_path(14, True), cm.cm_list[3].get_image_path(14, True)
+    open(longer, "wb").write(encode(synth_image(180, 320, "noise", seed=78), quality=100, subsampling=0))
+    open(shorter, "wb").write(encode(img, quality=5))
+    assert os.path.getsize(longer) > src._file_size(longer) and os.path.getsize(shorter) < src._file_size(shorter)
+    got = src.raw_batch([14]).cpu().numpy()                     # (far beyond what reading frame 1 prefetched)
+    for c, cmgr in enumerate(cm.cm_list):
+        want = pillow_rgb(open(cmgr.get_image_path(14, True), "rb").read())[:, :, ::-1]
+        assert np.array_equal(got[0, c], want), c
+    assert np.array_equal(src.raw_batch([1]).cpu().numpy(), first)
 
 
 def test_arena_staged_blobs_decode_like_bytes(dec):
