@@ -2,8 +2,9 @@
 """bench.py -- 6-camera reprojection frames/sec on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5          # starts its 8 ranks itself (torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              # ... or is started as one of N ranks (WORLD_SIZE set)
 
 Workloads (every scene: 6 pinhole cameras, 40 rendered frames at 1600x900, ~1e4 densified map
 vertices from CAMA-style labels, pose rows offset from the frame stamps so every frame interpolates; camera frames
@@ -29,13 +30,23 @@ compares them with tests/golden/scene_hashes.json -- the hashes of the ORACLE's 
 cannot print a number: the run fails instead.
 
 Extra objects in the JSON line:
-  roofline      dominant kernel = k_overlay, HBM-bound.  achieved = algorithmic bytes per launch
-                (13*N + 36*W*H per frame, SURVEY.md 8d, x frames per launch) / its mean duration measured live
-                with hipEvents on the launch stream (cama_profile_*; every 8th step is timed: the launch takes the
-                event pair as the kernel's own start / stop events, hipExtLaunchKernelGGL).  peak 8000 GB/s.  `traffic` is a cross-reference to the committed
+  roofline      dominant kernel = k_overlay, HBM-bound.  achieved = the bytes THAT kernel moves per launch -- every
+                source pixel read once, every mosaic pixel written once: 36*W*H per frame (SURVEY.md 8d's image term) x
+                frames per launch -- / its mean duration measured live with hipEvents on the launch stream
+                (cama_profile_*; every 8th step is timed: the launch takes the event pair as the kernel's own start /
+                stop events, hipExtLaunchKernelGGL).  peak 8000 GB/s.  `traffic` is a cross-reference to the committed
                 rocprofv3 --pmc run of the same configuration (`traffic_source`), not a measurement of this run.
+  roofline_project   the vertex term of SURVEY.md 8d belongs to k_frames_project, not to the overlay: bytes = 13 B (16 B
+                for maps that carry a draw key) x the vertices of the 64-vertex runs that survived the block cull
+                (cama_bin_stats: culled runs are never fetched) + 8 B per stamp written, / that kernel's own live
+                duration.  On ~1e4-vertex maps this is 0.25 % of a frame's bytes; on 1e6-vertex maps it is the term that
+                used to be charged to the overlay.
+  hbm_*_whole_step   (36*W*H*F + the projection's real bytes) per step / the step's wall time.
+  sustained     the same step loop run again for >= 1 s of wall time (the driver's K may be milliseconds of work).
   cpu_baseline  oracle/cama_oracle.py (numpy port of the reference, per-point circle calls into C) timed on this
-                box's host cores for a bounded number of passes over the same scene; rank 0, N=1 only.
+                box's host cores for a bounded number of passes over the same scene; rank 0, N=1 only.  `all_cores`:
+                the same loop in a process pool over independent scenes (main.py:32 has no cross-scene state), one
+                scene per worker, worker count stated.
 """
 import argparse
 import json
@@ -53,7 +64,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SWEEP_SCENES = 73              # BASELINE configs[2]: nuScenes v1.0-test
 STRESS = dict(verts=1000000, frames=1000)       # BASELINE configs[4]
-N_METRICS = 8
+N_METRICS = 16
 GOLDEN_SCENES = os.path.join(REPO, "tests", "golden", "scene_hashes.json")
 
 
@@ -89,6 +100,13 @@ def parse_args(argv=None):
     ap.add_argument("--stress-verts", type=int, default=STRESS["verts"])
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed per-scene hash pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    ap.add_argument("--cpu-pool-seconds", type=float, default=8.0,
+                    help="budget of the all-core CPU figure (process pool over scenes; 0 disables)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="workers of the all-core CPU figure (0 = every core "
+                    "that fits the host memory)")
+    ap.add_argument("--sustain-seconds", type=float, default=1.0,
+                    help="after the K timed steps, run the same loop for at least this long and report it as "
+                         "`sustained` (0 disables)")
     return ap.parse_args(argv)
 
 
@@ -201,16 +219,89 @@ def cpu_baseline(cm, frames, clip, args, budget_s):
             "geometry_only_fps": done / t_geom}
 
 
-def pmc_traffic(config_key):
-    """(HBM bytes per overlay launch, source) from a committed rocprofv3 --pmc run (profiles/pmc_traffic.json) of the
-    same configuration, else (None, None).  A cross-reference, not a measurement of the current run."""
-    p = os.path.join(REPO, "profiles", "pmc_traffic.json")
+def _cpu_pool_worker(job):
+    """One worker of the all-core CPU figure: its own scene (seed = worker id), a few resident frames, the reference-
+    structured loop of cpu_baseline until the budget is spent.  No torch, no GPU: numpy + oracle only."""
+    argd, seed, n_resident, budget_s = job
+    import argparse
+    import tempfile as _tf
+    from oracle import cama_oracle as O
+    from cama_amd.synth import CAMERA_NAMES, DEFAULT_CAMA_CONFIGS, frame_pattern_np
+    args = argparse.Namespace(**argd)
+    H, W = args.height, args.width
+    clip = os.path.join(_tf.mkdtemp(prefix=f"cama_cpu_s{seed}_"), "clip")
+    write_scene_clip(args, seed, clip)
+    att = O.read_attribute(clip)
+    cams = [O.camera_model(att, n, output_size=(H, W)) for n in CAMERA_NAMES]
+    labels = json.load(open(os.path.join(clip, "maps", "map_labels.json")))
+    bev = np.load(os.path.join(clip, "maps", "vision_road_mlp_ft.npy"))
+    static = O.static_map_cama(bev, labels)
+    stamps, poses = O.pose_track(clip, att, dict(DEFAULT_CAMA_CONFIGS), "cama")
+    secs = O.sensor_seconds(att, "camera_front", sync=True)
+    per_frame = 6 * H * W * 3
+    host = frame_pattern_np(seed, (n_resident, 6, H, W, 3), first=per_frame)          # image indices 1..n_resident
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        idx = 1 + done % (len(secs) - 1)
+        w2c = O.frame_world2chassis(stamps, poses, secs[idx])
+        maps_2d = O.project_all(O.crop_instances(O.transform_instances(static, w2c)), cams)
+        imgs = {}
+        for c, cam in enumerate(cams):
+            img = host[(idx - 1) % n_resident, c].copy()
+            imgs[cam["name"]] = O.render_instances(img, maps_2d[cam["name"]])
+        O.mosaic(imgs)
+        done += 1
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(args, budget_s):
+    """SURVEY.md 8d(c) / BASELINE.md 3: process pool over independent scenes, one per worker, every worker the
+    single-thread loop of cpu_baseline.  Workers = cores, capped so that their resident frames fit a quarter of the
+    free host memory.  Returns the aggregate frames/s (sum of frames / the slowest worker's time)."""
+    import multiprocessing as mp
+    n_resident = 4
+    per_worker = n_resident * 6 * args.height * args.width * 3 * 3 + (400 << 20)      # frames + copies + interpreter
     try:
-        rec = json.load(open(p))
-        if rec.get("config") == config_key:
-            return rec["bytes_per_launch"], "profiles/pmc_traffic.json (" + rec.get("source", "rocprofv3 --pmc") + ")"
-    except (OSError, ValueError, KeyError):
-        pass
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 64 << 30
+    cores = os.cpu_count() or 1
+    workers = args.cpu_workers or max(1, min(cores, int(avail // 4 // per_worker)))
+    argd = {k: getattr(args, k) for k in ("frames", "verts", "height", "width", "map")}
+    env_keep = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in env_keep:                                  # one thread per worker: the pool is the parallelism
+        os.environ[k] = "1"
+    try:
+        ctx = mp.get_context("spawn")                   # the parent holds a GPU context: never fork it
+        t0 = time.perf_counter()
+        with ctx.Pool(workers) as pool:
+            res = pool.map(_cpu_pool_worker, [(argd, w, n_resident, budget_s) for w in range(workers)], chunksize=1)
+        wall = time.perf_counter() - t0
+    finally:
+        for k, v in env_keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    frames = sum(r[0] for r in res)
+    slowest = max(r[1] for r in res)
+    return {"value": frames / slowest, "unit": "frames/s", "cores": workers, "host_cores": cores, "kind": "port",
+            "sample": f"{workers} worker processes (spawn), one independent scene each, {frames} frames in {slowest:.1f} s of "
+                      f"timed loop ({wall:.1f} s incl. start-up and scene generation); same per-frame loop as the 1-core figure"}
+
+
+def pmc_traffic(config_key):
+    """(HBM bytes per overlay launch, source) from the newest committed rocprofv3 --pmc run (profiles/r*_pmc_traffic.json)
+    of the same configuration, else (None, None).  A cross-reference, not a measurement of the current run."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9]*_pmc_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(p))
+            if rec.get("config") == config_key:
+                return rec["bytes_per_launch"], f"profiles/{os.path.basename(p)} (" + rec.get("source", "rocprofv3 --pmc") + ")"
+        except (OSError, ValueError, KeyError):
+            pass
     return None, None
 
 
@@ -264,9 +355,51 @@ class Job:
         sync_all()
         dt = time.perf_counter() - t0
         ov_ms, ov_n = ctypes.c_double(0.0), ctypes.c_int32(0)
+        pj_ms, pj_n = ctypes.c_double(0.0), ctypes.c_int32(0)
         L.cama_profile_collect(ctypes.byref(ov_ms), ctypes.byref(ov_n))
+        L.cama_profile_collect_project(ctypes.byref(pj_ms), ctypes.byref(pj_n))
         L.cama_profile_enable(0)
+        self.project_ms, self.project_n = pj_ms.value, pj_n.value
         return dt, ov_ms.value, ov_n.value
+
+    def sustain(self, seconds, steps_hint, dt_hint):
+        """The same loop, un-profiled, for at least `seconds` of wall time: (steps, seconds).  No barrier: every rank
+        times its own loop (the ranks share nothing); the aggregate is sum(frames) / max(seconds)."""
+        import torch
+        if seconds <= 0 or not self.scenes or not self.F:
+            return 0, 0.0
+        per = max(1e-6, dt_hint / max(1, steps_hint))
+        chunk = max(1, int(0.25 * seconds / per))
+        n, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(chunk):
+                self.step()
+            n += chunk
+            self.eng.join()
+            torch.cuda.synchronize(self.device)
+            if time.perf_counter() - t0 >= seconds:
+                break
+        return n, time.perf_counter() - t0
+
+    def projection_bytes(self):
+        """Untimed: one plain render of the first scene, then cama_bin_stats -> (vertex bytes read, stamp bytes written)
+        per FRAME, averaged over the launch, + the raw stats dict."""
+        import torch
+        if not self.scenes or not self.F:
+            return 0.0, 0.0, None
+        sid, cm, _, _ = self.scenes[0]
+        if getattr(self.args, "raw_frames", False):
+            return 13.0 * self.N, 0.0, None                      # (raw path: stats are not wired; vertex term only)
+        idx_all, w2c_all = cm.frame_poses("cama")
+        per = max(1, min(self.F, int(self.frames_per_launch() + 0.5)))
+        lo = self.lo
+        poses = (idx_all[lo:lo + per], w2c_all[lo:lo + per])
+        cm.render_clip("cama", out=self.out[:per], pipelined=False, poses=poses, frames_per_launch=per)
+        torch.cuda.synchronize(self.device)
+        st = self.eng.bin_stats()
+        if st is None or not st["frames"]:
+            return 13.0 * self.N, 0.0, st
+        return st["vertex_bytes_read"] / st["frames"], 8.0 * st["stamps"] / st["frames"], st
 
     def scene_hashes(self, sample_frames=None):
         """Untimed: render every scene once more (plain single-stream path) and hash it.  Whole-scene jobs: one
@@ -316,18 +449,55 @@ def stress_sample_frames(n_frames):
     return sorted(s)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves --
+    re-exec this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 and a free port) and
+    return its exit status.  Rank 0's JSON line goes to our stdout untouched; a failing rank makes the whole job (and
+    this process) exit non-zero."""
+    import subprocess
+    import torch
+    share = os.environ.get("CAMA_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not share and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s) visible (set CAMA_BENCH_SHARE_GPU=1 to let "
+              f"the ranks share GPUs: a functional check of the N > 1 path, not a measurement)", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ)
+    if share and have < args.gpus:
+        env.setdefault("CAMA_BENCH_BACKEND", "gloo")       # RCCL refuses two ranks on one device
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    # CAMA_BENCH_SHARE_GPU=1 + CAMA_BENCH_BACKEND=gloo: debugging aid to run the N>1 code path on a 1-GPU box
+    # CAMA_BENCH_SHARE_GPU=1 (+ CAMA_BENCH_BACKEND=gloo): run the N > 1 code path on a box with fewer GPUs than ranks
     share = os.environ.get("CAMA_BENCH_SHARE_GPU") == "1"
     backend = os.environ.get("CAMA_BENCH_BACKEND", "nccl")
-    device = torch.device(f"cuda:{local % torch.cuda.device_count() if share else local}")
+    n_dev = torch.cuda.device_count()
+    if not share and local >= n_dev:
+        print(f"bench.py: rank {rank} (LOCAL_RANK {local}) has no GPU: {n_dev} visible; one process per GPU is the "
+              f"contract (CAMA_BENCH_SHARE_GPU=1 to share)", file=sys.stderr, flush=True)
+        sys.exit(2)
+    device = torch.device(f"cuda:{local % n_dev if share else local}")
     torch.cuda.set_device(device)
     os.environ["CAMA_DEVICE"] = str(device)
     use_dist = world > 1 or os.environ.get("CAMA_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: 1-rank RCCL group (debug)
@@ -362,12 +532,16 @@ def main():
     job = Job(args, mine, device, frange)
     dt, ov_ms, ov_n = job.run(args.steps, args.warmup, sync_all, prof_every)
     N, F = job.N, job.F
+    sus_steps, sus_dt = job.sustain(args.sustain_seconds, args.steps, dt)
+    vbytes, sbytes, bin_stats = job.projection_bytes()
     key = workload_key(args.frames, args.verts, W, H, args.map, raw=args.raw_frames,
                        unit="frame" if args.shard_frames else "scene")
     samples = stress_sample_frames(args.frames) if args.shard_frames else None
     hashes = [] if args.no_verify else job.scene_hashes(samples)
     metrics = [float(F * args.steps * len(job.scenes)), dt, ov_ms, float(ov_n), float(N),
-               float(args.steps) * len(job.scenes) * shard.scene_cost(F, N, W, H), job.frames_per_launch(), 0.0]
+               float(args.steps) * len(job.scenes) * shard.scene_cost(F, N, W, H), job.frames_per_launch(), 0.0,
+               job.project_ms, float(job.project_n), vbytes, sbytes,
+               float(F * sus_steps * len(job.scenes)), sus_dt, 0.0, 0.0]
     cm0, frames0, clip0 = (job.scenes[0][1:] if job.scenes else (None, None, None))
     slots = max(16, -(-n_scenes // world) + 1)
     report = [shard.pack_report(metrics, hashes, slots)]
@@ -387,8 +561,10 @@ def main():
         sdt, sov_ms, sov_n = sjob.run(s_steps, s_warm, sync_all, prof_every)
         s_samples = stress_sample_frames(sargs.frames)
         s_hashes = [] if args.no_verify else sjob.scene_hashes(s_samples)
+        s_vb, s_sb, _ = sjob.projection_bytes()
         s_metrics = [float(sjob.F * s_steps), sdt, sov_ms, float(sov_n), float(sjob.N),
-                     float(s_steps) * shard.scene_cost(sjob.F, sjob.N, W, H), sjob.frames_per_launch(), float(s_steps)]
+                     float(s_steps) * shard.scene_cost(sjob.F, sjob.N, W, H), sjob.frames_per_launch(), float(s_steps),
+                     sjob.project_ms, float(sjob.project_n), s_vb, s_sb, 0.0, 0.0, 0.0, 0.0]
         report.append(shard.pack_report(s_metrics, s_hashes, len(s_samples)))
         s_key = workload_key(sargs.frames, sargs.verts, W, H, "random", unit="frame")
 
@@ -417,12 +593,35 @@ def main():
                                       samples if args.shard_frames else range(n_scenes),
                                       "frame positions" if args.shard_frames else "scenes")
         fps = agg["frames_per_s"]
-        bytes_per_frame = 13 * N + 36 * W * H
-        launches = max(1.0, float(m[0, 3]))
-        ov_avg_ms = float(m[0, 2]) / launches
-        fpl = float(m[0, 6])
-        achieved = bytes_per_frame * fpl / (ov_avg_ms * 1e-3) / 1e9 if ov_avg_ms > 0 else 0.0
-        traffic, traffic_source = pmc_traffic(f"N={N},F={F},{W}x{H}")
+
+        def rooflines(mm, image_bytes_per_frame, overlay_kernel):
+            """(roofline of the overlay, roofline of the projection, whole-step bytes per frame) from rank 0's row of
+            metrics `mm`: every kernel is charged the bytes IT moves."""
+            launches = max(1.0, float(mm[0, 3]))
+            ov_ms_ = float(mm[0, 2]) / launches
+            fpl_ = float(mm[0, 6])
+            ov_bytes = image_bytes_per_frame * fpl_
+            ach = ov_bytes / (ov_ms_ * 1e-3) / 1e9 if ov_ms_ > 0 else 0.0
+            r_ov = {"bound": "hbm", "kernel": overlay_kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "avg_launch_ms": ov_ms_,
+                    "launches": int(launches), "bytes_per_launch": ov_bytes,
+                    "bytes_per_frame": "36*W*H = every source pixel read once + every mosaic pixel written once"}
+            pj_n = float(mm[0, 9])
+            pj_ms_ = float(mm[0, 8]) / pj_n if pj_n > 0 else 0.0
+            pj_bytes = (float(mm[0, 10]) + float(mm[0, 11])) * fpl_
+            pj_ach = pj_bytes / (pj_ms_ * 1e-3) / 1e9 if pj_ms_ > 0 else 0.0
+            r_pj = {"bound": "hbm", "kernel": "k_frames_project", "achieved": pj_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": pj_ach / HBM_PEAK_GBS, "avg_launch_ms": pj_ms_, "launches": int(pj_n),
+                    "bytes_per_launch": pj_bytes, "vertex_bytes_read_per_frame": float(mm[0, 10]),
+                    "stamp_bytes_written_per_frame": float(mm[0, 11]),
+                    "vertex_read_fraction": float(mm[0, 10]) / max(1.0, 13.0 * float(mm[0, 4])),
+                    "note": "13 B per vertex of the 64-vertex runs that survived the block cull (cama_bin_stats) + 8 B "
+                            "per stamp; in practice fp64-issue bound, not HBM bound (DESIGN.md section 4)"}
+            return r_ov, r_pj, image_bytes_per_frame + float(mm[0, 10]) + float(mm[0, 11])
+
+        image_bytes = 36 * W * H                                # SURVEY.md 8(d): the image term, the overlay's bytes
+        r_overlay, r_project, bytes_per_frame = rooflines(m, image_bytes, "k_overlay")
+        r_overlay["traffic"], r_overlay["traffic_source"] = pmc_traffic(f"N={N},F={F},{W}x{H}")
         cfg_no = 4 if args.map == "random" else 3 if args.map == "site" else 2 if n_scenes > 1 else 1
         line = {
             "metric": "6-cam frames/sec (1600x900, ~10k map verts)" if (W, H) == (1600, 900)
@@ -449,27 +648,29 @@ def main():
                             if len(found) <= 8 else f"{len(found)} units (see hash_check)",
             "hbm_GBps_whole_step": bytes_per_frame * (float(m[0, 0]) / float(m[0, 1])) / 1e9,   # rank 0's GPU
             "hbm_frac_whole_step": bytes_per_frame * (float(m[0, 0]) / float(m[0, 1])) / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"bound": "hbm", "kernel": "k_overlay", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_source,
-                         "avg_launch_ms": ov_avg_ms, "launches": int(launches),
-                         "bytes_per_launch": bytes_per_frame * fpl},
+            "roofline": r_overlay,
+            "roofline_project": r_project,
         }
+        sus_frames, sus_secs = float(m[:, 12].sum()), float(m[:, 13].max())
+        if sus_secs > 0:
+            line["sustained"] = {"value": sus_frames / sus_secs, "unit": "frames/s", "seconds": sus_secs,
+                                 "frames": sus_frames,
+                                 "note": "the same step loop run for >= %.1f s after the K timed steps (per rank, no "
+                                         "barrier; sum of frames / slowest rank)" % args.sustain_seconds}
+        if bin_stats is not None:
+            line["projection_stats"] = bin_stats
         if args.raw_frames:
             line["config"]["workload"] += "; raw 1600x900 frames resampled on device each step"
             # this mode's kernel reads the raw frames and writes the resized mosaic: 3*C*(H0*W0 + H*W) bytes per frame
-            raw_bytes = 13 * N + 3 * 6 * (900 * 1600 + H * W)
-            ach = raw_bytes * fpl / (ov_avg_ms * 1e-3) / 1e9 if ov_avg_ms > 0 else 0.0
-            line["roofline"].update(kernel="k_overlay_raw*", achieved=ach, frac=ach / HBM_PEAK_GBS,
-                                    bytes_per_launch=raw_bytes * fpl, traffic=None, traffic_source=None)
+            raw_image = 3 * 6 * (900 * 1600 + H * W)
+            r_overlay, r_project, raw_bytes = rooflines(m, raw_image, "k_overlay_raw*")
+            r_overlay["bytes_per_frame"] = "3*C*(H0*W0 + H*W): raw frame read once, resized mosaic written once"
+            line["roofline"], line["roofline_project"] = r_overlay, r_project
             line["hbm_GBps_whole_step"] = raw_bytes * (float(m[0, 0]) / float(m[0, 1])) / 1e9
             line["hbm_frac_whole_step"] = line["hbm_GBps_whole_step"] / HBM_PEAK_GBS
         if do_stress:
             sm, sagg, sfound, scheck = finish(allrep[:, sizes[0]:], N_METRICS, s_key, s_samples, "frame positions")
-            s_bpf = 13 * int(sm[0, 4]) + 36 * W * H
-            s_l = max(1.0, float(sm[0, 3]))
-            s_ms = float(sm[0, 2]) / s_l
-            s_ach = s_bpf * float(sm[0, 6]) / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
+            s_rov, s_rpj, s_bpf = rooflines(sm, 36 * W * H, "k_overlay")
             line["stress"] = {
                 "workload": "BASELINE configs[4]: 1 scene of %d random verts x 6 cams x %d frames at %dx%d, contiguous "
                             "frame ranges over %d GPU(s)" % (int(sm[0, 4]), sargs.frames, W, H, world),
@@ -477,10 +678,8 @@ def main():
                 "ms_per_step": sagg["seconds"] / max(1.0, float(sm[0, 7])) * 1e3,
                 "per_rank_seconds": [float(x) for x in sm[:, 1]], "per_rank_frames": [float(x) for x in sm[:, 0]],
                 "hash_check": scheck,
-                "roofline": {"bound": "hbm", "kernel": "k_overlay", "achieved": s_ach, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": s_ach / HBM_PEAK_GBS, "avg_launch_ms": s_ms,
-                             "bytes_per_launch": s_bpf * float(sm[0, 6]),
-                             "note": "algorithmic bytes; culled vertex blocks are never read, real traffic is lower"},
+                "roofline": s_rov, "roofline_project": s_rpj,
+                "hbm_frac_whole_step": s_bpf * (float(sm[0, 0]) / float(sm[0, 1])) / 1e9 / HBM_PEAK_GBS,
             }
         if failures:
             print("\n".join(failures), file=sys.stderr, flush=True)
@@ -490,6 +689,12 @@ def main():
         if world == 1 and args.cpu_seconds > 0 and not args.raw_frames and cm0 is not None:
             line["cpu_baseline"] = cpu_baseline(cm0, frames0, clip0, args, args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = fps / line["cpu_baseline"]["value"]
+            if args.cpu_pool_seconds > 0 and args.map == "lanes":
+                try:
+                    line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(args, args.cpu_pool_seconds)
+                    line["speedup_vs_cpu_all_cores"] = fps / line["cpu_baseline"]["all_cores"]["value"]
+                except Exception as e:                              # a reported baseline, never a reason to lose the line
+                    line["cpu_baseline"]["all_cores"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

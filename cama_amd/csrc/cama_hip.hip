@@ -56,7 +56,8 @@ int fail(int code, const char *fmt, ...)
 // Opt-in timing of the dominant kernel (k_overlay) with HIP events recorded on the launch stream.
 struct ProfileState {
     bool on = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // recorded, not yet collected
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // recorded, not yet collected (overlay)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_project;   // the same for k_frames_project*
     std::vector<hipEvent_t> pool;
 };
 thread_local ProfileState g_prof;
@@ -120,7 +121,7 @@ int make_disc(int radius, const int32_t *hw, Disc &d)
     d.rows = 0;
     d.hw4 = 0;
     for (int k = 0; k <= radius; ++k) {
-        if (hw[k] > CAMA_MAX_RADIUS) return -1;
+        if (hw[k] > radius) return -1;           // owner rows carry `radius` spare cells per side (rasterise_one_padded)
         if (hw[k] < 0) continue;                 // row not drawn
         d.rows |= 1u << k;
         d.hw4 |= (uint64_t)hw[k] << (4 * k);
@@ -267,11 +268,11 @@ int cama_profile_enable(int32_t on)
     return CAMA_OK;
 }
 
-int cama_profile_collect(double *total_ms, int32_t *launches)
+static int profile_drain(std::vector<std::pair<hipEvent_t, hipEvent_t>> &pending, double *total_ms, int32_t *launches)
 {
     double sum = 0.0;
     int n = 0;
-    for (auto &pr : g_prof.pending) {
+    for (auto &pr : pending) {
         HIP_TRY(hipEventSynchronize(pr.second));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
@@ -280,10 +281,16 @@ int cama_profile_collect(double *total_ms, int32_t *launches)
         g_prof.pool.push_back(pr.first);
         g_prof.pool.push_back(pr.second);
     }
-    g_prof.pending.clear();
+    pending.clear();
     if (total_ms) *total_ms = sum;
     if (launches) *launches = n;
     return CAMA_OK;
+}
+
+int cama_profile_collect(double *total_ms, int32_t *launches) { return profile_drain(g_prof.pending, total_ms, launches); }
+int cama_profile_collect_project(double *total_ms, int32_t *launches)
+{
+    return profile_drain(g_prof.pending_project, total_ms, launches);
 }
 
 int cama_transform_points(const void *xyz, int32_t xyz_is_f64, int64_t N, const double *T, int32_t F,
@@ -490,21 +497,29 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
         }
 #endif
     }
+    // live timing (cama_profile_enable): the projection takes an event pair as its own start / stop events
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (N && g_prof.on) {
+        pe0 = prof_event();
+        pe1 = prof_event();
+        if (!pe0 || !pe1) pe0 = pe1 = nullptr;
+    }
     if (N && use_list && a.cam_mask) {
         if (xyz_is_f64)
-            hipLaunchKernelGGL(k_frames_project_list<double>, lgrid, dim3(BLOCK), hist_lds, s, a, work_count, work, vblocks,
-                               (uint32_t)L.list_cap);
+            hipExtLaunchKernelGGL(k_frames_project_list<double>, lgrid, dim3(BLOCK), (uint32_t)hist_lds, s, pe0, pe1, 0u, a,
+                                  work_count, work, vblocks, (uint32_t)L.list_cap);
         else
-            hipLaunchKernelGGL(k_frames_project_list<float>, lgrid, dim3(BLOCK), hist_lds, s, a, work_count, work, vblocks,
-                               (uint32_t)L.list_cap);
+            hipExtLaunchKernelGGL(k_frames_project_list<float>, lgrid, dim3(BLOCK), (uint32_t)hist_lds, s, pe0, pe1, 0u, a,
+                                  work_count, work, vblocks, (uint32_t)L.list_cap);
         HIP_TRY(hipGetLastError());
     } else if (N) {
         if (xyz_is_f64)
-            hipLaunchKernelGGL(k_frames_project<double>, fgrid, dim3(BLOCK), hist_lds, s, a, vb_per_wg);
+            hipExtLaunchKernelGGL(k_frames_project<double>, fgrid, dim3(BLOCK), (uint32_t)hist_lds, s, pe0, pe1, 0u, a, vb_per_wg);
         else
-            hipLaunchKernelGGL(k_frames_project<float>, fgrid, dim3(BLOCK), hist_lds, s, a, vb_per_wg);
+            hipExtLaunchKernelGGL(k_frames_project<float>, fgrid, dim3(BLOCK), (uint32_t)hist_lds, s, pe0, pe1, 0u, a, vb_per_wg);
         HIP_TRY(hipGetLastError());
     }
+    if (pe0 && pe1) g_prof.pending_project.emplace_back(pe0, pe1);
     hipLaunchKernelGGL(k_scan_bands, dim3(nfc), dim3(64), 0, s, counts, bin_off, fc_total, L.NB);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(64), 0, s, fc_total, fc_base, nfc);
@@ -519,6 +534,43 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
             hipLaunchKernelGGL(k_stamps_scatter, sgrid, dim3(BLOCK), align_up((size_t)2 * L.NB * 4, 16), s, a);
         HIP_TRY(hipGetLastError());
     }
+    return CAMA_OK;
+}
+
+// Diagnostic read-back of what a finished cama_bin_frames left in `scratch` (blocks the host on `stream`): how much of the
+// vertex buffer the projection actually read and how many stamps it produced -- the figures bench.py prices the
+// projection's roofline with.
+int cama_bin_stats(const void *scratch, size_t scratch_bytes, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                   int32_t radius, int32_t had_block_bounds, uint64_t *out, void *stream)
+{
+    ScratchLayout L;
+    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+    if (!out) return fail(CAMA_EINVAL, "out is NULL");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (F == 0) return CAMA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(s));
+    const char *base = (const char *)scratch;
+    const size_t nfc = (size_t)F * C;
+    const uint64_t vblocks = (uint64_t)((N + BLOCK - 1) / BLOCK), waves = (uint64_t)((N + 63) / 64);
+    if (had_block_bounds && N && !getenv("CAMA_NO_CAM_MASK")) {
+        std::vector<uint64_t> hm((size_t)vblocks * F);
+        HIP_TRY(hipMemcpy(hm.data(), base + L.cam_mask, hm.size() * 8, hipMemcpyDeviceToHost));
+        for (uint64_t m : hm) {
+            for (int w = 0; w < 4; ++w) out[0] += ((m >> (16 * w)) & 0xffffull) != 0;
+            out[1] += (uint64_t)__builtin_popcountll(m);
+        }
+    } else {
+        out[0] = waves * (uint64_t)F;
+        out[1] = waves * (uint64_t)F * (uint64_t)C;
+    }
+    std::vector<uint32_t> tot(nfc);
+    HIP_TRY(hipMemcpy(tot.data(), base + L.fc_total, nfc * 4, hipMemcpyDeviceToHost));
+    for (uint32_t v : tot) out[3] += v;                 // band entries = what the overlay reads
+    // stamps = non-empty entries of the compacted segments
+    std::vector<uint8_t> seg(nfc * L.nseg);
+    HIP_TRY(hipMemcpy(seg.data(), base + L.seg_cnt, seg.size(), hipMemcpyDeviceToHost));
+    for (uint8_t v : seg) out[2] += v;
     return CAMA_OK;
 }
 

@@ -386,28 +386,39 @@ class ClipManager:
         arguments per frame as a one-frame launch: only the batching differs."""
         B = max(1, int(self.configs.get("render_ahead", 16)))
         crop = tuple(float(v) for v in np.asarray(self.mm.crop_box()).reshape(-1))
-        key = (fr.dataset, id(self.instance_maps[fr.dataset]), crop, id(self._frame_source), B)
+        source = self.frame_source()                # create the (lazy) default source BEFORE it goes into the key
+        ins = self.instance_maps[fr.dataset]
+        key = (fr.dataset, crop, B)
         ra = getattr(self, "_ahead", None)
-        if ra is None or ra["key"] != key:
+        # the state holds the objects it was built for (identity, not id(): a held reference cannot be recycled)
+        if ra is None or ra["key"] != key or ra["ins"] is not ins or ra["src"] is not source:
             idx, w2c = self.frame_poses(fr.dataset)
-            ra = self._ahead = {"key": key, "idx": idx, "w2c": w2c, "pos": {int(i): k for k, i in enumerate(idx)},
+            # batches = runs of up to B CONSECUTIVE image indices: a pose gap (skipped frames) ends a batch, so sources
+            # that serve contiguous frame ranges only (RawDeviceFrameSource) never see a range with a hole
+            bounds, of_pos = [], np.zeros(len(idx), np.int64)
+            for k in range(len(idx)):
+                if not bounds or k - bounds[-1][0] >= B or idx[k] != idx[k - 1] + 1:
+                    bounds.append([k, k])
+                bounds[-1][1] = k + 1
+                of_pos[k] = len(bounds) - 1
+            ra = self._ahead = {"key": key, "ins": ins, "src": source, "idx": idx, "w2c": w2c,
+                                "pos": {int(i): k for k, i in enumerate(idx)}, "bounds": bounds, "of_pos": of_pos,
                                 "batches": {}}
         k = ra["pos"].get(int(fr.image_idx))
         if k is None or B == 1 or not np.array_equal(ra["w2c"][k], fr.world2chassis):
             return self._render_batch(fr.dataset, [int(fr.image_idx)], np.asarray(fr.world2chassis)[None]), 0
-        b = k // B
+        b = int(ra["of_pos"][k])
         batches = ra["batches"]
         if k < ra.get("last", -1):                  # a new pass over the clip: render it again (files may have changed)
             batches.clear()
         ra["last"] = k
         for nb in (b, b + 1):                       # this batch now, the next one a batch early
-            lo = nb * B
-            if nb not in batches and lo < len(ra["idx"]):
-                hi = min(len(ra["idx"]), lo + B)
+            if nb not in batches and nb < len(ra["bounds"]):
+                lo, hi = ra["bounds"][nb]
                 batches[nb] = self._render_batch(fr.dataset, [int(i) for i in ra["idx"][lo:hi]], ra["w2c"][lo:hi])
         for old in [n for n in batches if n < b - 1]:
             del batches[old]
-        return batches[b], k - b * B
+        return batches[b], k - ra["bounds"][b][0]
 
     # ------------------------------------------------------------------ whole-clip fused path
     def render_clip(self, dataset, out=None, frames_per_launch=None, poses=None, pipelined=False):

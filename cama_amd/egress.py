@@ -110,24 +110,42 @@ class DeviceMosaic:
         self.ndim = 3
         self._bgr = None
 
-    def __array__(self, dtype=None, copy=None):
+    def _host(self):
+        """The mosaic as a host ndarray (downloaded once).  From here on this object IS that array for every purpose:
+        the caller may have edited it in place, so the device-side I420 shortcut is off (i420() -> None) and
+        VideoGenerator.add_frame converts / writes the host bytes."""
         if self._bgr is None:
             self._bgr = self.batch.bgr(self.j)
-        return self._bgr if dtype is None else self._bgr.astype(dtype, copy=False)
+        return self._bgr
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._host()
+        return a if dtype is None else a.astype(dtype, copy=False)
 
     def astype(self, dtype, **kw):
-        return np.asarray(self).astype(dtype, **kw)
+        return self._host().astype(dtype, **kw)
 
     def tobytes(self):
-        return np.asarray(self).tobytes()
+        return self._host().tobytes()
 
     def __getitem__(self, k):
-        return np.asarray(self)[k]
+        return self._host()[k]
+
+    def __setitem__(self, k, v):
+        self._host()[k] = v
 
     def __len__(self):
         return self.shape[0]
 
+    def __getattr__(self, name):
+        # everything else an ndarray offers (copy, reshape, mean, size, T, ...) comes from the downloaded array
+        if name.startswith("__") or name in ("batch", "j", "_bgr"):
+            raise AttributeError(name)
+        return getattr(self._host(), name)
+
     def i420(self):
+        if self._bgr is not None:               # touched on the host: those bytes are the frame now
+            return None
         return self.batch.i420(self.j)
 
 

@@ -340,7 +340,26 @@ class Engine:
                 rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H,
                 src.data_ptr(), out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
                 self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), self._stream()))
+            self._last_bin = (dmap.N, F, rig.C, rig.H, rig.W, bnd is not None, key is not None, scratch)
             return out
+
+    def bin_stats(self):
+        """What the binning half of the LAST render_frames() call read and produced (cama_bin_stats; blocks until the
+        stream is idle): dict with frames, vertex_waves_read (64-vertex runs fetched, over all frames), camera_chains,
+        stamps, band_entries, vertex_bytes_read (13 B per vertex, 16 B when the map carries a draw key), or None."""
+        last = getattr(self, "_last_bin", None)
+        if last is None:
+            return None
+        N, F, C, H, W, had_bounds, has_key, scratch = last
+        out = np.zeros(4, np.uint64)
+        with _torch().cuda.device(self.device):
+            _lib.check(self.lib.cama_bin_stats(scratch.data_ptr(), scratch.numel(), N, F, C, H, W, self.radius,
+                                               int(had_bounds), out.ctypes.data, self._stream()))
+        per_vertex = 16 if has_key else 13
+        return {"frames": F, "verts": N, "vertex_waves_read": int(out[0]), "camera_chains": int(out[1]),
+                "stamps": int(out[2]), "band_entries": int(out[3]),
+                "vertex_bytes_read": int(min(int(out[0]) * 64, N * F)) * per_vertex,
+                "block_cull": bool(had_bounds)}
 
     # ------------------------------------------------------------------ frame resample (undistort + resize)
     def resample(self, cm, src, out=None):
@@ -378,9 +397,18 @@ class Engine:
         """Per-camera undistort/resize maps of a rig, concatenated on the device: (mapx, mapy, separable)."""
         torch = _torch()
         from .frames import camera_maps
-        key = tuple(id(cm) for cm in cm_list)
-        hit = getattr(self, "_rig_maps", None)
-        if hit is None or hit[0] != key:
+        # keyed on CONTENT (sizes, both intrinsics, distortion), not on object identity: ids are recycled, and two clips
+        # of one rig share a plan.  A small dict of plans: the tensors of a plan that queued launches still read stay
+        # referenced from the launches' keep tuples (render_frames_raw) as well.
+        def _sig(cm):
+            d = cm.d_origin if cm.d == [] else cm.d
+            return (int(cm.height), int(cm.width), int(cm.height_origin), int(cm.width_origin),
+                    np.asarray(cm.K_origin, np.float64).tobytes(), np.asarray(cm.K, np.float64).tobytes(),
+                    b"" if d is None else np.asarray(d, np.float64).tobytes())
+        key = tuple(_sig(cm) for cm in cm_list)
+        plans = self.__dict__.setdefault("_rig_plans", {})
+        hit = plans.get(key)
+        if hit is None:
             maps = [camera_maps(cm) for cm in cm_list]
             sep = all(bool((mx == mx[0:1, :]).all() and (my == my[:, 0:1]).all()) for mx, my in maps)
             if sep:
@@ -445,7 +473,9 @@ class Engine:
             hit = (key, torch.from_numpy(np.ascontiguousarray(mx)).to(self.device),
                    torch.from_numpy(np.ascontiguousarray(my)).to(self.device), int(sep), band_rows, max_rows,
                    tiles, tiles_x, max_tile, vrows)
-            self._rig_maps = hit
+            if len(plans) >= 16:                      # bounded: drop the oldest plan (dict order = insertion order)
+                plans.pop(next(iter(plans)))
+            plans[key] = hit
         return hit[1:]
 
     def render_frames_raw(self, dmap, rig, w2c, raw, cm_list, out=None, cols=3, crop=None, pipelined=False):
@@ -486,7 +516,9 @@ class Engine:
                     vrows[1].data_ptr(), vrows[2], out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
                     self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(), min(s0.numel(), s1.numel()), st))
                 seq = int(self.lib.cama_pipeline_issued(P["handle"]))
-                P["keep"].append((seq, T, raw, out, dmap, rig))
+                # the overlay runs later, on the pipeline's own stream, and reads the tap tables: they belong to the
+                # launch's keep set like the frames and the map (a later call with another rig may evict the plan)
+                P["keep"].append((seq, T, raw, out, dmap, rig, (vrows[0], vrows[1], mapx, mapy, band_rows, tiles)))
                 self._release_completed(P)
                 return out
             if T is None:
@@ -582,7 +614,7 @@ class Engine:
             # allocated until the library reports it complete (cama_pipeline_completed, a hipEventQuery over its ring
             # of per-launch events) -- however far ahead of the GPU the host is.
             seq = int(self.lib.cama_pipeline_issued(P["handle"]))
-            P["keep"].append((seq, T, src, out, dmap, rig))
+            P["keep"].append((seq, T, src, out, dmap, rig, ()))
             self._release_completed(P)
             return out
 
@@ -608,9 +640,9 @@ class Engine:
             _lib.check(self.lib.cama_pipeline_join(self._pipe["handle"], self._stream()))
             self._release_completed(self._pipe)
             cur = torch.cuda.current_stream(self.device)
-            for _, T, src, out, dmap, rig in self._pipe["keep"]:
+            for _, T, src, out, dmap, rig, extra in self._pipe["keep"]:
                 for t in (T, src, out, dmap.soa, dmap.colour, dmap.sorted_soa, dmap.sorted_key,
-                          getattr(dmap, "bounds", None), rig.c2cam, rig.K):
+                          getattr(dmap, "bounds", None), rig.c2cam, rig.K) + tuple(extra):
                     if t is not None:
                         t.record_stream(cur)
             self._pipe["keep"].clear()

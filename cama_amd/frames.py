@@ -409,20 +409,23 @@ class RawDeviceFrameSource:
         self._buf = None
 
     def raw_batch(self, image_indices):
-        idx = list(image_indices)
-        assert idx == list(range(idx[0], idx[0] + len(idx))), "contiguous frame ranges only"
-        return self.raw[idx[0]:idx[0] + len(idx)]
+        """Raw frames of the given image indices: a view for a contiguous range (the usual case), a gathered copy for
+        ranges with holes (clips whose pose lookup skips frames, cama/dataset.py:93-96)."""
+        import torch
+        idx = [int(i) for i in image_indices]
+        if idx == list(range(idx[0], idx[0] + len(idx))):
+            return self.raw[idx[0]:idx[0] + len(idx)]
+        return self.raw.index_select(0, torch.as_tensor(idx, dtype=torch.long, device=self.raw.device))
 
     def batch(self, image_indices):
         import torch
         from . import runtime
         eng = runtime.engine()
-        idx = list(image_indices)
-        assert idx == list(range(idx[0], idx[0] + len(idx))), "contiguous frame ranges only"
+        raw = self.raw_batch(image_indices)
         c0 = self.cm_list[0]
-        shape = (len(idx), len(self.cm_list), c0.height, c0.width, 3)
+        shape = (int(raw.shape[0]), len(self.cm_list), c0.height, c0.width, 3)
         if self._buf is None or tuple(self._buf.shape) != shape:
             self._buf = torch.empty(shape, dtype=torch.uint8, device=self.raw.device)
         for c, cm in enumerate(self.cm_list):
-            eng.resample(cm, self.raw[idx[0]:idx[0] + len(idx), c], out=self._buf[:, c])
+            eng.resample(cm, raw[:, c], out=self._buf[:, c])
         return self._buf

@@ -28,14 +28,21 @@ def set_engine(e):
 # ---------------------------------------------------------------------------------------------------------------
 # egress: a VideoGenerator that can take planar YUV 4:2:0 announces itself here, and the render path then prepares
 # every batch's I420 planes + download right behind its render (cama_amd/egress.py)
-_egress = None
+_egress_listeners = 0
 
 
 def request_egress(mode):
-    """mode: "i420" or None."""
-    global _egress
-    _egress = mode
+    """mode "i420": one more listener (a VideoGenerator that takes planar YUV 4:2:0); None: one listener less.
+    Counted, because main.py rebinds `vg = VideoGenerator(...)` per pass: the new object's __init__ runs BEFORE the old
+    object's __del__ -> close(), and a single slot would leave the second video without the prefetch."""
+    global _egress_listeners
+    if mode == "i420":
+        _egress_listeners += 1
+    elif mode is None:
+        _egress_listeners = max(0, _egress_listeners - 1)
+    else:
+        raise ValueError(f"unknown egress mode {mode!r}")
 
 
 def egress_mode():
-    return _egress
+    return "i420" if _egress_listeners > 0 else None

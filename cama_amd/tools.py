@@ -91,7 +91,9 @@ class VideoGenerator:
         if callable(handle):
             dev = handle(MOSAIC_ORDER)                 # already assembled in HBM by the overlay kernel: stays there
             if dev is not None:
-                return dev
+                # CAMA_EGRESS=bgr24 restores the reference's return type to the letter: a plain ndarray (cv2.* calls
+                # and other code that insists on a real ndarray), at the price of a 9 MB download per frame here
+                return np.asarray(dev) if os.environ.get("CAMA_EGRESS", "i420") == "bgr24" else dev
         mosaic = getattr(image_dict, "mosaic", None)
         if callable(mosaic):
             ready = mosaic(MOSAIC_ORDER)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 10
+#define CAMA_ABI_VERSION 11
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -126,7 +126,7 @@ int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz
  *              (c / cols, c % cols) -- tools.py:23-24 for C = 6, cols = 3 with camera_list order
  *   radius     circle radius (reference: 2); halfwidth host[radius+1]: half-width of the filled
  *              footprint on rows +-k (OpenCV midpoint circle; data, so a real-cv2 fixture can
- *              correct it) -- see cama_circle_halfwidths()
+ *              correct it) -- see cama_circle_halfwidths(); every halfwidth[k] <= radius (else CAMA_EINVAL)
  *   palette_bgr host[2*3]
  *   scratch    device scratch of at least cama_render_scratch_bytes(...) bytes
  */
@@ -346,6 +346,19 @@ int cama_overlay_band_rows(int32_t W);
  */
 int cama_profile_enable(int32_t on);
 int cama_profile_collect(double *total_ms /* host */, int32_t *launches /* host */);
+/* The same for the projection kernel (k_frames_project / k_frames_project_list) of every cama_bin_frames call made
+ * while profiling was enabled: the kernel's own start / stop events. */
+int cama_profile_collect_project(double *total_ms /* host */, int32_t *launches /* host */);
+/*
+ * Diagnostic read-back of a finished cama_bin_frames (same N, F, C, H, W, radius, scratch; had_block_bounds = whether
+ * block_bounds was passed).  Blocks the host until `stream` is idle, then copies the small tables back.  out (host, 4):
+ *   out[0] (wave, frame) items the projection read = 64-vertex runs whose camera mask was not 0 (all of them without
+ *          block_bounds): the vertex buffer bytes the kernel really fetched are 13 B (16 B with draw_key) x 64 x out[0]
+ *   out[1] camera bits set over those items (fp64 chains run = out[1] x 64 lanes)
+ *   out[2] stamps written (8 B each)          out[3] band entries (what the overlay reads, 8 B each)
+ */
+int cama_bin_stats(const void *scratch, size_t scratch_bytes, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                   int32_t radius, int32_t had_block_bounds, uint64_t *out /* host, 4 */, void *stream);
 
 /*
  * Device baseline-JPEG decode of a batch of camera frames: what CameraManager.read_resized_image /

@@ -1,0 +1,86 @@
+"""-m gpu: bench.py as the driver runs it -- a subprocess, the JSON line on stdout.
+
+  * `python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must start its own ranks.  The box has one
+    GPU, so the two ranks share it (CAMA_BENCH_SHARE_GPU=1 -> gloo for the one collective: RCCL refuses two ranks on one
+    device); what is checked is the N > 1 code path: sharding, the all_gather, the per-scene hash check.
+  * the N = 1 line: no roofline fraction above 1 on a map where the vertex term matters, the
+    projection has its own roofline object, a sustained figure and the CPU baselines are present.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env_extra=None, timeout=1500):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, cwd=REPO, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    env = {"CAMA_BENCH_SHARE_GPU": "1"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    p, line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert line is not None, p.stdout[-2000:]
+    assert line["n_gpus"] == 2 and line["rccl_world"] == 2
+    assert line["scaling"] == "strong" and line["config"]["scenes"] == 73
+    chk = line["hash_check"]
+    assert chk["verified"] == 73 and not chk["mismatched"] and not chk["missing"] and not chk["unverified"]
+    assert len(line["per_rank_frames"]) == 2 and sum(line["per_rank_frames"]) == 73 * 40 * 2
+    st = line["stress"]
+    assert st["hash_check"]["verified"] == 16 and not st["hash_check"]["mismatched"]
+    for r in (line["roofline"], line["roofline_project"], st["roofline"], st["roofline_project"]):
+        assert 0.0 < r["frac"] <= 1.0, r
+
+
+def test_bench_gpus_beyond_the_node_is_refused_not_asserted():
+    """Without the share switch, asking for more GPUs than the node has is a clear non-zero exit, not an AssertionError
+    from deep inside a rank."""
+    import torch
+    n = torch.cuda.device_count()
+    p, line = _run(["--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], {"CAMA_BENCH_SHARE_GPU": "0"}, timeout=300)
+    assert p.returncode == 2 and line is None
+    assert "GPU(s) visible" in p.stderr
+
+
+def test_bench_line_site_map_roofline_is_attributed_per_kernel():
+    """A site-sized map (~3e5 vertices over the 600 m extent): the overlay is charged its image bytes only, the
+    projection its own (culled) vertex bytes -- no fraction above 1 anywhere, whole-step below the kernel figures."""
+    p, line = _run(["--map", "site", "--verts", "300000", "--frames", "16", "--steps", "6", "--warmup", "2",
+                    "--cpu-seconds", "0", "--no-verify", "--sustain-seconds", "0.3"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    ro, rp = line["roofline"], line["roofline_project"]
+    assert ro["kernel"] == "k_overlay" and ro["bytes_per_launch"] == 36 * 1600 * 900 * 16
+    assert 0.3 < ro["frac"] <= 1.0
+    assert rp["launches"] > 0 and 0.0 < rp["frac"] <= 1.0
+    assert 0.0 < rp["vertex_read_fraction"] < 0.5              # most of the site is outside the crop box: never fetched
+    assert line["hbm_frac_whole_step"] <= max(ro["frac"], rp["frac"]) + 1e-9
+    assert line["projection_stats"]["block_cull"] is True
+    assert line["sustained"]["seconds"] >= 0.3 and line["sustained"]["value"] > 0
+
+
+def test_bench_default_line_has_every_contract_field():
+    p, line = _run(["--steps", "20", "--warmup", "5", "--cpu-seconds", "3", "--cpu-pool-seconds", "2", "--cpu-workers", "4"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["dtype"] == "f64" and line["vs_baseline"] is None
+    assert line["hash_check"]["verified"] == 1
+    assert line["roofline"]["bytes_per_launch"] == 36 * 1600 * 900 * 40
+    assert 0.5 < line["roofline"]["frac"] <= 1.0
+    assert line["sustained"]["seconds"] >= 1.0
+    cb = line["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["value"] > 0
+    assert cb["all_cores"]["cores"] == 4 and cb["all_cores"]["value"] > 0

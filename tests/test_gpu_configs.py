@@ -181,3 +181,63 @@ def test_stress_1e6_random_vertices_125_frames():
     eng.join()
     torch.cuda.synchronize()
     assert torch.equal(out, mosaic)
+
+
+def test_fullsize_sweep_remaining_scenes_24_to_72():
+    """configs[2], the other 49 scenes of the 73-scene sweep at full size (1600x900, 40 frames), one after the other
+    (build -> render pipelined -> hash -> free): with the 24 scenes above the driver-run suite covers all 73 golden
+    (oracle-rendered) scene hashes, not only the builder's own bench run."""
+    import torch
+    from cama_amd import runtime
+    a = _args()
+    golden = _golden(a)
+    assert len(golden) == bench.SWEEP_SCENES
+    dev = torch.device("cuda:0")
+    eng = runtime.engine()
+    out = None
+    bad = []
+    for sid in range(24, bench.SWEEP_SCENES):
+        cm, frames, _ = bench.build_scene(a, sid, dev)
+        if out is None:
+            out = torch.empty(eng.mosaic_shape(cm._rig(), a.frames), dtype=torch.uint8, device=dev)
+        out.zero_()
+        cm.render_clip("cama", out=out, pipelined=True)
+        eng.join()
+        torch.cuda.synchronize()
+        if shard.overlay_hash(out) != golden[sid]:
+            bad.append(sid)
+        del cm, frames
+    assert not bad, f"scenes {bad}: full-size render differs from the oracle's"
+
+
+def test_fullsize_stress_sampled_frames_equal_the_oracle():
+    """configs[4] at FULL size: 1e6 random vertices x 1000 frames at 1600x900, the 16 sampled frame positions (first and
+    last frame of every rank's range for 1, 2, 4 and 8 ranks) against the oracle-rendered golden hashes -- what
+    bench.py --gpus N checks in its nested stress, here inside the driver-run suite.  All 1001 frames are resident
+    (26 GB of the 288 GB); only the sampled positions are rendered, one launch each and once more as 8-frame launches
+    that contain them (a frame must not depend on its launch-mates)."""
+    import torch
+    from cama_amd import runtime
+    a = _args(frames=bench.STRESS["frames"], verts=bench.STRESS["verts"], map="random")
+    golden = _golden(a, unit="frame")
+    samples = bench.stress_sample_frames(a.frames)
+    assert sorted(golden) == samples and len(samples) == 16
+    dev = torch.device("cuda:0")
+    eng = runtime.engine()
+    cm, frames, _ = bench.build_scene(a, 0, dev)
+    idx, w2c = cm.frame_poses("cama")
+    assert len(idx) == a.frames
+    one = torch.empty(eng.mosaic_shape(cm._rig(), 1), dtype=torch.uint8, device=dev)
+    for pos in samples:
+        one.zero_()
+        cm.render_clip("cama", out=one, poses=(idx[pos:pos + 1], w2c[pos:pos + 1]))
+        torch.cuda.synchronize()
+        assert shard.overlay_hash(one[0]) == golden[pos], f"stress frame {pos} differs from the oracle's"
+    many = torch.empty(eng.mosaic_shape(cm._rig(), 8), dtype=torch.uint8, device=dev)
+    for pos in samples:
+        lo = min(max(0, pos - 3), a.frames - 8)
+        many.zero_()
+        cm.render_clip("cama", out=many, poses=(idx[lo:lo + 8], w2c[lo:lo + 8]), pipelined=True)
+        eng.join()
+        torch.cuda.synchronize()
+        assert shard.overlay_hash(many[pos - lo]) == golden[pos], f"stress frame {pos} (in an 8-frame launch)"

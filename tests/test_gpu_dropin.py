@@ -455,3 +455,85 @@ def test_integration_md_binding_example_runs(repo_root):
                         [-50, 50, -100, 100, -200, 200], src, out)
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+def test_pipelined_raw35_two_rigs_back_to_back(tmp_path):
+    """Two clips with DIFFERENT rigs (sizes 160x90 -> 96x54 and 320x180 -> 192x108) rendered alternately through the
+    pipelined 3:5 raw overlay with no join in between: the overlay of launch k runs while the host has long since built
+    the other rig's tap tables.  A launch keeps its own tables alive; the plan cache is keyed on calibration content,
+    not on object ids."""
+    import torch
+    from cama_amd import runtime
+    from cama_amd.dataset import ClipManager
+    from cama_amd.frames import RawDeviceFrameSource
+    from cama_amd.synth import frame_pattern, make_clip
+    eng = runtime.engine()
+    clips = []
+    for k, (origin, out_size) in enumerate((((90, 160), (54, 96)), ((180, 320), (108, 192)))):
+        clip = str(tmp_path / f"clip{k}")
+        make_clip(clip, n_frames=5, seed=40 + k, n_lines=40, verts_per_line=5, line_len_m=3.0, raster_size=400,
+                  origin_size=origin, with_nuscenes=False)
+        raw = frame_pattern(40 + k, (5, 6, origin[0], origin[1], 3), "cuda")
+        cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=out_size), clip)
+        cm.set_frame_source(RawDeviceFrameSource(raw, cm.cm_list, fused=True))
+        _, want = cm.render_clip("cama")                         # plain, single stream
+        torch.cuda.synchronize()
+        clips.append((cm, raw, want.clone(), torch.zeros_like(want)))
+    plans = eng.__dict__["_rig_plans"]
+    assert len(plans) >= 2
+    for rounds in range(6):
+        for cm, raw, want, out in clips:
+            cm.render_clip("cama", out=out, pipelined=True)
+            # a fresh ClipManager of the same clip (new objects, same calibration) must hit the same plan
+            cm2 = ClipManager(dict(cm.configs), cm.clip_path)
+            n = len(plans)
+            eng.rig_maps(cm2.cm_list)
+            assert len(plans) == n
+            del cm2
+    eng.join()
+    torch.cuda.synchronize()
+    for cm, raw, want, out in clips:
+        assert torch.equal(out, want)
+    # evicting every plan while launches are queued must not matter either: the launches hold their tables
+    for cm, raw, want, out in clips:
+        out.zero_()
+        cm.render_clip("cama", out=out, pipelined=True)
+        plans.clear()
+        junk = [torch.full((1 << 16,), 7, dtype=torch.int32, device="cuda") for _ in range(8)]   # reuse freed blocks
+    eng.join()
+    torch.cuda.synchronize()
+    del junk
+    for cm, raw, want, out in clips:
+        assert torch.equal(out, want)
+
+
+def test_main_loop_over_a_clip_with_pose_gaps_and_raw_frames(tmp_path):
+    """A clip whose pose track has a gap (frames skipped like cama/dataset.py:93-96) through main.py's loop with raw
+    device frames and render-ahead batches: batches end at the hole, every yielded frame equals its one-frame render."""
+    import torch
+    from cama_amd.dataset import ClipManager
+    from cama_amd.frames import RawDeviceFrameSource
+    from cama_amd.synth import frame_pattern
+    g = load_golden("c_gaps")
+    clip = rebuild_clip(g, tmp_path)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(540, 960), render_ahead=4), clip)
+    c0 = cm.cm_list[0]
+    assert (c0.height_origin, c0.width_origin) == (900, 1600)     # the golden clip is calibrated for 1600x900 frames
+    n_img = len(cm._track("cama")[1])
+    raw = frame_pattern(3, (n_img, 6, 900, 1600, 3), "cuda")
+    cm.set_frame_source(RawDeviceFrameSource(raw, cm.cm_list, fused=True))
+    idx, w2c = cm.frame_poses("cama")
+    assert len(idx) < n_img - 1 and (np.diff(idx) > 1).any()      # there IS a hole
+    seen = []
+    for image_idx, instance_map in cm.yield_frame(dataset="cama"):
+        image_dict = cm.render_vectors(cm.project_all_camera(instance_map), image_idx)
+        got = image_dict.mosaic_device.clone()
+        k = int(np.flatnonzero(idx == image_idx)[0])
+        _, one = cm.render_clip("cama", poses=(idx[k:k + 1], w2c[k:k + 1]))
+        torch.cuda.synchronize()
+        assert torch.equal(got, one[0]), image_idx
+        seen.append(image_idx)
+    assert seen == idx.tolist()
+    _, whole = cm.render_clip("cama")                              # the whole-clip path gathers across the hole too
+    torch.cuda.synchronize()
+    assert whole.shape[0] == len(idx)

@@ -254,6 +254,26 @@ def test_bad_arguments_fail_loudly(engine):
     assert b"C=99" in L.cama_last_error()
 
 
+def test_disc_table_wider_than_the_radius_is_rejected(engine):
+    """The fused overlay pads every LDS owner row by `radius` cells and does not clamp x: a caller-supplied half-width
+    table with hw[k] > radius must be refused at the C ABI (CAMA_EINVAL), not rasterised out of bounds."""
+    import torch
+    from cama_amd import _lib
+    xyz, col, cams, w2c = _random_scene(5, 500, 1, 160, 96)
+    rig = _rig(engine, cams)
+    dmap = engine.upload_map(xyz, col)
+    src = torch.zeros((1, 6, 96, 160, 3), dtype=torch.uint8, device="cuda")
+    want = engine.render_frames(dmap, rig, w2c, src).clone()
+    good = engine.halfwidth.copy()
+    try:
+        engine.halfwidth = np.asarray([2, 3, 0], np.int32)          # hw[1] = 3 > radius 2
+        with pytest.raises(_lib.CamaHipError, match="halfwidth"):
+            engine.render_frames(dmap, rig, w2c, src)
+    finally:
+        engine.halfwidth = good
+    assert torch.equal(engine.render_frames(dmap, rig, w2c, src), want)
+
+
 def test_resample_matches_restated_opencv_remap(engine):
     """Undistort+resize kernel vs the oracle's restatement of cv2.initUndistortRectifyMap + cv2.remap."""
     import torch
