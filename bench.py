@@ -88,6 +88,11 @@ def parse_args(argv=None):
                          "uniformly random map vertices over the 600 m map in random order (configs[4] stress); "
                          "site: --verts points on 50 m polylines (1 cm spacing) spread over the whole 600 m map "
                          "(configs[3]: site-aggregated labels, ~5 %% inside the crop box at a time)")
+    ap.add_argument("--sites", type=int, default=0,
+                    help="with --map site and --scenes K: BASELINE configs[3] as SURVEY.md D6 defines it -- S sites, each "
+                         "ONE static vertex buffer (--verts points) shared by the scenes driven on it (scene k belongs "
+                         "to site k %% S and has its own pose track and calibration); scenes are placed site by site "
+                         "(shard.assign_scenes(site_of=...)) and a rank uploads, sorts and indexes a site's map once")
     ap.add_argument("--raw-frames", action="store_true",
                     help="frames resident at sensor size 1600x900 and resampled (undistort+resize) to --height x "
                          "--width on the device inside every step: the reference's default 540x960 pipeline")
@@ -117,9 +122,25 @@ def workload_key(frames, verts, width, height, map_kind, raw=False, unit="scene"
             (",per-frame" if unit == "frame" else ""))
 
 
+def site_of_scene(args, seed):
+    """Site id of scene `seed` (--sites S > 0: scene k drives on site k % S), else None."""
+    S = getattr(args, "sites", 0)
+    return seed % S if S > 0 else None
+
+
+def args_key(args, unit="scene"):
+    """workload_key of an argument set (+ the site count, which changes which map a scene is rendered on)."""
+    key = workload_key(args.frames, args.verts, args.width, args.height, args.map, raw=getattr(args, "raw_frames", False),
+                       unit=unit)
+    return key + (f",sites={args.sites}" if getattr(args, "sites", 0) > 0 else "")
+
+
 def replace_map(cm, args, seed):
     """--map random / site: replace the clip's static map through the reference's public per-clip dict
     (cama/dataset.py:13-24).  Seeded by the scene id; numpy only, so the oracle side builds the same map."""
+    site = site_of_scene(args, seed)
+    if site is not None:
+        seed = site                                                # every scene of a site carries the SITE's labels
     if args.map == "site":
         # site-aggregated map: long polylines with random headings all over the 600 m extent, stored polyline-major
         rng = np.random.default_rng(2000 + seed)
@@ -148,9 +169,14 @@ def write_scene_clip(args, seed, clip):
     """The synthetic clip directory of scene `seed` (no GPU, no torch): shared by build_scene and the golden scripts."""
     from cama_amd.synth import make_clip
     n_lines = max(2, round(args.verts / 500)) if args.map == "lanes" else 4
+    kw = {}
+    if site_of_scene(args, seed) is not None:
+        # scenes of one site: each its own drive (start point seeded by the scene id) somewhere on the site
+        r = np.random.default_rng(7000 + seed)
+        kw["world_anchor"] = (float(r.uniform(-250.0, 100.0)), float(r.uniform(-250.0, 100.0)))
     # CAMA labels are densified at 0.1 BEV px = 1 cm: a 5 m polyline of 11 vertices gives ~500 points
     make_clip(clip, n_frames=args.frames + 1, seed=seed, n_lines=n_lines, verts_per_line=11, line_len_m=5.0,
-              raster_size=3000, origin_size=(900, 1600), with_nuscenes=False, extra_labels=False)
+              raster_size=3000, origin_size=(900, 1600), with_nuscenes=False, extra_labels=False, **kw)
 
 
 def build_scene(args, seed, device, frame_range=None):
@@ -259,7 +285,7 @@ def cpu_baseline_all_cores(args, budget_s):
     single-thread loop of cpu_baseline.  Workers = cores, capped so that their resident frames fit a quarter of the
     free host memory.  Returns the aggregate frames/s (sum of frames / the slowest worker's time)."""
     import multiprocessing as mp
-    n_resident = 4
+    n_resident = 2
     per_worker = n_resident * 6 * args.height * args.width * 3 * 3 + (400 << 20)      # frames + copies + interpreter
     try:
         import psutil
@@ -527,21 +553,25 @@ def main():
         frange = shard.frame_ranges(args.frames, world)[rank]
     else:
         cost = shard.scene_cost(args.frames, args.verts, W, H)
-        mine = shard.assign_scenes([cost] * n_scenes, world)[rank]       # scene ids of this rank (seed = scene id)
+        site_of = [site_of_scene(args, k) for k in range(n_scenes)] if args.sites > 0 else None
+        # a rank that takes a site pays for its map once: upload + Morton sort + block index ~ 40 B per vertex moved
+        assignment = shard.assign_scenes([cost] * n_scenes, world, site_of=site_of, site_cost=40.0 * args.verts)
+        mine = assignment[rank]                                          # scene ids of this rank (seed = scene id)
         frange = None
     job = Job(args, mine, device, frange)
     dt, ov_ms, ov_n = job.run(args.steps, args.warmup, sync_all, prof_every)
     N, F = job.N, job.F
     sus_steps, sus_dt = job.sustain(args.sustain_seconds, args.steps, dt)
     vbytes, sbytes, bin_stats = job.projection_bytes()
-    key = workload_key(args.frames, args.verts, W, H, args.map, raw=args.raw_frames,
-                       unit="frame" if args.shard_frames else "scene")
+    key = args_key(args, unit="frame" if args.shard_frames else "scene")
     samples = stress_sample_frames(args.frames) if args.shard_frames else None
     hashes = [] if args.no_verify else job.scene_hashes(samples)
     metrics = [float(F * args.steps * len(job.scenes)), dt, ov_ms, float(ov_n), float(N),
                float(args.steps) * len(job.scenes) * shard.scene_cost(F, N, W, H), job.frames_per_launch(), 0.0,
                job.project_ms, float(job.project_n), vbytes, sbytes,
-               float(F * sus_steps * len(job.scenes)), sus_dt, 0.0, 0.0]
+               float(F * sus_steps * len(job.scenes)), sus_dt,
+               float(getattr(job.eng, "map_cache_stats", {}).get("uploads", 0)),
+               float(getattr(job.eng, "map_cache_stats", {}).get("hits", 0))]
     cm0, frames0, clip0 = (job.scenes[0][1:] if job.scenes else (None, None, None))
     slots = max(16, -(-n_scenes // world) + 1)
     report = [shard.pack_report(metrics, hashes, slots)]
@@ -659,6 +689,15 @@ def main():
                                          "barrier; sum of frames / slowest rank)" % args.sustain_seconds}
         if bin_stats is not None:
             line["projection_stats"] = bin_stats
+        if args.sites > 0:
+            line["site_maps"] = {"sites": args.sites, "verts_per_site": N,
+                                 "sites_per_rank": shard.sites_per_rank(assignment, site_of),
+                                 "map_uploads_per_rank": [int(x) for x in m[:, 14]],
+                                 "map_cache_hits_per_rank": [int(x) for x in m[:, 15]],
+                                 "note": "scenes of a site share ONE device vertex buffer per rank (content-keyed "
+                                         "Engine.shared_map): uploaded, Morton-sorted and indexed once"}
+            line["config"]["workload"] += "; %d site(s), scene k on site k %% %d" % (args.sites, args.sites)
+            line["config"]["sharding"] = "whole scenes placed site by site (shard.assign_scenes(site_of=...)), no data-path collective"
         if args.raw_frames:
             line["config"]["workload"] += "; raw 1600x900 frames resampled on device each step"
             # this mode's kernel reads the raw frames and writes the resized mosaic: 3*C*(H0*W0 + H*W) bytes per frame

@@ -67,7 +67,8 @@ class _StaticMap:
 
     def device(self):
         if self._dmap is None:
-            self._dmap = runtime.engine().upload_map(self._xyz, self.colour)
+            # content-keyed: the scenes of one site (identical site-aggregated labels) share one device map per GPU
+            self._dmap = runtime.engine().shared_map(self._xyz, self.colour)
         return self._dmap
 
 

@@ -229,6 +229,32 @@ class Engine:
     def upload_map(self, xyz, colour_id, spatial_sort="auto"):
         return DeviceMap(xyz, colour_id, self.device, spatial_sort=spatial_sort)
 
+    def shared_map(self, xyz, colour_id, spatial_sort="auto"):
+        """Content-keyed DeviceMap: clips whose static maps are the same bytes -- CAMA v2's site-aggregated labels: every
+        scene of a site carries the site's labels (main.py:42, cama/reproject.py:26-27) -- share ONE device copy on this
+        GPU: one upload, one Morton sort, one block index per site, however many ClipManagers ask.  Weak: a map goes when
+        its last clip goes.  `map_cache_stats` counts uploads and hits."""
+        import weakref
+        import xxhash
+        xyz = np.asarray(xyz)
+        if xyz.dtype not in (np.float32, np.float64):
+            xyz = xyz.astype(np.float64)
+        col = np.ascontiguousarray(colour_id, dtype=np.uint8)
+        h = xxhash.xxh3_128()
+        h.update(np.ascontiguousarray(xyz).view(np.uint8).reshape(-1).data)
+        h.update(col.data)
+        key = (h.hexdigest(), xyz.shape, str(xyz.dtype), str(spatial_sort))
+        cache = self.__dict__.setdefault("_map_cache", weakref.WeakValueDictionary())
+        stats = self.__dict__.setdefault("map_cache_stats", {"uploads": 0, "hits": 0})
+        dmap = cache.get(key)
+        if dmap is None:
+            dmap = DeviceMap(xyz, col, self.device, spatial_sort=spatial_sort)
+            cache[key] = dmap
+            stats["uploads"] += 1
+        else:
+            stats["hits"] += 1
+        return dmap
+
     def make_rig(self, names, chassis2camera, K, W, H):
         return CameraRig(names, chassis2camera, K, W, H, self.device)
 

@@ -11,20 +11,59 @@ import numpy as np
 RECORD_FIELDS = ("frames", "seconds", "overlay_ms", "overlay_launches", "verts", "bytes", "frames_per_launch", "aux")
 
 
-def assign_scenes(costs, world):
+def assign_scenes(costs, world, site_of=None, site_cost=0.0):
     """Longest-processing-time-first assignment of scenes to `world` ranks.
 
     costs: per-scene cost estimate, e.g. F * (13 N + 36 W H) bytes.  Returns a list of `world` lists of scene
-    indices (each sorted).  Deterministic; ties broken by scene index.  Round-robin falls out for equal costs."""
+    indices (each sorted).  Deterministic; ties broken by scene index.  Round-robin falls out for equal costs.
+
+    site_of (optional, one site id per scene): scenes of one site share the site's static vertex buffer (CAMA v2's
+    site-aggregated labels) and every rank that renders one of them has to load, sort and index that
+    buffer (`site_cost`, in the units of `costs`, per (rank, site)).  Scenes are therefore placed site by site: a
+    site goes to the least loaded rank, which takes as many of its scenes as fit under the fair share of the job; only
+    what does not fit moves on to another rank (and pays the site's load again)."""
     costs = np.asarray(costs, np.float64)
-    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    if site_of is None:
+        order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+        load = [0.0] * world
+        out = [[] for _ in range(world)]
+        for i in order:
+            r = min(range(world), key=lambda k: (load[k], k))
+            out[r].append(i)
+            load[r] += float(costs[i])
+        return [sorted(s) for s in out]
+    site_of = list(site_of)
+    assert len(site_of) == len(costs)
+    groups = {}
+    for i, sid in enumerate(site_of):
+        groups.setdefault(sid, []).append(i)
+    # fair share of a rank, counting one load per site and at least one load per rank
+    fair = (float(costs.sum()) + site_cost * max(len(groups), world)) / world
+    site_total = {sid: float(costs[m].sum()) for sid, m in groups.items()}
     load = [0.0] * world
     out = [[] for _ in range(world)]
-    for i in order:
-        r = min(range(world), key=lambda k: (load[k], k))
-        out[r].append(i)
-        load[r] += float(costs[i])
+    # sites longest first; each goes to the least loaded rank, which takes as many of its scenes as fit under the fair
+    # share (always at least one); what does not fit moves on to the next least loaded rank, paying the load again
+    for sid in sorted(groups, key=lambda g: (-site_total[g], groups[g][0])):
+        todo = sorted(groups[sid], key=lambda i: (-costs[i], i))
+        while todo:
+            r = min(range(world), key=lambda k: (load[k], k))
+            load[r] += site_cost
+            took = 0
+            rest = float(costs[todo].sum())
+            while todo and (took == 0 or load[r] + float(costs[todo[0]]) <= 1.02 * fair or
+                            load[r] + rest <= 1.10 * fair):
+                i = todo.pop(0)
+                out[r].append(i)
+                load[r] += float(costs[i])
+                rest -= float(costs[i])
+                took += 1
     return [sorted(s) for s in out]
+
+
+def sites_per_rank(assignment, site_of):
+    """[sorted site ids each rank has to load] for an assign_scenes() result."""
+    return [sorted({site_of[i] for i in scenes}) for scenes in assignment]
 
 
 def frame_ranges(n_frames, world):

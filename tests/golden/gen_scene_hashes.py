@@ -103,7 +103,7 @@ def update(key, units):
 def main():
     import bench
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["sweep", "stress", "small"])
+    ap.add_argument("what", choices=["sweep", "stress", "small", "site"])
     ap.add_argument("--scenes", type=int, default=bench.SWEEP_SCENES)
     ap.add_argument("--jobs", type=int, default=min(8, os.cpu_count() or 1))
     a = ap.parse_args()
@@ -113,6 +113,8 @@ def main():
             res = pool.map(scene_hash, [(bargs, s) for s in range(a.scenes)], chunksize=1)
         update(bench.workload_key(bargs.frames, bargs.verts, bargs.width, bargs.height, "lanes"),
                {str(s): [lo, hi] for s, lo, hi in res})
+    elif a.what == "site":
+        site_twin(a.jobs)
     elif a.what == "stress":
         bargs = bench.parse_args([])
         bargs.map, bargs.verts, bargs.frames = "random", bench.STRESS["verts"], bench.STRESS["frames"]
@@ -127,6 +129,18 @@ def main():
         bargs = bench.parse_args(["--frames", "125", "--verts", "1000000", "--height", "180", "--width", "320", "--map", "random"])
         units = frame_hashes(bargs, 0, [0, 1, 31, 62, 93, 124])
         update(bench.workload_key(125, 1000000, 320, 180, "random", unit="frame"), units)
+        site_twin(a.jobs)
+
+
+def site_twin(jobs):
+    """configs[3] twin for tests/test_gpu_configs.py: 2 sites of 60 000 vertices, 8 scenes (scene k on site k % 2, its own
+    drive), 6 frames at 320x180."""
+    import bench
+    bargs = bench.parse_args(["--frames", "6", "--verts", "60000", "--height", "180", "--width", "320", "--map", "site",
+                              "--sites", "2", "--scenes", "8"])
+    with mp.get_context("spawn").Pool(jobs) as pool:
+        res = pool.map(scene_hash, [(bargs, s) for s in range(8)], chunksize=1)
+    update(bench.args_key(bargs), {str(s): [lo, hi] for s, lo, hi in res})
 
 
 if __name__ == "__main__":

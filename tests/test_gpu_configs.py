@@ -241,3 +241,46 @@ def test_fullsize_stress_sampled_frames_equal_the_oracle():
         eng.join()
         torch.cuda.synchronize()
         assert shard.overlay_hash(many[pos - lo]) == golden[pos], f"stress frame {pos} (in an 8-frame launch)"
+
+
+def test_site_aggregated_scenes_share_one_device_map():
+    """configs[3] as SURVEY.md D6 defines it: several scenes driven on ONE site map (2 sites x 4 scenes, 60 000 vertices
+    per site, every scene its own pose track and calibration).  Each ClipManager carries its own host copy of the site's
+    labels (main.py:42 reads them per scene); on the device they are ONE vertex buffer per site -- uploaded, sorted and
+    indexed once -- and every scene's mosaic hash equals the oracle's render of that scene."""
+    import torch
+    from cama_amd import runtime
+    a = _args(frames=6, verts=60000, height=180, width=320, map="site", sites=2, scenes=8)
+    key = bench.args_key(a)
+    golden = shard.load_golden_hashes(GOLDEN, key)
+    assert len(golden) == 8, key
+    dev = torch.device("cuda:0")
+    eng = runtime.engine()
+    before = dict(getattr(eng, "map_cache_stats", {"uploads": 0, "hits": 0}))
+    scenes = [bench.build_scene(a, s, dev) for s in range(8)]
+    out = torch.zeros((8,) + tuple(eng.mosaic_shape(scenes[0][0]._rig(), a.frames)), dtype=torch.uint8, device=dev)
+    for k, (cm, _, _) in enumerate(scenes):
+        cm.render_clip("cama", out=out[k], pipelined=True)
+    eng.join()
+    torch.cuda.synchronize()
+    stats = eng.map_cache_stats
+    assert stats["uploads"] - before["uploads"] == 2, stats          # one per site, not one per scene
+    assert stats["hits"] - before["hits"] == 6, stats
+    dmaps = [cm._static("cama").device() for cm, _, _ in scenes]
+    for k in range(8):
+        assert dmaps[k] is dmaps[k % 2] and dmaps[k].N == 60000
+        assert scenes[k][0].instance_maps["cama"] is not scenes[k % 2][0].instance_maps["cama"] or k < 2
+    assert dmaps[0] is not dmaps[1] and dmaps[0].soa.data_ptr() != dmaps[1].soa.data_ptr()
+    bad = [k for k in range(8) if shard.overlay_hash(out[k]) != golden[k]]
+    assert not bad, f"scenes {bad}: render on the shared site map differs from the oracle's"
+    # the tracks really differ: scenes of one site do not render the same pixels
+    assert len({shard.overlay_hash(out[k]) for k in range(8)}) == 8
+    # the cache is weak: dropping every scene of site 1 frees its device map
+    import gc
+    import weakref
+    ref = weakref.ref(dmaps[1])
+    del dmaps
+    scenes = [sc for k, sc in enumerate(scenes) if k % 2 == 0]
+    eng.join()
+    gc.collect()
+    assert ref() is None

@@ -133,3 +133,81 @@ def test_overlay_hash_detects_a_single_byte():
     c = a.reshape(125, 8).clone()
     c[[3, 4]] = c[[4, 3]]
     assert shard.overlay_hash(c)[0] == shard.overlay_hash(a)[0] and shard.overlay_hash(c)[1] != shard.overlay_hash(a)[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# site affinity (BASELINE configs[3]: scenes of one site share the site's static vertex buffer)
+# ---------------------------------------------------------------------------------------------------------------
+def test_assign_scenes_keeps_a_site_on_as_few_ranks_as_balance_allows():
+    site_of = [k // 6 for k in range(24)]                                   # 4 sites x 6 scenes
+    two = shard.assign_scenes([1.0] * 24, 2, site_of=site_of, site_cost=0.3)
+    assert shard.sites_per_rank(two, site_of) == [[0, 2], [1, 3]]           # whole sites, two per rank
+    eight = shard.assign_scenes([1.0] * 24, 8, site_of=site_of, site_cost=0.3)
+    assert [len(p) for p in eight] == [3] * 8                               # more ranks than sites: each site on 2 ranks
+    assert all(len(s) == 1 for s in shard.sites_per_rank(eight, site_of))
+    # no site id: the plain longest-processing-time-first assignment, unchanged
+    assert shard.assign_scenes([1.0] * 73, 8, site_of=None) == shard.assign_scenes([1.0] * 73, 8)
+    # every scene exactly once, balance within 15 % of the mean, for uneven costs and awkward site counts
+    rng = np.random.default_rng(0)
+    for n, world, n_sites in ((73, 8, 10), (73, 8, 3), (40, 4, 7), (9, 8, 2)):
+        costs = rng.uniform(0.5, 2.0, n)
+        site_of = [k % n_sites for k in range(n)]
+        parts = shard.assign_scenes(costs, world, site_of=site_of, site_cost=0.2)
+        assert sorted(i for p in parts for i in p) == list(range(n))
+        loads = [costs[p].sum() + 0.2 * len(s) for p, s in zip(parts, shard.sites_per_rank(parts, site_of))]
+        if n >= 4 * world:
+            assert max(loads) <= 1.15 * np.mean(loads), (n, world, n_sites, loads)
+        # affinity: far fewer (rank, site) pairs than the site-blind assignment produces
+        blind = shard.assign_scenes(costs, world)
+        pairs = sum(len(s) for s in shard.sites_per_rank(parts, site_of))
+        assert pairs <= sum(len(s) for s in shard.sites_per_rank(blind, site_of))
+
+
+def _site_worker(rank, world, port, q):
+    """Two ranks, 2 sites x 4 scenes: every rank builds the site maps of ITS scenes only (a set, as the content-keyed
+    device cache would hold them), "renders" its scenes against them, and the usual single all_gather carries the scene
+    hashes plus the number of site maps the rank had to load."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_scenes, n_sites = 8, 2
+        site_of = [k % n_sites for k in range(n_scenes)]
+        costs = [shard.scene_cost(6, 60000, 320, 180)] * n_scenes
+        mine = shard.assign_scenes(costs, world, site_of=site_of, site_cost=40.0 * 60000)[rank]
+        loaded = {}
+        hashes = []
+        for s in mine:
+            site = site_of[s]
+            if site not in loaded:                              # one "upload" per site per rank
+                loaded[site] = (torch.arange(4096, dtype=torch.int64) * (site + 11) % 253).to(torch.uint8)
+            m = _fake_mosaic(s) ^ loaded[site][:_fake_mosaic(s).numel() % 4096 + 1].sum().to(torch.uint8)
+            hashes.append((s,) + shard.overlay_hash(m))
+        metrics = [6.0 * len(mine), 1.0, float(len(loaded)), 0.0]
+        allrep = shard.gather_reports(shard.pack_report(metrics, hashes, n_scenes))
+        m, found, owner = shard.unpack_reports(allrep, len(metrics))
+        q.put((rank, mine, sorted(loaded), m[:, 2].tolist(), sorted(found), owner))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_site_affinity():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_site_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, l0, up0, f0, o0), (r1, s1, l1, up1, f1, o1) = got
+    assert sorted(s0 + s1) == list(range(8)) and f0 == f1 == list(range(8))
+    assert len(l0) == 1 and len(l1) == 1 and l0 != l1           # each rank loaded exactly one site, a different one
+    assert up0 == up1 == [1.0, 1.0]                             # ... and the gathered report says so on every rank
+    assert {k % 2 for k in s0} == set(l0) and {k % 2 for k in s1} == set(l1)

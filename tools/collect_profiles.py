@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs a gpurun call left under gpurun_out/ into the small summaries committed
-under profiles/ (the judged artefacts), and derive profiles/pmc_traffic.json for bench.py.
+"""Turn the rocprofv3 outputs a gpurun call left under gpurun_out/<tag>_<name>_* into the small summaries committed under
+profiles/ (the judged artefacts).
 
-    python tools/collect_profiles.py r01          # reads gpurun_out/r01_* , writes profiles/r01_*
+    python tools/collect_profiles.py r03 site1e6      # reads gpurun_out/r03_site1e6_{stats,pmc_fetch,pmc_write}*
+                                                      # writes profiles/r03_site1e6_{kernel_stats.csv,pmc_traffic.json,bench.json}
 
-HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are collected
-in SEPARATE --pmc passes (TCC slot limit), both are in KiB, and on gfx950 FETCH_SIZE reports exactly half of a
-wide coalesced streaming read, so it is doubled; both corrections are re-checked in the same run against a
-device copy of known size (the pmc_probe.py calibration copy).
-"""
+What tools/profile_workload.sh leaves behind per workload:
+    <tag>_<name>_bench.json        the plain bench line
+    <tag>_<name>_stats/            rocprofv3 --kernel-trace --stats of the same bench command (+ _stats.log = its line)
+    <tag>_<name>_pmc_fetch/, _pmc_write/   rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE of tools/pmc_probe.py
+                                   (+ .log = the probe's JSON line)
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are collected in
+SEPARATE --pmc passes (TCC slot limit), both are in KiB, and on gfx950 FETCH_SIZE reports exactly half of a wide
+coalesced streaming read, so it is doubled; both corrections are re-checked in the same run against a device copy of
+known size (the probe's calibration copy).  Traffic is reported per kernel and priced against THAT kernel's algorithmic
+bytes: the overlay's 36*W*H*F (raw: 3*C*(H0*W0 + H*W)*F), the projection's 13 B x vertices fetched + 8 B x stamps."""
 import collections
 import csv
 import glob
@@ -20,7 +27,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def first(pattern):
+def newest(pattern):
     """The NEWEST match: gpurun merges every session's outputs into gpurun_out/, rocprofv3 names them by process id."""
     hits = glob.glob(os.path.join(REPO, "gpurun_out", pattern))
     return max(hits, key=os.path.getmtime) if hits else None
@@ -34,56 +41,78 @@ def counters(path, name):
     return per
 
 
-def main(tag):
+def json_line(path):
+    if not path or not os.path.exists(path):
+        return None
+    lines = [l for l in open(path) if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+def mean(v):
+    return sum(v) / len(v) if v else None
+
+
+def main(tag, name):
     out = os.path.join(REPO, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats = first(f"{tag}_bench_stats/*/*kernel_stats.csv")
+    base = f"{tag}_{name}"
+    plain = os.path.join(REPO, "gpurun_out", f"{base}_bench.json")
+    if json_line(plain):
+        json.dump(json_line(plain), open(os.path.join(out, f"{base}_bench.json"), "w"))
+    stats = newest(f"{base}_stats/*/*kernel_stats.csv") or newest(f"{base}_stats/*kernel_stats.csv")
     if stats:
-        shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
-        log = os.path.join(REPO, "gpurun_out", f"{tag}_bench_stats.log")
-        if os.path.exists(log):
-            lines = [l for l in open(log) if l.startswith("{")]
-            open(os.path.join(out, f"{tag}_bench_under_rocprof.json"), "w").write("".join(lines))
-    fetch = first(f"{tag}_pmc_fetch/*/*counter_collection.csv")
-    write = first(f"{tag}_pmc_write/*/*counter_collection.csv")
-    if fetch and write:
-        fs, ws = counters(fetch, "FETCH_SIZE"), counters(write, "WRITE_SIZE")
-        log = open(os.path.join(REPO, "gpurun_out", f"{tag}_pmc_fetch.log")).read().split()
-        calib_bytes = int(log[log.index("calib_bytes") + 1])
-        N = int(log[log.index("N") + 1])
-        rows = []
-        for k in sorted(set(fs) | set(ws)):
-            f, w = fs.get(k, []), ws.get(k, [])
-            rows.append({"kernel": k[:90], "dispatches": max(len(f), len(w)),
-                         "FETCH_SIZE_KiB_mean": sum(f) / len(f) if f else None,
-                         "WRITE_SIZE_KiB_mean": sum(w) / len(w) if w else None})
-        with open(os.path.join(out, f"{tag}_pmc_hbm_summary.csv"), "w", newline="") as fh:
-            wr = csv.DictWriter(fh, fieldnames=list(rows[0]))
-            wr.writeheader()
-            wr.writerows(rows)
-        # calibration: the big device copies (the runtime's copy kernel), known byte count each way
-        ck = [k for k in fs if "copyBuffer" in k]
-        # (only the calibration copies themselves: other device copies of other sizes share the kernel name)
-        big_f = [v for k in ck for v in fs[k] if 0.4 * calib_bytes < v * 1024 < 1.2 * calib_bytes]
-        big_w = [v for k in ck for v in ws.get(k, []) if 0.8 * calib_bytes < v * 1024 < 1.2 * calib_bytes]
-        cal = {"calib_bytes_each_way": calib_bytes,
-               "FETCH_SIZE_ratio": (sum(big_f) / len(big_f)) * 1024 / calib_bytes if big_f else None,
-               "WRITE_SIZE_ratio": (sum(big_w) / len(big_w)) * 1024 / calib_bytes if big_w else None}
-        ok = [k for k in fs if "k_overlay" in k][0]
-        f_kib, w_kib = sum(fs[ok]) / len(fs[ok]), sum(ws[ok]) / len(ws[ok])
-        fetch_corr = 2.0 if cal["FETCH_SIZE_ratio"] and abs(cal["FETCH_SIZE_ratio"] - 0.5) < 0.05 else 1.0
-        traffic = (f_kib * fetch_corr + w_kib) * 1024
-        W, H, F = 1600, 900, 40
-        rec = {"kernel": "k_overlay", "config": f"N={N},F={F},{W}x{H}", "bytes_per_launch": traffic,
-               "fetch_bytes": f_kib * fetch_corr * 1024, "write_bytes": w_kib * 1024,
-               "fetch_correction": fetch_corr, "calibration": cal,
-               "algorithmic_bytes_per_launch": (13 * N + 36 * W * H) * F,
-               "traffic_over_algorithmic": traffic / ((13 * N + 36 * W * H) * F),
-               "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python tools/pmc_probe.py; tag {tag}"}
-        json.dump(rec, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-        json.dump(rec, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-        print(json.dumps(rec, indent=1))
+        shutil.copy(stats, os.path.join(out, f"{base}_kernel_stats.csv"))
+        line = json_line(os.path.join(REPO, "gpurun_out", f"{base}_stats.log"))
+        if line:
+            json.dump(line, open(os.path.join(out, f"{base}_bench_under_rocprof.json"), "w"))
+    fetch = newest(f"{base}_pmc_fetch/*/*counter_collection.csv") or newest(f"{base}_pmc_fetch/*counter_collection.csv")
+    write = newest(f"{base}_pmc_write/*/*counter_collection.csv") or newest(f"{base}_pmc_write/*counter_collection.csv")
+    probe = json_line(os.path.join(REPO, "gpurun_out", f"{base}_pmc_fetch.log"))
+    if not (fetch and write and probe):
+        print(f"{base}: no PMC passes found (fetch={fetch}, write={write}, probe line={bool(probe)})")
+        return
+    fs, ws = counters(fetch, "FETCH_SIZE"), counters(write, "WRITE_SIZE")
+    calib = probe["calib_bytes"]
+    ck = [k for k in fs if "copyBuffer" in k or "elementwise" in k]
+    big_f = [v for k in ck for v in fs[k] if 0.4 * calib < v * 1024 < 1.2 * calib]
+    big_w = [v for k in ck for v in ws.get(k, []) if 0.8 * calib < v * 1024 < 1.2 * calib]
+    cal = {"calib_bytes_each_way": calib,
+           "FETCH_SIZE_ratio": mean(big_f) * 1024 / calib if big_f else None,
+           "WRITE_SIZE_ratio": mean(big_w) * 1024 / calib if big_w else None}
+    corr = 2.0 if cal["FETCH_SIZE_ratio"] and abs(cal["FETCH_SIZE_ratio"] - 0.5) < 0.05 else 1.0
+    N, F, W, H = probe["N"], probe["F"], probe["W"], probe["H"]
+    st = probe.get("bin_stats") or {}
+    image = 3 * 6 * (900 * 1600 + H * W) * F if probe.get("raw") else 36 * W * H * F
+    algo = {"k_overlay": image,
+            "k_frames_project": (st.get("vertex_bytes_read", 13 * N * F) + 8 * st.get("stamps", 0)) if st else None,
+            "k_stamps_scatter": (8 * st["stamps"] + 8 * st["band_entries"]) if st else None}
+    rows, kernels = [], {}
+    for k in sorted(set(fs) | set(ws)):
+        f, w = fs.get(k, []), ws.get(k, [])
+        short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
+        rows.append({"kernel": short, "dispatches": max(len(f), len(w)), "FETCH_SIZE_KiB_mean": mean(f),
+                     "WRITE_SIZE_KiB_mean": mean(w)})
+        for key in algo:
+            if short.startswith(key) and f and w:
+                fb, wb = mean(f) * corr * 1024, mean(w) * 1024
+                kernels[short] = {"fetch_bytes": fb, "write_bytes": wb, "traffic_bytes": fb + wb,
+                                  "algorithmic_bytes": algo[key],
+                                  "traffic_over_algorithmic": (fb + wb) / algo[key] if algo[key] else None}
+    with open(os.path.join(out, f"{base}_pmc_hbm_summary.csv"), "w", newline="") as fh:
+        wr = csv.DictWriter(fh, fieldnames=list(rows[0]))
+        wr.writeheader()
+        wr.writerows(rows)
+    ov = next((v for k, v in kernels.items() if k.startswith("k_overlay")), None)
+    rec = {"config": f"N={N},F={F},{W}x{H}" + ("" if probe["map"] == "lanes" else f",map={probe['map']}") +
+                     (",raw1600x900" if probe.get("raw") else ""),
+           "kernel": "k_overlay", "bytes_per_launch": ov["traffic_bytes"] if ov else None,
+           "fetch_correction": corr, "calibration": cal, "kernels": kernels, "probe": probe,
+           "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python tools/pmc_probe.py; "
+                     f"tag {base}"}
+    json.dump(rec, open(os.path.join(out, f"{base}_pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps({k: {"traffic/algorithmic": v["traffic_over_algorithmic"], "traffic_MB": v["traffic_bytes"] / 1e6}
+                      for k, v in kernels.items()}, indent=1), json.dumps(cal))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1], sys.argv[2])

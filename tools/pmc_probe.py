@@ -1,20 +1,43 @@
-"""PMC probe: a known-size streaming copy (calibration) followed by a few whole-scene renders.
-Run under `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes)."""
-import os, sys
+"""PMC probe: a known-size streaming copy (calibration) followed by a few whole-scene renders of one bench workload.
+Run under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes: TCC slot limit).
+
+    N=1000000 MAP=site F=40 python tools/pmc_probe.py        # env: N, F, H, W, MAP (lanes|random|site), RAW=1
+
+Prints one JSON line (calibration bytes, the workload, cama_bin_stats of one launch) that tools/collect_profiles.py reads."""
+import argparse
+import json
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import argparse, torch
-sys.argv = [sys.argv[0]] + sys.argv[1:]
-import bench
-ap = argparse.Namespace(frames=40, verts=int(os.environ.get("N", 10000)), height=int(os.environ.get("H", 900)), width=int(os.environ.get("W", 1600)), map="lanes")
-dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
-cm, frames, clip = bench.build_scene(ap, 0, dev)
-from cama_amd import runtime
-eng = runtime.engine(); rig = cm._rig()
-out = torch.empty(eng.mosaic_shape(rig, 40), dtype=torch.uint8, device=dev)
-# calibration: elementwise copy of exactly frames[1:] bytes (read B, write B)
-a = frames[1:].reshape(-1); b = torch.empty_like(a)
-for _ in range(3): b.copy_(a)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+E = os.environ.get
+a = bench.parse_args([])
+a.frames, a.verts, a.height, a.width, a.map = int(E("F", 40)), int(E("N", 10000)), int(E("H", 900)), int(E("W", 1600)), E("MAP", "lanes")
+a.raw_frames = E("RAW") == "1"
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+cm, frames, clip = bench.build_scene(a, 0, dev)
+from cama_amd import runtime  # noqa: E402
+eng = runtime.engine()
+rig = cm._rig()
+dmap = cm._static("cama").device()
+per = max(1, min(a.frames, eng.max_frames_per_call(dmap, rig)))
+out = torch.empty(eng.mosaic_shape(rig, per), dtype=torch.uint8, device=dev)
+idx, w2c = cm.frame_poses("cama")
+poses = (idx[:per], w2c[:per])
+# calibration: elementwise copy of a known byte count (read B, write B)
+src = frames[1:1 + min(per, 40)].reshape(-1)
+dst = torch.empty_like(src)
+for _ in range(3):
+    dst.copy_(src)
 torch.cuda.synchronize()
-for _ in range(5): cm.render_clip("cama", out=out)
+for _ in range(5):
+    cm.render_clip("cama", out=out, poses=poses, frames_per_launch=per)
 torch.cuda.synchronize()
-print("calib_bytes", a.numel(), "N", cm._static("cama").device().N)
+stats = None if a.raw_frames else eng.bin_stats()
+print(json.dumps({"calib_bytes": src.numel(), "N": dmap.N, "F": per, "W": a.width, "H": a.height, "map": a.map,
+                  "raw": a.raw_frames, "bin_stats": stats}))
