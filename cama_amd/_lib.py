@@ -10,7 +10,7 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 11
+ABI_VERSION = 12
 BIN_WORKLIST = 1
 
 _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
@@ -49,6 +49,11 @@ SIGNATURES = {
                                     _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cama_pipeline_render_raw35": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i32,
                                           _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cama_bin_scenes": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "cama_overlay_scenes": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "cama_render_scenes": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "cama_pipeline_render_scenes": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
+                                           _vp, _vp, _sz, _vp]),
     "cama_pipeline_stage_poses": (_i32, [_vp, _vp, _i32, _vp]),
     "cama_pipeline_join": (_i32, [_vp, _vp]),
     "cama_pipeline_issued": (_i64, [_vp]),

@@ -419,17 +419,21 @@ static bool ext_events()
     return v;
 }   // consumed by the next overlay launch (cama_overlay_frames_alpha)
 
-int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
-                    const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N, const double *w2c, int32_t F,
-                    const double *c2cam, const double *K, int32_t C,
+}  // extern "C"
+
+// cama_bin_frames / cama_bin_scenes.  scenes_dev != nullptr: multi-scene launch -- F counts ALL frames of the launch,
+// frames_per_scene of them per scene, N = the largest scene's vertex count, x .. K are ignored (per-scene, from the table).
+static int bin_impl(const SceneRef *scenes_dev, int frames_per_scene, const void *x, const void *y, const void *z,
+                    int32_t xyz_is_f64, const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds,
+                    int32_t flags, int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
                     const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch, size_t scratch_bytes,
                     void *stream)
 {
     ScratchLayout L;
     if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
     if (F == 0) return CAMA_OK;
-    if (!w2c || !c2cam || !K || !crop) return fail(CAMA_EINVAL, "NULL pointer argument");
-    if (N && (!x || !y || !z || (!colour_id && !draw_key))) return fail(CAMA_EINVAL, "NULL vertex buffer");
+    if (!w2c || !crop || (!scenes_dev && (!c2cam || !K))) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (!scenes_dev && N && (!x || !y || !z || (!colour_id && !draw_key))) return fail(CAMA_EINVAL, "NULL vertex buffer");
 
     hipStream_t s = (hipStream_t)stream;
     char *base = (char *)scratch;
@@ -442,6 +446,7 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     HIP_TRY(hipMemsetAsync(counts, 0, L.zero_bytes, s));
 
     FrameArgs a{};
+    a.scenes = scenes_dev; a.frames_per_scene = frames_per_scene;
     a.x = x; a.y = y; a.z = z; a.colour = colour_id; a.key = draw_key; a.bounds = block_bounds; a.N = N;
     a.w2c = w2c; a.c2cam = c2cam; a.K = K; a.C = C; a.W = W; a.H = H;
     memcpy(a.crop.v, crop, sizeof(a.crop.v));
@@ -537,6 +542,18 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
     return CAMA_OK;
 }
 
+extern "C" {
+
+int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
+                    const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N, const double *w2c, int32_t F,
+                    const double *c2cam, const double *K, int32_t C,
+                    const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch, size_t scratch_bytes,
+                    void *stream)
+{
+    return bin_impl(nullptr, 0, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H,
+                    radius, scratch, scratch_bytes, stream);
+}
+
 // Diagnostic read-back of what a finished cama_bin_frames left in `scratch` (blocks the host on `stream`): how much of the
 // vertex buffer the projection actually read and how many stamps it produced -- the figures bench.py prices the
 // projection's roofline with.
@@ -587,13 +604,14 @@ struct RawSource {
 
 static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosaic, int64_t N, int32_t F, int32_t C,
                         int32_t H, int32_t W, int32_t cols, int32_t radius, const int32_t *halfwidth,
-                        const uint8_t *palette_bgr, const void *scratch, size_t scratch_bytes, void *stream)
+                        const uint8_t *palette_bgr, const void *scratch, size_t scratch_bytes, void *stream,
+                        const SceneRef *scenes_dev = nullptr, int frames_per_scene = 0)
 {
     ScratchLayout L;
     if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
     if (F == 0) return CAMA_OK;
     if (cols < 1) return fail(CAMA_EINVAL, "cols=%d", cols);
-    if (!src || !mosaic || !palette_bgr) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if ((!scenes_dev && (!src || !mosaic)) || !palette_bgr) return fail(CAMA_EINVAL, "NULL pointer argument");
     Disc disc;
     if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
     // (A/B knob: CAMA_OVERLAY_LDS_PAD=bytes inflates the allocation, i.e. lowers the overlay's workgroups per CU)
@@ -609,6 +627,7 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
 #endif
 
     OverlayArgs o{};
+    o.scenes = scenes_dev; o.frames_per_scene = frames_per_scene;
     o.src = src; o.mosaic = mosaic; o.C = C; o.H = H; o.W = W; o.cols = cols; o.R = L.R; o.NB = L.NB;
     const int rows = (C + cols - 1) / cols;
     o.mosaic_row_bytes = (size_t)cols * W * 3;
@@ -617,7 +636,8 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)(base + L.stamps);
     o.disc = disc; o.pal = make_palette(palette_bgr, g_next_alpha256);
     g_next_alpha256 = 256u;
-    const bool vec = (W % 16 == 0) && ((((raw ? 0 : (uintptr_t)src)) | (uintptr_t)mosaic) % 16 == 0);
+    // (multi-scene launches: the caller has checked every scene's src / mosaic alignment and W % 16 == 0)
+    const bool vec = (W % 16 == 0) && (scenes_dev || ((((raw ? 0 : (uintptr_t)src)) | (uintptr_t)mosaic) % 16 == 0));
     if (vec) {
         o.cpr = (uint32_t)(W * 3 / 16);
         o.cpr_magic = (uint32_t)(((1ull << 32) + o.cpr - 1) / o.cpr);
@@ -641,6 +661,7 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // Live timing of this launch (cama_profile_enable): the dominant kernel takes the two events as ITS OWN start / stop
     // events (hipExtLaunchKernelGGL), i.e. the kernel's duration itself, the figure rocprofv3 --kernel-trace reports;
@@ -648,6 +669,8 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     // separate record (an event can ride on a launch only once).
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool exact_timing = g_prof.on && !raw && o.pal.alpha256 == 256u && vec;
+    if (scenes_dev && (raw || !vec || o.pal.alpha256 != 256u))
+        return fail(CAMA_EINVAL, "multi-scene launches support the plain overlay only (W %% 16 == 0, opaque, pre-resized frames)");
     if (g_prof.on) {
         ev0 = prof_event();
         ev1 = prof_event();
@@ -680,6 +703,12 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
             hipLaunchKernelGGL((k_overlay<true, false, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
         else
             hipLaunchKernelGGL((k_overlay<false, false, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+    } else if (scenes_dev) {
+        // (events: start/stop when profiling, else the pipeline's completion event as the stop event, else none)
+        hipEvent_t e0 = (exact_timing && ev0 && ev1) ? ev0 : nullptr;
+        hipEvent_t e1 = e0 ? ev1 : g_overlay_stop_event;
+        hipExtLaunchKernelGGL((k_overlay<true, false, false, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), (uint32_t)lds, s, e0, e1, 0u, o);
+        if (!e0) g_overlay_stop_event = nullptr;
     } else if (vec) {
         if (exact_timing && ev0 && ev1) {
             hipExtLaunchKernelGGL((k_overlay<true, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), (uint32_t)lds, s, ev0, ev1, 0u, o);
@@ -1054,12 +1083,10 @@ int64_t cama_pipeline_completed(cama_pipeline *p)
 }  // extern "C"
 
 // shared body of the pipelined renders: bin on s_bin, then `overlay(scratch, stream)` on s_ov
-template <typename Overlay>
-static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
-                                const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
-                                const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
-                                const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch0, void *scratch1,
-                                size_t scratch_bytes, void *input_stream, bool overlay_takes_stop_event, Overlay overlay)
+template <typename Bin, typename Overlay>
+static int pipeline_impl(cama_pipeline *p, int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, int32_t radius,
+                         void *scratch0, void *scratch1, size_t scratch_bytes, void *input_stream,
+                         bool overlay_takes_stop_event, Bin bin, Overlay overlay)
 {
     if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
     if (!scratch0 || !scratch1) return fail(CAMA_EINVAL, "two scratch buffers are needed");
@@ -1085,8 +1112,7 @@ static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, 
         // the chain's last kernel (k_stamps_scatter, launched whenever N > 0) carries `binned` as its own stop event
         const bool ext = ext_events() && N > 0;
         g_scatter_stop_event = ext ? p->binned[slot] : nullptr;
-        if (int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H,
-                                     radius, scratch, scratch_bytes, p->s_bin)) {
+        if (int rc = bin(scratch, (void *)p->s_bin)) {
             g_scatter_stop_event = nullptr;
             return rc;
         }
@@ -1110,7 +1136,101 @@ static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, 
     return CAMA_OK;
 }
 
+template <typename Overlay>
+static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
+                                const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
+                                const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                                const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch0, void *scratch1,
+                                size_t scratch_bytes, void *input_stream, bool overlay_takes_stop_event, Overlay overlay)
+{
+    return pipeline_impl(p, N, F, C, W, H, radius, scratch0, scratch1, scratch_bytes, input_stream, overlay_takes_stop_event,
+                         [&](void *scratch, void *sb) {
+                             return cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F,
+                                                    c2cam, K, C, crop, W, H, radius, scratch, scratch_bytes, sb);
+                         },
+                         overlay);
+}
+
+// ------------------------------------------------------------------------------------------
+// many scenes per launch
+// ------------------------------------------------------------------------------------------
+// validate the host copy of the scene table; returns the largest vertex count through *nmax
+static int check_scenes(const cama_scene *sh, const cama_scene *sd, int32_t S, int32_t F, bool need_images, int64_t *nmax)
+{
+    if (!sh || !sd) return fail(CAMA_EINVAL, "scene table is NULL");
+    if (S < 1 || S > 65535) return fail(CAMA_EINVAL, "S=%d out of range [1, 65535]", S);
+    if (F < 0 || (int64_t)S * F > 65535) return fail(CAMA_EINVAL, "S*F = %lld frames per launch out of range [0, 65535]", (long long)S * F);
+    int64_t m = 0;
+    for (int k = 0; k < S; ++k) {
+        const cama_scene &c = sh[k];
+        if (c.N < 0 || c.N >= (1ll << 30)) return fail(CAMA_EINVAL, "scene %d: N=%lld out of range", k, (long long)c.N);
+        if (c.N && (!c.x || !c.y || !c.z || (!c.colour_id && !c.draw_key))) return fail(CAMA_EINVAL, "scene %d: NULL vertex buffer", k);
+        if (!c.c2cam || !c.K) return fail(CAMA_EINVAL, "scene %d: NULL calibration", k);
+        if (need_images && F && (!c.src || !c.mosaic || ((uintptr_t)c.src | (uintptr_t)c.mosaic) % 16))
+            return fail(CAMA_EINVAL, "scene %d: frames / mosaic are NULL or not 16-byte aligned", k);
+        m = std::max(m, c.N);
+    }
+    *nmax = m;
+    return CAMA_OK;
+}
+
 extern "C" {
+
+int cama_bin_scenes(const cama_scene *scenes_host, const cama_scene *scenes_dev, int32_t S, int32_t xyz_is_f64,
+                    const double *w2c, int32_t F, int32_t C, const double *crop, int32_t W, int32_t H, int32_t radius,
+                    void *scratch, size_t scratch_bytes, void *stream)
+{
+    int64_t nmax = 0;
+    if (int rc = check_scenes(scenes_host, scenes_dev, S, F, false, &nmax)) return rc;
+    return bin_impl(reinterpret_cast<const SceneRef *>(scenes_dev), F, nullptr, nullptr, nullptr, xyz_is_f64, nullptr, nullptr,
+                    nullptr, 0, nmax, w2c, S * F, nullptr, nullptr, C, crop, W, H, radius, scratch, scratch_bytes, stream);
+}
+
+int cama_overlay_scenes(const cama_scene *scenes_host, const cama_scene *scenes_dev, int32_t S, int32_t F, int32_t C,
+                        int32_t H, int32_t W, int32_t cols, int32_t radius, const int32_t *halfwidth,
+                        const uint8_t *palette_bgr, const void *scratch, size_t scratch_bytes, void *stream)
+{
+    int64_t nmax = 0;
+    if (int rc = check_scenes(scenes_host, scenes_dev, S, F, true, &nmax)) return rc;
+    if (W % 16) return fail(CAMA_EINVAL, "multi-scene launches need W %% 16 == 0 (W=%d)", W);
+    return overlay_impl(nullptr, nullptr, nullptr, nmax, S * F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
+                        scratch_bytes, stream, reinterpret_cast<const SceneRef *>(scenes_dev), F);
+}
+
+int cama_render_scenes(const cama_scene *scenes_host, const cama_scene *scenes_dev, int32_t S, int32_t xyz_is_f64,
+                       const double *w2c, int32_t F, int32_t C, const double *crop, int32_t W, int32_t H, int32_t cols,
+                       int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
+                       size_t scratch_bytes, void *stream)
+{
+    int64_t nmax = 0;
+    if (int rc = check_scenes(scenes_host, scenes_dev, S, F, true, &nmax)) return rc;   // nothing enqueued when the overlay
+    if (W % 16 || !palette_bgr || !halfwidth || cols < 1) return fail(CAMA_EINVAL, "bad overlay arguments"); // would be refused
+    if (int rc = cama_bin_scenes(scenes_host, scenes_dev, S, xyz_is_f64, w2c, F, C, crop, W, H, radius, scratch, scratch_bytes,
+                                 stream))
+        return rc;
+    return cama_overlay_scenes(scenes_host, scenes_dev, S, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
+                               scratch_bytes, stream);
+}
+
+int cama_pipeline_render_scenes(cama_pipeline *p, const cama_scene *scenes_host, const cama_scene *scenes_dev, int32_t S,
+                                int32_t xyz_is_f64, const double *w2c, int32_t F, int32_t C, const double *crop, int32_t W,
+                                int32_t H, int32_t cols, int32_t radius, const int32_t *halfwidth,
+                                const uint8_t *palette_bgr, void *scratch0, void *scratch1, size_t scratch_bytes,
+                                void *input_stream)
+{
+    int64_t nmax = 0;
+    if (int rc = check_scenes(scenes_host, scenes_dev, S, F, true, &nmax)) return rc;
+    if (W % 16 || !palette_bgr || !halfwidth || cols < 1) return fail(CAMA_EINVAL, "bad overlay arguments");
+    return pipeline_impl(p, nmax, S * F, C, W, H, radius, scratch0, scratch1, scratch_bytes, input_stream, true,
+                         [&](void *scratch, void *sb) {
+                             return cama_bin_scenes(scenes_host, scenes_dev, S, xyz_is_f64, w2c, F, C, crop, W, H, radius,
+                                                    scratch, scratch_bytes, sb);
+                         },
+                         [&](void *scratch, void *so) {
+                             return cama_overlay_scenes(scenes_host, scenes_dev, S, F, C, H, W, cols, radius, halfwidth,
+                                                        palette_bgr, scratch, scratch_bytes, so);
+                         });
+}
 
 int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
                          const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,

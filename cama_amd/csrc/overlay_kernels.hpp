@@ -7,6 +7,8 @@
 // overlay: band copy + deterministic stamp resolution
 // ------------------------------------------------------------------------------------------
 struct OverlayArgs {
+    const SceneRef *scenes;           // SCENES instantiation: per-scene src / mosaic (frame f -> scene f / frames_per_scene)
+    int frames_per_scene;
     const uint8_t *src;
     uint8_t *mosaic;
     int C, H, W, cols, R, NB;
@@ -165,7 +167,7 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <bool VEC, bool RESAMPLE, bool ALPHA = false>
+template <bool VEC, bool RESAMPLE, bool ALPHA = false, bool SCENES = false>
 __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x W, used only by stamped bands
@@ -189,6 +191,17 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
     const uint32_t fc = f * C + c;
     const uint32_t bin = fc * NB + b;
 #endif
+    // multi-scene launch: this frame's scene supplies the frames and the mosaic; fl = the frame's number inside its scene
+    // (everything in the scratch stays indexed by the launch-wide f)
+    uint32_t fl = f;
+    if (SCENES) {
+        const uint32_t sidx = f / (uint32_t)a.frames_per_scene;
+        fl = f - sidx * (uint32_t)a.frames_per_scene;
+        kSceneRef *sc = (kSceneRef *)(a.scenes) + sidx;
+        a.src = sc->src;
+        a.mosaic = sc->mosaic;
+    }
+    const uint32_t fcl = fl * C + c;                     // (frame, camera) inside the scene's own frame tensor
     const int y0 = (int)b * a.R;
     const int nrows = min(a.R, a.H - y0);
     const int W = a.W;
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
     const uint2 first = st[n ? min(threadIdx.x, n - 1u) : 0u];
     __builtin_amdgcn_sched_barrier(0);          // keep the record load ahead of the source loads (in-order vmcnt)
 
-    const uint8_t *sband = a.src + ((size_t)fc * a.H + y0) * (size_t)W * 3;      // (unused by RESAMPLE)
+    const uint8_t *sband = a.src + ((size_t)fcl * a.H + y0) * (size_t)W * 3;     // (unused by RESAMPLE)
     constexpr int U = OVERLAY_UNROLL;
     const u32x4 *s16 = reinterpret_cast<const u32x4 *>(sband);
     const uint32_t nchunks = (uint32_t)nrows * a.cpr;
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
         lds_barrier();
     }
 
-    uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
+    uint8_t *dcell = a.mosaic + (size_t)fl * a.mosaic_frame_bytes +
                      ((size_t)(c / (uint32_t)a.cols) * a.H + y0) * a.mosaic_row_bytes +
                      (size_t)(c % (uint32_t)a.cols) * W * 3;
 
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
         // adjacent in the raw frame.  Raw bytes are read once from HBM (re-reads hit L1/L2), resized frames never
         // exist in memory.
         const size_t raw_frame = (size_t)a.H0 * a.W0 * 3;
-        const uint8_t *raw = a.src + (size_t)fc * raw_frame;
+        const uint8_t *raw = a.src + (size_t)fcl * raw_frame;
         const float *mxc = a.mapx + (size_t)c * a.mapx_cam, *myc = a.mapy + (size_t)c * a.mapy_cam;
         const uint32_t nchunks = (uint32_t)nrows * a.cpr;
         for (uint32_t idx = threadIdx.x; idx < nchunks; idx += OVERLAY_BLOCK) {

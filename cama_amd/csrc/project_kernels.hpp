@@ -201,7 +201,25 @@ __global__ __launch_bounds__(BLOCK) void k_block_bounds(const void *x, const voi
     }
 }
 
+// Multi-scene launches (cama_*_scenes): frame f of the launch belongs to scene f / frames_per_scene; what differs per
+// scene -- vertex buffer, calibration, frames, mosaic -- comes from a device table read through wave-uniform (scalar)
+// loads.  Everything in the scratch is indexed by the launch-wide frame number, so the scans, the scatter and the
+// band lists are unaware of scenes.
+struct SceneRef {
+    const void *x, *y, *z;
+    const uint8_t *colour;
+    const uint32_t *key;
+    const double *c2cam, *K;
+    const uint8_t *src;
+    uint8_t *mosaic;
+    int64_t N;
+};
+static_assert(sizeof(SceneRef) == sizeof(cama_scene), "SceneRef mirrors cama_scene (include/cama_hip.h)");
+typedef const SceneRef __attribute__((address_space(4))) kSceneRef;
+
 struct FrameArgs {
+    const SceneRef *scenes; // optional [S]: multi-scene launch (x .. K below are then placeholders, N = max over scenes)
+    int frames_per_scene;
     const void *x, *y, *z;  // [N] each, float or double (template parameter T)
     const uint8_t *colour;
     const uint32_t *key;    // optional [N]: draw index << 1 | colour (maps stored in a different order than drawn)
@@ -225,6 +243,17 @@ struct FrameArgs {
     const uint32_t *bin_off, *fc_base;
     uint2 *stamps;          // band-sorted stamps (k_stamps_scatter)
 };
+
+// Multi-scene launch: overwrite the per-scene fields of the (by-value) argument block with frame f's scene.
+__device__ __forceinline__ void resolve_scene(FrameArgs &a, const int f)
+{
+    if (!a.scenes) return;
+    kSceneRef *sc = (kSceneRef *)(a.scenes) + (f / a.frames_per_scene);
+    a.x = sc->x; a.y = sc->y; a.z = sc->z;
+    a.colour = sc->colour; a.key = sc->key;
+    a.c2cam = sc->c2cam; a.K = sc->K;
+    a.N = sc->N;
+}
 
 // Emit mode: materialise (v,u) + visibility for every (frame, camera, vertex).
 template <typename T>
@@ -403,6 +432,7 @@ __global__ __launch_bounds__(BLOCK) void k_frames_project(FrameArgs a, const int
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [C*NB] stamp counts of this workgroup
     const int f = blockIdx.y;
+    resolve_scene(a, f);
     const int64_t vb0 = (int64_t)blockIdx.x * vb_per_wg;
     if (vb0 * BLOCK >= a.N) return;
     hist_clear(a, s_hist);

@@ -480,3 +480,43 @@ class ClipManager:
                 continue
             lo = hi
         return idx, out
+
+
+def render_clips(clips, dataset, outs, pipelined=True, poses=None, max_frames_per_launch=None):
+    """Render several clips (scenes) of one dataset pass back to back -- main.py:32's scene loop with the per-frame body
+    fused -- into `outs` (one [F, 2H, 3W, 3] device tensor per clip).
+
+    Scenes that agree in frame count, rig geometry and vertex dtype, have pre-resized device-resident frames and maps
+    small enough to run without the block index go out as ONE multi-scene launch per group of scenes (Engine.render_scenes:
+    one binning chain + one overlay launch for up to `max_frames_per_launch` frames, default 16 384); everything else
+    falls back to one ClipManager.render_clip per scene.  Same bytes either way.  With pipelined=True the outputs are
+    complete after runtime.engine().join().  `poses`: optional list of frame_poses() results, one per clip."""
+    eng = runtime.engine()
+    clips = list(clips)
+    assert len(outs) == len(clips)
+    items = []
+    for k, cm in enumerate(clips):
+        idx, w2c = poses[k] if poses is not None else cm.frame_poses(dataset)
+        src_all = cm.frame_source()
+        frames = None
+        if hasattr(src_all, "frames") and not getattr(src_all, "fused", False) and len(idx):
+            frames = src_all.batch(idx.tolist())
+        items.append((cm, idx, w2c, frames))
+    batch = [(cm._static(dataset).device(), cm._rig(), w2c, fr, outs[k]) for k, (cm, idx, w2c, fr) in enumerate(items)
+             if fr is not None]
+    crop0 = np.asarray(clips[0].mm.crop_box(), np.float64).reshape(-1) if clips else None
+    same_crop = all(np.array_equal(np.asarray(cm.mm.crop_box(), np.float64).reshape(-1), crop0) for cm in clips)
+    if len(batch) == len(clips) and same_crop and eng.scene_batchable(batch):
+        F = len(items[0][1])
+        per = max(1, (max_frames_per_launch or 16384) // max(1, F))
+        for lo in range(0, len(batch), per):
+            group = batch[lo:lo + per]
+            if len(group) == 1:
+                cm, idx, w2c, _ = items[lo]
+                cm.render_clip(dataset, out=outs[lo], pipelined=pipelined, poses=(idx, w2c))
+            else:
+                eng.render_scenes(group, crop=clips[0].mm.crop_box(), pipelined=pipelined)
+        return True
+    for k, (cm, idx, w2c, _) in enumerate(items):
+        cm.render_clip(dataset, out=outs[k], pipelined=pipelined, poses=(idx, w2c))
+    return False

@@ -25,6 +25,14 @@ def _torch():
     return torch
 
 
+class host_keepalive:
+    """Holds a host array alive inside a pipeline keep tuple (the library reads the scene table's host copy only during
+    the call, but the cache may evict it while launches are queued: keeping it costs nothing)."""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+
 class CameraRig:
     """Per-clip calibration on the device: [C,16] chassis->camera and [C,9] K (scaled to W x H)."""
 
@@ -644,6 +652,81 @@ class Engine:
             self._release_completed(P)
             return out
 
+    # ------------------------------------------------------------------ many scenes per launch
+    def scene_batchable(self, items):
+        """True when `items` = [(dmap, rig, w2c, src, out), ...] can go out as ONE multi-scene launch (cama_*_scenes):
+        same frame count, rig geometry and vertex dtype everywhere, pre-resized frames, maps small enough to run without
+        the block index (big site maps are launched per scene: there the launch is milliseconds, not its overhead)."""
+        if len(items) < 2 or self.alpha256 != 256:
+            return False
+        d0, r0, w0, s0, _ = items[0]
+        F = len(w0)
+        if F == 0 or r0.W % 16:
+            return False
+        for dmap, rig, w2c, src, out in items:
+            if (len(w2c) != F or (rig.C, rig.H, rig.W) != (r0.C, r0.H, r0.W) or dmap.is_f64 != d0.is_f64 or dmap.N == 0
+                    or dmap.N >= BOUNDS_MIN_VERTS and getattr(dmap, "bounds", None) is not None
+                    or tuple(src.shape) != (F, rig.C, rig.H, rig.W, 3) or not src.is_contiguous() or not out.is_contiguous()
+                    or not (isinstance(w2c, np.ndarray) and w2c.dtype == np.float32)):
+                return False
+        return len(items) * F <= 65535
+
+    def _scene_table(self, items):
+        """(host uint64 [S,10], device twin) of cama_scene entries for `items`, cached on the pointers themselves."""
+        torch = _torch()
+        rows = []
+        for dmap, rig, _, src, out in items:
+            if dmap.sorted_soa is None:
+                x, y, z = dmap.ptrs()
+                col, key = dmap.colour.data_ptr(), 0
+            else:
+                x, y, z, col, key = dmap.render_ptrs()[:5]
+            rows.append((x, y, z, col, key or 0, rig.c2cam.data_ptr(), rig.K.data_ptr(), src.data_ptr(), out.data_ptr(), dmap.N))
+        host = np.asarray(rows, dtype=np.uint64)
+        cache = self.__dict__.setdefault("_scene_tables", {})
+        k = host.tobytes()
+        hit = cache.get(k)
+        if hit is None:
+            if len(cache) >= 32:
+                cache.pop(next(iter(cache)))
+            hit = cache[k] = (host, torch.from_numpy(host.view(np.int64)).to(self.device))
+        return hit
+
+    def render_scenes(self, items, cols=3, crop=None, pipelined=True):
+        """items = [(dmap, rig, w2c float32 host [F,4,4], src [F,C,H,W,3], out [F,2H,3W,3]), ...] -> ONE binning chain and
+        ONE overlay launch for all of them (scene_batchable(items) must hold).  Bit-identical to rendering them one by
+        one.  pipelined: through the two-stream pipeline (outputs complete after join()), else on the current stream."""
+        torch = _torch()
+        cropa = self._crop(crop)
+        S = len(items)
+        d0, r0, w0, _, _ = items[0]
+        F = len(w0)
+        Nmax = max(it[0].N for it in items)
+        with torch.cuda.device(self.device):
+            host, dev = self._scene_table(items)
+            poses = np.ascontiguousarray(np.concatenate([np.asarray(it[2], np.float32).reshape(F, 16) for it in items]))
+            if pipelined:
+                P = self._pipeline()
+                s0, s1 = self._pipe_scratch(P, self._scratch_need(Nmax, S * F, r0))
+                T_ptr = self._stage_poses(P, poses)[0]
+                _lib.check(self.lib.cama_pipeline_render_scenes(
+                    P["handle"], host.ctypes.data, dev.data_ptr(), S, d0.is_f64, T_ptr, F, r0.C, cropa.ctypes.data, r0.W, r0.H,
+                    cols, self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(),
+                    min(s0.numel(), s1.numel()), self._stream()))
+                seq = int(self.lib.cama_pipeline_issued(P["handle"]))
+                P["keep"].append((seq, None, dev, items[0][4], d0, r0,
+                                  tuple(t for it in items for t in (it[3], it[4], it[0].soa, it[0].colour, it[0].sorted_soa,
+                                                                     it[0].sorted_key, it[1].c2cam, it[1].K) if t is not None)
+                                  + (host_keepalive(host),)))
+                self._release_completed(P)
+                return
+            T = self._mats(poses.reshape(-1, 4, 4))
+            scratch = self._scratch_buf(self._scratch_need(Nmax, S * F, r0))
+            _lib.check(self.lib.cama_render_scenes(
+                host.ctypes.data, dev.data_ptr(), S, d0.is_f64, T.data_ptr(), F, r0.C, cropa.ctypes.data, r0.W, r0.H, cols,
+                self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(),
+                self._stream()))
+
     def _release_completed(self, P):
         done = int(self.lib.cama_pipeline_completed(P["handle"]))
         if done < 0:
@@ -669,7 +752,7 @@ class Engine:
             for _, T, src, out, dmap, rig, extra in self._pipe["keep"]:
                 for t in (T, src, out, dmap.soa, dmap.colour, dmap.sorted_soa, dmap.sorted_key,
                           getattr(dmap, "bounds", None), rig.c2cam, rig.K) + tuple(extra):
-                    if t is not None:
+                    if t is not None and hasattr(t, "record_stream"):
                         t.record_stream(cur)
             self._pipe["keep"].clear()
 

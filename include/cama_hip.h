@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 11
+#define CAMA_ABI_VERSION 12
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -214,6 +214,44 @@ int cama_pipeline_render_raw35(cama_pipeline *p, const void *x, const void *y, c
 int cama_pipeline_join(cama_pipeline *p, void *stream);
 int64_t cama_pipeline_issued(cama_pipeline *p);
 int64_t cama_pipeline_completed(cama_pipeline *p);
+
+/*
+ * Many scenes per launch.  main.py:32 renders scene after scene; a scene of ~1e4 vertices x 40 frames is ~0.35 ms of GPU
+ * work behind 6-7 launches, so a 73-scene sweep spends a few percent of its time on kernel boundaries and on the host
+ * issuing ~500 launches.  These entries render S scenes that share frame count F, camera count C, image size and vertex
+ * dtype as ONE chain: a device table of per-scene pointers, frame f of the launch = frame f % F of scene f / F.
+ *   scenes_host / scenes_dev   the same S entries in host memory (validated here) and in device memory (read by the
+ *                              kernels through scalar loads); both stay valid until the launch has completed
+ *   w2c        [S*F,16] device, scene-major          scratch >= cama_render_scratch_bytes(max N, S*F, C, H, W, radius)
+ * Restrictions: no block_bounds / work lists (meant for many small maps; big site maps are launched per scene), the
+ * plain pre-resized-frame overlay only.  Bit-identical to S calls of the single-scene entries.
+ */
+typedef struct cama_scene {
+    const void *x, *y, *z;        /* [N] SoA vertex buffer (float32, or float64 when xyz_is_f64) */
+    const uint8_t *colour_id;     /* [N] */
+    const uint32_t *draw_key;     /* NULL or [N] */
+    const double *c2cam, *K;      /* [C,16], [C,9] */
+    const uint8_t *src;           /* [F,C,H,W,3] */
+    uint8_t *mosaic;              /* [F, rows*H, cols*W, 3] */
+    int64_t N;
+} cama_scene;
+int cama_bin_scenes(const cama_scene *scenes_host, const cama_scene *scenes_dev, int32_t S, int32_t xyz_is_f64,
+                    const double *w2c, int32_t F, int32_t C, const double *crop, int32_t W, int32_t H, int32_t radius,
+                    void *scratch, size_t scratch_bytes, void *stream);
+int cama_overlay_scenes(const cama_scene *scenes_host, const cama_scene *scenes_dev, int32_t S, int32_t F, int32_t C,
+                        int32_t H, int32_t W, int32_t cols, int32_t radius, const int32_t *halfwidth,
+                        const uint8_t *palette_bgr, const void *scratch, size_t scratch_bytes, void *stream);
+int cama_render_scenes(const cama_scene *scenes_host, const cama_scene *scenes_dev, int32_t S, int32_t xyz_is_f64,
+                       const double *w2c, int32_t F, int32_t C, const double *crop, int32_t W, int32_t H, int32_t cols,
+                       int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
+                       size_t scratch_bytes, void *stream);
+/* The two-stream pipeline (above) with a multi-scene launch as its unit; poses may come from cama_pipeline_stage_poses
+ * (S*F matrices). */
+int cama_pipeline_render_scenes(cama_pipeline *p, const cama_scene *scenes_host, const cama_scene *scenes_dev, int32_t S,
+                                int32_t xyz_is_f64, const double *w2c, int32_t F, int32_t C, const double *crop, int32_t W,
+                                int32_t H, int32_t cols, int32_t radius, const int32_t *halfwidth,
+                                const uint8_t *palette_bgr, void *scratch0, void *scratch1, size_t scratch_bytes,
+                                void *input_stream);
 
 /*
  * EXTENSION (no reference semantics; the reference draws opaque discs, cama/reproject.py:253-256): overlay half with

@@ -279,8 +279,81 @@ def test_site_aggregated_scenes_share_one_device_map():
     import gc
     import weakref
     ref = weakref.ref(dmaps[1])
-    del dmaps
+    del dmaps, cm                                   # (`cm`: the loop variable above still names scene 7, a site-1 scene)
     scenes = [sc for k, sc in enumerate(scenes) if k % 2 == 0]
     eng.join()
+    eng.__dict__.pop("_last_bin", None)
     gc.collect()
     assert ref() is None
+
+
+def test_many_scenes_in_one_launch_equal_the_per_scene_renders():
+    """dataset.render_clips: 24 distinct small scenes (own maps with different vertex counts, own calibrations, poses and
+    frames) as ONE multi-scene launch chain (cama_pipeline_render_scenes / cama_render_scenes) -- every scene's hash equals
+    the oracle's golden hash and the bytes of its own single-scene render; pipelined over several un-joined rounds, on the
+    current stream, and cut into groups of a few scenes per launch."""
+    import torch
+    from cama_amd import runtime
+    from cama_amd.dataset import render_clips
+    a = _args(frames=6, verts=3000, height=180, width=320)
+    dev = torch.device("cuda:0")
+    golden = _golden(a)
+    scenes = [bench.build_scene(a, s, dev) for s in range(24)]
+    cms = [cm for cm, _, _ in scenes]
+    assert len({cm._static("cama").device().N for cm in cms}) > 1          # the scenes' maps differ in size
+    eng = runtime.engine()
+    shape = eng.mosaic_shape(cms[0]._rig(), a.frames)
+    outs = [torch.zeros(shape, dtype=torch.uint8, device=dev) for _ in cms]
+    issued0 = int(eng.lib.cama_pipeline_issued(eng._pipeline()["handle"]))
+    for _ in range(5):
+        assert render_clips(cms, "cama", outs, pipelined=True) is True
+    assert int(eng.lib.cama_pipeline_issued(eng._pipe["handle"])) - issued0 == 5   # one launch chain per round, not 24
+    eng.join()
+    torch.cuda.synchronize()
+    for k, cm in enumerate(cms):
+        assert shard.overlay_hash(outs[k]) == golden[k], f"scene {k}: multi-scene launch differs from the oracle"
+        _, plain = cm.render_clip("cama")
+        torch.cuda.synchronize()
+        assert torch.equal(plain, outs[k]), k
+    # current-stream variant, and groups of 4 scenes per launch (24 frames per launch)
+    for kw in (dict(pipelined=False), dict(pipelined=True, max_frames_per_launch=24), dict(pipelined=True, max_frames_per_launch=7)):
+        for o in outs:
+            o.zero_()
+        assert render_clips(cms, "cama", outs, **kw) is True
+        eng.join()
+        torch.cuda.synchronize()
+        bad = [k for k in range(24) if shard.overlay_hash(outs[k]) != golden[k]]
+        assert not bad, (kw, bad)
+    # scenes that do not agree (another image size) fall back to per-scene launches: same bytes, returns False
+    b = _args(frames=6, verts=3000, height=90, width=160)
+    other = bench.build_scene(b, 0, dev)[0]
+    out_other = torch.zeros(eng.mosaic_shape(other._rig(), b.frames), dtype=torch.uint8, device=dev)
+    outs[0].zero_()
+    assert render_clips([cms[0], other], "cama", [outs[0], out_other], pipelined=True) is False
+    eng.join()
+    torch.cuda.synchronize()
+    assert shard.overlay_hash(outs[0]) == golden[0]
+    _, plain = other.render_clip("cama")
+    torch.cuda.synchronize()
+    assert torch.equal(plain, out_other)
+
+
+def test_multi_scene_abi_rejects_bad_tables():
+    """cama_render_scenes validates the HOST copy of the table before anything is enqueued."""
+    import torch
+    from cama_amd import _lib, runtime
+    eng = runtime.engine()
+    L = _lib.lib()
+    host = np.zeros((2, 10), np.uint64)
+    dev = torch.zeros((2, 10), dtype=torch.int64, device="cuda")
+    crop = np.asarray(eng.crop, np.float64)
+    scratch = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    rc = L.cama_render_scenes(host.ctypes.data, dev.data_ptr(), 2, 0, dev.data_ptr(), 1, 6, crop.ctypes.data, 160, 96, 3, 2,
+                              eng.halfwidth.ctypes.data, eng.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), None)
+    assert rc == -1 and b"calibration" in L.cama_last_error()
+    rc = L.cama_render_scenes(None, dev.data_ptr(), 2, 0, dev.data_ptr(), 1, 6, crop.ctypes.data, 160, 96, 3, 2,
+                              eng.halfwidth.ctypes.data, eng.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), None)
+    assert rc == -1 and b"scene table" in L.cama_last_error()
+    rc = L.cama_render_scenes(host.ctypes.data, dev.data_ptr(), 70000, 0, dev.data_ptr(), 1, 6, crop.ctypes.data, 160, 96, 3, 2,
+                              eng.halfwidth.ctypes.data, eng.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), None)
+    assert rc == -1 and b"S=70000" in L.cama_last_error()
