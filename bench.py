@@ -356,6 +356,8 @@ class Job:
         self.lo, self.hi, self.F = lo, hi, hi - lo
         self.out = None
         self.outs = None
+        self.own_outs = None
+        self.group_frames = int(os.environ.get("CAMA_SCENE_GROUP_FRAMES", "0")) or None      # A/B: frames per multi-scene launch
         self.batched = False
         if self.scenes and self.F:
             rig = self.scenes[0][1]._rig()
@@ -368,23 +370,28 @@ class Job:
                 self.eng.join()
                 if not self.batched:
                     self.outs = None
+            elif len(self.scenes) > 1 and frame_range is None and os.environ.get("CAMA_BENCH_OWN_OUTS") == "1":
+                # A/B knob: per-scene launches, but every scene into its own mosaic like the multi-scene path
+                self.own_outs = [self.out] + [torch.empty_like(self.out) for _ in self.scenes[1:]]
 
     def step_batched(self):
         from cama_amd.dataset import render_clips
-        return render_clips([cm for _, cm, _, _ in self.scenes], "cama", self.outs, pipelined=self.pipelined)
+        return render_clips([cm for _, cm, _, _ in self.scenes], "cama", self.outs, pipelined=self.pipelined,
+                            max_frames_per_launch=self.group_frames)
 
     def step(self, out=None):
         if self.batched and out is None:
             self.step_batched()
             return
-        for sid, cm, _, _ in self.scenes:
+        for k, (sid, cm, _, _) in enumerate(self.scenes):
             if not self.F:
                 continue
             poses = None
             if self.frame_range is not None:                            # this rank's slice of the clip's poses
                 idx_all, w2c_all = cm.frame_poses("cama")
                 poses = (idx_all[self.lo:self.hi], w2c_all[self.lo:self.hi])
-            cm.render_clip("cama", out=self.out if out is None else out, pipelined=self.pipelined, poses=poses)
+            dst = self.own_outs[k] if (out is None and self.own_outs) else (self.out if out is None else out)
+            cm.render_clip("cama", out=dst, pipelined=self.pipelined, poses=poses)
 
     def run(self, steps, warmup, sync_all, prof_every):
         import ctypes
@@ -478,7 +485,7 @@ class Job:
             return 0.0
         cm = self.scenes[0][1]
         if self.batched:                                                # scenes per launch x frames per scene
-            per = max(1, 16384 // self.F)
+            per = max(1, min(1024, (self.group_frames or 16384) // self.F))
             groups = -(-len(self.scenes) // per)
             return self.F * len(self.scenes) / float(groups)
         per_call = max(1, min(self.F, self.eng.max_frames_per_call(cm._static("cama").device(), cm._rig(),

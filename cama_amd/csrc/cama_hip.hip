@@ -605,12 +605,13 @@ struct RawSource {
 static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosaic, int64_t N, int32_t F, int32_t C,
                         int32_t H, int32_t W, int32_t cols, int32_t radius, const int32_t *halfwidth,
                         const uint8_t *palette_bgr, const void *scratch, size_t scratch_bytes, void *stream,
-                        const SceneRef *scenes_dev = nullptr, int frames_per_scene = 0)
+                        const cama_scene *scenes_host = nullptr, int frames_per_scene = 0)
 {
     ScratchLayout L;
     if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
     if (F == 0) return CAMA_OK;
     if (cols < 1) return fail(CAMA_EINVAL, "cols=%d", cols);
+    const bool scenes_dev = scenes_host != nullptr;         // multi-scene launch (image pointers travel in the kernel arguments)
     if ((!scenes_dev && (!src || !mosaic)) || !palette_bgr) return fail(CAMA_EINVAL, "NULL pointer argument");
     Disc disc;
     if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
@@ -622,12 +623,10 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     const size_t lds = align_up((size_t)L.R * (W + 2 * radius) * 4, 16) + lds_pad;
     hipStream_t s = (hipStream_t)stream;
     const char *base = (const char *)scratch;
-#ifdef OVERLAY_ORDER_FCB
-    const int nfc = F * C;
-#endif
 
     OverlayArgs o{};
-    o.scenes = scenes_dev; o.frames_per_scene = frames_per_scene;
+    o.f0 = 0;
+    o.cols_magic = (uint32_t)(((1ull << 32) + (uint32_t)cols - 1) / (uint32_t)cols);
     o.src = src; o.mosaic = mosaic; o.C = C; o.H = H; o.W = W; o.cols = cols; o.R = L.R; o.NB = L.NB;
     const int rows = (C + cols - 1) / cols;
     o.mosaic_row_bytes = (size_t)cols * W * 3;
@@ -652,16 +651,14 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
         o.ms.xr = raw->separable ? 0 : W; o.ms.xc = 1; o.ms.yr = raw->separable ? 1 : W; o.ms.yc = raw->separable ? 0 : 1;
         o.ms.w_magic = 0;
     }
-#ifdef OVERLAY_ORDER_FCB
-    const unsigned nblocks = (unsigned)((size_t)nfc * L.NB);
-#else
     const unsigned nblocks = (unsigned)((size_t)F * rows * cols * L.NB);   // (frame, camera row, band, camera column)
-#endif
+    // k_overlay / k_overlay_scenes: the same order as a 3-D grid (x = band * cols + camera column, y = camera row, z = frame)
+    if ((size_t)L.NB * cols >= 65536) return fail(CAMA_EINVAL, "bands x cols = %d x %d exceeds the overlay grid", L.NB, cols);
+    const dim3 ogrid((unsigned)(L.NB * cols), (unsigned)rows, (unsigned)F);
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // Live timing of this launch (cama_profile_enable): the dominant kernel takes the two events as ITS OWN start / stop
     // events (hipExtLaunchKernelGGL), i.e. the kernel's duration itself, the figure rocprofv3 --kernel-trace reports;
@@ -697,29 +694,40 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
                            reinterpret_cast<const int2 *>(raw->band_rows),
                            reinterpret_cast<const int2 *>(raw->tile_bytes), raw->tiles_x, Wt);
     } else if (raw)
-        hipLaunchKernelGGL((k_overlay<true, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+        hipLaunchKernelGGL((k_overlay<true, true>), ogrid, dim3(OVERLAY_BLOCK), lds, s, o);
     else if (o.pal.alpha256 != 256u) {      // translucent extension: its own instantiations, the exact kernels stay lean
         if (vec)
-            hipLaunchKernelGGL((k_overlay<true, false, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+            hipLaunchKernelGGL((k_overlay<true, false, true>), ogrid, dim3(OVERLAY_BLOCK), lds, s, o);
         else
-            hipLaunchKernelGGL((k_overlay<false, false, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+            hipLaunchKernelGGL((k_overlay<false, false, true>), ogrid, dim3(OVERLAY_BLOCK), lds, s, o);
     } else if (scenes_dev) {
-        // (events: start/stop when profiling, else the pipeline's completion event as the stop event, else none)
-        hipEvent_t e0 = (exact_timing && ev0 && ev1) ? ev0 : nullptr;
-        hipEvent_t e1 = e0 ? ev1 : g_overlay_stop_event;
-        hipExtLaunchKernelGGL((k_overlay<true, false, false, true>), dim3(nblocks), dim3(OVERLAY_BLOCK), (uint32_t)lds, s, e0, e1, 0u, o);
-        if (!e0) g_overlay_stop_event = nullptr;
+        // One overlay launch PER SCENE out of the shared scratch (frames f0 .. f0 + frames_per_scene of the chain).  A single
+        // launch over all scenes was built first (grid.z over every frame, per-scene image pointers in the kernel arguments)
+        // and measured SLOWER: the kernel's bandwidth falls with the length of the launch -- one scene of 20 / 40 / 80 /
+        // 160 / 640 frames per launch: 0.80 / 0.76 / 0.74 / 0.61-0.71 / 0.67 of 8 TB/s; 73 scenes as one launch 0.70 against
+        // 0.77 as 73 launches -- so the ~12 us kernel boundary every 40 frames is the cheaper price.
+        const int S = F / frames_per_scene;
+        const dim3 sgrid(ogrid.x, ogrid.y, (unsigned)frames_per_scene);
+        for (int k = 0; k < S; ++k) {
+            o.src = scenes_host[k].src;
+            o.mosaic = scenes_host[k].mosaic;
+            o.f0 = k * frames_per_scene;
+            hipEvent_t e0 = (k == 0 && exact_timing && ev0 && ev1) ? ev0 : nullptr;
+            hipEvent_t e1 = (k == S - 1) ? ((exact_timing && ev0 && ev1) ? ev1 : g_overlay_stop_event) : nullptr;
+            hipExtLaunchKernelGGL((k_overlay<true, false>), sgrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, e0, e1, 0u, o);
+        }
+        if (!(exact_timing && ev0 && ev1)) g_overlay_stop_event = nullptr;
     } else if (vec) {
         if (exact_timing && ev0 && ev1) {
-            hipExtLaunchKernelGGL((k_overlay<true, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), (uint32_t)lds, s, ev0, ev1, 0u, o);
+            hipExtLaunchKernelGGL((k_overlay<true, false>), ogrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, ev0, ev1, 0u, o);
         } else if (g_overlay_stop_event) {
-            hipExtLaunchKernelGGL((k_overlay<true, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), (uint32_t)lds, s, nullptr,
+            hipExtLaunchKernelGGL((k_overlay<true, false>), ogrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, nullptr,
                                   g_overlay_stop_event, 0u, o);
             g_overlay_stop_event = nullptr;
         } else
-            hipLaunchKernelGGL((k_overlay<true, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+            hipLaunchKernelGGL((k_overlay<true, false>), ogrid, dim3(OVERLAY_BLOCK), lds, s, o);
     } else
-        hipLaunchKernelGGL((k_overlay<false, false>), dim3(nblocks), dim3(OVERLAY_BLOCK), lds, s, o);
+        hipLaunchKernelGGL((k_overlay<false, false>), ogrid, dim3(OVERLAY_BLOCK), lds, s, o);
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) {
         if (!exact_timing) HIP_TRY(hipEventRecord(ev1, s));
@@ -821,7 +829,7 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     if (F == 0) return CAMA_OK;
     if (cols < 1) return fail(CAMA_EINVAL, "cols=%d", cols);
     if (!raw || !vrows || !band_rows || !mosaic || !palette_bgr) return fail(CAMA_EINVAL, "NULL pointer argument");
-    const int upr = W / 12;
+    int upr = W / 12;
     const unsigned items = (unsigned)L.R * (unsigned)upr;
     if (W % 48 != 0 || ((int64_t)W0 * 3) % 16 != 0 || (uintptr_t)raw % 16 != 0 || (uintptr_t)mosaic % 16 != 0 ||
         H0 < 1 || H0 > 65535 || 5ll * (W / 3) > W0 || items > RAW35_MAX_BLOCK || max_src_rows < 1 ||
@@ -841,33 +849,46 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)(base + L.stamps);
     o.disc = disc; o.pal = make_palette(palette_bgr);
     o.H0 = H0; o.W0 = W0;
-    const unsigned block = (items + 63u) & ~63u;
-    // the owner table of a stamped band goes INTO the staging area, behind the band's output rows (raw35_kernels.hpp)
-    const size_t staging_dw = (size_t)max_src_rows * W0 * 3 / 4, owner_off = (size_t)L.R * W * 3 / 4, owner_dw = (size_t)L.R * W;
+    // column tiles per band: 2 when a half band still fills 2+ waves (960-wide tiles: 160 threads, 17 KB of LDS -> 8
+    // workgroups per CU instead of 4), else 1.  CAMA_RAW35_TILES=1|2 overrides (A/B).
+    static const int forced_tx = getenv("CAMA_RAW35_TILES") ? atoi(getenv("CAMA_RAW35_TILES")) : 0;
+    int TX = (upr % 8 == 0 && items / 2 >= 128) ? 2 : 1;
+    if (forced_tx == 1 || (forced_tx == 2 && upr % 8 == 0)) TX = forced_tx;
+    const int upr_t = upr / TX, Wt = W / TX;
+    const unsigned block = ((unsigned)L.R * (unsigned)upr_t + 63u) & ~63u;
+    // the owner table of a stamped band goes INTO the staging area, behind the tile's output rows (raw35_kernels.hpp)
+    const size_t staging_dw = (size_t)max_src_rows * upr_t * 15, owner_off = (size_t)L.R * upr_t * 9, owner_dw = (size_t)L.R * Wt;
     if (staging_dw < owner_off + owner_dw)
         return fail(CAMA_EINVAL, "the plan's %d source rows leave no room for the owner table (W=%d, W0=%d)", max_src_rows, W, W0);
     const size_t lds = staging_dw * 4;
     if (lds > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the 3:5 raw overlay's LDS", W);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned nblocks = (unsigned)((size_t)F * rows * cols * L.NB);
+    if ((size_t)L.NB * cols * TX >= 65536) return fail(CAMA_EINVAL, "bands x cols x tiles exceeds the overlay grid");
+    const dim3 rgrid((unsigned)(L.NB * cols * TX), (unsigned)rows, (unsigned)F);
+    const uint32_t tx_magic = (uint32_t)(((1ull << 32) + (uint32_t)TX - 1) / (uint32_t)TX);
+    const uint32_t cpt = (uint32_t)upr_t * 15u / 4u, cpt_magic = (uint32_t)(((1ull << 32) + cpt - 1) / cpt);
+    o.cols_magic = (uint32_t)(((1ull << 32) + (uint32_t)cols - 1) / (uint32_t)cols);
+    const int upr_full = upr;
+    (void)upr_full;
+    upr = upr_t;                             // the kernel works in tile units from here on
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_prof.on) {                         // timed launch: the events are the kernel's own start / stop (see overlay_impl)
         ev0 = prof_event();
         ev1 = prof_event();
     }
     if (ev0 && ev1) {
-        hipExtLaunchKernelGGL(k_overlay_raw35, dim3(nblocks), dim3(block), (uint32_t)lds, s, ev0, ev1, 0u, o,
+        hipExtLaunchKernelGGL(k_overlay_raw35, rgrid, dim3(block), (uint32_t)lds, s, ev0, ev1, 0u, o,
                               reinterpret_cast<const uint2 *>(vrows), reinterpret_cast<const int2 *>(band_rows), upr,
-                              max_src_rows, (int)owner_off);
+                              max_src_rows, (int)owner_off, TX, tx_magic, cpt_magic);
     } else if (g_overlay_stop_event) {
-        hipExtLaunchKernelGGL(k_overlay_raw35, dim3(nblocks), dim3(block), (uint32_t)lds, s, nullptr, g_overlay_stop_event,
+        hipExtLaunchKernelGGL(k_overlay_raw35, rgrid, dim3(block), (uint32_t)lds, s, nullptr, g_overlay_stop_event,
                               0u, o, reinterpret_cast<const uint2 *>(vrows), reinterpret_cast<const int2 *>(band_rows), upr,
-                              max_src_rows, (int)owner_off);
+                              max_src_rows, (int)owner_off, TX, tx_magic, cpt_magic);
         g_overlay_stop_event = nullptr;
     } else
-        hipLaunchKernelGGL(k_overlay_raw35, dim3(nblocks), dim3(block), lds, s, o, reinterpret_cast<const uint2 *>(vrows),
-                           reinterpret_cast<const int2 *>(band_rows), upr, max_src_rows, (int)owner_off);
+        hipLaunchKernelGGL(k_overlay_raw35, rgrid, dim3(block), lds, s, o, reinterpret_cast<const uint2 *>(vrows),
+                           reinterpret_cast<const int2 *>(band_rows), upr, max_src_rows, (int)owner_off, TX, tx_magic, cpt_magic);
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) g_prof.pending.emplace_back(ev0, ev1);
     return CAMA_OK;
@@ -1193,8 +1214,9 @@ int cama_overlay_scenes(const cama_scene *scenes_host, const cama_scene *scenes_
     int64_t nmax = 0;
     if (int rc = check_scenes(scenes_host, scenes_dev, S, F, true, &nmax)) return rc;
     if (W % 16) return fail(CAMA_EINVAL, "multi-scene launches need W %% 16 == 0 (W=%d)", W);
+    if (S > CAMA_MAX_SCENES_PER_LAUNCH) return fail(CAMA_EINVAL, "S=%d: at most %d scenes per chain", S, CAMA_MAX_SCENES_PER_LAUNCH);
     return overlay_impl(nullptr, nullptr, nullptr, nmax, S * F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
-                        scratch_bytes, stream, reinterpret_cast<const SceneRef *>(scenes_dev), F);
+                        scratch_bytes, stream, scenes_host, F);
 }
 
 int cama_render_scenes(const cama_scene *scenes_host, const cama_scene *scenes_dev, int32_t S, int32_t xyz_is_f64,

@@ -7,8 +7,9 @@
 // overlay: band copy + deterministic stamp resolution
 // ------------------------------------------------------------------------------------------
 struct OverlayArgs {
-    const SceneRef *scenes;           // SCENES instantiation: per-scene src / mosaic (frame f -> scene f / frames_per_scene)
-    int frames_per_scene;
+    int f0;                           // multi-scene chains: launch-wide number of this launch's first frame (the scratch is
+                                      // indexed by the launch-wide frame, src / mosaic by the frame inside the scene)
+    uint32_t cols_magic;              // ceil(2^32 / cols): exact quotients below 2^16
     const uint8_t *src;
     uint8_t *mosaic;
     int C, H, W, cols, R, NB;
@@ -167,41 +168,26 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <bool VEC, bool RESAMPLE, bool ALPHA = false, bool SCENES = false>
-__global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
+// One band of one camera of one frame.  Launch geometry: grid (NB * cols, camera rows, frames) -- x = band * cols + camera
+// column, so workgroups are dispatched in the order (frame, mosaic row of cameras, band, camera column): the `cols`
+// cameras that share a mosaic row-band are adjacent in launch order and R full mosaic rows (R * cols*W*3 contiguous bytes)
+// are written close together in time instead of one third at a time.  (Round 3: the same order used to be decoded from a
+// linear blockIdx.x with three runtime divisions -- ~100 dependent scalar instructions incl. v_rcp / readfirstlane round
+// trips at the head of every workgroup, before its first load could be issued; with a 3-D grid one multiply-high is left.)
+// f0 = launch-wide number of the scene's first frame (0 for single-scene launches): everything in the scratch is indexed
+// by the launch-wide frame, the images (a.src / a.mosaic, already the scene's own) by the frame inside the scene.
+template <bool VEC, bool RESAMPLE, bool ALPHA>
+__device__ __forceinline__ void overlay_band(const OverlayArgs &a, const uint32_t fl, const uint32_t f0, uint32_t *s_owner)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x W, used only by stamped bands
-#ifdef OVERLAY_ORDER_FCB
-    const uint32_t bin = blockIdx.x;
-    const uint32_t fc = bin / (uint32_t)a.NB, b = bin - fc * (uint32_t)a.NB;
-    const uint32_t f = fc / (uint32_t)a.C, c = fc - f * (uint32_t)a.C;
-#else
-    // Workgroup order (frame, mosaic row of cameras, band, camera column): the `cols` cameras that share a mosaic
-    // row-band are adjacent in launch order, so R full mosaic rows (R * cols*W*3 contiguous bytes) are written
-    // close together in time instead of one third at a time.
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
-    const uint32_t camrows = (C + cols - 1) / cols;
-    uint32_t t = blockIdx.x;
-    const uint32_t cc = t % cols; t /= cols;
-    const uint32_t b = t % NB;    t /= NB;
-    const uint32_t cr = t % camrows;
-    const uint32_t f = t / camrows;
-    const uint32_t c = cr * cols + cc;
+    // exact for x < 2^16 (host-checked); a divisor of 1 has no 32-bit magic (ceil(2^32 / 1) does not fit)
+    const uint32_t b = cols == 1u ? blockIdx.x : __umulhi(blockIdx.x, a.cols_magic), cc = blockIdx.x - b * cols;
+    const uint32_t c = blockIdx.y * cols + cc;
     if (c >= C) return;                                  // ragged last camera row
+    const uint32_t fcl = fl * C + c;                     // (frame, camera) inside the scene's own frame tensor
+    const uint32_t f = f0 + fl;
     const uint32_t fc = f * C + c;
     const uint32_t bin = fc * NB + b;
-#endif
-    // multi-scene launch: this frame's scene supplies the frames and the mosaic; fl = the frame's number inside its scene
-    // (everything in the scratch stays indexed by the launch-wide f)
-    uint32_t fl = f;
-    if (SCENES) {
-        const uint32_t sidx = f / (uint32_t)a.frames_per_scene;
-        fl = f - sidx * (uint32_t)a.frames_per_scene;
-        kSceneRef *sc = (kSceneRef *)(a.scenes) + sidx;
-        a.src = sc->src;
-        a.mosaic = sc->mosaic;
-    }
-    const uint32_t fcl = fl * C + c;                     // (frame, camera) inside the scene's own frame tensor
     const int y0 = (int)b * a.R;
     const int nrows = min(a.R, a.H - y0);
     const int W = a.W;
@@ -211,13 +197,27 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
     const uint32_t n = a.counts[bin];
 #endif
 
+#ifdef OVERLAY_SRC_FIRST
+    // (A/B: the source loads go out before anything that depends on the band's stamp count)
+    const uint8_t *sband0 = a.src + ((size_t)fcl * a.H + y0) * (size_t)W * 3;
+    const u32x4 *s16_0 = reinterpret_cast<const u32x4 *>(sband0);
+    const uint32_t nchunks0 = (uint32_t)nrows * a.cpr;
+    u32x4 v[OVERLAY_UNROLL];
+    if (VEC && !RESAMPLE) {
+#pragma unroll
+        for (int j = 0; j < OVERLAY_UNROLL; ++j) v[j] = OVERLAY_LOAD(s16_0 + min(threadIdx.x + j * OVERLAY_BLOCK, nchunks0 - 1u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // A stamped band fetches this thread's first stamp record and THEN issues its (first, normally only) batch of
     // 16-byte source loads, all before clearing / rasterising: the source chunks do not depend on the owner table, so
     // their HBM latency runs under the LDS work, and the stamp record -- issued first, VMEM returns in order -- can
     // be waited for without draining them.
     // (the record load is unconditional -- lanes without a stamp re-read the bin's last one, empty bins read
     // stamps[0] -- because a load inside a divergent branch is waited for right there)
-    const uint2 *st = a.stamps + (n ? (size_t)a.fc_base[fc] + a.bin_off[bin] : (size_t)0);
+    // (count, offsets: three independent scalar loads, one latency -- not count first and the offsets behind a branch)
+    const uint32_t list0 = a.fc_base[fc] + a.bin_off[bin];
+    const uint2 *st = a.stamps + (n ? (size_t)list0 : (size_t)0);
     const uint2 first = st[n ? min(threadIdx.x, n - 1u) : 0u];
     __builtin_amdgcn_sched_barrier(0);          // keep the record load ahead of the source loads (in-order vmcnt)
 
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
     constexpr int U = OVERLAY_UNROLL;
     const u32x4 *s16 = reinterpret_cast<const u32x4 *>(sband);
     const uint32_t nchunks = (uint32_t)nrows * a.cpr;
+#ifndef OVERLAY_SRC_FIRST
     u32x4 v[U];
     if (VEC && !RESAMPLE) {
         // unconditional (index clamped to the band's last chunk): loads under a divergent branch are waited for at
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 #pragma unroll
         for (int j = 0; j < U; ++j) v[j] = OVERLAY_LOAD(s16 + min(threadIdx.x + j * OVERLAY_BLOCK, nchunks - 1u));
     }
+#endif
 
     // owner table: rows of Wp = W + 2 * radius cells, pixel x at cell x + radius (see rasterise_one_padded)
     const int rad = a.disc.radius, Wp = W + 2 * rad;
@@ -326,6 +328,14 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
         }
     }
 }
+
+template <bool VEC, bool RESAMPLE, bool ALPHA = false>
+__global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x (W + 2 radius), used only by stamped bands
+    overlay_band<VEC, RESAMPLE, ALPHA>(a, blockIdx.z, (uint32_t)a.f0, s_owner);
+}
+
 
 // Raw-frame overlay, LDS-staged (separable maps = zero lens distortion, the nuScenes / CAMA calibration):
 // the source rows a band of R destination rows needs (host-precomputed [first, count] per camera and band) are

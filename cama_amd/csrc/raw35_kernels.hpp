@@ -68,25 +68,163 @@ __device__ __forceinline__ void raw35_unit(const uint32_t (&d0)[15], const uint3
     ((px[K] = raw35_pixel<K>(d0, d1, wt, wb)), ...);
 }
 
+// ------------------------------------------------------------------------------------------
+// Packed arithmetic (round 3).  PMC showed the first version VALU-bound (76 % of SIMD issue cycles at 5 waves per SIMD:
+// ~8.5 VALU instructions per output byte value -- three v_dot4 for the horizontal taps of both rows, two 24-bit multiplies,
+// the rounding add, the shift, the byte packing).  The blend is exact integer arithmetic without intermediate rounding,
+// v = (sum_ij wv_i wh_j p_ij + 512) >> 10, so the order is free: VERTICAL FIRST on two taps at a time in packed 16-bit
+// lanes (q = wt*a + wb*b <= 32*255 fits 16 bits), then the horizontal pair with one v_dot2_u32_u16:
+//     A = v_perm(row0 dwords) = [a_e, 0, a_e+3, 0]        B = the same bytes of row 1
+//     Q = v_pk_mad_u16(A, wt, v_pk_mul_lo_u16(B, wb))      = [q_e, q_e+3]
+//     r = v_dot2_u32_u16(Q, [64 wl, 64 wr], 32768)         = 64 (S + 512): the result (S + 512) >> 10 is BYTE 2 of r
+// -- 5 instructions per two-tap value; the one-tap values (phase 0 columns, weights 32 | 0) go two at a time through
+//     Q' = v_pk_mad_u16(A, 8 wt, v_pk_mad_u16(B, 8 wb, 128)) = 8 q + 128: (q + 16) >> 5 is the HIGH byte of each lane
+// -- 2 instructions per value; and because every result sits on a byte boundary, the 36 output bytes are gathered with
+// v_perm_b32 (3 per output dword) instead of shift / or chains.  ~170 instead of ~350 VALU instructions per 12-pixel unit.
+// ------------------------------------------------------------------------------------------
+typedef unsigned short raw35_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t raw35_pk_mul(uint32_t a, uint32_t w)
+{
+    return __builtin_bit_cast(uint32_t, (raw35_u16x2)(__builtin_bit_cast(raw35_u16x2, a) * __builtin_bit_cast(raw35_u16x2, w)));
+}
+__device__ __forceinline__ uint32_t raw35_pk_mad(uint32_t a, uint32_t w, uint32_t c)
+{
+    return __builtin_bit_cast(uint32_t, (raw35_u16x2)(__builtin_bit_cast(raw35_u16x2, a) * __builtin_bit_cast(raw35_u16x2, w) +
+                                                      __builtin_bit_cast(raw35_u16x2, c)));
+}
+// v_perm_b32: result byte i = byte sel_i of the 8 bytes {hi, lo} (0..3 = lo, 4..7 = hi), 0x0c = 0x00
+__device__ __forceinline__ uint32_t raw35_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// source byte offset (inside the unit's 60 bytes) of the LEFT tap of destination pixel K, channel CH; the right tap is 3 on
+constexpr int raw35_e(int K, int CH) { return 3 * (5 * (K / 3) + (K % 3 == 0 ? 0 : K % 3 == 1 ? 1 : 3)) + CH; }
+
+// [d_E1, 0, d_E2, 0] from the unit's dwords
+template <int E1, int E2>
+__device__ __forceinline__ uint32_t raw35_gather2(const uint32_t (&d)[15])
+{
+    constexpr int w1 = E1 >> 2, w2 = E2 >> 2;
+    static_assert(w1 < 15 && w2 < 15, "tap outside the unit");
+    constexpr uint32_t sel = (uint32_t)(E1 & 3) | (0x0cu << 8) | ((uint32_t)((w1 == w2 ? 0 : 4) + (E2 & 3)) << 16) | (0x0cu << 24);
+    return raw35_perm(d[w2], d[w1], sel);
+}
+
+// Values of a unit, as registers whose bytes hold results: reg index + byte position of output byte m = 3 K + CH.
+//   two-tap pixels (K % 3 != 0): one register per (K, CH), value in byte 2           -> regs 0 .. 23
+//   one-tap pixels (K % 3 == 0: K = 0, 3, 6, 9), 12 values, two per register (bytes 1 and 3) -> regs 24 .. 29,
+//   paired in output order (m = 0,1 | 2,9 | 10,11 | 18,19 | 20,27 | 28,29) so that neighbours in a dword share a register
+constexpr int raw35_two_index(int K, int CH) { return ((K / 3) * 2 + (K % 3 - 1)) * 3 + CH; }
+constexpr int raw35_one_order(int K, int CH) { return (K / 3) * 3 + CH; }          // 0 .. 11 in output order
+constexpr int raw35_reg_of(int m)
+{
+    const int K = m / 3, CH = m % 3;
+    return K % 3 ? raw35_two_index(K, CH) : 24 + raw35_one_order(K, CH) / 2;
+}
+constexpr int raw35_byte_of(int m)
+{
+    const int K = m / 3, CH = m % 3;
+    return K % 3 ? 2 : 1 + 2 * (raw35_one_order(K, CH) % 2);
+}
+
+template <int K, int CH>
+__device__ __forceinline__ uint32_t raw35_two_tap(const uint32_t (&d0)[15], const uint32_t (&d1)[15], uint32_t wt2, uint32_t wb2)
+{
+    constexpr int E = raw35_e(K, CH);
+    constexpr uint32_t wl = K % 3 == 1 ? 11u : 21u, wr = 32u - wl;
+    const uint32_t A = raw35_gather2<E, E + 3>(d0), B = raw35_gather2<E, E + 3>(d1);
+    const uint32_t Q = raw35_pk_mad(A, wt2, raw35_pk_mul(B, wb2));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(raw35_u16x2, Q), __builtin_bit_cast(raw35_u16x2, (64u * wl) | ((64u * wr) << 16)),
+                                  32768u, false);
+}
+
+template <int J>        // one-tap pair J (output order): values j = 2 J and 2 J + 1 of the 12 one-tap values
+__device__ __forceinline__ uint32_t raw35_one_tap_pair(const uint32_t (&d0)[15], const uint32_t (&d1)[15], uint32_t wt8, uint32_t wb8)
+{
+    constexpr int j1 = 2 * J, j2 = 2 * J + 1;
+    constexpr int E1 = raw35_e((j1 / 3) * 3, j1 % 3), E2 = raw35_e((j2 / 3) * 3, j2 % 3);
+    const uint32_t A = raw35_gather2<E1, E2>(d0), B = raw35_gather2<E1, E2>(d1);
+    return raw35_pk_mad(A, wt8, raw35_pk_mad(B, wb8, 0x00800080u));
+}
+
+template <int I>
+__device__ __forceinline__ uint32_t raw35_value(const uint32_t (&d0)[15], const uint32_t (&d1)[15], uint32_t wt2, uint32_t wb2,
+                                            uint32_t wt8, uint32_t wb8)
+{
+    if constexpr (I < 24)
+        return raw35_two_tap<(I / 3 / 2) * 3 + (I / 3) % 2 + 1, I % 3>(d0, d1, wt2, wb2);
+    else
+        return raw35_one_tap_pair<I - 24>(d0, d1, wt8, wb8);
+}
+
+template <int... I>
+__device__ __forceinline__ void raw35_values(const uint32_t (&d0)[15], const uint32_t (&d1)[15], uint32_t wt, uint32_t wb,
+                                             uint32_t (&r)[30], std::integer_sequence<int, I...>)
+{
+    const uint32_t wt2 = wt | (wt << 16), wb2 = wb | (wb << 16), wt8 = wt2 << 3, wb8 = wb2 << 3;
+    // I = 0 .. 23: two-tap register I <-> (K, CH) with raw35_two_index(K, CH) == I;  I = 24 .. 29: one-tap pairs
+    ((r[I] = raw35_value<I>(d0, d1, wt2, wb2, wt8, wb8)), ...);
+}
+
+// output dword J of the unit (bytes 4 J .. 4 J + 3) gathered from the value registers
+template <int J>
+__device__ __forceinline__ uint32_t raw35_out_dword(const uint32_t (&r)[30])
+{
+    constexpr int r0 = raw35_reg_of(4 * J), r1 = raw35_reg_of(4 * J + 1), r2 = raw35_reg_of(4 * J + 2), r3 = raw35_reg_of(4 * J + 3);
+    constexpr uint32_t b0 = raw35_byte_of(4 * J), b1 = raw35_byte_of(4 * J + 1), b2 = raw35_byte_of(4 * J + 2),
+                       b3 = raw35_byte_of(4 * J + 3);
+    uint32_t t = raw35_perm(r[r1], r[r0], b0 | ((4u + b1) << 8) | (0x0cu << 16) | (0x0cu << 24));
+    if constexpr (r2 == r3) {
+        return raw35_perm(r[r2], t, 0u | (1u << 8) | ((4u + b2) << 16) | ((4u + b3) << 24));
+    } else {
+        t = raw35_perm(r[r2], t, 0u | (1u << 8) | ((4u + b2) << 16) | (0x0cu << 24));
+        return raw35_perm(r[r3], t, 0u | (1u << 8) | (2u << 16) | ((4u + b3) << 24));
+    }
+}
+
+template <int... J>
+__device__ __forceinline__ void raw35_gather_out(const uint32_t (&r)[30], uint32_t (&o)[9], std::integer_sequence<int, J...>)
+{
+    ((o[J] = raw35_out_dword<J>(r)), ...);
+}
+
 // A stamped band's owner table lives INSIDE the staging area, right behind the band's output rows (owner_off dwords; the
 // staging area is always big enough at a 3:5 scale: rows * 1.25 W >= R * 1.75 W dwords, host-checked): it is built after
 // every unit has read its taps, so a stamped band pays two more barriers and its rasterisation no longer overlaps the
 // source loads, but every workgroup needs 38 KB of LDS instead of 54 KB -- 4 instead of 3 per CU: 140.0 -> 145.5 k
 // frames/s at N = 10^4, 117.7 -> 123.5 k at N = 10^5 (same box).
+// Column tiles (round 3): a band is cut into TX tiles of upr / TX units, one workgroup each.  The ablations behind it
+// (tools/ab, 960x540 from 1600x900, one box): stage -> store without any arithmetic 223 us, + tap reads and the transpose
+// 227 us, + the arithmetic 249 us -- so the kernel is neither at the memory system's limit for this traffic shape nor short
+// of VALU throughput (VALU is ~1/3 busy): with 38 KB of LDS per band a CU holds 4 workgroups = 5 waves per SIMD, too few to
+// hide a workgroup's compute phase behind the others' loads.  Half a band needs half the staging: 8 workgroups per CU.
+__device__ __forceinline__ void raw35_rasterise_tile(uint32_t *s_owner, const uint2 r, int y0, int nrows, int x_first, int Wt,
+                                                     const Disc &disc)
+{
+    const int u = (int)(r.x & 0xffffu), v = (int)(r.x >> 16);
+    const uint32_t val = r.y + 1u;
+    const int ylo = max(v - disc.radius, y0), yhi = min(v + disc.radius, y0 + nrows - 1);
+    for (int y = ylo; y <= yhi; ++y) {
+        const int hw = disc_halfwidth(disc, abs(y - v));
+        if (hw < 0) continue;
+        const int xlo = max(u - hw, x_first), xhi = min(u + hw, x_first + Wt - 1);
+        uint32_t *row = s_owner + (y - y0) * Wt - x_first;
+        for (int x = xlo; x <= xhi; ++x) atomicMax(&row[x], val);
+    }
+}
+
 __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a, const uint2 *__restrict__ vrows,
                                                                    const int2 *__restrict__ band_rows, int upr,
-                                                                   int max_src_rows, int owner_off)
+                                                                   int max_src_rows, int owner_off, int TX,
+                                                                   uint32_t tx_magic, uint32_t cpt_magic)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    // same workgroup order as k_overlay: (frame, mosaic row of cameras, band, camera column)
+    // same workgroup order as k_overlay -- (frame, mosaic row of cameras, band, camera column), column tile innermost -- as a
+    // 3-D grid: x = (band * cols + camera column) * TX + tile, y = camera row, z = frame; quotients by multiply-high
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
-    const uint32_t camrows = (C + cols - 1) / cols;
-    uint32_t t = blockIdx.x;
-    const uint32_t cc = t % cols; t /= cols;
-    const uint32_t b = t % NB;    t /= NB;
-    const uint32_t cr = t % camrows;
-    const uint32_t f = t / camrows;
-    const uint32_t c = cr * cols + cc;
+    // (a divisor of 1 has no 32-bit magic: ceil(2^32 / 1) does not fit)
+    const uint32_t bc = TX == 1 ? blockIdx.x : __umulhi(blockIdx.x, tx_magic), tx = blockIdx.x - bc * (uint32_t)TX;
+    const uint32_t b = cols == 1u ? bc : __umulhi(bc, a.cols_magic), cc = bc - b * cols;
+    const uint32_t f = blockIdx.z;
+    const uint32_t c = blockIdx.y * cols + cc;
     if (c >= C) return;
     const uint32_t fc = f * C + c;
     const uint32_t bin = fc * NB + b;
@@ -94,24 +232,36 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     const int nrows = min(a.R, a.H - y0);
     const int W = a.W;
     const uint32_t n = a.counts[bin];
-    const uint32_t row_dwords = (uint32_t)W * 3u / 4u;                 // W % 48 == 0 (host-checked): multiple of 36
-    const uint32_t src_row_dwords = (uint32_t)a.W0 * 3u / 4u;          // W0 * 3 % 16 == 0 (host-checked)
+    // this workgroup's tile: upr units (12 destination pixels = 9 dwords out, 20 source pixels = 15 dwords in, each)
+    const int Wt = upr * 12, x_first = (int)tx * Wt;
+    const uint32_t row_dwords = (uint32_t)upr * 9u;                    // destination dwords per tile row (multiple of 4)
+    const uint32_t src_row_dwords = (uint32_t)upr * 15u;               // source dwords per tile row (multiple of 4)
+    const uint32_t src_pitch16 = (uint32_t)a.W0 * 3u / 16u;            // 16-byte chunks per raw row (W0*3 % 16 == 0)
     uint32_t *s_stage = s_dyn;                                         // [max_src_rows * src_row_dwords], later the output
-    uint32_t *s_owner = s_dyn + owner_off;                             // [R * W], stamped bands only
+    uint32_t *s_owner = s_dyn + owner_off;                             // [R * Wt], stamped bands only
 
     // the band's first stamp record before the source loads (VMEM returns in order; see k_overlay)
-    const uint2 *st = a.stamps + (n ? (size_t)a.fc_base[fc] + a.bin_off[bin] : (size_t)0);
+    const uint32_t list0 = a.fc_base[fc] + a.bin_off[bin];            // (unconditional: three parallel scalar loads)
+    const uint2 *st = a.stamps + (n ? (size_t)list0 : (size_t)0);
     const uint2 first = st[n ? min(threadIdx.x, n - 1u) : 0u];
     __builtin_amdgcn_sched_barrier(0);
 
     // stage the band's source rows: one contiguous range of the raw frame, same layout in LDS
     const int2 br = band_rows[c * NB + b];                             // {first source row, number of source rows}
-    const u32x4 *g = reinterpret_cast<const u32x4 *>(a.src + ((size_t)fc * a.H0 + br.x) * (size_t)a.W0 * 3);
-    const uint32_t nsrc = (uint32_t)br.y * (src_row_dwords >> 2);      // 16-byte chunks
+    const u32x4 *g = reinterpret_cast<const u32x4 *>(a.src + ((size_t)fc * a.H0 + br.x) * (size_t)a.W0 * 3) +
+                     tx * (src_row_dwords >> 2);
+    const uint32_t cpt = src_row_dwords >> 2;                          // 16-byte chunks per tile row
+    const uint32_t nsrc = (uint32_t)br.y * cpt;
+    // chunk idx of the tile = (source row idx / cpt, chunk idx % cpt) (cpt_magic = ceil(2^32 / cpt) from the host: exact for
+    // idx < 2^16); TX == 1: pitch == cpt, one contiguous range
+    const auto gaddr = [&](uint32_t idx) {
+        const uint32_t r = __umulhi(idx, cpt_magic);
+        return g + (size_t)r * src_pitch16 + (idx - r * cpt);
+    };
     constexpr int U = RAW35_STAGE_UNROLL;
     u32x4 v[U];
 #pragma unroll
-    for (int j = 0; j < U; ++j) v[j] = OVERLAY_LOAD(g + min(threadIdx.x + j * blockDim.x, nsrc - 1u));
+    for (int j = 0; j < U; ++j) v[j] = OVERLAY_LOAD(gaddr(min(threadIdx.x + j * blockDim.x, nsrc - 1u)));
 
     u32x4 *s16 = reinterpret_cast<u32x4 *>(s_stage);
 #pragma unroll
@@ -119,7 +269,7 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
         const uint32_t idx = threadIdx.x + j * blockDim.x;
         if (idx < nsrc) s16[idx] = v[j];
     }
-    for (uint32_t idx = threadIdx.x + U * blockDim.x; idx < nsrc; idx += blockDim.x) s16[idx] = OVERLAY_LOAD(g + idx);
+    for (uint32_t idx = threadIdx.x + U * blockDim.x; idx < nsrc; idx += blockDim.x) s16[idx] = OVERLAY_LOAD(gaddr(idx));
     __syncthreads();
 
     // one 12-pixel unit per thread (the block covers the band: items <= blockDim, host-checked)
@@ -140,40 +290,64 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     if (n) {                                                           // (workgroup-uniform)
         __syncthreads();                                               // every unit holds its taps: staging is dead
         uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
-        const int n4 = (nrows * W + 3) >> 2;
+        const int n4 = (nrows * Wt + 3) >> 2;
         for (int j = threadIdx.x; j < n4; j += blockDim.x) o4[j] = make_uint4(0, 0, 0, 0);
         lds_barrier();
-        if (threadIdx.x < n) rasterise_one(s_owner, first, y0, nrows, W, a.disc);
-        rasterise_rest(s_owner, st, threadIdx.x + blockDim.x, blockDim.x, n, y0, nrows, W, a.disc);
+        if (threadIdx.x < n) raw35_rasterise_tile(s_owner, first, y0, nrows, x_first, Wt, a.disc);
+        for (uint32_t sidx = threadIdx.x + blockDim.x; sidx < n; sidx += blockDim.x)
+            raw35_rasterise_tile(s_owner, st[sidx], y0, nrows, x_first, Wt, a.disc);
         __syncthreads();
     }
+    uint32_t o[9];
+#if defined(RAW35_ABL_NOMATH)                                          // ablation: taps read, nothing computed
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = d0[k] ^ d1[k + 6] ^ wt ^ wb;
+#elif defined(RAW35_OLD_MATH)
     uint32_t px[12];
     raw35_unit(d0, d1, wt, wb, px, std::make_integer_sequence<int, 12>{});
-    if (n) {
-        const uint4 *orow = reinterpret_cast<const uint4 *>(s_owner + row * (uint32_t)W + u * 12u);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const uint4 o = orow[j];
-            if (o.x) px[4 * j + 0] = ((o.x - 1u) & 1u) ? a.pal.c[1] : a.pal.c[0];
-            if (o.y) px[4 * j + 1] = ((o.y - 1u) & 1u) ? a.pal.c[1] : a.pal.c[0];
-            if (o.z) px[4 * j + 2] = ((o.z - 1u) & 1u) ? a.pal.c[1] : a.pal.c[0];
-            if (o.w) px[4 * j + 3] = ((o.w - 1u) & 1u) ? a.pal.c[1] : a.pal.c[0];
-        }
-    }
-    uint32_t o[9];
     raw35_pack4(px, o);
     raw35_pack4(px + 4, o + 3);
     raw35_pack4(px + 8, o + 6);
+#else
+    {
+        uint32_t r[30];
+        raw35_values(d0, d1, wt, wb, r, std::make_integer_sequence<int, 30>{});
+        raw35_gather_out(r, o, std::make_integer_sequence<int, 9>{});
+    }
+#endif
+    if (n) {
+        // stamped band: owned pixels take the palette colour -- colour and mask streams of the unit's 12 pixels, packed
+        // like the output, then one select per dword
+        const uint4 *orow = reinterpret_cast<const uint4 *>(s_owner + row * (uint32_t)Wt + u * 12u);
+        uint32_t cv[12], cm[12];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint4 ow = orow[j];
+            const uint32_t w4[4] = {ow.x, ow.y, ow.z, ow.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cm[4 * j + k] = w4[k] ? 0x00ffffffu : 0u;
+                cv[4 * j + k] = w4[k] ? (((w4[k] - 1u) & 1u) ? a.pal.c[1] : a.pal.c[0]) : 0u;
+            }
+        }
+        uint32_t V[9], M[9];
+        raw35_pack4(cv, V);     raw35_pack4(cv + 4, V + 3); raw35_pack4(cv + 8, V + 6);
+        raw35_pack4(cm, M);     raw35_pack4(cm + 4, M + 3); raw35_pack4(cm + 8, M + 6);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = (o[k] & ~M[k]) | V[k];
+    }
     __syncthreads();                                                   // every unit has read its taps: staging is dead
+#ifndef RAW35_ABL_COPYONLY                                             // (ablation: the staged bytes go out as they are)
     if (active) {
         uint32_t *dst = s_stage + row * row_dwords + u * 9u;           // R * row_dwords <= staging size (host-checked)
 #pragma unroll
         for (int k = 0; k < 9; ++k) dst[k] = o[k];
     }
     __syncthreads();
+#endif
     uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
-                     ((size_t)(c / cols) * a.H + y0) * a.mosaic_row_bytes + (size_t)(c % cols) * W * 3;
-    const uint32_t cpr = row_dwords >> 2;                               // 16-byte chunks per destination row
+                     ((size_t)(c / cols) * a.H + y0) * a.mosaic_row_bytes + (size_t)(c % cols) * W * 3 + (size_t)x_first * 3;
+    const uint32_t cpr = row_dwords >> 2;                               // 16-byte chunks per destination tile row
     const uint32_t nchunks = (uint32_t)nrows * cpr;
     uint32_t r = threadIdx.x / cpr, col = threadIdx.x - r * cpr;        // one division, then (row, chunk) advance by blockDim
     const uint32_t dr = blockDim.x / cpr, dc = blockDim.x - dr * cpr;

@@ -508,7 +508,8 @@ def render_clips(clips, dataset, outs, pipelined=True, poses=None, max_frames_pe
     same_crop = all(np.array_equal(np.asarray(cm.mm.crop_box(), np.float64).reshape(-1), crop0) for cm in clips)
     if len(batch) == len(clips) and same_crop and eng.scene_batchable(batch):
         F = len(items[0][1])
-        per = max(1, (max_frames_per_launch or 16384) // max(1, F))
+        from .engine import MAX_SCENES_PER_LAUNCH
+        per = max(1, min(MAX_SCENES_PER_LAUNCH, (max_frames_per_launch or 16384) // max(1, F)))
         for lo in range(0, len(batch), per):
             group = batch[lo:lo + per]
             if len(group) == 1:

@@ -18,6 +18,7 @@ RADIUS = 2                                                    # cama/reproject.p
 # maps with at least this many vertices hand their block index (per-block AABBs) to the render: below, the
 # one-thread-per-block pre-pass costs a launch for nothing.  CAMA_BOUNDS_MIN_VERTS=1 forces it (tests).
 BOUNDS_MIN_VERTS = int(os.environ.get("CAMA_BOUNDS_MIN_VERTS", "65536"))
+MAX_SCENES_PER_LAUNCH = 1024                                  # include/cama_hip.h CAMA_MAX_SCENES_PER_LAUNCH
 
 
 def _torch():
@@ -669,7 +670,7 @@ class Engine:
                     or tuple(src.shape) != (F, rig.C, rig.H, rig.W, 3) or not src.is_contiguous() or not out.is_contiguous()
                     or not (isinstance(w2c, np.ndarray) and w2c.dtype == np.float32)):
                 return False
-        return len(items) * F <= 65535
+        return len(items) * F <= 65535 and len(items) <= MAX_SCENES_PER_LAUNCH
 
     def _scene_table(self, items):
         """(host uint64 [S,10], device twin) of cama_scene entries for `items`, cached on the pointers themselves."""

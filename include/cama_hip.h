@@ -46,6 +46,7 @@ extern "C" {
 #define CAMA_MAX_CAMERAS 16
 #define CAMA_MAX_RADIUS  15
 #define CAMA_BIN_WORKLIST 1   /* flags of the bin / render entries */
+#define CAMA_MAX_SCENES_PER_LAUNCH 1024  /* cama_*_scenes: scenes per chain */
 
 int cama_abi_version(void);
 const char *cama_last_error(void);
@@ -216,12 +217,16 @@ int64_t cama_pipeline_issued(cama_pipeline *p);
 int64_t cama_pipeline_completed(cama_pipeline *p);
 
 /*
- * Many scenes per launch.  main.py:32 renders scene after scene; a scene of ~1e4 vertices x 40 frames is ~0.35 ms of GPU
- * work behind 6-7 launches, so a 73-scene sweep spends a few percent of its time on kernel boundaries and on the host
- * issuing ~500 launches.  These entries render S scenes that share frame count F, camera count C, image size and vertex
- * dtype as ONE chain: a device table of per-scene pointers, frame f of the launch = frame f % F of scene f / F.
- *   scenes_host / scenes_dev   the same S entries in host memory (validated here) and in device memory (read by the
- *                              kernels through scalar loads); both stay valid until the launch has completed
+ * Many scenes per chain.  main.py:32 renders scene after scene; a scene of ~1e4 vertices x 40 frames is ~0.35 ms of GPU
+ * work behind 6-7 launches, so a 73-scene sweep issues ~500 launches and at the reference's default image size the HOST
+ * issuing them is the bound.  These entries render S scenes that share frame count F, camera count C, image size and vertex
+ * dtype through ONE binning chain (memset, projection, scans, scatter over all S*F frames: a device table of per-scene
+ * pointers, frame f of the chain = frame f % F of scene f / F) followed by one overlay launch per scene out of the shared
+ * scratch.  (One overlay launch for all scenes was measured slower: the overlay's bandwidth falls with the length of a
+ * launch)
+ *   scenes_host / scenes_dev   the same S <= CAMA_MAX_SCENES_PER_LAUNCH entries in host memory (validated here; the
+ *                              overlay launches take their image pointers from this copy) and in device memory (read by
+ *                              the projection through scalar loads); both stay valid until the chain has completed
  *   w2c        [S*F,16] device, scene-major          scratch >= cama_render_scratch_bytes(max N, S*F, C, H, W, radius)
  * Restrictions: no block_bounds / work lists (meant for many small maps; big site maps are launched per scene), the
  * plain pre-resized-frame overlay only.  Bit-identical to S calls of the single-scene entries.
