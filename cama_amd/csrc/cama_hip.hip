@@ -221,6 +221,28 @@ unsigned persistent_workgroups()
     return v ? (v + 7u) & ~7u : 2048u;
 }
 
+// Workgroup -> band mapping of the overlay kernels (overlay_kernels.hpp: xcd_contiguous_item): 0 = workgroup L renders
+// band L (every XCD owns every eighth band of one stream), 31 = every XCD renders one contiguous eighth of the launch.
+// Chosen by the bytes a launch touches (frames read + mosaic written): measured on MI355X, kernel bandwidth / 8 TB/s,
+// interleaved vs contiguous --
+//   1600x900:  10 frames (0.5 GB) 0.79 / 0.76   20 (1 GB) 0.78 / 0.77   40 (2.1 GB) 0.755 / 0.815   160 (8 GB) 0.62 / 0.83
+//              640 (33 GB) 0.66 / 0.80          960x540:  40 (0.75 GB) 0.77 / 0.72   80 (1.5 GB) 0.78 / 0.75   160 (3 GB) 0.76 / 0.76
+// -- interleaved is the better order while every XCD can keep the whole launch's pages mapped; beyond ~2 GB per launch an
+// XCD that touches only its own eighth of the pages wins, and the more the longer the launch.
+// CAMA_OVERLAY_CHUNK_LOG2 = 0 | 31 (or 1..30: round-robin chunks of 2^k bands, never better) overrides, for A/B.
+uint32_t overlay_chunk_log2(size_t launch_bytes)
+{
+    static const int forced = getenv("CAMA_OVERLAY_CHUNK_LOG2") ? atoi(getenv("CAMA_OVERLAY_CHUNK_LOG2")) : -1;
+    if (forced >= 0) return forced > 31 ? 31u : (uint32_t)forced;
+    return launch_bytes >= ((size_t)7 << 28) ? 31u : 0u;         // 1.75 GiB
+}
+dim3 overlay_grid(size_t items, uint32_t chunk_log2)
+{
+    if (chunk_log2 >= 31u) return dim3((unsigned)((items + 7) / 8 * 8));
+    const size_t per = (size_t)8 << chunk_log2;
+    return dim3((unsigned)((items + per - 1) / per * per));
+}
+
 int check_common(int64_t N, int F, int C, int W, int H)
 {
     if (N < 0 || N >= (1ll << 30)) return fail(CAMA_EINVAL, "N=%lld out of range [0, 2^30)", (long long)N);
@@ -626,6 +648,8 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
 
     OverlayArgs o{};
     o.f0 = 0;
+    o.nb_magic = (uint32_t)(((1ull << 32) + (uint32_t)L.NB - 1) / (uint32_t)L.NB);
+    o.cr_magic = (uint32_t)(((1ull << 32) + (uint32_t)((C + cols - 1) / cols) - 1) / (uint32_t)((C + cols - 1) / cols));
     o.cols_magic = (uint32_t)(((1ull << 32) + (uint32_t)cols - 1) / (uint32_t)cols);
     o.src = src; o.mosaic = mosaic; o.C = C; o.H = H; o.W = W; o.cols = cols; o.R = L.R; o.NB = L.NB;
     const int rows = (C + cols - 1) / cols;
@@ -651,10 +675,19 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
         o.ms.xr = raw->separable ? 0 : W; o.ms.xc = 1; o.ms.yr = raw->separable ? 1 : W; o.ms.yc = raw->separable ? 0 : 1;
         o.ms.w_magic = 0;
     }
-    const unsigned nblocks = (unsigned)((size_t)F * rows * cols * L.NB);   // (frame, camera row, band, camera column)
-    // k_overlay / k_overlay_scenes: the same order as a 3-D grid (x = band * cols + camera column, y = camera row, z = frame)
-    if ((size_t)L.NB * cols >= 65536) return fail(CAMA_EINVAL, "bands x cols = %d x %d exceeds the overlay grid", L.NB, cols);
-    const dim3 ogrid((unsigned)(L.NB * cols), (unsigned)rows, (unsigned)F);
+    // items in the order (frame, camera row, band, camera column); the kernels map workgroups to items XCD-contiguously
+    // (overlay_kernels.hpp: decode_band), grid = items rounded up to a multiple of 8
+    const size_t items_per_frame = (size_t)rows * cols * L.NB;
+    const unsigned nblocks = (unsigned)((size_t)F * items_per_frame);
+    // bytes one launch touches: its frames (raw or pre-resized) + its mosaic
+    const size_t frames_in_launch = scenes_dev ? (size_t)frames_per_scene : (size_t)F;
+    const size_t launch_bytes = frames_in_launch * (size_t)C * 3 *
+                                ((raw ? (size_t)raw->H0 * raw->W0 : (size_t)H * W) + (size_t)H * W);
+    o.chunk_log2 = overlay_chunk_log2(launch_bytes);
+    const uint32_t chunk_log2 = o.chunk_log2;
+    const auto grid8 = [chunk_log2](size_t items) { return overlay_grid(items, chunk_log2); };
+    o.items = nblocks;
+    const dim3 ogrid = grid8(nblocks);
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -690,9 +723,11 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
         if (lds_raw > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_rawlds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_raw));
-        hipLaunchKernelGGL(k_overlay_rawlds, dim3(nblocks * (unsigned)raw->tiles_x), dim3(RAWLDS_BLOCK), lds_raw, s, o,
+        o.items = nblocks * (unsigned)raw->tiles_x;
+        hipLaunchKernelGGL(k_overlay_rawlds, grid8(o.items), dim3(RAWLDS_BLOCK), lds_raw, s, o,
                            reinterpret_cast<const int2 *>(raw->band_rows),
-                           reinterpret_cast<const int2 *>(raw->tile_bytes), raw->tiles_x, Wt);
+                           reinterpret_cast<const int2 *>(raw->tile_bytes), raw->tiles_x, Wt,
+                           (uint32_t)(((1ull << 32) + (uint32_t)raw->tiles_x - 1) / (uint32_t)raw->tiles_x));
     } else if (raw)
         hipLaunchKernelGGL((k_overlay<true, true>), ogrid, dim3(OVERLAY_BLOCK), lds, s, o);
     else if (o.pal.alpha256 != 256u) {      // translucent extension: its own instantiations, the exact kernels stay lean
@@ -707,7 +742,8 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
         // 160 / 640 frames per launch: 0.80 / 0.76 / 0.74 / 0.61-0.71 / 0.67 of 8 TB/s; 73 scenes as one launch 0.70 against
         // 0.77 as 73 launches -- so the ~12 us kernel boundary every 40 frames is the cheaper price.
         const int S = F / frames_per_scene;
-        const dim3 sgrid(ogrid.x, ogrid.y, (unsigned)frames_per_scene);
+        o.items = (uint32_t)((size_t)frames_per_scene * items_per_frame);
+        const dim3 sgrid = grid8(o.items);
         for (int k = 0; k < S; ++k) {
             o.src = scenes_host[k].src;
             o.mosaic = scenes_host[k].mosaic;
@@ -849,10 +885,10 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)(base + L.stamps);
     o.disc = disc; o.pal = make_palette(palette_bgr);
     o.H0 = H0; o.W0 = W0;
-    // column tiles per band: 2 when a half band still fills 2+ waves (960-wide tiles: 160 threads, 17 KB of LDS -> 8
-    // workgroups per CU instead of 4), else 1.  CAMA_RAW35_TILES=1|2 overrides (A/B).
+    // column tiles per band (CAMA_RAW35_TILES=2: 960-wide tiles, 160 threads, 17 KB of LDS -> 8 workgroups per CU instead of
+    // 4; A/B only)
     static const int forced_tx = getenv("CAMA_RAW35_TILES") ? atoi(getenv("CAMA_RAW35_TILES")) : 0;
-    int TX = (upr % 8 == 0 && items / 2 >= 128) ? 2 : 1;
+    int TX = 1;       // (measured at 960x540: two tiles 0.66-0.70 of 8 TB/s, one tile 0.70-0.74 -- half rows are short bursts)
     if (forced_tx == 1 || (forced_tx == 2 && upr % 8 == 0)) TX = forced_tx;
     const int upr_t = upr / TX, Wt = W / TX;
     const unsigned block = ((unsigned)L.R * (unsigned)upr_t + 63u) & ~63u;
@@ -864,8 +900,11 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     if (lds > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the 3:5 raw overlay's LDS", W);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if ((size_t)L.NB * cols * TX >= 65536) return fail(CAMA_EINVAL, "bands x cols x tiles exceeds the overlay grid");
-    const dim3 rgrid((unsigned)(L.NB * cols * TX), (unsigned)rows, (unsigned)F);
+    o.items = (uint32_t)((size_t)F * rows * cols * L.NB * TX);
+    o.chunk_log2 = overlay_chunk_log2((size_t)F * C * 3 * ((size_t)H0 * W0 + (size_t)H * W));
+    const dim3 rgrid = overlay_grid(o.items, o.chunk_log2);
+    o.nb_magic = (uint32_t)(((1ull << 32) + (uint32_t)L.NB - 1) / (uint32_t)L.NB);
+    o.cr_magic = (uint32_t)(((1ull << 32) + (uint32_t)rows - 1) / (uint32_t)rows);
     const uint32_t tx_magic = (uint32_t)(((1ull << 32) + (uint32_t)TX - 1) / (uint32_t)TX);
     const uint32_t cpt = (uint32_t)upr_t * 15u / 4u, cpt_magic = (uint32_t)(((1ull << 32) + cpt - 1) / cpt);
     o.cols_magic = (uint32_t)(((1ull << 32) + (uint32_t)cols - 1) / (uint32_t)cols);

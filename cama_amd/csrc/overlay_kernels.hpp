@@ -9,7 +9,9 @@
 struct OverlayArgs {
     int f0;                           // multi-scene chains: launch-wide number of this launch's first frame (the scratch is
                                       // indexed by the launch-wide frame, src / mosaic by the frame inside the scene)
-    uint32_t cols_magic;              // ceil(2^32 / cols): exact quotients below 2^16
+    uint32_t chunk_log2;              // items per XCD chunk = 2^chunk_log2 (>= 31: one contiguous range per XCD)
+    uint32_t items;                   // bands of this launch = F * camera rows * cols * NB (x column tiles); grid = 8 * ceil(items / 8)
+    uint32_t cols_magic, nb_magic, cr_magic;     // ceil(2^32 / d) for d = cols, NB, camera rows (divmod_magic)
     const uint8_t *src;
     uint8_t *mosaic;
     int C, H, W, cols, R, NB;
@@ -168,22 +170,66 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// One band of one camera of one frame.  Launch geometry: grid (NB * cols, camera rows, frames) -- x = band * cols + camera
-// column, so workgroups are dispatched in the order (frame, mosaic row of cameras, band, camera column): the `cols`
-// cameras that share a mosaic row-band are adjacent in launch order and R full mosaic rows (R * cols*W*3 contiguous bytes)
-// are written close together in time instead of one third at a time.  (Round 3: the same order used to be decoded from a
-// linear blockIdx.x with three runtime divisions -- ~100 dependent scalar instructions incl. v_rcp / readfirstlane round
-// trips at the head of every workgroup, before its first load could be issued; with a 3-D grid one multiply-high is left.)
-// f0 = launch-wide number of the scene's first frame (0 for single-scene launches): everything in the scratch is indexed
-// by the launch-wide frame, the images (a.src / a.mosaic, already the scene's own) by the frame inside the scene.
-template <bool VEC, bool RESAMPLE, bool ALPHA>
-__device__ __forceinline__ void overlay_band(const OverlayArgs &a, const uint32_t fl, const uint32_t f0, uint32_t *s_owner)
+// ------------------------------------------------------------------------------------------
+// Which band does workgroup L render?  (round 3)
+// The bands of a launch are numbered in the order (frame, mosaic row of cameras, band, camera column, [column tile]):
+// the `cols` cameras that share a mosaic row-band are neighbours, so consecutive items read consecutive source bytes and
+// write R full mosaic rows.  Workgroups are dispatched round-robin over the 8 XCDs (observed: block L runs on XCD L % 8;
+// /opt/skills/guides/MI355X_MICROARCH.md, "for speed only").  Two mappings, chosen per launch by the host
+// (cama_hip.hip: overlay_chunk_log2, with the measurements):
+//   interleaved  workgroup L renders item L: all XCDs advance through ONE stream, each touching every page of it;
+//   contiguous   XCD x renders items [x * ceil(T/8), (x+1) * ceil(T/8)): eight streams, each XCD touches an eighth of the
+//                pages.  Wins once a launch touches more than ~2 GB (the headline's 40 x 1600x900 frames: 0.755 -> 0.815
+//                of 8 TB/s; a 160-frame launch 0.62 -> 0.83), loses below (960x540: 0.77 -> 0.72).
+// (Round-robin CHUNKS of 2^k items were measured too: never better than k = 0, down to 0.70 at k = 11.)
+// Either mapping is a bijection whatever the hardware's placement is: a different dispatch rule costs speed, never pixels.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool xcd_contiguous_item(const uint32_t T, const uint32_t chunk_log2, uint32_t &item)
 {
-    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
-    // exact for x < 2^16 (host-checked); a divisor of 1 has no 32-bit magic (ceil(2^32 / 1) does not fit)
-    const uint32_t b = cols == 1u ? blockIdx.x : __umulhi(blockIdx.x, a.cols_magic), cc = blockIdx.x - b * cols;
-    const uint32_t c = blockIdx.y * cols + cc;
-    if (c >= C) return;                                  // ragged last camera row
+    const uint32_t L = blockIdx.x, x = L & 7u, slot = L >> 3;
+    if (chunk_log2 >= 31u) {                                 // one contiguous range per XCD; grid = 8 * ceil(T / 8)
+        item = x * ((T + 7u) >> 3) + slot;
+    } else {                                                 // chunks of K = 2^chunk_log2 items dealt round-robin to the XCDs;
+        const uint32_t K = 1u << chunk_log2;                 // grid = 8 * K * ceil(T / (8 K))
+        item = (((slot >> chunk_log2) << 3) + x) * K + (slot & (K - 1u));
+    }
+    return item < T;
+}
+
+// n / d by multiply-high with magic = ceil(2^32 / d) (host): the estimate is the quotient or one more for every n < 2^32
+// (excess n * (magic * d - 2^32) / (d * 2^32) < 1), hence one correction step; d = 1 has no 32-bit magic.
+__device__ __forceinline__ uint32_t divmod_magic(const uint32_t n, const uint32_t d, const uint32_t magic, uint32_t &r)
+{
+    uint32_t q = d == 1u ? n : __umulhi(n, magic);
+    r = n - q * d;
+    if ((int32_t)r < 0) { q -= 1u; r += d; }
+    return q;
+}
+
+struct BandId { uint32_t fl, c, b, tx; bool valid; };
+
+// item -> (frame inside the launch, camera, band, column tile); TX = column tiles per band (1 for k_overlay)
+__device__ __forceinline__ BandId decode_band(const OverlayArgs &a, const uint32_t T, const uint32_t TX, const uint32_t tx_magic)
+{
+    BandId id{0u, 0u, 0u, 0u, false};
+    uint32_t item;
+    if (!xcd_contiguous_item(T, a.chunk_log2, item)) return id;
+    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C, camrows = (C + cols - 1u) / cols;
+    uint32_t cc, cr;
+    const uint32_t q0 = TX == 1u ? item : divmod_magic(item, TX, tx_magic, id.tx);
+    const uint32_t q1 = divmod_magic(q0, cols, a.cols_magic, cc);
+    const uint32_t q2 = divmod_magic(q1, NB, a.nb_magic, id.b);
+    id.fl = divmod_magic(q2, camrows, a.cr_magic, cr);
+    id.c = cr * cols + cc;
+    id.valid = id.c < C;                                  // ragged last camera row
+    return id;
+}
+
+template <bool VEC, bool RESAMPLE, bool ALPHA>
+__device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint32_t fl, const uint32_t f0, const uint32_t c,
+                                                const uint32_t b, uint32_t *s_owner)
+{
+    const uint32_t NB = (uint32_t)a.NB, C = (uint32_t)a.C;
     const uint32_t fcl = fl * C + c;                     // (frame, camera) inside the scene's own frame tensor
     const uint32_t f = f0 + fl;
     const uint32_t fc = f * C + c;
@@ -333,7 +379,9 @@ template <bool VEC, bool RESAMPLE, bool ALPHA = false>
 __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x (W + 2 radius), used only by stamped bands
-    overlay_band<VEC, RESAMPLE, ALPHA>(a, blockIdx.z, (uint32_t)a.f0, s_owner);
+    const BandId id = decode_band(a, a.items, 1u, 0u);
+    if (!id.valid) return;
+    overlay_band_at<VEC, RESAMPLE, ALPHA>(a, id.fl, (uint32_t)a.f0, id.c, id.b, s_owner);
 }
 
 
@@ -353,19 +401,14 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 // one per 16 INPUT bytes.  Column tiles keep a workgroup's LDS near 20 KB (7 workgroups per CU) instead of 62 KB.
 // LDS: owner table R*Wt*4 | per-column packed taps Wt*4 | staged source rows.
 __global__ __launch_bounds__(RAWLDS_BLOCK) void k_overlay_rawlds(OverlayArgs a, const int2 *__restrict__ band_rows,
-                                                                 const int2 *__restrict__ tile_bytes, int TX, int Wt)
+                                                                 const int2 *__restrict__ tile_bytes, int TX, int Wt,
+                                                                 uint32_t tx_magic)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
-    const uint32_t camrows = (C + cols - 1) / cols;
-    uint32_t t = blockIdx.x;
-    const uint32_t tx = t % (uint32_t)TX; t /= (uint32_t)TX;
-    const uint32_t cc = t % cols; t /= cols;
-    const uint32_t b = t % NB;    t /= NB;
-    const uint32_t cr = t % camrows;
-    const uint32_t f = t / camrows;
-    const uint32_t c = cr * cols + cc;
-    if (c >= C) return;
+    const BandId id = decode_band(a, a.items, (uint32_t)TX, tx_magic);
+    if (!id.valid) return;
+    const uint32_t f = id.fl, c = id.c, b = id.b, tx = id.tx;
     const uint32_t fc = f * C + c;
     const uint32_t bin = fc * NB + b;
     const int y0 = (int)b * a.R;

@@ -217,15 +217,12 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
                                                                    uint32_t tx_magic, uint32_t cpt_magic)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    // same workgroup order as k_overlay -- (frame, mosaic row of cameras, band, camera column), column tile innermost -- as a
-    // 3-D grid: x = (band * cols + camera column) * TX + tile, y = camera row, z = frame; quotients by multiply-high
+    // same item order as k_overlay -- (frame, mosaic row of cameras, band, camera column), column tile innermost -- and the
+    // same XCD-contiguous assignment of items to workgroups (overlay_kernels.hpp: decode_band)
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
-    // (a divisor of 1 has no 32-bit magic: ceil(2^32 / 1) does not fit)
-    const uint32_t bc = TX == 1 ? blockIdx.x : __umulhi(blockIdx.x, tx_magic), tx = blockIdx.x - bc * (uint32_t)TX;
-    const uint32_t b = cols == 1u ? bc : __umulhi(bc, a.cols_magic), cc = bc - b * cols;
-    const uint32_t f = blockIdx.z;
-    const uint32_t c = blockIdx.y * cols + cc;
-    if (c >= C) return;
+    const BandId id = decode_band(a, a.items, (uint32_t)TX, tx_magic);
+    if (!id.valid) return;
+    const uint32_t f = id.fl, c = id.c, b = id.b, tx = id.tx;
     const uint32_t fc = f * C + c;
     const uint32_t bin = fc * NB + b;
     const int y0 = (int)b * a.R;

@@ -526,3 +526,22 @@ def test_alpha_extension_matches_own_restatement():
                 assert np.array_equal(out[f], want), (W, alpha256, f)
                 if alpha256 == 0:
                     assert np.array_equal(out[f], O.mosaic({c["name"]: src[f, k] for k, c in enumerate(cams)}))
+
+
+@pytest.mark.parametrize("chunk_log2", ["0", "3", "31"])
+def test_every_workgroup_to_band_mapping_renders_the_same_bytes(chunk_log2, repo_root):
+    """The overlay kernels choose per launch between the interleaved and the XCD-contiguous workgroup -> band mapping (by
+    the bytes a launch touches); small test scenes only ever see the interleaved one.  Force each mapping (and a chunked
+    one) in a subprocess -- the knob is read once per process -- and run the oracle-parity tests of this file and the raw
+    overlay families under it: ragged camera rows, odd widths, several radii, stamped and unstamped bands."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CAMA_OVERLAY_CHUNK_LOG2=chunk_log2)
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "tests/test_gpu_kernels.py", "tests/test_gpu_dropin.py",
+                        "-k", "byte_identical_to_oracle or radius_variants or other_camera_counts or last_writer or "
+                              "raw_overlay_kernel_families or fused_raw_frame or alpha_extension"],
+                       cwd=repo_root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout
