@@ -10,7 +10,7 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 12
+ABI_VERSION = 13
 BIN_WORKLIST = 1
 
 _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
@@ -67,6 +67,7 @@ SIGNATURES = {
     "cama_jpeg_plan": (_i32, [_vp, _i32, _u64, _vp]),
     "cama_jpeg_find_restarts": (_i32, [_vp, _u64, _vp, ctypes.c_uint32, _vp, _vp]),
     "cama_jpeg_decode": (_i32, [_vp, _u64, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _u64, _i32, _vp, _sz, _vp, _vp]),
+    "cama_read_files": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "cama_profile_enable": (_i32, [_i32]),
     "cama_profile_collect": (_i32, [_vp, _vp]),
     "cama_profile_collect_project": (_i32, [_vp, _vp]),

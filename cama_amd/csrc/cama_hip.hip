@@ -1557,3 +1557,51 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
     return CAMA_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// host-side ingest helper: many files -> caller-provided (pinned) buffers, without the interpreter
+// ------------------------------------------------------------------------------------------
+
+#include <atomic>
+#include <thread>
+#include <fcntl.h>
+#include <unistd.h>
+
+extern "C" {
+
+int cama_read_files(const char *const *paths, void *const *dst, const uint64_t *sizes, int32_t n, int32_t threads,
+                    int32_t *status)
+{
+    if (n < 0 || (n && (!paths || !dst || !sizes || !status))) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (n == 0) return CAMA_OK;
+    const int workers = std::max(1, std::min<int>(threads, std::min(n, 64)));
+    std::atomic<int> next{0};
+    const auto work = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            status[i] = 1;
+            if (!paths[i] || !dst[i]) continue;
+            const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
+            if (fd < 0) continue;
+            uint64_t got = 0;
+            bool ok = true;
+            while (got < sizes[i]) {
+                const ssize_t k = read(fd, (char *)dst[i] + got, (size_t)(sizes[i] - got));
+                if (k <= 0) { ok = false; break; }
+                got += (uint64_t)k;
+            }
+            if (ok) {                                   // the size came from a directory scan: the file must end here
+                char extra;
+                ok = read(fd, &extra, 1) == 0;
+            }
+            close(fd);
+            status[i] = ok ? 0 : 1;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < workers; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    return CAMA_OK;
+}
+
+}  // extern "C"

@@ -412,6 +412,9 @@ class ClipManager:
         batches = ra["batches"]
         if k < ra.get("last", -1):                  # a new pass over the clip: render it again (files may have changed)
             batches.clear()
+        if not batches and hasattr(source, "plan"):
+            # every batch of the pass from here on is known: let the source read and decode ahead of the renders
+            source.plan([[int(i) for i in ra["idx"][lo:hi]] for lo, hi in ra["bounds"][b:]])
         ra["last"] = k
         for nb in (b, b + 1):                       # this batch now, the next one a batch early
             if nb not in batches and nb < len(ra["bounds"]):

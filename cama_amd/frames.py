@@ -58,6 +58,28 @@ def _read_into(blob, path):
     return _read_jpeg_bytes_or_array(path)
 
 
+def _read_batch_native(blobs, paths, C, threads):
+    """All files of a batch into their arena slices through cama_read_files (the GIL is released for the whole call);
+    returns [(frame k, camera c, blob or fallback array, is_rgb)] in (frame, camera) order."""
+    import ctypes
+    from . import _lib
+    n = len(paths)
+    L = _lib.lib()
+    base = blobs[0].arena.np.ctypes.data
+    P = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    D = (ctypes.c_void_p * n)(*[base + b.off for b in blobs])
+    sizes = np.fromiter((b.n for b in blobs), dtype=np.uint64, count=n)
+    status = np.ones(n, np.int32)
+    _lib.check(L.cama_read_files(P, D, sizes.ctypes.data, n, int(threads), status.ctypes.data))
+    out = []
+    for k in range(n):
+        if status[k] == 0:
+            out.append((k // C, k % C, blobs[k], False))
+        else:                                              # changed since the directory scan, unreadable, ...
+            out.append((k // C, k % C) + tuple(_read_jpeg_bytes_or_array(paths[k])))
+    return out
+
+
 def _read_frame(items):
     """The camera files of one frame, one after the other (one pool task per frame instead of one per file: the pool's
     per-task cost on the submitting thread was the largest item of the main.py loop's host profile)."""
@@ -210,6 +232,12 @@ class ClipFrameSource:
         # files, a few are enough (more just burn the container's CPU quota)
         self._workers = workers or int(os.environ.get("CAMA_READ_WORKERS", 0)) or \
             (4 if self.decoder == "device" else min(12, (os.cpu_count() or 4)))
+        # planned passes (plan()): a pump thread reads, parses and submits the device decode of the next batches while the
+        # consumer renders / encodes the current one
+        self._plan = None
+        self._pump_depth = int(os.environ.get("CAMA_DECODE_AHEAD", 3))   # decoded or decoding batches ahead of the consumer
+        self._batch_reads = {}                                           # batch key -> future of its file reads
+        self._native_threads = int(os.environ.get("CAMA_READ_THREADS", 8))   # native reader threads per batch
         self._prefetch = prefetch
         self._pending = {}                                            # image index -> list of futures
         self._dir_sizes = {}                                          # directory -> {file name: bytes} (one scan each)
@@ -310,12 +338,136 @@ class ClipFrameSource:
             host[k, c] = arr[:, :, ::-1] if is_rgb else arr
         return host
 
+    # ------------------------------------------------------------------ planned passes: the decode pump
+    def plan(self, batches):
+        """Announce the batches raw_batch() will be asked for, in order (ClipManager knows every frame of a pass up front).
+        A pump thread then walks the plan ahead of the consumer: file reads for the next batches (straight into pinned
+        memory), header parsing, upload and the device decode launches all happen there, so the consumer's raw_batch()
+        finds its batch decoded or decoding instead of doing that work between two renders (profiles/r03_demo_loop_*:
+        45 % of the main.py loop was the consumer waiting for file reads, 20 % submitting decodes).  Device decoder only;
+        a request that leaves the announced order cancels the plan and takes the unplanned path."""
+        import threading
+        self.cancel_plan()
+        keys = [tuple(int(i) for i in b) for b in batches if len(b)]
+        if self.decoder != "device" or not keys or os.environ.get("CAMA_NO_DECODE_PUMP"):
+            return
+        P = {"keys": keys, "index": {k: j for j, k in enumerate(keys)}, "ready": {}, "consumed": 0,
+             "cv": threading.Condition(), "stop": False, "error": None}
+        P["thread"] = threading.Thread(target=self._pump, args=(P,), daemon=True, name="cama-decode-pump")
+        self._plan = P
+        P["thread"].start()
+
+    def cancel_plan(self):
+        P, self._plan = self._plan, None
+        if P is None:
+            return
+        with P["cv"]:
+            P["stop"] = True
+            P["cv"].notify_all()
+        P["thread"].join()
+        for pend in P["ready"].values():                 # release their lanes
+            if hasattr(pend, "result"):
+                try:
+                    pend.result()
+                except Exception:
+                    pass
+        P["ready"].clear()
+        for futs in self._pending.values():
+            for f in futs:
+                f.cancel()
+        self._pending.clear()
+        for f in self._batch_reads.values():               # (a started read finishes into its arena slice: harmless)
+            f.cancel()
+        self._batch_reads.clear()
+
+    def _pump(self, P):
+        import torch
+        from .jpeg import is_blob
+        try:
+            with torch.cuda.device(self.device):
+                keys = P["keys"]
+                for j, key in enumerate(keys):
+                    with P["cv"]:
+                        while not P["stop"] and j >= P["consumed"] + self._pump_depth:
+                            P["cv"].wait()
+                        if P["stop"]:
+                            return
+                    for ahead in keys[j:j + 3]:            # file reads: this batch and the next two
+                        self._submit_batch(ahead)
+                    items = self._batch_reads.pop(key).result()
+                    if all(is_blob(arr) for _, _, arr, _ in items):
+                        pend = self._decoder().decode_async([arr for _, _, arr, _ in items], bgr=True)
+                    else:
+                        pend = items                       # .npy twins / mixed sources: the consumer finishes them
+                    with P["cv"]:
+                        P["ready"][key] = pend
+                        P["cv"].notify_all()
+        except BaseException as e:                         # surfaces in the consumer's raw_batch()
+            with P["cv"]:
+                P["error"] = e
+                P["cv"].notify_all()
+
+    def _submit_batch(self, key):
+        """Start reading all camera files of the frames `key` (a tuple of image indices): ONE pool task that hands the
+        whole batch to cama_read_files -- native threads, the interpreter lock released for the duration -- reading
+        straight into slices of the pinned arena.  (One Python task per frame cost ~25 us of interpreter time per file:
+        with 1440 files per 240-frame pass that alone serialised ~40 ms per pass behind the GIL, next to the pump's and
+        the consumer's own Python.)  Files that are not JPEGs of a known size, or that changed since the directory scan,
+        go through the ordinary readers."""
+        if key in self._batch_reads:
+            return
+        paths = [cm.get_image_path(i, True) for i in key for cm in self.cm_list]
+        sizes = [self._file_size(p) if p.lower().endswith((".jpg", ".jpeg")) else -1 for p in paths]
+        C = len(self.cm_list)
+        if min(sizes) <= 0:
+            self._batch_reads[key] = self._executor().submit(
+                lambda: [(k // C, k % C) + tuple(_read_jpeg_bytes_or_array(p)) for k, p in enumerate(paths)])
+            return
+        need = sum(sz + 16 for sz in sizes)
+        a = getattr(self, "_arena", None)
+        if a is None or a.size - a.used < need:
+            a = self._arena = self._decoder().arena(max(need, 128 << 20))
+        blobs = [a.take(sz) for sz in sizes]
+        self._batch_reads[key] = self._executor().submit(_read_batch_native, blobs, paths, C, self._native_threads)
+
+    def _planned(self, key):
+        """The pump's result for `key` if it is the plan's next batch, else None (the plan is cancelled when the request
+        leaves the announced order)."""
+        P = self._plan
+        if P is None:
+            return None
+        if P["index"].get(key) != P["consumed"]:
+            self.cancel_plan()
+            return None
+        with P["cv"]:
+            while key not in P["ready"] and P["error"] is None:
+                P["cv"].wait()
+            if P["error"] is not None:
+                err = P["error"]
+            else:
+                err = None
+                pend = P["ready"].pop(key)
+                P["consumed"] += 1
+                P["cv"].notify_all()
+        if err is not None:
+            self.cancel_plan()
+            raise err
+        if P["consumed"] == len(P["keys"]):                # the pass is over: the pump has returned
+            self._plan = None
+        return pend
+
     def raw_batch(self, image_indices):
         """device uint8 BGR tensor [F,C,H0,W0,3]: every image goes to its slot as decoded (no host-side stacking or
         channel flip: both hold the GIL the decode threads need); RGB-decoded frames are flipped on the device."""
         import torch
         image_indices = [int(i) for i in image_indices]
         F = len(image_indices)
+        planned = self._planned(tuple(image_indices))
+        if planned is not None:
+            if hasattr(planned, "result"):
+                flat = planned.result()
+                return flat.view((F, len(self.cm_list)) + tuple(flat.shape[1:]))
+            return self._upload_items(planned, F)
         ahead = self._ahead.pop(tuple(image_indices), None) if self._ahead else None
         if ahead is not None:                                        # decoded while the previous batch was consumed
             flat = ahead.result()
@@ -327,6 +479,12 @@ class ClipFrameSource:
             # compressed bytes straight to the device decoder: one upload + one decode for the whole batch, BGR out
             flat = self._device_decode(image_indices, items)
             return flat.view((F, len(self.cm_list)) + tuple(flat.shape[1:]))
+        return self._upload_items(items, F)
+
+    def _upload_items(self, items, F):
+        """Host-decoded / mixed items [(frame k, camera c, array or JPEG bytes, is_rgb)] -> device BGR tensor."""
+        import torch
+        from .jpeg import as_bytes, is_blob
         items = [(k, c, _decode_bytes(as_bytes(arr)) if is_blob(arr) else arr,
                   True if is_blob(arr) else is_rgb) for k, c, arr, is_rgb in items]
         shape = items[0][2].shape

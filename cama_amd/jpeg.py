@@ -364,6 +364,8 @@ class DeviceJpegDecoder:
         self.group_wgs = int(os.environ.get("CAMA_JPEG_GROUP_WGS", 0)) or \
             self.WGS_PER_CU * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
         self.max_lanes = 16
+        import threading
+        self._lock = threading.Lock()      # lanes + stats: decode_async may run on a pump thread, result() on the consumer's
         self._lane = []
         self._templates = {}
         self.stats = {"device": 0, "host_unsupported": 0, "host_flagged": 0}
@@ -491,14 +493,15 @@ class DeviceJpegDecoder:
 
     def _lane_acquire(self):
         import torch
-        for L in self._lane:
-            if L is not None and not L["busy"]:
-                L["busy"] = True
-                return L
-        L = {"stream": torch.cuda.Stream(device=self.device), "pinned": None, "scratch": None, "status": None,
-             "busy": True}
-        self._lane = [x for x in self._lane if x is not None] + [L]
-        return L
+        with self._lock:
+            for L in self._lane:
+                if L is not None and not L["busy"]:
+                    L["busy"] = True
+                    return L
+            L = {"stream": torch.cuda.Stream(device=self.device), "pinned": None, "scratch": None, "status": None,
+                 "busy": True}
+            self._lane = [x for x in self._lane if x is not None] + [L]
+            return L
 
     @staticmethod
     def _repeat_templates(tmpl, counts):
@@ -658,7 +661,8 @@ class DeviceJpegDecoder:
         st.synchronize()                                   # one small readback per group (also frees the staging buffer)
         cur.wait_stream(st)
         bad = ticket["lane"]["status"][:ticket["n"]].numpy().copy()
-        ticket["lane"]["busy"] = False
+        with self._lock:
+            ticket["lane"]["busy"] = False
         local = {int(ticket["owner"][r]) for r in np.flatnonzero(bad)} | set(ticket["broken"])   # descriptor -> image
         return [ticket["slots"][i] for i in sorted(local)]
 
@@ -680,9 +684,10 @@ class PendingDecode:
                 flagged += dec._finish(t, out, cur)
             on_device = set(self.ok)
             host = [i for i in range(n) if i not in on_device] + flagged
-            dec.stats["device"] += len(self.ok) - len(flagged)
-            dec.stats["host_unsupported"] += n - len(self.ok)
-            dec.stats["host_flagged"] += len(flagged)
+            with dec._lock:
+                dec.stats["device"] += len(self.ok) - len(flagged)
+                dec.stats["host_unsupported"] += n - len(self.ok)
+                dec.stats["host_flagged"] += len(flagged)
             for i in host:
                 arr = _host_decode(as_bytes(self.blobs[i]), self.bgr)
                 if tuple(arr.shape[:2]) != tuple(out.shape[1:3]):

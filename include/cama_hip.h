@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 12
+#define CAMA_ABI_VERSION 13
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -472,6 +472,17 @@ int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, const cama_jp
                      const cama_jpeg_image *imgs_dev, int32_t n, const void *huff_sets, int32_t n_huff_sets,
                      const uint16_t *quant_sets, int32_t n_quant_sets, uint8_t *out, uint64_t out_stride, int32_t bgr,
                      void *scratch, size_t scratch_bytes, int32_t *status, void *stream_handle);
+
+/*
+ * Ingest helper (host only, no GPU work): read n files into caller-provided buffers -- the pinned arena the JPEG decoder
+ * uploads from -- with `threads` native threads and no interpreter in the loop.  What cv2.imread does per image before it
+ * decodes (cama/reproject.py:224,243), for a whole batch of camera frames at once: file i must be exactly sizes[i] bytes
+ * (the caller took them from a directory scan); status[i] = 0 when dst[i] holds the whole file, 1 when the file could not be
+ * opened, was shorter, or longer (the caller re-reads those the ordinary way).  Blocks until all files are read; bindings
+ * should release their interpreter lock around the call (ctypes does).
+ */
+int cama_read_files(const char *const *paths /* host */, void *const *dst /* host */, const uint64_t *sizes /* host */,
+                    int32_t n, int32_t threads, int32_t *status /* host */);
 
 #ifdef __cplusplus
 }
