@@ -433,6 +433,7 @@ int cama_map_bounds(const void *x, const void *y, const void *z, int32_t xyz_is_
 // Completion events attached to the NEXT overlay / scatter launch itself (hipExtLaunchKernelGGL stop event) instead of a
 // separate hipEventRecord marker packet behind it: one packet less between consecutive overlays on the pipeline's
 // stream.  Set by cama_pipeline_render, consumed (and cleared) by the launch.
+thread_local bool g_skip_bin_memset = false;   // (hipGraph experiment only: the clear is issued outside the captured chain)
 thread_local hipEvent_t g_overlay_stop_event = nullptr;
 thread_local hipEvent_t g_scatter_stop_event = nullptr;
 static bool ext_events()
@@ -465,7 +466,7 @@ static int bin_impl(const SceneRef *scenes_dev, int frames_per_scene, const void
     const int nfc = F * C;
 
     // counts, cursor, the work-list counter and the segment count table are adjacent: one memset
-    HIP_TRY(hipMemsetAsync(counts, 0, L.zero_bytes, s));
+    if (!g_skip_bin_memset) HIP_TRY(hipMemsetAsync(counts, 0, L.zero_bytes, s));
 
     FrameArgs a{};
     a.scenes = scenes_dev; a.frames_per_scene = frames_per_scene;
@@ -1196,6 +1197,69 @@ static int pipeline_impl(cama_pipeline *p, int64_t N, int32_t F, int32_t C, int3
     return CAMA_OK;
 }
 
+#ifdef CAMA_GRAPH_EXPERIMENT
+// EXPERIMENT (tools/ab build only): the round-2 hipGraph replay of the binning chain, rebuilt to find out why it faulted.
+// Modes (CAMA_GRAPH): 1 = cache per key and replay (the round-2 behaviour); 2 = capture + instantiate + launch + destroy the
+// exec after a stream sync, every time (no cache); 3 = cache, but synchronise the stream after every replay; 4 = cache and
+// keep the captured hipGraph_t alive next to its exec.
+struct BinKey {
+    const void *x, *y, *z, *colour, *key, *bounds, *w2c, *c2cam, *K, *scratch;
+    int64_t N;
+    size_t scratch_bytes;
+    double crop[6];
+    int32_t is64, flags, F, C, W, H, radius, pad;
+};
+struct BinGraph { BinKey key; hipGraphExec_t exec; };
+static std::vector<BinGraph> g_graphs;
+static int graph_bin(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
+                     const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N, const double *w2c, int32_t F,
+                     const double *c2cam, const double *K, int32_t C, const double *crop, int32_t W, int32_t H, int32_t radius,
+                     void *scratch, size_t scratch_bytes, void *sb)
+{
+    static const int mode = getenv("CAMA_GRAPH") ? atoi(getenv("CAMA_GRAPH")) : 0;
+    if (!mode || N <= 0 || F <= 0) return 1;                       // 1 = not handled: launch kernel by kernel
+    hipStream_t s = (hipStream_t)sb;
+    BinKey key;
+    memset(&key, 0, sizeof(key));
+    key.x = x; key.y = y; key.z = z; key.colour = colour_id; key.key = draw_key; key.bounds = block_bounds; key.w2c = w2c;
+    key.c2cam = c2cam; key.K = K; key.scratch = scratch; key.N = N; key.scratch_bytes = scratch_bytes;
+    memcpy(key.crop, crop, sizeof(key.crop));
+    key.is64 = xyz_is_f64; key.flags = flags; key.F = F; key.C = C; key.W = W; key.H = H; key.radius = radius;
+    BinGraph *hit = nullptr;
+    if (mode != 2)
+        for (auto &g : g_graphs)
+            if (!memcmp(&g.key, &key, sizeof(key))) { hit = &g; break; }
+    hipGraphExec_t exec = hit ? hit->exec : nullptr;
+    if (mode == 5) {                                               // mode 5: the scratch clear stays OUTSIDE the graph
+        ScratchLayout L;
+        layout_scratch(N, F, C, H, W, radius, L);
+        HIP_TRY(hipMemsetAsync((char *)scratch + L.counts, 0, L.zero_bytes, s));
+        g_skip_bin_memset = true;
+    }
+    if (!exec) {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        hipEvent_t keep = g_scatter_stop_event;
+        g_scatter_stop_event = nullptr;                            // (an event cannot ride on a captured launch)
+        const int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop,
+                                       W, H, radius, scratch, scratch_bytes, sb);
+        g_scatter_stop_event = keep;
+        g_skip_bin_memset = false;
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc || e != hipSuccess || !graph) return rc ? rc : fail(CAMA_EHIP, "hipStreamEndCapture -> %s", hipGetErrorString(e));
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (mode != 4) (void)hipGraphDestroy(graph);               // mode 4: the template graph is kept alive (leaked)
+        if (ei != hipSuccess) return fail(CAMA_EHIP, "hipGraphInstantiate -> %s", hipGetErrorString(ei));
+        if (mode != 2) g_graphs.push_back(BinGraph{key, exec});
+    }
+    g_skip_bin_memset = false;
+    HIP_TRY(hipGraphLaunch(exec, s));
+    if (mode == 2) { HIP_TRY(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(exec); }
+    if (mode == 3) HIP_TRY(hipStreamSynchronize(s));
+    return CAMA_OK;                                                // (g_scatter_stop_event stays set: the caller records it)
+}
+#endif
+
 template <typename Overlay>
 static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
                                 const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N,
@@ -1205,6 +1269,11 @@ static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, 
 {
     return pipeline_impl(p, N, F, C, W, H, radius, scratch0, scratch1, scratch_bytes, input_stream, overlay_takes_stop_event,
                          [&](void *scratch, void *sb) {
+#ifdef CAMA_GRAPH_EXPERIMENT
+                             if (int rc = graph_bin(p, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F,
+                                                    c2cam, K, C, crop, W, H, radius, scratch, scratch_bytes, sb); rc != 1)
+                                 return rc;
+#endif
                              return cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F,
                                                     c2cam, K, C, crop, W, H, radius, scratch, scratch_bytes, sb);
                          },
