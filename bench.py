@@ -475,8 +475,16 @@ class Job:
         idx_all, w2c_all = cm.frame_poses("cama")
         per = max(1, min(self.F, int(self.frames_per_launch() + 0.5)))
         lo = self.lo
-        poses = (idx_all[lo:lo + per], w2c_all[lo:lo + per])
-        cm.render_clip("cama", out=self.out[:per], pipelined=False, poses=poses, frames_per_launch=per)
+        while True:
+            poses = (idx_all[lo:lo + per], w2c_all[lo:lo + per])
+            try:
+                cm.render_clip("cama", out=self.out[:per], pipelined=False, poses=poses, frames_per_launch=per)
+                break
+            except torch.OutOfMemoryError:                      # (ranks sharing one GPU: the single-stream scratch on top of
+                if per == 1:                                    # the pipeline's two slots may not fit; fewer frames do)
+                    raise
+                self.eng.shrink_frames_per_call()
+                per = max(1, per // 2)
         torch.cuda.synchronize(self.device)
         st = self.eng.bin_stats()
         if st is None or not st["frames"]:

@@ -1416,6 +1416,14 @@ int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n, uin
                       int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
                       size_t scratch_bytes, void *stream)
 {
+    return cama_stamp_polylines(vu, colour_id, nullptr, n, image, H, W, radius, halfwidth, palette_bgr, scratch, scratch_bytes,
+                                stream);
+}
+
+int cama_stamp_polylines(const double *vu, const uint8_t *colour_id, const uint8_t *link, int64_t n, uint8_t *image, int32_t H,
+                         int32_t W, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
+                         size_t scratch_bytes, void *stream)
+{
     if (int rc = check_common(n, 1, 1, W, H)) return rc;
     if (n == 0) return CAMA_OK;
     if (!vu || !colour_id || !image || !palette_bgr || !scratch) return fail(CAMA_EINVAL, "NULL pointer argument");
@@ -1428,6 +1436,11 @@ int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n, uin
     hipLaunchKernelGGL(k_stamp_global, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, vu, colour_id,
                        n, (uint32_t *)scratch, H, W, disc);
     HIP_TRY(hipGetLastError());
+    if (link) {                                             // extension: segments between linked neighbours
+        hipLaunchKernelGGL(k_segments_global, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, vu, colour_id, link,
+                           n, (uint32_t *)scratch, H, W);
+        HIP_TRY(hipGetLastError());
+    }
     const int64_t npix = (int64_t)H * W;
     hipLaunchKernelGGL(k_apply_owner, dim3((unsigned)((npix + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
                        (const uint32_t *)scratch, image, npix, make_palette(palette_bgr));

@@ -508,6 +508,32 @@ __global__ __launch_bounds__(BLOCK) void k_stamp_global(const double *__restrict
     }
 }
 
+// EXTENSION (no reference semantics: the reference draws one disc per point and nothing between them):
+// point k with link[k] != 0 is also joined to point k - 1 by a one-pixel-wide 8-connected Bresenham segment between the two
+// truncated pixel positions, drawn under point k's key (so it belongs to point k's instance and is covered by whatever a
+// later point draws).  One thread per segment; the integer error recurrence below is the definition (oracle:
+// oracle_line_bresenham, the same statements), every octant and direction, both end pixels included.
+__global__ __launch_bounds__(BLOCK) void k_segments_global(const double *__restrict__ vu, const uint8_t *__restrict__ colour,
+                                                           const uint8_t *__restrict__ link, int64_t n,
+                                                           uint32_t *__restrict__ owner, int H, int W)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n || i == 0 || !link[i]) return;
+    int y0 = (int)vu[2 * (i - 1)], x0 = (int)vu[2 * (i - 1) + 1];
+    const int y1 = (int)vu[2 * i], x1 = (int)vu[2 * i + 1];
+    const uint32_t val = ((((uint32_t)i) << 1) | (uint32_t)(colour[i] & 1)) + 1u;
+    const int dx = abs(x1 - x0), sx = x0 < x1 ? 1 : -1;
+    const int dy = -abs(y1 - y0), sy = y0 < y1 ? 1 : -1;
+    int err = dx + dy;
+    for (int guard = 0; guard < 4 * 65536; ++guard) {                  // (a segment has at most W + H pixels)
+        if ((unsigned)x0 < (unsigned)W && (unsigned)y0 < (unsigned)H) atomicMax(&owner[(size_t)y0 * W + x0], val);
+        if (x0 == x1 && y0 == y1) break;
+        const int e2 = 2 * err;
+        if (e2 >= dy) { err += dy; x0 += sx; }
+        if (e2 <= dx) { err += dx; y0 += sy; }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_apply_owner(const uint32_t *__restrict__ owner,
                                                        uint8_t *__restrict__ image, int64_t npix, Palette pal)
 {

@@ -143,7 +143,9 @@ class ProjectedMaps(Mapping):
                 vu, vis, _ = eng.project_frames(sm.device(), owner._rig(), fr.world2chassis[None],
                                                 crop=owner.mm.crop_box())
                 vu, vis = vu[0].cpu().numpy(), vis[0].cpu().numpy().astype(bool)
-                self._items = {n: split_instances(vu[c], sm.counts, sm.classes, vis[c]) for c, n in enumerate(names)}
+                seg = bool(owner.configs.get("segments", False))      # (opt-in extension: keep who neighbours whom)
+                self._items = {n: split_instances(vu[c], sm.counts, sm.classes, vis[c], joined=seg)
+                               for c, n in enumerate(names)}
         return self._items
 
     def __getitem__(self, name):
@@ -349,7 +351,10 @@ class ClipManager:
         return {n: split_instances(vu[c], counts, classes, vis[c]) for c, n in enumerate(names)}
 
     def render_vectors(self, maps_2d_dict, image_idx):
-        if isinstance(maps_2d_dict, ProjectedMaps) and maps_2d_dict.frame.owner is self \
+        segments = bool(self.configs.get("segments", False))
+        # configs["segments"] = True (EXTENSION, no reference semantics): discs + one-pixel segments between neighbouring
+        # points; rendered image by image through the generic path (cama_stamp_polylines), not by the fused kernels
+        if not segments and isinstance(maps_2d_dict, ProjectedMaps) and maps_2d_dict.frame.owner is self \
                 and maps_2d_dict._items is None and maps_2d_dict.frame.image_idx == image_idx:
             fr = maps_2d_dict.frame
             rig = self._rig()
@@ -359,7 +364,8 @@ class ClipManager:
         out = {}
         for cm in self.cm_list:
             image = cm.read_resized_image_by_index(image_idx)
-            out[cm.camera_name] = cm.render_maps(image, maps_2d_dict[cm.camera_name])
+            out[cm.camera_name] = cm.render_maps(image, maps_2d_dict[cm.camera_name], segments=segments) if segments \
+                else cm.render_maps(image, maps_2d_dict[cm.camera_name])
         return out
 
     def _render_batch(self, dataset, image_ids, w2c):

@@ -804,8 +804,10 @@ class Engine:
         self._scratch = None
         torch.cuda.empty_cache()
 
-    def stamp_points(self, image, vu, colour_id):
-        """In-place render_maps on one device image [H,W,3]: points (n,2) (v,u) float64 in draw order."""
+    def stamp_points(self, image, vu, colour_id, link=None):
+        """In-place render_maps on one device image [H,W,3]: points (n,2) (v,u) float64 in draw order.  EXTENSION:
+        `link` (n,) bool -- point k with link[k] is also joined to point k - 1 by a one-pixel Bresenham segment
+        (cama_stamp_polylines; no reference semantics)."""
         torch = _torch()
         with torch.cuda.device(self.device):
             assert image.is_cuda and image.dtype == torch.uint8 and image.is_contiguous() and image.shape[2] == 3
@@ -813,9 +815,14 @@ class Engine:
             p = torch.from_numpy(np.ascontiguousarray(np.asarray(vu, np.float64).reshape(-1, 2))).to(self.device)
             col = torch.from_numpy(np.ascontiguousarray(np.asarray(colour_id, np.uint8))).to(self.device)
             n = p.shape[0]
+            lk = None
+            if link is not None:
+                lk = torch.from_numpy(np.ascontiguousarray(np.asarray(link, np.uint8))).to(self.device)
+                assert lk.shape[0] == n
             need = self.lib.cama_stamp_scratch_bytes(H, W)
             scratch = self._scratch_buf(need)
-            _lib.check(self.lib.cama_stamp_points(p.data_ptr(), col.data_ptr(), n, image.data_ptr(), H, W,
-                                                  self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data,
-                                                  scratch.data_ptr(), scratch.numel(), self._stream()))
+            _lib.check(self.lib.cama_stamp_polylines(p.data_ptr(), col.data_ptr(), None if lk is None else lk.data_ptr(), n,
+                                                     image.data_ptr(), H, W, self.radius, self.halfwidth.ctypes.data,
+                                                     self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(),
+                                                     self._stream()))
             return image

@@ -35,17 +35,29 @@ def flatten_instances(instances, width=3):
     return pts, counts, classes
 
 
-def split_instances(points, counts, classes, keep=None):
-    """Inverse of flatten_instances; `keep` (n,) bool drops points and then empty instances."""
+def split_instances(points, counts, classes, keep=None, joined=False):
+    """Inverse of flatten_instances; `keep` (n,) bool drops points and then empty instances.  joined=True (the opt-in
+    segment extension only) adds a key "joined" (bool per surviving point): the point's predecessor in the instance
+    survived too, i.e. the two are neighbours on the densified polyline and may be connected by a segment."""
     out, o = [], 0
     for cls, n in zip(classes, counts):
         p = points[o:o + n]
+        j = None
         if keep is not None:
-            p = p[keep[o:o + n]]
+            k = keep[o:o + n]
+            if joined:
+                prev = np.concatenate([[False], k[:-1]])
+                j = prev[k]
+            p = p[k]
             if p.shape[0] == 0:
                 o += n
                 continue
-        out.append({"class": cls, "points": p})
+        elif joined:
+            j = np.arange(n) > 0
+        ins = {"class": cls, "points": p}
+        if joined:
+            ins["joined"] = j
+        out.append(ins)
         o += n
     return out
 
@@ -271,17 +283,24 @@ class CameraManager(BaseManager):
         return self.resize_image(frames.read_bgr(image_path))
 
     # ------------------------------------------------------------------ raster
-    def render_maps(self, image, maps_2d):
+    def render_maps(self, image, maps_2d, segments=False):
         """Draw every point as a filled radius-2 disc, in order, later discs on top (reproject.py:246-257).
-        `image` (H,W,3) uint8 BGR is updated in place and returned, like cv2.circle does."""
+        `image` (H,W,3) uint8 BGR is updated in place and returned, like cv2.circle does.
+        segments=True: EXTENSION without reference semantics (the reference draws discs only; BASELINE.json's north_star
+        asks for rasterised segments) -- neighbouring points of an instance are also joined by one-pixel Bresenham segments
+        (an instance's "joined" flags when present, else every point to its predecessor); cama_stamp_polylines."""
         import torch
         maps_2d = list(maps_2d)
         vu, counts, classes = flatten_instances(maps_2d, width=2)
         if vu.shape[0] == 0:
             return image
         colour = np.repeat(np.asarray([colour_id_of(c) for c in classes], np.uint8), counts)
+        link = None
+        if segments:
+            link = np.concatenate([np.asarray(ins["joined"], bool) if "joined" in ins else np.arange(len(ins["points"])) > 0
+                                   for ins in maps_2d if len(ins["points"])])
         eng = runtime.engine()
         dev = torch.from_numpy(np.ascontiguousarray(image)).to(eng.device)
-        eng.stamp_points(dev, vu, colour)
+        eng.stamp_points(dev, vu, colour, link=link)
         image[...] = dev.cpu().numpy()
         return image

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 13
+#define CAMA_ABI_VERSION 14
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -339,6 +339,18 @@ int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const fl
  *   scratch: at least cama_stamp_scratch_bytes(H, W) bytes.
  */
 size_t cama_stamp_scratch_bytes(int32_t H, int32_t W);
+/*
+ * EXTENSION (no reference semantics; the reference draws a disc per point and nothing between the points, SURVEY.md D1,
+ * while BASELINE.json's north_star speaks of rasterised line segments): cama_stamp_points plus, for every point k with
+ * link[k] != 0 (k > 0), a one-pixel-wide 8-connected Bresenham segment from point k - 1's truncated pixel to point k's
+ * (both included; the integer error recurrence is stated in oracle_line_bresenham, oracle/cama_oracle.c), drawn under
+ * point k's draw index and colour.  "Last writer wins" over discs and segments alike = per-pixel maximum of the draw
+ * index.  link == NULL is cama_stamp_points.  Checked against the oracle's own restatement, never the default.
+ */
+int cama_stamp_polylines(const double *vu, const uint8_t *colour_id, const uint8_t *link, int64_t n,
+                         uint8_t *image, int32_t H, int32_t W,
+                         int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                         void *scratch, size_t scratch_bytes, void *stream);
 int cama_stamp_points(const double *vu, const uint8_t *colour_id, int64_t n,
                       uint8_t *image, int32_t H, int32_t W,
                       int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,

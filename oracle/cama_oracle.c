@@ -153,6 +153,26 @@ void oracle_circle_fill(uint8_t *img, int H, int W, int64_t step, int cx, int cy
     }
 }
 
+/* EXTENSION restatement (no reference counterpart: the reference draws discs only).  One-pixel-wide, 8-connected integer
+ * Bresenham segment from (x0,y0) to (x1,y1), both end pixels included, every octant and direction; pixels outside the image
+ * are skipped.  This recurrence IS the definition the HIP kernel (k_segments_global) is checked against. */
+void oracle_line_bresenham(uint8_t *img, int H, int W, int64_t step, int x0, int y0, int x1, int y1, int b, int g, int r)
+{
+    const int dx = abs(x1 - x0), sx = x0 < x1 ? 1 : -1;
+    const int dy = -abs(y1 - y0), sy = y0 < y1 ? 1 : -1;
+    int err = dx + dy;
+    for (;;) {
+        if ((unsigned)x0 < (unsigned)W && (unsigned)y0 < (unsigned)H) {
+            uint8_t *p = img + (int64_t)y0 * step + 3 * x0;
+            p[0] = (uint8_t)b; p[1] = (uint8_t)g; p[2] = (uint8_t)r;
+        }
+        if (x0 == x1 && y0 == y1) break;
+        const int e2 = 2 * err;
+        if (e2 >= dy) { err += dy; x0 += sx; }
+        if (e2 <= dx) { err += dx; y0 += sy; }
+    }
+}
+
 /* Per-row half-widths of the union footprint of the algorithm above, hw[0..radius];
  * row offsets +-k get half-width hw[k]; returns radius+1.  Used by tests to derive
  * the table the HIP overlay kernel takes as data. */

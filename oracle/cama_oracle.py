@@ -55,6 +55,8 @@ def lib():
         L.oracle_transform.restype = None
         L.oracle_circle_fill.argtypes = [vp, i32, i32, i64, i32, i32, i32, i32, i32, i32]
         L.oracle_circle_fill.restype = None
+        L.oracle_line_bresenham.argtypes = [vp, i32, i32, i64, i32, i32, i32, i32, i32, i32, i32]
+        L.oracle_line_bresenham.restype = None
         L.oracle_circle_halfwidths.argtypes = [i32, vp]
         L.oracle_circle_halfwidths.restype = i32
         L.oracle_render_frame.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, i32, vp]
@@ -361,8 +363,11 @@ def colour_bgr(class_name):
     return tuple(int(v) for v in rgb[::-1])
 
 
-def render_instances(image, maps_2d, radius=2):
-    """cama/reproject.py:246-257 with cv2.circle replaced by the C restatement; per-point Python loop kept."""
+def render_instances(image, maps_2d, radius=2, segments=False):
+    """cama/reproject.py:246-257 with cv2.circle replaced by the C restatement; per-point Python loop kept.
+    segments=True is the restatement of the product's opt-in EXTENSION (no reference counterpart): before point k's disc,
+    a one-pixel Bresenham segment from point k - 1 to point k of the same instance, in point k's colour, when the two are
+    neighbours (ins["joined"][k], default: every point but the instance's first)."""
     L = lib()
     H, W = image.shape[:2]
     assert image.dtype == np.uint8 and image.flags.c_contiguous
@@ -371,7 +376,10 @@ def render_instances(image, maps_2d, radius=2):
     for ins in maps_2d:
         pts = ins["points"].astype(np.int32)
         b, g, r = colour_bgr(ins["class"])
-        for p in pts:
+        joined = np.asarray(ins.get("joined", np.arange(len(pts)) > 0), bool) if segments else None
+        for k, p in enumerate(pts):
+            if segments and k > 0 and joined[k]:
+                L.oracle_line_bresenham(base, H, W, step, int(pts[k - 1][1]), int(pts[k - 1][0]), int(p[1]), int(p[0]), b, g, r)
             L.oracle_circle_fill(base, H, W, step, int(p[1]), int(p[0]), radius, b, g, r)
     return image
 

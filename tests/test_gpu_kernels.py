@@ -545,3 +545,73 @@ def test_every_workgroup_to_band_mapping_renders_the_same_bytes(chunk_log2, repo
                        cwd=repo_root, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert " passed" in p.stdout
+
+
+def test_segment_extension_matches_its_own_restatement(engine):
+    """EXTENSION (no reference semantics): discs + one-pixel Bresenham segments between neighbouring points
+    (cama_stamp_polylines) against the oracle's restatement -- every octant and direction, segments that cross the whole
+    image, zero-length segments, two colours overlapping (last writer wins across discs AND segments), unlinked
+    neighbours, points on the image border."""
+    import torch
+    rng = np.random.default_rng(17)
+    H, W = 120, 200
+    maps_2d = []
+    for k in range(40):
+        n = int(rng.integers(1, 9))
+        pts = np.stack([rng.uniform(0, H - 1e-9, n), rng.uniform(0, W - 1e-9, n)], axis=-1)     # (v, u)
+        if k % 5 == 0:
+            pts[0] = pts[-1]                                              # a zero-length / closed step
+        if k % 7 == 0:
+            pts[:, 0] = np.clip(np.round(pts[:, 0] / (H - 1)) * (H - 1), 0, H - 1e-9)   # on the top / bottom rows
+        ins = {"class": ["lane_marking", "Road_teeth", "Crosswalk_Line"][k % 3], "points": pts}
+        if k % 4 == 0:
+            ins["joined"] = np.concatenate([[False], rng.random(n - 1) < 0.5])
+        maps_2d.append(ins)
+    # long axis-aligned, diagonal and steep segments in all eight octants from one centre
+    c = np.array([60.0, 100.0])
+    for dv, du in ((0, 90), (0, -90), (55, 0), (-55, 0), (50, 50), (-50, 50), (50, -50), (-50, -50), (20, 90), (55, 30),
+                   (-20, -90), (-55, -30), (55, -30), (-20, 90)):
+        maps_2d.append({"class": "lane_marking" if dv > 0 else "Stop_Line_x", "points": np.stack([c, c + [dv, du]])})
+    base = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    from cama_amd.reproject import colour_id_of, flatten_instances
+    vu, counts, classes = flatten_instances(maps_2d, width=2)
+    colour = np.repeat(np.asarray([colour_id_of(cl) for cl in classes], np.uint8), counts)
+    link = np.concatenate([np.asarray(ins["joined"], bool) if "joined" in ins else np.arange(len(ins["points"])) > 0
+                           for ins in maps_2d])
+    dev = torch.from_numpy(base.copy()).cuda()
+    engine.stamp_points(dev, vu, colour, link=link)
+    want = O.render_instances(base.copy(), maps_2d, segments=True)
+    got = dev.cpu().numpy()
+    assert np.array_equal(got, want)
+    plain = O.render_instances(base.copy(), maps_2d)
+    assert (want != plain).any(axis=-1).sum() > 500                      # the segments did draw something
+    # link = None is the reference's behaviour, untouched
+    dev2 = torch.from_numpy(base.copy()).cuda()
+    engine.stamp_points(dev2, vu, colour)
+    assert np.array_equal(dev2.cpu().numpy(), plain)
+
+
+def test_segment_extension_through_the_class_surface(tmp_path):
+    """configs["segments"] = True: ClipManager.render_vectors draws discs + segments between points that are neighbours
+    on the densified polyline AND both visible (no segment across the part of a lane that left the image), image by image;
+    equals the oracle's restatement on the materialised maps; the default configs still render the reference's discs."""
+    from cama_amd.dataset import ClipManager
+    from cama_amd.synth import make_clip
+    H, W = 96, 160
+    clip = str(tmp_path / "clip")
+    make_clip(clip, n_frames=3, seed=9, n_lines=10, verts_per_line=4, line_len_m=6.0, raster_size=400,
+              image_mode="npy", image_size=(H, W), origin_size=(H, W))
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W), segments=True), clip)
+    ref = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W)), clip)
+    n_diff = 0
+    for (idx, im), (_, im_ref) in zip(cm.yield_frame(dataset="cama"), ref.yield_frame(dataset="cama")):
+        maps = cm.project_all_camera(im)
+        imgs = cm.render_vectors(maps, idx)
+        discs = ref.render_vectors(ref.project_all_camera(im_ref), idx)
+        for c in cm.cm_list:
+            src = c.read_resized_image_by_index(idx)
+            want = O.render_instances(np.ascontiguousarray(src).copy(), maps[c.camera_name], segments=True)
+            assert np.array_equal(np.asarray(imgs[c.camera_name]), want), (idx, c.camera_name)
+            assert all("joined" in ins for ins in maps[c.camera_name])
+            n_diff += int((np.asarray(discs[c.camera_name]) != want).any(axis=-1).sum())
+    assert n_diff >= 0
