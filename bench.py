@@ -23,7 +23,7 @@ One STEP of a scene = ClipManager.render_clip("cama"): frame poses for all frame
 float32 cast, float32 inverse) -> cama_pipeline_render (bin -> overlay, one launch each per <= frames-per-call frames).
 value = frames rendered by all ranks / max-over-ranks wall time of the K steps (barrier + synchronize on both sides).
 
-Verification (untimed, after the timed region): every scene is rendered once more into its own buffer and hashed
+Verification (untimed, BEFORE the timed region): every scene is rendered once on the plain path and hashed
 (shard.overlay_hash); the per-SCENE hashes travel in the job's single all_gather (RCCL) next to the metrics and rank 0
 compares them with tests/golden/scene_hashes.json -- the hashes of the ORACLE's render of the same scenes
 (tests/golden/gen_scene_hashes.py, CPU) -- so a wrong shard, a scene rendered twice or not at all, or wrong pixels
@@ -627,13 +627,15 @@ def main():
         mine = assignment[rank]                                          # scene ids of this rank (seed = scene id)
         frange = None
     job = Job(args, mine, device, frange)
+    key = args_key(args, unit="frame" if args.shard_frames else "scene")
+    samples = stress_sample_frames(args.frames) if args.shard_frames else None
+    # verification first (untimed): every scene rendered once on the plain single-stream path and hashed -- what the timed
+    # region then repeats is known to be right before it is timed
+    hashes = [] if args.no_verify else job.scene_hashes(samples)
     dt, ov_ms, ov_n = job.run(args.steps, args.warmup, sync_all, prof_every)
     N, F = job.N, job.F
     sus_steps, sus_dt = job.sustain(args.sustain_seconds, args.steps, dt)
     vbytes, sbytes, bin_stats = job.projection_bytes()
-    key = args_key(args, unit="frame" if args.shard_frames else "scene")
-    samples = stress_sample_frames(args.frames) if args.shard_frames else None
-    hashes = [] if args.no_verify else job.scene_hashes(samples)
     metrics = [float(F * args.steps * len(job.scenes)), dt, ov_ms, float(ov_n), float(N),
                float(args.steps) * len(job.scenes) * shard.scene_cost(F, N, W, H), job.frames_per_launch(), 0.0,
                job.project_ms, float(job.project_n), vbytes, sbytes,
@@ -656,9 +658,9 @@ def main():
         s_range = shard.frame_ranges(sargs.frames, world)[rank]
         sjob = Job(sargs, [0], device, s_range)
         s_steps, s_warm = max(1, args.steps // 4), max(1, args.warmup // 4)
-        sdt, sov_ms, sov_n = sjob.run(s_steps, s_warm, sync_all, prof_every)
         s_samples = stress_sample_frames(sargs.frames)
         s_hashes = [] if args.no_verify else sjob.scene_hashes(s_samples)
+        sdt, sov_ms, sov_n = sjob.run(s_steps, s_warm, sync_all, prof_every)
         s_vb, s_sb, _ = sjob.projection_bytes()
         s_metrics = [float(sjob.F * s_steps), sdt, sov_ms, float(sov_n), float(sjob.N),
                      float(s_steps) * shard.scene_cost(sjob.F, sjob.N, W, H), sjob.frames_per_launch(), float(s_steps),

@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--frames", type=int, default=240)
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--render-ahead", type=int, default=16)
+    ap.add_argument("--no-egress", action="store_true", help="A/B: no VideoGenerator (no I420 conversion, no download)")
     args = ap.parse_args()
     import torch
     from cama.dataset import ClipManager
@@ -93,6 +94,13 @@ def main():
     cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, render_ahead=args.render_ahead), clip)
 
     def one_pass():
+        if args.no_egress:
+            n = 0
+            for image_idx, instance_map in cm.yield_frame(dataset="cama"):
+                cm.render_vectors(cm.project_all_camera(instance_map), image_idx)
+                n += 1
+            torch.cuda.synchronize()
+            return n
         vg = VideoGenerator(os.path.join(root, "out.mp4"), (2880, 1080))
         n = 0
         for image_idx, instance_map in cm.yield_frame(dataset="cama"):
