@@ -577,6 +577,11 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 -- RCCL prints a
+    # version banner through C stdio when its first communicator is built -- is sent to stderr from here on
+    sys.stdout.flush()
+    record_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -806,7 +811,8 @@ def main():
                     line["speedup_vs_cpu_all_cores"] = fps / line["cpu_baseline"]["all_cores"]["value"]
                 except Exception as e:                              # a reported baseline, never a reason to lose the line
                     line["cpu_baseline"]["all_cores"] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
+        record_out.write(json.dumps(line) + "\n")
+        record_out.flush()
     if use_dist:
         dist.destroy_process_group()
 
