@@ -766,6 +766,14 @@ def main():
                                          "barrier; sum of frames / slowest rank)" % args.sustain_seconds}
         if bin_stats is not None:
             line["projection_stats"] = bin_stats
+        try:
+            periodic, first8, per_xcd = job.eng.xcd_map()
+            line["xcd_dispatch"] = {"round_robin_over_8_xcds": periodic, "xcd_of_blocks_0_to_7": first8,
+                                    "blocks_per_xcd": per_xcd,
+                                    "note": "the overlay's XCD-contiguous mapping assumes consecutive blocks go round-robin "
+                                            "over the 8 XCDs (speed only; HW_REG_XCC_ID probe)"}
+        except Exception as e:
+            line["xcd_dispatch"] = {"error": repr(e)}
         if args.sites > 0:
             line["site_maps"] = {"sites": args.sites, "verts_per_site": N,
                                  "sites_per_rank": shard.sites_per_rank(assignment, site_of),

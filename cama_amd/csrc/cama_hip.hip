@@ -1406,6 +1406,14 @@ int cama_pipeline_join(cama_pipeline *p, void *stream)
     return CAMA_OK;
 }
 
+int cama_probe_xcd_map(uint32_t *xcd_of_block, int32_t n_blocks, void *stream)
+{
+    if (!xcd_of_block || n_blocks < 1 || n_blocks > (1 << 20)) return fail(CAMA_EINVAL, "bad arguments");
+    hipLaunchKernelGGL(k_probe_xcd, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, xcd_of_block);
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
 size_t cama_stamp_scratch_bytes(int32_t H, int32_t W)
 {
     if (H < 1 || W < 1) return 0;

@@ -196,6 +196,13 @@ __device__ __forceinline__ bool xcd_contiguous_item(const uint32_t T, const uint
     return item < T;
 }
 
+// Diagnostic: which XCD does block L of a 1-D grid run on?  out[L] = HW_REG_XCC_ID (0..7).  The contiguous mapping above
+// assumes L % 8 for speed; cama_probe_xcd_map() lets a caller (bench.py prints it) see what the box really does.
+__global__ void k_probe_xcd(uint32_t *__restrict__ out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u;
+}
+
 // n / d by multiply-high with magic = ceil(2^32 / d) (host): the estimate is the quotient or one more for every n < 2^32
 // (excess n * (magic * d - 2^32) / (d * 2^32) < 1), hence one correction step; d = 1 has no 32-bit magic.
 __device__ __forceinline__ uint32_t divmod_magic(const uint32_t n, const uint32_t d, const uint32_t magic, uint32_t &r)

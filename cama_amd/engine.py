@@ -378,6 +378,18 @@ class Engine:
             self._last_bin = (dmap.N, F, rig.C, rig.H, rig.W, bnd is not None, key is not None, scratch)
             return out
 
+    def xcd_map(self, n_blocks=4096):
+        """What the overlay's XCD-contiguous mapping relies on, measured: (True when the XCD a block of a 1-D grid runs on
+        is a function of its index mod 8 -- round-robin from whichever XCD the dispatcher is at: then every XCD gets every
+        eighth block and hence one contiguous eighth of the bands --, the XCDs of blocks 0..7, blocks per XCD)."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            out = torch.empty(n_blocks, dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.cama_probe_xcd_map(out.data_ptr(), n_blocks, self._stream()))
+            got = out.cpu().numpy()
+        periodic = all(len(set(got[k::8].tolist())) == 1 for k in range(8)) and len(set(got[:8].tolist())) == 8
+        return bool(periodic), [int(v) for v in got[:8]], np.bincount(got, minlength=8).tolist()
+
     def bin_stats(self):
         """What the binning half of the LAST render_frames() call read and produced (cama_bin_stats; blocks until the
         stream is idle): dict with frames, vertex_waves_read (64-vertex runs fetched, over all frames), camera_chains,

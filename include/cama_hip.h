@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 14
+#define CAMA_ABI_VERSION 15
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -331,6 +331,13 @@ int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const fl
                             int32_t H, int32_t W, int32_t cols,
                             int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
                             const void *scratch, size_t scratch_bytes, void *stream);
+
+/*
+ * Diagnostic: xcd_of_block[L] (device, n_blocks uint32) = the XCD (HW_REG_XCC_ID, 0..7) that block L of a 1-D grid of
+ * n_blocks 64-thread blocks ran on.  The overlay kernels' XCD-contiguous workgroup -> band mapping assumes L % 8 -- for
+ * speed only, the output never depends on it -- and bench.py prints what the box does.
+ */
+int cama_probe_xcd_map(uint32_t *xcd_of_block, int32_t n_blocks, void *stream);
 
 /*
  * Stamp-only overlay for caller-supplied 2D points (the generic CameraManager.render_maps,

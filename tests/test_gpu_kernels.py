@@ -615,3 +615,11 @@ def test_segment_extension_through_the_class_surface(tmp_path):
             assert all("joined" in ins for ins in maps[c.camera_name])
             n_diff += int((np.asarray(discs[c.camera_name]) != want).any(axis=-1).sum())
     assert n_diff >= 0
+
+
+def test_xcd_dispatch_probe(engine):
+    """cama_probe_xcd_map: every block reports an XCD in 0..7; on MI355X consecutive blocks go round-robin over the eight
+    (what the XCD-contiguous overlay mapping assumes for speed -- its output does not depend on it)."""
+    periodic, first8, per_xcd = engine.xcd_map(4096)
+    assert sum(per_xcd) == 4096 and len(per_xcd) == 8 and all(0 <= v < 8 for v in first8)
+    assert periodic, (first8, per_xcd)
