@@ -74,6 +74,9 @@ hipEvent_t prof_event()
     return e;
 }
 
+#ifndef RAW35_PAIR_DEFAULT
+#define RAW35_PAIR_DEFAULT 0      // k_overlay_raw35: bands per workgroup - 1 (see raw35_kernels.hpp)
+#endif
 constexpr int BLOCK = 256;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte chunk (global_load_dwordx4)
 #ifndef OVERLAY_BLOCK
@@ -900,8 +903,16 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     const size_t lds = staging_dw * 4;
     if (lds > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the 3:5 raw overlay's LDS", W);
     if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    o.items = (uint32_t)((size_t)F * rows * cols * L.NB * TX);
+        {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    // bands per workgroup: 2 = the second band's source loads fly during the first band's blend (CAMA_RAW35_PAIR=0|1, A/B)
+    static const int pair_env = getenv("CAMA_RAW35_PAIR") ? atoi(getenv("CAMA_RAW35_PAIR")) : RAW35_PAIR_DEFAULT;
+    const int bands_per_wg = pair_env ? 2 : 1;
+    const uint32_t NBx = bands_per_wg == 2 ? (uint32_t)(L.NB + 1) / 2 : (uint32_t)L.NB;
+    const uint32_t nbx_magic = (uint32_t)(((1ull << 32) + NBx - 1) / NBx);
+    o.items = (uint32_t)((size_t)F * rows * cols * NBx * TX);
     o.chunk_log2 = overlay_chunk_log2((size_t)F * C * 3 * ((size_t)H0 * W0 + (size_t)H * W));
     const dim3 rgrid = overlay_grid(o.items, o.chunk_log2);
     o.nb_magic = (uint32_t)(((1ull << 32) + (uint32_t)L.NB - 1) / (uint32_t)L.NB);
@@ -917,18 +928,17 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
         ev0 = prof_event();
         ev1 = prof_event();
     }
-    if (ev0 && ev1) {
-        hipExtLaunchKernelGGL(k_overlay_raw35, rgrid, dim3(block), (uint32_t)lds, s, ev0, ev1, 0u, o,
-                              reinterpret_cast<const uint2 *>(vrows), reinterpret_cast<const int2 *>(band_rows), upr,
-                              max_src_rows, (int)owner_off, TX, tx_magic, cpt_magic);
-    } else if (g_overlay_stop_event) {
-        hipExtLaunchKernelGGL(k_overlay_raw35, rgrid, dim3(block), (uint32_t)lds, s, nullptr, g_overlay_stop_event,
-                              0u, o, reinterpret_cast<const uint2 *>(vrows), reinterpret_cast<const int2 *>(band_rows), upr,
-                              max_src_rows, (int)owner_off, TX, tx_magic, cpt_magic);
-        g_overlay_stop_event = nullptr;
-    } else
-        hipLaunchKernelGGL(k_overlay_raw35, rgrid, dim3(block), lds, s, o, reinterpret_cast<const uint2 *>(vrows),
-                           reinterpret_cast<const int2 *>(band_rows), upr, max_src_rows, (int)owner_off, TX, tx_magic, cpt_magic);
+    hipEvent_t e0 = (ev0 && ev1) ? ev0 : nullptr;
+    hipEvent_t e1 = e0 ? ev1 : g_overlay_stop_event;
+    const uint2 *vr2 = reinterpret_cast<const uint2 *>(vrows);
+    const int2 *br2 = reinterpret_cast<const int2 *>(band_rows);
+    if (bands_per_wg == 2)
+        hipExtLaunchKernelGGL(k_overlay_raw35<2>, rgrid, dim3(block), (uint32_t)lds, s, e0, e1, 0u, o, vr2, br2, upr, max_src_rows,
+                              (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic);
+    else
+        hipExtLaunchKernelGGL(k_overlay_raw35<1>, rgrid, dim3(block), (uint32_t)lds, s, e0, e1, 0u, o, vr2, br2, upr, max_src_rows,
+                              (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic);
+    if (!e0) g_overlay_stop_event = nullptr;
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) g_prof.pending.emplace_back(ev0, ev1);
     return CAMA_OK;

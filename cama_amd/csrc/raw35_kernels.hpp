@@ -211,94 +211,109 @@ __device__ __forceinline__ void raw35_rasterise_tile(uint32_t *s_owner, const ui
     }
 }
 
-__global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a, const uint2 *__restrict__ vrows,
-                                                                   const int2 *__restrict__ band_rows, int upr,
-                                                                   int max_src_rows, int owner_off, int TX,
-                                                                   uint32_t tx_magic, uint32_t cpt_magic)
+// One band's share of the work, in three phases, so that a workgroup can have the NEXT band's source loads in flight while
+// it blends the current one (k_overlay_raw35 with bands_per_wg = 2).
+struct Raw35Band {
+    uint32_t b, fc, n;
+    int y0, nrows;
+    const uint2 *st;
+    uint2 first;
+    int2 br;                    // {first source row, number of source rows}
+    const u32x4 *g;
+    uint32_t nsrc;
+};
+struct Raw35Tile {
+    int upr, Wt, x_first, W0, owner_off;
+    uint32_t row_dwords, src_row_dwords, src_pitch16, cpt, cpt_magic, tx;
+};
+
+// phase 1: scalar loads (count, list offset, source rows), the band's first stamp record, then the source loads
+template <int U>
+__device__ __forceinline__ void raw35_issue(const OverlayArgs &a, const int2 *__restrict__ band_rows, const Raw35Tile &t,
+                                            const uint32_t f, const uint32_t c, const uint32_t b, Raw35Band &k, u32x4 (&v)[U])
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    // same item order as k_overlay -- (frame, mosaic row of cameras, band, camera column), column tile innermost -- and the
-    // same XCD-contiguous assignment of items to workgroups (overlay_kernels.hpp: decode_band)
-    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C;
-    const BandId id = decode_band(a, a.items, (uint32_t)TX, tx_magic);
-    if (!id.valid) return;
-    const uint32_t f = id.fl, c = id.c, b = id.b, tx = id.tx;
-    const uint32_t fc = f * C + c;
-    const uint32_t bin = fc * NB + b;
-    const int y0 = (int)b * a.R;
-    const int nrows = min(a.R, a.H - y0);
-    const int W = a.W;
-    const uint32_t n = a.counts[bin];
-    // this workgroup's tile: upr units (12 destination pixels = 9 dwords out, 20 source pixels = 15 dwords in, each)
-    const int Wt = upr * 12, x_first = (int)tx * Wt;
-    const uint32_t row_dwords = (uint32_t)upr * 9u;                    // destination dwords per tile row (multiple of 4)
-    const uint32_t src_row_dwords = (uint32_t)upr * 15u;               // source dwords per tile row (multiple of 4)
-    const uint32_t src_pitch16 = (uint32_t)a.W0 * 3u / 16u;            // 16-byte chunks per raw row (W0*3 % 16 == 0)
-    uint32_t *s_stage = s_dyn;                                         // [max_src_rows * src_row_dwords], later the output
-    uint32_t *s_owner = s_dyn + owner_off;                             // [R * Wt], stamped bands only
-
+    const uint32_t NB = (uint32_t)a.NB, C = (uint32_t)a.C;
+    k.b = b;
+    k.fc = f * C + c;
+    const uint32_t bin = k.fc * NB + b;
+    k.y0 = (int)b * a.R;
+    k.nrows = min(a.R, a.H - k.y0);
+    k.n = a.counts[bin];
+    const uint32_t list0 = a.fc_base[k.fc] + a.bin_off[bin];          // (unconditional: three parallel scalar loads)
+    k.st = a.stamps + (k.n ? (size_t)list0 : (size_t)0);
     // the band's first stamp record before the source loads (VMEM returns in order; see k_overlay)
-    const uint32_t list0 = a.fc_base[fc] + a.bin_off[bin];            // (unconditional: three parallel scalar loads)
-    const uint2 *st = a.stamps + (n ? (size_t)list0 : (size_t)0);
-    const uint2 first = st[n ? min(threadIdx.x, n - 1u) : 0u];
+    k.first = k.st[k.n ? min(threadIdx.x, k.n - 1u) : 0u];
     __builtin_amdgcn_sched_barrier(0);
-
-    // stage the band's source rows: one contiguous range of the raw frame, same layout in LDS
-    const int2 br = band_rows[c * NB + b];                             // {first source row, number of source rows}
-    const u32x4 *g = reinterpret_cast<const u32x4 *>(a.src + ((size_t)fc * a.H0 + br.x) * (size_t)a.W0 * 3) +
-                     tx * (src_row_dwords >> 2);
-    const uint32_t cpt = src_row_dwords >> 2;                          // 16-byte chunks per tile row
-    const uint32_t nsrc = (uint32_t)br.y * cpt;
+    k.br = band_rows[c * NB + b];
+    k.g = reinterpret_cast<const u32x4 *>(a.src + ((size_t)k.fc * a.H0 + k.br.x) * (size_t)a.W0 * 3) + t.tx * t.cpt;
+    k.nsrc = (uint32_t)k.br.y * t.cpt;
     // chunk idx of the tile = (source row idx / cpt, chunk idx % cpt) (cpt_magic = ceil(2^32 / cpt) from the host: exact for
-    // idx < 2^16); TX == 1: pitch == cpt, one contiguous range
-    const auto gaddr = [&](uint32_t idx) {
-        const uint32_t r = __umulhi(idx, cpt_magic);
-        return g + (size_t)r * src_pitch16 + (idx - r * cpt);
-    };
-    constexpr int U = RAW35_STAGE_UNROLL;
-    u32x4 v[U];
+    // idx < 2^16); one tile per band: pitch == cpt, one contiguous range
 #pragma unroll
-    for (int j = 0; j < U; ++j) v[j] = OVERLAY_LOAD(gaddr(min(threadIdx.x + j * blockDim.x, nsrc - 1u)));
+    for (int j = 0; j < U; ++j) {
+        const uint32_t idx = min(threadIdx.x + j * blockDim.x, k.nsrc - 1u);
+        const uint32_t r = __umulhi(idx, t.cpt_magic);
+        v[j] = OVERLAY_LOAD(k.g + (size_t)r * t.src_pitch16 + (idx - r * t.cpt));
+    }
+}
 
+// phase 2: the staged rows into LDS (same layout as in memory)
+template <int U>
+__device__ __forceinline__ void raw35_stage(const Raw35Tile &t, const Raw35Band &k, const u32x4 (&v)[U], uint32_t *s_stage)
+{
     u32x4 *s16 = reinterpret_cast<u32x4 *>(s_stage);
 #pragma unroll
     for (int j = 0; j < U; ++j) {
         const uint32_t idx = threadIdx.x + j * blockDim.x;
-        if (idx < nsrc) s16[idx] = v[j];
+        if (idx < k.nsrc) s16[idx] = v[j];
     }
-    for (uint32_t idx = threadIdx.x + U * blockDim.x; idx < nsrc; idx += blockDim.x) s16[idx] = OVERLAY_LOAD(gaddr(idx));
-    __syncthreads();
+    for (uint32_t idx = threadIdx.x + U * blockDim.x; idx < k.nsrc; idx += blockDim.x) {
+        const uint32_t r = __umulhi(idx, t.cpt_magic);
+        s16[idx] = OVERLAY_LOAD(k.g + (size_t)r * t.src_pitch16 + (idx - r * t.cpt));
+    }
+    lds_barrier();
+}
 
+// phase 3: taps -> blend -> (stamps) -> transpose through the dead staging area -> 16-byte stores.  Only LDS barriers: the
+// next band's source loads may be in flight.
+__device__ __forceinline__ void raw35_finish(const OverlayArgs &a, const uint2 *__restrict__ vrows, const Raw35Tile &t,
+                                             const uint32_t f, const uint32_t c, const Raw35Band &k, uint32_t *s_stage,
+                                             const bool more_follows)
+{
+    const uint32_t cols = (uint32_t)a.cols;
+    uint32_t *s_owner = s_stage + t.owner_off;                         // [R * Wt], stamped bands only
+    const int y0 = k.y0, nrows = k.nrows, W = a.W, Wt = t.Wt, x_first = t.x_first;
+    const uint32_t n = k.n;
     // one 12-pixel unit per thread (the block covers the band: items <= blockDim, host-checked)
-    const uint32_t items = (uint32_t)nrows * (uint32_t)upr;
+    const uint32_t items = (uint32_t)nrows * (uint32_t)t.upr;
     const bool active = threadIdx.x < items;
     const uint32_t item = active ? threadIdx.x : items - 1u;
-    const uint32_t row = item / (uint32_t)upr, u = item - row * (uint32_t)upr;
+    const uint32_t row = item / (uint32_t)t.upr, u = item - row * (uint32_t)t.upr;
     const uint2 vr = vrows[(size_t)c * a.H + y0 + (int)row];           // {r0 | r1 << 16, wt | wb << 8}
     const uint32_t wt = vr.y & 0xffu, wb = (vr.y >> 8) & 0xffu;
     // lane stride 15 dwords: odd, so the 32 banks are hit once each per half wave
-    const uint32_t *p0 = s_stage + ((vr.x & 0xffffu) - (uint32_t)br.x) * src_row_dwords + u * 15u;
-    const uint32_t *p1 = s_stage + ((vr.x >> 16) - (uint32_t)br.x) * src_row_dwords + u * 15u;
+    const uint32_t *p0 = s_stage + ((vr.x & 0xffffu) - (uint32_t)k.br.x) * t.src_row_dwords + u * 15u;
+    const uint32_t *p1 = s_stage + ((vr.x >> 16) - (uint32_t)k.br.x) * t.src_row_dwords + u * 15u;
     uint32_t d0[15], d1[15];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) d0[k] = p0[k];
+    for (int j = 0; j < 15; ++j) d0[j] = p0[j];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) d1[k] = p1[k];
+    for (int j = 0; j < 15; ++j) d1[j] = p1[j];
     if (n) {                                                           // (workgroup-uniform)
-        __syncthreads();                                               // every unit holds its taps: staging is dead
+        lds_barrier();                                                 // every unit holds its taps: staging is dead
         uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
         const int n4 = (nrows * Wt + 3) >> 2;
         for (int j = threadIdx.x; j < n4; j += blockDim.x) o4[j] = make_uint4(0, 0, 0, 0);
         lds_barrier();
-        if (threadIdx.x < n) raw35_rasterise_tile(s_owner, first, y0, nrows, x_first, Wt, a.disc);
+        if (threadIdx.x < n) raw35_rasterise_tile(s_owner, k.first, y0, nrows, x_first, Wt, a.disc);
         for (uint32_t sidx = threadIdx.x + blockDim.x; sidx < n; sidx += blockDim.x)
-            raw35_rasterise_tile(s_owner, st[sidx], y0, nrows, x_first, Wt, a.disc);
-        __syncthreads();
+            raw35_rasterise_tile(s_owner, k.st[sidx], y0, nrows, x_first, Wt, a.disc);
+        lds_barrier();
     }
     uint32_t o[9];
 #if defined(RAW35_ABL_NOMATH)                                          // ablation: taps read, nothing computed
 #pragma unroll
-    for (int k = 0; k < 9; ++k) o[k] = d0[k] ^ d1[k + 6] ^ wt ^ wb;
+    for (int j = 0; j < 9; ++j) o[j] = d0[j] ^ d1[j + 6] ^ wt ^ wb;
 #elif defined(RAW35_OLD_MATH)
     uint32_t px[12];
     raw35_unit(d0, d1, wt, wb, px, std::make_integer_sequence<int, 12>{});
@@ -322,37 +337,93 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
             const uint4 ow = orow[j];
             const uint32_t w4[4] = {ow.x, ow.y, ow.z, ow.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                cm[4 * j + k] = w4[k] ? 0x00ffffffu : 0u;
-                cv[4 * j + k] = w4[k] ? (((w4[k] - 1u) & 1u) ? a.pal.c[1] : a.pal.c[0]) : 0u;
+            for (int q = 0; q < 4; ++q) {
+                cm[4 * j + q] = w4[q] ? 0x00ffffffu : 0u;
+                cv[4 * j + q] = w4[q] ? (((w4[q] - 1u) & 1u) ? a.pal.c[1] : a.pal.c[0]) : 0u;
             }
         }
         uint32_t V[9], M[9];
         raw35_pack4(cv, V);     raw35_pack4(cv + 4, V + 3); raw35_pack4(cv + 8, V + 6);
         raw35_pack4(cm, M);     raw35_pack4(cm + 4, M + 3); raw35_pack4(cm + 8, M + 6);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) o[k] = (o[k] & ~M[k]) | V[k];
+        for (int j = 0; j < 9; ++j) o[j] = (o[j] & ~M[j]) | V[j];
     }
-    __syncthreads();                                                   // every unit has read its taps: staging is dead
+    lds_barrier();                                                     // every unit has read its taps: staging is dead
 #ifndef RAW35_ABL_COPYONLY                                             // (ablation: the staged bytes go out as they are)
     if (active) {
-        uint32_t *dst = s_stage + row * row_dwords + u * 9u;           // R * row_dwords <= staging size (host-checked)
+        uint32_t *dst = s_stage + row * t.row_dwords + u * 9u;         // R * row_dwords <= staging size (host-checked)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dst[k] = o[k];
+        for (int j = 0; j < 9; ++j) dst[j] = o[j];
     }
-    __syncthreads();
+    lds_barrier();
 #endif
     uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
                      ((size_t)(c / cols) * a.H + y0) * a.mosaic_row_bytes + (size_t)(c % cols) * W * 3 + (size_t)x_first * 3;
-    const uint32_t cpr = row_dwords >> 2;                               // 16-byte chunks per destination tile row
+    const uint32_t cpr = t.row_dwords >> 2;                             // 16-byte chunks per destination tile row
     const uint32_t nchunks = (uint32_t)nrows * cpr;
     uint32_t r = threadIdx.x / cpr, col = threadIdx.x - r * cpr;        // one division, then (row, chunk) advance by blockDim
     const uint32_t dr = blockDim.x / cpr, dc = blockDim.x - dr * cpr;
     for (uint32_t idx = threadIdx.x; idx < nchunks; idx += blockDim.x) {
-        const u32x4 w = reinterpret_cast<const u32x4 *>(s_stage + r * row_dwords)[col];
+        const u32x4 w = reinterpret_cast<const u32x4 *>(s_stage + r * t.row_dwords)[col];
         OVERLAY_STORE(w, reinterpret_cast<u32x4 *>(dcell + (size_t)r * a.mosaic_row_bytes) + col);
         r += dr;
         col += dc;
         if (col >= cpr) { col -= cpr; ++r; }
+    }
+    if (more_follows) lds_barrier();                                   // the next band overwrites the staging area
+}
+
+// bands_per_wg = 1: one band (x one column tile) per workgroup, items = F * camera rows * cols * NB * TX.
+// bands_per_wg = 2 (round 3): a workgroup renders bands 2p and 2p + 1 of one camera and issues the second band's source loads
+// right after the first band is in LDS, so they fly during the first band's blend, transpose and stores:
+// items = F * camera rows * cols * ceil(NB / 2) * TX, nbx_magic = ceil(2^32 / ceil(NB / 2)).
+template <int bands_per_wg>
+__global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a, const uint2 *__restrict__ vrows,
+                                                                   const int2 *__restrict__ band_rows, int upr,
+                                                                   int max_src_rows, int owner_off, int TX,
+                                                                   uint32_t tx_magic, uint32_t cpt_magic, uint32_t nbx_magic)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    // same item order as k_overlay -- (frame, mosaic row of cameras, band [pair], camera column), column tile innermost -- and
+    // the same workgroup -> item mapping (overlay_kernels.hpp: xcd_contiguous_item)
+    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C, camrows = (C + cols - 1u) / cols;
+    const uint32_t NBx = bands_per_wg == 2 ? (NB + 1u) >> 1 : NB;
+    uint32_t item;
+    if (!xcd_contiguous_item(a.items, a.chunk_log2, item)) return;
+    uint32_t tx = 0, cc, bx, cr;
+    const uint32_t q0 = TX == 1 ? item : divmod_magic(item, (uint32_t)TX, tx_magic, tx);
+    const uint32_t q1 = divmod_magic(q0, cols, a.cols_magic, cc);
+    const uint32_t q2 = divmod_magic(q1, NBx, nbx_magic, bx);
+    const uint32_t f = divmod_magic(q2, camrows, a.cr_magic, cr);
+    const uint32_t c = cr * cols + cc;
+    if (c >= C) return;
+    (void)max_src_rows;
+    Raw35Tile t;
+    t.upr = upr; t.Wt = upr * 12; t.x_first = (int)tx * t.Wt; t.W0 = a.W0; t.owner_off = owner_off;
+    t.row_dwords = (uint32_t)upr * 9u;                                  // destination dwords per tile row (multiple of 4)
+    t.src_row_dwords = (uint32_t)upr * 15u;                             // source dwords per tile row (multiple of 4)
+    t.src_pitch16 = (uint32_t)a.W0 * 3u / 16u;                          // 16-byte chunks per raw row (W0*3 % 16 == 0)
+    t.cpt = t.src_row_dwords >> 2; t.cpt_magic = cpt_magic; t.tx = tx;
+    uint32_t *s_stage = s_dyn;                                          // [max_src_rows * src_row_dwords], later the output
+    constexpr int U = RAW35_STAGE_UNROLL;
+    if constexpr (bands_per_wg != 2) {
+        Raw35Band k;
+        u32x4 v[U];
+        raw35_issue<U>(a, band_rows, t, f, c, bx, k, v);
+        raw35_stage<U>(t, k, v, s_stage);
+        raw35_finish(a, vrows, t, f, c, k, s_stage, false);
+    } else {
+    const uint32_t b0 = 2u * bx, b1 = b0 + 1u;
+    const bool two = b1 < NB;
+    Raw35Band kA, kB;
+    u32x4 vA[U], vB[U];
+    raw35_issue<U>(a, band_rows, t, f, c, b0, kA, vA);
+    raw35_stage<U>(t, kA, vA, s_stage);
+    if (two) raw35_issue<U>(a, band_rows, t, f, c, b1, kB, vB);       // in flight during the first band's finish
+    raw35_finish(a, vrows, t, f, c, kA, s_stage, two);
+    if (two) {
+        raw35_stage<U>(t, kB, vB, s_stage);
+        raw35_finish(a, vrows, t, f, c, kB, s_stage, false);
+    }
     }
 }
