@@ -642,7 +642,19 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     Disc disc;
     if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
     // (A/B knob: CAMA_OVERLAY_LDS_PAD=bytes inflates the allocation, i.e. lowers the overlay's workgroups per CU)
-    static const size_t lds_pad = getenv("CAMA_OVERLAY_LDS_PAD") ? (size_t)atol(getenv("CAMA_OVERLAY_LDS_PAD")) : 0;
+    // The binning chain of the NEXT launch runs beside every overlay; an overlay that fills the CU's LDS (6 workgroups of
+    // 25.6 KB at W = 1600) leaves that chain one workgroup per CU, and on maps whose chain takes hundreds of microseconds the
+    // two then barely overlap.  So the overlay asks for a little more LDS than it needs -- just enough that ONE workgroup
+    // fewer fits a CU: site maps of 1e6 / 2e6 / 4e6 vertices 104 -> 114 / 99 -> 108 / 72 -> 84 k frames/s, dense lanes 1e6
+    // 54.4 -> 55.9 k, 1e5 lanes +1.5 %, the headline, the 73-scene sweep, 960x540 and the random 1e6 maps unchanged (within
+    // run-to-run noise).  CAMA_OVERLAY_LDS_PAD=bytes overrides (0 = never), for A/B.
+    static const long lds_pad_env = getenv("CAMA_OVERLAY_LDS_PAD") ? atol(getenv("CAMA_OVERLAY_LDS_PAD")) : -1;
+    size_t lds_pad = lds_pad_env >= 0 ? (size_t)lds_pad_env : 0;
+    if (lds_pad_env < 0) {
+        const size_t lds0 = align_up((size_t)L.R * (W + 2 * radius) * 4, 16), cu_lds = 160 * 1024;
+        const size_t fit = cu_lds / lds0;
+        if (fit >= 4 && fit <= 16) lds_pad = align_up(cu_lds / fit + 16 - lds0, 16);   // smallest size of which fit - 1 fit a CU
+    }
     // k_overlay's owner table carries `radius` spare cells on either side of every row (rasterise_one_padded: 4-bit half
     // widths of 8 rows in one register => radius <= 7 on this path; the generic cama_stamp_points has no such limit)
     if (radius > 7) return fail(CAMA_EINVAL, "radius %d: the fused overlay supports radius <= 7", radius);
