@@ -250,18 +250,6 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
     const uint32_t n = a.counts[bin];
 #endif
 
-#ifdef OVERLAY_SRC_FIRST
-    // (A/B: the source loads go out before anything that depends on the band's stamp count)
-    const uint8_t *sband0 = a.src + ((size_t)fcl * a.H + y0) * (size_t)W * 3;
-    const u32x4 *s16_0 = reinterpret_cast<const u32x4 *>(sband0);
-    const uint32_t nchunks0 = (uint32_t)nrows * a.cpr;
-    u32x4 v[OVERLAY_UNROLL];
-    if (VEC && !RESAMPLE) {
-#pragma unroll
-        for (int j = 0; j < OVERLAY_UNROLL; ++j) v[j] = OVERLAY_LOAD(s16_0 + min(threadIdx.x + j * OVERLAY_BLOCK, nchunks0 - 1u));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     // A stamped band fetches this thread's first stamp record and THEN issues its (first, normally only) batch of
     // 16-byte source loads, all before clearing / rasterising: the source chunks do not depend on the owner table, so
     // their HBM latency runs under the LDS work, and the stamp record -- issued first, VMEM returns in order -- can
@@ -278,7 +266,6 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
     constexpr int U = OVERLAY_UNROLL;
     const u32x4 *s16 = reinterpret_cast<const u32x4 *>(sband);
     const uint32_t nchunks = (uint32_t)nrows * a.cpr;
-#ifndef OVERLAY_SRC_FIRST
     u32x4 v[U];
     if (VEC && !RESAMPLE) {
         // unconditional (index clamped to the band's last chunk): loads under a divergent branch are waited for at
@@ -286,7 +273,7 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
 #pragma unroll
         for (int j = 0; j < U; ++j) v[j] = OVERLAY_LOAD(s16 + min(threadIdx.x + j * OVERLAY_BLOCK, nchunks - 1u));
     }
-#endif
+    // (issuing these loads BEFORE the count / offset / record chain was measured: 0.753 against 0.768 on the headline)
 
     // owner table: rows of Wp = W + 2 * radius cells, pixel x at cell x + radius (see rasterise_one_padded)
     const int rad = a.disc.radius, Wp = W + 2 * rad;
