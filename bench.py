@@ -27,7 +27,8 @@ Verification (untimed, BEFORE the timed region): every scene is rendered once on
 (shard.overlay_hash); the per-SCENE hashes travel in the job's single all_gather (RCCL) next to the metrics and rank 0
 compares them with tests/golden/scene_hashes.json -- the hashes of the ORACLE's render of the same scenes
 (tests/golden/gen_scene_hashes.py, CPU) -- so a wrong shard, a scene rendered twice or not at all, or wrong pixels
-cannot print a number: the run fails instead.
+cannot print a number: the run fails instead.  After the timed region every rank also hashes what the timed path itself
+left in its output buffers and compares it with those verified hashes (exit 3 on a difference).
 
 Extra objects in the JSON line:
   roofline      dominant kernel = k_overlay, HBM-bound.  achieved = the bytes THAT kernel moves per launch -- every
@@ -515,6 +516,26 @@ class Job:
                         out.append((f,) + shard.overlay_hash(self.out[f - self.lo]))
         return out
 
+    def timed_output_hashes(self, sample_frames=None):
+        """Hashes of what the LAST timed step left in its output buffers (same units as scene_hashes): the timed path --
+        pipelined, multi-scene chains -- must have produced the bytes the plain path produced before the timed region.
+        Only scenes whose mosaic is still there are reported (several scenes sharing one buffer: the last one)."""
+        import torch
+        from cama_amd import shard
+        torch.cuda.synchronize(self.device)
+        out = []
+        if not self.scenes or not self.F:
+            return out
+        if self.frame_range is not None:
+            for f in sample_frames or []:
+                if self.lo <= f < self.hi:
+                    out.append((f,) + shard.overlay_hash(self.out[f - self.lo]))
+            return out
+        bufs = self.outs if self.batched else self.own_outs
+        if bufs:
+            return [(sid,) + shard.overlay_hash(bufs[k]) for k, (sid, _, _, _) in enumerate(self.scenes)]
+        return [(self.scenes[-1][0],) + shard.overlay_hash(self.out)]
+
     def frames_per_launch(self):
         if not self.scenes or not self.F:
             return 0.0
@@ -639,6 +660,14 @@ def main():
     hashes = [] if args.no_verify else job.scene_hashes(samples)
     dt, ov_ms, ov_n = job.run(args.steps, args.warmup, sync_all, prof_every)
     N, F = job.N, job.F
+    if not args.no_verify and args.steps > 0:
+        # the bytes the timed path wrote must be the bytes that were verified before it (plain path): compared on this rank
+        want = {u: (lo, hi) for u, lo, hi in hashes}
+        bad = [u for u, lo, hi in job.timed_output_hashes(samples) if want.get(u) != (lo, hi)]
+        if bad:
+            print(f"bench.py: rank {rank}: the timed path's output differs from the verified render for units {bad}",
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
     sus_steps, sus_dt = job.sustain(args.sustain_seconds, args.steps, dt)
     vbytes, sbytes, bin_stats = job.projection_bytes()
     metrics = [float(F * args.steps * len(job.scenes)), dt, ov_ms, float(ov_n), float(N),
@@ -666,6 +695,13 @@ def main():
         s_samples = stress_sample_frames(sargs.frames)
         s_hashes = [] if args.no_verify else sjob.scene_hashes(s_samples)
         sdt, sov_ms, sov_n = sjob.run(s_steps, s_warm, sync_all, prof_every)
+        if not args.no_verify:
+            want = {u: (lo, hi) for u, lo, hi in s_hashes}
+            bad = [u for u, lo, hi in sjob.timed_output_hashes(s_samples) if want.get(u) != (lo, hi)]
+            if bad:
+                print(f"bench.py: rank {rank}: stress: timed output differs from the verified render for frames {bad}",
+                      file=sys.stderr, flush=True)
+                sys.exit(3)
         s_vb, s_sb, _ = sjob.projection_bytes()
         s_metrics = [float(sjob.F * s_steps), sdt, sov_ms, float(sov_n), float(sjob.N),
                      float(s_steps) * shard.scene_cost(sjob.F, sjob.N, W, H), sjob.frames_per_launch(), float(s_steps),
