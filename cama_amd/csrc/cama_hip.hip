@@ -643,11 +643,11 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
     // (A/B knob: CAMA_OVERLAY_LDS_PAD=bytes inflates the allocation, i.e. lowers the overlay's workgroups per CU)
     // The binning chain of the NEXT launch runs beside every overlay; an overlay that fills the CU's LDS (6 workgroups of
-    // 25.6 KB at W = 1600) leaves that chain one workgroup per CU, and on maps whose chain takes hundreds of microseconds the
-    // two then barely overlap.  So the overlay asks for a little more LDS than it needs -- just enough that ONE workgroup
-    // fewer fits a CU: site maps of 1e6 / 2e6 / 4e6 vertices 104 -> 114 / 99 -> 108 / 72 -> 84 k frames/s, dense lanes 1e6
-    // 54.4 -> 55.9 k, 1e5 lanes +1.5 %, the headline, the 73-scene sweep, 960x540 and the random 1e6 maps unchanged (within
-    // run-to-run noise).  CAMA_OVERLAY_LDS_PAD=bytes overrides (0 = never), for A/B.
+    // 25.6 KB at W = 1600) leaves that chain one workgroup per CU.  So the overlay asks for a little more LDS than it needs --
+    // just enough that ONE workgroup fewer fits a CU.  Alternating A/B runs on one box, 3 each, frames/s (sustained):
+    // site map of 4e6 vertices 74.0 (76.1) -> 80.3 (84.4) k, site 1e6 106.6 (110.3) -> 107.1 (111.0) k, headline 108.3 (111.7)
+    // -> 109.9 (113.2) k; 73-scene sweep, 960x540, random 1e6 within noise.  It pays where the chain is long (hundreds of
+    // microseconds) and costs nothing elsewhere.  CAMA_OVERLAY_LDS_PAD=bytes overrides (0 = never), for A/B.
     static const long lds_pad_env = getenv("CAMA_OVERLAY_LDS_PAD") ? atol(getenv("CAMA_OVERLAY_LDS_PAD")) : -1;
     size_t lds_pad = lds_pad_env >= 0 ? (size_t)lds_pad_env : 0;
     if (lds_pad_env < 0) {
