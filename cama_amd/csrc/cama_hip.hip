@@ -167,6 +167,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct ScratchLayout {
     size_t counts, cursor, work_count, seg_cnt, bin_off, fc_total, fc_base, cam_mask, cam_fn, stamps0, stamps, work, list_cap, total;
+    size_t frame_box, cand;        // candidate pre-pass of site-sized maps: [F][6] world crop AABBs, [F * vblocks] items
     size_t zero_bytes;              // counts .. seg_cnt: cleared by one memset before the projection pass
     uint64_t capacity;
     uint32_t nseg;
@@ -197,9 +198,16 @@ int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLay
     // work lists of the crop cull: 8 (one per XCD), each up to ceil(vblocks / 8) * F uint32 items
     L.list_cap = (size_t)(((N + BLOCK - 1) / BLOCK + 7) / 8) * (size_t)F;
     L.work = off;     off = align_up(off + 8 * L.list_cap * 4, 256);
+    // candidate pre-pass (k_block_candidates): per-frame world-space crop AABBs and the 8 (block, frame) candidate lists;
+    // their counters are words CAND_COUNT_WORD .. +7 of the work_count block (cleared by the same memset), word +8 the
+    // "candidate pre-pass ran" mark
+    L.frame_box = off; off = align_up(off + (size_t)F * 6 * 8, 256);
+    L.cand = off;     off = align_up(off + 8 * L.list_cap * 4, 256);             // 8 lists, like the work lists
     L.total = off;
     return 0;
 }
+
+constexpr int CAND_COUNT_WORD = 8;     // work_count[0..7] = the 8 work lists' lengths
 
 // (block, frame) items from which the crop cull goes through a work list + persistent workgroups; and how many of those
 // workgroups (256 CUs x 8 resident).  Env overrides are for A/B measurements only.
@@ -505,9 +513,20 @@ static int bin_impl(const SceneRef *scenes_dev, int frames_per_scene, const void
         const uint32_t nsub = (uint32_t)((N + 63) / 64);
         const dim3 cgrid((4 * vblocks + BLOCK - 1) / BLOCK, (unsigned)F);
         double *cam_fn = (double *)(base + L.cam_fn);
-        hipLaunchKernelGGL(k_camera_functionals, dim3(1), dim3(CAMA_MAX_CAMERAS * 20 <= 256 ? 256 : 512), 0, s, c2cam, K, C, W, H,
-                           cam_fn);
-        if (use_list)
+        // site-sized maps: a six-comparison world-space test first, the exact tests on the compacted candidates only
+        const bool use_cand = use_list && !getenv("CAMA_NO_CANDIDATES");
+        double *frame_box = (double *)(base + L.frame_box);
+        const unsigned fn_threads = CAMA_MAX_CAMERAS * 20 <= 256 ? 256 : 512;
+        hipLaunchKernelGGL(k_camera_functionals, dim3(use_cand ? 1 + ((unsigned)F + fn_threads - 1) / fn_threads : 1),
+                           dim3(fn_threads), 0, s, c2cam, K, C, W, H, cam_fn, w2c, (uint32_t)F, cr, frame_box);
+        if (use_cand) {
+            uint32_t *cand_count = work_count + CAND_COUNT_WORD, *cand = (uint32_t *)(base + L.cand);
+            const dim3 kgrid(cgrid.x, ((unsigned)F + CAND_FRAMES - 1) / CAND_FRAMES);
+            hipLaunchKernelGGL(k_block_candidates, kgrid, dim3(BLOCK), 0, s, block_bounds, frame_box, (uint32_t)F, vblocks, nsub,
+                               (uint32_t)L.list_cap, cand_count, cand);
+            hipLaunchKernelGGL(k_candidate_cameras, lgrid, dim3(BLOCK), 0, s, block_bounds, w2c, cam_fn, C, cr, vblocks, nsub,
+                               cand_count, cand, cam_mask, (uint32_t)L.list_cap, work_count, work);
+        } else if (use_list)
             hipLaunchKernelGGL(k_block_cameras<true>, cgrid, dim3(BLOCK), 0, s, block_bounds, w2c, cam_fn, C, cr, vblocks, nsub,
                                cam_mask, (uint32_t)L.list_cap, work_count, work);
         else
@@ -517,7 +536,14 @@ static int bin_impl(const SceneRef *scenes_dev, int frames_per_scene, const void
         a.cam_mask = (const uint64_t *)cam_mask;
         a.vblocks = vblocks;
 #ifdef ABL_MASK_STATS
-        {
+        if (use_cand) {
+            uint32_t wc[16];
+            hipStreamSynchronize(s);
+            hipMemcpy(wc, work_count, sizeof(wc), hipMemcpyDeviceToHost);
+            uint32_t listed = 0, cands = 0;
+            for (int l = 0; l < 8; ++l) listed += wc[l], cands += wc[CAND_COUNT_WORD + l];
+            fprintf(stderr, "[cand stats] %u (block, frame) items: %u candidates, %u listed\n", vblocks * F, cands, listed);
+        } else {
             std::vector<uint64_t> hm((size_t)vblocks * F);
             hipStreamSynchronize(s);
             hipMemcpy(hm.data(), (const void *)cam_mask, hm.size() * 8, hipMemcpyDeviceToHost);
@@ -599,10 +625,24 @@ int cama_bin_stats(const void *scratch, size_t scratch_bytes, int64_t N, int32_t
     if (had_block_bounds && N && !getenv("CAMA_NO_CAM_MASK")) {
         std::vector<uint64_t> hm((size_t)vblocks * F);
         HIP_TRY(hipMemcpy(hm.data(), base + L.cam_mask, hm.size() * 8, hipMemcpyDeviceToHost));
-        for (uint64_t m : hm) {
+        uint32_t wc[32];
+        HIP_TRY(hipMemcpy(wc, base + L.work_count, sizeof(wc), hipMemcpyDeviceToHost));
+        const auto add = [&](uint64_t m) {
             for (int w = 0; w < 4; ++w) out[0] += ((m >> (16 * w)) & 0xffffull) != 0;
             out[1] += (uint64_t)__builtin_popcountll(m);
-        }
+        };
+        if (wc[CAND_COUNT_WORD + 8]) {
+            // candidate pre-pass: only the listed blocks' masks were written (and are read by the projection)
+            std::vector<uint32_t> items(L.list_cap);
+            for (int l = 0; l < 8; ++l) {
+                const size_t n = wc[l] < L.list_cap ? wc[l] : L.list_cap;
+                if (!n) continue;
+                HIP_TRY(hipMemcpy(items.data(), base + L.work + (size_t)l * L.list_cap * 4, n * 4, hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < n; ++k)
+                    if (items[k] < hm.size()) add(hm[items[k]]);
+            }
+        } else
+            for (uint64_t m : hm) add(m);
     } else {
         out[0] = waves * (uint64_t)F;
         out[1] = waves * (uint64_t)F * (uint64_t)C;

@@ -565,16 +565,190 @@ __device__ __forceinline__ bool box_beyond(const double n0, const double n1, con
     return want_positive ? (v + s + margin < 0.0) : (v - s - margin > 0.0);
 }
 
+// Cameras that may see any vertex of the world AABB (centre w, half extents e) in the frame with world->chassis matrix m.
+__device__ __forceinline__ uint32_t box_cameras(const double *m, const double wx, const double wy, const double wz,
+                                                const double ex, const double ey, const double ez, const Crop &crop,
+                                                const double *fn, const int C)
+{
+    uint32_t mask = 0;
+    double mid[3], rad[3];
+    bool outside = false, finite = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double c0 = m[4 * r], c1 = m[4 * r + 1], c2 = m[4 * r + 2], c3 = m[4 * r + 3];
+        const double ctr = c0 * wx + c1 * wy + c2 * wz + c3;
+        const double rd = fabs(c0) * ex + fabs(c1) * ey + fabs(c2) * ez;
+        const double mag = fabs(c0 * wx) + fabs(c1 * wy) + fabs(c2 * wz) + fabs(c3) + rd;
+        const double margin = 1e-6 + 1e-9 * mag;
+        double lo = ctr - rd - margin, hi = ctr + rd + margin;
+        outside |= (hi < crop.v[2 * r]) | (lo > crop.v[2 * r + 1]);
+        finite &= (lo == lo) & (hi == hi) & (fabs(lo) < 1e300) & (fabs(hi) < 1e300);
+        lo = fmax(lo, crop.v[2 * r]);                   // clip to the crop box: only in-crop vertices are projected
+        hi = fmin(hi, crop.v[2 * r + 1]);
+        mid[r] = 0.5 * (lo + hi);
+        rad[r] = 0.5 * (hi - lo);
+    }
+    if (!finite) {
+        mask = (1u << C) - 1u;                          // NaN / inf anywhere: no claim, keep every camera
+    } else if (!outside) {
+        for (int c = 0; c < C; ++c) {
+            kdouble *P = (kdouble *)(fn + (size_t)c * 20);      // wave-uniform: scalar loads
+            bool gone = box_beyond(P[8], P[9], P[10], P[11], mid, rad, true);                               // h2 > 0
+            gone |= box_beyond(P[0], P[1], P[2], P[3], mid, rad, true);                                     // h0 >= 0
+            gone |= box_beyond(P[4], P[5], P[6], P[7], mid, rad, true);                                     // h1 >= 0
+            gone |= box_beyond(P[12], P[13], P[14], P[15], mid, rad, false);                                // h0 < W h2
+            gone |= box_beyond(P[16], P[17], P[18], P[19], mid, rad, false);                                // h1 < H h2
+            if (!gone) mask |= 1u << c;
+        }
+    }
+    return mask;
+}
+
 // The five functionals of every camera, once per launch: rows h0, h1, h2 of K [R | t], then h0 - W h2, h1 - H h2.
 // fn [C][5][4]; k_block_cameras reads them through scalar loads (as LDS broadcasts they were 120 ds_read_b64 per thread).
+// Workgroup 0 does that; workgroups 1.. (launched only for the candidate pre-pass below) write, per frame, a WORLD-space
+// AABB that contains every point the frame's world->chassis matrix can take into the crop box: the pre-image of the crop
+// box under c = A w + t is A^-1 (crop - t), bounded per world axis by centre +- sum |A^-1| half-extents.  A^-1 is the
+// adjugate over the determinant and is only trusted when A A^-1 = I to 1e-12 (rigid poses give ~1e-16); the margin
+// (1e-6 + 1e-9 of the magnitudes involved) is >= 3 orders above the rounding of the per-vertex chain it must cover.
+// Anything not finite, or a matrix that fails the check: the box is (-inf, +inf), i.e. no claim.
 __global__ void k_camera_functionals(const double *__restrict__ c2cam, const double *__restrict__ K, int C, int W, int H,
-                                     double *__restrict__ fn)
+                                     double *__restrict__ fn, const double *__restrict__ w2c, uint32_t F, Crop crop,
+                                     double *__restrict__ frame_box)
 {
-    if ((int)threadIdx.x >= C * 20) return;
-    const int c = threadIdx.x / 20, i = (threadIdx.x % 20) / 4, j = threadIdx.x % 4;
-    const double *M = c2cam + (size_t)c * 16, *Kc = K + (size_t)c * 9;
-    const auto row = [&](int r) { return Kc[3 * r] * M[j] + Kc[3 * r + 1] * M[4 + j] + Kc[3 * r + 2] * M[8 + j]; };
-    fn[threadIdx.x] = i < 3 ? row(i) : row(i - 3) - (i == 3 ? (double)W : (double)H) * row(2);
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x >= C * 20) return;
+        const int c = threadIdx.x / 20, i = (threadIdx.x % 20) / 4, j = threadIdx.x % 4;
+        const double *M = c2cam + (size_t)c * 16, *Kc = K + (size_t)c * 9;
+        const auto row = [&](int r) { return Kc[3 * r] * M[j] + Kc[3 * r + 1] * M[4 + j] + Kc[3 * r + 2] * M[8 + j]; };
+        fn[threadIdx.x] = i < 3 ? row(i) : row(i - 3) - (i == 3 ? (double)W : (double)H) * row(2);
+        return;
+    }
+    const uint32_t f = (blockIdx.x - 1u) * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const double *m = w2c + (size_t)f * 16;
+    double a[3][3], t[3], inv[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        a[r][0] = m[4 * r]; a[r][1] = m[4 * r + 1]; a[r][2] = m[4 * r + 2]; t[r] = m[4 * r + 3];
+    }
+    // inv = adj(A) / det
+    inv[0][0] = a[1][1] * a[2][2] - a[1][2] * a[2][1];
+    inv[0][1] = a[0][2] * a[2][1] - a[0][1] * a[2][2];
+    inv[0][2] = a[0][1] * a[1][2] - a[0][2] * a[1][1];
+    inv[1][0] = a[1][2] * a[2][0] - a[1][0] * a[2][2];
+    inv[1][1] = a[0][0] * a[2][2] - a[0][2] * a[2][0];
+    inv[1][2] = a[0][2] * a[1][0] - a[0][0] * a[1][2];
+    inv[2][0] = a[1][0] * a[2][1] - a[1][1] * a[2][0];
+    inv[2][1] = a[0][1] * a[2][0] - a[0][0] * a[2][1];
+    inv[2][2] = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+    const double det = a[0][0] * inv[0][0] + a[0][1] * inv[1][0] + a[0][2] * inv[2][0];
+    bool ok = fabs(det) > 0.0 && fabs(det) < 1e300;                           // false on NaN
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) inv[i][j] /= det;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double r = a[i][0] * inv[0][j] + a[i][1] * inv[1][j] + a[i][2] * inv[2][j] - (i == j ? 1.0 : 0.0);
+            ok &= fabs(r) <= 1e-12;
+        }
+    double cc[3], ch[3], cm[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double lo = crop.v[2 * r], hi = crop.v[2 * r + 1];
+        ok &= (fabs(lo) < 1e300) & (fabs(hi) < 1e300);
+        const double mid = 0.5 * (lo + hi);
+        cc[r] = mid - t[r];
+        ch[r] = fmax(0.5 * (hi - lo), 0.0);
+        cm[r] = fabs(mid) + fabs(t[r]) + ch[r];
+    }
+    const double inf = __builtin_huge_val();
+    double box[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double wc = inv[i][0] * cc[0] + inv[i][1] * cc[1] + inv[i][2] * cc[2];
+        const double wh = fabs(inv[i][0]) * ch[0] + fabs(inv[i][1]) * ch[1] + fabs(inv[i][2]) * ch[2];
+        const double mag = fabs(inv[i][0]) * cm[0] + fabs(inv[i][1]) * cm[1] + fabs(inv[i][2]) * cm[2];
+        const double margin = 1e-6 + 1e-9 * mag;
+        box[2 * i] = wc - wh - margin;
+        box[2 * i + 1] = wc + wh + margin;
+        ok &= (fabs(box[2 * i]) < 1e300) & (fabs(box[2 * i + 1]) < 1e300);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        frame_box[(size_t)f * 6 + 2 * i] = ok ? box[2 * i] : -inf;
+        frame_box[(size_t)f * 6 + 2 * i + 1] = ok ? box[2 * i + 1] : inf;
+    }
+}
+
+// Candidate pre-pass of site-sized maps (CAMA_BIN_WORKLIST).  k_block_cameras<true> below appends its survivors with one
+// global atomic per (wave, work list), and returning atomics on one address retire at ~1 per 18 ns on this part: 23 k
+// surviving (block, frame) items of a 4e6-vertex site map x 40 frames = 66 us of atomics around 5 us of arithmetic (the same
+// kernel with the tests compiled out: 5.3 us), ~107 us beside an overlay.  So the map is first cut down with a test that
+// costs six comparisons per (box, frame) -- box vs the frame's WORLD-space crop AABB (k_camera_functionals) -- by
+// workgroups that loop over the frames (one bit per frame and box), and reserve list space ONCE (8 atomics per workgroup,
+// a few hundred per launch); the exact tests then run on full waves of candidates only (k_candidate_cameras).
+// Candidate (block b, frame f) goes to list b % 8, like the work lists.
+// grid (ceil(4 * vblocks / BLOCK), ceil(F / CAND_FRAMES)); thread = box, looping over the frames of its chunk
+constexpr int CAND_FRAMES = 64;
+__global__ __launch_bounds__(BLOCK) void k_block_candidates(const double *__restrict__ bounds, const double *__restrict__ frame_box,
+                                                            uint32_t F, uint32_t vblocks, uint32_t nsub, uint32_t list_cap,
+                                                            uint32_t *__restrict__ cand_count, uint32_t *__restrict__ cand)
+{
+    __shared__ double s_fb[CAND_FRAMES * 6];
+    __shared__ uint32_t s_cnt[BLOCK / 4], s_at[BLOCK / 4];      // per vertex block of this workgroup ("column")
+    static_assert(CAND_FRAMES <= 64, "one bit per frame of the chunk");
+    const uint32_t sb = blockIdx.x * BLOCK + threadIdx.x, b = sb >> 2, lane = __lane_id();
+    const uint32_t f0 = blockIdx.y * (uint32_t)CAND_FRAMES, nf = min((uint32_t)CAND_FRAMES, F - f0);
+    if (sb == 0 && f0 == 0) cand_count[8] = 1u;     // "cam_mask is only valid for the listed blocks" (cama_bin_stats)
+    for (uint32_t t = threadIdx.x; t < nf * 6u; t += BLOCK) s_fb[t] = frame_box[(size_t)f0 * 6 + t];
+    double bx[6] = {0, 0, 0, 0, 0, 0};
+    const bool real = sb < nsub;
+    if (real) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bx[j] = bounds[(size_t)sb * 6 + j];
+    }
+    __syncthreads();
+    // bit k = this box may reach into the crop box of frame f0 + k
+    uint64_t bits = 0;
+#pragma unroll 4
+    for (uint32_t k = 0; k < nf; ++k) {
+        const double *fb = s_fb + k * 6;            // LDS broadcast
+        // every comparison is false on NaN: a box with a NaN bound stays a candidate
+        const bool in = !((bx[1] < fb[0]) | (bx[0] > fb[1]) | (bx[3] < fb[2]) | (bx[2] > fb[3]) | (bx[5] < fb[4]) |
+                          (bx[4] > fb[5]));
+        bits |= (uint64_t)in << k;
+    }
+    if (!real) bits = 0;
+    // a block is a candidate if any of its four boxes (adjacent lanes) is; its first lane owns it
+    uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+    lo |= (uint32_t)__shfl_xor((int)lo, 1, 64); hi |= (uint32_t)__shfl_xor((int)hi, 1, 64);
+    lo |= (uint32_t)__shfl_xor((int)lo, 2, 64); hi |= (uint32_t)__shfl_xor((int)hi, 2, 64);
+    bits = ((lane & 3u) == 0u && b < vblocks) ? ((uint64_t)hi << 32 | lo) : 0ull;
+    const uint32_t col = threadIdx.x >> 2, n = (uint32_t)__popcll(bits);
+    if ((lane & 3u) == 0u) s_cnt[col] = n;
+    __syncthreads();
+    // list l = the columns with col % 8 == l (the workgroup's first block is a multiple of 64): thread l reserves for them
+    if (threadIdx.x < 8u) {
+        uint32_t tot = 0;
+        for (uint32_t c = threadIdx.x; c < BLOCK / 4; c += 8u) tot += s_cnt[c];
+        uint32_t at = tot ? atomicAdd(&cand_count[threadIdx.x], tot) : 0u;
+        for (uint32_t c = threadIdx.x; c < BLOCK / 4; c += 8u) {
+            s_at[c] = at;
+            at += s_cnt[c];
+        }
+    }
+    __syncthreads();
+    if (!n) return;
+    uint32_t *dst = cand + (size_t)(col & 7u) * list_cap + s_at[col];
+    while (bits) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(bits);
+        bits &= bits - 1ull;
+        *dst++ = (f0 + k) * vblocks + b;
+    }
 }
 
 // grid (ceil(4 * vblocks / BLOCK), F): one thread per (box, frame); the four boxes of a vertex block sit in adjacent lanes.
@@ -591,36 +765,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_cameras(const double *__restric
         const double *m = w2c + (size_t)f * 16, *bx = bounds + (size_t)sb * 6;
         const double wx = 0.5 * (bx[0] + bx[1]), wy = 0.5 * (bx[2] + bx[3]), wz = 0.5 * (bx[4] + bx[5]);
         const double ex = 0.5 * (bx[1] - bx[0]), ey = 0.5 * (bx[3] - bx[2]), ez = 0.5 * (bx[5] - bx[4]);
-        double mid[3], rad[3];
-        bool outside = false, finite = true;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double c0 = m[4 * r], c1 = m[4 * r + 1], c2 = m[4 * r + 2], c3 = m[4 * r + 3];
-            const double ctr = c0 * wx + c1 * wy + c2 * wz + c3;
-            const double rd = fabs(c0) * ex + fabs(c1) * ey + fabs(c2) * ez;
-            const double mag = fabs(c0 * wx) + fabs(c1 * wy) + fabs(c2 * wz) + fabs(c3) + rd;
-            const double margin = 1e-6 + 1e-9 * mag;
-            double lo = ctr - rd - margin, hi = ctr + rd + margin;
-            outside |= (hi < crop.v[2 * r]) | (lo > crop.v[2 * r + 1]);
-            finite &= (lo == lo) & (hi == hi) & (fabs(lo) < 1e300) & (fabs(hi) < 1e300);
-            lo = fmax(lo, crop.v[2 * r]);                   // clip to the crop box: only in-crop vertices are projected
-            hi = fmin(hi, crop.v[2 * r + 1]);
-            mid[r] = 0.5 * (lo + hi);
-            rad[r] = 0.5 * (hi - lo);
-        }
-        if (!finite) {
-            mask = (1u << C) - 1u;                          // NaN / inf anywhere: no claim, keep every camera
-        } else if (!outside) {
-            for (int c = 0; c < C; ++c) {
-                kdouble *P = (kdouble *)(fn + (size_t)c * 20);      // wave-uniform: scalar loads
-                bool gone = box_beyond(P[8], P[9], P[10], P[11], mid, rad, true);                               // h2 > 0
-                gone |= box_beyond(P[0], P[1], P[2], P[3], mid, rad, true);                                     // h0 >= 0
-                gone |= box_beyond(P[4], P[5], P[6], P[7], mid, rad, true);                                     // h1 >= 0
-                gone |= box_beyond(P[12], P[13], P[14], P[15], mid, rad, false);                                // h0 < W h2
-                gone |= box_beyond(P[16], P[17], P[18], P[19], mid, rad, false);                                // h1 < H h2
-                if (!gone) mask |= 1u << c;
-            }
-        }
+        mask = box_cameras(m, wx, wy, wz, ex, ey, ez, crop, fn, C);
     }
     // [F, vblocks] x 4 x u16 = the u64 per block the projection reads (boxes past the last vertex: 0)
     if (b < vblocks) cam_mask[((size_t)f * vblocks + b) * 4 + (sb & 3u)] = (uint16_t)mask;
@@ -643,6 +788,57 @@ __global__ __launch_bounds__(BLOCK) void k_block_cameras(const double *__restric
     if (keep) {
         const uint64_t mine = mk & (pair << (4u * l));
         work[(size_t)l * list_cap + base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = f * vblocks + b;
+    }
+}
+
+// The exact tests of k_block_cameras<true> on the candidate lists: workgroup g walks list g % 8 (gridDim.x is a multiple of
+// 8), 64 candidates per iteration, thread 4 i + j = box j of candidate i.  Frames differ between lanes, so the frame's
+// matrix comes through vector loads; the camera functionals stay scalar.  Writes the camera masks of the candidates (the
+// projection reads cam_mask only for listed blocks) and appends the blocks with any camera left to work list g % 8 with ONE
+// atomic per workgroup and iteration.
+__global__ __launch_bounds__(BLOCK) void k_candidate_cameras(const double *__restrict__ bounds, const double *__restrict__ w2c,
+                                                             const double *fn, int C, Crop crop, uint32_t vblocks, uint32_t nsub,
+                                                             const uint32_t *__restrict__ cand_count,
+                                                             const uint32_t *__restrict__ cand, uint16_t *__restrict__ cam_mask,
+                                                             uint32_t list_cap, uint32_t *__restrict__ work_count,
+                                                             uint32_t *__restrict__ work)
+{
+    __shared__ uint32_t s_cnt[2][BLOCK / 64], s_base[2];
+    const uint32_t l = blockIdx.x & 7u, lane = __lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t n = ((const uint32_t __attribute__((address_space(4))) *)cand_count)[l];
+    cand += (size_t)l * list_cap;
+    work += (size_t)l * list_cap;
+    uint32_t par = 0;
+    for (uint32_t i0 = (blockIdx.x >> 3) * (BLOCK / 4); i0 < n; i0 += (gridDim.x >> 3) * (BLOCK / 4), par ^= 1u) {
+        const uint32_t i = i0 + (threadIdx.x >> 2);
+        const bool live = i < n;
+        const uint32_t item = live ? cand[i] : 0u;
+        const uint32_t f = item / vblocks, b = item - f * vblocks, sb = 4u * b + (lane & 3u);
+        uint32_t mask = 0;
+        if (live && sb < nsub) {
+            const double *m = w2c + (size_t)f * 16, *bx = bounds + (size_t)sb * 6;
+            const double wx = 0.5 * (bx[0] + bx[1]), wy = 0.5 * (bx[2] + bx[3]), wz = 0.5 * (bx[4] + bx[5]);
+            const double ex = 0.5 * (bx[1] - bx[0]), ey = 0.5 * (bx[3] - bx[2]), ez = 0.5 * (bx[5] - bx[4]);
+            mask = box_cameras(m, wx, wy, wz, ex, ey, ez, crop, fn, C);
+        }
+        if (live) cam_mask[(size_t)item * 4 + (lane & 3u)] = (uint16_t)mask;
+        uint32_t any = mask | (uint32_t)__shfl_xor((int)mask, 1, 64);
+        any |= (uint32_t)__shfl_xor((int)any, 2, 64);
+        const bool keep = any != 0u && (lane & 3u) == 0u;
+        const uint64_t kk = __ballot(keep);
+        if (lane == 0) s_cnt[par][wave] = (uint32_t)__popcll(kk);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < BLOCK / 64; ++w) tot += s_cnt[par][w];
+            s_base[par] = tot ? atomicAdd(&work_count[l], tot) : 0u;
+        }
+        __syncthreads();
+        // (the buffers of this parity are next written two iterations on, behind the next iteration's barriers)
+        uint32_t at = s_base[par];
+        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[par][w];
+        if (keep) work[at + (uint32_t)__popcll(kk & ((1ull << lane) - 1ull))] = item;
     }
 }
 

@@ -59,6 +59,31 @@ def _case(rng):
         w2c.append(np.linalg.inv(M.astype(np.float32)))
     crop = [-50, 50, -100, 100, -200, 200] if rng.random() < 0.6 else \
         sorted(rng.uniform(-30, 30, 2).tolist()) + sorted(rng.uniform(-30, 30, 2).tolist()) + [-5.0, 5.0]
+    if os.environ.get("CAMA_FUZZ_POSES") == "odd":
+        # world->chassis matrices the candidate pre-pass must not be fooled by (it bounds the crop box's pre-image in world
+        # space through an inverse it has to verify): any heading and tilt, survey-grid offsets, scale + shear, rank 2,
+        # NaN / inf entries, an unbounded crop box
+        mode = str(rng.choice(["tilt", "utm", "affine", "singular", "nan", "open_crop"]))
+        shift = np.zeros(3)
+        if mode == "utm":
+            shift = np.array([4.1e5, 5.3e6, 31.0])
+            xyz = (xyz.astype(np.float64) + shift).astype(np.float64 if f64 else np.float32)
+        w2c = []
+        for f in range(F):
+            M = np.eye(4)
+            M[:3, :3] = Rotation.from_euler("zyx", [rng.uniform(-np.pi, np.pi), rng.normal(0, 0.3), rng.normal(0, 0.3)]).as_matrix()
+            M[:3, 3] = rng.normal(0, 5.0, 3) + shift
+            Wc = np.linalg.inv(M)
+            if mode == "affine":
+                Wc[:3, :] = (np.diag(rng.uniform(0.2, 3.0, 3)) + rng.normal(0, 0.2, (3, 3))) @ Wc[:3, :]
+            elif mode == "singular" and f == 0:
+                Wc[1, :3] = 2.0 * Wc[0, :3]                # rank 2: the whole world maps onto a plane
+            elif mode == "nan" and f == 0:
+                Wc[int(rng.integers(0, 3)), int(rng.integers(0, 4))] = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]
+            w2c.append(Wc)
+        if mode == "open_crop":
+            crop = [-np.inf, 50.0, -100.0, np.inf, -200.0, 200.0]
+        kind = f"{kind}/{mode}"
     return dict(W=W, H=H, C=C, F=F, N=N, radius=radius, xyz=xyz, col=col, cams=cams, w2c=np.stack(w2c), crop=crop,
                 sort=bool(rng.random() < 0.3), kind=str(kind))
 
@@ -66,7 +91,7 @@ def _case(rng):
 def _fuzz_child(extra_env):
     import subprocess
     import sys
-    env = dict(os.environ, CAMA_FUZZ_ITERS=os.environ.get("CAMA_FUZZ_ITERS", "40"), **extra_env)
+    env = dict(os.environ, **dict({"CAMA_FUZZ_ITERS": os.environ.get("CAMA_FUZZ_ITERS", "40")}, **extra_env))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
                         __file__ + "::test_fuzz_against_oracle"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=1200)
@@ -84,6 +109,18 @@ def test_fuzz_work_list_path():
     """... and with CAMA_CULL_LIST_MIN=1 on top: every site-sized map additionally goes through the work lists and the
     persistent k_frames_project_list instead of the grid launch."""
     _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "77"})
+
+
+def test_fuzz_candidate_prepass_odd_poses():
+    """The work-list path again (candidate pre-pass: world-space crop AABB per frame -> candidate lists -> exact tests) with
+    world->chassis matrices that stress the inverse it relies on -- full rotations with tilt, survey-grid translations of
+    5e6 m, scale + shear, a rank-2 matrix, NaN / inf entries -- and a crop box open to infinity.  Bit-exact against the
+    oracle, i.e. the pre-pass never drops a vertex the per-vertex test keeps."""
+    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "505", "CAMA_FUZZ_POSES": "odd",
+                 "CAMA_FUZZ_ITERS": "60"})
+    # and the same cases through the one-kernel pre-pass it replaced (A/B switch): the oracle agrees with both
+    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "505", "CAMA_FUZZ_POSES": "odd",
+                 "CAMA_FUZZ_ITERS": "20", "CAMA_NO_CANDIDATES": "1"})
 
 
 def test_fuzz_several_vertex_blocks_per_workgroup():
