@@ -228,7 +228,7 @@ struct Raw35Tile {
 };
 
 // phase 1: scalar loads (count, list offset, source rows), the band's first stamp record, then the source loads
-template <int U>
+template <int U, bool LOAD = true>
 __device__ __forceinline__ void raw35_issue(const OverlayArgs &a, const int2 *__restrict__ band_rows, const Raw35Tile &t,
                                             const uint32_t f, const uint32_t c, const uint32_t b, Raw35Band &k, u32x4 (&v)[U])
 {
@@ -249,11 +249,13 @@ __device__ __forceinline__ void raw35_issue(const OverlayArgs &a, const int2 *__
     k.nsrc = (uint32_t)k.br.y * t.cpt;
     // chunk idx of the tile = (source row idx / cpt, chunk idx % cpt) (cpt_magic = ceil(2^32 / cpt) from the host: exact for
     // idx < 2^16); one tile per band: pitch == cpt, one contiguous range
+    if constexpr (LOAD) {
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-        const uint32_t idx = min(threadIdx.x + j * blockDim.x, k.nsrc - 1u);
-        const uint32_t r = __umulhi(idx, t.cpt_magic);
-        v[j] = OVERLAY_LOAD(k.g + (size_t)r * t.src_pitch16 + (idx - r * t.cpt));
+        for (int j = 0; j < U; ++j) {
+            const uint32_t idx = min(threadIdx.x + j * blockDim.x, k.nsrc - 1u);
+            const uint32_t r = __umulhi(idx, t.cpt_magic);
+            v[j] = OVERLAY_LOAD(k.g + (size_t)r * t.src_pitch16 + (idx - r * t.cpt));
+        }
     }
 }
 
@@ -408,9 +410,32 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     constexpr int U = RAW35_STAGE_UNROLL;
     if constexpr (bands_per_wg != 2) {
         Raw35Band k;
-        u32x4 v[U];
-        raw35_issue<U>(a, band_rows, t, f, c, bx, k, v);
-        raw35_stage<U>(t, k, v, s_stage);
+#ifndef RAW35_NO_LDS_DIRECT
+        constexpr bool lds_direct = true;
+#else
+        constexpr bool lds_direct = false;
+#endif
+        if (lds_direct && TX == 1) {
+            // source rows straight into LDS (gfx950's global_load_lds_dwordx4: a wave's 64 x 16 bytes land at M0 + 16 lane):
+            // no VGPR staging, no ds_write -- with one tile per band the staged rows are one contiguous range of memory and
+            // keep their layout.  Measured at 960x540 against the register-staged version (-DRAW35_NO_LDS_DIRECT),
+            // alternating, three each on one box: 141.5 -> 143.7 k frames/s with the non-temporal hint, 140.5 k without.
+            u32x4 none[1];
+            raw35_issue<1, false>(a, band_rows, t, f, c, bx, k, none);
+            for (uint32_t base = threadIdx.x & ~63u; base < k.nsrc; base += blockDim.x) {
+                const uint32_t idx = base + (threadIdx.x & 63u);
+                if (idx < k.nsrc)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(k.g + idx),
+                                                     (__attribute__((address_space(3))) void *)(s_stage + base * 4u), 16, 0,
+                                                     2 /* nt */);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0)
+            lds_barrier();
+        } else {
+            u32x4 v[U];
+            raw35_issue<U>(a, band_rows, t, f, c, bx, k, v);
+            raw35_stage<U>(t, k, v, s_stage);
+        }
         raw35_finish(a, vrows, t, f, c, k, s_stage, false);
     } else {
     const uint32_t b0 = 2u * bx, b1 = b0 + 1u;
