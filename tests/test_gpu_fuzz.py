@@ -15,7 +15,7 @@ def _case(rng):
     W = int(rng.choice([16, 48, 64, 100, 160, 272, 333, 640]))
     H = int(rng.integers(9, 150))
     C = int(rng.integers(1, 10))
-    F = int(rng.integers(1, 4))
+    F = int(os.environ.get("CAMA_FUZZ_FRAMES", 0)) or int(rng.integers(1, 4))
     N = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, 3000, 5000, 20000]))
     radius = int(rng.choice([0, 1, 2, 2, 2, 3]))
     f64 = bool(rng.random() < 0.3)
@@ -118,6 +118,9 @@ def test_fuzz_candidate_prepass_odd_poses():
     oracle, i.e. the pre-pass never drops a vertex the per-vertex test keeps."""
     _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "505", "CAMA_FUZZ_POSES": "odd",
                  "CAMA_FUZZ_ITERS": "60"})
+    # launches of 130 frames: the candidate search runs over three frame chunks (64 + 64 + 2) per box
+    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "506", "CAMA_FUZZ_FRAMES": "130",
+                 "CAMA_FUZZ_ITERS": "8"})
     # and the same cases through the one-kernel pre-pass it replaced (A/B switch): the oracle agrees with both
     _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "505", "CAMA_FUZZ_POSES": "odd",
                  "CAMA_FUZZ_ITERS": "20", "CAMA_NO_CANDIDATES": "1"})
