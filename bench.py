@@ -810,6 +810,13 @@ def main():
                                             "over the 8 XCDs (speed only; HW_REG_XCC_ID probe)"}
         except Exception as e:
             line["xcd_dispatch"] = {"error": repr(e)}
+        try:
+            line["overlay_mapping"] = dict(job.eng.overlay_mapping(),
+                                           note="big launches (>= 1.75 GiB): the library times the XCD-contiguous order (31) "
+                                                "against round-robin chunks of 32 bands (5) on this process's first launches and "
+                                                "keeps the faster; -1 = not decided (no big launch, or forced)")
+        except Exception as e:
+            line["overlay_mapping"] = {"error": repr(e)}
         if args.sites > 0:
             line["site_maps"] = {"sites": args.sites, "verts_per_site": N,
                                  "sites_per_rank": shard.sites_per_rank(assignment, site_of),

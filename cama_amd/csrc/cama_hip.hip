@@ -31,6 +31,8 @@
 #include <algorithm>
 #include <utility>
 #include <vector>
+#include <mutex>
+#include <algorithm>
 
 #include "cama_hip.h"
 
@@ -240,13 +242,86 @@ unsigned persistent_workgroups()
 //              640 (33 GB) 0.66 / 0.80          960x540:  40 (0.75 GB) 0.77 / 0.72   80 (1.5 GB) 0.78 / 0.75   160 (3 GB) 0.76 / 0.76
 // -- interleaved is the better order while every XCD can keep the whole launch's pages mapped; beyond ~2 GB per launch an
 // XCD that touches only its own eighth of the pages wins, and the more the longer the launch.
-// CAMA_OVERLAY_CHUNK_LOG2 = 0 | 31 (or 1..30: round-robin chunks of 2^k bands, never better) overrides, for A/B.
-uint32_t overlay_chunk_log2(size_t launch_bytes)
+// Round 3, later: both figures of a column were taken in DIFFERENT processes, and the contiguous order turned out to run in
+// one of three speed modes that is fixed per process (profiles/r03_process_modes.txt: 0.75 / 0.79 / 0.82 at 40 frames, the
+// interleaved order 0.755 in all of them).  Measured inside single processes instead (whole step / 8 TB/s, 8 processes):
+// contiguous 0.70 .. 0.79, interleaved 0.73-0.74 in every one, round-robin chunks of 32 bands 0.74-0.76 in every one.  So:
+//   * launches below 1.75 GiB: chunks of 32 bands (>= the interleaved order wherever measured: 960x540 raw +1 %,
+//     20 frames of 1600x900 +0.7 %);
+//   * launches of 1.75 GiB and more: the process finds out which of {contiguous, chunks of 32} is faster HERE -- the first
+//     launches alternate between the two with their own start / stop events, and once each has two timings the faster
+//     one (per byte) is kept for the life of the process (MapTuner below; cama_overlay_mapping_info() reports it).
+// The mapping is a bijection either way: pixels never depend on it.
+// CAMA_OVERLAY_CHUNK_LOG2 = 0 .. 31 forces one mapping (no tuning), CAMA_OVERLAY_TUNE=0 keeps "contiguous" for big launches.
+constexpr uint32_t MAP_CHUNKED = 5u, MAP_CONTIGUOUS = 31u;
+constexpr size_t MAP_BIG_LAUNCH = (size_t)7 << 28;               // 1.75 GiB
+int overlay_forced_chunk_log2()
 {
     static const int forced = getenv("CAMA_OVERLAY_CHUNK_LOG2") ? atoi(getenv("CAMA_OVERLAY_CHUNK_LOG2")) : -1;
-    if (forced >= 0) return forced > 31 ? 31u : (uint32_t)forced;
-    return launch_bytes >= ((size_t)7 << 28) ? 31u : 0u;         // 1.75 GiB
+    return forced > 31 ? 31 : forced;
 }
+uint32_t overlay_chunk_log2(size_t launch_bytes)
+{
+    const int forced = overlay_forced_chunk_log2();
+    if (forced >= 0) return (uint32_t)forced;
+    return launch_bytes >= MAP_BIG_LAUNCH ? MAP_CONTIGUOUS : MAP_CHUNKED;
+}
+
+// Which mapping do big launches get in this process?  (see above)
+struct MapTrial { uint32_t chunk_log2; hipEvent_t e0, e1; int which; };     // e0 == nullptr: not a trial
+struct MapTuner {
+    std::mutex mu;
+    int decided = -1;                         // -1 = still measuring, else MAP_CONTIGUOUS | MAP_CHUNKED
+    int issued = 0;
+    int done[2] = {0, 0};
+    double best[2] = {1e300, 1e300};          // seconds per byte: [0] contiguous, [1] chunked
+    struct Pending { hipEvent_t e0, e1; int which; double bytes; };
+    std::vector<Pending> pending;
+
+    void poll()
+    {
+        for (size_t k = 0; k < pending.size();) {
+            if (hipEventQuery(pending[k].e1) != hipSuccess) { ++k; continue; }
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pending[k].e0, pending[k].e1) == hipSuccess && ms > 0.f) {
+                best[pending[k].which] = std::min(best[pending[k].which], (double)ms * 1e-3 / pending[k].bytes);
+                ++done[pending[k].which];
+            }
+            (void)hipEventDestroy(pending[k].e0);
+            (void)hipEventDestroy(pending[k].e1);
+            pending[k] = pending.back();
+            pending.pop_back();
+        }
+        (void)hipGetLastError();              // (hipEventQuery's "not ready" is not an error of ours)
+        if (decided < 0 && done[0] >= 2 && done[1] >= 2)
+            decided = best[1] < best[0] * 0.995 ? (int)MAP_CHUNKED : (int)MAP_CONTIGUOUS;
+    }
+    // the mapping for a big launch; trial = true if the caller can give the launch its own start / stop events
+    MapTrial pick(bool can_trial)
+    {
+        static const bool tune = !(getenv("CAMA_OVERLAY_TUNE") && atoi(getenv("CAMA_OVERLAY_TUNE")) == 0);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!tune) return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0};
+        poll();
+        if (decided >= 0) return MapTrial{(uint32_t)decided, nullptr, nullptr, 0};
+        if (!can_trial || issued >= 16) return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0};
+        MapTrial t{MAP_CONTIGUOUS, nullptr, nullptr, issued & 1};
+        if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) {
+            if (t.e0) (void)hipEventDestroy(t.e0);
+            return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0};
+        }
+        t.chunk_log2 = t.which ? MAP_CHUNKED : MAP_CONTIGUOUS;
+        ++issued;
+        return t;
+    }
+    void submitted(const MapTrial &t, double bytes)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        pending.push_back(Pending{t.e0, t.e1, t.which, bytes});
+    }
+};
+MapTuner g_map_tuner;
+
 dim3 overlay_grid(size_t items, uint32_t chunk_log2)
 {
     if (chunk_log2 >= 31u) return dim3((unsigned)((items + 7) / 8 * 8));
@@ -740,6 +815,14 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     const size_t launch_bytes = frames_in_launch * (size_t)C * 3 *
                                 ((raw ? (size_t)raw->H0 * raw->W0 : (size_t)H * W) + (size_t)H * W);
     o.chunk_log2 = overlay_chunk_log2(launch_bytes);
+    // big launches of the plain overlay: the process's own choice between the contiguous and the chunked order, or a trial of
+    // one of them (MapTuner); a launch that is being profiled, or that cannot carry events of its own, just follows
+    const bool plain_vec = !raw && o.pal.alpha256 == 256u && vec;
+    MapTrial trial{o.chunk_log2, nullptr, nullptr, 0};
+    if (launch_bytes >= MAP_BIG_LAUNCH && overlay_forced_chunk_log2() < 0 && plain_vec) {
+        trial = g_map_tuner.pick(!g_prof.on);
+        o.chunk_log2 = trial.chunk_log2;
+    }
     const uint32_t chunk_log2 = o.chunk_log2;
     const auto grid8 = [chunk_log2](size_t items) { return overlay_grid(items, chunk_log2); };
     o.items = nblocks;
@@ -806,11 +889,26 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
             o.f0 = k * frames_per_scene;
             hipEvent_t e0 = (k == 0 && exact_timing && ev0 && ev1) ? ev0 : nullptr;
             hipEvent_t e1 = (k == S - 1) ? ((exact_timing && ev0 && ev1) ? ev1 : g_overlay_stop_event) : nullptr;
+            if (k == 0 && trial.e0 && S > 1) {           // a mapping trial: the first scene's launch, timed on its own
+                e0 = trial.e0;
+                e1 = trial.e1;
+            }
             hipExtLaunchKernelGGL((k_overlay<true, false>), sgrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, e0, e1, 0u, o);
         }
+        if (trial.e0 && S > 1) g_map_tuner.submitted(trial, (double)launch_bytes);
+        else if (trial.e0) { (void)hipEventDestroy(trial.e0); (void)hipEventDestroy(trial.e1); }
         if (!(exact_timing && ev0 && ev1)) g_overlay_stop_event = nullptr;
     } else if (vec) {
-        if (exact_timing && ev0 && ev1) {
+        if (trial.e0) {
+            // a mapping trial: the launch carries the tuner's start / stop events; the pipeline's completion event, which
+            // would have ridden on the launch, is recorded behind it
+            hipExtLaunchKernelGGL((k_overlay<true, false>), ogrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, trial.e0, trial.e1, 0u, o);
+            g_map_tuner.submitted(trial, (double)launch_bytes);
+            if (g_overlay_stop_event) {
+                HIP_TRY(hipEventRecord(g_overlay_stop_event, s));
+                g_overlay_stop_event = nullptr;
+            }
+        } else if (exact_timing && ev0 && ev1) {
             hipExtLaunchKernelGGL((k_overlay<true, false>), ogrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, ev0, ev1, 0u, o);
         } else if (g_overlay_stop_event) {
             hipExtLaunchKernelGGL((k_overlay<true, false>), ogrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, nullptr,
@@ -1465,6 +1563,18 @@ int cama_pipeline_join(cama_pipeline *p, void *stream)
     if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
     // one overlay stream: the newest launch's event covers every earlier one
     if (p->issued) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->done[p->issued % cama_pipeline::RING], 0));
+    return CAMA_OK;
+}
+
+int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per_mb)
+{
+    std::lock_guard<std::mutex> lock(g_map_tuner.mu);
+    g_map_tuner.poll();
+    if (decided) *decided = overlay_forced_chunk_log2() >= 0 ? overlay_forced_chunk_log2() : g_map_tuner.decided;
+    for (int k = 0; k < 2; ++k) {
+        if (samples) samples[k] = g_map_tuner.done[k];
+        if (ns_per_mb) ns_per_mb[k] = g_map_tuner.done[k] ? g_map_tuner.best[k] * 1e15 : 0.0;
+    }
     return CAMA_OK;
 }
 

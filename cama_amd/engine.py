@@ -390,6 +390,17 @@ class Engine:
         periodic = all(len(set(got[k::8].tolist())) == 1 for k in range(8)) and len(set(got[:8].tolist())) == 8
         return bool(periodic), [int(v) for v in got[:8]], np.bincount(got, minlength=8).tolist()
 
+    def overlay_mapping(self):
+        """Which workgroup -> band order this process's big overlay launches use (cama_overlay_mapping_info): dict with
+        decided (-1 while the library is still timing both, else 31 = contiguous per XCD or 5 = round-robin chunks of 32 bands),
+        samples and best ns per 10^6 bytes for [contiguous, chunked]."""
+        import ctypes
+        d = ctypes.c_int32(-1)
+        n = (ctypes.c_int32 * 2)()
+        t = (ctypes.c_double * 2)()
+        _lib.check(self.lib.cama_overlay_mapping_info(ctypes.byref(d), n, t))
+        return {"decided": int(d.value), "samples": [int(n[0]), int(n[1])], "ns_per_mb": [float(t[0]), float(t[1])]}
+
     def bin_stats(self):
         """What the binning half of the LAST render_frames() call read and produced (cama_bin_stats; blocks until the
         stream is idle): dict with frames, vertex_waves_read (64-vertex runs fetched, over all frames), camera_chains,

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 15
+#define CAMA_ABI_VERSION 16
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -338,6 +338,13 @@ int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const fl
  * speed only, the output never depends on it -- and bench.py prints what the box does.
  */
 int cama_probe_xcd_map(uint32_t *xcd_of_block, int32_t n_blocks, void *stream);
+
+/* Which workgroup -> band order do this process's big overlay launches (>= 1.75 GiB touched) use?  The library times the
+ * contiguous order (31) against round-robin chunks of 32 bands (5) on the first such launches and keeps the faster one for
+ * the life of the process (cama_hip.hip: MapTuner; speed only, the pixels never depend on it).  decided: -1 while measuring,
+ * else 31 or 5 (or the value CAMA_OVERLAY_CHUNK_LOG2 forces); samples[2], ns_per_mb[2]: timings taken so far and the
+ * best time per 10^6 bytes, [0] = contiguous, [1] = chunked.  Any pointer may be NULL.  (No reference counterpart.) */
+int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per_mb);
 
 /*
  * Stamp-only overlay for caller-supplied 2D points (the generic CameraManager.render_maps,

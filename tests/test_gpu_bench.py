@@ -84,3 +84,7 @@ def test_bench_default_line_has_every_contract_field():
     cb = line["cpu_baseline"]
     assert cb["cores"] == 1 and cb["value"] > 0
     assert cb["all_cores"]["cores"] == 4 and cb["all_cores"]["value"] > 0
+    # the headline's launches touch 2 GB: by the end of the run the library has timed both workgroup -> band orders on
+    # this process's own launches and settled on one of them
+    om = line["overlay_mapping"]
+    assert om["decided"] in (5, 31) and min(om["samples"]) >= 2 and min(om["ns_per_mb"]) > 0, om

@@ -530,10 +530,11 @@ def test_alpha_extension_matches_own_restatement():
 
 @pytest.mark.parametrize("chunk_log2", ["0", "3", "31"])
 def test_every_workgroup_to_band_mapping_renders_the_same_bytes(chunk_log2, repo_root):
-    """The overlay kernels choose per launch between the interleaved and the XCD-contiguous workgroup -> band mapping (by
-    the bytes a launch touches); small test scenes only ever see the interleaved one.  Force each mapping (and a chunked
-    one) in a subprocess -- the knob is read once per process -- and run the oracle-parity tests of this file and the raw
-    overlay families under it: ragged camera rows, odd widths, several radii, stamped and unstamped bands."""
+    """The overlay kernels choose per launch between workgroup -> band mappings (round-robin chunks of 32 bands for small
+    launches -- what the rest of this suite runs under --, and for big ones whichever of "contiguous per XCD" and the chunks
+    the process's own timings favour).  Force the interleaved, another chunked and the contiguous mapping in a subprocess --
+    the knob is read once per process -- and run the oracle-parity tests of this file and the raw overlay families under
+    each: ragged camera rows, odd widths, several radii, stamped and unstamped bands."""
     import os
     import subprocess
     import sys
