@@ -257,7 +257,11 @@ constexpr uint32_t MAP_CHUNKED = 5u, MAP_CONTIGUOUS = 31u;
 constexpr size_t MAP_BIG_LAUNCH = (size_t)7 << 28;               // 1.75 GiB
 int overlay_forced_chunk_log2()
 {
+#ifdef OVERLAY_MAP_SWITCH                 // A/B build for tools/map_modes.py: the knob is re-read at every launch
+    const int forced = getenv("CAMA_OVERLAY_CHUNK_LOG2") ? atoi(getenv("CAMA_OVERLAY_CHUNK_LOG2")) : -1;
+#else
     static const int forced = getenv("CAMA_OVERLAY_CHUNK_LOG2") ? atoi(getenv("CAMA_OVERLAY_CHUNK_LOG2")) : -1;
+#endif
     return forced > 31 ? 31 : forced;
 }
 uint32_t overlay_chunk_log2(size_t launch_bytes)
