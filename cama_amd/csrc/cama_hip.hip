@@ -246,8 +246,9 @@ unsigned persistent_workgroups()
 // one of three speed modes that is fixed per process (profiles/r03_process_modes.txt: 0.75 / 0.79 / 0.82 at 40 frames, the
 // interleaved order 0.755 in all of them).  Measured inside single processes instead (whole step / 8 TB/s, 8 processes):
 // contiguous 0.70 .. 0.79, interleaved 0.73-0.74 in every one, round-robin chunks of 32 bands 0.74-0.76 in every one.  So:
-//   * launches below 1.75 GiB: chunks of 32 bands (>= the interleaved order wherever measured: 960x540 raw +1 %,
-//     20 frames of 1600x900 +0.7 %);
+//   * launches below 1.75 GiB, and every launch of the raw-frame / translucent variants: chunks of 32 bands (>= the
+//     interleaved order wherever measured: 960x540 raw +1 %, 20 frames of 1600x900 +0.7 %; the contiguous order at 1.41 GB
+//     of raw frames: 0.63-0.71 against 0.72 in every process);
 //   * launches of 1.75 GiB and more: the process finds out which of {contiguous, chunks of 32} is faster HERE -- the first
 //     launches alternate between the two with their own start / stop events, and once each has two timings the faster
 //     one (per byte) is kept for the life of the process (MapTuner below; cama_overlay_mapping_info() reports it).
@@ -264,11 +265,11 @@ int overlay_forced_chunk_log2()
 #endif
     return forced > 31 ? 31 : forced;
 }
-uint32_t overlay_chunk_log2(size_t launch_bytes)
+// the order of a launch that does not go through the tuner (small launches; the raw-frame and translucent variants): chunks
+uint32_t overlay_chunk_log2()
 {
     const int forced = overlay_forced_chunk_log2();
-    if (forced >= 0) return (uint32_t)forced;
-    return launch_bytes >= MAP_BIG_LAUNCH ? MAP_CONTIGUOUS : MAP_CHUNKED;
+    return forced >= 0 ? (uint32_t)forced : MAP_CHUNKED;
 }
 
 // Which mapping do big launches get in this process?  (see above)
@@ -818,7 +819,7 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     const size_t frames_in_launch = scenes_dev ? (size_t)frames_per_scene : (size_t)F;
     const size_t launch_bytes = frames_in_launch * (size_t)C * 3 *
                                 ((raw ? (size_t)raw->H0 * raw->W0 : (size_t)H * W) + (size_t)H * W);
-    o.chunk_log2 = overlay_chunk_log2(launch_bytes);
+    o.chunk_log2 = overlay_chunk_log2();
     // big launches of the plain overlay: the process's own choice between the contiguous and the chunked order, or a trial of
     // one of them (MapTuner); a launch that is being profiled, or that cannot carry events of its own, just follows
     const bool plain_vec = !raw && o.pal.alpha256 == 256u && vec;
@@ -1067,7 +1068,9 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     const uint32_t NBx = bands_per_wg == 2 ? (uint32_t)(L.NB + 1) / 2 : (uint32_t)L.NB;
     const uint32_t nbx_magic = (uint32_t)(((1ull << 32) + NBx - 1) / NBx);
     o.items = (uint32_t)((size_t)F * rows * cols * NBx * TX);
-    o.chunk_log2 = overlay_chunk_log2((size_t)F * C * 3 * ((size_t)H0 * W0 + (size_t)H * W));
+    // (the 3:5 raw overlay always takes the chunked order unless one is forced: measured inside single processes at 1.41 GB per
+    // launch, contiguous 0.63-0.71 of 8 TB/s against 0.72 for chunks of 32 bands in every process)
+    o.chunk_log2 = overlay_chunk_log2();
     const dim3 rgrid = overlay_grid(o.items, o.chunk_log2);
     o.nb_magic = (uint32_t)(((1ull << 32) + (uint32_t)L.NB - 1) / (uint32_t)L.NB);
     o.cr_magic = (uint32_t)(((1ull << 32) + (uint32_t)rows - 1) / (uint32_t)rows);

@@ -175,13 +175,15 @@ __device__ __forceinline__ void lds_barrier()
 // The bands of a launch are numbered in the order (frame, mosaic row of cameras, band, camera column, [column tile]):
 // the `cols` cameras that share a mosaic row-band are neighbours, so consecutive items read consecutive source bytes and
 // write R full mosaic rows.  Workgroups are dispatched round-robin over the 8 XCDs (observed: block L runs on XCD L % 8;
-// /opt/skills/guides/MI355X_MICROARCH.md, "for speed only").  Two mappings, chosen per launch by the host
-// (cama_hip.hip: overlay_chunk_log2, with the measurements):
-//   interleaved  workgroup L renders item L: all XCDs advance through ONE stream, each touching every page of it;
-//   contiguous   XCD x renders items [x * ceil(T/8), (x+1) * ceil(T/8)): eight streams, each XCD touches an eighth of the
-//                pages.  Wins once a launch touches more than ~2 GB (the headline's 40 x 1600x900 frames: 0.755 -> 0.815
-//                of 8 TB/s; a 160-frame launch 0.62 -> 0.83), loses below (960x540: 0.77 -> 0.72).
-// (Round-robin CHUNKS of 2^k items were measured too: never better than k = 0, down to 0.70 at k = 11.)
+// /opt/skills/guides/MI355X_MICROARCH.md, "for speed only").  One function, three orders, chosen per launch by the host
+// (cama_hip.hip: MapTuner / overlay_chunk_log2, with the measurements):
+//   interleaved  (chunk_log2 = 0) workgroup L renders item L: all XCDs advance through ONE stream, each touching every page;
+//   chunked      (1 .. 30) chunks of 2^k items dealt round-robin to the XCDs -- k = 5 is what small launches and the raw-frame
+//                variants use: the same speed in every process, a little above the interleaved order;
+//   contiguous   (31) XCD x renders items [x * ceil(T/8), (x+1) * ceil(T/8)): eight streams, each XCD touches an eighth of the
+//                pages.  The fastest order for launches beyond ~2 GB in most processes (the headline's 40 x 1600x900 frames:
+//                0.82 of 8 TB/s against 0.755 / 0.78 for the other two), the slowest in others (0.75): the process times it
+//                against the chunked order on its own first launches.
 // Either mapping is a bijection whatever the hardware's placement is: a different dispatch rule costs speed, never pixels.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool xcd_contiguous_item(const uint32_t T, const uint32_t chunk_log2, uint32_t &item)
