@@ -18,15 +18,16 @@ __global__ __launch_bounds__(256) void k_copy(const u32x4 *__restrict__ s, u32x4
     if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
 }
 
+static hipStream_t g_stream = 0;
 template <typename F>
 static double timeit(F f)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int k = 0; k < 5; ++k) f();
     CK(hipDeviceSynchronize());
-    CK(hipEventRecord(a, 0));
+    CK(hipEventRecord(a, g_stream));
     for (int k = 0; k < 20; ++k) f();
-    CK(hipEventRecord(b, 0));
+    CK(hipEventRecord(b, g_stream));
     CK(hipEventSynchronize(b));
     float ms = 0; CK(hipEventElapsedTime(&ms, a, b));
     return ms / 20.0;
@@ -40,12 +41,22 @@ int main(int argc, char **argv)
     for (int p = 0; p < pairs; ++p) {                    // (earlier pairs stay allocated: every pair sits on other pages)
         u32x4 *s, *d; CK(hipMalloc(&s, bytes)); CK(hipMalloc(&d, bytes));
         CK(hipMemset(s, 1, bytes)); CK(hipMemset(d, 2, bytes));
-        const double ti = timeit([&] { hipLaunchKernelGGL((k_copy<false>), dim3(blocks), dim3(256), 0, 0, s, d, n, per); });
-        const double tc = timeit([&] { hipLaunchKernelGGL((k_copy<true>), dim3(grid8), dim3(256), 0, 0, s, d, n, per); });
-        const double ti2 = timeit([&] { hipLaunchKernelGGL((k_copy<false>), dim3(blocks), dim3(256), 0, 0, s, d, n, per); });
-        const double tc2 = timeit([&] { hipLaunchKernelGGL((k_copy<true>), dim3(grid8), dim3(256), 0, 0, s, d, n, per); });
+        const double ti = timeit([&] { hipLaunchKernelGGL((k_copy<false>), dim3(blocks), dim3(256), 0, g_stream, s, d, n, per); });
+        const double tc = timeit([&] { hipLaunchKernelGGL((k_copy<true>), dim3(grid8), dim3(256), 0, g_stream, s, d, n, per); });
+        const double ti2 = timeit([&] { hipLaunchKernelGGL((k_copy<false>), dim3(blocks), dim3(256), 0, g_stream, s, d, n, per); });
+        const double tc2 = timeit([&] { hipLaunchKernelGGL((k_copy<true>), dim3(grid8), dim3(256), 0, g_stream, s, d, n, per); });
         printf("%ssrc %p dst %p   interleaved %.3f / %.3f   contiguous %.3f / %.3f   of 8 TB/s\n", p ? "   +  " : "", (void *)s, (void *)d,
                2.0 * bytes / ti / 8e9, 2.0 * bytes / ti2 / 8e9, 2.0 * bytes / tc / 8e9, 2.0 * bytes / tc2 / 8e9);
+        if (argc > 2) {                                   // the same pair on a few more streams (other hardware queues)
+            printf("      contiguous on %d more streams:", atoi(argv[2]));
+            for (int q = 0; q < atoi(argv[2]); ++q) {
+                CK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+                const double t = timeit([&] { hipLaunchKernelGGL((k_copy<true>), dim3(grid8), dim3(256), 0, g_stream, s, d, n, per); });
+                printf(" %.3f", 2.0 * bytes / t / 8e9);
+            }
+            printf("\n");
+            g_stream = 0;
+        }
     }
     return 0;
 }
