@@ -10,7 +10,7 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 16
+ABI_VERSION = 17
 BIN_WORKLIST = 1
 
 _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
@@ -62,6 +62,8 @@ SIGNATURES = {
     "cama_stamp_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_probe_xcd_map": (_i32, [_vp, _i32, _vp]),
     "cama_overlay_mapping_info": (_i32, [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(ctypes.c_double)]),
+    "cama_set_option": (_i32, [ctypes.c_char_p, _i64]),
+    "cama_get_option": (_i32, [ctypes.c_char_p, ctypes.POINTER(_i64)]),
     "cama_stamp_polylines": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_circle_halfwidths": (_i32, [_i32, _vp]),
     "cama_overlay_band_rows": (_i32, [_i32]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "cama_read_files": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "cama_profile_enable": (_i32, [_i32]),
     "cama_profile_collect": (_i32, [_vp, _vp]),
+    "cama_profile_collect_each": (_i32, [_vp, _i32, _vp]),
     "cama_profile_collect_project": (_i32, [_vp, _vp]),
     "cama_bin_stats": (_i32, [_vp, _sz, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
 }

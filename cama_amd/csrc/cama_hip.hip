@@ -32,6 +32,7 @@
 #include <utility>
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include <algorithm>
 
 #include "cama_hip.h"
@@ -234,7 +235,7 @@ unsigned persistent_workgroups()
     return v ? (v + 7u) & ~7u : 2048u;
 }
 
-// Workgroup -> band mapping of the overlay kernels (overlay_kernels.hpp: xcd_contiguous_item): 0 = workgroup L renders
+// Workgroup -> band mapping of the overlay kernels (overlay_kernels.hpp: xcd_item_of): 0 = workgroup L renders
 // band L (every XCD owns every eighth band of one stream), 31 = every XCD renders one contiguous eighth of the launch.
 // Chosen by the bytes a launch touches (frames read + mosaic written): measured on MI355X, kernel bandwidth / 8 TB/s,
 // interleaved vs contiguous --
@@ -256,14 +257,33 @@ unsigned persistent_workgroups()
 // CAMA_OVERLAY_CHUNK_LOG2 = 0 .. 31 forces one mapping (no tuning), CAMA_OVERLAY_TUNE=0 keeps "contiguous" for big launches.
 constexpr uint32_t MAP_CHUNKED = 5u, MAP_CONTIGUOUS = 31u;
 constexpr size_t MAP_BIG_LAUNCH = (size_t)7 << 28;               // 1.75 GiB
+
+// Process-wide tuning options (cama_set_option / cama_get_option, include/cama_hip.h): performance knobs only -- none of
+// them can change a result.  Each starts from its environment variable (read once) and may be changed at run time.
+struct Option { const char *name, *env; int64_t fallback; std::atomic<int64_t> value; std::atomic<bool> loaded; };
+Option g_options[] = {
+    {"overlay_chunk_log2", "CAMA_OVERLAY_CHUNK_LOG2", -1, {0}, {false}},   // -1 = library's choice, 0..31 = forced order
+    {"overlay_tune", "CAMA_OVERLAY_TUNE", 1, {0}, {false}},                // 0 = big launches keep the contiguous order
+    {"overlay_rot", "CAMA_OVERLAY_ROT", 0, {0}, {false}},                  // contiguous order: XCD x starts rot * x bands in
+    {"overlay_prefetch", "CAMA_OVERLAY_PREFETCH", -1, {0}, {false}},       // translation look-ahead in workgroups per XCD:
+                                                                            // 0 = off, -1 = library's choice
+};
+enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_COUNT };
+static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
+int64_t option(int k)
+{
+    Option &o = g_options[k];
+    if (!o.loaded.load(std::memory_order_acquire)) {
+        const char *e = getenv(o.env);
+        o.value.store(e && *e ? strtoll(e, nullptr, 10) : o.fallback, std::memory_order_relaxed);
+        o.loaded.store(true, std::memory_order_release);
+    }
+    return o.value.load(std::memory_order_relaxed);
+}
 int overlay_forced_chunk_log2()
 {
-#ifdef OVERLAY_MAP_SWITCH                 // A/B build for tools/map_modes.py: the knob is re-read at every launch
-    const int forced = getenv("CAMA_OVERLAY_CHUNK_LOG2") ? atoi(getenv("CAMA_OVERLAY_CHUNK_LOG2")) : -1;
-#else
-    static const int forced = getenv("CAMA_OVERLAY_CHUNK_LOG2") ? atoi(getenv("CAMA_OVERLAY_CHUNK_LOG2")) : -1;
-#endif
-    return forced > 31 ? 31 : forced;
+    const int64_t forced = option(OPT_CHUNK_LOG2);
+    return forced > 31 ? 31 : (int)forced;
 }
 // the order of a launch that does not go through the tuner (small launches; the raw-frame and translucent variants): chunks
 uint32_t overlay_chunk_log2()
@@ -304,7 +324,7 @@ struct MapTuner {
     // the mapping for a big launch; trial = true if the caller can give the launch its own start / stop events
     MapTrial pick(bool can_trial)
     {
-        static const bool tune = !(getenv("CAMA_OVERLAY_TUNE") && atoi(getenv("CAMA_OVERLAY_TUNE")) == 0);
+        const bool tune = option(OPT_TUNE) != 0;
         std::lock_guard<std::mutex> lock(mu);
         if (!tune) return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0};
         poll();
@@ -326,6 +346,19 @@ struct MapTuner {
     }
 };
 MapTuner g_map_tuner;
+
+// stagger + translation look-ahead of a launch of `items` bands (OverlayArgs::rot / per_magic / pf_slots)
+void set_walk_options(OverlayArgs &o, uint32_t items)
+{
+    const uint32_t per = (items + 7u) >> 3;
+    o.rot = 0; o.per_magic = 0; o.pf_slots = 0;
+    if (o.chunk_log2 >= 31u && per > 1u) {
+        o.rot = (uint32_t)((uint64_t)std::max<int64_t>(option(OPT_ROT), 0) % per);
+        o.per_magic = (uint32_t)(((1ull << 32) + per - 1) / per);
+    }
+    const int64_t pf = option(OPT_PREFETCH);
+    o.pf_slots = pf < 0 ? 0u : (uint32_t)std::min<int64_t>(pf, 1 << 20);
+}
 
 dim3 overlay_grid(size_t items, uint32_t chunk_log2)
 {
@@ -401,6 +434,26 @@ static int profile_drain(std::vector<std::pair<hipEvent_t, hipEvent_t>> &pending
 }
 
 int cama_profile_collect(double *total_ms, int32_t *launches) { return profile_drain(g_prof.pending, total_ms, launches); }
+
+// per-launch durations of the timed overlay launches, in issue order: up to `capacity` values into ms[], *launches = how many
+// were pending (all of them are drained)
+int cama_profile_collect_each(double *ms, int32_t capacity, int32_t *launches)
+{
+    if ((!ms && capacity > 0) || capacity < 0) return fail(CAMA_EINVAL, "bad arguments");
+    int n = 0;
+    for (auto &pr : g_prof.pending) {
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second));
+        if (n < capacity) ms[n] = t;
+        ++n;
+        g_prof.pool.push_back(pr.first);
+        g_prof.pool.push_back(pr.second);
+    }
+    g_prof.pending.clear();
+    if (launches) *launches = n;
+    return CAMA_OK;
+}
 int cama_profile_collect_project(double *total_ms, int32_t *launches)
 {
     return profile_drain(g_prof.pending_project, total_ms, launches);
@@ -831,6 +884,7 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     const uint32_t chunk_log2 = o.chunk_log2;
     const auto grid8 = [chunk_log2](size_t items) { return overlay_grid(items, chunk_log2); };
     o.items = nblocks;
+    set_walk_options(o, scenes_dev ? (uint32_t)((size_t)frames_per_scene * items_per_frame) : nblocks);
     const dim3 ogrid = grid8(nblocks);
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1571,6 +1625,29 @@ int cama_pipeline_join(cama_pipeline *p, void *stream)
     // one overlay stream: the newest launch's event covers every earlier one
     if (p->issued) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->done[p->issued % cama_pipeline::RING], 0));
     return CAMA_OK;
+}
+
+int cama_set_option(const char *name, int64_t value)
+{
+    if (!name) return fail(CAMA_EINVAL, "name is NULL");
+    for (int k = 0; k < OPT_COUNT; ++k)
+        if (!strcmp(name, g_options[k].name)) {
+            (void)option(k);
+            g_options[k].value.store(value, std::memory_order_relaxed);
+            return CAMA_OK;
+        }
+    return fail(CAMA_EINVAL, "unknown option '%s'", name);
+}
+
+int cama_get_option(const char *name, int64_t *value)
+{
+    if (!name || !value) return fail(CAMA_EINVAL, "NULL pointer argument");
+    for (int k = 0; k < OPT_COUNT; ++k)
+        if (!strcmp(name, g_options[k].name)) {
+            *value = option(k);
+            return CAMA_OK;
+        }
+    return fail(CAMA_EINVAL, "unknown option '%s'", name);
 }
 
 int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per_mb)

@@ -10,6 +10,9 @@ struct OverlayArgs {
     int f0;                           // multi-scene chains: launch-wide number of this launch's first frame (the scratch is
                                       // indexed by the launch-wide frame, src / mosaic by the frame inside the scene)
     uint32_t chunk_log2;              // items per XCD chunk = 2^chunk_log2 (>= 31: one contiguous range per XCD)
+    uint32_t rot, per_magic;          // contiguous order: XCD x starts rot * x items into its own range (wraps); ceil(2^32 / per)
+    uint32_t pf_slots;                // translation look-ahead: 0 = off, else every 16th workgroup of an XCD touches the pages
+                                      // of the band that XCD renders pf_slots workgroups later (tlb_lookahead)
     uint32_t items;                   // bands of this launch = F * camera rows * cols * NB (x column tiles); grid = 8 * ceil(items / 8)
     uint32_t cols_magic, nb_magic, cr_magic;     // ceil(2^32 / d) for d = cols, NB, camera rows (divmod_magic)
     const uint8_t *src;
@@ -186,11 +189,18 @@ __device__ __forceinline__ void lds_barrier()
 //                against the chunked order on its own first launches.
 // Either mapping is a bijection whatever the hardware's placement is: a different dispatch rule costs speed, never pixels.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool xcd_contiguous_item(const uint32_t T, const uint32_t chunk_log2, uint32_t &item)
+__device__ __forceinline__ uint32_t divmod_magic(const uint32_t n, const uint32_t d, const uint32_t magic, uint32_t &r);
+
+// workgroup number L -> item; `rot` (contiguous order only): XCD x walks its range starting rot * x items in
+__device__ __forceinline__ bool xcd_item_of(const uint32_t L, const uint32_t T, const uint32_t chunk_log2, const uint32_t rot,
+                                            const uint32_t per_magic, uint32_t &item)
 {
-    const uint32_t L = blockIdx.x, x = L & 7u, slot = L >> 3;
+    const uint32_t x = L & 7u, slot = L >> 3;
     if (chunk_log2 >= 31u) {                                 // one contiguous range per XCD; grid = 8 * ceil(T / 8)
-        item = x * ((T + 7u) >> 3) + slot;
+        const uint32_t per = (T + 7u) >> 3;
+        uint32_t s = slot;
+        if (rot) (void)divmod_magic(slot + rot * x, per, per_magic, s);     // (rot < per, slot < per: no overflow)
+        item = x * per + s;
     } else {                                                 // chunks of K = 2^chunk_log2 items dealt round-robin to the XCDs;
         const uint32_t K = 1u << chunk_log2;                 // grid = 8 * K * ceil(T / (8 K))
         item = (((slot >> chunk_log2) << 3) + x) * K + (slot & (K - 1u));
@@ -218,11 +228,12 @@ __device__ __forceinline__ uint32_t divmod_magic(const uint32_t n, const uint32_
 struct BandId { uint32_t fl, c, b, tx; bool valid; };
 
 // item -> (frame inside the launch, camera, band, column tile); TX = column tiles per band (1 for k_overlay)
-__device__ __forceinline__ BandId decode_band(const OverlayArgs &a, const uint32_t T, const uint32_t TX, const uint32_t tx_magic)
+__device__ __forceinline__ BandId decode_band(const OverlayArgs &a, const uint32_t T, const uint32_t TX, const uint32_t tx_magic,
+                                              const uint32_t L = blockIdx.x)
 {
     BandId id{0u, 0u, 0u, 0u, false};
     uint32_t item;
-    if (!xcd_contiguous_item(T, a.chunk_log2, item)) return id;
+    if (!xcd_item_of(L, T, a.chunk_log2, a.rot, a.per_magic, item)) return id;
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C, camrows = (C + cols - 1u) / cols;
     uint32_t cc, cr;
     const uint32_t q0 = TX == 1u ? item : divmod_magic(item, TX, tx_magic, id.tx);
@@ -371,13 +382,42 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
     }
 }
 
+// Translation look-ahead (round 4).  A launch over buffers it has not touched before (a long clip, the 73-scene sweep: frames
+// are never re-read, main.py:57-61) meets a cold address translation at every 2 MB of every stream it walks: 8.6 GB per
+// launch = 4 300 page walks, and in the XCD-contiguous order all ~180 workgroups an XCD has in flight sit on the same two or
+// three pages, so they meet a walk together.  Every 16th workgroup of an XCD therefore ends by touching -- one byte, result
+// unused -- the source and the mosaic address of the band that SAME XCD renders `pf_slots` workgroups later (the page then
+// sits in that XCD's UTCL2 when the band's own loads arrive).  The load is the wave's last instruction: nothing in the
+// workgroup waits for it except its own end.  Addresses are those of a real later band of this launch, so they are inside
+// the caller's buffers by construction.  Speed only.
+template <bool RESAMPLE>
+__device__ __forceinline__ void tlb_lookahead(const OverlayArgs &a)
+{
+    if (!a.pf_slots) return;
+    const uint32_t slot = blockIdx.x >> 3;
+    if ((slot & 15u) != 0u) return;                                     // wave-uniform
+    const uint32_t L2 = blockIdx.x + (a.pf_slots << 3);                 // same XCD, pf_slots workgroups on
+    if (L2 >= gridDim.x || threadIdx.x != 0) return;
+    const BandId id = decode_band(a, a.items, 1u, 0u, L2);
+    if (!id.valid) return;
+    const int y0 = (int)id.b * a.R;
+    const uint32_t fcl = id.fl * (uint32_t)a.C + id.c;
+    const uint8_t *sp = RESAMPLE ? a.src + (size_t)fcl * ((size_t)a.H0 * a.W0 * 3)
+                                 : a.src + ((size_t)fcl * a.H + y0) * (size_t)a.W * 3;
+    const uint8_t *dp = a.mosaic + (size_t)id.fl * a.mosaic_frame_bytes +
+                        ((size_t)(id.c / (uint32_t)a.cols) * a.H + y0) * a.mosaic_row_bytes +
+                        (size_t)(id.c % (uint32_t)a.cols) * a.W * 3;
+    uint32_t t0, t1;
+    asm volatile("global_load_ubyte %0, %2, off\n\tglobal_load_ubyte %1, %3, off" : "=&v"(t0), "=&v"(t1) : "v"(sp), "v"(dp) : "memory");
+}
+
 template <bool VEC, bool RESAMPLE, bool ALPHA = false>
 __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x (W + 2 radius), used only by stamped bands
     const BandId id = decode_band(a, a.items, 1u, 0u);
-    if (!id.valid) return;
-    overlay_band_at<VEC, RESAMPLE, ALPHA>(a, id.fl, (uint32_t)a.f0, id.c, id.b, s_owner);
+    if (id.valid) overlay_band_at<VEC, RESAMPLE, ALPHA>(a, id.fl, (uint32_t)a.f0, id.c, id.b, s_owner);
+    tlb_lookahead<RESAMPLE>(a);
 }
 
 

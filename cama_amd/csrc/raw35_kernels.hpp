@@ -387,11 +387,11 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     // same item order as k_overlay -- (frame, mosaic row of cameras, band [pair], camera column), column tile innermost -- and
-    // the same workgroup -> item mapping (overlay_kernels.hpp: xcd_contiguous_item)
+    // the same workgroup -> item mapping (overlay_kernels.hpp: xcd_item_of)
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C, camrows = (C + cols - 1u) / cols;
     const uint32_t NBx = bands_per_wg == 2 ? (NB + 1u) >> 1 : NB;
     uint32_t item;
-    if (!xcd_contiguous_item(a.items, a.chunk_log2, item)) return;
+    if (!xcd_item_of(blockIdx.x, a.items, a.chunk_log2, a.rot, a.per_magic, item)) return;
     uint32_t tx = 0, cc, bx, cr;
     const uint32_t q0 = TX == 1 ? item : divmod_magic(item, (uint32_t)TX, tx_magic, tx);
     const uint32_t q1 = divmod_magic(q0, cols, a.cols_magic, cc);
@@ -415,7 +415,10 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
 #else
         constexpr bool lds_direct = false;
 #endif
-        if (lds_direct && TX == 1) {
+        // (only when the staged rows are contiguous in memory, i.e. the raw row pitch equals the staged row: W0 * 3 == 5 * W
+        // bytes; a wider sensor row -- 5 * W / 3 < W0, which the plan accepts -- takes the register-staged path with its
+        // src_pitch16 stride)
+        if (lds_direct && TX == 1 && t.src_pitch16 == t.cpt) {
             // source rows straight into LDS (gfx950's global_load_lds_dwordx4: a wave's 64 x 16 bytes land at M0 + 16 lane):
             // no VGPR staging, no ds_write -- with one tile per band the staged rows are one contiguous range of memory and
             // keep their layout.  Measured at 960x540 against the register-staged version (-DRAW35_NO_LDS_DIRECT),

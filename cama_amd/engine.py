@@ -26,6 +26,18 @@ def _torch():
     return torch
 
 
+def _content_hasher():
+    """128-bit content hash for Engine.shared_map's cache key: xxh3 when the xxhash package is there (10x faster on a
+    4e6-vertex site map), else hashlib's blake2b -- neither the reference's requirements.txt nor ours demands xxhash.  The
+    key only has to be deterministic inside one process."""
+    try:
+        import xxhash
+        return xxhash.xxh3_128()
+    except ImportError:
+        import hashlib
+        return hashlib.blake2b(digest_size=16)
+
+
 class host_keepalive:
     """Holds a host array alive inside a pipeline keep tuple (the library reads the scene table's host copy only during
     the call, but the cache may evict it while launches are queued: keeping it costs nothing)."""
@@ -244,12 +256,11 @@ class Engine:
         GPU: one upload, one Morton sort, one block index per site, however many ClipManagers ask.  Weak: a map goes when
         its last clip goes.  `map_cache_stats` counts uploads and hits."""
         import weakref
-        import xxhash
         xyz = np.asarray(xyz)
         if xyz.dtype not in (np.float32, np.float64):
             xyz = xyz.astype(np.float64)
         col = np.ascontiguousarray(colour_id, dtype=np.uint8)
-        h = xxhash.xxh3_128()
+        h = _content_hasher()
         h.update(np.ascontiguousarray(xyz).view(np.uint8).reshape(-1).data)
         h.update(col.data)
         key = (h.hexdigest(), xyz.shape, str(xyz.dtype), str(spatial_sort))

@@ -28,7 +28,7 @@ def assign_scenes(costs, world, site_of=None, site_cost=0.0):
         load = [0.0] * world
         out = [[] for _ in range(world)]
         for i in order:
-            r = min(range(world), key=lambda k: (load[k], k))
+            r = min(range(world), key=lambda k: (load[k], len(out[k]), k))    # (zero costs: fewest scenes first)
             out[r].append(i)
             load[r] += float(costs[i])
         return [sorted(s) for s in out]
@@ -37,28 +37,42 @@ def assign_scenes(costs, world, site_of=None, site_cost=0.0):
     groups = {}
     for i, sid in enumerate(site_of):
         groups.setdefault(sid, []).append(i)
+
+    def makespan(assignment):
+        return max((sum(float(costs[i]) for i in sc) + site_cost * len({site_of[i] for i in sc})) for sc in assignment) \
+            if assignment else 0.0
+
+    plain = assign_scenes(costs, world)                       # no affinity: every rank may load every site
     # fair share of a rank, counting one load per site and at least one load per rank
     fair = (float(costs.sum()) + site_cost * max(len(groups), world)) / world
+    if fair <= 0.0:                                           # nothing to balance on: round-robin
+        return plain
     site_total = {sid: float(costs[m].sum()) for sid, m in groups.items()}
     load = [0.0] * world
     out = [[] for _ in range(world)]
     # sites longest first; each goes to the least loaded rank, which takes as many of its scenes as fit under the fair
-    # share (always at least one); what does not fit moves on to the next least loaded rank, paying the load again
+    # share (always at least one); what does not fit moves on to the next least loaded rank, paying the load again.  With
+    # fewer sites than ranks a rank takes at most its even share of a site's scenes -- a dominant site_cost must not park
+    # a whole site (in the limit the whole job) on one rank while the others idle.
     for sid in sorted(groups, key=lambda g: (-site_total[g], groups[g][0])):
         todo = sorted(groups[sid], key=lambda i: (-costs[i], i))
+        cap = len(todo) if len(groups) >= world else max(1, -(-len(todo) * len(groups) // world))
         while todo:
             r = min(range(world), key=lambda k: (load[k], k))
             load[r] += site_cost
             took = 0
             rest = float(costs[todo].sum())
-            while todo and (took == 0 or load[r] + float(costs[todo[0]]) <= 1.02 * fair or
-                            load[r] + rest <= 1.10 * fair):
+            while todo and took < cap and (took == 0 or load[r] + float(costs[todo[0]]) <= 1.02 * fair or
+                                           load[r] + rest <= 1.10 * fair):
                 i = todo.pop(0)
                 out[r].append(i)
                 load[r] += float(costs[i])
                 rest -= float(costs[i])
                 took += 1
-    return [sorted(s) for s in out]
+    out = [sorted(s) for s in out]
+    # the affinity is a heuristic: never accept it when the plain longest-first placement (each rank paying for every
+    # site it touches) finishes earlier
+    return out if makespan(out) <= makespan(plain) else plain
 
 
 def sites_per_rank(assignment, site_of):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 16
+#define CAMA_ABI_VERSION 17
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -346,6 +346,19 @@ int cama_probe_xcd_map(uint32_t *xcd_of_block, int32_t n_blocks, void *stream);
  * best time per 10^6 bytes, [0] = contiguous, [1] = chunked.  Any pointer may be NULL.  (No reference counterpart.) */
 int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per_mb);
 
+/* Process-wide tuning options: performance only -- no option can change a result (every one of them selects among orders /
+ * schedules that are bijections over the same work; the parity suite runs with each forced).  An option starts from its
+ * environment variable, read once, and may be changed at run time; launches already enqueued keep what they were given.
+ *   name                  env                      meaning
+ *   overlay_chunk_log2    CAMA_OVERLAY_CHUNK_LOG2  -1 = library's choice; 0 = workgroup L renders band L; 1..30 = round-robin
+ *                                                  chunks of 2^k bands over the 8 XCDs; 31 = one contiguous range per XCD
+ *   overlay_tune          CAMA_OVERLAY_TUNE        0 = big launches keep the contiguous order (no self-timing)
+ *   overlay_rot           CAMA_OVERLAY_ROT         contiguous order: XCD x starts rot * x bands into its own range
+ *   overlay_prefetch      CAMA_OVERLAY_PREFETCH    translation look-ahead, in workgroups per XCD (0 = off, -1 = library's choice)
+ * Unknown names: CAMA_EINVAL.  (No reference counterpart: the reference has no native code.) */
+int cama_set_option(const char *name, int64_t value);
+int cama_get_option(const char *name, int64_t *value);
+
 /*
  * Stamp-only overlay for caller-supplied 2D points (the generic CameraManager.render_maps,
  * cama/reproject.py:246-257, for one image): points are (v,u) float64 in draw order.
@@ -415,6 +428,9 @@ int cama_overlay_band_rows(int32_t W);
  */
 int cama_profile_enable(int32_t on);
 int cama_profile_collect(double *total_ms /* host */, int32_t *launches /* host */);
+/* The same, launch by launch: the durations (ms) of the timed overlay launches since the last collect, in issue order, up to
+ * `capacity` of them into ms[]; *launches = how many there were (all are drained).  bench.py reports min / mean / max. */
+int cama_profile_collect_each(double *ms /* host */, int32_t capacity, int32_t *launches /* host */);
 /* The same for the projection kernel (k_frames_project / k_frames_project_list) of every cama_bin_frames call made
  * while profiling was enabled: the kernel's own start / stop events. */
 int cama_profile_collect_project(double *total_ms /* host */, int32_t *launches /* host */);

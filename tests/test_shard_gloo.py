@@ -163,6 +163,23 @@ def test_assign_scenes_keeps_a_site_on_as_few_ranks_as_balance_allows():
         assert pairs <= sum(len(s) for s in shard.sites_per_rank(blind, site_of))
 
 
+def test_assign_scenes_never_parks_the_job_on_one_rank():
+    # a dominant site load must not collapse a site (here: the whole job) onto one rank while seven idle
+    assert shard.assign_scenes([1.0] * 8, 8, site_of=[0] * 8, site_cost=100.0) == [[k] for k in range(8)]
+    # all-zero costs: round-robin, with and without sites
+    assert shard.assign_scenes([0.0] * 8, 4) == [[0, 4], [1, 5], [2, 6], [3, 7]]
+    assert shard.assign_scenes([0.0] * 8, 4, site_of=[0] * 8, site_cost=0.0) == [[0, 4], [1, 5], [2, 6], [3, 7]]
+    # the affinity never loses to the plain longest-first placement once every rank pays for the sites it touches
+    rng = np.random.default_rng(1)
+    for _ in range(500):
+        n, world, n_sites = int(rng.integers(1, 30)), int(rng.integers(1, 9)), int(rng.integers(1, 6))
+        costs, site_of, sc = rng.uniform(0, 10, n), rng.integers(0, n_sites, n).tolist(), float(rng.uniform(0, 50))
+        span = lambda parts: max(sum(costs[i] for i in p) + sc * len({site_of[i] for i in p}) for p in parts)
+        got = shard.assign_scenes(costs, world, site_of=site_of, site_cost=sc)
+        assert sorted(i for p in got for i in p) == list(range(n))
+        assert span(got) <= span(shard.assign_scenes(costs, world)) * (1 + 1e-12)
+
+
 def _site_worker(rank, world, port, q):
     """Two ranks, 2 sites x 4 scenes: every rank builds the site maps of ITS scenes only (a set, as the content-keyed
     device cache would hold them), "renders" its scenes against them, and the usual single all_gather carries the scene
