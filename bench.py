@@ -27,15 +27,18 @@ Verification (untimed, BEFORE the timed region): every scene is rendered once on
 (shard.overlay_hash); the per-SCENE hashes travel in the job's single all_gather (RCCL) next to the metrics and rank 0
 compares them with tests/golden/scene_hashes.json -- the hashes of the ORACLE's render of the same scenes
 (tests/golden/gen_scene_hashes.py, CPU) -- so a wrong shard, a scene rendered twice or not at all, or wrong pixels
-cannot print a number: the run fails instead.  After the timed region every rank also hashes what the timed path itself
-left in its output buffers and compares it with those verified hashes (exit 3 on a difference).
+cannot print a number: the run fails instead.  Between the warm-up and the timed region every output buffer is
+overwritten with 0xA5 (Job.poison); after the timed region every rank hashes what the timed path itself left in its output
+buffers and compares it with those verified hashes (exit 3 on a difference) -- which can therefore only pass on bytes the
+timed steps wrote.  CAMA_BENCH_FAULT=skip_overlay (tests) makes the timed steps render nothing and must end in exit 3.
 
 Extra objects in the JSON line:
   roofline      dominant kernel = k_overlay, HBM-bound.  achieved = the bytes THAT kernel moves per launch -- every
                 source pixel read once, every mosaic pixel written once: 36*W*H per frame (SURVEY.md 8d's image term) x
                 frames per launch -- / its mean duration measured live with hipEvents on the launch stream
                 (cama_profile_*; every 8th step is timed: the launch takes the event pair as the kernel's own start /
-                stop events, hipExtLaunchKernelGGL).  peak 8000 GB/s.  `traffic` is a cross-reference to the committed
+                stop events, hipExtLaunchKernelGGL).  launch_ms_min / launch_ms_max: the fastest and slowest of those
+                timed launches (a step of a long clip is several launches over different memory).  peak 8000 GB/s.  `traffic` is a cross-reference to the committed
                 rocprofv3 --pmc run of the same configuration (`traffic_source`), not a measurement of this run.
   roofline_project   the vertex term of SURVEY.md 8d belongs to k_frames_project, not to the overlay: bytes = 13 B (16 B
                 for maps that carry a draw key) x the vertices of the 64-vertex runs that survived the block cull
@@ -65,7 +68,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SWEEP_SCENES = 73              # BASELINE configs[2]: nuScenes v1.0-test
 STRESS = dict(verts=1000000, frames=1000)       # BASELINE configs[4]
-N_METRICS = 16
+N_METRICS = 20
 GOLDEN_SCENES = os.path.join(REPO, "tests", "golden", "scene_hashes.json")
 
 
@@ -428,22 +431,41 @@ class Job:
         for _ in range(warmup):
             self.step()
         self.eng.join()
+        # Every byte of every output buffer is overwritten with a pattern no render produces BEFORE the timed region: the
+        # hash check after it (timed_output_hashes) can then only pass on bytes the timed steps themselves wrote -- the
+        # verified render of scene_hashes() and the warm-up's output are gone.
+        self.poison()
+        step = self.step
+        if os.environ.get("CAMA_BENCH_FAULT") == "skip_overlay":       # fault injection (tests): the timed steps render nothing
+            step = lambda: None
         sync_all()
         t0 = time.perf_counter()
         for k in range(steps):
             if prof_every > 0:                                          # live hipEvent timing of every n-th overlay
                 L.cama_profile_enable(1 if k % prof_every == 0 else 0)
-            self.step()
+            step()
         self.eng.join()
         sync_all()
         dt = time.perf_counter() - t0
-        ov_ms, ov_n = ctypes.c_double(0.0), ctypes.c_int32(0)
+        cap = 8192
+        each = (ctypes.c_double * cap)()
+        ov_n = ctypes.c_int32(0)
         pj_ms, pj_n = ctypes.c_double(0.0), ctypes.c_int32(0)
-        L.cama_profile_collect(ctypes.byref(ov_ms), ctypes.byref(ov_n))
+        L.cama_profile_collect_each(each, cap, ctypes.byref(ov_n))
         L.cama_profile_collect_project(ctypes.byref(pj_ms), ctypes.byref(pj_n))
         L.cama_profile_enable(0)
         self.project_ms, self.project_n = pj_ms.value, pj_n.value
-        return dt, ov_ms.value, ov_n.value
+        got = [each[k] for k in range(min(cap, ov_n.value))]
+        # per-launch spread of the timed overlay launches (a step of a long clip is several launches over different memory)
+        self.overlay_each = {"min": min(got), "max": max(got), "n": len(got)} if got else {"min": 0.0, "max": 0.0, "n": 0}
+        return dt, float(sum(got)), len(got)
+
+    def poison(self):
+        import torch
+        for t in [self.out] + list(self.outs or []) + list(self.own_outs or []):
+            if t is not None:
+                t.fill_(0xA5)
+        torch.cuda.synchronize(self.device)
 
     def sustain(self, seconds, steps_hint, dt_hint):
         """The same loop, un-profiled, for at least `seconds` of wall time: (steps, seconds).  No barrier: every rank
@@ -547,6 +569,16 @@ class Job:
         per_call = max(1, min(self.F, self.eng.max_frames_per_call(cm._static("cama").device(), cm._rig(),
                                                                    pipelined=self.pipelined)))
         return self.F / float(-(-self.F // per_call))                   # render_clip splits big clips into launches
+
+    def scratch_bytes(self):
+        """Device bytes of stamp scratch this rank's engine holds (both pipeline slots + the single-stream buffer)."""
+        eng = self.eng
+        total = 0
+        pipe = getattr(eng, "_pipe", None)
+        for t in (list(pipe["scratch"]) if pipe else []) + [getattr(eng, "_scratch", None)]:
+            if t is not None:
+                total += int(t.numel())
+        return total
 
     def free(self):
         self.scenes, self.out, self.outs = [], None, None
@@ -675,7 +707,8 @@ def main():
                job.project_ms, float(job.project_n), vbytes, sbytes,
                float(F * sus_steps * len(job.scenes)), sus_dt,
                float(getattr(job.eng, "map_cache_stats", {}).get("uploads", 0)),
-               float(getattr(job.eng, "map_cache_stats", {}).get("hits", 0))]
+               float(getattr(job.eng, "map_cache_stats", {}).get("hits", 0)),
+               job.overlay_each["min"], job.overlay_each["max"], float(job.scratch_bytes()), 0.0]
     cm0, frames0, clip0 = (job.scenes[0][1:] if job.scenes else (None, None, None))
     slots = max(16, -(-n_scenes // world) + 1)
     report = [shard.pack_report(metrics, hashes, slots)]
@@ -705,7 +738,8 @@ def main():
         s_vb, s_sb, _ = sjob.projection_bytes()
         s_metrics = [float(sjob.F * s_steps), sdt, sov_ms, float(sov_n), float(sjob.N),
                      float(s_steps) * shard.scene_cost(sjob.F, sjob.N, W, H), sjob.frames_per_launch(), float(s_steps),
-                     sjob.project_ms, float(sjob.project_n), s_vb, s_sb, 0.0, 0.0, 0.0, 0.0]
+                     sjob.project_ms, float(sjob.project_n), s_vb, s_sb, 0.0, 0.0, 0.0, 0.0,
+                     sjob.overlay_each["min"], sjob.overlay_each["max"], float(sjob.scratch_bytes()), 0.0]
         report.append(shard.pack_report(s_metrics, s_hashes, len(s_samples)))
         s_key = workload_key(sargs.frames, sargs.verts, W, H, "random", unit="frame")
 
@@ -746,6 +780,8 @@ def main():
             r_ov = {"bound": "hbm", "kernel": overlay_kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "avg_launch_ms": ov_ms_,
                     "launches": int(launches), "bytes_per_launch": ov_bytes,
+                    "launch_ms_min": float(mm[0, 16]), "launch_ms_max": float(mm[0, 17]),
+                    "launch_max_over_min": (float(mm[0, 17]) / float(mm[0, 16])) if float(mm[0, 16]) > 0 else None,
                     "bytes_per_frame": "36*W*H = every source pixel read once + every mosaic pixel written once"}
             pj_n = float(mm[0, 9])
             pj_ms_ = float(mm[0, 8]) / pj_n if pj_n > 0 else 0.0
@@ -793,6 +829,7 @@ def main():
             "hbm_frac_whole_step": bytes_per_frame * (float(m[0, 0]) / float(m[0, 1])) / 1e9 / HBM_PEAK_GBS,
             "roofline": r_overlay,
             "roofline_project": r_project,
+            "scratch_bytes": int(m[0, 18]),
         }
         sus_frames, sus_secs = float(m[:, 12].sum()), float(m[:, 13].max())
         if sus_secs > 0:

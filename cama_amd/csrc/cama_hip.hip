@@ -267,8 +267,11 @@ Option g_options[] = {
     {"overlay_rot", "CAMA_OVERLAY_ROT", 0, {0}, {false}},                  // contiguous order: XCD x starts rot * x bands in
     {"overlay_prefetch", "CAMA_OVERLAY_PREFETCH", -1, {0}, {false}},       // translation look-ahead in workgroups per XCD:
                                                                             // 0 = off, -1 = library's choice
+    {"overlay_item_order", "CAMA_OVERLAY_ITEM_ORDER", 0, {0}, {false}},    // 0 = camera column innermost, 1 = band innermost
+    {"overlay_groups_log2", "CAMA_OVERLAY_GROUPS_LOG2", 0, {0}, {false}},  // 1 / 2: 2 / 4 XCD groups, chunked inside (with a
+                                                                            // forced overlay_chunk_log2 < 31)
 };
-enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_COUNT };
+enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
 int64_t option(int k)
 {
@@ -292,57 +295,109 @@ uint32_t overlay_chunk_log2()
     return forced >= 0 ? (uint32_t)forced : MAP_CHUNKED;
 }
 
-// Which mapping do big launches get in this process?  (see above)
-struct MapTrial { uint32_t chunk_log2; hipEvent_t e0, e1; int which; };     // e0 == nullptr: not a trial
+// Which mapping does a big launch get?  Round 4: the speed of the contiguous order is a property of the BUFFERS a launch walks
+// (their physical placement), not of the process -- one process that cycles through 12 (frames, mosaic) pairs sees 0.313 ..
+// 0.350 ms on them, each pair always the same (profiles/r04_overlay_modes.txt) -- so the choice is kept per (device, frames
+// pointer, mosaic pointer, bytes): the first launches over a pair alternate between the two orders with their own start /
+// stop events, and once each has three timings the faster MEDIAN (per byte) is kept for that pair.  A table of the 64 most
+// recently used pairs; a pair that is never seen six times (a stream of new buffers) simply keeps the contiguous order, which
+// is the better one on average for launches of this size (40 frames: 0.75 .. 0.835 against 0.775 .. 0.79 for the chunks;
+// 167 frames: 0.765 against 0.735).  Process-wide state behind a mutex (include/cama_hip.h, "global state").
+struct MapTrial { uint32_t chunk_log2; hipEvent_t e0, e1; int which; uint64_t key_id; };     // e0 == nullptr: not a trial
 struct MapTuner {
+    static constexpr int SAMPLES = 3, MAX_KEYS = 64;
     std::mutex mu;
-    int decided = -1;                         // -1 = still measuring, else MAP_CONTIGUOUS | MAP_CHUNKED
-    int issued = 0;
-    int done[2] = {0, 0};
-    double best[2] = {1e300, 1e300};          // seconds per byte: [0] contiguous, [1] chunked
-    struct Pending { hipEvent_t e0, e1; int which; double bytes; };
+    struct Entry {
+        int device; const void *src, *dst; size_t bytes;
+        uint64_t id, stamp;
+        int decided = -1;                     // -1 = still measuring, else MAP_CONTIGUOUS | MAP_CHUNKED
+        int issued = 0;
+        int done[2] = {0, 0};
+        double t[2][SAMPLES] = {};            // seconds per byte: [0] contiguous, [1] chunked
+    };
+    std::vector<Entry> entries;
+    uint64_t clock = 0, next_id = 1, last_id = 0;
+    struct Pending { hipEvent_t e0, e1; int which; double bytes; uint64_t key_id; };
     std::vector<Pending> pending;
 
+    Entry *find(uint64_t id)
+    {
+        for (auto &e : entries)
+            if (e.id == id) return &e;
+        return nullptr;
+    }
+    static double median(const double *v, int n)
+    {
+        double a[SAMPLES];
+        std::copy(v, v + n, a);
+        std::sort(a, a + n);
+        return n & 1 ? a[n / 2] : 0.5 * (a[n / 2 - 1] + a[n / 2]);
+    }
     void poll()
     {
         for (size_t k = 0; k < pending.size();) {
-            if (hipEventQuery(pending[k].e1) != hipSuccess) { ++k; continue; }
+            const hipError_t q = hipEventQuery(pending[k].e1);
+            if (q == hipErrorNotReady) { ++k; continue; }
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pending[k].e0, pending[k].e1) == hipSuccess && ms > 0.f) {
-                best[pending[k].which] = std::min(best[pending[k].which], (double)ms * 1e-3 / pending[k].bytes);
-                ++done[pending[k].which];
-            }
-            (void)hipEventDestroy(pending[k].e0);
+            Entry *e = find(pending[k].key_id);
+            if (q == hipSuccess && e && hipEventElapsedTime(&ms, pending[k].e0, pending[k].e1) == hipSuccess && ms > 0.f &&
+                e->done[pending[k].which] < SAMPLES)
+                e->t[pending[k].which][e->done[pending[k].which]++] = (double)ms * 1e-3 / pending[k].bytes;
+            (void)hipEventDestroy(pending[k].e0);         // (also when the launch or the query failed: nothing leaks)
             (void)hipEventDestroy(pending[k].e1);
             pending[k] = pending.back();
             pending.pop_back();
+            if (e && e->decided < 0 && e->done[0] >= SAMPLES && e->done[1] >= SAMPLES)
+                e->decided = median(e->t[1], SAMPLES) < median(e->t[0], SAMPLES) * 0.995 ? (int)MAP_CHUNKED : (int)MAP_CONTIGUOUS;
         }
         (void)hipGetLastError();              // (hipEventQuery's "not ready" is not an error of ours)
-        if (decided < 0 && done[0] >= 2 && done[1] >= 2)
-            decided = best[1] < best[0] * 0.995 ? (int)MAP_CHUNKED : (int)MAP_CONTIGUOUS;
     }
-    // the mapping for a big launch; trial = true if the caller can give the launch its own start / stop events
-    MapTrial pick(bool can_trial)
+    // the mapping for a big launch over (src, dst); a trial if the caller can give the launch its own start / stop events
+    MapTrial pick(const void *src, const void *dst, size_t bytes, bool can_trial)
     {
         const bool tune = option(OPT_TUNE) != 0;
+        if (!tune) return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0, 0};
+        int device = 0;
+        (void)hipGetDevice(&device);
         std::lock_guard<std::mutex> lock(mu);
-        if (!tune) return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0};
         poll();
-        if (decided >= 0) return MapTrial{(uint32_t)decided, nullptr, nullptr, 0};
-        if (!can_trial || issued >= 16) return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0};
-        MapTrial t{MAP_CONTIGUOUS, nullptr, nullptr, issued & 1};
+        Entry *e = nullptr;
+        for (auto &c : entries)
+            if (c.device == device && c.src == src && c.dst == dst && c.bytes == bytes) { e = &c; break; }
+        if (!e) {
+            if ((int)entries.size() >= MAX_KEYS) {        // evict the least recently used pair
+                size_t lru = 0;
+                for (size_t k = 1; k < entries.size(); ++k)
+                    if (entries[k].stamp < entries[lru].stamp) lru = k;
+                entries[lru] = entries.back();
+                entries.pop_back();
+            }
+            entries.emplace_back();
+            e = &entries.back();
+            e->device = device; e->src = src; e->dst = dst; e->bytes = bytes; e->id = next_id++;
+        }
+        e->stamp = ++clock;
+        last_id = e->id;
+        if (e->decided >= 0) return MapTrial{(uint32_t)e->decided, nullptr, nullptr, 0, e->id};
+        if (!can_trial || e->issued >= 4 * SAMPLES) return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0, e->id};
+        MapTrial t{MAP_CONTIGUOUS, nullptr, nullptr, e->issued & 1, e->id};
         if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) {
             if (t.e0) (void)hipEventDestroy(t.e0);
-            return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0};
+            return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0, e->id};
         }
         t.chunk_log2 = t.which ? MAP_CHUNKED : MAP_CONTIGUOUS;
-        ++issued;
+        ++e->issued;
         return t;
     }
     void submitted(const MapTrial &t, double bytes)
     {
         std::lock_guard<std::mutex> lock(mu);
-        pending.push_back(Pending{t.e0, t.e1, t.which, bytes});
+        pending.push_back(Pending{t.e0, t.e1, t.which, bytes, t.key_id});
+    }
+    void abandon(const MapTrial &t)           // a trial whose launch did not happen
+    {
+        if (t.e0) (void)hipEventDestroy(t.e0);
+        if (t.e1) (void)hipEventDestroy(t.e1);
     }
 };
 MapTuner g_map_tuner;
@@ -358,10 +413,19 @@ void set_walk_options(OverlayArgs &o, uint32_t items)
     }
     const int64_t pf = option(OPT_PREFETCH);
     o.pf_slots = pf < 0 ? 0u : (uint32_t)std::min<int64_t>(pf, 1 << 20);
+    o.item_order = option(OPT_ITEM_ORDER) == 1 ? 1u : 0u;
+    const int64_t gl2 = option(OPT_GROUPS);
+    o.groups_log2 = (o.chunk_log2 < 31u && (gl2 == 1 || gl2 == 2)) ? (uint32_t)gl2 : 0u;
 }
 
 dim3 overlay_grid(size_t items, uint32_t chunk_log2)
 {
+    const int64_t gl2 = option(OPT_GROUPS);
+    if (chunk_log2 < 31u && (gl2 == 1 || gl2 == 2)) {        // grouped order: 8 * K * ceil(ceil(T / G) / (M K))
+        const size_t G = (size_t)1 << gl2, M = 8 / G, K = (size_t)1 << chunk_log2;
+        const size_t per_g = (items + G - 1) / G;
+        return dim3((unsigned)(8 * K * ((per_g + M * K - 1) / (M * K))));
+    }
     if (chunk_log2 >= 31u) return dim3((unsigned)((items + 7) / 8 * 8));
     const size_t per = (size_t)8 << chunk_log2;
     return dim3((unsigned)((items + per - 1) / per * per));
@@ -876,9 +940,11 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     // big launches of the plain overlay: the process's own choice between the contiguous and the chunked order, or a trial of
     // one of them (MapTuner); a launch that is being profiled, or that cannot carry events of its own, just follows
     const bool plain_vec = !raw && o.pal.alpha256 == 256u && vec;
-    MapTrial trial{o.chunk_log2, nullptr, nullptr, 0};
+    MapTrial trial{o.chunk_log2, nullptr, nullptr, 0, 0};
     if (launch_bytes >= MAP_BIG_LAUNCH && overlay_forced_chunk_log2() < 0 && plain_vec) {
-        trial = g_map_tuner.pick(!g_prof.on);
+        trial = g_map_tuner.pick(scenes_dev ? (const void *)scenes_host[0].src : (const void *)src,
+                                 scenes_dev ? (const void *)scenes_host[0].mosaic : (const void *)mosaic, launch_bytes,
+                                 !g_prof.on);
         o.chunk_log2 = trial.chunk_log2;
     }
     const uint32_t chunk_log2 = o.chunk_log2;
@@ -955,7 +1021,7 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
             hipExtLaunchKernelGGL((k_overlay<true, false>), sgrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, e0, e1, 0u, o);
         }
         if (trial.e0 && S > 1) g_map_tuner.submitted(trial, (double)launch_bytes);
-        else if (trial.e0) { (void)hipEventDestroy(trial.e0); (void)hipEventDestroy(trial.e1); }
+        else if (trial.e0) g_map_tuner.abandon(trial);
         if (!(exact_timing && ev0 && ev1)) g_overlay_stop_event = nullptr;
     } else if (vec) {
         if (trial.e0) {
@@ -1654,10 +1720,11 @@ int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per
 {
     std::lock_guard<std::mutex> lock(g_map_tuner.mu);
     g_map_tuner.poll();
-    if (decided) *decided = overlay_forced_chunk_log2() >= 0 ? overlay_forced_chunk_log2() : g_map_tuner.decided;
+    const MapTuner::Entry *e = g_map_tuner.find(g_map_tuner.last_id);       // the pair of the most recent big launch
+    if (decided) *decided = overlay_forced_chunk_log2() >= 0 ? overlay_forced_chunk_log2() : (e ? e->decided : -1);
     for (int k = 0; k < 2; ++k) {
-        if (samples) samples[k] = g_map_tuner.done[k];
-        if (ns_per_mb) ns_per_mb[k] = g_map_tuner.done[k] ? g_map_tuner.best[k] * 1e15 : 0.0;
+        if (samples) samples[k] = e ? e->done[k] : 0;
+        if (ns_per_mb) ns_per_mb[k] = (e && e->done[k]) ? MapTuner::median(e->t[k], e->done[k]) * 1e15 : 0.0;
     }
     return CAMA_OK;
 }

@@ -11,6 +11,10 @@ struct OverlayArgs {
                                       // indexed by the launch-wide frame, src / mosaic by the frame inside the scene)
     uint32_t chunk_log2;              // items per XCD chunk = 2^chunk_log2 (>= 31: one contiguous range per XCD)
     uint32_t rot, per_magic;          // contiguous order: XCD x starts rot * x items into its own range (wraps); ceil(2^32 / per)
+    uint32_t groups_log2;             // 0 = the two-order scheme above; 1 / 2: 2 / 4 groups of XCDs, each group one contiguous
+                                      // range, chunks of 2^chunk_log2 items round-robin inside (xcd_item_grouped)
+    uint32_t item_order;              // 0: items run (frame, camera row, band, camera column); 1: (frame, camera row, camera
+                                      // column, band) -- one source stream per XCD at a time instead of `cols`
     uint32_t pf_slots;                // translation look-ahead: 0 = off, else every 16th workgroup of an XCD touches the pages
                                       // of the band that XCD renders pf_slots workgroups later (tlb_lookahead)
     uint32_t items;                   // bands of this launch = F * camera rows * cols * NB (x column tiles); grid = 8 * ceil(items / 8)
@@ -208,6 +212,21 @@ __device__ __forceinline__ bool xcd_item_of(const uint32_t L, const uint32_t T, 
     return item < T;
 }
 
+// The general form (round 4 experiment): the launch is cut into G = 2^groups_log2 contiguous ranges, one per group of
+// M = 8 / G neighbouring XCDs, and inside a range chunks of K = 2^chunk_log2 items go round-robin to the group's members.
+// G = 1 is the chunked order above, G = 8 the contiguous one; G = 4 makes the two XCDs of a pair share a stream.
+// grid = 8 * K * ceil(ceil(T / G) / (M K)).
+__device__ __forceinline__ bool xcd_item_grouped(const uint32_t L, const uint32_t T, const uint32_t chunk_log2,
+                                                 const uint32_t groups_log2, uint32_t &item)
+{
+    const uint32_t x = L & 7u, slot = L >> 3, ml2 = 3u - groups_log2, M = 1u << ml2, G = 1u << groups_log2;
+    const uint32_t per_g = (T + G - 1u) >> groups_log2, K = 1u << chunk_log2;
+    const uint32_t g = x >> ml2, m = x & (M - 1u);
+    const uint32_t local = ((((slot >> chunk_log2) << ml2) + m) << chunk_log2) + (slot & (K - 1u));
+    item = g * per_g + local;
+    return local < per_g && item < T;
+}
+
 // Diagnostic: which XCD does block L of a 1-D grid run on?  out[L] = HW_REG_XCC_ID (0..7).  The contiguous mapping above
 // assumes L % 8 for speed; cama_probe_xcd_map() lets a caller (bench.py prints it) see what the box really does.
 __global__ void k_probe_xcd(uint32_t *__restrict__ out)
@@ -233,12 +252,19 @@ __device__ __forceinline__ BandId decode_band(const OverlayArgs &a, const uint32
 {
     BandId id{0u, 0u, 0u, 0u, false};
     uint32_t item;
-    if (!xcd_item_of(L, T, a.chunk_log2, a.rot, a.per_magic, item)) return id;
+    if (a.groups_log2 ? !xcd_item_grouped(L, T, a.chunk_log2, a.groups_log2, item)
+                      : !xcd_item_of(L, T, a.chunk_log2, a.rot, a.per_magic, item)) return id;
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C, camrows = (C + cols - 1u) / cols;
     uint32_t cc, cr;
     const uint32_t q0 = TX == 1u ? item : divmod_magic(item, TX, tx_magic, id.tx);
-    const uint32_t q1 = divmod_magic(q0, cols, a.cols_magic, cc);
-    const uint32_t q2 = divmod_magic(q1, NB, a.nb_magic, id.b);
+    uint32_t q2;
+    if (a.item_order == 0u) {
+        const uint32_t q1 = divmod_magic(q0, cols, a.cols_magic, cc);
+        q2 = divmod_magic(q1, NB, a.nb_magic, id.b);
+    } else {
+        const uint32_t q1 = divmod_magic(q0, NB, a.nb_magic, id.b);
+        q2 = divmod_magic(q1, cols, a.cols_magic, cc);
+    }
     id.fl = divmod_magic(q2, camrows, a.cr_magic, cr);
     id.c = cr * cols + cc;
     id.valid = id.c < C;                                  // ragged last camera row

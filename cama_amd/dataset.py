@@ -170,7 +170,8 @@ class RenderedFrame(Mapping):
 
     def _mosaic_host(self):
         if self._host is None:
-            self._host = self.mosaic_device.cpu().numpy()
+            # (the batch's pinned host copy when a bgr24 download was started behind the render, else one download)
+            self._host = self.batch.bgr(self.j) if self.batch is not None else self.mosaic_device.cpu().numpy()
         return self._host
 
     def mosaic(self, order=None):
@@ -381,8 +382,9 @@ class ClipManager:
         else:
             mosaic = eng.render_frames(dmap, rig, w2c, source.batch(image_ids), crop=self.mm.crop_box())
         batch = RenderBatch(eng, image_ids, mosaic)
-        if runtime.egress_mode() == "i420":
-            batch.start_egress()
+        fmt = runtime.egress_mode()                     # a VideoGenerator is listening: start the batch's host copy now
+        if fmt is not None and not batch.start_egress(fmt) and fmt == "i420":
+            batch.start_egress("bgr24")                 # (mosaic shape the I420 converter cannot take)
         return batch
 
     def _render_ahead(self, fr):

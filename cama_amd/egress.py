@@ -7,9 +7,11 @@ what leaves the GPU per frame is a 9.3 MB BGR mosaic that the encoder's front en
   * ClipManager.render_vectors renders `render_ahead` consecutive frames of the pass in ONE launch the first time a frame
     of the batch is asked for (all poses of a pass are known up front) and hands out slices afterwards; the next batch
     is issued one batch early, so the GPU works while the host consumes.
-  * when a VideoGenerator is listening (runtime.egress_mode() == "i420") every batch is converted to planar YUV 4:2:0 on
-    the device (cama_bgr_to_i420) and copied to pinned host memory asynchronously, right behind its render: the
-    per-frame add_frame() is then a wait on an already finished copy plus a 4.7 MB pipe write.
+  * when a VideoGenerator is listening every batch is copied to pinned host memory asynchronously, right behind its
+    render: as the BGR mosaics themselves (default: the reference's bgr24 stream, concate_image returns an ndarray view
+    of that copy), or -- opt-in, runtime.egress_format() == "i420" -- converted to planar YUV 4:2:0 on the device first
+    (cama_bgr_to_i420: half the bytes).  The per-frame add_frame() is then a wait on an already finished copy plus a
+    pipe write.
 """
 import numpy as np
 
@@ -22,21 +24,45 @@ def _torch():
 
 
 class PinnedPool:
-    """Pinned host buffers are expensive to create (hipHostMalloc): recycle them by size."""
+    """Pinned host buffers are expensive to create (hipHostMalloc): recycle them by size.  In bgr24 mode concate_image
+    hands out ndarray VIEWS of a batch's buffer: such a buffer comes back with the array those views are slices of and
+    waits in `limbo` until that array is gone (a view keeps its base alive, so a dead weak reference = no view left)."""
 
     def __init__(self):
         self.free = {}
+        self.limbo = []                 # (buffer, weak reference to the ndarray every handed-out view is a view of)
+
+    def _sweep(self):
+        keep = []
+        for buf, ref in self.limbo:
+            if ref() is None:
+                self._shelve(buf)
+            else:
+                keep.append((buf, ref))
+        self.limbo = keep
+
+    def _shelve(self, buf):
+        lst = self.free.setdefault(buf.numel(), [])
+        if len(lst) < 4:
+            lst.append(buf)
 
     def take(self, nbytes):
+        if self.limbo:
+            self._sweep()
         lst = self.free.get(nbytes)
         if lst:
             return lst.pop()
         return _torch().empty(nbytes, dtype=_torch().uint8, pin_memory=True)
 
-    def give(self, buf):
-        lst = self.free.setdefault(buf.numel(), [])
-        if len(lst) < 4:
-            lst.append(buf)
+    def give(self, buf, views_of=None):
+        """Hand a buffer back.  views_of: the ndarray whose slices went out to callers (or None: nothing went out)."""
+        if views_of is None:
+            self._shelve(buf)
+            return
+        import weakref
+        if len(self.limbo) >= 8:                # (callers hoarding frames: let the oldest go, the GC frees it)
+            self.limbo.pop(0)
+        self.limbo.append((buf, weakref.ref(views_of)))
 
 
 _POOL = PinnedPool()
@@ -44,24 +70,37 @@ _POOL = PinnedPool()
 
 class RenderBatch:
     """B consecutive frames rendered in one launch: `mosaic` [B, rows*H, cols*W, 3] uint8 in HBM (complete on the
-    stream it was rendered on), plus -- after start_egress() -- their I420 planes on their way to pinned host memory."""
+    stream it was rendered on), plus -- after start_egress() -- their host copy on its way to pinned memory: the BGR
+    bytes themselves ("bgr24", the reference's stream) or their I420 planes ("i420")."""
 
     def __init__(self, engine, image_ids, mosaic):
         self.engine, self.ids, self.mosaic = engine, [int(i) for i in image_ids], mosaic
         self._host = self._event = self._i420_dev = None
         self._host_np = None
+        self._fmt = None
 
-    def start_egress(self):
-        """Enqueue BGR -> I420 and the download behind the render (same stream).  False when the mosaic shape does not
-        fit the converter (odd height, width not a multiple of 16): the caller then falls back to BGR downloads."""
+    def start_egress(self, fmt="bgr24"):
+        """Enqueue the download (i420: BGR -> I420 first) behind the render, on the same stream.  False when the mosaic
+        shape does not fit the I420 converter (odd height, width not a multiple of 16): the caller then falls back to BGR."""
         torch = _torch()
         B, H2, W2 = (int(v) for v in self.mosaic.shape[:3])
-        per = H2 * W2 * 3 // 2
         if self._event is not None:
+            return self._fmt == fmt
+        eng = self.engine
+        if fmt == "bgr24":
+            if not self.mosaic.is_contiguous():
+                return False
+            per = H2 * W2 * 3
+            with torch.cuda.device(eng.device):
+                self._host = _POOL.take(B * per)
+                self._host.view(B, per).copy_(self.mosaic.view(B, per), non_blocking=True)
+                self._event = torch.cuda.Event()
+                self._event.record(torch.cuda.current_stream(eng.device))
+            self._fmt = fmt
             return True
+        per = H2 * W2 * 3 // 2
         if H2 % 2 or W2 % 16 or per % 16 or not self.mosaic.is_contiguous():
             return False
-        eng = self.engine
         with torch.cuda.device(eng.device):
             self._i420_dev = torch.empty((B, per), dtype=torch.uint8, device=eng.device)
             _lib.check(eng.lib.cama_bgr_to_i420(self.mosaic.data_ptr(), H2 * W2 * 3, self._i420_dev.data_ptr(), per, B, H2,
@@ -70,20 +109,30 @@ class RenderBatch:
             self._host.view(B, per).copy_(self._i420_dev, non_blocking=True)
             self._event = torch.cuda.Event()
             self._event.record(torch.cuda.current_stream(eng.device))
+        self._fmt = "i420"
         return True
 
-    def i420(self, j):
-        """The I420 bytes of frame j as a uint8 ndarray view of the pinned buffer (valid while the batch lives)."""
-        if self._event is None and not self.start_egress():
-            return None
+    def _host_rows(self):
         if self._host_np is None:
             self._event.synchronize()
             B = int(self.mosaic.shape[0])
             self._host_np = self._host.numpy().reshape(B, -1)
             self._i420_dev = None
-        return self._host_np[j]
+        return self._host_np
+
+    def i420(self, j):
+        """The I420 bytes of frame j as a uint8 ndarray view of the pinned buffer (valid while the batch lives)."""
+        if self._event is None and not self.start_egress("i420"):
+            return None
+        if self._fmt != "i420":
+            return None
+        return self._host_rows()[j]
 
     def bgr(self, j):
+        """Frame j's mosaic (2H, 3W, 3) as a host ndarray: a view of the batch's pinned copy when the bgr24 download was
+        started behind the render (the buffer is not reused while the view lives), else a synchronous download."""
+        if self._fmt == "bgr24":
+            return self._host_rows()[j].reshape(tuple(int(v) for v in self.mosaic.shape[1:]))
         return self.mosaic[j].cpu().numpy()
 
     def __del__(self):
@@ -93,7 +142,9 @@ class RenderBatch:
             try:
                 if ev is not None:
                     ev.synchronize()            # the copy into it must be over before someone else reuses it
-                _POOL.give(host)
+                rows = self._host_np
+                self._host_np = None
+                _POOL.give(host, rows)
             except Exception:
                 pass
 
@@ -109,6 +160,11 @@ class DeviceMosaic:
         self.dtype = np.dtype(np.uint8)
         self.ndim = 3
         self._bgr = None
+
+    def ndarray(self):
+        """The reference's return value of concate_image: the mosaic as a real ndarray (a view of the batch's pinned
+        host copy when the bgr24 download was started behind the render)."""
+        return self._host()
 
     def _host(self):
         """The mosaic as a host ndarray (downloaded once).  From here on this object IS that array for every purpose:

@@ -48,11 +48,14 @@ class VideoGenerator:
     yuv420p out, 10 fps, overwrite, quiet) is started at the first add_frame, because only then it is known what
     crosses the pipe:
 
-      * frames that come out of ClipManager.render_vectors as device mosaics leave the GPU as planar YUV 4:2:0 (the
-        encoder's own pixel format: cama_bgr_to_i420 + a pinned, asynchronous download prepared per render batch), so the
-        pipe carries `-pix_fmt yuv420p` rawvideo: half the bytes, no libswscale pass in ffmpeg;
-      * plain ndarrays (the reference's path) are piped as bgr24, exactly the reference's bytes.  CAMA_EGRESS=bgr24 forces
-        this mode for device mosaics too.
+      * DEFAULT = the reference's bytes: concate_image returns an ndarray and add_frame pipes it as bgr24 rawvideo
+        (tools.py:27-32).  For frames that come out of ClipManager.render_vectors the ndarray is a view of a pinned host
+        copy of the whole render batch, downloaded asynchronously right behind the render (cama_amd/egress.py), so the
+        per-frame loop never waits for a copy it could have started a batch earlier;
+      * OPT-IN (CAMA_EGRESS=i420, or configs["egress"] = "i420" on the ClipManager): those frames leave the GPU as planar
+        YUV 4:2:0 (cama_bgr_to_i420), the pipe carries `-pix_fmt yuv420p` rawvideo: half the bytes, no libswscale pass in
+        ffmpeg.  The conversion restates libswscale's C arithmetic and could not be pinned against a real ffmpeg (none on
+        any box; x86 builds may average chroma in a SIMD body), which is why it is not the default.
 
     `sink`: a binary file object that receives the raw stream instead of an encoder (tests; CAMA_VIDEO_SINK=null or a file
     path does the same for an unchanged main.py on a machine without ffmpeg)."""
@@ -71,11 +74,9 @@ class VideoGenerator:
             self._own_sink = False
         if self._sink is None and shutil.which("ffmpeg") is None:
             raise FileNotFoundError("the `ffmpeg` binary is needed to encode the reprojection video")
-        self._asked_egress = False
-        if os.environ.get("CAMA_EGRESS", "i420") != "bgr24":
-            from . import runtime
-            runtime.request_egress("i420")              # render batches prepare their I420 planes from now on
-            self._asked_egress = True
+        from . import runtime
+        runtime.request_egress("listen")                # render batches prepare their host copies from now on
+        self._asked_egress = True
 
     def _start(self, pix_fmt):
         self.pix_fmt = pix_fmt
@@ -89,11 +90,12 @@ class VideoGenerator:
         """camera name -> (H,W,3) images => (2H,3W,3): front_left | front | front_right over the three rear cameras."""
         handle = getattr(image_dict, "mosaic_handle", None)
         if callable(handle):
-            dev = handle(MOSAIC_ORDER)                 # already assembled in HBM by the overlay kernel: stays there
+            dev = handle(MOSAIC_ORDER)                 # already assembled in HBM by the overlay kernel
             if dev is not None:
-                # CAMA_EGRESS=bgr24 restores the reference's return type to the letter: a plain ndarray (cv2.* calls
-                # and other code that insists on a real ndarray), at the price of a 9 MB download per frame here
-                return np.asarray(dev) if os.environ.get("CAMA_EGRESS", "i420") == "bgr24" else dev
+                # default: the reference's return type to the letter, a plain ndarray (a view of the batch's pinned host
+                # copy); with the i420 opt-in the mosaic stays in HBM behind an ndarray-like handle
+                from . import runtime
+                return dev if runtime.egress_format() == "i420" else dev.ndarray()
         mosaic = getattr(image_dict, "mosaic", None)
         if callable(mosaic):
             ready = mosaic(MOSAIC_ORDER)
@@ -107,8 +109,10 @@ class VideoGenerator:
         pix_fmt = getattr(self, "pix_fmt", None) or ("bgr24" if getattr(self, "writer", None) is not None else None)
         i420 = getattr(image, "i420", None)
         planes = None
-        if callable(i420) and pix_fmt in (None, "yuv420p") and os.environ.get("CAMA_EGRESS", "i420") != "bgr24":
-            planes = i420()                             # pinned host bytes prepared behind the render; None = cannot
+        if callable(i420) and pix_fmt in (None, "yuv420p"):
+            from . import runtime
+            if runtime.egress_format() == "i420":
+                planes = i420()                         # pinned host bytes prepared behind the render; None = cannot
         if planes is not None:
             if self.writer is None:
                 self._start("yuv420p")

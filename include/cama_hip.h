@@ -19,7 +19,12 @@
  *   - return 0 on success; <0 on error: CAMA_EINVAL (bad argument, nothing was
  *     enqueued), CAMA_EHIP (a HIP call failed).  cama_last_error() returns a
  *     thread-local message for the most recent failure on the calling thread.
- *   - no global state: calls on distinct streams / buffers are thread-safe.
+ *   - thread-safety: calls on distinct streams / buffers may run concurrently.  The library keeps three pieces of
+ *     process-wide state, none of which can change a result: (i) the tuning options (cama_set_option; atomics, each
+ *     initialised once from its environment variable), (ii) the overlay's per-buffer-pair choice between two workgroup
+ *     orders (cama_overlay_mapping_info; a table behind a mutex, entries keyed by device and buffer addresses, its
+ *     pending timing events are destroyed whether or not their launch succeeded), (iii) per-THREAD profiling state
+ *     (cama_profile_*) and the per-thread last-error string.  A cama_pipeline is owned by one thread at a time.
  *   - matrices are row-major doubles.  world->chassis matrices are the float32
  *     np.linalg.inv result (cama/dataset.py:99) promoted to double on the host
  *     (exact), so one matrix type crosses the boundary.
@@ -339,11 +344,15 @@ int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const fl
  */
 int cama_probe_xcd_map(uint32_t *xcd_of_block, int32_t n_blocks, void *stream);
 
-/* Which workgroup -> band order do this process's big overlay launches (>= 1.75 GiB touched) use?  The library times the
- * contiguous order (31) against round-robin chunks of 32 bands (5) on the first such launches and keeps the faster one for
- * the life of the process (cama_hip.hip: MapTuner; speed only, the pixels never depend on it).  decided: -1 while measuring,
- * else 31 or 5 (or the value CAMA_OVERLAY_CHUNK_LOG2 forces); samples[2], ns_per_mb[2]: timings taken so far and the
- * best time per 10^6 bytes, [0] = contiguous, [1] = chunked.  Any pointer may be NULL.  (No reference counterpart.) */
+/* Which workgroup -> band order do big overlay launches (>= 1.75 GiB touched) use?  The speed of the XCD-contiguous order (31)
+ * depends on the buffers a launch walks (their physical placement: 0.75 .. 0.835 of 8 TB/s at 40 frames of 1600x900, the same
+ * for a given pair of buffers every time), that of round-robin chunks of 32 bands (5) does not (0.775 .. 0.79).  So the
+ * library times both on the first launches over each (frames, mosaic) pair -- three timings each, the launch's own start /
+ * stop events, no host synchronisation -- and keeps the faster median for that pair (cama_hip.hip: MapTuner; the 64 most
+ * recently used pairs per process; speed only, the pixels never depend on it).  This call reports the pair of the most
+ * recent big launch: decided: -1 while measuring, else 31 or 5 (or the value overlay_chunk_log2 forces); samples[2],
+ * ns_per_mb[2]: timings taken so far and their median time per 10^6 bytes, [0] = contiguous, [1] = chunked.  Any pointer
+ * may be NULL.  (No reference counterpart.) */
 int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per_mb);
 
 /* Process-wide tuning options: performance only -- no option can change a result (every one of them selects among orders /

@@ -27,18 +27,41 @@ class _FakeBatch:
 
 def test_egress_listeners_are_counted_across_a_rebind():
     """main.py rebinds `vg = VideoGenerator(...)` per dataset pass: the new generator's __init__ runs before the old one's
-    __del__ -> close().  The second generator must still find the I420 prefetch switched on."""
+    __del__ -> close().  The second generator must still find the host-copy prefetch switched on.  The format is the
+    reference's bgr24 unless CAMA_EGRESS / configs["egress"] opt into I420."""
     assert runtime.egress_mode() is None
     vg = VideoGenerator("a.mp4", sink=io.BytesIO())
-    assert runtime.egress_mode() == "i420"
+    assert runtime.egress_mode() == "bgr24"
     old = vg
     vg = VideoGenerator("b.mp4", sink=io.BytesIO())      # (the rebind: `old` is closed only afterwards)
     old.close()
-    assert runtime.egress_mode() == "i420"
+    assert runtime.egress_mode() == "bgr24"
     old.close()                                            # closing twice releases once
-    assert runtime.egress_mode() == "i420"
+    assert runtime.egress_mode() == "bgr24"
+    runtime.set_egress_format("i420")                      # what ClipManager does for configs["egress"] = "i420"
+    try:
+        assert runtime.egress_mode() == "i420"
+    finally:
+        runtime.set_egress_format(None)
     vg.close()
     assert runtime.egress_mode() is None
+
+
+def test_egress_format_comes_from_the_environment_or_the_configs(monkeypatch):
+    import pytest
+    assert runtime.egress_format() == "bgr24"              # default = the reference's stream
+    monkeypatch.setenv("CAMA_EGRESS", "i420")
+    assert runtime.egress_format() == "i420"
+    runtime.set_egress_format("bgr24")                     # an explicit choice beats the environment
+    try:
+        assert runtime.egress_format() == "bgr24"
+    finally:
+        runtime.set_egress_format(None)
+    monkeypatch.setenv("CAMA_EGRESS", "rgb565")
+    with pytest.raises(ValueError):
+        runtime.egress_format()
+    with pytest.raises(ValueError):
+        runtime.set_egress_format("rgb565")
 
 
 def test_device_mosaic_behaves_like_the_ndarray_once_touched():
@@ -57,7 +80,8 @@ def test_device_mosaic_behaves_like_the_ndarray_once_touched():
     assert m.tobytes() == np.asarray(m).tobytes() and m.astype(np.uint8).tobytes() == m.tobytes()
 
 
-def test_add_frame_writes_the_edited_host_bytes_into_an_i420_stream():
+def test_add_frame_writes_the_edited_host_bytes_into_an_i420_stream(monkeypatch):
+    monkeypatch.setenv("CAMA_EGRESS", "i420")              # the opt-in
     rng = np.random.default_rng(1)
     arr = rng.integers(0, 256, (2, 4, 32, 3), dtype=np.uint8)
     b = _FakeBatch(arr)
@@ -75,17 +99,61 @@ def test_add_frame_writes_the_edited_host_bytes_into_an_i420_stream():
         vg.close()
 
 
-def test_concate_image_returns_a_plain_ndarray_in_bgr24_mode(monkeypatch):
-    arr = np.zeros((1, 4, 32, 3), np.uint8)
+def test_concate_image_returns_a_plain_ndarray_by_default_and_the_stream_is_bgr24(monkeypatch):
+    rng = np.random.default_rng(2)
+    arr = rng.integers(0, 256, (1, 4, 32, 3), dtype=np.uint8)
+    batch = _FakeBatch(arr)
 
     class Frame(dict):
         def mosaic_handle(self, order=None):
-            return egress.DeviceMosaic(_FakeBatch(arr), 0)
-    monkeypatch.setenv("CAMA_EGRESS", "bgr24")
-    vg = VideoGenerator("x.mp4", sink=io.BytesIO())
+            return egress.DeviceMosaic(batch, 0)
+    monkeypatch.delenv("CAMA_EGRESS", raising=False)
+    sink = io.BytesIO()
+    vg = VideoGenerator("x.mp4", output_shape=(32, 4), sink=sink)
     try:
-        assert runtime.egress_mode() is None               # bgr24 mode never asks for the I420 prefetch
+        assert runtime.egress_mode() == "bgr24"
         out = vg.concate_image(Frame())
-        assert type(out) is np.ndarray and out.shape == (4, 32, 3)
+        assert type(out) is np.ndarray and out.shape == (4, 32, 3) and np.array_equal(out, arr[0])
+        vg.add_frame(out)
+        assert vg.pix_fmt == "bgr24" and sink.getvalue() == arr[0].tobytes() and batch.i420_calls == 0
     finally:
         vg.close()
+    # opt-in: the handle stays a DeviceMosaic and the stream is yuv420p
+    monkeypatch.setenv("CAMA_EGRESS", "i420")
+    sink = io.BytesIO()
+    vg = VideoGenerator("y.mp4", output_shape=(32, 4), sink=sink)
+    try:
+        out = vg.concate_image(Frame())
+        assert isinstance(out, egress.DeviceMosaic)
+        vg.add_frame(out)
+        assert vg.pix_fmt == "yuv420p" and sink.getvalue() == egress.bgr_to_i420_host(arr[0]).tobytes()
+    finally:
+        vg.close()
+
+
+def test_pinned_pool_keeps_a_buffer_out_of_circulation_while_views_of_it_live():
+    """bgr24 mode hands out ndarray VIEWS of a batch's pinned host copy; the pool must not give that buffer to the next
+    batch while a caller still holds one (main.py's `image` outlives the batch by one loop iteration)."""
+    class Buf:                                             # stands in for a pinned torch tensor
+        def __init__(self, n):
+            self.n = n
+
+        def numel(self):
+            return self.n
+    pool = egress.PinnedPool()
+    buf, rows = Buf(64), np.zeros((4, 16), np.uint8)
+    view = rows[2]
+    pool.give(buf, rows)
+    del rows
+    pool._sweep()
+    assert pool.free == {} and len(pool.limbo) == 1        # a view is out: parked
+    del view
+    pool._sweep()
+    assert pool.free[64] == [buf] and not pool.limbo       # view gone: back in circulation
+    rows2 = np.zeros((4, 16), np.uint8)
+    pool.give(Buf(32), rows2)                              # no view handed out: back as soon as the batch lets go of it
+    del rows2
+    pool._sweep()
+    assert len(pool.free[32]) == 1
+    pool.give(Buf(16))                                     # nothing went out at all (I420 planes are copied into the pipe)
+    assert len(pool.free[16]) == 1

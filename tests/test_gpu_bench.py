@@ -88,3 +88,40 @@ def test_bench_default_line_has_every_contract_field():
     # this process's own launches and settled on one of them
     om = line["overlay_mapping"]
     assert om["decided"] in (5, 31) and min(om["samples"]) >= 2 and min(om["ns_per_mb"]) > 0, om
+
+
+def test_bench_timed_path_that_renders_nothing_is_caught():
+    """the output buffers are poisoned between the warm-up and the timed region, so the hash check after
+    it can only pass on bytes the timed steps wrote.  Fault injection: the timed steps render nothing -> exit 3, no line."""
+    args = ["--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--sustain-seconds", "0"]
+    p, line = _run(args, {"CAMA_BENCH_FAULT": "skip_overlay"}, timeout=600)
+    assert p.returncode == 3 and line is None, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    assert "timed path's output differs" in p.stderr
+    # the same command without the fault prints its line (the poison itself breaks nothing)
+    p, line = _run(args, timeout=600)
+    assert p.returncode == 0 and line["hash_check"]["verified"] == 1, p.stderr[-1500:]
+    ro = line["roofline"]
+    assert 0.0 < ro["launch_ms_min"] <= ro["avg_launch_ms"] <= ro["launch_ms_max"]
+    assert line["scratch_bytes"] > 0
+
+
+def test_bench_frame_sharded_timed_path_is_checked_too():
+    """The frame-sharded (stress-shaped) job: same poison + fault, on the sampled frame positions."""
+    args = ["--map", "random", "--verts", "200000", "--frames", "48", "--shard-frames", "--height", "180", "--width", "320",
+            "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--sustain-seconds", "0"]
+    p, line = _run(args, {"CAMA_BENCH_FAULT": "skip_overlay"}, timeout=600)
+    assert p.returncode == 3 and line is None, (p.returncode, p.stderr[-1500:])
+    p, line = _run(args, timeout=600)
+    assert p.returncode == 0 and line is not None, p.stderr[-1500:]
+
+
+def test_bench_one_rank_rccl_group():
+    """the RCCL path of the bench inside the driver-run suite -- a 1-rank `nccl` process group
+    (init with device_id, barrier, the int64 all_gather_into_tensor of the report) on the box's one GPU."""
+    env = {"CAMA_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29517", "RANK": "0", "WORLD_SIZE": "1",
+           "LOCAL_RANK": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    p, line = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--sustain-seconds", "0"], env,
+                   timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert line["rccl_world"] == 1 and "RCCL" in line["collective"], line["collective"]
+    assert line["hash_check"]["verified"] == 1

@@ -270,7 +270,7 @@ def test_video_generator_sink_and_i420_stream(tmp_path):
     assert np.array_equal(bgr_to_i420_host(extremes), O.bgr_to_i420(extremes))
     buf = io.BytesIO()
     vg = VideoGenerator(str(tmp_path / "x.mp4"), (32, 8), sink=buf)
-    assert runtime.egress_mode() == "i420"              # announced itself to the render path
+    assert runtime.egress_mode() == "bgr24"             # announced itself to the render path; default = the reference's bytes
     vg.add_frame(a)
     assert vg.pix_fmt == "bgr24" and buf.getvalue() == a.tobytes()
     vg.close()
@@ -285,12 +285,16 @@ def test_video_generator_sink_and_i420_stream(tmp_path):
             return a
 
     buf = io.BytesIO()
-    vg = VideoGenerator(str(tmp_path / "y.mp4"), (32, 8), sink=buf)
-    vg.add_frame(Planes())
-    vg.add_frame(b)
-    assert vg.pix_fmt == "yuv420p"
-    assert buf.getvalue() == O.bgr_to_i420(a).tobytes() + O.bgr_to_i420(b).tobytes()
-    assert len(buf.getvalue()) == 2 * 8 * 32 * 3 // 2
-    assert runtime.egress_mode() == "i420"
-    vg.close()
-    assert runtime.egress_mode() is None                # the render path stops preparing I420 once the sink is closed
+    runtime.set_egress_format("i420")                   # the opt-in (configs["egress"] = "i420" / CAMA_EGRESS=i420)
+    try:
+        vg = VideoGenerator(str(tmp_path / "y.mp4"), (32, 8), sink=buf)
+        vg.add_frame(Planes())
+        vg.add_frame(b)
+        assert vg.pix_fmt == "yuv420p"
+        assert buf.getvalue() == O.bgr_to_i420(a).tobytes() + O.bgr_to_i420(b).tobytes()
+        assert len(buf.getvalue()) == 2 * 8 * 32 * 3 // 2
+        assert runtime.egress_mode() == "i420"
+        vg.close()
+    finally:
+        runtime.set_egress_format(None)
+    assert runtime.egress_mode() is None                # the render path stops preparing host copies once the sink is closed

@@ -22,9 +22,48 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 #define CA(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #x, r_, cama_last_error()); exit(1); } } while (0)
 
+// "vmm:<chunk MB>:<shuffle>": one virtual range backed by separate physical allocations of <chunk MB> each
+// (hipMemCreate), mapped in allocation order (shuffle 0), in a seeded random order (1) or reversed (2): what the physical
+// placement of a buffer's pieces does to the eight XCD streams, under this program's control.
+static unsigned g_seed = 12345;
+static void *alloc_vmm(size_t bytes, size_t chunk, int shuffle, size_t va_align)
+{
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t gran = 0;
+    CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t n = (bytes + chunk - 1) / chunk;
+    void *base = nullptr;
+    CK(hipMemAddressReserve(&base, n * chunk, va_align ? va_align : (2u << 20), nullptr, 0));
+    std::vector<hipMemGenericAllocationHandle_t> h(n);
+    for (size_t k = 0; k < n; ++k) CK(hipMemCreate(&h[k], chunk, &prop, 0));
+    std::vector<size_t> order(n);
+    for (size_t k = 0; k < n; ++k) order[k] = shuffle == 2 ? n - 1 - k : k;
+    if (shuffle == 1)
+        for (size_t k = n; k > 1; --k) {
+            g_seed = g_seed * 1664525u + 1013904223u;
+            std::swap(order[k - 1], order[(g_seed >> 8) % k]);
+        }
+    for (size_t k = 0; k < n; ++k) CK(hipMemMap((char *)base + k * chunk, chunk, 0, h[order[k]], 0));
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    CK(hipMemSetAccess(base, n * chunk, &acc, 1));
+    return base;
+}
+
 static void *alloc_dev(const char *kind, size_t bytes)
 {
     void *p = nullptr;
+    if (!strncmp(kind, "vmm", 3)) {
+        double mb = 2, va_mb = 0;
+        int shuffle = 0;
+        sscanf(kind, "vmm:%lf:%d:%lf", &mb, &shuffle, &va_mb);                 // vmm:<chunk MB>:<shuffle>[:<VA alignment MB>]
+        return alloc_vmm(bytes, (size_t)(mb * (1 << 20)), shuffle, (size_t)(va_mb * (1 << 20)));
+    }
     if (!strcmp(kind, "contig")) CK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous));
     else CK(hipMalloc(&p, bytes));
     return p;
@@ -65,8 +104,10 @@ int main(int argc, char **argv)
     while (pos < script.size()) {
         size_t end = script.find(',', pos);
         if (end == std::string::npos) end = script.size();
-        long order = -1, rot = 0, pf = 0, cold = 0;
-        sscanf(script.substr(pos, end - pos).c_str(), "%ld:%ld:%ld:%ld", &order, &rot, &pf, &cold);
+        long order = -1, rot = 0, pf = 0, cold = 0, io = 0, grp = 0;
+        sscanf(script.substr(pos, end - pos).c_str(), "%ld:%ld:%ld:%ld:%ld:%ld", &order, &rot, &pf, &cold, &io, &grp);
+        CA(cama_set_option("overlay_item_order", io));
+        CA(cama_set_option("overlay_groups_log2", grp));
         pos = end + 1;
         CA(cama_set_option("overlay_chunk_log2", order));
         CA(cama_set_option("overlay_tune", 0));
@@ -91,7 +132,7 @@ int main(int argc, char **argv)
         for (double v : ms) mean += v;
         mean /= reps;
         const double bytes = 2.0 * set_bytes;
-        printf("order %3ld rot %5ld pf %4ld %s  min %.4f med %.4f mean %.4f max %.4f ms   frac(med) %.3f frac(mean) %.3f\n", order, rot, pf,
+        printf("order %3ld grp %ld io %ld rot %5ld pf %4ld %s  min %.4f med %.4f mean %.4f max %.4f ms   frac(med) %.3f frac(mean) %.3f\n", order, grp, io, rot, pf,
                cold ? "cold" : "warm", so[0], so[reps / 2], mean, so[reps - 1], bytes / (so[reps / 2] * 1e-3) / 8e12,
                bytes / (mean * 1e-3) / 8e12);
         fflush(stdout);
