@@ -116,6 +116,11 @@ def parse_args(argv=None):
                     help="budget of the all-core CPU figure (process pool over scenes; 0 disables)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="workers of the all-core CPU figure (0 = every core "
                     "that fits the host memory)")
+    ap.add_argument("--plan", action="store_true",
+                    help="no GPU needed: print, as one JSON object, what every rank of `--gpus N` would hold -- its scenes, "
+                         "resident frame / mosaic / map bytes, stamp scratch (worst case and, for planned site-sized maps, "
+                         "the measured demand) -- against the HBM of one MI355X, and exit 0 (1 if a rank does not fit)")
+    ap.add_argument("--hbm-gb", type=float, default=288.0, help="--plan: HBM per GPU to plan against")
     ap.add_argument("--sustain-seconds", type=float, default=1.0,
                     help="after the K timed steps, run the same loop for at least this long and report it as "
                          "`sustained` (0 disables)")
@@ -571,14 +576,9 @@ class Job:
         return self.F / float(-(-self.F // per_call))                   # render_clip splits big clips into launches
 
     def scratch_bytes(self):
-        """Device bytes of stamp scratch this rank's engine holds (both pipeline slots + the single-stream buffer)."""
-        eng = self.eng
-        total = 0
-        pipe = getattr(eng, "_pipe", None)
-        for t in (list(pipe["scratch"]) if pipe else []) + [getattr(eng, "_scratch", None)]:
-            if t is not None:
-                total += int(t.numel())
-        return total
+        """Device bytes of stamp scratch this rank's engine holds (the pipeline's own demand-sized buffers + the
+        single-stream buffer)."""
+        return self.eng.scratch_bytes()
 
     def free(self):
         self.scenes, self.out, self.outs = [], None, None
@@ -626,8 +626,83 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def plan(args):
+    """`bench.py --gpus N --plan`: the memory every rank of the job needs, computed on the host (no GPU, no torch.cuda):
+    which scenes it gets (the same shard.assign_scenes / frame_ranges calls main() makes), what is resident in HBM during
+    the timed region, and the stamp scratch.  An 8-GPU node's first run must not die on memory."""
+    from cama_amd import _lib, shard
+    L = _lib.lib()                                    # host-side size functions of the library (no device call)
+    world = args.gpus
+    H, W, C = args.height, args.width, 6
+    frame_b = C * H * W * 3
+    n_scenes = args.scenes if args.scenes > 0 else (1 if (world == 1 or args.shard_frames) else SWEEP_SCENES)
+    cap = int(args.hbm_gb * 1e9)
+
+    def scratch(N, F, planned_demand=None):
+        """(worst-case bytes of ONE slot, what the pipeline will hold for its two slots)."""
+        worst = int(L.cama_render_scratch_bytes(int(N), int(F), C, H, W, 2))
+        if planned_demand is not None:
+            return worst, int(2 * planned_demand * F)
+        return worst, 2 * worst
+
+    ranks = []
+    if args.shard_frames:
+        parts = [[0]] * world
+        ranges = shard.frame_ranges(args.frames, world)
+    else:
+        cost = shard.scene_cost(args.frames, args.verts, W, H)
+        site_of = [site_of_scene(args, k) for k in range(n_scenes)] if args.sites > 0 else None
+        parts = shard.assign_scenes([cost] * n_scenes, world, site_of=site_of, site_cost=40.0 * args.verts)
+        ranges = [None] * world
+    site_like = args.map in ("site", "random") and args.verts >= 65536       # planned: pipeline-owned, demand-sized scratch
+    # measured demand of the planned stress map: ~5.5 MB of stamp scratch per frame and slot (profiles/r04_stress_*)
+    demand_per_frame = 8e6 * (args.verts / 1e6) if site_like else None
+    do_stress = world > 1 and not args.no_stress and not args.shard_frames and args.scenes == 0 and args.map == "lanes"
+    for r in range(world):
+        mine = parts[r]
+        if ranges[r] is not None:
+            lo, hi = ranges[r]
+            F = hi - lo
+            frames_res = F * frame_b
+            mosaics = F * frame_b
+            fpl = min(F, 128 if site_like else F)
+            worst, held = scratch(args.verts, fpl, demand_per_frame)
+        else:
+            F = args.frames
+            frames_res = len(mine) * (F + 1) * frame_b
+            batched = len(mine) > 1 and not args.no_scene_batch and not args.raw_frames and not site_like
+            mosaics = (len(mine) if batched else 1) * F * frame_b
+            fpl = len(mine) * F if batched else F
+            worst, held = scratch(args.verts, min(fpl, 16384), demand_per_frame)
+        maps = len({site_of_scene(args, k) for k in mine} if args.sites > 0 else mine) * args.verts * (13 + 16 + 48 // 64 + 1)
+        rec = {"rank": r, "scenes": list(mine), "frame_range": ranges[r], "resident_frames_bytes": frames_res,
+               "mosaic_bytes": mosaics, "map_bytes": maps, "frames_per_launch": fpl,
+               "scratch_worst_case_one_slot": worst, "scratch_held": held}
+        total = frames_res + mosaics + maps + held
+        if do_stress:                                               # runs after the sweep's buffers are freed
+            slo, shi = shard.frame_ranges(args.stress_frames, world)[r]
+            sF = shi - slo
+            sw, sh = int(L.cama_render_scratch_bytes(args.stress_verts, min(sF, 128), C, H, W, 2)), int(2 * 8e6 * (args.stress_verts / 1e6) * min(sF, 128))
+            stress_total = 2 * sF * frame_b + args.stress_verts * 30 + sh
+            rec["stress"] = {"frame_range": [slo, shi], "resident_frames_bytes": sF * frame_b, "mosaic_bytes": sF * frame_b,
+                             "scratch_worst_case_one_slot": sw, "scratch_held_planned": sh, "total_bytes": stress_total}
+            total = max(total, stress_total)
+        rec["total_bytes"] = total
+        rec["fits"] = total <= 0.92 * cap
+        ranks.append(rec)
+    out = {"plan": True, "gpus": world, "hbm_bytes_per_gpu": cap, "workload": args_key(args), "scenes": n_scenes,
+           "ranks": ranks, "fits": all(r["fits"] for r in ranks),
+           "note": "host arithmetic only: frames / mosaics / maps resident during the timed region + the stamp scratch the "
+                   "two pipeline slots hold (site-sized maps: demand-sized by the pipeline, ~8 MB per frame and 10^6 "
+                   "vertices measured; others: the worst case of cama_render_scratch_bytes)"}
+    print(json.dumps(out))
+    return 0 if out["fits"] else 1
+
+
 def main():
     args = parse_args()
+    if args.plan:
+        sys.exit(plan(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
     # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 -- RCCL prints a

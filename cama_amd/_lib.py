@@ -58,6 +58,10 @@ SIGNATURES = {
     "cama_pipeline_join": (_i32, [_vp, _vp]),
     "cama_pipeline_issued": (_i64, [_vp]),
     "cama_pipeline_completed": (_i64, [_vp]),
+    "cama_pipeline_scratch_bytes": (_i64, [_vp]),
+    "cama_pipeline_info": (_i32, [_vp, _vp]),
+    "cama_pipeline_bin_stats": (_i32, [_vp, _vp]),
+    "cama_pipeline_guard_check": (_i32, [_vp, _vp]),
     "cama_stamp_scratch_bytes": (_sz, [_i32, _i32]),
     "cama_stamp_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_probe_xcd_map": (_i32, [_vp, _i32, _vp]),

@@ -168,57 +168,103 @@ int log2i(int v)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Scratch of one launch = two parts (round 4):
+//   plan part   what the cull pre-pass writes and the chain reads: work-list / candidate counters, the camera masks, the work
+//               and candidate lists, the per-frame item counters and ranks.  Its size depends on (N, F, C) only.
+//   stamp part  band counters, segment counts, the per-wave compacted stamps (stamps0) and the band-sorted stamps.  Sized for
+//               the worst case -- every vertex visible in every camera: 24 B per (frame, camera, vertex) -- unless the launch
+//               was PLANNED: for site-sized maps the pre-pass knows, before the projection runs, how many (block, frame) items
+//               survive per frame and how many (wave, camera) chains they carry, which bounds both buffers exactly (BinPlan).
+// Callers that bring their own scratch (cama_render_frames & co.) get both parts in one buffer, plan part first, worst-case
+// sized.  A pipeline that owns its scratch (cama_pipeline_render* with scratch0 == NULL) keeps them apart and plans.
+struct BinPlan {
+    bool planned = false;
+    uint32_t nseg = 0;              // segments per (frame, camera): 4 x the largest number of surviving blocks of any frame
+    uint64_t capacity = 0;          // band entries the sorted list must hold: (wave, camera) chains x 64 x bands per stamp
+};
 struct ScratchLayout {
-    size_t counts, cursor, work_count, seg_cnt, bin_off, fc_total, fc_base, cam_mask, cam_fn, stamps0, stamps, work, list_cap, total;
-    size_t frame_box, cand;        // candidate pre-pass of site-sized maps: [F][6] world crop AABBs, [F * vblocks] items
+    // plan part (offsets from its base)
+    size_t work_count, cam_mask, cam_fn, work, work_rank, frame_box, cand, frame_items, demand, plan_zero_bytes, plan_total;
+    // stamp part (offsets from its base)
+    size_t counts, cursor, seg_cnt, bin_off, fc_total, fc_base, stamps0, stamps, stamp_total;
     size_t zero_bytes;              // counts .. seg_cnt: cleared by one memset before the projection pass
+    size_t list_cap;
+    size_t total;                   // both parts in one buffer: plan_total + stamp_total
     uint64_t capacity;
     uint32_t nseg;
+    bool planned;
     int R, NB, bands_per_stamp;
 };
 
-int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLayout &L)
+int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLayout &L, const BinPlan *plan = nullptr)
 {
     L.R = band_rows_for(W);
     L.NB = (H + L.R - 1) / L.R;
     L.bands_per_stamp = radius > 0 ? 2 : 1;  // 2r+1 rows touch <= 2 bands when 2r <= R (checked by the caller)
     const size_t nbins = (size_t)F * C * L.NB, nfc = (size_t)F * C;
-    L.capacity = (uint64_t)F * C * (uint64_t)N * L.bands_per_stamp;
-    L.nseg = (uint32_t)((N + BLOCK - 1) / BLOCK) * (BLOCK / SEG);   // one segment per wave of the projection grid
+    L.planned = plan && plan->planned;
+    L.capacity = L.planned ? plan->capacity : (uint64_t)F * C * (uint64_t)N * L.bands_per_stamp;
+    // one segment per wave of the projection grid; planned: per wave of a SURVIVING block of the frame (rank order)
+    L.nseg = L.planned ? plan->nseg : (uint32_t)((N + BLOCK - 1) / BLOCK) * (BLOCK / SEG);
+    // ---- plan part
+    // work lists of the crop cull: 8 (one per XCD), each up to ceil(vblocks / 8) * F uint32 items
+    L.list_cap = (size_t)(((N + BLOCK - 1) / BLOCK + 7) / 8) * (size_t)F;
     size_t off = 0;
+    L.work_count = off; off += 256;            // [0..7] work-list lengths, [8..15] candidate-list lengths, [16] "candidates ran"
+    L.frame_items = off; off = align_up(off + (size_t)F * 4, 256);     // surviving blocks per frame (rank counters)
+    L.demand = off; off += 256;                // [0] u64 (wave, camera) chains of the surviving blocks
+    L.plan_zero_bytes = off;                   // work_count .. demand: one memset before the pre-pass
+    L.cam_mask = off; off = align_up(off + (size_t)F * ((N + BLOCK - 1) / BLOCK) * 8, 256);   // per (frame, vertex block): 4 x u16
+    L.cam_fn = off; off = align_up(off + (size_t)CAMA_MAX_CAMERAS * 20 * 8, 256);
+    L.work = off;     off = align_up(off + 8 * L.list_cap * 4, 256);
+    L.work_rank = off; off = align_up(off + 8 * L.list_cap * 4, 256);  // rank of a listed block among its frame's survivors
+    // candidate pre-pass (k_block_candidates): per-frame world-space crop AABBs and the 8 (block, frame) candidate lists
+    L.frame_box = off; off = align_up(off + (size_t)F * 6 * 8, 256);
+    L.cand = off;     off = align_up(off + 8 * L.list_cap * 4, 256);             // 8 lists, like the work lists
+    L.plan_total = off;
+    // ---- stamp part
+    off = 0;
     L.counts = off;   off = align_up(off + nbins * 4, 256);
     L.cursor = off;   off = align_up(off + nbins * 4, 256);
-    L.work_count = off; off += 256;
     L.seg_cnt = off;  off = align_up(off + nfc * L.nseg, 256);      // one byte per (frame, camera, segment)
     L.zero_bytes = off - L.counts;
     L.bin_off = off;  off = align_up(off + nbins * 4, 256);
     L.fc_total = off; off = align_up(off + nfc * 4, 256);
     L.fc_base = off;  off = align_up(off + nfc * 4, 256);
-    L.cam_mask = off; off = align_up(off + (size_t)F * ((N + BLOCK - 1) / BLOCK) * 8, 256);   // per (frame, vertex block): 4 x u16
-    L.cam_fn = off; off = align_up(off + (size_t)CAMA_MAX_CAMERAS * 20 * 8, 256);
-    L.stamps0 = off;  off = align_up(off + nfc * L.nseg * SEG * 8 + 8, 256);   // compacted per-segment stamps (worst case)
+    L.stamps0 = off;  off = align_up(off + nfc * L.nseg * SEG * 8 + 8, 256);   // compacted per-segment stamps
     L.stamps = off;   off = align_up(off + (size_t)L.capacity * 8 + 8, 256);   // >= 1 record: empty bins read stamps[0]
-    // work lists of the crop cull: 8 (one per XCD), each up to ceil(vblocks / 8) * F uint32 items
-    L.list_cap = (size_t)(((N + BLOCK - 1) / BLOCK + 7) / 8) * (size_t)F;
-    L.work = off;     off = align_up(off + 8 * L.list_cap * 4, 256);
-    // candidate pre-pass (k_block_candidates): per-frame world-space crop AABBs and the 8 (block, frame) candidate lists;
-    // their counters are words CAND_COUNT_WORD .. +7 of the work_count block (cleared by the same memset), word +8 the
-    // "candidate pre-pass ran" mark
-    L.frame_box = off; off = align_up(off + (size_t)F * 6 * 8, 256);
-    L.cand = off;     off = align_up(off + 8 * L.list_cap * 4, 256);             // 8 lists, like the work lists
-    L.total = off;
+    L.stamp_total = off;
+    L.total = L.plan_total + L.stamp_total;
     return 0;
 }
 
-constexpr int CAND_COUNT_WORD = 8;     // work_count[0..7] = the 8 work lists' lengths
+// where a launch's two scratch parts live
+struct ScratchRef {
+    char *plan = nullptr, *stamp = nullptr;
+    size_t plan_bytes = 0, stamp_bytes = 0;
+    BinPlan bin_plan;
+};
+// a caller's single buffer: plan part first, worst-case sized (no plan)
+ScratchRef legacy_scratch(const void *scratch, size_t scratch_bytes, int64_t N, int F, int C, int H, int W, int radius)
+{
+    ScratchRef r;
+    if (!scratch || N < 0 || F < 0 || C < 1 || H < 1 || W < 1 || radius < 0) return r;
+    ScratchLayout L;
+    layout_scratch(N, F, C, H, W, radius, L);
+    r.plan = (char *)scratch;
+    r.plan_bytes = std::min(scratch_bytes, L.plan_total);
+    r.stamp = (char *)scratch + L.plan_total;
+    r.stamp_bytes = scratch_bytes > L.plan_total ? scratch_bytes - L.plan_total : 0;
+    return r;
+}
+
+constexpr int CAND_COUNT_WORD = 8;     // work_count[0..7] = the 8 work lists' lengths, [8..15] the candidate lists', [16] =
+                                       // "the candidate pre-pass ran" (cama_bin_stats)
 
 // (block, frame) items from which the crop cull goes through a work list + persistent workgroups; and how many of those
 // workgroups (256 CUs x 8 resident).  Env overrides are for A/B measurements only.
-uint64_t cull_list_threshold()
-{
-    static const uint64_t v = getenv("CAMA_CULL_LIST_MIN") ? strtoull(getenv("CAMA_CULL_LIST_MIN"), nullptr, 10) : 16384ull;
-    return v;
-}
+int64_t option(int k);
+uint64_t cull_list_threshold();
 // vertex blocks one projection workgroup runs: 1 until the launch has >= 16 k (block, frame) items, then as many as keep
 // ~16 k workgroups (64 per CU), at most 8.  CAMA_PROJECT_VB overrides (A/B).
 int project_blocks_per_workgroup(uint64_t items)
@@ -270,8 +316,10 @@ Option g_options[] = {
     {"overlay_item_order", "CAMA_OVERLAY_ITEM_ORDER", 0, {0}, {false}},    // 0 = camera column innermost, 1 = band innermost
     {"overlay_groups_log2", "CAMA_OVERLAY_GROUPS_LOG2", 0, {0}, {false}},  // 1 / 2: 2 / 4 XCD groups, chunked inside (with a
                                                                             // forced overlay_chunk_log2 < 31)
+    {"cull_list_min", "CAMA_CULL_LIST_MIN", 16384, {0}, {false}},          // (block, frame) items from which a site-sized
+                                                                            // map's cull goes through work lists
 };
-enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_COUNT };
+enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_CULL_LIST_MIN, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
 int64_t option(int k)
 {
@@ -283,6 +331,7 @@ int64_t option(int k)
     }
     return o.value.load(std::memory_order_relaxed);
 }
+uint64_t cull_list_threshold() { return (uint64_t)std::max<int64_t>(option(OPT_CULL_LIST_MIN), 0); }
 int overlay_forced_chunk_log2()
 {
     const int64_t forced = option(OPT_CHUNK_LOG2);
@@ -601,17 +650,19 @@ size_t cama_render_scratch_bytes(int64_t N, int32_t F, int32_t C, int32_t H, int
 }
 
 // validation shared by the bin / overlay halves of the fused render
-static int check_render(int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, int32_t radius, const void *scratch,
-                        size_t scratch_bytes, ScratchLayout &L)
+static int check_render(int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, int32_t radius, const ScratchRef &sc,
+                        ScratchLayout &L)
 {
     if (int rc = check_common(N, F, C, W, H)) return rc;
     if (radius < 0 || radius > CAMA_MAX_RADIUS) return fail(CAMA_EINVAL, "radius %d out of range", radius);
-    if (!scratch) return fail(CAMA_EINVAL, "scratch is NULL");
-    layout_scratch(N, F, C, H, W, radius, L);
-    if (scratch_bytes < L.total) return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", scratch_bytes, L.total);
+    if (!sc.plan || !sc.stamp) return fail(CAMA_EINVAL, "scratch is NULL");
+    layout_scratch(N, F, C, H, W, radius, L, &sc.bin_plan);
+    if (sc.plan_bytes < L.plan_total || sc.stamp_bytes < L.stamp_total)
+        return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", sc.plan_bytes + sc.stamp_bytes, L.total);
     if (L.capacity >= (1ull << 32))
-        return fail(CAMA_EINVAL, "F*C*N*%d = %llu stamps exceed 32-bit offsets: render fewer frames per call",
-                    L.bands_per_stamp, (unsigned long long)L.capacity);
+        return fail(CAMA_EINVAL, "%llu band entries exceed 32-bit offsets: render fewer frames per call",
+                    (unsigned long long)L.capacity);
+    if ((uint64_t)F * C * L.nseg >= (1ull << 32)) return fail(CAMA_EINVAL, "too many stamp segments: render fewer frames per call");
     if ((size_t)F * C * L.NB >= (1ull << 31)) return fail(CAMA_EINVAL, "too many bands");
     if (2 * radius > L.R)
         return fail(CAMA_EINVAL, "radius %d too large for the fused path (needs 2r <= band rows = %d)", radius, L.R);
@@ -619,6 +670,17 @@ static int check_render(int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, i
         return fail(CAMA_EINVAL, "C*bands = %d*%d exceeds the per-workgroup LDS histogram", C, L.NB);
     if (align_up((size_t)L.R * (W + 2 * radius) * 4, 16) > 160 * 1024) return fail(CAMA_EINVAL, "W=%d too wide for the LDS owner table", W);
     return CAMA_OK;
+}
+static int check_render(int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, int32_t radius, const void *scratch,
+                        size_t scratch_bytes, ScratchLayout &L)
+{
+    if (!scratch) return fail(CAMA_EINVAL, "scratch is NULL");
+    if (int rc = check_common(N, F, C, W, H)) return rc;
+    if (radius < 0 || radius > CAMA_MAX_RADIUS) return fail(CAMA_EINVAL, "radius %d out of range", radius);
+    const ScratchRef sc = legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius);
+    layout_scratch(N, F, C, H, W, radius, L);
+    if (scratch_bytes < L.total) return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", scratch_bytes, L.total);
+    return check_render(N, F, C, W, H, radius, sc, L);
 }
 
 int cama_map_bounds_block(void) { return 64; }      // one box per wave of the projection kernel
@@ -654,37 +716,117 @@ static bool ext_events()
 
 // cama_bin_frames / cama_bin_scenes.  scenes_dev != nullptr: multi-scene launch -- F counts ALL frames of the launch,
 // frames_per_scene of them per scene, N = the largest scene's vertex count, x .. K are ignored (per-scene, from the table).
-static int bin_impl(const SceneRef *scenes_dev, int frames_per_scene, const void *x, const void *y, const void *z,
-                    int32_t xyz_is_f64, const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds,
-                    int32_t flags, int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
-                    const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch, size_t scratch_bytes,
-                    void *stream)
-{
-    ScratchLayout L;
-    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
-    if (F == 0) return CAMA_OK;
-    if (!w2c || !crop || (!scenes_dev && (!c2cam || !K))) return fail(CAMA_EINVAL, "NULL pointer argument");
-    if (!scenes_dev && N && (!x || !y || !z || (!colour_id && !draw_key))) return fail(CAMA_EINVAL, "NULL vertex buffer");
+// Two halves: bin_prepass (the cull: camera masks, work lists, and what a PLANNED launch needs to size its stamp part) and
+// bin_main (projection, scans, scatter).  bin_impl = both on one stream, unplanned.
+struct BinCall {
+    const SceneRef *scenes_dev; int frames_per_scene;
+    const void *x, *y, *z; int32_t xyz_is_f64;
+    const uint8_t *colour_id; const uint32_t *draw_key; const double *block_bounds; int32_t flags;
+    int64_t N; const double *w2c; int32_t F; const double *c2cam, *K; int32_t C; const double *crop;
+    int32_t W, H, radius;
+};
 
-    hipStream_t s = (hipStream_t)stream;
-    char *base = (char *)scratch;
-    uint32_t *counts = (uint32_t *)(base + L.counts), *cursor = (uint32_t *)(base + L.cursor);
-    uint32_t *bin_off = (uint32_t *)(base + L.bin_off), *fc_total = (uint32_t *)(base + L.fc_total);
-    uint32_t *fc_base = (uint32_t *)(base + L.fc_base);
+// does this launch's cull go through work lists (site-sized maps) / the candidate pre-pass (what a plan needs)?
+static bool bin_uses_list(const BinCall &b)
+{
+    const unsigned vblocks = (unsigned)((b.N + BLOCK - 1) / BLOCK);
+    return b.N && b.block_bounds && !getenv("CAMA_NO_CAM_MASK") && (b.flags & CAMA_BIN_WORKLIST) &&
+           (uint64_t)vblocks * (uint64_t)b.F >= cull_list_threshold();
+}
+static bool bin_plannable(const BinCall &b) { return !b.scenes_dev && bin_uses_list(b) && !getenv("CAMA_NO_CANDIDATES"); }
+
+static int check_bin_call(const BinCall &b)
+{
+    if (!b.w2c || !b.crop || (!b.scenes_dev && (!b.c2cam || !b.K))) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (!b.scenes_dev && b.N && (!b.x || !b.y || !b.z || (!b.colour_id && !b.draw_key))) return fail(CAMA_EINVAL, "NULL vertex buffer");
+    return CAMA_OK;
+}
+
+// The cull pre-pass into the plan part `pbase` (layout L: only its plan offsets are used, so L may still be unplanned).
+static int bin_prepass(const BinCall &b, const ScratchLayout &L, char *pbase, hipStream_t s)
+{
+    if (b.F == 0) return CAMA_OK;
+    const int64_t N = b.N;
+    const int F = b.F, C = b.C;
+    uint32_t *work_count = (uint32_t *)(pbase + L.work_count), *work = (uint32_t *)(pbase + L.work);
+    // the work-list / candidate counters, the per-frame item counters and the demand word are adjacent: one memset
+    HIP_TRY(hipMemsetAsync(pbase + L.work_count, 0, L.plan_zero_bytes - L.work_count, s));
+    if (!(N && b.block_bounds && !getenv("CAMA_NO_CAM_MASK"))) return CAMA_OK;
+    const unsigned vblocks = (unsigned)((N + BLOCK - 1) / BLOCK);
+    const bool use_list = bin_uses_list(b);
+    const dim3 lgrid(persistent_workgroups());
+    Crop cr;
+    memcpy(cr.v, b.crop, sizeof(cr.v));
+    uint16_t *cam_mask = (uint16_t *)(pbase + L.cam_mask);
+    const uint32_t nsub = (uint32_t)((N + 63) / 64);
+    const dim3 cgrid((4 * vblocks + BLOCK - 1) / BLOCK, (unsigned)F);
+    double *cam_fn = (double *)(pbase + L.cam_fn);
+    // site-sized maps: a six-comparison world-space test first, the exact tests on the compacted candidates only
+    const bool use_cand = use_list && !getenv("CAMA_NO_CANDIDATES");
+    double *frame_box = (double *)(pbase + L.frame_box);
+    const unsigned fn_threads = CAMA_MAX_CAMERAS * 20 <= 256 ? 256 : 512;
+    hipLaunchKernelGGL(k_camera_functionals, dim3(use_cand ? 1 + ((unsigned)F + fn_threads - 1) / fn_threads : 1),
+                       dim3(fn_threads), 0, s, b.c2cam, b.K, C, b.W, b.H, cam_fn, b.w2c, (uint32_t)F, cr, frame_box);
+    if (use_cand) {
+        uint32_t *cand_count = work_count + CAND_COUNT_WORD, *cand = (uint32_t *)(pbase + L.cand);
+        const dim3 kgrid(cgrid.x, ((unsigned)F + CAND_FRAMES - 1) / CAND_FRAMES);
+        hipLaunchKernelGGL(k_block_candidates, kgrid, dim3(BLOCK), 0, s, b.block_bounds, frame_box, (uint32_t)F, vblocks, nsub,
+                           (uint32_t)L.list_cap, cand_count, cand);
+        hipLaunchKernelGGL(k_candidate_cameras, lgrid, dim3(BLOCK), 0, s, b.block_bounds, b.w2c, cam_fn, C, cr, vblocks, nsub,
+                           cand_count, cand, cam_mask, (uint32_t)L.list_cap, work_count, work,
+                           (uint32_t *)(pbase + L.frame_items), (uint32_t *)(pbase + L.work_rank),
+                           (unsigned long long *)(pbase + L.demand));
+    } else if (use_list)
+        hipLaunchKernelGGL(k_block_cameras<true>, cgrid, dim3(BLOCK), 0, s, b.block_bounds, b.w2c, cam_fn, C, cr, vblocks, nsub,
+                           cam_mask, (uint32_t)L.list_cap, work_count, work);
+    else
+        hipLaunchKernelGGL(k_block_cameras<false>, cgrid, dim3(BLOCK), 0, s, b.block_bounds, b.w2c, cam_fn, C, cr, vblocks, nsub,
+                           cam_mask, (uint32_t)L.list_cap, work_count, work);
+    HIP_TRY(hipGetLastError());
+#ifdef ABL_MASK_STATS
+    if (use_cand) {
+        uint32_t wc[32];
+        hipStreamSynchronize(s);
+        hipMemcpy(wc, work_count, sizeof(wc), hipMemcpyDeviceToHost);
+        uint32_t listed = 0, cands = 0;
+        for (int l = 0; l < 8; ++l) listed += wc[l], cands += wc[CAND_COUNT_WORD + l];
+        fprintf(stderr, "[cand stats] %u (block, frame) items: %u candidates, %u listed\n", vblocks * F, cands, listed);
+    } else {
+        std::vector<uint64_t> hm((size_t)vblocks * F);
+        hipStreamSynchronize(s);
+        hipMemcpy(hm.data(), (const void *)cam_mask, hm.size() * 8, hipMemcpyDeviceToHost);
+        uint64_t bits = 0, zero = 0;
+        for (uint64_t m : hm) { bits += __builtin_popcountll(m); zero += m == 0; }
+        fprintf(stderr, "[mask stats] %zu (block, frame) items: %.3f cameras per wave, %.3f of the blocks empty\n", hm.size(),
+                (double)bits / hm.size() / 4, (double)zero / hm.size());
+    }
+#endif
+    return CAMA_OK;
+}
+
+// projection -> scans -> scatter, out of the plan part `pbase` into the stamp part `sbase` (layout L, planned or not)
+static int bin_main(const BinCall &b, const ScratchLayout &L, char *pbase, char *sbase, hipStream_t s)
+{
+    if (b.F == 0) return CAMA_OK;
+    const int64_t N = b.N;
+    const int F = b.F, C = b.C, W = b.W, H = b.H, radius = b.radius;
+    uint32_t *counts = (uint32_t *)(sbase + L.counts), *cursor = (uint32_t *)(sbase + L.cursor);
+    uint32_t *bin_off = (uint32_t *)(sbase + L.bin_off), *fc_total = (uint32_t *)(sbase + L.fc_total);
+    uint32_t *fc_base = (uint32_t *)(sbase + L.fc_base);
     const int nfc = F * C;
 
-    // counts, cursor, the work-list counter and the segment count table are adjacent: one memset
+    // counts, cursor and the segment count table are adjacent: one memset
     if (!g_skip_bin_memset) HIP_TRY(hipMemsetAsync(counts, 0, L.zero_bytes, s));
 
     FrameArgs a{};
-    a.scenes = scenes_dev; a.frames_per_scene = frames_per_scene;
-    a.x = x; a.y = y; a.z = z; a.colour = colour_id; a.key = draw_key; a.bounds = block_bounds; a.N = N;
-    a.w2c = w2c; a.c2cam = c2cam; a.K = K; a.C = C; a.W = W; a.H = H;
-    memcpy(a.crop.v, crop, sizeof(a.crop.v));
+    a.scenes = b.scenes_dev; a.frames_per_scene = b.frames_per_scene;
+    a.x = b.x; a.y = b.y; a.z = b.z; a.colour = b.colour_id; a.key = b.draw_key; a.bounds = b.block_bounds; a.N = N;
+    a.w2c = b.w2c; a.c2cam = b.c2cam; a.K = b.K; a.C = C; a.W = W; a.H = H;
+    memcpy(a.crop.v, b.crop, sizeof(a.crop.v));
     a.band_shift = log2i(L.R); a.NB = L.NB; a.radius = radius;
-    a.nseg = L.nseg; a.seg_cnt = (uint8_t *)(base + L.seg_cnt); a.stamps0 = (uint2 *)(base + L.stamps0);
+    a.nseg = L.nseg; a.seg_cnt = (uint8_t *)(sbase + L.seg_cnt); a.stamps0 = (uint2 *)(sbase + L.stamps0);
     a.counts = counts; a.cursor = cursor; a.bin_off = bin_off; a.fc_base = fc_base;
-    a.stamps = (uint2 *)(base + L.stamps);
+    a.stamps = (uint2 *)(sbase + L.stamps);
     // XCD-aware mapping: workgroup (x, y) has linear id x + y * gridDim.x and runs on XCD id % 8.  With gridDim.x a
     // multiple of 8, vertex chunk x is processed on the SAME XCD for every frame y, so on big maps each XCD's 4 MB L2
     // keeps its 1/8 of the vertex buffer across all frames instead of re-fetching it per frame (padding workgroups
@@ -696,60 +838,18 @@ static int bin_impl(const SceneRef *scenes_dev, int frames_per_scene, const void
     const unsigned vchunks = (vblocks + vb_per_wg - 1) / vb_per_wg;
     const dim3 fgrid(getenv("CAMA_NO_XCD_PAD") ? vchunks : ((vchunks + 7u) & ~7u), (unsigned)F);
     const size_t hist_lds = align_up((size_t)C * L.NB * 4, 16);
-    // With the map's spatial index (block AABBs) a one-thread-per-(block, frame) pre-pass decides which cameras can see
-    // each block at all (k_block_cameras); the projection skips the others.  Site-sized maps (CAMA_BIN_WORKLIST: most
+    // With the map's spatial index (block AABBs) a one-thread-per-(block, frame) pre-pass decided which cameras can see
+    // each block at all (bin_prepass); the projection skips the others.  Site-sized maps (CAMA_BIN_WORKLIST: most
     // blocks are outside the crop box on any frame) additionally go through work lists + persistent workgroups: an empty
     // workgroup still costs ~0.8 ns of dispatch, 1.25 M of them = 1 ms.
-    const bool use_list = block_bounds && (flags & CAMA_BIN_WORKLIST) && (uint64_t)vblocks * (uint64_t)F >= cull_list_threshold();
-    uint32_t *work_count = (uint32_t *)(base + L.work_count), *work = (uint32_t *)(base + L.work);
+    const bool use_list = bin_uses_list(b);
+    if (L.planned && !bin_plannable(b)) return fail(CAMA_EINVAL, "a planned layout needs the candidate pre-pass");
+    uint32_t *work_count = (uint32_t *)(pbase + L.work_count), *work = (uint32_t *)(pbase + L.work);
+    const uint32_t *work_rank = L.planned ? (const uint32_t *)(pbase + L.work_rank) : nullptr;
     const dim3 lgrid(persistent_workgroups());
-    if (N && block_bounds && !getenv("CAMA_NO_CAM_MASK")) {
-        Crop cr;
-        memcpy(cr.v, crop, sizeof(cr.v));
-        uint16_t *cam_mask = (uint16_t *)(base + L.cam_mask);
-        const uint32_t nsub = (uint32_t)((N + 63) / 64);
-        const dim3 cgrid((4 * vblocks + BLOCK - 1) / BLOCK, (unsigned)F);
-        double *cam_fn = (double *)(base + L.cam_fn);
-        // site-sized maps: a six-comparison world-space test first, the exact tests on the compacted candidates only
-        const bool use_cand = use_list && !getenv("CAMA_NO_CANDIDATES");
-        double *frame_box = (double *)(base + L.frame_box);
-        const unsigned fn_threads = CAMA_MAX_CAMERAS * 20 <= 256 ? 256 : 512;
-        hipLaunchKernelGGL(k_camera_functionals, dim3(use_cand ? 1 + ((unsigned)F + fn_threads - 1) / fn_threads : 1),
-                           dim3(fn_threads), 0, s, c2cam, K, C, W, H, cam_fn, w2c, (uint32_t)F, cr, frame_box);
-        if (use_cand) {
-            uint32_t *cand_count = work_count + CAND_COUNT_WORD, *cand = (uint32_t *)(base + L.cand);
-            const dim3 kgrid(cgrid.x, ((unsigned)F + CAND_FRAMES - 1) / CAND_FRAMES);
-            hipLaunchKernelGGL(k_block_candidates, kgrid, dim3(BLOCK), 0, s, block_bounds, frame_box, (uint32_t)F, vblocks, nsub,
-                               (uint32_t)L.list_cap, cand_count, cand);
-            hipLaunchKernelGGL(k_candidate_cameras, lgrid, dim3(BLOCK), 0, s, block_bounds, w2c, cam_fn, C, cr, vblocks, nsub,
-                               cand_count, cand, cam_mask, (uint32_t)L.list_cap, work_count, work);
-        } else if (use_list)
-            hipLaunchKernelGGL(k_block_cameras<true>, cgrid, dim3(BLOCK), 0, s, block_bounds, w2c, cam_fn, C, cr, vblocks, nsub,
-                               cam_mask, (uint32_t)L.list_cap, work_count, work);
-        else
-            hipLaunchKernelGGL(k_block_cameras<false>, cgrid, dim3(BLOCK), 0, s, block_bounds, w2c, cam_fn, C, cr, vblocks, nsub,
-                               cam_mask, (uint32_t)L.list_cap, work_count, work);
-        HIP_TRY(hipGetLastError());
-        a.cam_mask = (const uint64_t *)cam_mask;
+    if (N && b.block_bounds && !getenv("CAMA_NO_CAM_MASK")) {
+        a.cam_mask = (const uint64_t *)(pbase + L.cam_mask);
         a.vblocks = vblocks;
-#ifdef ABL_MASK_STATS
-        if (use_cand) {
-            uint32_t wc[16];
-            hipStreamSynchronize(s);
-            hipMemcpy(wc, work_count, sizeof(wc), hipMemcpyDeviceToHost);
-            uint32_t listed = 0, cands = 0;
-            for (int l = 0; l < 8; ++l) listed += wc[l], cands += wc[CAND_COUNT_WORD + l];
-            fprintf(stderr, "[cand stats] %u (block, frame) items: %u candidates, %u listed\n", vblocks * F, cands, listed);
-        } else {
-            std::vector<uint64_t> hm((size_t)vblocks * F);
-            hipStreamSynchronize(s);
-            hipMemcpy(hm.data(), (const void *)cam_mask, hm.size() * 8, hipMemcpyDeviceToHost);
-            uint64_t bits = 0, zero = 0;
-            for (uint64_t m : hm) { bits += __builtin_popcountll(m); zero += m == 0; }
-            fprintf(stderr, "[mask stats] %zu (block, frame) items: %.3f cameras per wave, %.3f of the blocks empty\n", hm.size(),
-                    (double)bits / hm.size() / 4, (double)zero / hm.size());
-        }
-#endif
     }
     // live timing (cama_profile_enable): the projection takes an event pair as its own start / stop events
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
@@ -759,15 +859,15 @@ static int bin_impl(const SceneRef *scenes_dev, int frames_per_scene, const void
         if (!pe0 || !pe1) pe0 = pe1 = nullptr;
     }
     if (N && use_list && a.cam_mask) {
-        if (xyz_is_f64)
+        if (b.xyz_is_f64)
             hipExtLaunchKernelGGL(k_frames_project_list<double>, lgrid, dim3(BLOCK), (uint32_t)hist_lds, s, pe0, pe1, 0u, a,
-                                  work_count, work, vblocks, (uint32_t)L.list_cap);
+                                  work_count, work, vblocks, (uint32_t)L.list_cap, work_rank);
         else
             hipExtLaunchKernelGGL(k_frames_project_list<float>, lgrid, dim3(BLOCK), (uint32_t)hist_lds, s, pe0, pe1, 0u, a,
-                                  work_count, work, vblocks, (uint32_t)L.list_cap);
+                                  work_count, work, vblocks, (uint32_t)L.list_cap, work_rank);
         HIP_TRY(hipGetLastError());
     } else if (N) {
-        if (xyz_is_f64)
+        if (b.xyz_is_f64)
             hipExtLaunchKernelGGL(k_frames_project<double>, fgrid, dim3(BLOCK), (uint32_t)hist_lds, s, pe0, pe1, 0u, a, vb_per_wg);
         else
             hipExtLaunchKernelGGL(k_frames_project<float>, fgrid, dim3(BLOCK), (uint32_t)hist_lds, s, pe0, pe1, 0u, a, vb_per_wg);
@@ -791,6 +891,23 @@ static int bin_impl(const SceneRef *scenes_dev, int frames_per_scene, const void
     return CAMA_OK;
 }
 
+static int bin_impl(const SceneRef *scenes_dev, int frames_per_scene, const void *x, const void *y, const void *z,
+                    int32_t xyz_is_f64, const uint8_t *colour_id, const uint32_t *draw_key, const double *block_bounds,
+                    int32_t flags, int64_t N, const double *w2c, int32_t F, const double *c2cam, const double *K, int32_t C,
+                    const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch, size_t scratch_bytes,
+                    void *stream)
+{
+    ScratchLayout L;
+    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+    if (F == 0) return CAMA_OK;
+    const BinCall b{scenes_dev, frames_per_scene, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K,
+                    C, crop, W, H, radius};
+    if (int rc = check_bin_call(b)) return rc;
+    char *pbase = (char *)scratch, *sbase = (char *)scratch + L.plan_total;
+    if (int rc = bin_prepass(b, L, pbase, (hipStream_t)stream)) return rc;
+    return bin_main(b, L, pbase, sbase, (hipStream_t)stream);
+}
+
 extern "C" {
 
 int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
@@ -806,17 +923,18 @@ int cama_bin_frames(const void *x, const void *y, const void *z, int32_t xyz_is_
 // Diagnostic read-back of what a finished cama_bin_frames left in `scratch` (blocks the host on `stream`): how much of the
 // vertex buffer the projection actually read and how many stamps it produced -- the figures bench.py prices the
 // projection's roofline with.
-int cama_bin_stats(const void *scratch, size_t scratch_bytes, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
-                   int32_t radius, int32_t had_block_bounds, uint64_t *out, void *stream)
+}  // extern "C"
+
+static int bin_stats_impl(const ScratchRef &sc, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W, int32_t radius,
+                          int32_t had_block_bounds, uint64_t *out, hipStream_t s)
 {
     ScratchLayout L;
-    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+    if (int rc = check_render(N, F, C, W, H, radius, sc, L)) return rc;
     if (!out) return fail(CAMA_EINVAL, "out is NULL");
     out[0] = out[1] = out[2] = out[3] = 0;
     if (F == 0) return CAMA_OK;
-    hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipStreamSynchronize(s));
-    const char *base = (const char *)scratch;
+    const char *base = sc.plan, *sbase = sc.stamp;
     const size_t nfc = (size_t)F * C;
     const uint64_t vblocks = (uint64_t)((N + BLOCK - 1) / BLOCK), waves = (uint64_t)((N + 63) / 64);
     if (had_block_bounds && N && !getenv("CAMA_NO_CAM_MASK")) {
@@ -845,13 +963,24 @@ int cama_bin_stats(const void *scratch, size_t scratch_bytes, int64_t N, int32_t
         out[1] = waves * (uint64_t)F * (uint64_t)C;
     }
     std::vector<uint32_t> tot(nfc);
-    HIP_TRY(hipMemcpy(tot.data(), base + L.fc_total, nfc * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tot.data(), sbase + L.fc_total, nfc * 4, hipMemcpyDeviceToHost));
     for (uint32_t v : tot) out[3] += v;                 // band entries = what the overlay reads
     // stamps = non-empty entries of the compacted segments
     std::vector<uint8_t> seg(nfc * L.nseg);
-    HIP_TRY(hipMemcpy(seg.data(), base + L.seg_cnt, seg.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(seg.data(), sbase + L.seg_cnt, seg.size(), hipMemcpyDeviceToHost));
     for (uint8_t v : seg) out[2] += v;
     return CAMA_OK;
+}
+
+extern "C" {
+
+int cama_bin_stats(const void *scratch, size_t scratch_bytes, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                   int32_t radius, int32_t had_block_bounds, uint64_t *out, void *stream)
+{
+    ScratchLayout L;
+    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+    return bin_stats_impl(legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius), N, F, C, H, W, radius, had_block_bounds,
+                          out, (hipStream_t)stream);
 }
 
 thread_local uint32_t g_next_alpha256 = 256u;
@@ -867,11 +996,11 @@ struct RawSource {
 
 static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosaic, int64_t N, int32_t F, int32_t C,
                         int32_t H, int32_t W, int32_t cols, int32_t radius, const int32_t *halfwidth,
-                        const uint8_t *palette_bgr, const void *scratch, size_t scratch_bytes, void *stream,
+                        const uint8_t *palette_bgr, const ScratchRef &sc, void *stream,
                         const cama_scene *scenes_host = nullptr, int frames_per_scene = 0)
 {
     ScratchLayout L;
-    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+    if (int rc = check_render(N, F, C, W, H, radius, sc, L)) return rc;
     if (F == 0) return CAMA_OK;
     if (cols < 1) return fail(CAMA_EINVAL, "cols=%d", cols);
     const bool scenes_dev = scenes_host != nullptr;         // multi-scene launch (image pointers travel in the kernel arguments)
@@ -897,7 +1026,7 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     if (radius > 7) return fail(CAMA_EINVAL, "radius %d: the fused overlay supports radius <= 7", radius);
     const size_t lds = align_up((size_t)L.R * (W + 2 * radius) * 4, 16) + lds_pad;
     hipStream_t s = (hipStream_t)stream;
-    const char *base = (const char *)scratch;
+    const char *base = sc.stamp;              // the overlay reads the stamp part only
 
     OverlayArgs o{};
     o.f0 = 0;
@@ -1055,8 +1184,8 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
                         int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
                         const void *scratch, size_t scratch_bytes, void *stream)
 {
-    return overlay_impl(src, nullptr, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
-                        scratch_bytes, stream);
+    return overlay_impl(src, nullptr, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr,
+                        legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius), stream);
 }
 
 int cama_overlay_frames_alpha(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
@@ -1065,8 +1194,8 @@ int cama_overlay_frames_alpha(const uint8_t *src, uint8_t *mosaic, int64_t N, in
 {
     if (alpha256 < 0 || alpha256 > 256) return fail(CAMA_EINVAL, "alpha256=%d out of range [0, 256]", alpha256);
     g_next_alpha256 = (uint32_t)alpha256;
-    const int rc = overlay_impl(src, nullptr, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
-                                scratch_bytes, stream);
+    const int rc = overlay_impl(src, nullptr, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr,
+                                legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius), stream);
     g_next_alpha256 = 256u;
     return rc;
 }
@@ -1079,8 +1208,8 @@ int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const fl
                             size_t scratch_bytes, void *stream)
 {
     const RawSource rs{H0, W0, mapx, mapy, separable, band_src_rows, max_src_rows, tile_src_bytes, tiles_x, max_tile_bytes};
-    return overlay_impl(raw, &rs, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch, scratch_bytes,
-                        stream);
+    return overlay_impl(raw, &rs, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr,
+                        legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius), stream);
 }
 
 // cvRound(v * 32) as cv2.remap's fixed-point path does on float32 maps (round half to even)
@@ -1134,13 +1263,15 @@ int cama_raw35_plan(const float *mapx, const float *mapy, int32_t C, int32_t H, 
     return 1;
 }
 
-int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t *vrows, const int32_t *band_rows,
-                              int32_t max_src_rows, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
-                              int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
-                              const void *scratch, size_t scratch_bytes, void *stream)
+}  // extern "C"
+
+static int raw35_impl(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t *vrows, const int32_t *band_rows,
+                      int32_t max_src_rows, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                      int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                      const ScratchRef &sc, void *stream)
 {
     ScratchLayout L;
-    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+    if (int rc = check_render(N, F, C, W, H, radius, sc, L)) return rc;
     if (F == 0) return CAMA_OK;
     if (cols < 1) return fail(CAMA_EINVAL, "cols=%d", cols);
     if (!raw || !vrows || !band_rows || !mosaic || !palette_bgr) return fail(CAMA_EINVAL, "NULL pointer argument");
@@ -1154,7 +1285,7 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     Disc disc;
     if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
     hipStream_t s = (hipStream_t)stream;
-    const char *base = (const char *)scratch;
+    const char *base = sc.stamp;
     OverlayArgs o{};
     o.src = raw; o.mosaic = mosaic; o.C = C; o.H = H; o.W = W; o.cols = cols; o.R = L.R; o.NB = L.NB;
     const int rows = (C + cols - 1) / cols;
@@ -1219,6 +1350,19 @@ int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const 
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) g_prof.pending.emplace_back(ev0, ev1);
     return CAMA_OK;
+}
+
+extern "C" {
+
+int cama_overlay_frames_raw35(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t *vrows, const int32_t *band_rows,
+                              int32_t max_src_rows, uint8_t *mosaic, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
+                              int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                              const void *scratch, size_t scratch_bytes, void *stream)
+{
+    ScratchLayout L;
+    if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+    return raw35_impl(raw, H0, W0, vrows, band_rows, max_src_rows, mosaic, N, F, C, H, W, cols, radius, halfwidth, palette_bgr,
+                      legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius), stream);
 }
 
 int cama_render_frames(const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
@@ -1325,6 +1469,17 @@ struct cama_pipeline {
     // buffer per scratch slot: no per-call pose tensor on the caller's side, the upload rides on the binning stream
     double *pose_host = nullptr, *pose_dev[2] = {nullptr, nullptr};
     size_t pose_cap = 0;                        // doubles per slot
+    // scratch the pipeline owns (cama_pipeline_render* with scratch0 == NULL): per slot a plan part and a stamp part, grown
+    // on demand and never shrunk; the stamp part carries `guard` pattern bytes on either side (cama_pipeline_guard_check)
+    char *own_plan[2] = {nullptr, nullptr}, *own_stamp[2] = {nullptr, nullptr};
+    size_t own_plan_bytes[2] = {0, 0}, own_stamp_bytes[2] = {0, 0};
+    static constexpr size_t GUARD = (size_t)1 << 20;
+    uint64_t *demand_host = nullptr;            // pinned: [0] (wave, camera) chains, [1..] surviving blocks per frame
+    size_t demand_cap = 0;                      // uint64 words
+    // what the last launch of each slot looked like (cama_pipeline_bin_stats)
+    struct Last { ScratchRef sc; int64_t N = 0; int32_t F = 0, C = 0, H = 0, W = 0, radius = 0; bool bounds = false; } last[2];
+    int last_slot = -1;
+    uint64_t planned_launches = 0, grows = 0;
 };
 
 int cama_pipeline_create(cama_pipeline **out)
@@ -1364,8 +1519,12 @@ int cama_pipeline_destroy(cama_pipeline *p)
     for (int k = 0; k < cama_pipeline::RING; ++k)
         if (p->done[k]) (void)hipEventDestroy(p->done[k]);
     if (p->pose_host) (void)hipHostFree(p->pose_host);
-    for (int k = 0; k < 2; ++k)
+    if (p->demand_host) (void)hipHostFree(p->demand_host);
+    for (int k = 0; k < 2; ++k) {
         if (p->pose_dev[k]) (void)hipFree(p->pose_dev[k]);
+        if (p->own_plan[k]) (void)hipFree(p->own_plan[k]);
+        if (p->own_stamp[k]) (void)hipFree(p->own_stamp[k] - cama_pipeline::GUARD);
+    }
     delete p;
     return CAMA_OK;
 }
@@ -1430,37 +1589,117 @@ int64_t cama_pipeline_completed(cama_pipeline *p)
 
 }  // extern "C"
 
-// shared body of the pipelined renders: bin on s_bin, then `overlay(scratch, stream)` on s_ov
+// grow one of the pipeline's own buffers (rare; the old one may still be read by the overlay that last used the slot)
+static int pipeline_grow(cama_pipeline *p, char **buf, size_t *have, size_t need, bool guarded, uint64_t k)
+{
+    if (*have >= need) return CAMA_OK;
+    constexpr uint64_t RING = cama_pipeline::RING;
+    if (k > 2) HIP_TRY(hipEventSynchronize(p->done[(k - 2) % RING]));     // the previous user of this slot is over
+    HIP_TRY(hipStreamSynchronize(p->s_bin));
+    const size_t g = guarded ? cama_pipeline::GUARD : 0;
+    if (*buf) HIP_TRY(hipFree(*buf - g));
+    *buf = nullptr;
+    *have = 0;
+    // a quarter of headroom: consecutive launches of a drive need about the same, a little more or less
+    const size_t bytes = align_up(need + need / 4, (size_t)2 << 20);
+    char *raw = nullptr;
+    const hipError_t e = hipMalloc((void **)&raw, bytes + 2 * g);
+    if (e != hipSuccess)
+        return fail(CAMA_EHIP, "hipMalloc of %zu bytes of pipeline scratch -> %s", bytes + 2 * g, hipGetErrorString(e));
+    if (g) {
+        HIP_TRY(hipMemsetAsync(raw, 0x5A, g, p->s_bin));
+        HIP_TRY(hipMemsetAsync(raw + g + bytes, 0x5A, g, p->s_bin));
+    }
+    *buf = raw + g;
+    *have = bytes;
+    ++p->grows;
+    return CAMA_OK;
+}
+
+// shared body of the pipelined renders: bin on s_bin, then `overlay(scratch, stream)` on s_ov.
+// scratch0 == NULL: the pipeline's own scratch.  `plan_call` (may be NULL) describes the binning half: when it can be planned
+// (site-sized map + block index: bin_plannable) the cull pre-pass runs first, the host waits for its two demand figures --
+// a few tens of microseconds behind the previous launch's chain, while the overlays of earlier launches keep the GPU busy --
+// and the stamp part is sized from them instead of from the worst case.
 template <typename Bin, typename Overlay>
 static int pipeline_impl(cama_pipeline *p, int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, int32_t radius,
                          void *scratch0, void *scratch1, size_t scratch_bytes, void *input_stream,
-                         bool overlay_takes_stop_event, Bin bin, Overlay overlay)
+                         bool overlay_takes_stop_event, const BinCall *plan_call, Bin bin, Overlay overlay)
 {
     if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
-    if (!scratch0 || !scratch1) return fail(CAMA_EINVAL, "two scratch buffers are needed");
+    const bool managed = !scratch0 && !scratch1;
+    if (!managed && (!scratch0 || !scratch1)) return fail(CAMA_EINVAL, "two scratch buffers are needed (or none: pipeline-owned)");
     constexpr uint64_t RING = cama_pipeline::RING;
     const uint64_t k = p->issued + 1;                     // this launch
     const int slot = (int)((k - 1) & 1u);
-    void *scratch = slot ? scratch1 : scratch0;
     // bound the run-ahead (and keep done[k % RING], last used by launch k - RING, free): launch k - (RING - 2) must be over
     if (k > RING - 2) {
         HIP_TRY(hipEventSynchronize(p->done[(k - (RING - 2)) % RING]));
         if (int rc = pipeline_poll(p)) return rc;
     }
-    // validate before anything is enqueued, so a rejected call leaves the pipeline state untouched
-    {
-        ScratchLayout L;
+    if (int rc = check_common(N, F, C, W, H)) return rc;
+    if (radius < 0 || radius > CAMA_MAX_RADIUS) return fail(CAMA_EINVAL, "radius %d out of range", radius);
+    ScratchRef sc;
+    ScratchLayout L;
+    bool prepass_done = false;
+    if (!managed) {
+        // validate before anything is enqueued, so a rejected call leaves the pipeline state untouched
+        void *scratch = slot ? scratch1 : scratch0;
         if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
+        sc = legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius);
+    } else {
+        layout_scratch(N, F, C, H, W, radius, L);
+        const bool plannable = plan_call && F > 0 && bin_plannable(*plan_call) && !getenv("CAMA_NO_PLAN");
+        if (int rc = pipeline_grow(p, &p->own_plan[slot], &p->own_plan_bytes[slot], L.plan_total, false, k)) return rc;
+        sc.plan = p->own_plan[slot];
+        sc.plan_bytes = p->own_plan_bytes[slot];
+        if (plannable) {
+            if (int rc = check_bin_call(*plan_call)) return rc;
+            // the pre-pass only writes the plan part, which the overlay of launch k - 2 never reads: it need not wait for it
+            HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
+            HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
+            if (int rc = bin_prepass(*plan_call, L, sc.plan, p->s_bin)) return rc;
+            const size_t words = 1 + (size_t)F;
+            if (words > p->demand_cap) {
+                if (p->demand_host) (void)hipHostFree(p->demand_host);
+                p->demand_host = nullptr;
+                p->demand_cap = 0;
+                HIP_TRY(hipHostMalloc((void **)&p->demand_host, std::max(words, (size_t)1024) * 8, hipHostMallocDefault));
+                p->demand_cap = std::max(words, (size_t)1024);
+            }
+            HIP_TRY(hipMemcpyAsync(p->demand_host, sc.plan + L.demand, 8, hipMemcpyDeviceToHost, p->s_bin));
+            HIP_TRY(hipMemcpyAsync(p->demand_host + 1, sc.plan + L.frame_items, (size_t)F * 4, hipMemcpyDeviceToHost, p->s_bin));
+            HIP_TRY(hipStreamSynchronize(p->s_bin));
+            const uint32_t *per_frame = (const uint32_t *)(p->demand_host + 1);
+            uint32_t most = 0;
+            for (int f = 0; f < F; ++f) most = std::max(most, per_frame[f]);
+            sc.bin_plan.planned = true;
+            sc.bin_plan.nseg = std::max(most, 1u) * (BLOCK / SEG);
+            sc.bin_plan.capacity = std::max<uint64_t>(p->demand_host[0], 1) * SEG * (uint64_t)L.bands_per_stamp;
+            layout_scratch(N, F, C, H, W, radius, L, &sc.bin_plan);
+            prepass_done = true;
+            ++p->planned_launches;
+        }
+        if (L.capacity >= (1ull << 32))
+            return fail(CAMA_EINVAL, "%llu band entries exceed 32-bit offsets: render fewer frames per call",
+                        (unsigned long long)L.capacity);
+        if (int rc = pipeline_grow(p, &p->own_stamp[slot], &p->own_stamp_bytes[slot], L.stamp_total, true, k)) return rc;
+        sc.stamp = p->own_stamp[slot];
+        sc.stamp_bytes = p->own_stamp_bytes[slot];
+        ScratchLayout chk;
+        if (int rc = check_render(N, F, C, W, H, radius, sc, chk)) return rc;
     }
     // inputs (w2c upload, frames) are complete on the caller's stream at this point
-    HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
-    HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
+    if (!prepass_done) {
+        HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
+        HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
+    }
     if (k > 2) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->done[(k - 2) % RING], 0));   // the overlay that read this slot
     {
         // the chain's last kernel (k_stamps_scatter, launched whenever N > 0) carries `binned` as its own stop event
         const bool ext = ext_events() && N > 0;
         g_scatter_stop_event = ext ? p->binned[slot] : nullptr;
-        if (int rc = bin(scratch, (void *)p->s_bin)) {
+        if (int rc = bin(sc, L, prepass_done, (void *)p->s_bin)) {
             g_scatter_stop_event = nullptr;
             return rc;
         }
@@ -1473,7 +1712,7 @@ static int pipeline_impl(cama_pipeline *p, int64_t N, int32_t F, int32_t C, int3
     // `binned` also carries `ready` (s_bin waited for it above): one barrier packet between overlays, not two
     HIP_TRY(hipStreamWaitEvent(so, p->binned[slot], 0));
     g_overlay_stop_event = (overlay_takes_stop_event && ext_events()) ? p->done[k % RING] : nullptr;
-    if (int rc = overlay(scratch, (void *)so)) {
+    if (int rc = overlay(sc, (void *)so)) {
         g_overlay_stop_event = nullptr;
         return rc;
     }
@@ -1481,71 +1720,13 @@ static int pipeline_impl(cama_pipeline *p, int64_t N, int32_t F, int32_t C, int3
         HIP_TRY(hipEventRecord(p->done[k % RING], so));      // the launch did not take the event: record it behind
     g_overlay_stop_event = nullptr;
     p->issued = k;
+    p->last[slot].sc = sc;
+    p->last[slot].N = N; p->last[slot].F = F; p->last[slot].C = C; p->last[slot].H = H; p->last[slot].W = W;
+    p->last[slot].radius = radius;
+    p->last[slot].bounds = plan_call && plan_call->block_bounds != nullptr;
+    p->last_slot = slot;
     return CAMA_OK;
 }
-
-#ifdef CAMA_GRAPH_EXPERIMENT
-// EXPERIMENT (tools/ab build only): the round-2 hipGraph replay of the binning chain, rebuilt to find out why it faulted.
-// Modes (CAMA_GRAPH): 1 = cache per key and replay (the round-2 behaviour); 2 = capture + instantiate + launch + destroy the
-// exec after a stream sync, every time (no cache); 3 = cache, but synchronise the stream after every replay; 4 = cache and
-// keep the captured hipGraph_t alive next to its exec.
-struct BinKey {
-    const void *x, *y, *z, *colour, *key, *bounds, *w2c, *c2cam, *K, *scratch;
-    int64_t N;
-    size_t scratch_bytes;
-    double crop[6];
-    int32_t is64, flags, F, C, W, H, radius, pad;
-};
-struct BinGraph { BinKey key; hipGraphExec_t exec; };
-static std::vector<BinGraph> g_graphs;
-static int graph_bin(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64, const uint8_t *colour_id,
-                     const uint32_t *draw_key, const double *block_bounds, int32_t flags, int64_t N, const double *w2c, int32_t F,
-                     const double *c2cam, const double *K, int32_t C, const double *crop, int32_t W, int32_t H, int32_t radius,
-                     void *scratch, size_t scratch_bytes, void *sb)
-{
-    static const int mode = getenv("CAMA_GRAPH") ? atoi(getenv("CAMA_GRAPH")) : 0;
-    if (!mode || N <= 0 || F <= 0) return 1;                       // 1 = not handled: launch kernel by kernel
-    hipStream_t s = (hipStream_t)sb;
-    BinKey key;
-    memset(&key, 0, sizeof(key));
-    key.x = x; key.y = y; key.z = z; key.colour = colour_id; key.key = draw_key; key.bounds = block_bounds; key.w2c = w2c;
-    key.c2cam = c2cam; key.K = K; key.scratch = scratch; key.N = N; key.scratch_bytes = scratch_bytes;
-    memcpy(key.crop, crop, sizeof(key.crop));
-    key.is64 = xyz_is_f64; key.flags = flags; key.F = F; key.C = C; key.W = W; key.H = H; key.radius = radius;
-    BinGraph *hit = nullptr;
-    if (mode != 2)
-        for (auto &g : g_graphs)
-            if (!memcmp(&g.key, &key, sizeof(key))) { hit = &g; break; }
-    hipGraphExec_t exec = hit ? hit->exec : nullptr;
-    if (mode == 5) {                                               // mode 5: the scratch clear stays OUTSIDE the graph
-        ScratchLayout L;
-        layout_scratch(N, F, C, H, W, radius, L);
-        HIP_TRY(hipMemsetAsync((char *)scratch + L.counts, 0, L.zero_bytes, s));
-        g_skip_bin_memset = true;
-    }
-    if (!exec) {
-        hipGraph_t graph = nullptr;
-        HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        hipEvent_t keep = g_scatter_stop_event;
-        g_scatter_stop_event = nullptr;                            // (an event cannot ride on a captured launch)
-        const int rc = cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop,
-                                       W, H, radius, scratch, scratch_bytes, sb);
-        g_scatter_stop_event = keep;
-        g_skip_bin_memset = false;
-        const hipError_t e = hipStreamEndCapture(s, &graph);
-        if (rc || e != hipSuccess || !graph) return rc ? rc : fail(CAMA_EHIP, "hipStreamEndCapture -> %s", hipGetErrorString(e));
-        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        if (mode != 4) (void)hipGraphDestroy(graph);               // mode 4: the template graph is kept alive (leaked)
-        if (ei != hipSuccess) return fail(CAMA_EHIP, "hipGraphInstantiate -> %s", hipGetErrorString(ei));
-        if (mode != 2) g_graphs.push_back(BinGraph{key, exec});
-    }
-    g_skip_bin_memset = false;
-    HIP_TRY(hipGraphLaunch(exec, s));
-    if (mode == 2) { HIP_TRY(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(exec); }
-    if (mode == 3) HIP_TRY(hipStreamSynchronize(s));
-    return CAMA_OK;                                                // (g_scatter_stop_event stays set: the caller records it)
-}
-#endif
 
 template <typename Overlay>
 static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, const void *z, int32_t xyz_is_f64,
@@ -1554,15 +1735,16 @@ static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, 
                                 const double *crop, int32_t W, int32_t H, int32_t radius, void *scratch0, void *scratch1,
                                 size_t scratch_bytes, void *input_stream, bool overlay_takes_stop_event, Overlay overlay)
 {
-    return pipeline_impl(p, N, F, C, W, H, radius, scratch0, scratch1, scratch_bytes, input_stream, overlay_takes_stop_event,
-                         [&](void *scratch, void *sb) {
-#ifdef CAMA_GRAPH_EXPERIMENT
-                             if (int rc = graph_bin(p, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F,
-                                                    c2cam, K, C, crop, W, H, radius, scratch, scratch_bytes, sb); rc != 1)
-                                 return rc;
-#endif
-                             return cama_bin_frames(x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F,
-                                                    c2cam, K, C, crop, W, H, radius, scratch, scratch_bytes, sb);
+    const BinCall b{nullptr, 0, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H,
+                    radius};
+    if (F > 0)
+        if (int rc = check_bin_call(b)) return rc;
+    return pipeline_impl(p, N, F, C, W, H, radius, scratch0, scratch1, scratch_bytes, input_stream, overlay_takes_stop_event, &b,
+                         [&](const ScratchRef &sc, const ScratchLayout &L, bool prepass_done, void *sb) {
+                             if (F == 0) return (int)CAMA_OK;
+                             if (!prepass_done)
+                                 if (int rc = bin_prepass(b, L, sc.plan, (hipStream_t)sb)) return rc;
+                             return bin_main(b, L, sc.plan, sc.stamp, (hipStream_t)sb);
                          },
                          overlay);
 }
@@ -1610,8 +1792,8 @@ int cama_overlay_scenes(const cama_scene *scenes_host, const cama_scene *scenes_
     if (int rc = check_scenes(scenes_host, scenes_dev, S, F, true, &nmax)) return rc;
     if (W % 16) return fail(CAMA_EINVAL, "multi-scene launches need W %% 16 == 0 (W=%d)", W);
     if (S > CAMA_MAX_SCENES_PER_LAUNCH) return fail(CAMA_EINVAL, "S=%d: at most %d scenes per chain", S, CAMA_MAX_SCENES_PER_LAUNCH);
-    return overlay_impl(nullptr, nullptr, nullptr, nmax, S * F, C, H, W, cols, radius, halfwidth, palette_bgr, scratch,
-                        scratch_bytes, stream, scenes_host, F);
+    return overlay_impl(nullptr, nullptr, nullptr, nmax, S * F, C, H, W, cols, radius, halfwidth, palette_bgr,
+                        legacy_scratch(scratch, scratch_bytes, nmax, S * F, C, H, W, radius), stream, scenes_host, F);
 }
 
 int cama_render_scenes(const cama_scene *scenes_host, const cama_scene *scenes_dev, int32_t S, int32_t xyz_is_f64,
@@ -1638,14 +1820,18 @@ int cama_pipeline_render_scenes(cama_pipeline *p, const cama_scene *scenes_host,
     int64_t nmax = 0;
     if (int rc = check_scenes(scenes_host, scenes_dev, S, F, true, &nmax)) return rc;
     if (W % 16 || !palette_bgr || !halfwidth || cols < 1) return fail(CAMA_EINVAL, "bad overlay arguments");
-    return pipeline_impl(p, nmax, S * F, C, W, H, radius, scratch0, scratch1, scratch_bytes, input_stream, true,
-                         [&](void *scratch, void *sb) {
-                             return cama_bin_scenes(scenes_host, scenes_dev, S, xyz_is_f64, w2c, F, C, crop, W, H, radius,
-                                                    scratch, scratch_bytes, sb);
+    if (!w2c || !crop) return fail(CAMA_EINVAL, "NULL pointer argument");
+    const BinCall b{reinterpret_cast<const SceneRef *>(scenes_dev), F, nullptr, nullptr, nullptr, xyz_is_f64, nullptr, nullptr,
+                    nullptr, 0, nmax, w2c, S * F, nullptr, nullptr, C, crop, W, H, radius};
+    return pipeline_impl(p, nmax, S * F, C, W, H, radius, scratch0, scratch1, scratch_bytes, input_stream, true, nullptr,
+                         [&](const ScratchRef &sc, const ScratchLayout &L, bool, void *sb) {
+                             if (S * F == 0) return (int)CAMA_OK;
+                             if (int rc = bin_prepass(b, L, sc.plan, (hipStream_t)sb)) return rc;
+                             return bin_main(b, L, sc.plan, sc.stamp, (hipStream_t)sb);
                          },
-                         [&](void *scratch, void *so) {
-                             return cama_overlay_scenes(scenes_host, scenes_dev, S, F, C, H, W, cols, radius, halfwidth,
-                                                        palette_bgr, scratch, scratch_bytes, so);
+                         [&](const ScratchRef &sc, void *so) {
+                             return overlay_impl(nullptr, nullptr, nullptr, nmax, S * F, C, H, W, cols, radius, halfwidth,
+                                                 palette_bgr, sc, so, scenes_host, F);
                          });
 }
 
@@ -1660,9 +1846,9 @@ int cama_pipeline_render(cama_pipeline *p, const void *x, const void *y, const v
     if (F > 0 && (!src || !mosaic || !palette_bgr || !halfwidth || cols < 1)) return fail(CAMA_EINVAL, "NULL pointer argument");
     return pipeline_render_impl(p, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H,
                                 radius, scratch0, scratch1, scratch_bytes, input_stream, true,
-                                [&](void *scratch, void *so) {
-                                    return cama_overlay_frames(src, mosaic, N, F, C, H, W, cols, radius, halfwidth,
-                                                               palette_bgr, scratch, scratch_bytes, so);
+                                [&](const ScratchRef &sc, void *so) {
+                                    return overlay_impl(src, nullptr, mosaic, N, F, C, H, W, cols, radius, halfwidth,
+                                                        palette_bgr, sc, so);
                                 });
 }
 
@@ -1678,11 +1864,58 @@ int cama_pipeline_render_raw35(cama_pipeline *p, const void *x, const void *y, c
         return fail(CAMA_EINVAL, "NULL pointer argument");
     return pipeline_render_impl(p, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H,
                                 radius, scratch0, scratch1, scratch_bytes, input_stream, true,
-                                [&](void *scratch, void *so) {
-                                    return cama_overlay_frames_raw35(raw, H0, W0, vrows, band_rows, max_src_rows, mosaic, N,
-                                                                     F, C, H, W, cols, radius, halfwidth, palette_bgr,
-                                                                     scratch, scratch_bytes, so);
+                                [&](const ScratchRef &sc, void *so) {
+                                    return raw35_impl(raw, H0, W0, vrows, band_rows, max_src_rows, mosaic, N, F, C, H, W, cols,
+                                                      radius, halfwidth, palette_bgr, sc, so);
                                 });
+}
+
+int64_t cama_pipeline_scratch_bytes(cama_pipeline *p)
+{
+    if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
+    int64_t n = 0;
+    for (int k = 0; k < 2; ++k) n += (int64_t)p->own_plan_bytes[k] + (int64_t)p->own_stamp_bytes[k];
+    return n;
+}
+
+int cama_pipeline_info(cama_pipeline *p, uint64_t *out)
+{
+    if (!p || !out) return fail(CAMA_EINVAL, "NULL pointer argument");
+    out[0] = p->issued; out[1] = p->planned_launches; out[2] = p->grows;
+    out[3] = (uint64_t)cama_pipeline_scratch_bytes(p);
+    const int sl = p->last_slot;
+    out[4] = sl >= 0 ? p->last[sl].sc.bin_plan.nseg : 0;
+    out[5] = sl >= 0 ? p->last[sl].sc.bin_plan.capacity : 0;
+    return CAMA_OK;
+}
+
+int cama_pipeline_bin_stats(cama_pipeline *p, uint64_t *out)
+{
+    if (!p || !out) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (p->last_slot < 0) return fail(CAMA_EINVAL, "no launch yet");
+    HIP_TRY(hipStreamSynchronize(p->s_ov));
+    const cama_pipeline::Last &l = p->last[p->last_slot];
+    return bin_stats_impl(l.sc, l.N, l.F, l.C, l.H, l.W, l.radius, l.bounds ? 1 : 0, out, p->s_bin);
+}
+
+int cama_pipeline_guard_check(cama_pipeline *p, int64_t *bad_bytes)
+{
+    if (!p || !bad_bytes) return fail(CAMA_EINVAL, "NULL pointer argument");
+    HIP_TRY(hipStreamSynchronize(p->s_bin));
+    HIP_TRY(hipStreamSynchronize(p->s_ov));
+    constexpr size_t G = cama_pipeline::GUARD;
+    std::vector<uint8_t> h(G);
+    int64_t bad = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (!p->own_stamp[k]) continue;
+        for (int side = 0; side < 2; ++side) {
+            const char *g = side ? p->own_stamp[k] + p->own_stamp_bytes[k] : p->own_stamp[k] - G;
+            HIP_TRY(hipMemcpy(h.data(), g, G, hipMemcpyDeviceToHost));
+            for (uint8_t v : h) bad += v != 0x5A;
+        }
+    }
+    *bad_bytes = bad;
+    return CAMA_OK;
 }
 
 int cama_pipeline_join(cama_pipeline *p, void *stream)

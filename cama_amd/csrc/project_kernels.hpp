@@ -310,13 +310,14 @@ struct WaveVerts {
 };
 
 template <typename T>
-__device__ __forceinline__ WaveVerts load_wave_verts(const FrameArgs &a, const int64_t vblock, const int f, const uint64_t cams4)
+__device__ __forceinline__ WaveVerts load_wave_verts(const FrameArgs &a, const int64_t vblock, const int f, const uint64_t cams4,
+                                                     const uint32_t seg_base)
 {
     WaveVerts v{0.0, 0.0, 0.0, 0u, false, 0u, 0u};
     // this wave's 16 camera bits (wave-uniform: kept in an SGPR)
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     v.cams = (uint32_t)(cams4 >> (16u * wave)) & 0xffffu;
-    v.seg = (uint32_t)vblock * (BLOCK / SEG) + wave;
+    v.seg = seg_base + wave;            // (vblock * 4, or -- planned launches -- the block's rank among its frame's survivors * 4)
     if (!v.cams) return v;
     // world->chassis + crop FIRST, with the frame's matrix read through wave-uniform (scalar) loads: on site-sized
     // maps ~95 % of the waves end here
@@ -372,9 +373,9 @@ __device__ __forceinline__ void emit_wave_stamps(const FrameArgs &a, const int f
 // waves of a workgroup run through their blocks independently; the caller flushes s_cnt after a barrier.
 template <typename T>
 __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t vblock, const int f, const uint64_t cams4,
-                                              uint32_t *s_cnt)
+                                              uint32_t *s_cnt, const uint32_t seg_base)
 {
-    const WaveVerts v = load_wave_verts<T>(a, vblock, f, cams4);
+    const WaveVerts v = load_wave_verts<T>(a, vblock, f, cams4, seg_base);
     if (!v.cams) return;
     const double Wd = (double)a.W, Hd = (double)a.H;
     // -DABL_PROJ_NO_CAMS / -DABL_PROJ_NO_OUT: ablation builds behind profiles/r02_project_ablation.txt
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(BLOCK) void k_frames_project(FrameArgs a, const int
         const int64_t vb = vb0 + b;
         if (vb * BLOCK >= a.N) break;
         const uint64_t cams = cm ? cm[vb] : ~0ull;                           // scalar load
-        if (cams) project_block<T>(a, vb, f, cams, s_hist);
+        if (cams) project_block<T>(a, vb, f, cams, s_hist, (uint32_t)vb * (BLOCK / SEG));
     }
     hist_flush(a, f, s_hist);
 }
@@ -801,13 +802,16 @@ __global__ __launch_bounds__(BLOCK) void k_candidate_cameras(const double *__res
                                                              const uint32_t *__restrict__ cand_count,
                                                              const uint32_t *__restrict__ cand, uint16_t *__restrict__ cam_mask,
                                                              uint32_t list_cap, uint32_t *__restrict__ work_count,
-                                                             uint32_t *__restrict__ work)
+                                                             uint32_t *__restrict__ work, uint32_t *__restrict__ frame_items,
+                                                             uint32_t *__restrict__ work_rank,
+                                                             unsigned long long *__restrict__ demand)
 {
-    __shared__ uint32_t s_cnt[2][BLOCK / 64], s_base[2];
+    __shared__ uint32_t s_cnt[2][BLOCK / 64], s_base[2], s_wc[2][BLOCK / 64];
     const uint32_t l = blockIdx.x & 7u, lane = __lane_id(), wave = threadIdx.x >> 6;
     const uint32_t n = ((const uint32_t __attribute__((address_space(4))) *)cand_count)[l];
     cand += (size_t)l * list_cap;
     work += (size_t)l * list_cap;
+    work_rank += (size_t)l * list_cap;
     uint32_t par = 0;
     for (uint32_t i0 = (blockIdx.x >> 3) * (BLOCK / 4); i0 < n; i0 += (gridDim.x >> 3) * (BLOCK / 4), par ^= 1u) {
         const uint32_t i = i0 + (threadIdx.x >> 2);
@@ -826,37 +830,52 @@ __global__ __launch_bounds__(BLOCK) void k_candidate_cameras(const double *__res
         any |= (uint32_t)__shfl_xor((int)any, 2, 64);
         const bool keep = any != 0u && (lane & 3u) == 0u;
         const uint64_t kk = __ballot(keep);
-        if (lane == 0) s_cnt[par][wave] = (uint32_t)__popcll(kk);
+        // what the launch will need (the host sizes the stamp scratch from it before the projection runs): the (wave, camera)
+        // chains of the listed blocks -- every lane is one wave of its block -- and each listed block's rank in its frame
+        uint32_t wc = any != 0u ? (uint32_t)__popc(mask) : 0u;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) wc += (uint32_t)__shfl_xor((int)wc, d, 64);
+        if (lane == 0) { s_cnt[par][wave] = (uint32_t)__popcll(kk); s_wc[par][wave] = wc; }
+        const uint32_t rank = keep ? atomicAdd(&frame_items[f], 1u) : 0u;
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t tot = 0;
+            uint32_t tot = 0, chains = 0;
 #pragma unroll
-            for (int w = 0; w < BLOCK / 64; ++w) tot += s_cnt[par][w];
+            for (int w = 0; w < BLOCK / 64; ++w) { tot += s_cnt[par][w]; chains += s_wc[par][w]; }
             s_base[par] = tot ? atomicAdd(&work_count[l], tot) : 0u;
+            if (chains) atomicAdd(demand, (unsigned long long)chains);
         }
         __syncthreads();
         // (the buffers of this parity are next written two iterations on, behind the next iteration's barriers)
         uint32_t at = s_base[par];
         for (uint32_t w = 0; w < wave; ++w) at += s_cnt[par][w];
-        if (keep) work[at + (uint32_t)__popcll(kk & ((1ull << lane) - 1ull))] = item;
+        if (keep) {
+            const uint32_t pos = at + (uint32_t)__popcll(kk & ((1ull << lane) - 1ull));
+            work[pos] = item;
+            work_rank[pos] = rank;
+        }
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_frames_project_list(FrameArgs a, const uint32_t *__restrict__ work_count,
                                                                const uint32_t *__restrict__ work, uint32_t vblocks,
-                                                               uint32_t list_cap)
+                                                               uint32_t list_cap, const uint32_t *__restrict__ work_rank)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
     const uint32_t list = blockIdx.x & 7u;          // gridDim.x is a multiple of 8
     const uint32_t n = work_count[list];
     work += (size_t)list * list_cap;
+    if (work_rank) work_rank += (size_t)list * list_cap;
     for (uint32_t w = blockIdx.x >> 3; w < n; w += gridDim.x >> 3) {
         const uint32_t item = work[w];
         const int64_t vb = (int64_t)(item % vblocks);
         const int f = (int)(item / vblocks);
+        // planned launches (work_rank): the block's segments are numbered by its rank among the frame's surviving blocks, so
+        // a (frame, camera) row of the segment tables is as long as the busiest frame needs, not as long as the map
+        const uint32_t seg_base = (work_rank ? work_rank[w] : (uint32_t)vb) * (BLOCK / SEG);
         hist_clear(a, s_hist);
-        project_block<T>(a, vb, f, a.cam_mask[(size_t)f * a.vblocks + (size_t)vb], s_hist);
+        project_block<T>(a, vb, f, a.cam_mask[(size_t)f * a.vblocks + (size_t)vb], s_hist, seg_base);
         hist_flush(a, f, s_hist);
         __syncthreads();                            // the next item's clear must not overtake this flush
     }

@@ -210,6 +210,9 @@ class ClipManager:
         self._static_cache = {}
         self._track_cache = {}
         self._rig_cache = None
+        # configs["egress"] = "i420" | "bgr24": what a listening VideoGenerator receives (runtime.egress_format); absent =
+        # the environment's choice (default bgr24, the reference's stream).  Process-wide: the newest ClipManager decides.
+        runtime.set_egress_format(configs.get("egress") if isinstance(configs, dict) else None)
         self._frame_source = None
         if clip_path is not None:
             self.clip_path = clip_path

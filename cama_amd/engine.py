@@ -368,9 +368,16 @@ class Engine:
             if out is None:
                 out = torch.empty(shape, dtype=torch.uint8, device=self.device)
             assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.uint8
+            x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
+            if self.alpha256 == 256 and bnd is not None and (bflags & _lib.BIN_WORKLIST):
+                # site-sized map: the caller-scratch entry point below would size its stamp scratch for the worst case
+                # (24 B per frame x camera x vertex); the pipeline plans the launch and sizes it from what survives the
+                # cull (cama_pipeline_render with its own scratch).  Same kernels; complete on the current stream on return.
+                self.render_frames_pipelined(dmap, rig, T, src, out, cols=cols, crop=crop)
+                self.join()
+                return out
             need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
             scratch = self._scratch_buf(need)
-            x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
             if self.alpha256 != 256:        # extension path: binning + translucent overlay
                 _lib.check(self.lib.cama_bin_frames(
                     x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(),
@@ -422,8 +429,11 @@ class Engine:
         N, F, C, H, W, had_bounds, has_key, scratch = last
         out = np.zeros(4, np.uint64)
         with _torch().cuda.device(self.device):
-            _lib.check(self.lib.cama_bin_stats(scratch.data_ptr(), scratch.numel(), N, F, C, H, W, self.radius,
-                                               int(had_bounds), out.ctypes.data, self._stream()))
+            if scratch is None:             # the launch went through the pipeline's own scratch
+                _lib.check(self.lib.cama_pipeline_bin_stats(self._pipe["handle"], out.ctypes.data))
+            else:
+                _lib.check(self.lib.cama_bin_stats(scratch.data_ptr(), scratch.numel(), N, F, C, H, W, self.radius,
+                                                   int(had_bounds), out.ctypes.data, self._stream()))
         per_vertex = 16 if has_key else 13
         return {"frames": F, "verts": N, "vertex_waves_read": int(out[0]), "camera_chains": int(out[1]),
                 "stamps": int(out[2]), "band_entries": int(out[3]),
@@ -570,20 +580,17 @@ class Engine:
                 out = torch.empty(shape, dtype=torch.uint8, device=self.device)
             assert tuple(out.shape) == shape and out.is_contiguous()
             mapx, mapy, sep, band_rows, max_rows, tiles, tiles_x, max_tile, vrows = self.rig_maps(cm_list)
-            need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
-            scratch = self._scratch_buf(need)
             x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
             st = self._stream()
             if pipelined and vrows is not None:
                 P = self._pipeline()
-                s0, s1 = self._pipe_scratch(P, need)
                 staged = self._stage_poses(P, w2c)
                 T_ptr = staged[0] if staged is not None else T.data_ptr()
                 _lib.check(self.lib.cama_pipeline_render_raw35(
                     P["handle"], x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T_ptr, F, rig.c2cam.data_ptr(),
                     rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, raw.data_ptr(), H0, W0, vrows[0].data_ptr(),
                     vrows[1].data_ptr(), vrows[2], out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
-                    self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(), min(s0.numel(), s1.numel()), st))
+                    self.palette.ctypes.data, None, None, 0, st))      # (scratch: the pipeline's own, demand-sized)
                 seq = int(self.lib.cama_pipeline_issued(P["handle"]))
                 # the overlay runs later, on the pipeline's own stream, and reads the tap tables: they belong to the
                 # launch's keep set like the frames and the map (a later call with another rig may evict the plan)
@@ -592,6 +599,8 @@ class Engine:
                 return out
             if T is None:
                 T = self._mats(w2c)
+            need = self.lib.cama_render_scratch_bytes(dmap.N, F, rig.C, rig.H, rig.W, self.radius)
+            scratch = self._scratch_buf(need)
             _lib.check(self.lib.cama_bin_frames(
                 x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T.data_ptr(), F, rig.c2cam.data_ptr(), rig.K.data_ptr(), rig.C,
                 cropa.ctypes.data, rig.W, rig.H, self.radius, scratch.data_ptr(), scratch.numel(), st))
@@ -617,18 +626,25 @@ class Engine:
             handle = ctypes.c_void_p()
             with _torch().cuda.device(self.device):          # its streams live on this engine's GPU
                 _lib.check(self.lib.cama_pipeline_create(ctypes.byref(handle)))
-            self._pipe = {"handle": handle, "scratch": [None, None], "keep": []}
+            self._pipe = {"handle": handle, "keep": []}
         return self._pipe
 
-    def _pipe_scratch(self, P, need):
-        torch = _torch()
-        for k in range(2):
-            if P["scratch"][k] is None or P["scratch"][k].numel() < need:
-                if P["scratch"][k] is not None:
-                    self.join()
-                    torch.cuda.current_stream(self.device).synchronize()     # old buffer may still be in use
-                P["scratch"][k] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
-        return P["scratch"]
+    def pipeline_info(self):
+        """What the pipeline's own scratch looks like (cama_pipeline_info): dict with launches, planned_launches, grows,
+        scratch_bytes, last_plan_segments, last_plan_capacity; None before the first pipelined launch."""
+        if self._pipe is None:
+            return None
+        out = np.zeros(6, np.uint64)
+        _lib.check(self.lib.cama_pipeline_info(self._pipe["handle"], out.ctypes.data))
+        return dict(zip(("launches", "planned_launches", "grows", "scratch_bytes", "last_plan_segments",
+                         "last_plan_capacity"), (int(v) for v in out)))
+
+    def scratch_bytes(self):
+        """Device bytes of stamp scratch this engine holds: the pipeline's own (demand-sized) + the single-stream buffer."""
+        n = 0 if self._scratch is None else int(self._scratch.numel())
+        if self._pipe is not None:
+            n += int(self.lib.cama_pipeline_scratch_bytes(self._pipe["handle"]))
+        return n
 
     def _scratch_need(self, N, F, rig):
         key = (N, F, rig.C, rig.H, rig.W, self.radius)
@@ -672,13 +688,14 @@ class Engine:
             assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
             assert tuple(src.shape) == (F, rig.C, rig.H, rig.W, 3)
             assert tuple(out.shape) == self.mosaic_shape(rig, F, cols) and out.is_contiguous()
-            s0, s1 = self._pipe_scratch(P, self._scratch_need(dmap.N, F, rig))
             x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
+            # scratch: the pipeline's own (NULL, NULL) -- sized from what the launch's cull lets through when the map is
+            # site-sized (the call then waits on the host for the pre-pass: include/cama_hip.h), else for the worst case
             _lib.check(self.lib.cama_pipeline_render(
                 P["handle"], x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T_ptr, F, rig.c2cam.data_ptr(),
                 rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, src.data_ptr(), out.data_ptr(), cols,
-                self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(),
-                min(s0.numel(), s1.numel()), self._stream()))
+                self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, None, None, 0, self._stream()))
+            self._last_bin = (dmap.N, F, rig.C, rig.H, rig.W, bnd is not None, key is not None, None)
             # The internal streams are invisible to torch's caching allocator: what launch k reads / writes must stay
             # allocated until the library reports it complete (cama_pipeline_completed, a hipEventQuery over its ring
             # of per-launch events) -- however far ahead of the GPU the host is.
@@ -742,12 +759,10 @@ class Engine:
             poses = np.ascontiguousarray(np.concatenate([np.asarray(it[2], np.float32).reshape(F, 16) for it in items]))
             if pipelined:
                 P = self._pipeline()
-                s0, s1 = self._pipe_scratch(P, self._scratch_need(Nmax, S * F, r0))
                 T_ptr = self._stage_poses(P, poses)[0]
                 _lib.check(self.lib.cama_pipeline_render_scenes(
                     P["handle"], host.ctypes.data, dev.data_ptr(), S, d0.is_f64, T_ptr, F, r0.C, cropa.ctypes.data, r0.W, r0.H,
-                    cols, self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, s0.data_ptr(), s1.data_ptr(),
-                    min(s0.numel(), s1.numel()), self._stream()))
+                    cols, self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, None, None, 0, self._stream()))
                 seq = int(self.lib.cama_pipeline_issued(P["handle"]))
                 P["keep"].append((seq, None, dev, items[0][4], d0, r0,
                                   tuple(t for it in items for t in (it[3], it[4], it[0].soa, it[0].colour, it[0].sorted_soa,
@@ -811,6 +826,16 @@ class Engine:
         memo = self.__dict__.setdefault("_fpc_memo", {})
         if memo_key in memo:                    # (the free-memory probe is a driver call: once per shape is enough)
             return memo[memo_key]
+        planned = (self.alpha256 == 256 and getattr(dmap, "bounds", None) is not None and dmap.N >= BOUNDS_MIN_VERTS
+                   and dmap.site_sized(self.crop) and not os.environ.get("CAMA_NO_PLAN"))
+        if planned and resident_frames:
+            # site-sized maps are PLANNED (the pipeline sizes its own stamp scratch from what survives the launch's cull:
+            # ~1 GB per 167 frames of the 10^6-vertex stress instead of 24 GB), so memory no longer bounds the launch;
+            # what does is the overlay's bandwidth, which falls slowly with the bytes a launch walks (40 / 80 / 167 frames
+            # of 1600x900: 0.784 / 0.779 / 0.767 of 8 TB/s on never-touched buffers) against one ~12 us kernel boundary per
+            # launch.  CAMA_FRAMES_PER_LAUNCH overrides.
+            memo[memo_key] = max(1, int(os.environ.get("CAMA_FRAMES_PER_LAUNCH", "128")))
+            return memo[memo_key]
         if budget_bytes is None:
             free, _ = _torch().cuda.mem_get_info(self.device)
             budget_bytes = min(64 << 30, max(1 << 30, free // 4))
@@ -834,7 +859,8 @@ class Engine:
         if self._pipe is not None:
             self.join()
             torch.cuda.current_stream(self.device).synchronize()
-            self._pipe["scratch"] = [None, None]
+            self.lib.cama_pipeline_destroy(self._pipe["handle"])      # (gives its own scratch back)
+            self._pipe = None
         self._scratch = None
         torch.cuda.empty_cache()
 

@@ -353,7 +353,11 @@ class ClipFrameSource:
             return
         P = {"keys": keys, "index": {k: j for j, k in enumerate(keys)}, "ready": {}, "consumed": 0,
              "cv": threading.Condition(), "stop": False, "error": None}
-        P["thread"] = threading.Thread(target=self._pump, args=(P,), daemon=True, name="cama-decode-pump")
+        # the thread holds only a WEAK reference to this source (and wakes up now and then to look at it): a consumer that
+        # abandons a pass -- break, exception, dropping the ClipManager -- must not leave a parked thread that keeps the
+        # source, its decoded batches (~0.4 GB of HBM each), pinned arenas and decoder lanes alive for ever
+        import weakref
+        P["thread"] = threading.Thread(target=_pump_entry, args=(weakref.ref(self), P), daemon=True, name="cama-decode-pump")
         self._plan = P
         P["thread"].start()
 
@@ -361,10 +365,12 @@ class ClipFrameSource:
         P, self._plan = self._plan, None
         if P is None:
             return
+        import threading
         with P["cv"]:
             P["stop"] = True
             P["cv"].notify_all()
-        P["thread"].join()
+        if P["thread"] is not threading.current_thread():      # (the pump itself may drop the last reference to the source)
+            P["thread"].join()
         for pend in P["ready"].values():                 # release their lanes
             if hasattr(pend, "result"):
                 try:
@@ -380,32 +386,33 @@ class ClipFrameSource:
             f.cancel()
         self._batch_reads.clear()
 
-    def _pump(self, P):
+    def _pump_step(self, P, j, key):
+        """One batch of the plan, on the pump thread: reads (this batch and the next two), then parse + upload + decode."""
         import torch
         from .jpeg import is_blob
+        with torch.cuda.device(self.device):
+            keys = P["keys"]
+            for ahead in keys[j:j + 3]:            # file reads: this batch and the next two
+                self._submit_batch(ahead)
+            items = self._batch_reads.pop(key).result()
+            if all(is_blob(arr) for _, _, arr, _ in items):
+                return self._decoder().decode_async([arr for _, _, arr, _ in items], bgr=True)
+            return items                           # .npy twins / mixed sources: the consumer finishes them
+
+    def close(self):
+        """Stop the decode pump and the reader pool; safe to call more than once."""
         try:
-            with torch.cuda.device(self.device):
-                keys = P["keys"]
-                for j, key in enumerate(keys):
-                    with P["cv"]:
-                        while not P["stop"] and j >= P["consumed"] + self._pump_depth:
-                            P["cv"].wait()
-                        if P["stop"]:
-                            return
-                    for ahead in keys[j:j + 3]:            # file reads: this batch and the next two
-                        self._submit_batch(ahead)
-                    items = self._batch_reads.pop(key).result()
-                    if all(is_blob(arr) for _, _, arr, _ in items):
-                        pend = self._decoder().decode_async([arr for _, _, arr, _ in items], bgr=True)
-                    else:
-                        pend = items                       # .npy twins / mixed sources: the consumer finishes them
-                    with P["cv"]:
-                        P["ready"][key] = pend
-                        P["cv"].notify_all()
-        except BaseException as e:                         # surfaces in the consumer's raw_batch()
-            with P["cv"]:
-                P["error"] = e
-                P["cv"].notify_all()
+            self.cancel_plan()
+        finally:
+            pool, self._pool = self._pool, None
+            if pool is not None:
+                pool.shutdown(wait=False, cancel_futures=True)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _submit_batch(self, key):
         """Start reading all camera files of the frames `key` (a tuple of image indices): ONE pool task that hands the
@@ -587,3 +594,34 @@ class RawDeviceFrameSource:
         for c, cm in enumerate(self.cm_list):
             eng.resample(cm, raw[:, c], out=self._buf[:, c])
         return self._buf
+
+
+def _pump_entry(ref, P):
+    """Body of a ClipFrameSource's decode-pump thread.  `ref` is a weak reference to the source: while the thread is parked
+    (waiting for the consumer to catch up) it holds no strong one, wakes up twice a second, and ends when the source is gone
+    or the plan was cancelled."""
+    try:
+        for j, key in enumerate(P["keys"]):
+            with P["cv"]:
+                while True:
+                    src = ref()
+                    if src is None or P["stop"]:
+                        return
+                    depth = src._pump_depth
+                    del src
+                    if j < P["consumed"] + depth:
+                        break
+                    P["cv"].wait(timeout=0.5)
+            src = ref()
+            if src is None:
+                return
+            pend = src._pump_step(P, j, key)
+            del src
+            with P["cv"]:
+                P["ready"][key] = pend
+                P["cv"].notify_all()
+            del pend
+    except BaseException as e:                         # surfaces in the consumer's raw_batch()
+        with P["cv"]:
+            P["error"] = e
+            P["cv"].notify_all()

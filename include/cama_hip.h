@@ -179,8 +179,22 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
  * back: cama_pipeline_render enqueues cama_bin_frames on an internal stream and cama_overlay_frames on another, so the
  * binning of batch k+1 overlaps the HBM-bound overlay of batch k; scratch0 / scratch1 (each >=
  * cama_render_scratch_bytes) are used alternately.  Inputs must be complete on `input_stream` when the call is made;
- * outputs are complete after cama_pipeline_join(p, stream) in `stream`'s order.  The context owns two HIP streams and
- * a ring of 64 completion events (device-scope release, no timing) and no device memory.  One context per thread.
+ * outputs are complete after cama_pipeline_join(p, stream) in `stream`'s order.  The context owns two HIP streams, a
+ * ring of 64 completion events (device-scope release, no timing), its staged-pose buffers and -- see below -- optionally
+ * its scratch.  One context per thread.
+ *
+ * Pipeline-owned, demand-sized scratch (round 4): pass scratch0 == scratch1 == NULL (scratch_bytes ignored) to any
+ * cama_pipeline_render*.  cama_render_scratch_bytes() is a worst case -- every vertex visible in every camera: 24 B per
+ * (frame, camera, vertex), 24 GB for 167 frames of a 10^6-vertex map -- while a site-sized map leaves ~5 % of its vertices
+ * inside the crop box (cama/reproject.py:118-131) of which a camera sees a fraction (:187-205).  The pipeline then keeps two
+ * buffers per slot: the plan part (camera masks, work lists: O(F * N / 256)) and the stamp part.  For launches whose cull goes
+ * through the candidate pre-pass (block_bounds + CAMA_BIN_WORKLIST) it runs that pre-pass first, waits on the host for two
+ * figures it leaves behind -- the surviving blocks of the busiest frame and the (wave, camera) projection chains of all
+ * surviving blocks, an exact upper bound of what the projection can emit -- and sizes the stamp part from them (grow-only,
+ * hipMalloc inside the call when it has to grow); other launches get the worst case.  That wait is a few tens of
+ * microseconds behind the previous launch's binning chain and is hidden by the overlays already queued; it makes such a
+ * call synchronous with the binning stream, not with the overlays.  cama_pipeline_info / cama_pipeline_bin_stats /
+ * cama_pipeline_guard_check below report on it.
  *
  * Lifetime of what a launch reads and writes: the internal streams are invisible to the caller's allocator, so every
  * buffer handed to launch k (w2c, src, mosaic, the map, the calibration) must stay allocated and unmodified until
@@ -220,6 +234,16 @@ int cama_pipeline_render_raw35(cama_pipeline *p, const void *x, const void *y, c
 int cama_pipeline_join(cama_pipeline *p, void *stream);
 int64_t cama_pipeline_issued(cama_pipeline *p);
 int64_t cama_pipeline_completed(cama_pipeline *p);
+/* Device bytes of scratch the pipeline owns right now (both slots, plan + stamp parts). */
+int64_t cama_pipeline_scratch_bytes(cama_pipeline *p);
+/* out[6] (host): launches issued, launches that were planned, buffer (re)allocations so far, scratch bytes owned, and the
+ * last launch's plan: segments per (frame, camera), band-entry capacity (0, 0 when it was not planned). */
+int cama_pipeline_info(cama_pipeline *p, uint64_t *out);
+/* cama_bin_stats (below) of the pipeline's LAST launch out of its own scratch; blocks until that launch is over. */
+int cama_pipeline_bin_stats(cama_pipeline *p, uint64_t *out /* host, 4 */);
+/* Test hook: the pipeline-owned stamp buffers sit between two 1 MiB zones filled with 0x5A; *bad_bytes = how many of
+ * those bytes no longer hold the pattern (0 = no launch wrote outside its demand-sized buffers).  Blocks. */
+int cama_pipeline_guard_check(cama_pipeline *p, int64_t *bad_bytes /* host */);
 
 /*
  * Many scenes per chain.  main.py:32 renders scene after scene; a scene of ~1e4 vertices x 40 frames is ~0.35 ms of GPU
@@ -364,6 +388,11 @@ int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per
  *   overlay_tune          CAMA_OVERLAY_TUNE        0 = big launches keep the contiguous order (no self-timing)
  *   overlay_rot           CAMA_OVERLAY_ROT         contiguous order: XCD x starts rot * x bands into its own range
  *   overlay_prefetch      CAMA_OVERLAY_PREFETCH    translation look-ahead, in workgroups per XCD (0 = off, -1 = library's choice)
+ *   overlay_item_order    CAMA_OVERLAY_ITEM_ORDER  0 = bands run (frame, camera row, band, camera column); 1 = band innermost
+ *   overlay_groups_log2   CAMA_OVERLAY_GROUPS_LOG2 with a forced overlay_chunk_log2 < 31: 2^g groups of XCDs, each one contiguous
+ *                                                  range of the launch, chunks round-robin inside a group (1, 2; 0 = off)
+ *   cull_list_min         CAMA_CULL_LIST_MIN       (vertex block, frame) items from which the cull of a site-sized map goes
+ *                                                  through work lists + persistent workgroups (default 16384)
  * Unknown names: CAMA_EINVAL.  (No reference counterpart: the reference has no native code.) */
 int cama_set_option(const char *name, int64_t value);
 int cama_get_option(const char *name, int64_t *value);

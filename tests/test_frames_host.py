@@ -84,3 +84,55 @@ def test_undistort_map_bit_identical_to_the_opencv_order_restatement():
         FR.undistort_rectify_map(K0, tilt, Kn, 8, 8)
     with pytest.raises(NotImplementedError):
         O.undistort_map(K0, tilt, Kn, 8, 8)
+
+
+def test_decode_pump_thread_ends_when_its_source_is_dropped():
+    """the decode pump used to be a bound method parked in cv.wait() for ever once a consumer abandoned
+    a pass, pinning the source and its decoded batches.  The thread now holds a weak reference only and looks at it twice a
+    second."""
+    import gc
+    import threading
+    import weakref
+
+    class FakeSource:
+        _pump_depth = 1
+
+        def __init__(self):
+            self.steps = []
+
+        def _pump_step(self, P, j, key):
+            self.steps.append(key)
+            return ("decoded", key)
+
+    keys = [(1, 2), (3, 4), (5, 6), (7, 8)]
+    P = {"keys": keys, "index": {k: j for j, k in enumerate(keys)}, "ready": {}, "consumed": 0,
+         "cv": threading.Condition(), "stop": False, "error": None}
+    src = FakeSource()
+    t = threading.Thread(target=FR._pump_entry, args=(weakref.ref(src), P), daemon=True)
+    t.start()
+    with P["cv"]:
+        while keys[0] not in P["ready"]:
+            P["cv"].wait(timeout=5)
+    assert src.steps == [keys[0]] and t.is_alive()              # one batch ahead, then parked
+    with P["cv"]:                                                # the consumer takes it: the pump moves on by one
+        P["ready"].pop(keys[0])
+        P["consumed"] += 1
+        P["cv"].notify_all()
+    with P["cv"]:
+        while keys[1] not in P["ready"]:
+            P["cv"].wait(timeout=5)
+    assert t.is_alive()
+    del src                                                      # the consumer walks away mid-pass
+    gc.collect()
+    t.join(timeout=3)
+    assert not t.is_alive(), "the pump thread must end once its source is gone"
+    # and a cancelled plan ends it at once
+    src = FakeSource()
+    P2 = dict(P, ready={}, consumed=0, cv=threading.Condition(), stop=False)
+    t = threading.Thread(target=FR._pump_entry, args=(weakref.ref(src), P2), daemon=True)
+    t.start()
+    with P2["cv"]:
+        P2["stop"] = True
+        P2["cv"].notify_all()
+    t.join(timeout=3)
+    assert not t.is_alive()

@@ -388,3 +388,50 @@ def test_many_scenes_in_one_chain_with_spatially_sorted_maps():
     got = outs[2].cpu().numpy()
     for pos in range(a.frames):
         assert np.array_equal(got[pos], G.render_frame(a, 2, pos, xyz, col, cams, w2c)), pos
+
+
+def test_two_threads_two_pipelines_share_the_mapping_table(sweep_scenes):
+    """the overlay's per-buffer-pair choice of workgroup order is process-wide state behind a mutex.
+    Two threads, each with its own Engine (own pipeline context, own streams) and its own full-size scene (2 GB read +
+    2 GB written per launch, i.e. big enough for the tuner), render concurrently: 14 launches each, so both pairs go
+    through their six trial launches and get decided while the other thread is launching too.  Every render must equal
+    the oracle-checked golden hash; the table must end up with a decision for the last pair."""
+    import threading
+    import torch
+    from cama_amd.engine import Engine
+    a, scenes = sweep_scenes
+    golden = _golden(a)
+    dev = torch.device("cuda:0")
+    errors, hashes = [], {}
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(dev)
+            eng = Engine("cuda:0")
+            cm, frames, _ = scenes[k]
+            idx, w2c = cm.frame_poses("cama")
+            rig, dmap = cm._rig(), cm._static("cama").device()
+            out = torch.zeros(eng.mosaic_shape(rig, a.frames), dtype=torch.uint8, device=dev)
+            stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(stream):
+                src = frames[1:1 + a.frames]
+                got = []
+                for rep in range(14):
+                    out.fill_(0xA5)
+                    eng.render_frames_pipelined(dmap, rig, w2c, src, out)
+                    eng.join()
+                    stream.synchronize()
+                    got.append(shard.overlay_hash(out))
+            hashes[k] = got
+            hashes[("info", k)] = eng.overlay_mapping()
+        except Exception as e:                                        # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors
+    for k in (0, 1):
+        assert all(h == golden[k] for h in hashes[k]), f"scene {k}: a concurrent render differs from the oracle's hash"
+    last = [hashes[("info", k)] for k in (0, 1)]
+    assert any(i["decided"] in (5, 31) and min(i["samples"]) >= 3 for i in last), last

@@ -110,10 +110,15 @@ def test_bgr_to_i420_matches_the_swscale_restatement():
     assert L.cama_bgr_to_i420(src.data_ptr(), 90 * 160 * 3, dst.data_ptr(), 90 * 160 * 3 // 2, 1, 90, 150, st) == -1   # W % 16
 
 
-def test_main_loop_with_video_generator_streams_i420(tmp_path):
+def test_main_loop_with_video_generator_streams_the_references_bytes_by_default(tmp_path):
     """main.py:56-61 verbatim INCLUDING the VideoGenerator (writing to a sink: no ffmpeg on the boxes).  Frames are
-    rendered ahead in batches behind the per-frame surface and leave the GPU as planar YUV 4:2:0; the stream must be,
-    frame by frame, the libswscale-restated conversion of the oracle's mosaic -- for every render_ahead setting."""
+    rendered ahead in batches behind the per-frame surface.
+
+    Default leg: concate_image returns a real ndarray and the pipe carries the reference's bgr24 bytes
+    (cama/tools.py:27-32) -- frame by frame the oracle's mosaic -- for every render_ahead setting; the arrays are views of
+    the batch's pinned host copy and stay intact while the caller holds them.
+    Opt-in leg (configs["egress"] = "i420"): the frames leave the GPU as planar YUV 4:2:0; the stream is the
+    libswscale-restated conversion of the oracle's mosaic."""
     import io
     from cama.dataset import ClipManager
     from cama.tools import VideoGenerator
@@ -126,38 +131,68 @@ def test_main_loop_with_video_generator_streams_i420(tmp_path):
               image_mode="npy", image_size=(H, W), origin_size=(H, W), with_nuscenes=False)
     att = O.read_attribute(clip)
     cams = [O.camera_model(att, n, output_size=(H, W)) for n in CAMERA_NAMES]
-    streams = {}
-    try:
-        for ahead in (4, 1, 16):
-            configs = dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W), render_ahead=ahead)
-            cm = ClipManager(configs, clip)
-            sink = io.BytesIO()
-            vg = VideoGenerator(str(tmp_path / "out.mp4"), (3 * W, 2 * H), sink=sink)
-            n = 0
-            for image_idx, instance_map in cm.yield_frame(dataset="cama"):
-                maps_2d_dict = cm.project_all_camera(instance_map)
-                image_dict = cm.render_vectors(maps_2d_dict, image_idx)
-                image = vg.concate_image(image_dict)
-                assert isinstance(image, DeviceMosaic) and image.shape == (2 * H, 3 * W, 3)
-                vg.add_frame(image)
-                n += 1
-            vg.close()
-            assert n == 10 and vg.pix_fmt == "yuv420p"
-            streams[ahead] = sink.getvalue()
-        per = 2 * H * 3 * W * 3 // 2
-        assert len(streams[4]) == 10 * per and streams[4] == streams[1] == streams[16]
+
+    def oracle_mosaics(cm, configs):
         want = {i: m2 for i, _, _, m2 in _oracle_frames(clip, configs, "cama", cm.instance_maps["cama"], cams)}
-        for k, image_idx in enumerate(sorted(want)):
+        out = []
+        for image_idx in sorted(want):
             imgs = {}
             for c in cams:
                 img = np.load(f"{clip}/{c['name']}/{att['sync'][c['name']][image_idx]}.npy")
                 imgs[c["name"]] = O.render_instances(img.copy(), want[image_idx][c["name"]])
-            ref = O.bgr_to_i420(O.mosaic(imgs))
-            assert streams[4][k * per:(k + 1) * per] == ref.tobytes(), image_idx
+            out.append(O.mosaic(imgs))
+        return out
+
+    def loop(configs, check_image):
+        cm = ClipManager(configs, clip)
+        sink = io.BytesIO()
+        vg = VideoGenerator(str(tmp_path / "out.mp4"), (3 * W, 2 * H), sink=sink)
+        held = []
+        for image_idx, instance_map in cm.yield_frame(dataset="cama"):
+            maps_2d_dict = cm.project_all_camera(instance_map)
+            image_dict = cm.render_vectors(maps_2d_dict, image_idx)
+            image = vg.concate_image(image_dict)
+            check_image(image)
+            vg.add_frame(image)
+            held.append(image)
+        vg.close()
+        return cm, vg, sink.getvalue(), held
+
+    try:
+        # ---- default: the reference's bytes
+        streams = {}
+        for ahead in (4, 1, 16):
+            configs = dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W), render_ahead=ahead)
+
+            def is_ndarray(image):
+                assert type(image) is np.ndarray and image.shape == (2 * H, 3 * W, 3) and image.dtype == np.uint8
+            cm, vg, streams[ahead], held = loop(configs, is_ndarray)
+            assert len(held) == 10 and vg.pix_fmt == "bgr24"
+        ref = oracle_mosaics(cm, configs)
+        per = 2 * H * 3 * W * 3
+        assert len(streams[4]) == 10 * per and streams[4] == streams[1] == streams[16]
+        for k in range(10):
+            assert streams[4][k * per:(k + 1) * per] == ref[k].tobytes(), k
+            assert np.array_equal(held[k], ref[k]), k             # every array the loop was handed is still that frame
+        # ---- opt-in: device-side I420
+        streams = {}
+        for ahead in (4, 16):
+            configs = dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W), render_ahead=ahead, egress="i420")
+
+            def is_handle(image):
+                assert isinstance(image, DeviceMosaic) and image.shape == (2 * H, 3 * W, 3)
+            cm, vg, streams[ahead], held = loop(configs, is_handle)
+            assert vg.pix_fmt == "yuv420p"
+        per = 2 * H * 3 * W * 3 // 2
+        assert len(streams[4]) == 10 * per and streams[4] == streams[16]
+        for k in range(10):
+            assert streams[4][k * per:(k + 1) * per] == O.bgr_to_i420(ref[k]).tobytes(), k
         # touching the lazy mosaic gives the reference's BGR array
-        assert np.array_equal(np.asarray(image), O.mosaic(imgs)) and image.astype(np.uint8).tobytes() == O.mosaic(imgs).tobytes()
+        assert np.array_equal(np.asarray(held[-1]), ref[-1]) and held[-1].astype(np.uint8).tobytes() == ref[-1].tobytes()
     finally:
-        runtime.request_egress(None)
+        runtime.set_egress_format(None)
+        while runtime.egress_mode() is not None:
+            runtime.request_egress(None)
 
 
 def test_render_clip_batched_equals_per_frame_and_device_source(tmp_path):

@@ -190,3 +190,68 @@ def test_guard_pages_do_catch_an_overrun(repo_root, tmp_path):
     if p.returncode == 0 and "GUARD_OK" in p.stdout:
         pytest.xfail("the page after a 2 MB-granular hipMalloc is mapped on this box: overruns would go unnoticed")
     assert p.returncode != 0
+
+
+def test_planned_launches_size_their_scratch_from_the_cull_and_stay_inside_it(monkeypatch):
+    """site-sized maps no longer get 24 B of stamp scratch per (frame, camera, vertex).  The pipeline runs
+    the cull pre-pass first, reads back what survives -- blocks of the busiest frame, (wave, camera) chains -- and sizes its
+    own stamp buffers from that exact bound (cama_pipeline_render with scratch0 == NULL).  Checked here: the planned render
+    equals the worst-case-sized one (caller scratch, exactly sized between guard zones) byte for byte; the pipeline's buffers
+    are a small fraction of the worst case; their own guard zones are intact after launches of growing and shrinking
+    demand; a launch with NO survivor at all and one where every block survives both work."""
+    import torch
+    from cama_amd import engine as E
+    monkeypatch.setattr(E, "BOUNDS_MIN_VERTS", 1)
+    eng = E.Engine("cuda:0")
+    assert eng.lib.cama_set_option(b"cull_list_min", 1) == 0     # (the work-list route normally starts at 16 k items)
+    try:
+        _planned_launches(eng)
+    finally:
+        eng.lib.cama_set_option(b"cull_list_min", 16384)
+
+
+def _planned_launches(eng):
+    import torch
+    N, W, H = 120000, 320, 180
+    outs = {}
+    worst = {}
+    for tag, F, spread, seed in (("site", 12, 300.0, 3), ("site-long", 40, 300.0, 4), ("site-short", 2, 300.0, 5),
+                                 ("dense", 6, 40.0, 6)):
+        xyz, col, cams, w2c = _scene(seed, N, F, W, H, spread)
+        rig = eng.make_rig([c["name"] for c in cams], [c["chassis2camera"] for c in cams], [c["K"] for c in cams], W, H)
+        dmap = eng.upload_map(xyz, col)
+        src = torch.randint(0, 256, (F, 6, H, W, 3), dtype=torch.uint8, device="cuda")
+        ptrs = dmap.render_ptrs(eng.crop)
+        want = _render_with_guarded_scratch(eng, dmap, rig, w2c, src)              # worst case, caller scratch, guarded
+        out = torch.zeros_like(want)
+        eng.render_frames_pipelined(dmap, rig, np.asarray(w2c, np.float32), src, out)
+        eng.join()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), tag
+        info = eng.pipeline_info()
+        worst[tag] = int(eng.lib.cama_render_scratch_bytes(N, F, rig.C, H, W, eng.radius))
+        outs[tag] = (info, bool(ptrs[6] & 1))
+        bad = np.zeros(1, np.int64)
+        from cama_amd import _lib
+        _lib.check(eng.lib.cama_pipeline_guard_check(eng._pipe["handle"], bad.ctypes.data))
+        assert int(bad[0]) == 0, (tag, int(bad[0]))
+    # site-sized maps were planned, the clip-sized one (every block in view) was not
+    assert outs["site"][1] and outs["site"][0]["planned_launches"] >= 1 and outs["site"][0]["last_plan_capacity"] > 0
+    assert outs["site-long"][0]["planned_launches"] > outs["site"][0]["planned_launches"]
+    assert not outs["dense"][1] and outs["dense"][0]["planned_launches"] == outs["site-short"][0]["planned_launches"]
+    # two slots of demand-sized scratch against ONE worst-case buffer: well below a tenth for the 40-frame site launch
+    assert outs["site-long"][0]["scratch_bytes"] < 0.1 * worst["site-long"], (outs["site-long"][0], worst["site-long"])
+    # a frame batch with no survivor anywhere (the car far outside the map): still a pure mosaic copy
+    xyz, col, cams, w2c = _scene(9, N, 3, W, H, 300.0)
+    far = np.asarray(w2c, np.float32).copy()
+    far[:, 0, 3] += 5000.0
+    rig = eng.make_rig([c["name"] for c in cams], [c["chassis2camera"] for c in cams], [c["K"] for c in cams], W, H)
+    dmap = eng.upload_map(xyz, col)
+    src = torch.randint(0, 256, (3, 6, H, W, 3), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(eng.mosaic_shape(rig, 3), dtype=torch.uint8, device="cuda")
+    eng.render_frames_pipelined(dmap, rig, far, src, out)
+    eng.join()
+    torch.cuda.synchronize()
+    want = torch.cat([torch.cat([src[:, c] for c in range(r * 3, r * 3 + 3)], dim=2) for r in range(2)], dim=1)
+    assert torch.equal(out, want)
+    assert eng.pipeline_info()["last_plan_capacity"] >= 1
