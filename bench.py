@@ -116,6 +116,10 @@ def parse_args(argv=None):
                     help="budget of the all-core CPU figure (process pool over scenes; 0 disables)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="workers of the all-core CPU figure (0 = every core "
                     "that fits the host memory)")
+    ap.add_argument("--segments", action="store_true",
+                    help="EXTENSION (no reference semantics, SURVEY.md D1): also join neighbouring points of a polyline by "
+                         "one-pixel Bresenham segments (CAMA_BIN_SEGMENTS) -- BASELINE.json's north_star wording; the bytes are "
+                         "checked against the oracle's own restatement in the test-suite, not against golden hashes")
     ap.add_argument("--plan", action="store_true",
                     help="no GPU needed: print, as one JSON object, what every rank of `--gpus N` would hold -- its scenes, "
                          "resident frame / mosaic / map bytes, stamp scratch (worst case and, for planned site-sized maps, "
@@ -134,6 +138,10 @@ def workload_key(frames, verts, width, height, map_kind, raw=False, unit="scene"
             (",per-frame" if unit == "frame" else ""))
 
 
+def _segments(args):
+    return bool(getattr(args, "segments", False))
+
+
 def site_of_scene(args, seed):
     """Site id of scene `seed` (--sites S > 0: scene k drives on site k % S), else None."""
     S = getattr(args, "sites", 0)
@@ -144,7 +152,7 @@ def args_key(args, unit="scene"):
     """workload_key of an argument set (+ the site count, which changes which map a scene is rendered on)."""
     key = workload_key(args.frames, args.verts, args.width, args.height, args.map, raw=getattr(args, "raw_frames", False),
                        unit=unit)
-    return key + (f",sites={args.sites}" if getattr(args, "sites", 0) > 0 else "")
+    return key + (f",sites={args.sites}" if getattr(args, "sites", 0) > 0 else "") + (",segments" if _segments(args) else "")
 
 
 def replace_map(cm, args, seed):
@@ -400,7 +408,7 @@ class Job:
             self.out = torch.empty(self.eng.mosaic_shape(rig, self.F), dtype=torch.uint8, device=device)   # shared
             # several whole scenes per rank: ONE multi-scene launch chain per step, every scene into its own mosaic
             if (len(self.scenes) > 1 and frame_range is None and not getattr(args, "no_scene_batch", False)
-                    and not getattr(args, "raw_frames", False)):
+                    and not getattr(args, "raw_frames", False) and not _segments(args)):
                 self.outs = [self.out] + [torch.empty_like(self.out) for _ in self.scenes[1:]]
                 self.batched = self.step_batched()
                 self.eng.join()
@@ -427,7 +435,7 @@ class Job:
                 idx_all, w2c_all = cm.frame_poses("cama")
                 poses = (idx_all[self.lo:self.hi], w2c_all[self.lo:self.hi])
             dst = self.own_outs[k] if (out is None and self.own_outs) else (self.out if out is None else out)
-            cm.render_clip("cama", out=dst, pipelined=self.pipelined, poses=poses)
+            cm.render_clip("cama", out=dst, pipelined=self.pipelined, poses=poses, segments=_segments(self.args))
 
     def run(self, steps, warmup, sync_all, prof_every):
         import ctypes
@@ -506,7 +514,8 @@ class Job:
         while True:
             poses = (idx_all[lo:lo + per], w2c_all[lo:lo + per])
             try:
-                cm.render_clip("cama", out=self.out[:per], pipelined=False, poses=poses, frames_per_launch=per)
+                cm.render_clip("cama", out=self.out[:per], pipelined=False, poses=poses, frames_per_launch=per,
+                               segments=_segments(self.args))
                 break
             except torch.OutOfMemoryError:                      # (ranks sharing one GPU: the single-stream scratch on top of
                 if per == 1:                                    # the pipeline's two slots may not fit; fewer frames do)
@@ -533,7 +542,7 @@ class Job:
                 idx_all, w2c_all = cm.frame_poses("cama")
                 poses = (idx_all[self.lo:self.hi], w2c_all[self.lo:self.hi])
             self.out.zero_()
-            cm.render_clip("cama", out=self.out, pipelined=False, poses=poses)
+            cm.render_clip("cama", out=self.out, pipelined=False, poses=poses, segments=_segments(self.args))
             torch.cuda.synchronize(self.device)
             if self.frame_range is None:
                 out.append((sid,) + shard.overlay_hash(self.out))
@@ -938,6 +947,11 @@ def main():
                                          "Engine.shared_map): uploaded, Morton-sorted and indexed once"}
             line["config"]["workload"] += "; %d site(s), scene k on site k %% %d" % (args.sites, args.sites)
             line["config"]["sharding"] = "whole scenes placed site by site (shard.assign_scenes(site_of=...)), no data-path collective"
+        if _segments(args):
+            line["config"]["workload"] += "; EXTENSION: discs + one-pixel Bresenham segments between polyline neighbours"
+            line["config"]["extension"] = ("segments: no reference semantics (the reference draws a disc per point, "
+                                           "cama/reproject.py:255-256); bytes checked against the oracle's own restatement "
+                                           "in tests/test_gpu_kernels.py and tests/test_gpu_fullsize.py")
         if args.raw_frames:
             line["config"]["workload"] += "; raw 1600x900 frames resampled on device each step"
             # this mode's kernel reads the raw frames and writes the resized mosaic: 3*C*(H0*W0 + H*W) bytes per frame

@@ -146,11 +146,8 @@ Palette make_palette(const uint8_t *bgr, uint32_t alpha256 = 256u)
 
 int band_rows_for(int W)
 {
-    const char *env = getenv("CAMA_BAND_ROWS");
-    if (env) {
-        int r = atoi(env);
-        if (r == 4 || r == 8 || r == 16 || r == 32) return r;
-    }
+    static const int forced = getenv("CAMA_BAND_ROWS") ? atoi(getenv("CAMA_BAND_ROWS")) : 0;      // (A/B; read once)
+    if (forced == 4 || forced == 8 || forced == 16 || forced == 32) return forced;
     // Measured on MI355X (profiles/): ~20 KB of image per workgroup streams best (more, smaller
     // workgroups balance stamped bands and keep the LDS owner table R*W*4 <= 26 KB -> 6 workgroups per CU).
     // R must stay >= 2*radius so a disc touches at most two bands.
@@ -181,6 +178,11 @@ struct BinPlan {
     bool planned = false;
     uint32_t nseg = 0;              // segments per (frame, camera): 4 x the largest number of surviving blocks of any frame
     uint64_t capacity = 0;          // band entries the sorted list must hold: (wave, camera) chains x 64 x bands per stamp
+    // segment EXTENSION (CAMA_BIN_SEGMENTS): 16-byte records, and a record reaches every band its segment crosses, so no
+    // a-priori bound exists: the band-sorted list lives in a buffer of its own, sized from the scans' grand total
+    bool segments = false;
+    bool have_sorted_capacity = false;
+    uint64_t sorted_capacity = 0;
 };
 struct ScratchLayout {
     // plan part (offsets from its base)
@@ -192,7 +194,8 @@ struct ScratchLayout {
     size_t total;                   // both parts in one buffer: plan_total + stamp_total
     uint64_t capacity;
     uint32_t nseg;
-    bool planned;
+    bool planned, segments;
+    size_t record_bytes;            // 8, or 16 with segment records
     int R, NB, bands_per_stamp;
 };
 
@@ -203,7 +206,10 @@ int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLay
     L.bands_per_stamp = radius > 0 ? 2 : 1;  // 2r+1 rows touch <= 2 bands when 2r <= R (checked by the caller)
     const size_t nbins = (size_t)F * C * L.NB, nfc = (size_t)F * C;
     L.planned = plan && plan->planned;
+    L.segments = plan && plan->segments;
+    L.record_bytes = L.segments ? 16 : 8;
     L.capacity = L.planned ? plan->capacity : (uint64_t)F * C * (uint64_t)N * L.bands_per_stamp;
+    if (L.segments) L.capacity = plan->have_sorted_capacity ? plan->sorted_capacity : 0;   // (its own buffer: ScratchRef::sorted)
     // one segment per wave of the projection grid; planned: per wave of a SURVIVING block of the frame (rank order)
     L.nseg = L.planned ? plan->nseg : (uint32_t)((N + BLOCK - 1) / BLOCK) * (BLOCK / SEG);
     // ---- plan part
@@ -231,8 +237,12 @@ int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLay
     L.bin_off = off;  off = align_up(off + nbins * 4, 256);
     L.fc_total = off; off = align_up(off + nfc * 4, 256);
     L.fc_base = off;  off = align_up(off + nfc * 4, 256);
-    L.stamps0 = off;  off = align_up(off + nfc * L.nseg * SEG * 8 + 8, 256);   // compacted per-segment stamps
-    L.stamps = off;   off = align_up(off + (size_t)L.capacity * 8 + 8, 256);   // >= 1 record: empty bins read stamps[0]
+    L.stamps0 = off;  off = align_up(off + nfc * L.nseg * SEG * L.record_bytes + 16, 256);   // compacted per-segment stamps
+    if (L.segments) {
+        L.stamps = 0;                                                            // offset inside the sorted buffer
+    } else {
+        L.stamps = off;   off = align_up(off + (size_t)L.capacity * 8 + 8, 256);   // >= 1 record: empty bins read stamps[0]
+    }
     L.stamp_total = off;
     L.total = L.plan_total + L.stamp_total;
     return 0;
@@ -243,6 +253,9 @@ struct ScratchRef {
     char *plan = nullptr, *stamp = nullptr;
     size_t plan_bytes = 0, stamp_bytes = 0;
     BinPlan bin_plan;
+    char *sorted = nullptr;         // segment extension only: the band-sorted 16-byte records
+    size_t sorted_bytes = 0;
+    char *stamps_base(const ScratchLayout &L) const { return L.segments ? sorted : stamp + L.stamps; }
 };
 // a caller's single buffer: plan part first, worst-case sized (no plan)
 ScratchRef legacy_scratch(const void *scratch, size_t scratch_bytes, int64_t N, int F, int C, int H, int W, int radius)
@@ -316,10 +329,12 @@ Option g_options[] = {
     {"overlay_item_order", "CAMA_OVERLAY_ITEM_ORDER", 0, {0}, {false}},    // 0 = camera column innermost, 1 = band innermost
     {"overlay_groups_log2", "CAMA_OVERLAY_GROUPS_LOG2", 0, {0}, {false}},  // 1 / 2: 2 / 4 XCD groups, chunked inside (with a
                                                                             // forced overlay_chunk_log2 < 31)
+    {"raw35_ws", "CAMA_RAW35_WS", 0, {0}, {false}},                        // 3:5 raw overlay: wave-specialised persistent
+                                                                            // kernel, value = workgroups per CU (0 = classic)
     {"cull_list_min", "CAMA_CULL_LIST_MIN", 16384, {0}, {false}},          // (block, frame) items from which a site-sized
                                                                             // map's cull goes through work lists
 };
-enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_CULL_LIST_MIN, OPT_COUNT };
+enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_RAW35_WS, OPT_CULL_LIST_MIN, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
 int64_t option(int k)
 {
@@ -659,6 +674,8 @@ static int check_render(int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, i
     layout_scratch(N, F, C, H, W, radius, L, &sc.bin_plan);
     if (sc.plan_bytes < L.plan_total || sc.stamp_bytes < L.stamp_total)
         return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", sc.plan_bytes + sc.stamp_bytes, L.total);
+    if (L.segments && sc.bin_plan.have_sorted_capacity && (!sc.sorted || sc.sorted_bytes < (size_t)L.capacity * 16 + 16))
+        return fail(CAMA_EINVAL, "segment records: the sorted buffer is too small");
     if (L.capacity >= (1ull << 32))
         return fail(CAMA_EINVAL, "%llu band entries exceed 32-bit offsets: render fewer frames per call",
                     (unsigned long long)L.capacity);
@@ -726,14 +743,24 @@ struct BinCall {
     int32_t W, H, radius;
 };
 
+// A/B switches of the binning chain, read from the environment once (a getenv per launch is a scan of the whole environment,
+// and the 960x540 pipeline is bound by the host issuing its launches)
+struct BinEnv { bool no_cam_mask, no_candidates, no_plan, no_xcd_pad; };
+static const BinEnv &bin_env()
+{
+    static const BinEnv e{getenv("CAMA_NO_CAM_MASK") != nullptr, getenv("CAMA_NO_CANDIDATES") != nullptr,
+                          getenv("CAMA_NO_PLAN") != nullptr, getenv("CAMA_NO_XCD_PAD") != nullptr};
+    return e;
+}
+
 // does this launch's cull go through work lists (site-sized maps) / the candidate pre-pass (what a plan needs)?
 static bool bin_uses_list(const BinCall &b)
 {
     const unsigned vblocks = (unsigned)((b.N + BLOCK - 1) / BLOCK);
-    return b.N && b.block_bounds && !getenv("CAMA_NO_CAM_MASK") && (b.flags & CAMA_BIN_WORKLIST) &&
+    return b.N && b.block_bounds && !bin_env().no_cam_mask && (b.flags & CAMA_BIN_WORKLIST) &&
            (uint64_t)vblocks * (uint64_t)b.F >= cull_list_threshold();
 }
-static bool bin_plannable(const BinCall &b) { return !b.scenes_dev && bin_uses_list(b) && !getenv("CAMA_NO_CANDIDATES"); }
+static bool bin_plannable(const BinCall &b) { return !b.scenes_dev && bin_uses_list(b) && !bin_env().no_candidates; }
 
 static int check_bin_call(const BinCall &b)
 {
@@ -749,9 +776,11 @@ static int bin_prepass(const BinCall &b, const ScratchLayout &L, char *pbase, hi
     const int64_t N = b.N;
     const int F = b.F, C = b.C;
     uint32_t *work_count = (uint32_t *)(pbase + L.work_count), *work = (uint32_t *)(pbase + L.work);
+    // (maps without a block index have no pre-pass: nothing reads the plan part, nothing to clear -- a memset per launch is
+    // 6-8 us of host time, which the 960x540 pipeline is bound by)
+    if (!(N && b.block_bounds && !bin_env().no_cam_mask)) return CAMA_OK;
     // the work-list / candidate counters, the per-frame item counters and the demand word are adjacent: one memset
     HIP_TRY(hipMemsetAsync(pbase + L.work_count, 0, L.plan_zero_bytes - L.work_count, s));
-    if (!(N && b.block_bounds && !getenv("CAMA_NO_CAM_MASK"))) return CAMA_OK;
     const unsigned vblocks = (unsigned)((N + BLOCK - 1) / BLOCK);
     const bool use_list = bin_uses_list(b);
     const dim3 lgrid(persistent_workgroups());
@@ -762,7 +791,7 @@ static int bin_prepass(const BinCall &b, const ScratchLayout &L, char *pbase, hi
     const dim3 cgrid((4 * vblocks + BLOCK - 1) / BLOCK, (unsigned)F);
     double *cam_fn = (double *)(pbase + L.cam_fn);
     // site-sized maps: a six-comparison world-space test first, the exact tests on the compacted candidates only
-    const bool use_cand = use_list && !getenv("CAMA_NO_CANDIDATES");
+    const bool use_cand = use_list && !bin_env().no_candidates;
     double *frame_box = (double *)(pbase + L.frame_box);
     const unsigned fn_threads = CAMA_MAX_CAMERAS * 20 <= 256 ? 256 : 512;
     hipLaunchKernelGGL(k_camera_functionals, dim3(use_cand ? 1 + ((unsigned)F + fn_threads - 1) / fn_threads : 1),
@@ -804,10 +833,13 @@ static int bin_prepass(const BinCall &b, const ScratchLayout &L, char *pbase, hi
     return CAMA_OK;
 }
 
-// projection -> scans -> scatter, out of the plan part `pbase` into the stamp part `sbase` (layout L, planned or not)
-static int bin_main(const BinCall &b, const ScratchLayout &L, char *pbase, char *sbase, hipStream_t s)
+// projection -> scans (phase A) -> scatter (phase B), out of the plan part into the stamp part (layout L, planned or not).
+// Segment records: the caller reads the scans' grand total between A and B and sizes the sorted buffer from it.
+enum { BIN_PHASE_A = 1, BIN_PHASE_B = 2, BIN_PHASES_AB = 3 };
+static int bin_main(const BinCall &b, const ScratchLayout &L, const ScratchRef &sc, hipStream_t s, int phases = BIN_PHASES_AB)
 {
     if (b.F == 0) return CAMA_OK;
+    char *pbase = sc.plan, *sbase = sc.stamp;
     const int64_t N = b.N;
     const int F = b.F, C = b.C, W = b.W, H = b.H, radius = b.radius;
     uint32_t *counts = (uint32_t *)(sbase + L.counts), *cursor = (uint32_t *)(sbase + L.cursor);
@@ -816,7 +848,7 @@ static int bin_main(const BinCall &b, const ScratchLayout &L, char *pbase, char 
     const int nfc = F * C;
 
     // counts, cursor and the segment count table are adjacent: one memset
-    if (!g_skip_bin_memset) HIP_TRY(hipMemsetAsync(counts, 0, L.zero_bytes, s));
+    if ((phases & BIN_PHASE_A) && !g_skip_bin_memset) HIP_TRY(hipMemsetAsync(counts, 0, L.zero_bytes, s));
 
     FrameArgs a{};
     a.scenes = b.scenes_dev; a.frames_per_scene = b.frames_per_scene;
@@ -826,7 +858,11 @@ static int bin_main(const BinCall &b, const ScratchLayout &L, char *pbase, char 
     a.band_shift = log2i(L.R); a.NB = L.NB; a.radius = radius;
     a.nseg = L.nseg; a.seg_cnt = (uint8_t *)(sbase + L.seg_cnt); a.stamps0 = (uint2 *)(sbase + L.stamps0);
     a.counts = counts; a.cursor = cursor; a.bin_off = bin_off; a.fc_base = fc_base;
-    a.stamps = (uint2 *)(sbase + L.stamps);
+    a.stamps = (uint2 *)sc.stamps_base(L);
+    a.segments = L.segments ? 1 : 0;
+    if (L.segments && b.draw_key)
+        return fail(CAMA_EINVAL, "segments need the map in draw order (no draw_key: a spatially sorted copy has no polyline neighbours)");
+    if (L.segments && b.scenes_dev) return fail(CAMA_EINVAL, "segments are not offered for multi-scene launches");
     // XCD-aware mapping: workgroup (x, y) has linear id x + y * gridDim.x and runs on XCD id % 8.  With gridDim.x a
     // multiple of 8, vertex chunk x is processed on the SAME XCD for every frame y, so on big maps each XCD's 4 MB L2
     // keeps its 1/8 of the vertex buffer across all frames instead of re-fetching it per frame (padding workgroups
@@ -836,7 +872,7 @@ static int bin_main(const BinCall &b, const ScratchLayout &L, char *pbase, char 
     // chip anyway (launch + histogram clear / flush per 256 vertices made big maps dispatch-bound)
     const int vb_per_wg = project_blocks_per_workgroup((uint64_t)vblocks * (uint64_t)F);
     const unsigned vchunks = (vblocks + vb_per_wg - 1) / vb_per_wg;
-    const dim3 fgrid(getenv("CAMA_NO_XCD_PAD") ? vchunks : ((vchunks + 7u) & ~7u), (unsigned)F);
+    const dim3 fgrid(bin_env().no_xcd_pad ? vchunks : ((vchunks + 7u) & ~7u), (unsigned)F);
     const size_t hist_lds = align_up((size_t)C * L.NB * 4, 16);
     // With the map's spatial index (block AABBs) a one-thread-per-(block, frame) pre-pass decided which cameras can see
     // each block at all (bin_prepass); the projection skips the others.  Site-sized maps (CAMA_BIN_WORKLIST: most
@@ -847,10 +883,11 @@ static int bin_main(const BinCall &b, const ScratchLayout &L, char *pbase, char 
     uint32_t *work_count = (uint32_t *)(pbase + L.work_count), *work = (uint32_t *)(pbase + L.work);
     const uint32_t *work_rank = L.planned ? (const uint32_t *)(pbase + L.work_rank) : nullptr;
     const dim3 lgrid(persistent_workgroups());
-    if (N && b.block_bounds && !getenv("CAMA_NO_CAM_MASK")) {
+    if (N && b.block_bounds && !bin_env().no_cam_mask) {
         a.cam_mask = (const uint64_t *)(pbase + L.cam_mask);
         a.vblocks = vblocks;
     }
+    if (phases & BIN_PHASE_A) {
     // live timing (cama_profile_enable): the projection takes an event pair as its own start / stop events
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (N && g_prof.on) {
@@ -878,9 +915,15 @@ static int bin_main(const BinCall &b, const ScratchLayout &L, char *pbase, char 
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(64), 0, s, fc_total, fc_base, nfc);
     HIP_TRY(hipGetLastError());
-    if (N) {
+    }
+    if (N && (phases & BIN_PHASE_B)) {
         const dim3 sgrid((L.nseg + SCATTER_SEGS - 1) / SCATTER_SEGS, (unsigned)nfc);
-        if (g_scatter_stop_event) {
+        if (L.segments) {
+            hipEvent_t stop = g_scatter_stop_event;
+            g_scatter_stop_event = nullptr;
+            hipExtLaunchKernelGGL(k_stamps_scatter_seg, sgrid, dim3(BLOCK), (uint32_t)align_up((size_t)2 * L.NB * 4, 16), s,
+                                  nullptr, stop, 0u, a);
+        } else if (g_scatter_stop_event) {
             hipExtLaunchKernelGGL(k_stamps_scatter, sgrid, dim3(BLOCK), (uint32_t)align_up((size_t)2 * L.NB * 4, 16), s,
                                   nullptr, g_scatter_stop_event, 0u, a);
             g_scatter_stop_event = nullptr;
@@ -903,9 +946,11 @@ static int bin_impl(const SceneRef *scenes_dev, int frames_per_scene, const void
     const BinCall b{scenes_dev, frames_per_scene, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K,
                     C, crop, W, H, radius};
     if (int rc = check_bin_call(b)) return rc;
-    char *pbase = (char *)scratch, *sbase = (char *)scratch + L.plan_total;
-    if (int rc = bin_prepass(b, L, pbase, (hipStream_t)stream)) return rc;
-    return bin_main(b, L, pbase, sbase, (hipStream_t)stream);
+    if (flags & CAMA_BIN_SEGMENTS)
+        return fail(CAMA_EINVAL, "CAMA_BIN_SEGMENTS needs a pipeline that owns its scratch (cama_pipeline_render with scratch0 == NULL)");
+    const ScratchRef sc = legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius);
+    if (int rc = bin_prepass(b, L, sc.plan, (hipStream_t)stream)) return rc;
+    return bin_main(b, L, sc, (hipStream_t)stream);
 }
 
 extern "C" {
@@ -937,7 +982,7 @@ static int bin_stats_impl(const ScratchRef &sc, int64_t N, int32_t F, int32_t C,
     const char *base = sc.plan, *sbase = sc.stamp;
     const size_t nfc = (size_t)F * C;
     const uint64_t vblocks = (uint64_t)((N + BLOCK - 1) / BLOCK), waves = (uint64_t)((N + 63) / 64);
-    if (had_block_bounds && N && !getenv("CAMA_NO_CAM_MASK")) {
+    if (had_block_bounds && N && !bin_env().no_cam_mask) {
         std::vector<uint64_t> hm((size_t)vblocks * F);
         HIP_TRY(hipMemcpy(hm.data(), base + L.cam_mask, hm.size() * 8, hipMemcpyDeviceToHost));
         uint32_t wc[32];
@@ -1038,7 +1083,7 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     o.mosaic_row_bytes = (size_t)cols * W * 3;
     o.mosaic_frame_bytes = (size_t)rows * H * o.mosaic_row_bytes;
     o.counts = (const uint32_t *)(base + L.counts); o.bin_off = (const uint32_t *)(base + L.bin_off);
-    o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)(base + L.stamps);
+    o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)sc.stamps_base(L);
     o.disc = disc; o.pal = make_palette(palette_bgr, g_next_alpha256);
     g_next_alpha256 = 256u;
     // (multi-scene launches: the caller has checked every scene's src / mosaic alignment and W % 16 == 0)
@@ -1112,7 +1157,18 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
                   (size_t)raw->max_src_rows * raw->max_tile_bytes + 16;
         raw_lds = lds_raw <= 160 * 1024;
     }
-    if (raw_lds) {
+    if (L.segments) {
+        // EXTENSION: 16-byte records, discs + one-pixel segments; the plain vectorised overlay only
+        if (raw || !vec || o.pal.alpha256 != 256u || scenes_dev)
+            return fail(CAMA_EINVAL, "segments: plain overlay only (W %% 16 == 0, opaque, pre-resized frames, one scene)");
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (trial.e0) { g_map_tuner.abandon(trial); trial.e0 = trial.e1 = nullptr; }
+        hipEvent_t e0 = (exact_timing && ev0 && ev1) ? ev0 : nullptr;
+        hipEvent_t e1 = e0 ? ev1 : g_overlay_stop_event;
+        hipExtLaunchKernelGGL((k_overlay<true, false, false, true>), ogrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, e0, e1, 0u, o);
+        if (!e0) g_overlay_stop_event = nullptr;
+    } else if (raw_lds) {
         if (lds_raw > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_rawlds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_raw));
@@ -1292,7 +1348,8 @@ static int raw35_impl(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t
     o.mosaic_row_bytes = (size_t)cols * W * 3;
     o.mosaic_frame_bytes = (size_t)rows * H * o.mosaic_row_bytes;
     o.counts = (const uint32_t *)(base + L.counts); o.bin_off = (const uint32_t *)(base + L.bin_off);
-    o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)(base + L.stamps);
+    o.fc_base = (const uint32_t *)(base + L.fc_base); o.stamps = (const uint2 *)sc.stamps_base(L);
+    if (L.segments) return fail(CAMA_EINVAL, "segments: plain overlay only");
     o.disc = disc; o.pal = make_palette(palette_bgr);
     o.H0 = H0; o.W0 = W0;
     // column tiles per band (CAMA_RAW35_TILES=2: 960-wide tiles, 160 threads, 17 KB of LDS -> 8 workgroups per CU instead of
@@ -1340,7 +1397,19 @@ static int raw35_impl(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t
     hipEvent_t e1 = e0 ? ev1 : g_overlay_stop_event;
     const uint2 *vr2 = reinterpret_cast<const uint2 *>(vrows);
     const int2 *br2 = reinterpret_cast<const int2 *>(band_rows);
-    if (bands_per_wg == 2)
+    // wave-specialised persistent variant (raw35_kernels.hpp: k_overlay_raw35_ws; option raw35_ws): one band per workgroup
+    // round, a loader wave, a double staging buffer -- needs contiguous staged rows (row pitch == staged row) and whole bands
+    const int64_t ws = option(OPT_RAW35_WS);
+    const uint32_t src_pitch16 = (uint32_t)W0 * 3u / 16u;
+    if (ws > 0 && TX == 1 && bands_per_wg == 1 && src_pitch16 == cpt && block + 64u <= 1024u && 2 * lds + 64 <= 160 * 1024) {
+        const size_t lds2 = 2 * lds;
+        if (lds2 > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ws, (160 * 1024) / lds2));
+        const unsigned G = std::min<unsigned>(256u * per_cu, (rgrid.x + 7u) & ~7u) & ~7u;
+        hipExtLaunchKernelGGL(k_overlay_raw35_ws, dim3(std::max(G, 8u)), dim3(block + 64u), (uint32_t)lds2, s, e0, e1, 0u, o, vr2, br2,
+                              upr, max_src_rows, (int)owner_off, nbx_magic, rgrid.x, (uint32_t)staging_dw);
+    } else if (bands_per_wg == 2)
         hipExtLaunchKernelGGL(k_overlay_raw35<2>, rgrid, dim3(block), (uint32_t)lds, s, e0, e1, 0u, o, vr2, br2, upr, max_src_rows,
                               (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic);
     else
@@ -1471,8 +1540,8 @@ struct cama_pipeline {
     size_t pose_cap = 0;                        // doubles per slot
     // scratch the pipeline owns (cama_pipeline_render* with scratch0 == NULL): per slot a plan part and a stamp part, grown
     // on demand and never shrunk; the stamp part carries `guard` pattern bytes on either side (cama_pipeline_guard_check)
-    char *own_plan[2] = {nullptr, nullptr}, *own_stamp[2] = {nullptr, nullptr};
-    size_t own_plan_bytes[2] = {0, 0}, own_stamp_bytes[2] = {0, 0};
+    char *own_plan[2] = {nullptr, nullptr}, *own_stamp[2] = {nullptr, nullptr}, *own_sorted[2] = {nullptr, nullptr};
+    size_t own_plan_bytes[2] = {0, 0}, own_stamp_bytes[2] = {0, 0}, own_sorted_bytes[2] = {0, 0};
     static constexpr size_t GUARD = (size_t)1 << 20;
     uint64_t *demand_host = nullptr;            // pinned: [0] (wave, camera) chains, [1..] surviving blocks per frame
     size_t demand_cap = 0;                      // uint64 words
@@ -1523,6 +1592,7 @@ int cama_pipeline_destroy(cama_pipeline *p)
     for (int k = 0; k < 2; ++k) {
         if (p->pose_dev[k]) (void)hipFree(p->pose_dev[k]);
         if (p->own_plan[k]) (void)hipFree(p->own_plan[k]);
+        if (p->own_sorted[k]) (void)hipFree(p->own_sorted[k]);
         if (p->own_stamp[k]) (void)hipFree(p->own_stamp[k] - cama_pipeline::GUARD);
     }
     delete p;
@@ -1621,14 +1691,17 @@ static int pipeline_grow(cama_pipeline *p, char **buf, size_t *have, size_t need
 // (site-sized map + block index: bin_plannable) the cull pre-pass runs first, the host waits for its two demand figures --
 // a few tens of microseconds behind the previous launch's chain, while the overlays of earlier launches keep the GPU busy --
 // and the stamp part is sized from them instead of from the worst case.
-template <typename Bin, typename Overlay>
-static int pipeline_impl(cama_pipeline *p, int64_t N, int32_t F, int32_t C, int32_t W, int32_t H, int32_t radius,
-                         void *scratch0, void *scratch1, size_t scratch_bytes, void *input_stream,
-                         bool overlay_takes_stop_event, const BinCall *plan_call, Bin bin, Overlay overlay)
+template <typename Overlay>
+static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, void *scratch1, size_t scratch_bytes,
+                         void *input_stream, bool overlay_takes_stop_event, Overlay overlay)
 {
     if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
+    const int64_t N = call.N;
+    const int32_t F = call.F, C = call.C, W = call.W, H = call.H, radius = call.radius;
     const bool managed = !scratch0 && !scratch1;
     if (!managed && (!scratch0 || !scratch1)) return fail(CAMA_EINVAL, "two scratch buffers are needed (or none: pipeline-owned)");
+    const bool segments = (call.flags & CAMA_BIN_SEGMENTS) != 0;
+    if (segments && !managed) return fail(CAMA_EINVAL, "CAMA_BIN_SEGMENTS needs pipeline-owned scratch (scratch0 == scratch1 == NULL)");
     constexpr uint64_t RING = cama_pipeline::RING;
     const uint64_t k = p->issued + 1;                     // this launch
     const int slot = (int)((k - 1) & 1u);
@@ -1639,26 +1712,28 @@ static int pipeline_impl(cama_pipeline *p, int64_t N, int32_t F, int32_t C, int3
     }
     if (int rc = check_common(N, F, C, W, H)) return rc;
     if (radius < 0 || radius > CAMA_MAX_RADIUS) return fail(CAMA_EINVAL, "radius %d out of range", radius);
+    if (F > 0)
+        if (int rc = check_bin_call(call)) return rc;
     ScratchRef sc;
     ScratchLayout L;
     bool prepass_done = false;
+    sc.bin_plan.segments = segments;
     if (!managed) {
         // validate before anything is enqueued, so a rejected call leaves the pipeline state untouched
         void *scratch = slot ? scratch1 : scratch0;
         if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
         sc = legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius);
     } else {
-        layout_scratch(N, F, C, H, W, radius, L);
-        const bool plannable = plan_call && F > 0 && bin_plannable(*plan_call) && !getenv("CAMA_NO_PLAN");
+        layout_scratch(N, F, C, H, W, radius, L, &sc.bin_plan);
+        const bool plannable = F > 0 && bin_plannable(call) && !bin_env().no_plan;
         if (int rc = pipeline_grow(p, &p->own_plan[slot], &p->own_plan_bytes[slot], L.plan_total, false, k)) return rc;
         sc.plan = p->own_plan[slot];
         sc.plan_bytes = p->own_plan_bytes[slot];
         if (plannable) {
-            if (int rc = check_bin_call(*plan_call)) return rc;
             // the pre-pass only writes the plan part, which the overlay of launch k - 2 never reads: it need not wait for it
             HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
             HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
-            if (int rc = bin_prepass(*plan_call, L, sc.plan, p->s_bin)) return rc;
+            if (int rc = bin_prepass(call, L, sc.plan, p->s_bin)) return rc;
             const size_t words = 1 + (size_t)F;
             if (words > p->demand_cap) {
                 if (p->demand_host) (void)hipHostFree(p->demand_host);
@@ -1686,6 +1761,8 @@ static int pipeline_impl(cama_pipeline *p, int64_t N, int32_t F, int32_t C, int3
         if (int rc = pipeline_grow(p, &p->own_stamp[slot], &p->own_stamp_bytes[slot], L.stamp_total, true, k)) return rc;
         sc.stamp = p->own_stamp[slot];
         sc.stamp_bytes = p->own_stamp_bytes[slot];
+        sc.sorted = p->own_sorted[slot];
+        sc.sorted_bytes = p->own_sorted_bytes[slot];
         ScratchLayout chk;
         if (int rc = check_render(N, F, C, W, H, radius, sc, chk)) return rc;
     }
@@ -1695,17 +1772,43 @@ static int pipeline_impl(cama_pipeline *p, int64_t N, int32_t F, int32_t C, int3
         HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
     }
     if (k > 2) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->done[(k - 2) % RING], 0));   // the overlay that read this slot
-    {
-        // the chain's last kernel (k_stamps_scatter, launched whenever N > 0) carries `binned` as its own stop event
+    if (F > 0) {
+        if (!prepass_done)
+            if (int rc = bin_prepass(call, L, sc.plan, p->s_bin)) return rc;
+        // the chain's last kernel (the scatter, launched whenever N > 0) carries `binned` as its own stop event
         const bool ext = ext_events() && N > 0;
-        g_scatter_stop_event = ext ? p->binned[slot] : nullptr;
-        if (int rc = bin(sc, L, prepass_done, (void *)p->s_bin)) {
+        int rc = CAMA_OK;
+        if (segments) {
+            // a record reaches every band its segment crosses: project + scan first, read the grand total of band entries,
+            // size the sorted list exactly, then scatter
+            rc = bin_main(call, L, sc, p->s_bin, BIN_PHASE_A);
+            if (rc) return rc;
+            const size_t nfc = (size_t)F * C;
+            uint32_t tail[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(&tail[0], sc.stamp + L.fc_base + (nfc - 1) * 4, 4, hipMemcpyDeviceToHost, p->s_bin));
+            HIP_TRY(hipMemcpyAsync(&tail[1], sc.stamp + L.fc_total + (nfc - 1) * 4, 4, hipMemcpyDeviceToHost, p->s_bin));
+            HIP_TRY(hipStreamSynchronize(p->s_bin));
+            sc.bin_plan.have_sorted_capacity = true;
+            sc.bin_plan.sorted_capacity = (uint64_t)tail[0] + tail[1] + 1;
+            if (int rg = pipeline_grow(p, &p->own_sorted[slot], &p->own_sorted_bytes[slot],
+                                       (size_t)sc.bin_plan.sorted_capacity * 16 + 16, false, k)) return rg;
+            sc.sorted = p->own_sorted[slot];
+            sc.sorted_bytes = p->own_sorted_bytes[slot];
+            layout_scratch(N, F, C, H, W, radius, L, &sc.bin_plan);
+            g_scatter_stop_event = ext ? p->binned[slot] : nullptr;
+            rc = bin_main(call, L, sc, p->s_bin, BIN_PHASE_B);
+        } else {
+            g_scatter_stop_event = ext ? p->binned[slot] : nullptr;
+            rc = bin_main(call, L, sc, p->s_bin);
+        }
+        if (rc) {
             g_scatter_stop_event = nullptr;
             return rc;
         }
         if (!ext || g_scatter_stop_event) HIP_TRY(hipEventRecord(p->binned[slot], p->s_bin));
         g_scatter_stop_event = nullptr;
-    }
+    } else
+        HIP_TRY(hipEventRecord(p->binned[slot], p->s_bin));
     // (overlays stay on ONE stream: two overlays in flight at once interleave their streams in DRAM -- measured
     // 106.8 k vs 109.9 k frames/s)
     hipStream_t so = p->s_ov;
@@ -1723,7 +1826,7 @@ static int pipeline_impl(cama_pipeline *p, int64_t N, int32_t F, int32_t C, int3
     p->last[slot].sc = sc;
     p->last[slot].N = N; p->last[slot].F = F; p->last[slot].C = C; p->last[slot].H = H; p->last[slot].W = W;
     p->last[slot].radius = radius;
-    p->last[slot].bounds = plan_call && plan_call->block_bounds != nullptr;
+    p->last[slot].bounds = call.block_bounds != nullptr;
     p->last_slot = slot;
     return CAMA_OK;
 }
@@ -1737,16 +1840,7 @@ static int pipeline_render_impl(cama_pipeline *p, const void *x, const void *y, 
 {
     const BinCall b{nullptr, 0, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H,
                     radius};
-    if (F > 0)
-        if (int rc = check_bin_call(b)) return rc;
-    return pipeline_impl(p, N, F, C, W, H, radius, scratch0, scratch1, scratch_bytes, input_stream, overlay_takes_stop_event, &b,
-                         [&](const ScratchRef &sc, const ScratchLayout &L, bool prepass_done, void *sb) {
-                             if (F == 0) return (int)CAMA_OK;
-                             if (!prepass_done)
-                                 if (int rc = bin_prepass(b, L, sc.plan, (hipStream_t)sb)) return rc;
-                             return bin_main(b, L, sc.plan, sc.stamp, (hipStream_t)sb);
-                         },
-                         overlay);
+    return pipeline_impl(p, b, scratch0, scratch1, scratch_bytes, input_stream, overlay_takes_stop_event, overlay);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1823,12 +1917,7 @@ int cama_pipeline_render_scenes(cama_pipeline *p, const cama_scene *scenes_host,
     if (!w2c || !crop) return fail(CAMA_EINVAL, "NULL pointer argument");
     const BinCall b{reinterpret_cast<const SceneRef *>(scenes_dev), F, nullptr, nullptr, nullptr, xyz_is_f64, nullptr, nullptr,
                     nullptr, 0, nmax, w2c, S * F, nullptr, nullptr, C, crop, W, H, radius};
-    return pipeline_impl(p, nmax, S * F, C, W, H, radius, scratch0, scratch1, scratch_bytes, input_stream, true, nullptr,
-                         [&](const ScratchRef &sc, const ScratchLayout &L, bool, void *sb) {
-                             if (S * F == 0) return (int)CAMA_OK;
-                             if (int rc = bin_prepass(b, L, sc.plan, (hipStream_t)sb)) return rc;
-                             return bin_main(b, L, sc.plan, sc.stamp, (hipStream_t)sb);
-                         },
+    return pipeline_impl(p, b, scratch0, scratch1, scratch_bytes, input_stream, true,
                          [&](const ScratchRef &sc, void *so) {
                              return overlay_impl(nullptr, nullptr, nullptr, nmax, S * F, C, H, W, cols, radius, halfwidth,
                                                  palette_bgr, sc, so, scenes_host, F);
@@ -1874,7 +1963,7 @@ int64_t cama_pipeline_scratch_bytes(cama_pipeline *p)
 {
     if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
     int64_t n = 0;
-    for (int k = 0; k < 2; ++k) n += (int64_t)p->own_plan_bytes[k] + (int64_t)p->own_stamp_bytes[k];
+    for (int k = 0; k < 2; ++k) n += (int64_t)p->own_plan_bytes[k] + (int64_t)p->own_stamp_bytes[k] + (int64_t)p->own_sorted_bytes[k];
     return n;
 }
 

@@ -78,6 +78,28 @@ __device__ __forceinline__ void rasterise_one_padded(uint32_t *s_owner, const ui
     }
 }
 
+// EXTENSION (segment records, 16 bytes): the one-pixel 8-connected Bresenham segment from the predecessor's pixel (r.z) to the
+// point's own (r.x), both ends included, under the point's key -- the integer recurrence of oracle_line_bresenham, restated;
+// only the rows of this band are written (the other bands the segment crosses hold a copy of the record and do theirs).
+__device__ __forceinline__ void rasterise_segment_padded(uint32_t *s_owner, const uint4 r, int y0, int nrows, int Wp, int radius)
+{
+    if (r.z == 0xffffffffu) return;
+    int x = (int)(r.z & 0xffffu), y = (int)(r.z >> 16);
+    const int x1 = (int)(r.x & 0xffffu), y1 = (int)(r.x >> 16);
+    const uint32_t val = r.y + 1u;
+    const int dx = abs(x1 - x), sx = x < x1 ? 1 : -1;
+    const int dy = -abs(y1 - y), sy = y < y1 ? 1 : -1;
+    int err = dx + dy;
+    for (int guard = 0; guard < 4 * 65536; ++guard) {                  // (a segment has at most W + H pixels)
+        if ((unsigned)(y - y0) < (unsigned)nrows) atomicMax(&s_owner[(y - y0) * Wp + x + radius], val);
+        else if ((sy > 0 && y >= y0 + nrows) || (sy < 0 && y < y0)) break;     // past the band, moving away from it
+        if (x == x1 && y == y1) break;
+        const int e2 = 2 * err;
+        if (e2 >= dy) { err += dy; x += sx; }
+        if (e2 <= dx) { err += dx; y += sy; }
+    }
+}
+
 // Stamps `first`, first + stride, ... < n of a band's list, four record loads in flight per thread: on bands that
 // collect tens of thousands of stamps (dense maps: every far lane converges on a few horizon rows) the loop is a chain of
 // global-load latencies, and such a band's workgroup is the kernel's straggler.  Loads are unconditional (clamped index):
@@ -271,7 +293,7 @@ __device__ __forceinline__ BandId decode_band(const OverlayArgs &a, const uint32
     return id;
 }
 
-template <bool VEC, bool RESAMPLE, bool ALPHA>
+template <bool VEC, bool RESAMPLE, bool ALPHA, bool SEGS = false>
 __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint32_t fl, const uint32_t f0, const uint32_t c,
                                                 const uint32_t b, uint32_t *s_owner)
 {
@@ -298,7 +320,14 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
     // (count, offsets: three independent scalar loads, one latency -- not count first and the offsets behind a branch)
     const uint32_t list0 = a.fc_base[fc] + a.bin_off[bin];
     const uint2 *st = a.stamps + (n ? (size_t)list0 : (size_t)0);
-    const uint2 first = st[n ? min(threadIdx.x, n - 1u) : 0u];
+    const uint4 *st4 = reinterpret_cast<const uint4 *>(a.stamps) + (n ? (size_t)list0 : (size_t)0);   // (SEGS: 16-byte records)
+    uint2 first = make_uint2(0u, 0u);
+    uint4 first4 = make_uint4(0u, 0u, 0xffffffffu, 0u);
+    if (SEGS) {
+        first4 = st4[n ? min(threadIdx.x, n - 1u) : 0u];
+        first = make_uint2(first4.x, first4.y);
+    } else
+        first = st[n ? min(threadIdx.x, n - 1u) : 0u];
     __builtin_amdgcn_sched_barrier(0);          // keep the record load ahead of the source loads (in-order vmcnt)
 
     const uint8_t *sband = a.src + ((size_t)fcl * a.H + y0) * (size_t)W * 3;     // (unused by RESAMPLE)
@@ -323,8 +352,19 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
         lds_barrier();
 #ifndef ABL_NO_RASTER
         const uint32_t hw8 = (uint32_t)a.disc.hw4, rowmask = a.disc.rows;      // radius <= 7 (host-checked for this kernel)
-        if (threadIdx.x < n) rasterise_one_padded(s_owner, first, y0, nrows, Wp, rad, hw8, rowmask);
-        rasterise_rest_padded(s_owner, st, threadIdx.x + OVERLAY_BLOCK, OVERLAY_BLOCK, n, y0, nrows, Wp, rad, hw8, rowmask);
+        if (SEGS) {
+            for (uint32_t sidx = threadIdx.x; sidx < n; sidx += OVERLAY_BLOCK) {
+                const uint4 r = sidx == threadIdx.x ? first4 : st4[sidx];
+                rasterise_segment_padded(s_owner, r, y0, nrows, Wp, rad);
+                // (the disc of a record that is here only because its segment crosses this band may lie outside it)
+                const int v = (int)(r.x >> 16);
+                if (v + rad >= y0 && v - rad < y0 + nrows)
+                    rasterise_one_padded(s_owner, make_uint2(r.x, r.y), y0, nrows, Wp, rad, hw8, rowmask);
+            }
+        } else {
+            if (threadIdx.x < n) rasterise_one_padded(s_owner, first, y0, nrows, Wp, rad, hw8, rowmask);
+            rasterise_rest_padded(s_owner, st, threadIdx.x + OVERLAY_BLOCK, OVERLAY_BLOCK, n, y0, nrows, Wp, rad, hw8, rowmask);
+        }
 #endif
         lds_barrier();
     }
@@ -437,12 +477,12 @@ __device__ __forceinline__ void tlb_lookahead(const OverlayArgs &a)
     asm volatile("global_load_ubyte %0, %2, off\n\tglobal_load_ubyte %1, %3, off" : "=&v"(t0), "=&v"(t1) : "v"(sp), "v"(dp) : "memory");
 }
 
-template <bool VEC, bool RESAMPLE, bool ALPHA = false>
+template <bool VEC, bool RESAMPLE, bool ALPHA = false, bool SEGS = false>
 __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x (W + 2 radius), used only by stamped bands
     const BandId id = decode_band(a, a.items, 1u, 0u);
-    if (id.valid) overlay_band_at<VEC, RESAMPLE, ALPHA>(a, id.fl, (uint32_t)a.f0, id.c, id.b, s_owner);
+    if (id.valid) overlay_band_at<VEC, RESAMPLE, ALPHA, SEGS>(a, id.fl, (uint32_t)a.f0, id.c, id.b, s_owner);
     tlb_lookahead<RESAMPLE>(a);
 }
 

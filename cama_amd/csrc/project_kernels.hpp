@@ -242,6 +242,8 @@ struct FrameArgs {
     uint32_t *counts, *cursor;
     const uint32_t *bin_off, *fc_base;
     uint2 *stamps;          // band-sorted stamps (k_stamps_scatter)
+    int segments;           // EXTENSION (no reference semantics): records are 16 bytes {uv, key, uv of the polyline
+                            // predecessor or ~0, 0}: the overlay also draws the one-pixel segment between the two
 };
 
 // Multi-scene launch: overwrite the per-scene fields of the (by-value) argument block with frame f's scene.
@@ -307,13 +309,18 @@ struct WaveVerts {
     bool in;
     uint32_t cams;          // cameras that may see these 64 vertices (wave-uniform); 0 = nothing to do
     uint32_t seg;           // segment index inside (frame, camera)
+    // segment extension: is this vertex joined to its predecessor on the polyline (bit 1 of its colour byte)?  Lane 0's
+    // predecessor belongs to the previous wave: its chassis point travels in (hx, hy, hz, hin) of lane 0
+    bool link;
+    double hx, hy, hz;
+    bool hin;
 };
 
 template <typename T>
 __device__ __forceinline__ WaveVerts load_wave_verts(const FrameArgs &a, const int64_t vblock, const int f, const uint64_t cams4,
                                                      const uint32_t seg_base)
 {
-    WaveVerts v{0.0, 0.0, 0.0, 0u, false, 0u, 0u};
+    WaveVerts v{0.0, 0.0, 0.0, 0u, false, 0u, 0u, false, 0.0, 0.0, 0.0, false};
     // this wave's 16 camera bits (wave-uniform: kept in an SGPR)
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     v.cams = (uint32_t)(cams4 >> (16u * wave)) & 0xffffu;
@@ -330,7 +337,17 @@ __device__ __forceinline__ WaveVerts load_wave_verts(const FrameArgs &a, const i
         v.in = in_crop(a.crop, v.cx, v.cy, v.cz);
         // draw index << 1 | colour.  Spatially re-ordered maps carry it per vertex (a.key), otherwise it is the
         // storage index itself
-        v.key = a.key ? a.key[i] : (((uint32_t)i << 1) | (uint32_t)(a.colour[i] & 1));
+        const uint32_t cbyte = a.key ? 0u : (uint32_t)a.colour[i];
+        v.key = a.key ? a.key[i] : (((uint32_t)i << 1) | (cbyte & 1u));
+        if (a.segments) {
+            v.link = v.in && i > 0 && ((cbyte >> 1) & 1u);
+            if ((threadIdx.x & 63u) == 0u && v.link) {          // the predecessor lives in the previous wave: fetch it here
+                const double px = (double)static_cast<const T *>(a.x)[i - 1], py = (double)static_cast<const T *>(a.y)[i - 1],
+                             pz = (double)static_cast<const T *>(a.z)[i - 1];
+                affine3x4(w2c, px, py, pz, v.hx, v.hy, v.hz);
+                v.hin = in_crop(a.crop, v.hx, v.hy, v.hz);
+            }
+        }
     }
     // whole wave outside the crop box: done (its segments stay empty: the count table was zeroed)
     if (!__ballot(v.in)) v.cams = 0;
@@ -339,6 +356,35 @@ __device__ __forceinline__ WaveVerts load_wave_verts(const FrameArgs &a, const i
 
 // The wave's stamps of camera c (uv = packed truncated pixel or 0xffffffff): drop same-pixel predecessors, compact into the
 // wave's segment, count, add the bands to the LDS histogram.
+// Segment extension: the same with 16-byte records {uv, key, uv of the predecessor | ~0, 0}.  `uv_halo` = lane 0's
+// predecessor pixel in this camera (or ~0).  A record reaches every band its disc rows OR its segment rows touch.
+__device__ __forceinline__ void emit_wave_segments(const FrameArgs &a, const int f, const int c, const WaveVerts &v,
+                                                   const uint32_t uv, const uint32_t uv_halo, uint32_t *s_cnt)
+{
+    const uint32_t lane = __lane_id();
+    uint32_t uv_prev = __shfl_up(uv, 1, 64);
+    if (lane == 0u) uv_prev = uv_halo;
+    // joined: both ends visible in this camera, neighbours on the polyline, and not the same pixel (the disc covers that)
+    const bool has_seg = v.link && uv != 0xffffffffu && uv_prev != 0xffffffffu && uv_prev != uv;
+    const uint32_t uv_next = __shfl_down(uv, 1, 64);
+    const uint32_t key_next = __shfl_down(v.key, 1, 64);
+    // (a disc under a later point's identical disc is invisible -- but its segment is not)
+    const bool covered = (lane != 63u) && (uv_next == uv) && (key_next > v.key) && !has_seg;
+    const bool keep = (uv != 0xffffffffu) && !covered;
+    const uint64_t m = __ballot(keep);
+    if (!m) return;
+    const size_t fcseg = ((size_t)f * a.C + c) * a.nseg + v.seg;
+    if (keep) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        reinterpret_cast<uint4 *>(a.stamps0)[fcseg * SEG + rank] = make_uint4(uv, v.key, has_seg ? uv_prev : 0xffffffffu, 0u);
+        const int vi = (int)(uv >> 16), vp = has_seg ? (int)(uv_prev >> 16) : vi;
+        const int b0 = max(min(vi - a.radius, vp), 0) >> a.band_shift;
+        const int b1 = min(max(vi + a.radius, vp), a.H - 1) >> a.band_shift;
+        for (int b = b0; b <= b1; ++b) atomicAdd(&s_cnt[c * a.NB + b], 1u);
+    }
+    if (lane == 0u) a.seg_cnt[fcseg] = (uint8_t)__popcll(m);
+}
+
 __device__ __forceinline__ void emit_wave_stamps(const FrameArgs &a, const int f, const int c, const WaveVerts &v,
                                                  const uint32_t uv, uint32_t *s_cnt)
 {
@@ -399,7 +445,17 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
 #ifdef ABL_PROJ_NO_OUT
         sink ^= uv;                     // (ablation: the chains run, nothing is emitted)
 #else
-        emit_wave_stamps(a, f, c, v, uv, s_cnt);
+        if (a.segments) {               // (wave-uniform; the halo chain runs for lane 0 only -- an opt-in extension pays it)
+            uint32_t uv_halo = 0xffffffffu;
+            if (v.link && v.hin && (threadIdx.x & 63u) == 0u) {
+                uint32_t packed;
+                if (visible_pixel<kdouble *>((kdouble *)(a.c2cam + (size_t)c * 16), (kdouble *)(a.K + (size_t)c * 9), v.hx,
+                                             v.hy, v.hz, Wd, Hd, packed))
+                    uv_halo = packed;
+            }
+            emit_wave_segments(a, f, c, v, uv, uv_halo, s_cnt);
+        } else
+            emit_wave_stamps(a, f, c, v, uv, s_cnt);
 #endif
     }
 #endif
@@ -531,6 +587,70 @@ __global__ __launch_bounds__(BLOCK) void k_stamps_scatter(FrameArgs a)
             if (e_slot[j] != 0xffffffffu)
                 a.stamps[(size_t)s_base[e_slot[j] >> 12] + (e_slot[j] & 0xfffu)] = make_uint2(e_uv[j >> 1], e_key[j >> 1]);
         __syncthreads();                 // s_base / s_cnt are rewritten by the next round
+    }
+}
+
+// The same for 16-byte segment records (EXTENSION): a record goes to EVERY band between the first row its disc or its segment
+// touches and the last -- usually one or two, a whole image column of them for a segment that crosses the frame -- so ranks
+// are not kept in registers: a counting sweep, one reservation per non-empty band, then a second sweep that ranks and writes.
+__global__ __launch_bounds__(BLOCK) void k_stamps_scatter_seg(FrameArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [NB] counts | [NB] bases
+    __shared__ uint32_t s_off[SCATTER_SEGS + 1];
+    __shared__ uint32_t s_wave[BLOCK / 64];
+    const uint32_t fc = blockIdx.y, seg0 = blockIdx.x * SCATTER_SEGS;
+    const int NB = a.NB;
+    uint32_t *s_cnt = s_hist, *s_base = s_hist + NB;
+    {
+        const uint32_t sg = seg0 + threadIdx.x;
+        const uint32_t v = (threadIdx.x < SCATTER_SEGS && sg < a.nseg) ? (uint32_t)a.seg_cnt[(size_t)fc * a.nseg + sg] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(x, d, 64);
+            if ((int)(threadIdx.x & 63) >= d) x += t;
+        }
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = x;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += s_wave[w];
+        if (threadIdx.x < SCATTER_SEGS) s_off[threadIdx.x + 1] = before + x;
+        if (threadIdx.x == 0) s_off[0] = 0u;
+    }
+    for (int t = threadIdx.x; t < NB; t += BLOCK) s_cnt[t] = 0u;
+    __syncthreads();
+    const uint32_t total = s_off[SCATTER_SEGS];
+    if (!total) return;
+    const uint4 *segs = reinterpret_cast<const uint4 *>(a.stamps0) + ((size_t)fc * a.nseg + seg0) * SEG;
+    uint4 *sorted = reinterpret_cast<uint4 *>(a.stamps);
+    const size_t gbin0 = (size_t)fc * NB;
+    const uint32_t fcb = a.fc_base[fc];
+    for (uint32_t base = 0; base < total; base += BLOCK) {
+        const uint32_t t = base + threadIdx.x;
+        uint4 r = make_uint4(0, 0, 0, 0);
+        int b0 = 0, b1 = -1;
+        if (t < total) {
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t step = SCATTER_SEGS / 2; step; step >>= 1)
+                if (s_off[lo + step] <= t) lo += step;
+            r = segs[(size_t)lo * SEG + (t - s_off[lo])];
+            const int vi = (int)(r.x >> 16), vp = r.z != 0xffffffffu ? (int)(r.z >> 16) : vi;
+            b0 = max(min(vi - a.radius, vp), 0) >> a.band_shift;
+            b1 = min(max(vi + a.radius, vp), a.H - 1) >> a.band_shift;
+            for (int b = b0; b <= b1; ++b) atomicAdd(&s_cnt[b], 1u);
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < NB; b += BLOCK) {
+            const uint32_t n = s_cnt[b];
+            s_base[b] = n ? atomicAdd(&a.cursor[gbin0 + b], n) + a.bin_off[gbin0 + b] + fcb : 0u;
+            s_cnt[b] = 0u;
+        }
+        __syncthreads();
+        for (int b = b0; b <= b1; ++b) sorted[(size_t)s_base[b] + atomicAdd(&s_cnt[b], 1u)] = r;
+        __syncthreads();
+        for (int b = threadIdx.x; b < NB; b += BLOCK) s_cnt[b] = 0u;
+        __syncthreads();
     }
 }
 

@@ -278,9 +278,10 @@ __device__ __forceinline__ void raw35_stage(const Raw35Tile &t, const Raw35Band 
 
 // phase 3: taps -> blend -> (stamps) -> transpose through the dead staging area -> 16-byte stores.  Only LDS barriers: the
 // next band's source loads may be in flight.
+// nthreads = the threads that take part (the whole block, or -- k_overlay_raw35_ws -- its blend waves)
 __device__ __forceinline__ void raw35_finish(const OverlayArgs &a, const uint2 *__restrict__ vrows, const Raw35Tile &t,
                                              const uint32_t f, const uint32_t c, const Raw35Band &k, uint32_t *s_stage,
-                                             const bool more_follows)
+                                             const bool more_follows, const uint32_t nthreads)
 {
     const uint32_t cols = (uint32_t)a.cols;
     uint32_t *s_owner = s_stage + t.owner_off;                         // [R * Wt], stamped bands only
@@ -305,10 +306,10 @@ __device__ __forceinline__ void raw35_finish(const OverlayArgs &a, const uint2 *
         lds_barrier();                                                 // every unit holds its taps: staging is dead
         uint4 *o4 = reinterpret_cast<uint4 *>(s_owner);
         const int n4 = (nrows * Wt + 3) >> 2;
-        for (int j = threadIdx.x; j < n4; j += blockDim.x) o4[j] = make_uint4(0, 0, 0, 0);
+        for (int j = threadIdx.x; j < n4; j += (int)nthreads) o4[j] = make_uint4(0, 0, 0, 0);
         lds_barrier();
         if (threadIdx.x < n) raw35_rasterise_tile(s_owner, k.first, y0, nrows, x_first, Wt, a.disc);
-        for (uint32_t sidx = threadIdx.x + blockDim.x; sidx < n; sidx += blockDim.x)
+        for (uint32_t sidx = threadIdx.x + nthreads; sidx < n; sidx += nthreads)
             raw35_rasterise_tile(s_owner, k.st[sidx], y0, nrows, x_first, Wt, a.disc);
         lds_barrier();
     }
@@ -364,8 +365,8 @@ __device__ __forceinline__ void raw35_finish(const OverlayArgs &a, const uint2 *
     const uint32_t cpr = t.row_dwords >> 2;                             // 16-byte chunks per destination tile row
     const uint32_t nchunks = (uint32_t)nrows * cpr;
     uint32_t r = threadIdx.x / cpr, col = threadIdx.x - r * cpr;        // one division, then (row, chunk) advance by blockDim
-    const uint32_t dr = blockDim.x / cpr, dc = blockDim.x - dr * cpr;
-    for (uint32_t idx = threadIdx.x; idx < nchunks; idx += blockDim.x) {
+    const uint32_t dr = nthreads / cpr, dc = nthreads - dr * cpr;
+    for (uint32_t idx = threadIdx.x; idx < nchunks; idx += nthreads) {
         const u32x4 w = reinterpret_cast<const u32x4 *>(s_stage + r * t.row_dwords)[col];
         OVERLAY_STORE(w, reinterpret_cast<u32x4 *>(dcell + (size_t)r * a.mosaic_row_bytes) + col);
         r += dr;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
             raw35_issue<U>(a, band_rows, t, f, c, bx, k, v);
             raw35_stage<U>(t, k, v, s_stage);
         }
-        raw35_finish(a, vrows, t, f, c, k, s_stage, false);
+        raw35_finish(a, vrows, t, f, c, k, s_stage, false, blockDim.x);
     } else {
     const uint32_t b0 = 2u * bx, b1 = b0 + 1u;
     const bool two = b1 < NB;
@@ -448,10 +449,126 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     raw35_issue<U>(a, band_rows, t, f, c, b0, kA, vA);
     raw35_stage<U>(t, kA, vA, s_stage);
     if (two) raw35_issue<U>(a, band_rows, t, f, c, b1, kB, vB);       // in flight during the first band's finish
-    raw35_finish(a, vrows, t, f, c, kA, s_stage, two);
+    raw35_finish(a, vrows, t, f, c, kA, s_stage, two, blockDim.x);
     if (two) {
         raw35_stage<U>(t, kB, vB, s_stage);
-        raw35_finish(a, vrows, t, f, c, kB, s_stage, false);
+        raw35_finish(a, vrows, t, f, c, kB, s_stage, false, blockDim.x);
     }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Round 4: wave-specialised, persistent variant (k_overlay_raw35_ws).
+// What bounds k_overlay_raw35<1> is bytes in flight: a band's 33.6 KB of source rows are requested when its workgroup starts
+// and nothing else is in flight for that workgroup for the remaining ~5 us of its ~7.6 us life (blend, transpose, stores):
+// four workgroups per CU -- all the LDS holds -- average about ONE band's worth of loads in flight per CU.  The two persistent
+// variants of round 3 that tried to keep a second band in flight (every wave loading the next band's rows before blending
+// this one) were slower: on gfx9 loads and stores share vmcnt, so a wave that waits for its next rows also waits for the
+// stores it has just issued.  Here the roles are split instead: a workgroup = 5 blend waves + ONE loader wave that does
+// nothing but issue the next band's rows straight into the other half of a double staging buffer (global_load_lds) and wait
+// for them -- its vmcnt sees loads only -- while the blend waves work on the current half and never wait for memory at all
+// (their stores are fire-and-forget).  2 workgroups per CU x 2 x 33.6 KB: a full band per workgroup is in flight all the time.
+// Persistent: workgroup g renders the bands of virtual blocks g, g + G, g + 2 G, ... under the launch's usual workgroup ->
+// band order (G a multiple of 8: every workgroup stays on its XCD's share).  Same taps, same arithmetic, same stamp
+// resolution as k_overlay_raw35<1> (raw35_finish): byte-identical.
+// ------------------------------------------------------------------------------------------
+struct Raw35Item { uint32_t f, c, b; bool valid; };
+
+__device__ __forceinline__ Raw35Item raw35_item_of(const OverlayArgs &a, const uint32_t L, const uint32_t nbx_magic)
+{
+    Raw35Item it{0u, 0u, 0u, false};
+    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C, camrows = (C + cols - 1u) / cols;
+    uint32_t item;
+    if (!xcd_item_of(L, a.items, a.chunk_log2, a.rot, a.per_magic, item)) return it;
+    uint32_t cc, cr;
+    const uint32_t q1 = divmod_magic(item, cols, a.cols_magic, cc);
+    const uint32_t q2 = divmod_magic(q1, NB, nbx_magic, it.b);
+    it.f = divmod_magic(q2, camrows, a.cr_magic, cr);
+    it.c = cr * cols + cc;
+    it.valid = it.c < C;
+    return it;
+}
+
+// header of a band (scalar loads), its first stamp record, and -- loader only -- its source rows into `stage`
+template <bool LOADER>
+__device__ __forceinline__ void raw35_ws_begin(const OverlayArgs &a, const int2 *__restrict__ band_rows, const Raw35Tile &t,
+                                               const Raw35Item &it, Raw35Band &k, uint32_t *stage, const uint32_t lane)
+{
+    u32x4 none[1];
+    raw35_issue<1, false>(a, band_rows, t, it.f, it.c, it.b, k, none);
+    if (LOADER) {
+        for (uint32_t base = 0; base < k.nsrc; base += 64u) {
+            const uint32_t idx = base + lane;
+            if (idx < k.nsrc)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(k.g + idx),
+                                                 (__attribute__((address_space(3))) void *)(stage + base * 4u), 16, 0, 2 /* nt */);
+        }
+    }
+}
+
+__global__ __launch_bounds__(RAW35_MAX_BLOCK + 64) void k_overlay_raw35_ws(OverlayArgs a, const uint2 *__restrict__ vrows,
+                                                                            const int2 *__restrict__ band_rows, int upr,
+                                                                            int max_src_rows, int owner_off, uint32_t nbx_magic,
+                                                                            uint32_t virtual_blocks, uint32_t stage_dwords)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    Raw35Tile t;
+    t.upr = upr; t.Wt = upr * 12; t.x_first = 0; t.W0 = a.W0; t.owner_off = owner_off;
+    t.row_dwords = (uint32_t)upr * 9u;
+    t.src_row_dwords = (uint32_t)upr * 15u;
+    t.src_pitch16 = (uint32_t)a.W0 * 3u / 16u;
+    t.cpt = t.src_row_dwords >> 2; t.cpt_magic = 0u; t.tx = 0u;
+    (void)max_src_rows;
+    const uint32_t nblend = blockDim.x - 64u;                          // blend threads (a multiple of 64); the last wave loads
+    const bool loader = threadIdx.x >= nblend;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t L = blockIdx.x;
+    // first band of this workgroup
+    Raw35Item it = raw35_item_of(a, L, nbx_magic);
+    while (!it.valid && L < virtual_blocks) {                           // (ragged camera rows / padding of the order: skip)
+        L += gridDim.x;
+        if (L >= virtual_blocks) break;
+        it = raw35_item_of(a, L, nbx_magic);
+    }
+    if (!it.valid) return;                                               // workgroup-uniform
+    uint32_t cur = 0;
+    Raw35Band k;
+    if (loader) {
+        raw35_ws_begin<true>(a, band_rows, t, it, k, s_dyn, lane);
+        __builtin_amdgcn_s_waitcnt(0x0f70);                              // vmcnt(0): the first band has landed
+    } else
+        raw35_ws_begin<false>(a, band_rows, t, it, k, s_dyn, lane);
+    lds_barrier();
+    for (;;) {
+        // the next band of this workgroup (workgroup-uniform)
+        uint32_t Ln = L + gridDim.x;
+        Raw35Item nx{0u, 0u, 0u, false};
+        while (Ln < virtual_blocks) {
+            nx = raw35_item_of(a, Ln, nbx_magic);
+            if (nx.valid) break;
+            Ln += gridDim.x;
+        }
+        const bool more = nx.valid;
+        uint32_t *stage = s_dyn + cur * stage_dwords, *stage_next = s_dyn + (cur ^ 1u) * stage_dwords;
+        Raw35Band kn;
+        if (loader) {
+            // the other half is free: whoever read it last did so before the barrier that ended the previous round
+            if (more) raw35_ws_begin<true>(a, band_rows, t, nx, kn, stage_next, lane);
+            // the same barriers as raw35_finish executes for this band (n is workgroup-uniform)
+            if (k.n) { lds_barrier(); lds_barrier(); lds_barrier(); }
+            lds_barrier();
+            lds_barrier();
+            __builtin_amdgcn_s_waitcnt(0x0f70);                          // the next band's rows are in LDS
+            lds_barrier();
+        } else {
+            if (more) raw35_ws_begin<false>(a, band_rows, t, nx, kn, stage_next, lane);
+            raw35_finish(a, vrows, t, it.f, it.c, k, stage, true, nblend);
+        }
+        if (!more) break;
+        k = kn;
+        it = nx;
+        L = Ln;
+        cur ^= 1u;
     }
 }

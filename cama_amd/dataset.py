@@ -54,6 +54,12 @@ class _StaticMap:
             if self._xyz.dtype not in (np.float32, np.float64):
                 self._xyz = self._xyz.astype(np.float64)
             self.colour = np.repeat(np.asarray([colour_id_of(c) for c in self.classes], np.uint8), self.counts)
+            # bit 1: "joined to the previous vertex" = every point but the first of its instance (read by the opt-in
+            # segment extension only; the disc path looks at bit 0)
+            if self.colour.size:
+                first = np.zeros(self.colour.size, bool)
+                first[np.concatenate([[0], np.cumsum(self.counts)[:-1]])[np.asarray(self.counts) > 0]] = True
+                self.colour = self.colour | (np.uint8(2) * (~first).astype(np.uint8))
 
     @property
     def xyz(self):
@@ -251,6 +257,15 @@ class ClipManager:
         dmap = runtime.engine().build_static_map(table, lift=bev_height is not None, bev_height=bev_height,
                                                  solution=mm.solution, map_width=mm.map_width, map_height=mm.map_height,
                                                  center_x=mm.center_x, center_y=mm.center_y)
+        if self.configs.get("segments", False) and dmap.N:
+            # the segment extension reads "joined to the previous vertex" from bit 1 of the colour byte: every point but
+            # the first of its instance
+            import torch
+            counts = np.asarray(table["counts"], np.int64)
+            starts = np.concatenate([[0], np.cumsum(counts)[:-1]])[counts > 0]
+            dmap.colour |= 2
+            dmap.colour[torch.from_numpy(starts).to(dmap.colour.device)] &= 1
+            dmap.has_links = True
         return StaticInstances(dmap, table["counts"], table["classes"])
 
     def prepare_camera_manager(self, clip_path):
@@ -357,8 +372,11 @@ class ClipManager:
     def render_vectors(self, maps_2d_dict, image_idx):
         segments = bool(self.configs.get("segments", False))
         # configs["segments"] = True (EXTENSION, no reference semantics): discs + one-pixel segments between neighbouring
-        # points; rendered image by image through the generic path (cama_stamp_polylines), not by the fused kernels
-        if not segments and isinstance(maps_2d_dict, ProjectedMaps) and maps_2d_dict.frame.owner is self \
+        # points; caller-supplied 2D instances go image by image through the generic path (cama_stamp_polylines)
+        # (round 4: the fused path draws them too -- CAMA_BIN_SEGMENTS -- as long as the source frames are pre-resized)
+        fused_ok = not segments or not (getattr(self.frame_source(), "fused", False)
+                                        and hasattr(self.frame_source(), "raw_batch"))
+        if fused_ok and isinstance(maps_2d_dict, ProjectedMaps) and maps_2d_dict.frame.owner is self \
                 and maps_2d_dict._items is None and maps_2d_dict.frame.image_idx == image_idx:
             fr = maps_2d_dict.frame
             rig = self._rig()
@@ -383,7 +401,8 @@ class ClipManager:
             # raw sensor frames: undistort + resize happens inside the overlay kernel
             mosaic = eng.render_frames_raw(dmap, rig, w2c, source.raw_batch(image_ids), self.cm_list, crop=self.mm.crop_box())
         else:
-            mosaic = eng.render_frames(dmap, rig, w2c, source.batch(image_ids), crop=self.mm.crop_box())
+            mosaic = eng.render_frames(dmap, rig, w2c, source.batch(image_ids), crop=self.mm.crop_box(),
+                                       segments=bool(self.configs.get("segments", False)))
         batch = RenderBatch(eng, image_ids, mosaic)
         fmt = runtime.egress_mode()                     # a VideoGenerator is listening: start the batch's host copy now
         if fmt is not None and not batch.start_egress(fmt) and fmt == "i420":
@@ -436,7 +455,7 @@ class ClipManager:
         return batches[b], k - ra["bounds"][b][0]
 
     # ------------------------------------------------------------------ whole-clip fused path
-    def render_clip(self, dataset, out=None, frames_per_launch=None, poses=None, pipelined=False):
+    def render_clip(self, dataset, out=None, frames_per_launch=None, poses=None, pipelined=False, segments=None):
         """Render every frame of `dataset` in launches of up to `frames_per_launch` frames.
 
         Returns (image indices (F,), mosaic device tensor [F, 2H, 3W, 3] uint8).  Nothing is copied to the host.
@@ -447,6 +466,8 @@ class ClipManager:
         eng = runtime.engine()
         rig = self._rig()
         dmap = self._static(dataset).device()
+        # segments: the opt-in extension (discs + one-pixel segments between polyline neighbours); None = configs["segments"]
+        segments = bool(self.configs.get("segments", False)) if segments is None else bool(segments)
         idx, w2c = poses if poses is not None else self.frame_poses(dataset)
         F = len(idx)
         shape = eng.mosaic_shape(rig, F)
@@ -481,9 +502,9 @@ class ClipManager:
                 else:
                     src = src_all.batch(ids[lo:hi])
                     if pipelined:
-                        eng.render_frames_pipelined(dmap, rig, T[lo:hi], src, out[lo:hi], crop=crop)
+                        eng.render_frames_pipelined(dmap, rig, T[lo:hi], src, out[lo:hi], crop=crop, segments=segments)
                     else:
-                        eng.render_frames(dmap, rig, T[lo:hi], src, out=out[lo:hi], crop=crop)
+                        eng.render_frames(dmap, rig, T[lo:hi], src, out=out[lo:hi], crop=crop, segments=segments)
             except torch.OutOfMemoryError:
                 # the per-call scratch is a worst case (every vertex visible in every camera) sized from the memory that
                 # was free when the shape was first seen; if the device has filled up since, render fewer frames per call

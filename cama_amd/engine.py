@@ -104,11 +104,15 @@ class DeviceMap:
         colour_id = np.ascontiguousarray(colour_id, dtype=np.uint8)
         assert colour_id.shape[0] == self.N
         self.soa = torch.from_numpy(np.ascontiguousarray(xyz.T)).to(device)          # [3,N]
+        # bit 0 = palette index; bit 1 (optional, set by the caller: _StaticMap) = "joined to the previous vertex", read by
+        # the segment extension only
         self.colour = torch.from_numpy(colour_id).to(device)
+        self.has_links = bool((colour_id & 2).any())
         self.sorted_soa = self.sorted_key = None
         if spatial_sort is True or (spatial_sort == "auto" and lacks_spatial_order(xyz)):
             order = morton_order(xyz)
             key = ((order.astype(np.uint32) << np.uint32(1)) | (colour_id[order] & 1).astype(np.uint32))
+            self.has_links = False                        # (a spatially sorted copy has no polyline neighbours)
             self.sorted_soa = torch.from_numpy(np.ascontiguousarray(xyz[order].T)).to(device)
             self.sorted_key = torch.from_numpy(np.ascontiguousarray(key)).to(device)
         self._index()
@@ -225,6 +229,7 @@ class Engine:
             dmap = DeviceMap.__new__(DeviceMap)
             dmap.N, dmap.is_f64, dmap.soa, dmap.colour = N, int(is64), soa, colour
             dmap.sorted_soa = dmap.sorted_key = None
+            dmap.has_links = False
             dmap.bounds, dmap.extent_xy = None, (0.0, 0.0)
             if N == 0:
                 return dmap
@@ -354,7 +359,7 @@ class Engine:
         rows = (rig.C + cols - 1) // cols
         return (F, rows * rig.H, cols * rig.W, 3)
 
-    def render_frames(self, dmap, rig, w2c, src, out=None, cols=3, crop=None):
+    def render_frames(self, dmap, rig, w2c, src, out=None, cols=3, crop=None, segments=False):
         """src [F,C,H,W,3] uint8 device tensor -> mosaic [F, rows*H, cols*W, 3] uint8 device tensor."""
         torch = _torch()
         cropa = self._crop(crop)
@@ -369,6 +374,10 @@ class Engine:
                 out = torch.empty(shape, dtype=torch.uint8, device=self.device)
             assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.uint8
             x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
+            if segments:                    # extension: only through the pipeline (its sorted list is sized per launch)
+                self.render_frames_pipelined(dmap, rig, T, src, out, cols=cols, crop=crop, segments=True)
+                self.join()
+                return out
             if self.alpha256 == 256 and bnd is not None and (bflags & _lib.BIN_WORKLIST):
                 # site-sized map: the caller-scratch entry point below would size its stamp scratch for the worst case
                 # (24 B per frame x camera x vertex); the pipeline plans the launch and sizes it from what survives the
@@ -667,7 +676,7 @@ class Engine:
         _lib.check(self.lib.cama_pipeline_stage_poses(P["handle"], a.ctypes.data, a.shape[0], ctypes.byref(ptr)))
         return ptr.value, a.shape[0]
 
-    def render_frames_pipelined(self, dmap, rig, w2c, src, out, cols=3, crop=None):
+    def render_frames_pipelined(self, dmap, rig, w2c, src, out, cols=3, crop=None, segments=False):
         """Like render_frames, but through the library's two-stream pipeline (cama_pipeline_render): the binning half
         runs on one internal stream and the overlay half on another with double-buffered scratch, so call k+1's
         binning overlaps call k's overlay (HBM-bound) instead of queueing behind it.  `src` / `w2c` must be complete
@@ -689,6 +698,14 @@ class Engine:
             assert tuple(src.shape) == (F, rig.C, rig.H, rig.W, 3)
             assert tuple(out.shape) == self.mosaic_shape(rig, F, cols) and out.is_contiguous()
             x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
+            if segments:
+                # EXTENSION (no reference semantics): discs + one-pixel Bresenham segments between polyline neighbours
+                if key is not None or not getattr(dmap, "has_links", False):
+                    raise _lib.CamaHipError("segments need a map in draw order that carries its polyline links "
+                                            "(ClipManager builds one; spatially sorted maps have no neighbours)")
+                if self.alpha256 != 256:
+                    raise _lib.CamaHipError("segments and translucent stamps are separate extensions")
+                bflags |= _lib.BIN_SEGMENTS
             # scratch: the pipeline's own (NULL, NULL) -- sized from what the launch's cull lets through when the map is
             # site-sized (the call then waits on the host for the pre-pass: include/cama_hip.h), else for the worst case
             _lib.check(self.lib.cama_pipeline_render(

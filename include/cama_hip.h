@@ -51,6 +51,13 @@ extern "C" {
 #define CAMA_MAX_CAMERAS 16
 #define CAMA_MAX_RADIUS  15
 #define CAMA_BIN_WORKLIST 1   /* flags of the bin / render entries */
+#define CAMA_BIN_SEGMENTS 2   /* EXTENSION (no reference semantics; BASELINE.json's north_star asks for rasterised line segments, the
+                               * reference draws a disc per point: SURVEY.md D1): a point whose colour_id byte has bit 1 set is
+                               * also joined to its predecessor in the vertex buffer -- when both are visible in the camera --
+                               * by a one-pixel 8-connected Bresenham segment between the two truncated pixels, under the later
+                               * point's draw index and colour.  Only through cama_pipeline_render with pipeline-owned scratch
+                               * (a record reaches every band its segment crosses: the sorted list is sized from the scans'
+                               * grand total, which costs one host wait per launch); draw_key must be NULL. */
 #define CAMA_MAX_SCENES_PER_LAUNCH 1024  /* cama_*_scenes: scenes per chain */
 
 int cama_abi_version(void);
@@ -114,7 +121,8 @@ int cama_project_frames(const void *x, const void *y, const void *z, int32_t xyz
  *   per point, sequential = last writer wins) -> concate_image (cama/tools.py:22-25).
  * No coordinates are materialised.  Stamps are binned by (frame, camera, row band), each band
  * is resolved deterministically (per-pixel max draw index) and written once into the mosaic.
- *   x,y,z      [N] float32/float64 (xyz_is_f64)   colour_id [N] uint8: palette index (0 lane grey, 1 gold)
+ *   x,y,z      [N] float32/float64 (xyz_is_f64)   colour_id [N] uint8: bit 0 = palette index (0 lane grey, 1 gold); bit 1 =
+ *              "joined to the previous vertex" (same polyline), read only with CAMA_BIN_SEGMENTS; other bits ignored
  *   draw_key   NULL, or [N] uint32 = (draw index << 1) | colour for vertex buffers stored in another order than
  *              they are drawn (e.g. spatially sorted): "last writer wins" follows the draw index, not storage
  *              order; colour_id is ignored when draw_key is given

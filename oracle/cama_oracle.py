@@ -497,6 +497,34 @@ def frame_project_flat(xyz, w2c, cams, W, H, crop=CROP_BOX, want_chassis=False):
     return {"vu": vu, "vis": vis, "crop_mask": cmask, "chassis": chassis}
 
 
+def frame_render_flat_segments(src, vu, vis, colour_id, link, radius=2, cols=3):
+    """Restatement of the product's opt-in segment EXTENSION on a flat point buffer (no reference counterpart: the reference
+    draws one disc per point, cama/reproject.py:255-256): per camera, in draw order, point k first gets the one-pixel
+    Bresenham segment from point k - 1 (oracle_line_bresenham) when link[k] is set and BOTH points are visible in that
+    camera, then its disc, all in point k's colour; later draws overwrite.  src (C,H,W,3) -> mosaic."""
+    L = lib()
+    C, H, W = src.shape[:3]
+    rows = (C + cols - 1) // cols
+    out = np.zeros((rows * H, cols * W, 3), np.uint8)
+    pal = (tuple(int(v) for v in GREY_RGB[::-1]), tuple(int(v) for v in GOLD_RGB[::-1]))
+    link = np.asarray(link, bool)
+    for c in range(C):
+        img = np.ascontiguousarray(src[c]).copy()
+        base, step = img.ctypes.data, img.strides[0]
+        ok = np.asarray(vis[c], bool)
+        px = np.zeros((vu.shape[1], 2), np.int64)
+        px[ok] = vu[c][ok].astype(np.int32)                         # reproject.py:249: truncation (values >= 0)
+        for k in np.flatnonzero(ok):
+            b, g, r = pal[int(colour_id[k]) & 1]
+            if k > 0 and link[k] and ok[k - 1]:
+                L.oracle_line_bresenham(base, H, W, step, int(px[k - 1][1]), int(px[k - 1][0]), int(px[k][1]), int(px[k][0]),
+                                        b, g, r)
+            L.oracle_circle_fill(base, H, W, step, int(px[k][1]), int(px[k][0]), radius, b, g, r)
+        r0, q0 = divmod(c, cols)
+        out[r0 * H:(r0 + 1) * H, q0 * W:(q0 + 1) * W] = img
+    return out
+
+
 def frame_render_flat(src, vu, vis, colour_id, radius=2, cols=3, alpha256=256):
     """src (C,H,W,3) uint8 -> mosaic ((C/cols)*H, cols*W, 3) through the C renderer.  alpha256 < 256 selects the
     translucent EXTENSION (own restatement, no reference semantics)."""

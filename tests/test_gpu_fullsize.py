@@ -109,3 +109,38 @@ def test_stamps_only_touch_disc_footprints(scene):
         is_grey = (px == np.array([211, 211, 211], np.uint8)).all(axis=-1)
         is_gold = (px == np.array([0, 215, 255], np.uint8)).all(axis=-1)
         assert (is_grey | is_gold).all()
+
+
+def test_headline_scene_with_segments_byte_identical_to_the_restatement(scene):
+    """VERDICT r3 x1 at full size: the headline scene -- 6 cameras x 40 frames at 1600x900, ~1e4 vertices -- rendered with
+    the segment EXTENSION in the batched path (render_clip(..., segments=True): one fused launch, CAMA_BIN_SEGMENTS), every
+    frame byte-equal to the oracle's restatement (disc per point + oracle_line_bresenham between polyline neighbours visible
+    in the same camera).  No reference semantics: the reference draws discs only."""
+    import torch
+    from cama_amd import runtime
+    cm, frames, clip = scene
+    idx, mosaic = cm.render_clip("cama", segments=True)
+    _, plain = cm.render_clip("cama")
+    torch.cuda.synchronize()
+    att = O.read_attribute(clip)
+    cams = [O.camera_model(att, n, output_size=(900, 1600)) for n in CAMERA_NAMES]
+    ins = cm.instance_maps["cama"]
+    xyz, col, _, _ = O.flatten_instances(ins)
+    link = np.concatenate([np.arange(len(i["points"])) > 0 for i in ins])
+    _, w2c = cm.frame_poses("cama")
+    src = frames.cpu().numpy()
+    changed = 0
+    for k, i in enumerate(idx):
+        flat = O.frame_project_flat(xyz, w2c[k], cams, 1600, 900)
+        want = O.frame_render_flat_segments(src[i], flat["vu"], flat["vis"], col, link)
+        got = mosaic[k].cpu().numpy()
+        assert np.array_equal(got, want), f"frame {i}"
+        changed += int(np.count_nonzero((got != plain[k].cpu().numpy()).any(axis=2)))
+    assert changed > 0                              # close to the car consecutive points are pixels apart: segments show
+    # pipelined, several launches in flight == plain
+    out = torch.empty_like(mosaic)
+    for _ in range(3):
+        cm.render_clip("cama", out=out, pipelined=True, segments=True)
+    runtime.engine().join()
+    torch.cuda.synchronize()
+    assert torch.equal(out, mosaic)

@@ -629,3 +629,67 @@ def test_xcd_dispatch_probe(engine):
     periodic, first8, per_xcd = engine.xcd_map(4096)
     assert sum(per_xcd) == 4096 and len(per_xcd) == 8 and all(0 <= v < 8 for v in first8)
     assert periodic, (first8, per_xcd)
+
+
+def _polyline_scene(seed, W, H, F, n_dense=24, n_sparse=10, n_single=5):
+    """Polylines for the segment extension: dense ones (1 cm steps, hundreds of points: links across waves and vertex blocks),
+    sparse ones (metre-long steps close to the car: segments that cross dozens of rows and several bands, end points that
+    leave the image or the crop box) and one-point instances; instance boundaries fall anywhere relative to the 64-vertex
+    waves.  Returns xyz (N,3) f32, colour bit0, link (N,) bool, cams, w2c."""
+    rng = np.random.default_rng(seed)
+    _, _, cams, w2c = _random_scene(seed, 8, F, W, H)
+    parts, cols, links = [], [], []
+    for k in range(n_dense + n_sparse + n_single):
+        if k < n_dense:
+            n, step = int(rng.integers(100, 700)), 0.01
+        elif k < n_dense + n_sparse:
+            n, step = int(rng.integers(2, 12)), float(rng.uniform(0.5, 6.0))
+        else:
+            n, step = 1, 0.0
+        p0 = np.array([rng.uniform(-30, 40), rng.uniform(-40, 40), rng.normal(0, 0.2)])
+        ang = rng.uniform(0, 2 * np.pi)
+        t = np.arange(n)[:, None] * step
+        pts = p0[None] + t * np.array([np.cos(ang), np.sin(ang), 0.0])[None] + rng.normal(0, 0.002, (n, 3)) * (step > 0.1)
+        parts.append(pts.astype(np.float32))
+        cols.append(np.full(n, k % 2, np.uint8))
+        links.append(np.arange(n) > 0)
+    return np.concatenate(parts), np.concatenate(cols), np.concatenate(links), cams, w2c
+
+
+@pytest.mark.parametrize("W,H,F", [(320, 180, 5), (1600, 900, 2)])
+def test_segment_extension_in_the_fused_path_equals_its_restatement(engine, W, H, F):
+    """the north-star's "line segments" in the BATCHED path (CAMA_BIN_SEGMENTS) -- 16-byte records binned to
+    every band their segment crosses, rasterised in the overlay's LDS owner table next to the discs -- byte-equal to the
+    oracle's restatement (oracle_line_bresenham + the disc, in draw order), for dense and sparse polylines, links across
+    wave and block boundaries, end points that drop out of view.  EXTENSION: no reference semantics."""
+    import torch
+    xyz, col, link, cams, w2c = _polyline_scene(11 + W, W, H, F)
+    rig = engine.make_rig([c["name"] for c in cams], [c["chassis2camera"] for c in cams], [c["K"] for c in cams], W, H)
+    dmap = engine.upload_map(xyz, col | (link.astype(np.uint8) << 1), spatial_sort=False)
+    assert dmap.has_links
+    src = torch.randint(0, 256, (F, 6, H, W, 3), dtype=torch.uint8, device="cuda")
+    got = engine.render_frames(dmap, rig, w2c, src, segments=True)
+    plain = engine.render_frames(dmap, rig, w2c, src)
+    torch.cuda.synchronize()
+    host = src.cpu().numpy()
+    drew = 0
+    for f in range(F):
+        flat = O.frame_project_flat(xyz, w2c[f], cams, W, H)
+        want = O.frame_render_flat_segments(host[f], flat["vu"], flat["vis"], col, link)
+        assert np.array_equal(got[f].cpu().numpy(), want), f"frame {f}: segments differ from the restatement"
+        # and the disc-only render of the same map is untouched by the link bits
+        assert np.array_equal(plain[f].cpu().numpy(), O.frame_render_flat(host[f], flat["vu"], flat["vis"], col)), f
+        drew += int((got[f] != plain[f]).any())
+    assert drew == F                                          # the segments did change pixels in every frame
+    # the same through the pipeline, several launches in flight (the sorted list is re-sized per launch)
+    outs = [torch.zeros_like(got) for _ in range(3)]
+    for o in outs:
+        engine.render_frames_pipelined(dmap, rig, np.asarray(w2c, np.float32), src, o, segments=True)
+    engine.join()
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, got)
+    # a spatially sorted copy has no polyline neighbours: refused, not drawn wrong
+    sorted_map = engine.upload_map(xyz, col | (link.astype(np.uint8) << 1), spatial_sort=True)
+    with pytest.raises(Exception):
+        engine.render_frames(sorted_map, rig, w2c, src, segments=True)

@@ -104,7 +104,9 @@ def main(tag, name):
         wr.writerows(rows)
     ov = next((v for k, v in kernels.items() if k.startswith("k_overlay")), None)
     rec = {"config": f"N={N},F={F},{W}x{H}" + ("" if probe["map"] == "lanes" else f",map={probe['map']}") +
-                     (",raw1600x900" if probe.get("raw") else ""),
+                     (",raw1600x900" if probe.get("raw") else "") +
+                     (f",scenes={probe['scenes']}" if probe.get("scenes", 1) > 1 else "") +
+                     (f",sites={probe['sites']}" if probe.get("sites", 0) > 0 else ""),
            "kernel": "k_overlay", "bytes_per_launch": ov["traffic_bytes"] if ov else None,
            "fetch_correction": corr, "calibration": cal, "kernels": kernels, "probe": probe,
            "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python tools/pmc_probe.py; "

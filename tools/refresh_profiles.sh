@@ -1,21 +1,22 @@
 #!/bin/bash
 # Everything under profiles/<tag>_* that comes from bench.py, in one gpurun call (from the repo root, on the GPU box):
 #   gpurun --timeout 3000 -- 'tools/refresh_profiles.sh r03'
-# then, in the build container:  for n in headline site1e6 random1e6 stress raw35; do python tools/collect_profiles.py r03 $n; done
+# then, in the build container:  for n in headline site1e6 random1e6 stress raw35 scenes73 sites3x12; do python tools/collect_profiles.py r04 $n; done
 # and copy gpurun_out/<tag>_*_bench.json of the plain lines into profiles/.
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 ulimit -c 0
 tools/profile_workload.sh $tag headline "N=10000" --steps 20 --warmup 5 > /dev/null
 tools/profile_workload.sh $tag site1e6 "N=1000000 MAP=site" --map site --verts 1000000 --steps 30 --warmup 5 --no-verify > /dev/null
 tools/profile_workload.sh $tag random1e6 "N=1000000 MAP=random" --map random --verts 1000000 --steps 30 --warmup 5 > /dev/null
 tools/profile_workload.sh $tag stress "N=1000000 MAP=random F=1000" --map random --verts 1000000 --frames 1000 --shard-frames --steps 3 --warmup 1 > /dev/null
 tools/profile_workload.sh $tag raw35 "N=10000 RAW=1 H=540 W=960" --raw-frames --height 540 --width 960 --steps 100 --warmup 5 > /dev/null
+# round 4: rocprof behind every N = 1 BASELINE line (configs[2] = the 73-scene sweep, configs[3] = 3 sites x 12 scenes)
+tools/profile_workload.sh $tag scenes73 "N=10000 SCENES=73" --scenes 73 --steps 20 --warmup 2 --cpu-seconds 0 > /dev/null
+tools/profile_workload.sh $tag sites3x12 "N=1000000 MAP=site SITES=3 SCENES=12" --map site --verts 1000000 --sites 3 --scenes 12 --steps 10 --warmup 2 --cpu-seconds 0 > /dev/null
 # plain bench lines (no trace behind them)
 plain() { name=$1; shift; timeout 900 python bench.py "$@" > gpurun_out/${tag}_${name}_bench.json 2> gpurun_out/${tag}_${name}_bench.err; tail -c 300 gpurun_out/${tag}_${name}_bench.json; echo; }
 plain 960x540 --height 540 --width 960 --steps 60 --warmup 5
 plain n1e5 --verts 100000 --steps 30 --warmup 5
 plain dense1e6 --verts 1000000 --steps 20 --warmup 3
 plain site4e6 --map site --verts 4000000 --steps 20 --warmup 3
-plain scenes73 --scenes 73 --steps 20 --warmup 2 --cpu-seconds 0
-plain sites3x12 --map site --verts 1000000 --sites 3 --scenes 12 --steps 10 --warmup 2 --cpu-seconds 0
