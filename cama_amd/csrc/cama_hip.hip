@@ -331,10 +331,12 @@ Option g_options[] = {
                                                                             // forced overlay_chunk_log2 < 31)
     {"raw35_ws", "CAMA_RAW35_WS", 0, {0}, {false}},                        // 3:5 raw overlay: wave-specialised persistent
                                                                             // kernel, value = workgroups per CU (0 = classic)
+    {"raw35_loaders", "CAMA_RAW35_LOADERS", 2, {0}, {false}},              // ... and its loader waves per workgroup
+    {"raw35_subrows", "CAMA_RAW35_SUBROWS", 0, {0}, {false}},              // 3:5 raw overlay: 1 = half bands per workgroup
     {"cull_list_min", "CAMA_CULL_LIST_MIN", 16384, {0}, {false}},          // (block, frame) items from which a site-sized
                                                                             // map's cull goes through work lists
 };
-enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_RAW35_WS, OPT_CULL_LIST_MIN, OPT_COUNT };
+enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_RAW35_WS, OPT_RAW35_LOADERS, OPT_RAW35_SUBROWS, OPT_CULL_LIST_MIN, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
 int64_t option(int k)
 {
@@ -1315,7 +1317,20 @@ int cama_raw35_plan(const float *mapx, const float *mapy, int32_t C, int32_t H, 
     }
     // the output of a band (R rows of W*3 bytes) is transposed through the staging area
     if ((size_t)most * W0 < (size_t)R * W) return 0;
-    *max_src_rows = most;
+    // round 4: the same for half bands (R / 2 rows per workgroup, cama_overlay_frames_raw35 with option raw35_subrows): their
+    // largest source-row count rides in the high half of the plan word (0 = half bands cannot be used)
+    int most_half = 0;
+    if (R % 2 == 0 && R >= 2) {
+        const int S = R / 2;
+        for (int c = 0; c < C && most_half >= 0; ++c)
+            for (int y = 0; y < H; y += S) {
+                const int ye = std::min(H, std::min(y + S, (y / R) * R + R)) - 1;
+                const int first = (int)(vrows[((size_t)c * H + y) * 2] & 0xffffu), last = (int)(vrows[((size_t)c * H + ye) * 2] >> 16);
+                most_half = std::max(most_half, last - first + 1);
+            }
+        if ((size_t)most_half * W0 < (size_t)S * W || most_half > 0x7fff) most_half = 0;
+    }
+    *max_src_rows = most | (most_half << 16);
     return 1;
 }
 
@@ -1331,6 +1346,9 @@ static int raw35_impl(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t
     if (F == 0) return CAMA_OK;
     if (cols < 1) return fail(CAMA_EINVAL, "cols=%d", cols);
     if (!raw || !vrows || !band_rows || !mosaic || !palette_bgr) return fail(CAMA_EINVAL, "NULL pointer argument");
+    // the plan word: low half = source rows of the tallest band, high half = of the tallest half band (0: not available)
+    const int32_t max_half_rows = (max_src_rows >> 16) & 0x7fff;
+    max_src_rows &= 0xffff;
     int upr = W / 12;
     const unsigned items = (unsigned)L.R * (unsigned)upr;
     if (W % 48 != 0 || ((int64_t)W0 * 3) % 16 != 0 || (uintptr_t)raw % 16 != 0 || (uintptr_t)mosaic % 16 != 0 ||
@@ -1358,9 +1376,19 @@ static int raw35_impl(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t
     int TX = 1;       // (measured at 960x540: two tiles 0.66-0.70 of 8 TB/s, one tile 0.70-0.74 -- half rows are short bursts)
     if (forced_tx == 1 || (forced_tx == 2 && upr % 8 == 0)) TX = forced_tx;
     const int upr_t = upr / TX, Wt = W / TX;
-    const unsigned block = ((unsigned)L.R * (unsigned)upr_t + 63u) & ~63u;
+    // Half bands (round 4, option raw35_subrows = 1; A/B only): a band's R rows go to two workgroups of R / 2 rows -- 4 source
+    // rows = 19.2 KB of staging instead of 7 = 33.6 KB at 960 wide, 8 workgroups per CU instead of 4, a half band's rows still
+    // one contiguous range (unlike round 3's column tiles).  Built on the theory that the kernel is bound by the source bytes
+    // it keeps in flight (counters: 16 KB per CU on average, profiles/r04_raw35_account.txt); measured: no gain (0.692-0.704
+    // against 0.704-0.710 of 8 TB/s, alternating inside single processes), byte-identical.
+    const int64_t sub_opt = option(OPT_RAW35_SUBROWS);
+    const bool halves = sub_opt != 0 && TX == 1 && max_half_rows > 0 && L.R % 2 == 0 && L.R / 2 >= 1 &&
+                        (size_t)max_half_rows * upr_t * 15 >= (size_t)(L.R / 2) * upr_t * 9 + (size_t)(L.R / 2) * Wt;
+    const uint32_t sub = halves ? 2u : 1u, subrows = halves ? (uint32_t)L.R / 2u : (uint32_t)L.R;
+    const int stage_rows = halves ? max_half_rows : max_src_rows;
+    const unsigned block = (subrows * (unsigned)upr_t + 63u) & ~63u;
     // the owner table of a stamped band goes INTO the staging area, behind the tile's output rows (raw35_kernels.hpp)
-    const size_t staging_dw = (size_t)max_src_rows * upr_t * 15, owner_off = (size_t)L.R * upr_t * 9, owner_dw = (size_t)L.R * Wt;
+    const size_t staging_dw = (size_t)stage_rows * upr_t * 15, owner_off = (size_t)subrows * upr_t * 9, owner_dw = (size_t)subrows * Wt;
     if (staging_dw < owner_off + owner_dw)
         return fail(CAMA_EINVAL, "the plan's %d source rows leave no room for the owner table (W=%d, W0=%d)", max_src_rows, W, W0);
     const size_t lds = staging_dw * 4;
@@ -1372,8 +1400,8 @@ static int raw35_impl(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t
     }
     // bands per workgroup: 2 = the second band's source loads fly during the first band's blend (CAMA_RAW35_PAIR=0|1, A/B)
     static const int pair_env = getenv("CAMA_RAW35_PAIR") ? atoi(getenv("CAMA_RAW35_PAIR")) : RAW35_PAIR_DEFAULT;
-    const int bands_per_wg = pair_env ? 2 : 1;
-    const uint32_t NBx = bands_per_wg == 2 ? (uint32_t)(L.NB + 1) / 2 : (uint32_t)L.NB;
+    const int bands_per_wg = (pair_env && !halves) ? 2 : 1;
+    const uint32_t NBx = bands_per_wg == 2 ? (uint32_t)(L.NB + 1) / 2 : (uint32_t)L.NB * sub;
     const uint32_t nbx_magic = (uint32_t)(((1ull << 32) + NBx - 1) / NBx);
     o.items = (uint32_t)((size_t)F * rows * cols * NBx * TX);
     // (the 3:5 raw overlay always takes the chunked order unless one is forced: measured inside single processes at 1.41 GB per
@@ -1401,20 +1429,21 @@ static int raw35_impl(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t
     // round, a loader wave, a double staging buffer -- needs contiguous staged rows (row pitch == staged row) and whole bands
     const int64_t ws = option(OPT_RAW35_WS);
     const uint32_t src_pitch16 = (uint32_t)W0 * 3u / 16u;
-    if (ws > 0 && TX == 1 && bands_per_wg == 1 && src_pitch16 == cpt && block + 64u <= 1024u && 2 * lds + 64 <= 160 * 1024) {
+    const unsigned nloaders = (unsigned)std::min<int64_t>(std::max<int64_t>(option(OPT_RAW35_LOADERS), 1), 8);
+    if (ws > 0 && !halves && TX == 1 && bands_per_wg == 1 && src_pitch16 == cpt && block + 64u * nloaders <= 1024u && 2 * lds + 64 <= 160 * 1024) {
         const size_t lds2 = 2 * lds;
         if (lds2 > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ws, (160 * 1024) / lds2));
         const unsigned G = std::min<unsigned>(256u * per_cu, (rgrid.x + 7u) & ~7u) & ~7u;
-        hipExtLaunchKernelGGL(k_overlay_raw35_ws, dim3(std::max(G, 8u)), dim3(block + 64u), (uint32_t)lds2, s, e0, e1, 0u, o, vr2, br2,
-                              upr, max_src_rows, (int)owner_off, nbx_magic, rgrid.x, (uint32_t)staging_dw);
+        hipExtLaunchKernelGGL(k_overlay_raw35_ws, dim3(std::max(G, 8u)), dim3(block + 64u * nloaders), (uint32_t)lds2, s, e0, e1, 0u, o,
+                              vr2, br2, upr, max_src_rows, (int)owner_off, nbx_magic, rgrid.x, (uint32_t)staging_dw, nloaders);
     } else if (bands_per_wg == 2)
         hipExtLaunchKernelGGL(k_overlay_raw35<2>, rgrid, dim3(block), (uint32_t)lds, s, e0, e1, 0u, o, vr2, br2, upr, max_src_rows,
-                              (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic);
+                              (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic, 1u, (uint32_t)L.R);
     else
-        hipExtLaunchKernelGGL(k_overlay_raw35<1>, rgrid, dim3(block), (uint32_t)lds, s, e0, e1, 0u, o, vr2, br2, upr, max_src_rows,
-                              (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic);
+        hipExtLaunchKernelGGL(k_overlay_raw35<1>, rgrid, dim3(block), (uint32_t)lds, s, e0, e1, 0u, o, vr2, br2, upr, stage_rows,
+                              (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic, sub, subrows);
     if (!e0) g_overlay_stop_event = nullptr;
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) g_prof.pending.emplace_back(ev0, ev1);

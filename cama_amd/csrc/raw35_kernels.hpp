@@ -225,26 +225,37 @@ struct Raw35Band {
 struct Raw35Tile {
     int upr, Wt, x_first, W0, owner_off;
     uint32_t row_dwords, src_row_dwords, src_pitch16, cpt, cpt_magic, tx;
+    uint32_t sub = 1, subrows = 0;   // round 4: a band of R rows is rendered by `sub` workgroups of `subrows` rows each
 };
 
 // phase 1: scalar loads (count, list offset, source rows), the band's first stamp record, then the source loads
 template <int U, bool LOAD = true>
 __device__ __forceinline__ void raw35_issue(const OverlayArgs &a, const int2 *__restrict__ band_rows, const Raw35Tile &t,
-                                            const uint32_t f, const uint32_t c, const uint32_t b, Raw35Band &k, u32x4 (&v)[U])
+                                            const uint32_t f, const uint32_t c, const uint32_t bsub, Raw35Band &k, u32x4 (&v)[U],
+                                            const uint2 *__restrict__ vrows = nullptr)
 {
     const uint32_t NB = (uint32_t)a.NB, C = (uint32_t)a.C;
+    // sub-bands (t.sub > 1): workgroup `bsub` = rows [h * subrows, (h + 1) * subrows) of band bsub / sub -- the band's stamp
+    // list is shared, each part rasterises its own rows
+    const uint32_t b = t.sub > 1u ? bsub / t.sub : bsub, h = t.sub > 1u ? bsub - b * t.sub : 0u;
     k.b = b;
     k.fc = f * C + c;
     const uint32_t bin = k.fc * NB + b;
-    k.y0 = (int)b * a.R;
-    k.nrows = min(a.R, a.H - k.y0);
+    k.y0 = (int)b * a.R + (int)(h * t.subrows);
+    k.nrows = t.sub > 1u ? min((int)t.subrows, min(a.R, a.H - (int)b * a.R) - (int)(h * t.subrows)) : min(a.R, a.H - k.y0);
     k.n = a.counts[bin];
     const uint32_t list0 = a.fc_base[k.fc] + a.bin_off[bin];          // (unconditional: three parallel scalar loads)
     k.st = a.stamps + (k.n ? (size_t)list0 : (size_t)0);
     // the band's first stamp record before the source loads (VMEM returns in order; see k_overlay)
     k.first = k.st[k.n ? min(threadIdx.x, k.n - 1u) : 0u];
     __builtin_amdgcn_sched_barrier(0);
-    k.br = band_rows[c * NB + b];
+    if (t.sub > 1u) {
+        if (k.nrows <= 0) { k.nrows = 0; k.nsrc = 0; k.br = make_int2(0, 0); k.g = nullptr; return; }   // ragged last band
+        // the part's source rows from its first and last row's vertical taps (the per-band table covers whole bands)
+        const uint2 va = vrows[(size_t)c * a.H + k.y0], vb = vrows[(size_t)c * a.H + k.y0 + k.nrows - 1];
+        k.br = make_int2((int)(va.x & 0xffffu), (int)(vb.x >> 16) - (int)(va.x & 0xffffu) + 1);
+    } else
+        k.br = band_rows[c * NB + b];
     k.g = reinterpret_cast<const u32x4 *>(a.src + ((size_t)k.fc * a.H0 + k.br.x) * (size_t)a.W0 * 3) + t.tx * t.cpt;
     k.nsrc = (uint32_t)k.br.y * t.cpt;
     // chunk idx of the tile = (source row idx / cpt, chunk idx % cpt) (cpt_magic = ceil(2^32 / cpt) from the host: exact for
@@ -384,13 +395,14 @@ template <int bands_per_wg>
 __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a, const uint2 *__restrict__ vrows,
                                                                    const int2 *__restrict__ band_rows, int upr,
                                                                    int max_src_rows, int owner_off, int TX,
-                                                                   uint32_t tx_magic, uint32_t cpt_magic, uint32_t nbx_magic)
+                                                                   uint32_t tx_magic, uint32_t cpt_magic, uint32_t nbx_magic,
+                                                                   uint32_t sub, uint32_t subrows)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     // same item order as k_overlay -- (frame, mosaic row of cameras, band [pair], camera column), column tile innermost -- and
     // the same workgroup -> item mapping (overlay_kernels.hpp: xcd_item_of)
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C, camrows = (C + cols - 1u) / cols;
-    const uint32_t NBx = bands_per_wg == 2 ? (NB + 1u) >> 1 : NB;
+    const uint32_t NBx = bands_per_wg == 2 ? (NB + 1u) >> 1 : NB * sub;
     uint32_t item;
     if (!xcd_item_of(blockIdx.x, a.items, a.chunk_log2, a.rot, a.per_magic, item)) return;
     uint32_t tx = 0, cc, bx, cr;
@@ -407,6 +419,7 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     t.src_row_dwords = (uint32_t)upr * 15u;                             // source dwords per tile row (multiple of 4)
     t.src_pitch16 = (uint32_t)a.W0 * 3u / 16u;                          // 16-byte chunks per raw row (W0*3 % 16 == 0)
     t.cpt = t.src_row_dwords >> 2; t.cpt_magic = cpt_magic; t.tx = tx;
+    t.sub = bands_per_wg == 2 ? 1u : sub; t.subrows = subrows;
     uint32_t *s_stage = s_dyn;                                          // [max_src_rows * src_row_dwords], later the output
     constexpr int U = RAW35_STAGE_UNROLL;
     if constexpr (bands_per_wg != 2) {
@@ -425,7 +438,8 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
             // keep their layout.  Measured at 960x540 against the register-staged version (-DRAW35_NO_LDS_DIRECT),
             // alternating, three each on one box: 141.5 -> 143.7 k frames/s with the non-temporal hint, 140.5 k without.
             u32x4 none[1];
-            raw35_issue<1, false>(a, band_rows, t, f, c, bx, k, none);
+            raw35_issue<1, false>(a, band_rows, t, f, c, bx, k, none, vrows);
+            if (!k.nrows) return;                                       // (ragged last band of a sub-band launch; uniform)
             for (uint32_t base = threadIdx.x & ~63u; base < k.nsrc; base += blockDim.x) {
                 const uint32_t idx = base + (threadIdx.x & 63u);
                 if (idx < k.nsrc)
@@ -437,7 +451,8 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
             lds_barrier();
         } else {
             u32x4 v[U];
-            raw35_issue<U>(a, band_rows, t, f, c, bx, k, v);
+            raw35_issue<U>(a, band_rows, t, f, c, bx, k, v, vrows);
+            if (!k.nrows) return;
             raw35_stage<U>(t, k, v, s_stage);
         }
         raw35_finish(a, vrows, t, f, c, k, s_stage, false, blockDim.x);
@@ -493,12 +508,14 @@ __device__ __forceinline__ Raw35Item raw35_item_of(const OverlayArgs &a, const u
 // header of a band (scalar loads), its first stamp record, and -- loader only -- its source rows into `stage`
 template <bool LOADER>
 __device__ __forceinline__ void raw35_ws_begin(const OverlayArgs &a, const int2 *__restrict__ band_rows, const Raw35Tile &t,
-                                               const Raw35Item &it, Raw35Band &k, uint32_t *stage, const uint32_t lane)
+                                               const Raw35Item &it, Raw35Band &k, uint32_t *stage, const uint32_t lane,
+                                               const uint32_t lwave, const uint32_t nloaders)
 {
     u32x4 none[1];
     raw35_issue<1, false>(a, band_rows, t, it.f, it.c, it.b, k, none);
     if (LOADER) {
-        for (uint32_t base = 0; base < k.nsrc; base += 64u) {
+        // (one wave issuing all ~33 KB of a band took ~3.3 us per band: the loader waves share the chunks round-robin)
+        for (uint32_t base = lwave * 64u; base < k.nsrc; base += 64u * nloaders) {
             const uint32_t idx = base + lane;
             if (idx < k.nsrc)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(k.g + idx),
@@ -507,10 +524,10 @@ __device__ __forceinline__ void raw35_ws_begin(const OverlayArgs &a, const int2 
     }
 }
 
-__global__ __launch_bounds__(RAW35_MAX_BLOCK + 64) void k_overlay_raw35_ws(OverlayArgs a, const uint2 *__restrict__ vrows,
-                                                                            const int2 *__restrict__ band_rows, int upr,
-                                                                            int max_src_rows, int owner_off, uint32_t nbx_magic,
-                                                                            uint32_t virtual_blocks, uint32_t stage_dwords)
+__global__ __launch_bounds__(1024) void k_overlay_raw35_ws(OverlayArgs a, const uint2 *__restrict__ vrows,
+                                                           const int2 *__restrict__ band_rows, int upr, int max_src_rows,
+                                                           int owner_off, uint32_t nbx_magic, uint32_t virtual_blocks,
+                                                           uint32_t stage_dwords, uint32_t nloaders)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     Raw35Tile t;
@@ -520,9 +537,9 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK + 64) void k_overlay_raw35_ws(Overl
     t.src_pitch16 = (uint32_t)a.W0 * 3u / 16u;
     t.cpt = t.src_row_dwords >> 2; t.cpt_magic = 0u; t.tx = 0u;
     (void)max_src_rows;
-    const uint32_t nblend = blockDim.x - 64u;                          // blend threads (a multiple of 64); the last wave loads
+    const uint32_t nblend = blockDim.x - 64u * nloaders;               // blend threads (a multiple of 64); the last waves load
     const bool loader = threadIdx.x >= nblend;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, lwave = loader ? (threadIdx.x - nblend) >> 6 : 0u;
     uint32_t L = blockIdx.x;
     // first band of this workgroup
     Raw35Item it = raw35_item_of(a, L, nbx_magic);
@@ -535,10 +552,10 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK + 64) void k_overlay_raw35_ws(Overl
     uint32_t cur = 0;
     Raw35Band k;
     if (loader) {
-        raw35_ws_begin<true>(a, band_rows, t, it, k, s_dyn, lane);
+        raw35_ws_begin<true>(a, band_rows, t, it, k, s_dyn, lane, lwave, nloaders);
         __builtin_amdgcn_s_waitcnt(0x0f70);                              // vmcnt(0): the first band has landed
     } else
-        raw35_ws_begin<false>(a, band_rows, t, it, k, s_dyn, lane);
+        raw35_ws_begin<false>(a, band_rows, t, it, k, s_dyn, lane, 0u, nloaders);
     lds_barrier();
     for (;;) {
         // the next band of this workgroup (workgroup-uniform)
@@ -554,7 +571,7 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK + 64) void k_overlay_raw35_ws(Overl
         Raw35Band kn;
         if (loader) {
             // the other half is free: whoever read it last did so before the barrier that ended the previous round
-            if (more) raw35_ws_begin<true>(a, band_rows, t, nx, kn, stage_next, lane);
+            if (more) raw35_ws_begin<true>(a, band_rows, t, nx, kn, stage_next, lane, lwave, nloaders);
             // the same barriers as raw35_finish executes for this band (n is workgroup-uniform)
             if (k.n) { lds_barrier(); lds_barrier(); lds_barrier(); }
             lds_barrier();
@@ -562,7 +579,7 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK + 64) void k_overlay_raw35_ws(Overl
             __builtin_amdgcn_s_waitcnt(0x0f70);                          // the next band's rows are in LDS
             lds_barrier();
         } else {
-            if (more) raw35_ws_begin<false>(a, band_rows, t, nx, kn, stage_next, lane);
+            if (more) raw35_ws_begin<false>(a, band_rows, t, nx, kn, stage_next, lane, 0u, nloaders);
             raw35_finish(a, vrows, t, it.f, it.c, k, stage, true, nblend);
         }
         if (!more) break;

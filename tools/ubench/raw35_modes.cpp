@@ -60,9 +60,10 @@ int main(int argc, char **argv)
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     CA(cama_bin_frames(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, w2c, F, c2cam, K, C, crop, W, H, radius, scratch, sb, s));
     CK(hipStreamSynchronize(s));
-    printf("# raw35 F=%d max_src_rows=%d band rows=%d reps=%d\n", F, most, R, reps);
+    printf("# raw35 F=%d max_src_rows=%d (half bands: %d) band rows=%d reps=%d\n", F, most & 0xffff, most >> 16, R, reps);
     // reference bytes: the classic kernel
     CA(cama_set_option("raw35_ws", 0));
+    CA(cama_set_option("raw35_subrows", 0));
     CA(cama_overlay_frames_raw35(src, H0, W0, d_vrows, d_brows, most, ref, 0, F, C, H, W, cols, radius, hw, pal, scratch, sb, s));
     CK(hipStreamSynchronize(s));
     std::vector<uint8_t> href(std::min(dst_bytes, (size_t)256 << 20)), hgot(href.size());
@@ -71,8 +72,10 @@ int main(int argc, char **argv)
     while (pos < script.size()) {
         size_t end = script.find(',', pos);
         if (end == std::string::npos) end = script.size();
-        long ws = 0, order = -1;
-        sscanf(script.substr(pos, end - pos).c_str(), "%ld:%ld", &ws, &order);
+        long ws = 0, order = -1, nl = 2, stg = 0;
+        sscanf(script.substr(pos, end - pos).c_str(), "%ld:%ld:%ld:%ld", &ws, &order, &nl, &stg);
+        CA(cama_set_option("raw35_subrows", stg));           // 4th field: 1 = half bands, 0 = whole bands
+        CA(cama_set_option("raw35_loaders", nl));
         pos = end + 1;
         CA(cama_set_option("raw35_ws", ws));
         CA(cama_set_option("overlay_chunk_log2", order));
@@ -91,7 +94,7 @@ int main(int argc, char **argv)
         CA(cama_profile_enable(0));
         std::sort(ms.begin(), ms.end());
         const double bytes = (double)src_bytes + (double)dst_bytes;
-        printf("ws %ld order %3ld  min %.4f med %.4f max %.4f ms   frac(med) %.3f   bytes %s\n", ws, order, ms[0], ms[reps / 2], ms[reps - 1],
+        printf("ws %ld loaders %ld halves %ld order %3ld  min %.4f med %.4f max %.4f ms   frac(med) %.3f   bytes %s\n", ws, nl, stg, order, ms[0], ms[reps / 2], ms[reps - 1],
                bytes / (ms[reps / 2] * 1e-3) / 8e12, same ? "identical to the classic kernel" : "DIFFER");
         fflush(stdout);
     }
