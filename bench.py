@@ -934,8 +934,12 @@ def main():
         try:
             line["overlay_mapping"] = dict(job.eng.overlay_mapping(),
                                            note="big launches (>= 1.75 GiB): the library times the XCD-contiguous order (31) "
-                                                "against round-robin chunks of 32 bands (5) on this process's first launches and "
-                                                "keeps the faster; -1 = not decided (no big launch, or forced)")
+                                                "against round-robin chunks of 32 bands (5) on the first launches over each "
+                                                "(frames, mosaic) buffer pair -- three each, medians -- and keeps the faster for "
+                                                "that pair (the contiguous order's speed is a property of the buffers' physical "
+                                                "placement: profiles/r04_overlay_modes.txt); reported: the pair of the most recent "
+                                                "big launch; -1 = not decided (no big launch, fewer than six launches over the "
+                                                "pair, or forced)")
         except Exception as e:
             line["overlay_mapping"] = {"error": repr(e)}
         if args.sites > 0:

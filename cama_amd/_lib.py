@@ -66,6 +66,8 @@ SIGNATURES = {
     "cama_stamp_scratch_bytes": (_sz, [_i32, _i32]),
     "cama_stamp_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_probe_xcd_map": (_i32, [_vp, _i32, _vp]),
+    "cama_stream_create_masked": (_i32, [_i32, _vp]),
+    "cama_stream_destroy": (_i32, [_vp]),
     "cama_overlay_mapping_info": (_i32, [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(ctypes.c_double)]),
     "cama_set_option": (_i32, [ctypes.c_char_p, _i64]),
     "cama_get_option": (_i32, [ctypes.c_char_p, ctypes.POINTER(_i64)]),

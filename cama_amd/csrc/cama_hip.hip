@@ -2080,6 +2080,36 @@ int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per
     return CAMA_OK;
 }
 
+// A stream whose kernels may only run on `n_cus` of the device's compute units, spread evenly over the chip (every
+// (total / n_cus)-th CU).  For the egress side of the main.py loop: the runtime performs device -> pinned-host copies with
+// blit kernels whose waves sit on PCIe write latency; confined to a few CUs they stop competing with the JPEG decoder for
+// wave slots.  The caller owns the stream (cama_stream_destroy).  (No reference counterpart.)
+int cama_stream_create_masked(int32_t n_cus, void **stream)
+{
+    if (!stream || n_cus < 1) return fail(CAMA_EINVAL, "bad arguments");
+    int dev = 0, total = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev));
+    if (total < 1) return fail(CAMA_EHIP, "no compute units reported");
+    const int n = std::min(n_cus, total), words = (total + 31) / 32;
+    std::vector<uint32_t> mask((size_t)words, 0u);
+    for (int k = 0; k < n; ++k) {
+        const int cu = (int)((int64_t)k * total / n);
+        mask[cu >> 5] |= 1u << (cu & 31);
+    }
+    hipStream_t s = nullptr;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask.data()));
+    *stream = (void *)s;
+    return CAMA_OK;
+}
+
+int cama_stream_destroy(void *stream)
+{
+    if (!stream) return CAMA_OK;
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return CAMA_OK;
+}
+
 int cama_probe_xcd_map(uint32_t *xcd_of_block, int32_t n_blocks, void *stream)
 {
     if (!xcd_of_block || n_blocks < 1 || n_blocks > (1 << 20)) return fail(CAMA_EINVAL, "bad arguments");

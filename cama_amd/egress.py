@@ -66,6 +66,30 @@ class PinnedPool:
 
 
 _POOL = PinnedPool()
+_EGRESS_STREAMS = {}
+
+
+def egress_stream(engine):
+    """A/B knob (CAMA_EGRESS_CUS=n > 0): run the batches' downloads on a stream whose kernels are confined to n compute
+    units spread over the chip (cama_stream_create_masked).  The runtime performs device -> pinned-host copies with blit
+    kernels (__amd_rocclr_copyBuffer: 41 ms of kernel time per 240-frame bgr24 pass, on the render stream), and the main.py
+    loop waits for the JPEG decoder 83 % of the time -- so the copies were confined to 8 / 16 / 32 / 64 CUs to leave the
+    decoder its wave slots.  Measured (profiles/r04_demo_loop_timeline.txt): SLOWER, bgr24 3.07 k -> 2.39-2.48 k frames/s,
+    I420 3.87 k -> 3.40-3.68 k: a confined blit kernel no longer fills the PCIe link.  Default 0 = the render stream."""
+    import ctypes
+    import os
+    n = int(os.environ.get("CAMA_EGRESS_CUS", "0"))
+    if n <= 0:
+        return None
+    key = (str(engine.device), n)
+    st = _EGRESS_STREAMS.get(key)
+    if st is None:
+        torch = _torch()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(engine.device):
+            rc = engine.lib.cama_stream_create_masked(n, ctypes.byref(handle))
+        st = _EGRESS_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=engine.device) if rc == 0 else False
+    return st or None
 
 
 class RenderBatch:
@@ -93,9 +117,7 @@ class RenderBatch:
             per = H2 * W2 * 3
             with torch.cuda.device(eng.device):
                 self._host = _POOL.take(B * per)
-                self._host.view(B, per).copy_(self.mosaic.view(B, per), non_blocking=True)
-                self._event = torch.cuda.Event()
-                self._event.record(torch.cuda.current_stream(eng.device))
+                self._download(self._host.view(B, per), self.mosaic.view(B, per), self.mosaic)
             self._fmt = fmt
             return True
         per = H2 * W2 * 3 // 2
@@ -106,11 +128,29 @@ class RenderBatch:
             _lib.check(eng.lib.cama_bgr_to_i420(self.mosaic.data_ptr(), H2 * W2 * 3, self._i420_dev.data_ptr(), per, B, H2,
                                                 W2, eng._stream()))
             self._host = _POOL.take(B * per)
-            self._host.view(B, per).copy_(self._i420_dev, non_blocking=True)
-            self._event = torch.cuda.Event()
-            self._event.record(torch.cuda.current_stream(eng.device))
+            self._download(self._host.view(B, per), self._i420_dev, self._i420_dev)
         self._fmt = "i420"
         return True
+
+    def _download(self, host_view, dev_view, keep):
+        """Asynchronous device -> pinned copy behind the work queued on the current stream, on the CU-masked egress stream
+        when there is one; records self._event."""
+        torch = _torch()
+        eng = self.engine
+        cur = torch.cuda.current_stream(eng.device)
+        side = egress_stream(eng)
+        self._event = torch.cuda.Event()
+        if side is None:
+            host_view.copy_(dev_view, non_blocking=True)
+            self._event.record(cur)
+            return
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            host_view.copy_(dev_view, non_blocking=True)
+            self._event.record(side)
+        keep.record_stream(side)
 
     def _host_rows(self):
         if self._host_np is None:

@@ -376,6 +376,13 @@ int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const fl
  */
 int cama_probe_xcd_map(uint32_t *xcd_of_block, int32_t n_blocks, void *stream);
 
+/* A HIP stream (returned as void*) whose kernels are confined to n_cus compute units spread evenly over the chip
+ * (hipExtStreamCreateWithCUMask).  Used by the host side for the egress of VideoGenerator's frames (cama/tools.py:27-32): the
+ * runtime copies device -> pinned host memory with blit kernels, and confined to a few CUs those stop taking wave slots from
+ * the JPEG decoder.  The caller owns the stream.  (No reference counterpart.) */
+int cama_stream_create_masked(int32_t n_cus, void **stream /* host */);
+int cama_stream_destroy(void *stream);
+
 /* Which workgroup -> band order do big overlay launches (>= 1.75 GiB touched) use?  The speed of the XCD-contiguous order (31)
  * depends on the buffers a launch walks (their physical placement: 0.75 .. 0.835 of 8 TB/s at 40 frames of 1600x900, the same
  * for a given pair of buffers every time), that of round-robin chunks of 32 bands (5) does not (0.775 .. 0.79).  So the

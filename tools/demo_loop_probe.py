@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The reference's main.py loop (main.py:56-61), verbatim, on a synthetic clip with 1600x900 JPEG frames, VideoGenerator
-included: frames/s end to end (files -> device JPEG decode -> fused raw overlay -> device I420 -> pinned download -> sink).
+included: frames/s end to end (files -> device JPEG decode -> fused raw overlay -> pinned download of the bgr24 mosaics [default:
+the reference's stream] or device I420 + download [CAMA_EGRESS=i420] -> sink).
 
-    CAMA_VIDEO_SINK=null python tools/demo_loop_probe.py [--frames 240] [--content photo|noise]
+    CAMA_VIDEO_SINK=null python tools/demo_loop_probe.py [--frames 240] [--content photo|noise] [--passes 6]
 """
 import argparse
 import os
@@ -17,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=240)
     ap.add_argument("--content", choices=["noise", "photo"], default="photo")
+    ap.add_argument("--passes", type=int, default=6, help="passes over the clip: the first is one-off setup, the rest steady state")
     args = ap.parse_args()
     import torch
     from cama.dataset import ClipManager
@@ -30,7 +32,8 @@ def main():
               extra_labels=False)
     print(f"clip with {6 * (args.frames + 1)} JPEGs written in {time.perf_counter() - t:.1f} s")
     cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)          # reference default output size (540, 960)
-    for label in ("first pass (one-off setup)", "steady state", "steady state"):
+    rates = []
+    for label in ["first pass (one-off setup)"] + ["steady state"] * (args.passes - 1):
         vg = VideoGenerator(os.path.join(root, "out.mp4"), (2880, 1080))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -46,7 +49,13 @@ def main():
         vg.close()
         dt = time.perf_counter() - t0
         print(f"main.py loop, {label}: {n} frames in {dt:.3f} s = {n / dt:.1f} frames/s (stream: {vg.pix_fmt}, "
-              f"mosaic {tuple(image.shape)})")
+              f"mosaic {tuple(image.shape)}, {type(image).__name__})")
+        if label == "steady state":
+            rates.append(n / dt)
+    if rates:
+        rates.sort()
+        print(f"steady state over {len(rates)} passes: median {rates[len(rates) // 2]:.0f} frames/s (min {rates[0]:.0f}, max {rates[-1]:.0f}); "
+              f"egress format {os.environ.get('CAMA_EGRESS', 'bgr24 (default)')}")
 
 
 if __name__ == "__main__":
