@@ -104,6 +104,9 @@ def parse_args(argv=None):
                     help="with --raw-frames: separate resample kernel + overlay instead of the fused raw-frame overlay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single stream: binning and overlay of consecutive steps do not overlap")
+    ap.add_argument("--audition", type=int, default=None,
+                    help="candidate allocations timed per long-lived frames / mosaic buffer (Engine.alloc_mosaic; default "
+                         "CAMA_AUDITION or 16; 0 = plain allocations)")
     ap.add_argument("--no-scene-batch", action="store_true",
                     help="several scenes per rank: one launch chain per scene (ClipManager.render_clip) instead of one "
                          "multi-scene launch chain per step (dataset.render_clips)")
@@ -405,11 +408,11 @@ class Job:
         self.batched = False
         if self.scenes and self.F:
             rig = self.scenes[0][1]._rig()
-            self.out = torch.empty(self.eng.mosaic_shape(rig, self.F), dtype=torch.uint8, device=device)   # shared
+            self.out = self._alloc_out(0)                                 # shared by the scenes of per-scene launches
             # several whole scenes per rank: ONE multi-scene launch chain per step, every scene into its own mosaic
             if (len(self.scenes) > 1 and frame_range is None and not getattr(args, "no_scene_batch", False)
                     and not getattr(args, "raw_frames", False) and not _segments(args)):
-                self.outs = [self.out] + [torch.empty_like(self.out) for _ in self.scenes[1:]]
+                self.outs = [self.out] + [self._alloc_out(k) for k in range(1, len(self.scenes))]
                 self.batched = self.step_batched()
                 self.eng.join()
                 if not self.batched:
@@ -417,6 +420,31 @@ class Job:
             elif len(self.scenes) > 1 and frame_range is None and os.environ.get("CAMA_BENCH_OWN_OUTS") == "1":
                 # A/B knob: per-scene launches, but every scene into its own mosaic like the multi-scene path
                 self.own_outs = [self.out] + [torch.empty_like(self.out) for _ in self.scenes[1:]]
+
+    def _alloc_out(self, k):
+        """Scene k's mosaic buffer, and -- both are long-lived, rendered from / into on every step -- placed by
+        Engine.alloc_mosaic / place_frames: the fastest of a few candidate allocations for THIS source / mosaic pair
+        (profiles/r04_overlay_modes.txt section 5; CAMA_AUDITION=0 or --audition 0: plain allocations)."""
+        import torch
+        from cama_amd.frames import DeviceFrameSource
+        sid, cm, frames, clip = self.scenes[k]
+        rig = cm._rig()
+        K = getattr(self.args, "audition", None)
+        if getattr(self.args, "raw_frames", False) or K == 0:
+            return torch.empty(self.eng.mosaic_shape(rig, self.F), dtype=torch.uint8, device=self.device)
+        first = 1 if self.frame_range is None else 0                    # image index 0 is never rendered
+        shape = self.eng.mosaic_shape(rig, self.F)
+        if int(np.prod(shape)) > (8 << 30) and len(self.scenes) == 1:   # a long clip: one placed buffer per launch
+            per = max(1, min(self.F, self.eng.max_frames_per_call(cm._static("cama").device(), rig, pipelined=self.pipelined)))
+            srcs = [frames[first + lo:first + min(self.F, lo + per)] for lo in range(0, self.F, per)]
+            return self.eng.alloc_mosaics(rig, srcs, pool=None if K is None else K * len(srcs) // 4)
+        out = self.eng.alloc_mosaic(rig, frames[first:first + self.F], candidates=K)
+        placed = self.eng.place_frames(rig, frames, out, first=first, candidates=None if K is None else max(K // 2, 0))
+        if placed is not frames:
+            src = cm.frame_source()
+            cm.set_frame_source(DeviceFrameSource(placed, index_offset=src.index_offset))
+            self.scenes[k] = (sid, cm, placed, clip)
+        return out
 
     def step_batched(self):
         from cama_amd.dataset import render_clips
@@ -942,6 +970,23 @@ def main():
                                                 "pair, or forced)")
         except Exception as e:
             line["overlay_mapping"] = {"error": repr(e)}
+        log = getattr(job.eng, "audition_log", None)
+        if log:
+            mos = [e for e in log if e["role"] == "mosaic"]
+            frs = [e for e in log if e["role"] == "frames"]
+            line["placement"] = {
+                "buffers": len(mos), "candidates_per_mosaic": mos[0]["candidates"] if mos else 0,
+                "candidates_per_frames": frs[0]["candidates"] if frs else 0,
+                "first_mosaic_candidates_ms": mos[0]["ms"] if mos else None,
+                "first_frames_candidates_ms": frs[0]["ms"] if frs else None,
+                "kept_of_pool": mos[0].get("kept") if mos else None,
+                "chosen_ms_mean": float(np.mean([e["chosen_ms"] for e in (frs or mos)])),
+                "plain_ms_mean": float(np.mean([e["ms"][0] for e in mos])) if mos else None,
+                "note": "rank 0; before the timed region, every long-lived mosaic buffer is the fastest of N candidate "
+                        "allocations for its source (stamp-free overlay launches timed into each), then the frames are moved "
+                        "into the fastest of M candidates for that mosaic: the overlay's bandwidth depends on the pair's "
+                        "physical placement (profiles/r04_overlay_modes.txt section 5); plain = the first candidate, what an "
+                        "un-auditioned allocation would have been; --audition 0 switches it off"}
         if args.sites > 0:
             line["site_maps"] = {"sites": args.sites, "verts_per_site": N,
                                  "sites_per_rank": shard.sites_per_rank(assignment, site_of),

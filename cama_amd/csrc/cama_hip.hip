@@ -335,8 +335,13 @@ Option g_options[] = {
     {"raw35_subrows", "CAMA_RAW35_SUBROWS", 0, {0}, {false}},              // 3:5 raw overlay: 1 = half bands per workgroup
     {"cull_list_min", "CAMA_CULL_LIST_MIN", 16384, {0}, {false}},          // (block, frame) items from which a site-sized
                                                                             // map's cull goes through work lists
+    {"pipeline_host_wait", "CAMA_PIPELINE_HOST_WAIT", -1, {0}, {false}},   // 1: cama_pipeline_* wait for a launch's binning on the
+                                                                            // HOST before queueing its overlay (no barrier packet
+                                                                            // between consecutive overlays; the call blocks ~0.1 ms);
+                                                                            // 0: stream-side wait; -1: host wait for launches that
+                                                                            // move >= 512 MiB (the host has the time to spare)
 };
-enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_RAW35_WS, OPT_RAW35_LOADERS, OPT_RAW35_SUBROWS, OPT_CULL_LIST_MIN, OPT_COUNT };
+enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_RAW35_WS, OPT_RAW35_LOADERS, OPT_RAW35_SUBROWS, OPT_CULL_LIST_MIN, OPT_HOST_WAIT, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
 int64_t option(int k)
 {
@@ -1842,6 +1847,11 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
     // 106.8 k vs 109.9 k frames/s)
     hipStream_t so = p->s_ov;
     // `binned` also carries `ready` (s_bin waited for it above): one barrier packet between overlays, not two
+    // (pipeline_host_wait: the wait happens here instead -- hipStreamWaitEvent on a complete event queues nothing, so the
+    // overlay goes into its queue directly behind the previous one)
+    const int64_t host_wait = option(OPT_HOST_WAIT);
+    if (host_wait > 0 || (host_wait < 0 && (size_t)F * C * H * W * 6 >= ((size_t)1 << 29)))
+        HIP_TRY(hipEventSynchronize(p->binned[slot]));
     HIP_TRY(hipStreamWaitEvent(so, p->binned[slot], 0));
     g_overlay_stop_event = (overlay_takes_stop_event && ext_events()) ? p->done[k % RING] : nullptr;
     if (int rc = overlay(sc, (void *)so)) {

@@ -492,9 +492,11 @@ class ClipManager:
         host_poses = pipelined and isinstance(w2c, np.ndarray) and w2c.dtype == np.float32
         T = w2c if host_poses else eng._mats(w2c)
         ids = idx.tolist()
+        # a ChunkedMosaic (one allocation per launch, Engine.alloc_mosaics): launches end at its chunk boundaries
+        cuts = sorted(set(getattr(out, "bounds", ())))
         lo = 0
         while lo < F:
-            hi = min(F, lo + step)
+            hi = min([F, lo + step] + [c for c in cuts if c > lo][:1])
             try:
                 if fused_raw:      # raw sensor frames: undistort + resize inside the overlay kernel
                     eng.render_frames_raw(dmap, rig, T[lo:hi], src_all.raw_batch(ids[lo:hi]),

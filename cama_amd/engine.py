@@ -166,6 +166,64 @@ class DeviceMap:
                 bounds, flags)
 
 
+class ChunkedMosaic:
+    """F mosaic frames kept as separate device allocations of a few frames each (one per launch of a long clip), so that
+    every launch's destination can be PLACED on its own (Engine.alloc_mosaics).  Indexing: an int gives a frame, a slice
+    [lo:hi] a view when it stays inside one chunk (what ClipManager.render_clip asks for -- it cuts its launches at the
+    chunk boundaries), anything else raises."""
+
+    def __init__(self, chunks):
+        self.chunks = list(chunks)
+        assert self.chunks and all(c.shape[1:] == self.chunks[0].shape[1:] for c in self.chunks)
+        self.bounds = [0]
+        for c in self.chunks:
+            self.bounds.append(self.bounds[-1] + int(c.shape[0]))
+
+    @property
+    def shape(self):
+        return (self.bounds[-1],) + tuple(self.chunks[0].shape[1:])
+
+    @property
+    def device(self):
+        return self.chunks[0].device
+
+    def __len__(self):
+        return self.bounds[-1]
+
+    def spans(self):
+        return [(self.bounds[k], self.bounds[k + 1], c) for k, c in enumerate(self.chunks)]
+
+    def _chunk_of(self, f):
+        import bisect
+        if not 0 <= f < self.bounds[-1]:
+            raise IndexError(f)
+        return bisect.bisect_right(self.bounds, f) - 1
+
+    def __getitem__(self, key):
+        F = self.bounds[-1]
+        if isinstance(key, slice):
+            lo, hi, step = key.indices(F)
+            if step != 1:
+                raise IndexError("ChunkedMosaic: unit-stride slices only")
+            if hi <= lo:
+                return self.chunks[0][:0]
+            k = self._chunk_of(lo)
+            if hi > self.bounds[k + 1]:
+                raise IndexError("ChunkedMosaic: [%d:%d] crosses the chunk boundary at %d" % (lo, hi, self.bounds[k + 1]))
+            return self.chunks[k][lo - self.bounds[k]:hi - self.bounds[k]]
+        f = int(key) + (F if int(key) < 0 else 0)
+        k = self._chunk_of(f)
+        return self.chunks[k][f - self.bounds[k]]
+
+    def fill_(self, v):
+        for c in self.chunks:
+            c.fill_(v)
+        return self
+
+    def zero_(self):
+        return self.fill_(0)
+
+
 class Engine:
     def __init__(self, device="cuda:0", crop=CROP_BOX, radius=RADIUS, palette_bgr=PALETTE_BGR, alpha=1.0):
         torch = _torch()
@@ -404,6 +462,142 @@ class Engine:
                 self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), self._stream()))
             self._last_bin = (dmap.N, F, rig.C, rig.H, rig.W, bnd is not None, key is not None, scratch)
             return out
+
+    # ------------------------------------------------------------------ placement-aware allocation of long-lived buffers
+    def _overlay_ms(self, rig, src, out, cols, reps):
+        """Mean duration (ms) of `reps` stamp-free overlay launches src -> out in the XCD-contiguous order (torch events on
+        the current stream; blocks)."""
+        import ctypes
+        torch = _torch()
+        F = int(src.shape[0])
+        L = self.lib
+        need = int(L.cama_render_scratch_bytes(0, F, rig.C, rig.H, rig.W, self.radius))
+        memo = self.__dict__.setdefault("_audition_scratch", {})
+        key = (F, rig.C, rig.H, rig.W)
+        if key not in memo:
+            scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+            w2c = torch.zeros((F, 16), dtype=torch.float64, device=self.device)
+            _lib.check(L.cama_bin_frames(None, None, None, 0, None, None, None, 0, 0, w2c.data_ptr(), F, rig.c2cam.data_ptr(),
+                                         rig.K.data_ptr(), rig.C, self.crop.ctypes.data, rig.W, rig.H, self.radius,
+                                         scratch.data_ptr(), scratch.numel(), self._stream()))
+            memo.clear()
+            memo[key] = (scratch, w2c)
+        scratch = memo[key][0]
+        prev = ctypes.c_int64(-1)
+        _lib.check(L.cama_get_option(b"overlay_chunk_log2", ctypes.byref(prev)))
+        _lib.check(L.cama_set_option(b"overlay_chunk_log2", 31))
+        try:
+            def launch():
+                _lib.check(L.cama_overlay_frames(src.data_ptr(), out.data_ptr(), 0, F, rig.C, rig.H, rig.W, cols, self.radius,
+                                                 self.halfwidth.ctypes.data, self.palette.ctypes.data, scratch.data_ptr(),
+                                                 scratch.numel(), self._stream()))
+            launch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                launch()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+        finally:
+            L.cama_set_option(b"overlay_chunk_log2", prev.value)
+
+    def alloc_mosaic(self, rig, src, cols=3, candidates=None, reps=3):
+        """A mosaic buffer [F, rows*H, cols*W, 3] for frames `src` [F,C,H,W,3] that is going to be rendered into MANY times
+        (a service's output ring, bench.py's output buffer) -- chosen among `candidates` fresh allocations by timing the
+        overlay itself into each of them.
+
+        Why (round 4, profiles/r04_overlay_modes.txt section 5): the overlay's bandwidth depends on where its source and its
+        destination sit physically RELATIVE to each other -- scanning 48 one-gigabyte destinations for one source gives
+        0.312-0.326 ms for about one in six of them and 0.341-0.349 ms for the rest (0.85 against 0.77 of 8 TB/s), the same
+        ones every time -- a DRAM-side read / write interference that no order of the kernel's accesses removes.  A caller
+        who keeps the buffer can afford to look: `candidates` allocations (default CAMA_AUDITION, 16; 0 or a launch below
+        512 MiB: no audition, a plain allocation) stay alive together, each is timed with `reps` stamp-free launches, the fastest
+        is returned and the others go back to the allocator.  ~0.4 ms per candidate launch; speed only."""
+        torch = _torch()
+        F = int(src.shape[0])
+        shape = self.mosaic_shape(rig, F, cols)
+        nbytes = int(np.prod(shape))
+        K = int(os.environ.get("CAMA_AUDITION", "16")) if candidates is None else int(candidates)
+        with torch.cuda.device(self.device):
+            if K <= 1 or nbytes < (1 << 29) or nbytes > (8 << 30) or rig.W % 16 or self.alpha256 != 256:
+                return torch.empty(shape, dtype=torch.uint8, device=self.device)
+            free, _ = torch.cuda.mem_get_info(self.device)
+            K = max(1, min(K, int(free // 2 // nbytes)))          # never more than half of what is free
+            best, best_ms, pool, times = None, float("inf"), [], []
+            for _ in range(K):
+                cand = torch.empty(shape, dtype=torch.uint8, device=self.device)
+                pool.append(cand)                                  # alive together: distinct memory
+                ms = self._overlay_ms(rig, src, cand, cols, reps)
+                times.append(ms)
+                if ms < best_ms:
+                    best, best_ms = cand, ms
+            self.__dict__.setdefault("audition_log", []).append(
+                {"role": "mosaic", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4)})
+            return best
+
+    def alloc_mosaics(self, rig, srcs, cols=3, pool=None, reps=3):
+        """The same for a long clip rendered in several launches: `srcs` = the source view [F_k,C,H,W,3] of every launch;
+        returns a ChunkedMosaic with one separately allocated buffer per launch.  A pool of `pool` allocations of the
+        largest launch's size (default CAMA_AUDITION_POOL or 4 per launch, at most 3/4 of the free memory) is timed against
+        the first launch's source -- a destination's speed is mostly its own (3.3 GB launches: 0.99 ms into one buffer in
+        four to six, 1.07-1.085 ms into the others, whichever source) -- and the fastest len(srcs) are kept, the rest freed
+        to the driver.  pool = 0 / CAMA_AUDITION=0: plain allocations."""
+        torch = _torch()
+        n = len(srcs)
+        Fmax = max(int(s.shape[0]) for s in srcs)
+        shape = self.mosaic_shape(rig, Fmax, cols)
+        nbytes = int(np.prod(shape))
+        if pool is None:
+            pool = 0 if os.environ.get("CAMA_AUDITION", "16") == "0" else int(os.environ.get("CAMA_AUDITION_POOL", str(4 * n)))
+        with torch.cuda.device(self.device):
+            free, _ = torch.cuda.mem_get_info(self.device)
+            P = min(int(pool), int(free * 3 // 4 // nbytes))
+            if P <= n or nbytes < (1 << 29) or rig.W % 16 or self.alpha256 != 256:
+                return ChunkedMosaic([torch.empty(self.mosaic_shape(rig, int(s.shape[0]), cols), dtype=torch.uint8,
+                                                  device=self.device) for s in srcs])
+            F0 = int(srcs[0].shape[0])
+            cands = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(P)]
+            times = [self._overlay_ms(rig, srcs[0], c[:F0], cols, reps) for c in cands]
+            rank = sorted(range(P), key=lambda i: times[i])
+            keep = sorted(rank[:n])                                    # (in allocation order: nothing depends on it)
+            chunks = [cands[i][:int(s.shape[0])] for i, s in zip(keep, srcs)]
+            self.__dict__.setdefault("audition_log", []).append(
+                {"role": "mosaic", "bytes": nbytes, "candidates": P, "ms": [round(t, 4) for t in times],
+                 "chosen_ms": round(float(np.mean([times[i] for i in keep])), 4), "kept": n})
+            del cands
+            torch.cuda.empty_cache()                                   # the losers go back to the driver, not to torch's cache
+            return ChunkedMosaic(chunks)
+
+    def place_frames(self, rig, frames, out, first=0, cols=3, candidates=None, reps=3):
+        """The counterpart for the SOURCE side: `frames` [>= first + F, C,H,W,3] (already filled; the F = out.shape[0] frames
+        from index `first` are what gets rendered) is copied into the one of `candidates` fresh buffers from which the overlay
+        into `out` runs fastest (the source's placement is worth 2-4 % once the mosaic's is good).  Returns the buffer to use
+        from now on (possibly `frames` itself)."""
+        torch = _torch()
+        F = int(out.shape[0])
+        view = lambda t: t[first:first + F]
+        nbytes = int(frames.numel())
+        K = int(os.environ.get("CAMA_AUDITION", "16")) // 2 if candidates is None else int(candidates)
+        with torch.cuda.device(self.device):
+            if K <= 1 or nbytes < (1 << 29) or nbytes > (8 << 30) or rig.W % 16 or self.alpha256 != 256:
+                return frames
+            free, _ = torch.cuda.mem_get_info(self.device)
+            K = max(1, min(K, int(free // 2 // nbytes)))
+            best, best_ms = frames, self._overlay_ms(rig, view(frames), out, cols, reps)
+            times, pool = [best_ms], []
+            for _ in range(K):
+                cand = torch.empty_like(frames)
+                pool.append(cand)
+                ms = self._overlay_ms(rig, view(cand), out, cols, reps)     # (content does not matter for the timing)
+                times.append(ms)
+                if ms < best_ms * 0.995:
+                    best, best_ms = cand, ms
+            if best is not frames:
+                best.copy_(frames)
+            self.__dict__.setdefault("audition_log", []).append(
+                {"role": "frames", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4)})
+            return best
 
     def xcd_map(self, n_blocks=4096):
         """What the overlay's XCD-contiguous mapping relies on, measured: (True when the XCD a block of a 1-D grid runs on

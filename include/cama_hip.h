@@ -408,6 +408,10 @@ int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per
  *                                                  range of the launch, chunks round-robin inside a group (1, 2; 0 = off)
  *   cull_list_min         CAMA_CULL_LIST_MIN       (vertex block, frame) items from which the cull of a site-sized map goes
  *                                                  through work lists + persistent workgroups (default 16384)
+ *   pipeline_host_wait    CAMA_PIPELINE_HOST_WAIT  1 = cama_pipeline_render* waits on the HOST for a launch's binning before it
+ *                                                  queues the overlay (the call blocks ~0.1 ms; no barrier packet between
+ *                                                  consecutive overlays on the GPU: +1.5 % on the headline); 0 = stream-side
+ *                                                  wait; -1 (default) = host wait for launches that move >= 512 MiB
  * Unknown names: CAMA_EINVAL.  (No reference counterpart: the reference has no native code.) */
 int cama_set_option(const char *name, int64_t value);
 int cama_get_option(const char *name, int64_t *value);

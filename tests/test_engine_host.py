@@ -35,3 +35,26 @@ def test_requirements_file_lists_what_the_default_path_imports():
     req = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "requirements.txt")).read()
     for name in ("numpy", "scipy", "PyYAML", "tqdm", "torch", "Pillow"):
         assert name in req
+
+
+def test_chunked_mosaic_indexes_frames_and_refuses_slices_across_chunks():
+    """engine.ChunkedMosaic: a long clip's mosaic as one allocation per launch (Engine.alloc_mosaics).  Frames by int,
+    views by slices inside one chunk; ClipManager.render_clip cuts its launches at `bounds`."""
+    import pytest
+    import torch
+    chunks = [torch.full((n, 2, 4, 3), k, dtype=torch.uint8) for k, n in enumerate((4, 4, 3))]
+    m = engine.ChunkedMosaic(chunks)
+    assert m.shape == (11, 2, 4, 3) and len(m) == 11 and m.bounds == [0, 4, 8, 11]
+    assert [int(m[f][0, 0, 0]) for f in range(11)] == [0] * 4 + [1] * 4 + [2] * 3 and int(m[-1][0, 0, 0]) == 2
+    v = m[4:8]
+    assert v.shape[0] == 4 and v.data_ptr() == chunks[1].data_ptr()
+    assert m[9:11].data_ptr() == chunks[2][1:].data_ptr() and m[:3].shape[0] == 3 and m[5:5].shape[0] == 0
+    with pytest.raises(IndexError):
+        m[3:5]
+    with pytest.raises(IndexError):
+        m[11]
+    with pytest.raises(IndexError):
+        m[0:8:2]
+    m.fill_(7)
+    assert all(int(c.min()) == 7 and int(c.max()) == 7 for c in chunks)
+    assert [(lo, hi) for lo, hi, _ in m.spans()] == [(0, 4), (4, 8), (8, 11)]

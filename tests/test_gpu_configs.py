@@ -435,3 +435,50 @@ def test_two_threads_two_pipelines_share_the_mapping_table(sweep_scenes):
         assert all(h == golden[k] for h in hashes[k]), f"scene {k}: a concurrent render differs from the oracle's hash"
     last = [hashes[("info", k)] for k in (0, 1)]
     assert any(i["decided"] in (5, 31) and min(i["samples"]) >= 3 for i in last), last
+
+
+@pytest.mark.gpu
+def test_placed_buffers_render_the_same_bytes(monkeypatch):
+    """Engine.alloc_mosaic / place_frames / alloc_mosaics (round 4: long-lived buffers chosen among candidate allocations by
+    timing the overlay into them) change WHERE the bytes live, never what they are: the headline scene rendered into an
+    auditioned mosaic from auditioned frames, and into a ChunkedMosaic of placed launches, equals the plain
+    render; the audition leaves the process options as they were."""
+    import ctypes
+    import torch
+    from cama_amd import runtime, _lib
+    from cama_amd.frames import DeviceFrameSource
+    a = _args()
+    dev = torch.device("cuda:0")
+    eng = runtime.engine()
+    cm, frames, _ = bench.build_scene(a, 0, dev)
+    rig = cm._rig()
+    _, plain = cm.render_clip("cama")
+    want = shard.overlay_hash(plain)
+    before = ctypes.c_int64(-7)
+    _lib.check(eng.lib.cama_get_option(b"overlay_chunk_log2", ctypes.byref(before)))
+    out = eng.alloc_mosaic(rig, frames[1:1 + a.frames], candidates=4)
+    log = eng.audition_log[-1]
+    assert log["role"] == "mosaic" and log["candidates"] == 4 and len(log["ms"]) == 4 and log["chosen_ms"] == min(log["ms"])
+    placed = eng.place_frames(rig, frames, out, first=1, candidates=3)
+    assert eng.audition_log[-1]["role"] == "frames" and len(eng.audition_log[-1]["ms"]) == 4
+    assert torch.equal(placed, frames)
+    cm.set_frame_source(DeviceFrameSource(placed, index_offset=0))
+    out.fill_(0xA5)
+    cm.render_clip("cama", out=out, pipelined=True)
+    eng.join()
+    torch.cuda.synchronize()
+    assert shard.overlay_hash(out) == want
+    after = ctypes.c_int64(-7)
+    _lib.check(eng.lib.cama_get_option(b"overlay_chunk_log2", ctypes.byref(after)))
+    assert after.value == before.value
+    # chunked: two launches of 24 + 16 frames, each into its own placed allocation (candidates of 622 MB)
+    srcs = [placed[1 + lo:1 + min(a.frames, lo + 24)] for lo in range(0, a.frames, 24)]
+    chunked = eng.alloc_mosaics(rig, srcs, pool=5)
+    assert chunked.shape == tuple(plain.shape) and chunked.bounds == [0, 24, 40]
+    assert eng.audition_log[-1]["candidates"] == 5 and eng.audition_log[-1]["kept"] == 2
+    chunked.fill_(0xA5)
+    cm.render_clip("cama", out=chunked, pipelined=True)
+    eng.join()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([c for _, _, c in chunked.spans()]), plain)
+    assert isinstance(eng.alloc_mosaics(rig, srcs, pool=0), type(chunked))      # pool 0: plain allocations, same type

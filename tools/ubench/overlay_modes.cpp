@@ -104,8 +104,8 @@ int main(int argc, char **argv)
     while (pos < script.size()) {
         size_t end = script.find(',', pos);
         if (end == std::string::npos) end = script.size();
-        long order = -1, rot = 0, pf = 0, cold = 0, io = 0, grp = 0;
-        sscanf(script.substr(pos, end - pos).c_str(), "%ld:%ld:%ld:%ld:%ld:%ld", &order, &rot, &pf, &cold, &io, &grp);
+        long order = -1, rot = 0, pf = 0, cold = 0, io = 0, grp = 0, si = -1, di = -1;
+        sscanf(script.substr(pos, end - pos).c_str(), "%ld:%ld:%ld:%ld:%ld:%ld:%ld:%ld", &order, &rot, &pf, &cold, &io, &grp, &si, &di);
         CA(cama_set_option("overlay_item_order", io));
         CA(cama_set_option("overlay_groups_log2", grp));
         pos = end + 1;
@@ -113,8 +113,9 @@ int main(int argc, char **argv)
         CA(cama_set_option("overlay_tune", 0));
         CA(cama_set_option("overlay_rot", rot));
         CA(cama_set_option("overlay_prefetch", pf));
-        const auto launch = [&](int k) {
-            CA(cama_overlay_frames(src[k], dst[k], 0, F, C, H, W, cols, radius, hw, pal, scratch, sb, s));
+        const auto launch = [&](int k) {          // (fields 7, 8 of a run: a fixed source set and a fixed mosaic set)
+            CA(cama_overlay_frames(src[si >= 0 ? si % sets : k], dst[di >= 0 ? di % sets : k], 0, F, C, H, W, cols, radius, hw, pal,
+                                   scratch, sb, s));
         };
         for (int k = 0; k < 3; ++k) launch(cold ? (cursor++ % sets) : 0);       // warm-up (cold: just moves on)
         CK(hipStreamSynchronize(s));
@@ -132,6 +133,7 @@ int main(int argc, char **argv)
         for (double v : ms) mean += v;
         mean /= reps;
         const double bytes = 2.0 * set_bytes;
+        if (si >= 0 || di >= 0) printf("src %ld dst %ld  ", si, di);
         printf("order %3ld grp %ld io %ld rot %5ld pf %4ld %s  min %.4f med %.4f mean %.4f max %.4f ms   frac(med) %.3f frac(mean) %.3f\n", order, grp, io, rot, pf,
                cold ? "cold" : "warm", so[0], so[reps / 2], mean, so[reps - 1], bytes / (so[reps / 2] * 1e-3) / 8e12,
                bytes / (mean * 1e-3) / 8e12);
