@@ -339,7 +339,7 @@ Option g_options[] = {
                                                                             // HOST before queueing its overlay (no barrier packet
                                                                             // between consecutive overlays; the call blocks ~0.1 ms);
                                                                             // 0: stream-side wait; -1: host wait for launches that
-                                                                            // move >= 512 MiB (the host has the time to spare)
+                                                                            // move >= 1 GiB (the host has the time to spare; at 960x540 it has not)
 };
 enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_RAW35_WS, OPT_RAW35_LOADERS, OPT_RAW35_SUBROWS, OPT_CULL_LIST_MIN, OPT_HOST_WAIT, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
@@ -1850,7 +1850,7 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
     // (pipeline_host_wait: the wait happens here instead -- hipStreamWaitEvent on a complete event queues nothing, so the
     // overlay goes into its queue directly behind the previous one)
     const int64_t host_wait = option(OPT_HOST_WAIT);
-    if (host_wait > 0 || (host_wait < 0 && (size_t)F * C * H * W * 6 >= ((size_t)1 << 29)))
+    if (host_wait > 0 || (host_wait < 0 && (size_t)F * C * H * W * 6 >= ((size_t)1 << 30)))
         HIP_TRY(hipEventSynchronize(p->binned[slot]));
     HIP_TRY(hipStreamWaitEvent(so, p->binned[slot], 0));
     g_overlay_stop_event = (overlay_takes_stop_event && ext_events()) ? p->done[k % RING] : nullptr;
