@@ -38,7 +38,8 @@ Extra objects in the JSON line:
                 frames per launch -- / its mean duration measured live with hipEvents on the launch stream
                 (cama_profile_*; every 8th step is timed: the launch takes the event pair as the kernel's own start /
                 stop events, hipExtLaunchKernelGGL).  launch_ms_min / launch_ms_max: the fastest and slowest of those
-                timed launches (a step of a long clip is several launches over different memory).  peak 8000 GB/s.  `traffic` is a cross-reference to the committed
+                timed launches of the full launch size (a step of a long clip is several launches over different memory; its
+                shorter last launch is left out of the spread).  peak 8000 GB/s.  `traffic` is a cross-reference to the committed
                 rocprofv3 --pmc run of the same configuration (`traffic_source`), not a measurement of this run.
   roofline_project   the vertex term of SURVEY.md 8d belongs to k_frames_project, not to the overlay: bytes = 13 B (16 B
                 for maps that carry a draw key) x the vertices of the 64-vertex runs that survived the block cull
@@ -419,7 +420,7 @@ class Job:
                     self.outs = None
             elif len(self.scenes) > 1 and frame_range is None and os.environ.get("CAMA_BENCH_OWN_OUTS") == "1":
                 # A/B knob: per-scene launches, but every scene into its own mosaic like the multi-scene path
-                self.own_outs = [self.out] + [torch.empty_like(self.out) for _ in self.scenes[1:]]
+                self.own_outs = [self.out] + [self._alloc_out(k) for k in range(1, len(self.scenes))]
 
     def _alloc_out(self, k):
         """Scene k's mosaic buffer, and -- both are long-lived, rendered from / into on every step -- placed by
@@ -498,7 +499,14 @@ class Job:
         self.project_ms, self.project_n = pj_ms.value, pj_n.value
         got = [each[k] for k in range(min(cap, ov_n.value))]
         # per-launch spread of the timed overlay launches (a step of a long clip is several launches over different memory)
-        self.overlay_each = {"min": min(got), "max": max(got), "n": len(got)} if got else {"min": 0.0, "max": 0.0, "n": 0}
+        # -- over launches of the FULL launch size: a long clip's last launch is shorter (1000 frames = 7 x 128 + 104) and
+        # would otherwise be the minimum
+        full = got
+        bounds = getattr(self.out, "bounds", None)
+        if bounds and len(bounds) > 2 and len(got) % (len(bounds) - 1) == 0:
+            sizes = [b - a for a, b in zip(bounds, bounds[1:])]
+            full = [t for k, t in enumerate(got) if sizes[k % len(sizes)] == max(sizes)] or got
+        self.overlay_each = {"min": min(full), "max": max(full), "n": len(got)} if got else {"min": 0.0, "max": 0.0, "n": 0}
         return dt, float(sum(got)), len(got)
 
     def poison(self):

@@ -1564,8 +1564,13 @@ int cama_build_static_map(const float *verts, const int32_t *seg_v0, const int32
 // launch k blocks until launch k - (RING - 2) has completed.
 struct cama_pipeline {
     static constexpr int RING = 64;
-    hipStream_t s_bin = nullptr, s_ov = nullptr;
-    hipEvent_t ready = nullptr, binned[2] = {nullptr, nullptr};
+    // s_pre: the cull pre-pass of PLANNED launches (site-sized maps) and their pose upload -- the call waits for it on the
+    // host, and on its own stream it runs beside the previous launch's projection / scatter instead of queueing behind them
+    hipStream_t s_bin = nullptr, s_ov = nullptr, s_pre = nullptr;
+    hipEvent_t ready = nullptr, staged = nullptr, binned[2] = {nullptr, nullptr};
+    bool prev_planned = false;                  // the previous launch was planned: the next poses go up on s_pre
+    uint64_t poses_for = 0;                     // the launch the staged poses belong to, and the stream they went up on
+    bool poses_on_pre = false;
     hipEvent_t done[RING] = {};
     uint64_t issued = 0, completed = 0;
     // staged poses (cama_pipeline_stage_poses): a pinned host ring (one slot per in-flight launch) and one device pose
@@ -1600,7 +1605,9 @@ int cama_pipeline_create(cama_pipeline **out)
     hipError_t e = pe ? hipStreamCreateWithPriority(&p->s_bin, hipStreamNonBlocking, bin_prio)
                       : hipStreamCreateWithFlags(&p->s_bin, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_ov, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_pre, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready, flags);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->staged, flags);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->binned[k], flags);
     for (int k = 0; k < cama_pipeline::RING && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->done[k], flags);
     if (e != hipSuccess) {
@@ -1616,7 +1623,9 @@ int cama_pipeline_destroy(cama_pipeline *p)
     if (!p) return CAMA_OK;
     if (p->s_bin) { (void)hipStreamSynchronize(p->s_bin); (void)hipStreamDestroy(p->s_bin); }
     if (p->s_ov) { (void)hipStreamSynchronize(p->s_ov); (void)hipStreamDestroy(p->s_ov); }
+    if (p->s_pre) { (void)hipStreamSynchronize(p->s_pre); (void)hipStreamDestroy(p->s_pre); }
     if (p->ready) (void)hipEventDestroy(p->ready);
+    if (p->staged) (void)hipEventDestroy(p->staged);
     for (int k = 0; k < 2; ++k)
         if (p->binned[k]) (void)hipEventDestroy(p->binned[k]);
     for (int k = 0; k < cama_pipeline::RING; ++k)
@@ -1636,7 +1645,8 @@ int cama_pipeline_destroy(cama_pipeline *p)
 // Copy the next launch's world->chassis matrices (HOST, float32 [F,16]: the np.linalg.inv result of
 // cama/dataset.py:99, promoted to double here, exactly) into the pipeline's pinned ring and enqueue their upload on the
 // binning stream, into the device pose buffer of the next launch's scratch slot.  Returns that device pointer: pass it
-// as `w2c` to the next cama_pipeline_render*.  In-order on s_bin behind the previous user of the slot (launch k - 2).
+// as `w2c` to the next cama_pipeline_render*.  In order behind the previous user of the slot (launch k - 2): on s_bin, or --
+// after a planned launch -- on the pre-pass stream s_pre.
 int cama_pipeline_stage_poses(cama_pipeline *p, const float *w2c_host_f32, int32_t F, const double **w2c_dev)
 {
     if (!p || !w2c_dev) return fail(CAMA_EINVAL, "NULL pointer argument");
@@ -1647,6 +1657,7 @@ int cama_pipeline_stage_poses(cama_pipeline *p, const float *w2c_host_f32, int32
     if (need > p->pose_cap) {                   // grow (rare): drain what may still read the old buffers
         HIP_TRY(hipStreamSynchronize(p->s_bin));
         HIP_TRY(hipStreamSynchronize(p->s_ov));
+        HIP_TRY(hipStreamSynchronize(p->s_pre));
         const size_t cap = std::max(need, (size_t)64 * 16);
         if (p->pose_host) (void)hipHostFree(p->pose_host);
         for (int k = 0; k < 2; ++k)
@@ -1664,8 +1675,15 @@ int cama_pipeline_stage_poses(cama_pipeline *p, const float *w2c_host_f32, int32
     }
     double *h = p->pose_host + (size_t)(k % RING) * p->pose_cap;
     for (size_t i = 0; i < (size_t)F * 16; ++i) h[i] = (double)w2c_host_f32[i];
-    double *d = p->pose_dev[(k - 1) & 1u];
-    if (F) HIP_TRY(hipMemcpyAsync(d, h, (size_t)F * 16 * sizeof(double), hipMemcpyHostToDevice, p->s_bin));
+    const int slot = (int)((k - 1) & 1u);
+    double *d = p->pose_dev[slot];
+    // after a planned launch the next one is expected to be planned too: its poses go up on the pre-pass stream, behind the
+    // chain that last read this slot's pose buffer (launch k - 2); cama_pipeline_render* orders whichever stream it did
+    // not go up on behind the copy
+    p->poses_on_pre = p->prev_planned;
+    p->poses_for = k;
+    if (p->poses_on_pre && k > 2) HIP_TRY(hipStreamWaitEvent(p->s_pre, p->binned[slot], 0));
+    if (F) HIP_TRY(hipMemcpyAsync(d, h, (size_t)F * 16 * sizeof(double), hipMemcpyHostToDevice, p->poses_on_pre ? p->s_pre : p->s_bin));
     *w2c_dev = d;
     return CAMA_OK;
 }
@@ -1764,10 +1782,19 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
         sc.plan = p->own_plan[slot];
         sc.plan_bytes = p->own_plan_bytes[slot];
         if (plannable) {
-            // the pre-pass only writes the plan part, which the overlay of launch k - 2 never reads: it need not wait for it
+            // the pre-pass only writes the plan part, which the overlay of launch k - 2 never reads: it need not wait for it --
+            // only for that launch's binning chain (`binned`), which read the plan part and the pose buffer of this slot.  It
+            // runs on its own stream: behind the previous launch's projection + scatter on s_bin the host wait below was
+            // ~0.3 ms instead of ~0.1 ms, and the binning streams's cycle -- not the overlay -- set the pace (sites3x12)
+            hipStream_t sp = p->s_pre;
+            if (k > 2) HIP_TRY(hipStreamWaitEvent(sp, p->binned[slot], 0));
             HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
-            HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
-            if (int rc = bin_prepass(call, L, sc.plan, p->s_bin)) return rc;
+            HIP_TRY(hipStreamWaitEvent(sp, p->ready, 0));
+            if (p->poses_for == k && !p->poses_on_pre) {           // the poses went up on s_bin
+                HIP_TRY(hipEventRecord(p->staged, p->s_bin));
+                HIP_TRY(hipStreamWaitEvent(sp, p->staged, 0));
+            }
+            if (int rc = bin_prepass(call, L, sc.plan, sp)) return rc;
             const size_t words = 1 + (size_t)F;
             if (words > p->demand_cap) {
                 if (p->demand_host) (void)hipHostFree(p->demand_host);
@@ -1776,9 +1803,9 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
                 HIP_TRY(hipHostMalloc((void **)&p->demand_host, std::max(words, (size_t)1024) * 8, hipHostMallocDefault));
                 p->demand_cap = std::max(words, (size_t)1024);
             }
-            HIP_TRY(hipMemcpyAsync(p->demand_host, sc.plan + L.demand, 8, hipMemcpyDeviceToHost, p->s_bin));
-            HIP_TRY(hipMemcpyAsync(p->demand_host + 1, sc.plan + L.frame_items, (size_t)F * 4, hipMemcpyDeviceToHost, p->s_bin));
-            HIP_TRY(hipStreamSynchronize(p->s_bin));
+            HIP_TRY(hipMemcpyAsync(p->demand_host, sc.plan + L.demand, 8, hipMemcpyDeviceToHost, sp));
+            HIP_TRY(hipMemcpyAsync(p->demand_host + 1, sc.plan + L.frame_items, (size_t)F * 4, hipMemcpyDeviceToHost, sp));
+            HIP_TRY(hipStreamSynchronize(sp));               // (everything s_pre did is complete: s_bin needs no event for it)
             const uint32_t *per_frame = (const uint32_t *)(p->demand_host + 1);
             uint32_t most = 0;
             for (int f = 0; f < F; ++f) most = std::max(most, per_frame[f]);
@@ -1804,7 +1831,12 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
     if (!prepass_done) {
         HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
         HIP_TRY(hipStreamWaitEvent(p->s_bin, p->ready, 0));
+        if (p->poses_for == k && p->poses_on_pre) {               // the poses went up on s_pre (the previous launch was planned)
+            HIP_TRY(hipEventRecord(p->staged, p->s_pre));
+            HIP_TRY(hipStreamWaitEvent(p->s_bin, p->staged, 0));
+        }
     }
+    p->prev_planned = prepass_done;
     if (k > 2) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->done[(k - 2) % RING], 0));   // the overlay that read this slot
     if (F > 0) {
         if (!prepass_done)
@@ -1850,7 +1882,9 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
     // (pipeline_host_wait: the wait happens here instead -- hipStreamWaitEvent on a complete event queues nothing, so the
     // overlay goes into its queue directly behind the previous one)
     const int64_t host_wait = option(OPT_HOST_WAIT);
-    if (host_wait > 0 || (host_wait < 0 && (size_t)F * C * H * W * 6 >= ((size_t)1 << 30)))
+    // (not for a planned launch: its call already waited for the cull on the host, and waiting for the rest of the chain as
+    // well would start the NEXT launch's cull ~0.3 ms later than the GPU could -- sites3x12: 94 k -> 89 k frames/s)
+    if (host_wait > 0 || (host_wait < 0 && !prepass_done && !segments && (size_t)F * C * H * W * 6 >= ((size_t)1 << 30)))
         HIP_TRY(hipEventSynchronize(p->binned[slot]));
     HIP_TRY(hipStreamWaitEvent(so, p->binned[slot], 0));
     g_overlay_stop_event = (overlay_takes_stop_event && ext_events()) ? p->done[k % RING] : nullptr;

@@ -502,6 +502,25 @@ class Engine:
         finally:
             L.cama_set_option(b"overlay_chunk_log2", prev.value)
 
+    def settle_mapping(self, rig, src, out, cols=3):
+        """Let the library finish choosing the workgroup -> band order for the pair (src, out) NOW -- it times both orders
+        on the first six big launches over a pair (MapTuner, cama_hip.hip) -- with stamp-free launches, so that none of the
+        caller's own launches over this pair is a trial.  No-op for launches below the tuner's 1.75 GiB."""
+        torch = _torch()
+        F = int(src.shape[0])
+        if 6 * F * rig.C * rig.H * rig.W < (7 << 28) or rig.W % 16 or self.alpha256 != 256:
+            return
+        L = self.lib
+        self._overlay_ms(rig, src, out, cols, 1)                    # (makes sure the stamp-free scratch for F frames exists)
+        scratch = self._audition_scratch[(F, rig.C, rig.H, rig.W)][0]
+        for _ in range(4 * 3 + 1):
+            _lib.check(L.cama_overlay_frames(src.data_ptr(), out.data_ptr(), 0, F, rig.C, rig.H, rig.W, cols, self.radius,
+                                             self.halfwidth.ctypes.data, self.palette.ctypes.data, scratch.data_ptr(),
+                                             scratch.numel(), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+            if self.overlay_mapping()["decided"] >= 0:
+                break
+
     def alloc_mosaic(self, rig, src, cols=3, candidates=None, reps=3):
         """A mosaic buffer [F, rows*H, cols*W, 3] for frames `src` [F,C,H,W,3] that is going to be rendered into MANY times
         (a service's output ring, bench.py's output buffer) -- chosen among `candidates` fresh allocations by timing the
@@ -534,6 +553,8 @@ class Engine:
                     best, best_ms = cand, ms
             self.__dict__.setdefault("audition_log", []).append(
                 {"role": "mosaic", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4)})
+            del pool, cand
+            self.settle_mapping(rig, src, best, cols)
             return best
 
     def alloc_mosaics(self, rig, srcs, cols=3, pool=None, reps=3):
@@ -567,6 +588,8 @@ class Engine:
                  "chosen_ms": round(float(np.mean([times[i] for i in keep])), 4), "kept": n})
             del cands
             torch.cuda.empty_cache()                                   # the losers go back to the driver, not to torch's cache
+            for s, c in zip(srcs, chunks):
+                self.settle_mapping(rig, s, c, cols)
             return ChunkedMosaic(chunks)
 
     def place_frames(self, rig, frames, out, first=0, cols=3, candidates=None, reps=3):
@@ -595,6 +618,8 @@ class Engine:
                     best, best_ms = cand, ms
             if best is not frames:
                 best.copy_(frames)
+                del pool
+                self.settle_mapping(rig, view(best), out, cols)
             self.__dict__.setdefault("audition_log", []).append(
                 {"role": "frames", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4)})
             return best
