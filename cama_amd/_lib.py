@@ -10,7 +10,7 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 17
+ABI_VERSION = 18
 BIN_WORKLIST = 1
 BIN_SEGMENTS = 2            # EXTENSION: discs + one-pixel segments between polyline neighbours (include/cama_hip.h)
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "cama_stream_create_masked": (_i32, [_i32, _vp]),
     "cama_stream_destroy": (_i32, [_vp]),
     "cama_overlay_mapping_info": (_i32, [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(ctypes.c_double)]),
+    "cama_overlay_probe": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, ctypes.POINTER(ctypes.c_double), _vp]),
     "cama_set_option": (_i32, [ctypes.c_char_p, _i64]),
     "cama_get_option": (_i32, [ctypes.c_char_p, ctypes.POINTER(_i64)]),
     "cama_stamp_polylines": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -729,6 +729,7 @@ int cama_map_bounds(const void *x, const void *y, const void *z, int32_t xyz_is_
 // stream.  Set by cama_pipeline_render, consumed (and cleared) by the launch.
 thread_local bool g_skip_bin_memset = false;   // (hipGraph experiment only: the clear is issued outside the captured chain)
 thread_local hipEvent_t g_overlay_stop_event = nullptr;
+thread_local bool g_overlay_probe = false;     // the next plain overlay launch is cama_overlay_probe's: k_overlay_probe, contiguous order
 thread_local hipEvent_t g_scatter_stop_event = nullptr;
 static bool ext_events()
 {
@@ -1122,7 +1123,12 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     // one of them (MapTuner); a launch that is being profiled, or that cannot carry events of its own, just follows
     const bool plain_vec = !raw && o.pal.alpha256 == 256u && vec;
     MapTrial trial{o.chunk_log2, nullptr, nullptr, 0, 0};
-    if (launch_bytes >= MAP_BIG_LAUNCH && overlay_forced_chunk_log2() < 0 && plain_vec) {
+    const bool probe = g_overlay_probe;
+    g_overlay_probe = false;
+    if (probe) {
+        if (!plain_vec || scenes_dev) return fail(CAMA_EINVAL, "cama_overlay_probe needs W %% 16 == 0 and 16-byte aligned buffers");
+        o.chunk_log2 = MAP_CONTIGUOUS;
+    } else if (launch_bytes >= MAP_BIG_LAUNCH && overlay_forced_chunk_log2() < 0 && plain_vec) {
         trial = g_map_tuner.pick(scenes_dev ? (const void *)scenes_host[0].src : (const void *)src,
                                  scenes_dev ? (const void *)scenes_host[0].mosaic : (const void *)mosaic, launch_bytes,
                                  !g_prof.on);
@@ -1215,6 +1221,10 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
         if (trial.e0 && S > 1) g_map_tuner.submitted(trial, (double)launch_bytes);
         else if (trial.e0) g_map_tuner.abandon(trial);
         if (!(exact_timing && ev0 && ev1)) g_overlay_stop_event = nullptr;
+    } else if (vec && probe) {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_overlay_probe, ogrid, dim3(OVERLAY_BLOCK), lds, s, o);
     } else if (vec) {
         if (trial.e0) {
             // a mapping trial: the launch carries the tuner's start / stop events; the pipeline's completion event, which
@@ -1261,6 +1271,53 @@ int cama_overlay_frames_alpha(const uint8_t *src, uint8_t *mosaic, int64_t N, in
                                 legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius), stream);
     g_next_alpha256 = 256u;
     return rc;
+}
+
+// Mean duration of `reps` stamp-free overlay launches src -> mosaic (XCD-contiguous order), after one untimed launch; blocks.
+int cama_overlay_probe(const uint8_t *src, uint8_t *mosaic, int32_t F, int32_t C, int32_t H, int32_t W, int32_t cols,
+                       int32_t reps, double *ms_mean, void *stream)
+{
+    if (!src || !mosaic || !ms_mean) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (F < 1 || reps < 1 || reps > 1000) return fail(CAMA_EINVAL, "F=%d reps=%d", F, reps);
+    if (int rc = check_common(0, F, C, W, H)) return rc;
+    constexpr int radius = 2;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sb = cama_render_scratch_bytes(0, F, C, H, W, radius);
+    const size_t mats = align_up((size_t)F * 128 + (size_t)C * 200, 256);
+    char *buf = nullptr;
+    HIP_TRY(hipMalloc((void **)&buf, sb + mats));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = CAMA_OK;
+    const auto done = [&](int r) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipFree(buf);
+        return r;
+    };
+    if (hipMemsetAsync(buf + sb, 0, mats, s) != hipSuccess) return done(fail(CAMA_EHIP, "hipMemsetAsync failed"));
+    const double *w2c = (const double *)(buf + sb), *c2cam = w2c + (size_t)F * 16, *K = c2cam + (size_t)C * 16;
+    const double crop[6] = {-1, 1, -1, 1, -1, 1};
+    rc = bin_impl(nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, w2c, F, c2cam, K, C, crop, W, H, radius,
+                  buf, sb, stream);                                  // an empty map: every band's stamp count is zero
+    if (rc) return done(rc);
+    int32_t hw[CAMA_MAX_RADIUS + 1];
+    cama_circle_halfwidths(radius, hw);
+    const uint8_t pal[6] = {0, 0, 0, 0, 0, 0};
+    const ScratchRef sc = legacy_scratch(buf, sb, 0, F, C, H, W, radius);
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(fail(CAMA_EHIP, "hipEventCreate failed"));
+    for (int k = 0; k <= reps && !rc; ++k) {
+        if (k == 1 && hipEventRecord(e0, s) != hipSuccess) rc = fail(CAMA_EHIP, "hipEventRecord failed");
+        g_overlay_probe = true;
+        if (!rc) rc = overlay_impl(src, nullptr, mosaic, 0, F, C, H, W, cols, radius, hw, pal, sc, stream);
+        g_overlay_probe = false;
+    }
+    if (rc) { (void)hipStreamSynchronize(s); return done(rc); }
+    float ms = 0.f;
+    if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+        hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+        return done(fail(CAMA_EHIP, "timing the probe launches failed: %s", hipGetErrorString(hipGetLastError())));
+    *ms_mean = (double)ms / reps;
+    return done(CAMA_OK);
 }
 
 int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const float *mapx, const float *mapy,

@@ -487,6 +487,16 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 }
 
 
+// The plain overlay under its own name, for cama_overlay_probe (timing candidate allocations of long-lived buffers): the same
+// body, but a workload's rocprofv3 --stats keeps the probe launches apart from k_overlay's.
+__global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay_probe(OverlayArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];
+    const BandId id = decode_band(a, a.items, 1u, 0u);
+    if (id.valid) overlay_band_at<true, false, false, false>(a, id.fl, (uint32_t)a.f0, id.c, id.b, s_owner);
+    tlb_lookahead<false>(a);
+}
+
 // Raw-frame overlay, LDS-staged (separable maps = zero lens distortion, the nuScenes / CAMA calibration):
 // the source rows a band of R destination rows needs (host-precomputed [first, count] per camera and band) are
 // streamed into LDS once with 16-byte loads -- the only global reads of image data -- and every bilinear tap is an

@@ -465,42 +465,13 @@ class Engine:
 
     # ------------------------------------------------------------------ placement-aware allocation of long-lived buffers
     def _overlay_ms(self, rig, src, out, cols, reps):
-        """Mean duration (ms) of `reps` stamp-free overlay launches src -> out in the XCD-contiguous order (torch events on
-        the current stream; blocks)."""
+        """Mean duration (ms) of `reps` stamp-free overlay launches src -> out in the XCD-contiguous order
+        (cama_overlay_probe: its own kernel name, not through the mapping table; blocks)."""
         import ctypes
-        torch = _torch()
-        F = int(src.shape[0])
-        L = self.lib
-        need = int(L.cama_render_scratch_bytes(0, F, rig.C, rig.H, rig.W, self.radius))
-        memo = self.__dict__.setdefault("_audition_scratch", {})
-        key = (F, rig.C, rig.H, rig.W)
-        if key not in memo:
-            scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
-            w2c = torch.zeros((F, 16), dtype=torch.float64, device=self.device)
-            _lib.check(L.cama_bin_frames(None, None, None, 0, None, None, None, 0, 0, w2c.data_ptr(), F, rig.c2cam.data_ptr(),
-                                         rig.K.data_ptr(), rig.C, self.crop.ctypes.data, rig.W, rig.H, self.radius,
-                                         scratch.data_ptr(), scratch.numel(), self._stream()))
-            memo.clear()
-            memo[key] = (scratch, w2c)
-        scratch = memo[key][0]
-        prev = ctypes.c_int64(-1)
-        _lib.check(L.cama_get_option(b"overlay_chunk_log2", ctypes.byref(prev)))
-        _lib.check(L.cama_set_option(b"overlay_chunk_log2", 31))
-        try:
-            def launch():
-                _lib.check(L.cama_overlay_frames(src.data_ptr(), out.data_ptr(), 0, F, rig.C, rig.H, rig.W, cols, self.radius,
-                                                 self.halfwidth.ctypes.data, self.palette.ctypes.data, scratch.data_ptr(),
-                                                 scratch.numel(), self._stream()))
-            launch()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                launch()
-            e1.record()
-            e1.synchronize()
-            return e0.elapsed_time(e1) / reps
-        finally:
-            L.cama_set_option(b"overlay_chunk_log2", prev.value)
+        ms = ctypes.c_double(0.0)
+        _lib.check(self.lib.cama_overlay_probe(src.data_ptr(), out.data_ptr(), int(src.shape[0]), rig.C, rig.H, rig.W, cols,
+                                               reps, ctypes.byref(ms), self._stream()))
+        return ms.value
 
     def settle_mapping(self, rig, src, out, cols=3):
         """Let the library finish choosing the workgroup -> band order for the pair (src, out) NOW -- it times both orders
@@ -511,8 +482,12 @@ class Engine:
         if 6 * F * rig.C * rig.H * rig.W < (7 << 28) or rig.W % 16 or self.alpha256 != 256:
             return
         L = self.lib
-        self._overlay_ms(rig, src, out, cols, 1)                    # (makes sure the stamp-free scratch for F frames exists)
-        scratch = self._audition_scratch[(F, rig.C, rig.H, rig.W)][0]
+        need = int(L.cama_render_scratch_bytes(0, F, rig.C, rig.H, rig.W, self.radius))
+        scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        w2c = torch.zeros((F, 16), dtype=torch.float64, device=self.device)
+        _lib.check(L.cama_bin_frames(None, None, None, 0, None, None, None, 0, 0, w2c.data_ptr(), F, rig.c2cam.data_ptr(),
+                                     rig.K.data_ptr(), rig.C, self.crop.ctypes.data, rig.W, rig.H, self.radius,
+                                     scratch.data_ptr(), scratch.numel(), self._stream()))
         for _ in range(4 * 3 + 1):
             _lib.check(L.cama_overlay_frames(src.data_ptr(), out.data_ptr(), 0, F, rig.C, rig.H, rig.W, cols, self.radius,
                                              self.halfwidth.ctypes.data, self.palette.ctypes.data, scratch.data_ptr(),

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 17
+#define CAMA_ABI_VERSION 18
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -393,6 +393,18 @@ int cama_stream_destroy(void *stream);
  * ns_per_mb[2]: timings taken so far and their median time per 10^6 bytes, [0] = contiguous, [1] = chunked.  Any pointer
  * may be NULL.  (No reference counterpart.) */
 int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per_mb);
+
+/* How fast does the overlay run from `src` [F,C,H,W,3] into `mosaic` [F, rows*H, cols*W, 3] -- as a pure copy (no stamps), in
+ * the XCD-contiguous order?  One untimed launch, then `reps` timed ones on `stream`; *ms_mean = their mean duration; blocks
+ * until they are done; the mosaic ends up holding the plain mosaic of the frames.  For CHOOSING BUFFERS: the overlay's
+ * bandwidth depends on where its source and destination sit physically relative to each other (about one destination
+ * allocation in six runs at 0.83 of 8 TB/s, the others at 0.77, the same every time: profiles/r04_overlay_modes.txt section 5),
+ * so a caller that keeps a mosaic (or frame) buffer for many launches allocates a few candidates, probes each and keeps the
+ * fastest (cama_amd/engine.py: Engine.alloc_mosaic / alloc_mosaics / place_frames).  The launches run under their own kernel
+ * name (k_overlay_probe: the same code) so that a workload's kernel statistics keep them apart, and do not go through the
+ * mapping table above.  W % 16 == 0 and 16-byte aligned buffers (CAMA_EINVAL otherwise).  (No reference counterpart.) */
+int cama_overlay_probe(const uint8_t *src /* device */, uint8_t *mosaic /* device */, int32_t F, int32_t C, int32_t H, int32_t W,
+                       int32_t cols, int32_t reps, double *ms_mean /* host */, void *stream);
 
 /* Process-wide tuning options: performance only -- no option can change a result (every one of them selects among orders /
  * schedules that are bijections over the same work; the parity suite runs with each forced).  An option starts from its

@@ -456,6 +456,17 @@ def test_placed_buffers_render_the_same_bytes(monkeypatch):
     want = shard.overlay_hash(plain)
     before = ctypes.c_int64(-7)
     _lib.check(eng.lib.cama_get_option(b"overlay_chunk_log2", ctypes.byref(before)))
+    # the probe itself: a pure mosaic copy under its own kernel name, a time, and an error for what it cannot take
+    probe_out = torch.empty_like(plain)
+    ms = ctypes.c_double(0.0)
+    _lib.check(eng.lib.cama_overlay_probe(frames[1:].data_ptr(), probe_out.data_ptr(), a.frames, rig.C, rig.H, rig.W, 3, 2,
+                                          ctypes.byref(ms), eng._stream()))
+    assert 0.05 < ms.value < 50.0
+    want_copy = frames[1:1 + a.frames].reshape(a.frames, 2, 3, rig.H, rig.W, 3).permute(0, 1, 3, 2, 4, 5).reshape(plain.shape)
+    assert torch.equal(probe_out, want_copy)
+    assert eng.lib.cama_overlay_probe(frames[1:].data_ptr(), probe_out.data_ptr(), 1, rig.C, rig.H, 1592, 3, 1,
+                                      ctypes.byref(ms), eng._stream()) != 0
+    del probe_out, want_copy
     out = eng.alloc_mosaic(rig, frames[1:1 + a.frames], candidates=4)
     log = eng.audition_log[-1]
     assert log["role"] == "mosaic" and log["candidates"] == 4 and len(log["ms"]) == 4 and log["chosen_ms"] == min(log["ms"])
