@@ -431,6 +431,8 @@ class Job:
         sid, cm, frames, clip = self.scenes[k]
         rig = cm._rig()
         K = getattr(self.args, "audition", None)
+        if os.environ.get("CAMA_BENCH_SHARE_GPU") == "1":               # ranks sharing one GPU (tests): no transient candidates
+            K = 0
         if getattr(self.args, "raw_frames", False) or K == 0:
             return torch.empty(self.eng.mosaic_shape(rig, self.F), dtype=torch.uint8, device=self.device)
         first = 1 if self.frame_range is None else 0                    # image index 0 is never rendered
@@ -724,6 +726,10 @@ def plan(args):
                "mosaic_bytes": mosaics, "map_bytes": maps, "frames_per_launch": fpl,
                "scratch_worst_case_one_slot": worst, "scratch_held": held}
         total = frames_res + mosaics + maps + held
+        # before the timed region: candidate allocations of one mosaic / frames buffer at a time (Engine.alloc_mosaic, capped by
+        # the engine at half of what is free, so it cannot be what does not fit)
+        one = min(F, fpl) * frame_b if ranges[r] is not None else F * frame_b
+        rec["placement_transient_bytes"] = 0 if (args.audition == 0 or args.raw_frames) else (args.audition or 16) * one
         if do_stress:                                               # runs after the sweep's buffers are freed
             slo, shi = shard.frame_ranges(args.stress_frames, world)[r]
             sF = shi - slo

@@ -187,8 +187,8 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
  * back: cama_pipeline_render enqueues cama_bin_frames on an internal stream and cama_overlay_frames on another, so the
  * binning of batch k+1 overlaps the HBM-bound overlay of batch k; scratch0 / scratch1 (each >=
  * cama_render_scratch_bytes) are used alternately.  Inputs must be complete on `input_stream` when the call is made;
- * outputs are complete after cama_pipeline_join(p, stream) in `stream`'s order.  The context owns two HIP streams, a
- * ring of 64 completion events (device-scope release, no timing), its staged-pose buffers and -- see below -- optionally
+ * outputs are complete after cama_pipeline_join(p, stream) in `stream`'s order.  The context owns three HIP streams (binning,
+ * overlay, and one for the cull pre-pass + pose upload of planned launches, below), a ring of 64 completion events (device-scope release, no timing), its staged-pose buffers and -- see below -- optionally
  * its scratch.  One context per thread.
  *
  * Pipeline-owned, demand-sized scratch (round 4): pass scratch0 == scratch1 == NULL (scratch_bytes ignored) to any
@@ -199,9 +199,12 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
  * through the candidate pre-pass (block_bounds + CAMA_BIN_WORKLIST) it runs that pre-pass first, waits on the host for two
  * figures it leaves behind -- the surviving blocks of the busiest frame and the (wave, camera) projection chains of all
  * surviving blocks, an exact upper bound of what the projection can emit -- and sizes the stamp part from them (grow-only,
- * hipMalloc inside the call when it has to grow); other launches get the worst case.  That wait is a few tens of
- * microseconds behind the previous launch's binning chain and is hidden by the overlays already queued; it makes such a
- * call synchronous with the binning stream, not with the overlays.  cama_pipeline_info / cama_pipeline_bin_stats /
+ * hipMalloc inside the call when it has to grow); other launches get the worst case.  The pre-pass runs on the context's
+ * third stream, beside the previous launch's projection and scatter (queued behind them it made the wait ~0.3 ms and the
+ * binning stream, not the overlay, set the pace: 94 k -> 105 k frames/s on 12 scenes over three 10^6-vertex site maps); the
+ * wait is ~0.1 ms, hidden by the overlays already queued; it makes such a call synchronous with the pre-pass, not with the
+ * overlays.  An unplanned launch that moves >= 1 GiB waits on the host for its whole binning chain instead of queueing a
+ * stream-side wait in front of its overlay (option pipeline_host_wait, below).  cama_pipeline_info / cama_pipeline_bin_stats /
  * cama_pipeline_guard_check below report on it.
  *
  * Lifetime of what a launch reads and writes: the internal streams are invisible to the caller's allocator, so every
