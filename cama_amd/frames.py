@@ -396,7 +396,14 @@ class ClipFrameSource:
                 self._submit_batch(ahead)
             items = self._batch_reads.pop(key).result()
             if all(is_blob(arr) for _, _, arr, _ in items):
-                return self._decoder().decode_async([arr for _, _, arr, _ in items], bgr=True)
+                # on a stream of the pump's own: the decoder orders its lanes behind the CALLER's current stream, and the
+                # device's default stream is where the consumer thread queues its renders and the 150 MB downloads of
+                # its mosaics -- every decode used to start behind whatever of those was queued (round 4: the loop ran
+                # at decode + download, not at the larger of the two)
+                if getattr(self, "_pump_stream", None) is None:
+                    self._pump_stream = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(self._pump_stream):
+                    return self._decoder().decode_async([arr for _, _, arr, _ in items], bgr=True)
             return items                           # .npy twins / mixed sources: the consumer finishes them
 
     def close(self):

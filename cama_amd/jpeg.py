@@ -693,6 +693,9 @@ class PendingDecode:
                 if tuple(arr.shape[:2]) != tuple(out.shape[1:3]):
                     raise ValueError(f"image {i} is {arr.shape[1]}x{arr.shape[0]}, the batch is {out.shape[2]}x{out.shape[1]}")
                 out[i].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+            # `out` may have been allocated under another stream than the consumer's (the decode pump's own): the allocator
+            # must not hand the block out again while the consumer's stream still reads it
+            out.record_stream(cur)
         self._done = True
         self.blobs = self.tickets = None
         return out

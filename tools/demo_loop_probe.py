@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--frames", type=int, default=240)
     ap.add_argument("--content", choices=["noise", "photo"], default="photo")
     ap.add_argument("--passes", type=int, default=6, help="passes over the clip: the first is one-off setup, the rest steady state")
+    ap.add_argument("--sweep", default="", help="NAME=v1,v2,...: repeat the steady-state measurement on the same clip with the "
+                                                "environment variable NAME set to each value (a fresh ClipManager each)")
     args = ap.parse_args()
     import torch
     from cama.dataset import ClipManager
@@ -31,6 +33,18 @@ def main():
               image_mode="jpg" if args.content == "noise" else "jpg_photo", image_size=(900, 1600), with_nuscenes=False,
               extra_labels=False)
     print(f"clip with {6 * (args.frames + 1)} JPEGs written in {time.perf_counter() - t:.1f} s")
+    settings = [None]
+    if args.sweep:
+        name, vals = args.sweep.split("=")
+        settings = [(name, v) for v in vals.split(",")]
+    for setting in settings:
+        if setting is not None:
+            os.environ[setting[0]] = setting[1]
+            print(f"## {setting[0]}={setting[1]}")
+        run_passes(args, root, clip, ClipManager, VideoGenerator, DEFAULT_CAMA_CONFIGS, torch)
+
+
+def run_passes(args, root, clip, ClipManager, VideoGenerator, DEFAULT_CAMA_CONFIGS, torch):
     cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)          # reference default output size (540, 960)
     rates = []
     for label in ["first pass (one-off setup)"] + ["steady state"] * (args.passes - 1):

@@ -49,6 +49,7 @@ class Clock:
         import threading
         self.t = collections.OrderedDict()
         self.n = collections.Counter()
+        self.events = []
         self.local = threading.local()
         self.main = threading.get_ident()
 
@@ -69,6 +70,7 @@ class Clock:
                 inner = stack.pop()
                 clock.t[lab] = clock.t.get(lab, 0.0) + dt - inner          # exclusive time
                 clock.n[lab] += 1
+                clock.events.append((t0, t0 + dt, lab))
                 if stack:
                     stack[-1] += dt
         setattr(obj, name, timed)
@@ -79,6 +81,7 @@ def main():
     ap.add_argument("--frames", type=int, default=240)
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--render-ahead", type=int, default=16)
+    ap.add_argument("--events", action="store_true", help="print the instrumented pass as a timeline of calls")
     ap.add_argument("--no-egress", action="store_true", help="A/B: no VideoGenerator (no I420 conversion, no download)")
     args = ap.parse_args()
     import torch
@@ -125,6 +128,9 @@ def main():
     ck.wrap(frames.ClipFrameSource, "_submit_batch", "queue a batch's file reads")
     ck.wrap(jpeg.DeviceJpegDecoder, "decode_async", "submit device JPEG decode (parse + upload + launches)")
     ck.wrap(jpeg.DeviceJpegDecoder, "decode", "device JPEG decode, synchronous path")
+    ck.wrap(frames.ClipFrameSource, "_pump_step", "pump step (exclusive: waiting for the batch's file reads)")
+    ck.wrap(jpeg.DeviceJpegDecoder, "_submit", "decode group submit (pack + upload + launches)")
+    ck.wrap(jpeg.PendingDecode, "result", "PendingDecode.result: wait for the GPU decode of a batch")
     ck.wrap(frames.ClipFrameSource, "raw_batch", "raw_batch: wait for a decoded batch + bookkeeping")
     ck.wrap(ClipManager, "_render_batch", "issue render (cama_render_frames / raw overlay)")
     ck.wrap(egress.RenderBatch, "start_egress", "issue egress (BGR->I420 + async download)")
@@ -143,6 +149,11 @@ def main():
             acc += sec
         print(f"  {sec * 1e3:8.2f} ms  {100 * sec / total:5.1f} %  x{ck.n[label]:<5d} {label}")
     print(f"  {(total - acc) * 1e3:8.2f} ms  {100 * (total - acc) / total:5.1f} %         loop Python (yield_frame, handles, tqdm, concate_image)")
+    if args.events:
+        print("timeline of the instrumented pass (ms from its start; begin..end label), calls of >= 0.15 ms:")
+        for a, b, lab in sorted(ck.events):
+            if b - a >= 0.15e-3 and "bookkeeping" not in lab[:16]:
+                print(f"  {(a - t0) * 1e3:7.2f} .. {(b - t0) * 1e3:7.2f}  {lab[:70]}")
 
 
 if __name__ == "__main__":
