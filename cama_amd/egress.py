@@ -71,11 +71,11 @@ _EGRESS_STREAMS = {}
 
 def egress_stream(engine):
     """A/B knob (CAMA_EGRESS_CUS=n > 0): run the batches' downloads on a stream whose kernels are confined to n compute
-    units spread over the chip (cama_stream_create_masked).  The runtime performs device -> pinned-host copies with blit
-    kernels (__amd_rocclr_copyBuffer: 41 ms of kernel time per 240-frame bgr24 pass, on the render stream), and the main.py
-    loop waits for the JPEG decoder 83 % of the time -- so the copies were confined to 8 / 16 / 32 / 64 CUs to leave the
-    decoder its wave slots.  Measured (profiles/r04_demo_loop_timeline.txt): SLOWER, bgr24 3.07 k -> 2.39-2.48 k frames/s,
-    I420 3.87 k -> 3.40-3.68 k: a confined blit kernel no longer fills the PCIe link.  Default 0 = the render stream."""
+    units spread over the chip (cama_stream_create_masked).  Built when a trace showed the downloads as blit kernels
+    (__amd_rocclr_copyBuffer, 41 ms per 240-frame bgr24 pass) next to the JPEG decoder; measured SLOWER (bgr24 3.07 k ->
+    2.39-2.48 k frames/s) -- and the premise was an artefact: torch's bundled HIP runtime copies device -> pinned memory with
+    blit kernels only while rocprofv3 is attached, by SDMA otherwise (profiles/r04_demo_loop_timeline.txt, CORRECTION).
+    Default 0 = the render stream."""
     import ctypes
     import os
     n = int(os.environ.get("CAMA_EGRESS_CUS", "0"))

@@ -380,9 +380,10 @@ int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const fl
 int cama_probe_xcd_map(uint32_t *xcd_of_block, int32_t n_blocks, void *stream);
 
 /* A HIP stream (returned as void*) whose kernels are confined to n_cus compute units spread evenly over the chip
- * (hipExtStreamCreateWithCUMask).  Used by the host side for the egress of VideoGenerator's frames (cama/tools.py:27-32): the
- * runtime copies device -> pinned host memory with blit kernels, and confined to a few CUs those stop taking wave slots from
- * the JPEG decoder.  The caller owns the stream.  (No reference counterpart.) */
+ * (hipExtStreamCreateWithCUMask).  An A/B knob of the host side's egress (CAMA_EGRESS_CUS, default off): it was built to
+ * confine the blit kernels a trace showed the runtime copying device -> pinned host memory with -- which it only does while
+ * a profiler is attached (SDMA otherwise), and confined they were slower anyway.  The caller owns the stream.  (No reference
+ * counterpart.) */
 int cama_stream_create_masked(int32_t n_cus, void **stream /* host */);
 int cama_stream_destroy(void *stream);
 
