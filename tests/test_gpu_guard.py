@@ -255,3 +255,43 @@ def _planned_launches(eng):
     want = torch.cat([torch.cat([src[:, c] for c in range(r * 3, r * 3 + 3)], dim=2) for r in range(2)], dim=1)
     assert torch.equal(out, want)
     assert eng.pipeline_info()["last_plan_capacity"] >= 1
+
+
+def test_planned_and_unplanned_launches_interleaved_without_joins(monkeypatch):
+    """Round 4: the cull pre-pass and the pose upload of PLANNED launches run on the pipeline's third stream, ordered by
+    events behind the chain that last used the slot; whether a launch's staged poses went up on that stream or on the
+    binning stream depends on what the PREVIOUS launch was.  Twenty launches back to back on one pipeline -- planned (site map)
+    and unplanned (dense map) in every order of succession, staged host poses, different frame counts, no join in between --
+    must each equal their plain single-stream render."""
+    import torch
+    from cama_amd import engine as E
+    monkeypatch.setattr(E, "BOUNDS_MIN_VERTS", 1)
+    eng = E.Engine("cuda:0")
+    assert eng.lib.cama_set_option(b"cull_list_min", 1) == 0
+    try:
+        N, W, H = 60000, 320, 180
+        scenes = []
+        for tag, F, spread, seed in (("site", 9, 300.0, 11), ("dense", 5, 40.0, 12), ("site2", 14, 300.0, 13), ("dense2", 3, 40.0, 14)):
+            xyz, col, cams, w2c = _scene(seed, N, F, W, H, spread)
+            rig = eng.make_rig([c["name"] for c in cams], [c["chassis2camera"] for c in cams], [c["K"] for c in cams], W, H)
+            dmap = eng.upload_map(xyz, col)
+            src = torch.randint(0, 256, (F, 6, H, W, 3), dtype=torch.uint8, device="cuda")
+            want = eng.render_frames(dmap, rig, w2c, src).clone()
+            scenes.append((tag, dmap, rig, np.asarray(w2c, np.float32), src, want))
+        torch.cuda.synchronize()
+        before = eng.pipeline_info()["planned_launches"] if getattr(eng, "_pipe", None) else 0
+        order = [0, 0, 1, 1, 0, 2, 1, 3, 2, 2, 3, 0, 3, 1, 2, 0, 1, 0, 3, 2]      # planned->planned, ->unplanned, and back
+        outs = []
+        for k in order:
+            tag, dmap, rig, w2c, src, want = scenes[k]
+            out = torch.full_like(want, 0xA5)
+            eng.render_frames_pipelined(dmap, rig, w2c, src, out)
+            outs.append((k, out))
+        eng.join()
+        torch.cuda.synchronize()
+        for n, (k, out) in enumerate(outs):
+            assert torch.equal(out, scenes[k][5]), (n, scenes[k][0])
+        info = eng.pipeline_info()
+        assert info["planned_launches"] - before == sum(1 for k in order if k in (0, 2))
+    finally:
+        eng.lib.cama_set_option(b"cull_list_min", 16384)
