@@ -409,11 +409,14 @@ class Job:
         self.batched = False
         if self.scenes and self.F:
             rig = self.scenes[0][1]._rig()
-            self.out = self._alloc_out(0)                                 # shared by the scenes of per-scene launches
             # several whole scenes per rank: ONE multi-scene launch chain per step, every scene into its own mosaic
-            if (len(self.scenes) > 1 and frame_range is None and not getattr(args, "no_scene_batch", False)
-                    and not getattr(args, "raw_frames", False) and not _segments(args)):
-                self.outs = [self.out] + [self._alloc_out(k) for k in range(1, len(self.scenes))]
+            site_like = args.map in ("site", "random") and args.verts >= 65536     # (render_clips would decline: per-scene launches)
+            multi = (len(self.scenes) > 1 and frame_range is None and not getattr(args, "no_scene_batch", False)
+                     and not getattr(args, "raw_frames", False) and not _segments(args) and not site_like)
+            pooled = self._alloc_outs_pooled() if multi else None
+            self.out = pooled[0] if pooled else self._alloc_out(0)        # shared by the scenes of per-scene launches
+            if multi:
+                self.outs = pooled or ([self.out] + [self._alloc_out(k) for k in range(1, len(self.scenes))])
                 self.batched = self.step_batched()
                 self.eng.join()
                 if not self.batched:
@@ -448,6 +451,18 @@ class Job:
             cm.set_frame_source(DeviceFrameSource(placed, index_offset=src.index_offset))
             self.scenes[k] = (sid, cm, placed, clip)
         return out
+
+    def _alloc_outs_pooled(self):
+        """The mosaics of all scenes of a multi-scene launch chain as the fastest len(scenes) of ONE pool of candidate
+        allocations (Engine.alloc_mosaics): timing 16 candidates per scene, one scene after the other, would mostly re-time the
+        previous scene's losers -- the allocator hands them straight back."""
+        K = getattr(self.args, "audition", None)
+        if K == 0 or os.environ.get("CAMA_BENCH_SHARE_GPU") == "1" or os.environ.get("CAMA_AUDITION") == "0":
+            return None
+        rig = self.scenes[0][1]._rig()
+        first = 1 if self.frame_range is None else 0
+        srcs = [frames[first:first + self.F] for _, _, frames, _ in self.scenes]
+        return list(self.eng.alloc_mosaics(rig, srcs, pool=None if K is None else max(K // 4, 2) * len(srcs), settle=False).chunks)
 
     def step_batched(self):
         from cama_amd.dataset import render_clips

@@ -532,13 +532,16 @@ class Engine:
             self.settle_mapping(rig, src, best, cols)
             return best
 
-    def alloc_mosaics(self, rig, srcs, cols=3, pool=None, reps=3):
+    def alloc_mosaics(self, rig, srcs, cols=3, pool=None, reps=3, settle=True):
         """The same for a long clip rendered in several launches: `srcs` = the source view [F_k,C,H,W,3] of every launch;
         returns a ChunkedMosaic with one separately allocated buffer per launch.  A pool of `pool` allocations of the
         largest launch's size (default CAMA_AUDITION_POOL or 4 per launch, at most 3/4 of the free memory) is timed against
         the first launch's source -- a destination's speed is mostly its own (3.3 GB launches: 0.99 ms into one buffer in
         four to six, 1.07-1.085 ms into the others, whichever source) -- and the fastest len(srcs) are kept, the rest freed
-        to the driver.  pool = 0 / CAMA_AUDITION=0: plain allocations."""
+        to the driver.  pool = 0 / CAMA_AUDITION=0: plain allocations.  Also the way to place the mosaics of MANY scenes
+        (srcs = one per scene; use the result's .chunks): candidates timed one buffer at a time would mostly be the previous
+        buffer's losers, handed back by the allocator.  settle=False skips the per-pair order trials (multi-scene launches
+        are keyed differently)."""
         torch = _torch()
         n = len(srcs)
         Fmax = max(int(s.shape[0]) for s in srcs)
@@ -556,15 +559,16 @@ class Engine:
             cands = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(P)]
             times = [self._overlay_ms(rig, srcs[0], c[:F0], cols, reps) for c in cands]
             rank = sorted(range(P), key=lambda i: times[i])
-            keep = sorted(rank[:n])                                    # (in allocation order: nothing depends on it)
+            keep = rank[:n]                                            # fastest first
             chunks = [cands[i][:int(s.shape[0])] for i, s in zip(keep, srcs)]
             self.__dict__.setdefault("audition_log", []).append(
                 {"role": "mosaic", "bytes": nbytes, "candidates": P, "ms": [round(t, 4) for t in times],
                  "chosen_ms": round(float(np.mean([times[i] for i in keep])), 4), "kept": n})
             del cands
             torch.cuda.empty_cache()                                   # the losers go back to the driver, not to torch's cache
-            for s, c in zip(srcs, chunks):
-                self.settle_mapping(rig, s, c, cols)
+            if settle:
+                for s, c in zip(srcs, chunks):
+                    self.settle_mapping(rig, s, c, cols)
             return ChunkedMosaic(chunks)
 
     def place_frames(self, rig, frames, out, first=0, cols=3, candidates=None, reps=3):
