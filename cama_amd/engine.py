@@ -506,8 +506,10 @@ class Engine:
         0.312-0.326 ms for about one in six of them and 0.341-0.349 ms for the rest (0.85 against 0.77 of 8 TB/s), the same
         ones every time -- a DRAM-side read / write interference that no order of the kernel's accesses removes.  A caller
         who keeps the buffer can afford to look: `candidates` allocations (default CAMA_AUDITION, 16; 0 or a launch below
-        512 MiB: no audition, a plain allocation) stay alive together, each is timed with `reps` stamp-free launches, the fastest
-        is returned and the others go back to the allocator.  ~0.4 ms per candidate launch; speed only."""
+        512 MiB: no audition, a plain allocation) -- and as many again, up to twice, when all of them ran within 3 % of each
+        other (a sample of one kind) -- stay alive together, each is timed with `reps` stamp-free launches
+        (cama_overlay_probe), the fastest is returned and the others go back to the allocator.  ~0.4 ms per candidate
+        launch; speed only."""
         torch = _torch()
         F = int(src.shape[0])
         shape = self.mosaic_shape(rig, F, cols)
@@ -519,13 +521,20 @@ class Engine:
             free, _ = torch.cuda.mem_get_info(self.device)
             K = max(1, min(K, int(free // 2 // nbytes)))          # never more than half of what is free
             best, best_ms, pool, times = None, float("inf"), [], []
-            for _ in range(K):
-                cand = torch.empty(shape, dtype=torch.uint8, device=self.device)
-                pool.append(cand)                                  # alive together: distinct memory
-                ms = self._overlay_ms(rig, src, cand, cols, reps)
-                times.append(ms)
-                if ms < best_ms:
-                    best, best_ms = cand, ms
+            budget = int(free // 2 // nbytes)
+            for rnd in range(3):
+                # a second and a third round when all candidates so far ran alike (within 3 %): the two levels are 6-10 % apart,
+                # so a sample like that is all of one kind -- and if it is the slow kind, fresh memory may hold the other
+                if rnd and (len(pool) + K > budget or max(times) > 1.03 * min(times)):
+                    break
+                for _ in range(K):
+                    cand = torch.empty(shape, dtype=torch.uint8, device=self.device)
+                    pool.append(cand)                              # alive together: distinct memory
+                    ms = self._overlay_ms(rig, src, cand, cols, reps)
+                    times.append(ms)
+                    if ms < best_ms:
+                        best, best_ms = cand, ms
+            K = len(pool)
             self.__dict__.setdefault("audition_log", []).append(
                 {"role": "mosaic", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4)})
             del pool, cand

@@ -469,7 +469,9 @@ def test_placed_buffers_render_the_same_bytes(monkeypatch):
     del probe_out, want_copy
     out = eng.alloc_mosaic(rig, frames[1:1 + a.frames], candidates=4)
     log = eng.audition_log[-1]
-    assert log["role"] == "mosaic" and log["candidates"] == 4 and len(log["ms"]) == 4 and log["chosen_ms"] == min(log["ms"])
+    # (4 candidates, and up to two more rounds of 4 when all so far ran within 3 % of each other)
+    assert log["role"] == "mosaic" and log["candidates"] in (4, 8, 12) and len(log["ms"]) == log["candidates"]
+    assert log["chosen_ms"] == min(log["ms"])
     placed = eng.place_frames(rig, frames, out, first=1, candidates=3)
     assert eng.audition_log[-1]["role"] == "frames" and len(eng.audition_log[-1]["ms"]) == 4
     assert torch.equal(placed, frames)
