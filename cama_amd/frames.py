@@ -236,6 +236,7 @@ class ClipFrameSource:
         # consumer renders / encodes the current one
         self._plan = None
         self._pump_depth = int(os.environ.get("CAMA_DECODE_AHEAD", 3))   # decoded or decoding batches ahead of the consumer
+        self._pump_groups = int(os.environ.get("CAMA_PUMP_GROUPS", 1)) or None   # decode groups per pumped batch (0: the decoder's own rule)
         self._batch_reads = {}                                           # batch key -> future of its file reads
         self._native_threads = int(os.environ.get("CAMA_READ_THREADS", 8))   # native reader threads per batch
         self._prefetch = prefetch
@@ -403,7 +404,8 @@ class ClipFrameSource:
                 if getattr(self, "_pump_stream", None) is None:
                     self._pump_stream = torch.cuda.Stream(device=self.device)
                 with torch.cuda.stream(self._pump_stream):
-                    return self._decoder().decode_async([arr for _, _, arr, _ in items], bgr=True)
+                    # one group per batch: the pump keeps `_pump_depth` batches in flight, that is the concurrency
+                    return self._decoder().decode_async([arr for _, _, arr, _ in items], bgr=True, groups=self._pump_groups)
             return items                           # .npy twins / mixed sources: the consumer finishes them
 
     def close(self):

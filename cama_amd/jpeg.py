@@ -445,10 +445,13 @@ class DeviceJpegDecoder:
     def decode(self, blobs, bgr=True, out=None):
         return self.decode_async(blobs, bgr=bgr, out=out).result()
 
-    def decode_async(self, blobs, bgr=True, out=None):
+    def decode_async(self, blobs, bgr=True, out=None, groups=None):
         """Parse, upload and launch; returns a PendingDecode whose result() waits, re-decodes flagged / unsupported
         images on the host and returns the [n, H, W, 3] tensor.  Several decodes may be in flight (each takes its
-        own lanes), e.g. the next frame's while the current one is consumed."""
+        own lanes), e.g. the next frame's while the current one is consumed.  `groups` fixes how many groups (streams) THIS
+        batch is split into: a caller that keeps several batches in flight anyway (the decode pump: three) passes 1 --
+        the batches tile the chip, and a batch's images then go through ONE chain of kernels instead of three shorter,
+        staggered ones (main.py loop, 96-image batches: 3.4-3.5 k -> 3.9-4.35 k frames/s)."""
         import torch
         n = len(blobs)
         assert n >= 1
@@ -476,7 +479,9 @@ class DeviceJpegDecoder:
                 # decode workgroups per image (from the stuffed length: a slight over-estimate), groups of ~group_wgs
                 wgs = np.array([-(-(headers[i].scan_end - headers[i].scan_start) // self.WG_BYTES) for i in ok])
                 cum = np.concatenate([[0], np.cumsum(wgs)])
-                if self.lanes is not None:
+                if groups is not None:
+                    groups = max(1, min(int(groups), max(1, len(ok) // self.min_group)))
+                elif self.lanes is not None:
                     groups = max(1, min(self.lanes, len(ok) // self.min_group))
                 else:
                     groups = max(1, min(self.max_lanes, len(ok) // self.min_group, -(-int(cum[-1]) // self.group_wgs)))

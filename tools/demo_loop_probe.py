@@ -35,17 +35,22 @@ def main():
     print(f"clip with {6 * (args.frames + 1)} JPEGs written in {time.perf_counter() - t:.1f} s")
     settings = [None]
     if args.sweep:
-        name, vals = args.sweep.split("=")
-        settings = [(name, v) for v in vals.split(",")]
+        if ";" in args.sweep or args.sweep.count("=") > 1:          # "A=1;B=2,A=3;B=4": several variables per setting
+            settings = [[kv.split("=") for kv in one.split(";")] for one in args.sweep.split(",")]
+        else:
+            name, vals = args.sweep.split("=")
+            settings = [[(name, v)] for v in vals.split(",")]
     for setting in settings:
         if setting is not None:
-            os.environ[setting[0]] = setting[1]
-            print(f"## {setting[0]}={setting[1]}")
+            for k, v in setting:
+                os.environ[k] = v
+            print("## " + " ".join(f"{k}={v}" for k, v in setting))
         run_passes(args, root, clip, ClipManager, VideoGenerator, DEFAULT_CAMA_CONFIGS, torch)
 
 
 def run_passes(args, root, clip, ClipManager, VideoGenerator, DEFAULT_CAMA_CONFIGS, torch):
-    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)          # reference default output size (540, 960)
+    # reference default output size (540, 960); PROBE_RENDER_AHEAD: frames per render batch (configs["render_ahead"], 16)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, render_ahead=int(os.environ.get("PROBE_RENDER_AHEAD", "16"))), clip)
     rates = []
     for label in ["first pass (one-off setup)"] + ["steady state"] * (args.passes - 1):
         vg = VideoGenerator(os.path.join(root, "out.mp4"), (2880, 1080))
