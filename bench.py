@@ -487,6 +487,23 @@ class Job:
         import ctypes
         from cama_amd import _lib
         L = _lib.lib()
+        # The interpreter's cyclic collector is parked for warm-up + timed region, as timeit does: a full collection over the
+        # objects torch and numpy bring along takes ~10 ms, longer than the 20 timed steps of the headline together (one run in
+        # 40 reported half the frames/s of its neighbours with an unchanged kernel time: profiles/r04_process_distribution.txt).
+        # Collected BEFORE the warm-up, not between warm-up and timed region: with a pause of tens of milliseconds there the timed
+        # steps ran slower at an unchanged kernel time (120-122 k -> 112-114 k frames/s, twelve of twelve processes).
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._run_timed(L, steps, warmup, sync_all, prof_every)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _run_timed(self, L, steps, warmup, sync_all, prof_every):
+        import ctypes
         for _ in range(warmup):
             self.step()
         self.eng.join()

@@ -450,7 +450,10 @@ struct MapTuner {
         e->stamp = ++clock;
         last_id = e->id;
         if (e->decided >= 0) return MapTrial{(uint32_t)e->decided, nullptr, nullptr, 0, e->id};
-        if (!can_trial || e->issued >= 4 * SAMPLES) return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0, e->id};
+        // a pair whose trials never completed (timing failures) stays on the order whose speed does not depend on the pair;
+        // a launch that merely cannot carry a trial right now (it is being profiled) follows the contiguous order
+        if (e->issued >= 4 * SAMPLES) return MapTrial{MAP_CHUNKED, nullptr, nullptr, 0, e->id};
+        if (!can_trial) return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0, e->id};
         MapTrial t{MAP_CONTIGUOUS, nullptr, nullptr, e->issued & 1, e->id};
         if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) {
             if (t.e0) (void)hipEventDestroy(t.e0);
