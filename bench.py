@@ -514,15 +514,24 @@ class Job:
         step = self.step
         if os.environ.get("CAMA_BENCH_FAULT") == "skip_overlay":       # fault injection (tests): the timed steps render nothing
             step = lambda: None
+        trace = [] if os.environ.get("CAMA_BENCH_STEP_TRACE") == "1" else None     # diagnostic: host time of every step's issue
         sync_all()
         t0 = time.perf_counter()
         for k in range(steps):
             if prof_every > 0:                                          # live hipEvent timing of every n-th overlay
                 L.cama_profile_enable(1 if k % prof_every == 0 else 0)
             step()
+            if trace is not None:
+                trace.append(time.perf_counter())
         self.eng.join()
+        if trace is not None:
+            trace.append(time.perf_counter())
         sync_all()
         dt = time.perf_counter() - t0
+        if trace is not None:
+            ts = [t0] + trace + [t0 + dt]
+            print("step trace (us): issue of each step, join, final sync: " +
+                  " ".join("%.0f" % ((b - a) * 1e6) for a, b in zip(ts, ts[1:])), file=sys.stderr, flush=True)
         cap = 8192
         each = (ctypes.c_double * cap)()
         ov_n = ctypes.c_int32(0)
