@@ -464,6 +464,12 @@ class Engine:
             return out
 
     # ------------------------------------------------------------------ placement-aware allocation of long-lived buffers
+    def _probeable(self, rig, src):
+        """Can cama_overlay_probe time launches from `src`?  (contiguous uint8 [F, C, H, W, 3] of the rig's size, W % 16 == 0,
+        opaque stamps)"""
+        return (src.dim() == 5 and tuple(src.shape[1:]) == (rig.C, rig.H, rig.W, 3) and src.is_contiguous()
+                and str(src.dtype) == "torch.uint8" and src.data_ptr() % 16 == 0 and rig.W % 16 == 0 and self.alpha256 == 256)
+
     def _overlay_ms(self, rig, src, out, cols, reps):
         """Mean duration (ms) of `reps` stamp-free overlay launches src -> out in the XCD-contiguous order
         (cama_overlay_probe: its own kernel name, not through the mapping table; blocks)."""
@@ -479,7 +485,7 @@ class Engine:
         caller's own launches over this pair is a trial.  No-op for launches below the tuner's 1.75 GiB."""
         torch = _torch()
         F = int(src.shape[0])
-        if 6 * F * rig.C * rig.H * rig.W < (7 << 28) or rig.W % 16 or self.alpha256 != 256:
+        if 6 * F * rig.C * rig.H * rig.W < (7 << 28) or not self._probeable(rig, src):
             return
         L = self.lib
         need = int(L.cama_render_scratch_bytes(0, F, rig.C, rig.H, rig.W, self.radius))
@@ -516,7 +522,7 @@ class Engine:
         nbytes = int(np.prod(shape))
         K = int(os.environ.get("CAMA_AUDITION", "16")) if candidates is None else int(candidates)
         with torch.cuda.device(self.device):
-            if K <= 1 or nbytes < (1 << 29) or nbytes > (8 << 30) or rig.W % 16 or self.alpha256 != 256:
+            if K <= 1 or nbytes < (1 << 29) or nbytes > (8 << 30) or not self._probeable(rig, src):
                 return torch.empty(shape, dtype=torch.uint8, device=self.device)
             free, _ = torch.cuda.mem_get_info(self.device)
             K = max(1, min(K, int(free // 2 // nbytes)))          # never more than half of what is free
@@ -561,7 +567,7 @@ class Engine:
         with torch.cuda.device(self.device):
             free, _ = torch.cuda.mem_get_info(self.device)
             P = min(int(pool), int(free * 3 // 4 // nbytes))
-            if P <= n or nbytes < (1 << 29) or rig.W % 16 or self.alpha256 != 256:
+            if P <= n or nbytes < (1 << 29) or not all(self._probeable(rig, s) for s in srcs):
                 return ChunkedMosaic([torch.empty(self.mosaic_shape(rig, int(s.shape[0]), cols), dtype=torch.uint8,
                                                   device=self.device) for s in srcs])
             F0 = int(srcs[0].shape[0])
@@ -591,7 +597,7 @@ class Engine:
         nbytes = int(frames.numel())
         K = int(os.environ.get("CAMA_AUDITION", "16")) // 2 if candidates is None else int(candidates)
         with torch.cuda.device(self.device):
-            if K <= 1 or nbytes < (1 << 29) or nbytes > (8 << 30) or rig.W % 16 or self.alpha256 != 256:
+            if K <= 1 or nbytes < (1 << 29) or nbytes > (8 << 30) or not self._probeable(rig, view(frames)):
                 return frames
             free, _ = torch.cuda.mem_get_info(self.device)
             K = max(1, min(K, int(free // 2 // nbytes)))

@@ -58,3 +58,22 @@ def test_chunked_mosaic_indexes_frames_and_refuses_slices_across_chunks():
     m.fill_(7)
     assert all(int(c.min()) == 7 and int(c.max()) == 7 for c in chunks)
     assert [(lo, hi) for lo, hi, _ in m.spans()] == [(0, 4), (4, 8), (8, 11)]
+
+
+def test_placement_helpers_only_probe_what_the_probe_kernel_can_read():
+    """Engine.alloc_mosaic / place_frames / alloc_mosaics fall back to plain allocations unless the source is a contiguous
+    uint8 [F, C, H, W, 3] tensor of the rig's size with W % 16 == 0 and opaque stamps (what cama_overlay_probe takes)."""
+    import types
+    import torch
+    eng = types.SimpleNamespace(alpha256=256)
+    rig = types.SimpleNamespace(C=6, H=4, W=32)
+    ok = torch.zeros((3, 6, 4, 32, 3), dtype=torch.uint8)
+    probe = engine.Engine._probeable
+    assert probe(eng, rig, ok)
+    assert probe(eng, rig, ok[1:])                                   # a slice along frames stays contiguous
+    assert not probe(eng, rig, ok[:, :, :, ::2])                     # strided view
+    assert not probe(eng, rig, ok.permute(0, 1, 3, 2, 4))            # wrong layout
+    assert not probe(eng, rig, ok.to(torch.int8))
+    assert not probe(eng, types.SimpleNamespace(C=6, H=4, W=24), torch.zeros((3, 6, 4, 24, 3), dtype=torch.uint8))   # W % 16
+    assert not probe(types.SimpleNamespace(alpha256=128), rig, ok)   # translucent stamps go through another kernel
+    assert not probe(eng, rig, torch.zeros((3, 6, 4, 32), dtype=torch.uint8))
