@@ -27,6 +27,27 @@ def main():
     job.eng.join()
     torch.cuda.synchronize()
     print("plain: %.1f us per step" % ((time.perf_counter() - t0) / n * 1e6))
+    # host time inside the library's two per-step entry points
+    lib = job.eng.lib
+    acc, originals = {}, {}
+    for name in ("cama_pipeline_render", "cama_pipeline_stage_poses", "cama_pipeline_issued", "cama_pipeline_completed"):
+        orig = originals[name] = getattr(lib, name)
+
+        def timed(*a, _orig=orig, _name=name):
+            t = time.perf_counter()
+            r = _orig(*a)
+            acc[_name] = acc.get(_name, 0.0) + time.perf_counter() - t
+            return r
+        setattr(lib, name, timed)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        job.step()
+    job.eng.join()
+    torch.cuda.synchronize()
+    print("with the library calls timed: %.1f us per step; inside " % ((time.perf_counter() - t0) / n * 1e6) +
+          ", ".join("%s %.1f us" % (k, v / n * 1e6) for k, v in acc.items()))
+    for name, orig in originals.items():        # (put the typed ctypes functions back: a fresh lookup would have no argtypes)
+        setattr(lib, name, orig)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(n):

@@ -4,7 +4,7 @@ set -u
 R=$PWD
 export TMPDIR=/tmp
 d=$R/gpurun_out/${1:-stress}_trace
-(cd /tmp && timeout 900 rocprofv3 --output-format csv --kernel-trace --memory-copy-trace -d $d -o t -- python $R/bench.py ${BENCH_ARGS:---map random --verts 1000000 \
+(cd /tmp && timeout 900 rocprofv3 --output-format csv --kernel-trace --memory-copy-trace -d $d -o t -- python ${BENCH_PY:-$R/bench.py} ${BENCH_ARGS:---map random --verts 1000000 \
    --frames 1000 --shard-frames --steps 3 --warmup 1} --cpu-seconds 0 --sustain-seconds 0 > $d.log 2>&1)
 tail -c 300 $d.log | head -c 200; echo
 python - $d ${SHOW:-17} <<'PY'
