@@ -124,6 +124,8 @@ def parse_args(argv=None):
                     help="EXTENSION (no reference semantics, SURVEY.md D1): also join neighbouring points of a polyline by "
                          "one-pixel Bresenham segments (CAMA_BIN_SEGMENTS) -- BASELINE.json's north_star wording; the bytes are "
                          "checked against the oracle's own restatement in the test-suite, not against golden hashes")
+    ap.add_argument("--wu", action="store_true",
+                    help="with --segments: the anti-aliased variant (Wu lines blended once by coverage, CAMA_BIN_SEGMENTS_WU)")
     ap.add_argument("--plan", action="store_true",
                     help="no GPU needed: print, as one JSON object, what every rank of `--gpus N` would hold -- its scenes, "
                          "resident frame / mosaic / map bytes, stamp scratch (worst case and, for planned site-sized maps, "
@@ -143,6 +145,9 @@ def workload_key(frames, verts, width, height, map_kind, raw=False, unit="scene"
 
 
 def _segments(args):
+    """False, True (Bresenham) or "wu" (anti-aliased): what ClipManager.render_clip(segments=...) takes."""
+    if getattr(args, "wu", False):
+        return "wu"
     return bool(getattr(args, "segments", False))
 
 
@@ -1052,7 +1057,9 @@ def main():
             line["config"]["workload"] += "; %d site(s), scene k on site k %% %d" % (args.sites, args.sites)
             line["config"]["sharding"] = "whole scenes placed site by site (shard.assign_scenes(site_of=...)), no data-path collective"
         if _segments(args):
-            line["config"]["workload"] += "; EXTENSION: discs + one-pixel Bresenham segments between polyline neighbours"
+            line["config"]["workload"] += ("; EXTENSION: discs + anti-aliased (Wu) segments between polyline neighbours"
+                                           if _segments(args) == "wu" else
+                                           "; EXTENSION: discs + one-pixel Bresenham segments between polyline neighbours")
             line["config"]["extension"] = ("segments: no reference semantics (the reference draws a disc per point, "
                                            "cama/reproject.py:255-256); bytes checked against the oracle's own restatement "
                                            "in tests/test_gpu_kernels.py and tests/test_gpu_fullsize.py")

@@ -10,9 +10,10 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 18
+ABI_VERSION = 19
 BIN_WORKLIST = 1
-BIN_SEGMENTS = 2            # EXTENSION: discs + one-pixel segments between polyline neighbours (include/cama_hip.h)
+BIN_SEGMENTS = 2
+BIN_SEGMENTS_WU = 4            # EXTENSION: discs + one-pixel segments between polyline neighbours (include/cama_hip.h)
 
 _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _u64 = ctypes.c_uint64

@@ -181,6 +181,7 @@ struct BinPlan {
     // segment EXTENSION (CAMA_BIN_SEGMENTS): 16-byte records, and a record reaches every band its segment crosses, so no
     // a-priori bound exists: the band-sorted list lives in a buffer of its own, sized from the scans' grand total
     bool segments = false;
+    bool wu = false;                // ... anti-aliased (CAMA_BIN_SEGMENTS_WU)
     bool have_sorted_capacity = false;
     uint64_t sorted_capacity = 0;
 };
@@ -194,7 +195,7 @@ struct ScratchLayout {
     size_t total;                   // both parts in one buffer: plan_total + stamp_total
     uint64_t capacity;
     uint32_t nseg;
-    bool planned, segments;
+    bool planned, segments, wu;
     size_t record_bytes;            // 8, or 16 with segment records
     int R, NB, bands_per_stamp;
 };
@@ -207,6 +208,7 @@ int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLay
     const size_t nbins = (size_t)F * C * L.NB, nfc = (size_t)F * C;
     L.planned = plan && plan->planned;
     L.segments = plan && plan->segments;
+    L.wu = L.segments && plan->wu;
     L.record_bytes = L.segments ? 16 : 8;
     L.capacity = L.planned ? plan->capacity : (uint64_t)F * C * (uint64_t)N * L.bands_per_stamp;
     if (L.segments) L.capacity = plan->have_sorted_capacity ? plan->sorted_capacity : 0;   // (its own buffer: ScratchRef::sorted)
@@ -870,7 +872,8 @@ static int bin_main(const BinCall &b, const ScratchLayout &L, const ScratchRef &
     a.nseg = L.nseg; a.seg_cnt = (uint8_t *)(sbase + L.seg_cnt); a.stamps0 = (uint2 *)(sbase + L.stamps0);
     a.counts = counts; a.cursor = cursor; a.bin_off = bin_off; a.fc_base = fc_base;
     a.stamps = (uint2 *)sc.stamps_base(L);
-    a.segments = L.segments ? 1 : 0;
+    a.segments = L.segments ? (L.wu ? 2 : 1) : 0;
+    if (L.wu && N >= ((int64_t)1 << 22)) return fail(CAMA_EINVAL, "anti-aliased segments: N must be below 2^22");
     if (L.segments && b.draw_key)
         return fail(CAMA_EINVAL, "segments need the map in draw order (no draw_key: a spatially sorted copy has no polyline neighbours)");
     if (L.segments && b.scenes_dev) return fail(CAMA_EINVAL, "segments are not offered for multi-scene launches");
@@ -1177,12 +1180,17 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
         // EXTENSION: 16-byte records, discs + one-pixel segments; the plain vectorised overlay only
         if (raw || !vec || o.pal.alpha256 != 256u || scenes_dev)
             return fail(CAMA_EINVAL, "segments: plain overlay only (W %% 16 == 0, opaque, pre-resized frames, one scene)");
-        if (lds > 64 * 1024)
+        if (lds > 64 * 1024) {
             HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         if (trial.e0) { g_map_tuner.abandon(trial); trial.e0 = trial.e1 = nullptr; }
         hipEvent_t e0 = (exact_timing && ev0 && ev1) ? ev0 : nullptr;
         hipEvent_t e1 = e0 ? ev1 : g_overlay_stop_event;
-        hipExtLaunchKernelGGL((k_overlay<true, false, false, true>), ogrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, e0, e1, 0u, o);
+        if (L.wu)
+            hipExtLaunchKernelGGL((k_overlay<true, false, false, true, true>), ogrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, e0, e1, 0u, o);
+        else
+            hipExtLaunchKernelGGL((k_overlay<true, false, false, true>), ogrid, dim3(OVERLAY_BLOCK), (uint32_t)lds, s, e0, e1, 0u, o);
         if (!e0) g_overlay_stop_event = nullptr;
     } else if (raw_lds) {
         if (lds_raw > 64 * 1024)
@@ -1830,6 +1838,8 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
     ScratchLayout L;
     bool prepass_done = false;
     sc.bin_plan.segments = segments;
+    sc.bin_plan.wu = segments && (call.flags & CAMA_BIN_SEGMENTS_WU) != 0;
+    if ((call.flags & CAMA_BIN_SEGMENTS_WU) && !segments) return fail(CAMA_EINVAL, "CAMA_BIN_SEGMENTS_WU goes with CAMA_BIN_SEGMENTS");
     if (!managed) {
         // validate before anything is enqueued, so a rejected call leaves the pipeline state untouched
         void *scratch = slot ? scratch1 : scratch0;

@@ -100,6 +100,61 @@ __device__ __forceinline__ void rasterise_segment_padded(uint32_t *s_owner, cons
     }
 }
 
+// EXTENSION, anti-aliased variant (Wu): the claims of oracle_render_frame_wu's wu_line_claims -- the same integer recurrence --
+// for the rows of this band; a claim is ((key + 1) << 8) | coverage, zero coverages claim nothing, atomicMax keeps the
+// greatest (key, coverage) per pixel.  Columns -1 and W fall into the owner rows' padding (radius >= 1 cells either side).
+__device__ __forceinline__ void wu_claim_padded(uint32_t *s_owner, int x, int y, uint32_t v, int y0, int nrows, int Wp, int radius)
+{
+    if ((unsigned)(y - y0) < (unsigned)nrows && x >= -radius && x < Wp - radius && (v & 255u))
+        atomicMax(&s_owner[(y - y0) * Wp + x + radius], v);
+}
+
+__device__ __forceinline__ void rasterise_segment_wu_padded(uint32_t *s_owner, const uint4 r, int y0, int nrows, int Wp, int radius)
+{
+    if (r.z == 0xffffffffu) return;
+    const int x0 = (int)(r.z & 0xffffu), yy0 = (int)(r.z >> 16), x1 = (int)(r.x & 0xffffu), yy1 = (int)(r.x >> 16);
+    const uint32_t key1 = (r.y + 1u) << 8;
+    const bool steep = abs(yy1 - yy0) > abs(x1 - x0);
+    int a0 = steep ? yy0 : x0, b0 = steep ? x0 : yy0, a1 = steep ? yy1 : x1, b1 = steep ? x1 : yy1;      // a = major, b = minor
+    if (a0 > a1) { int t = a0; a0 = a1; a1 = t; t = b0; b0 = b1; b1 = t; }
+    const int da = a1 - a0, db = b1 - b0;
+    if (da == 0) return;                                     // (same pixel: the record carries no segment then)
+    const int num = db * 65536;
+    int grad = num / da;
+    if (num % da != 0 && num < 0) grad -= 1;                 // floor division, da > 0
+    // steep: the major axis is the row -- only the band's rows are walked
+    const int j_lo = steep ? max(0, y0 - a0) : 0, j_hi = steep ? min(da, y0 + nrows - 1 - a0) : da;
+    for (int j = j_lo; j <= j_hi; ++j) {
+        const int y = b0 * 65536 + grad * j;
+        const int row = y >> 16;                             // arithmetic shift: floor
+        const uint32_t f = ((uint32_t)y & 0xffffu) >> 8;
+        const int a = a0 + j;
+        if (steep) {
+            wu_claim_padded(s_owner, row, a, key1 | (255u - f), y0, nrows, Wp, radius);
+            wu_claim_padded(s_owner, row + 1, a, key1 | f, y0, nrows, Wp, radius);
+        } else {
+            wu_claim_padded(s_owner, a, row, key1 | (255u - f), y0, nrows, Wp, radius);
+            wu_claim_padded(s_owner, a, row + 1, key1 | f, y0, nrows, Wp, radius);
+        }
+    }
+}
+
+// the disc of a record in the anti-aliased variant: coverage 255 under ((key + 1) << 8)
+__device__ __forceinline__ void rasterise_disc_wu_padded(uint32_t *s_owner, const uint2 r, int y0, int nrows, int Wp, int radius,
+                                                         uint32_t hw8, uint32_t rowmask)
+{
+    const int u = (int)(r.x & 0xffffu), v = (int)(r.x >> 16);
+    const uint32_t val = ((r.y + 1u) << 8) | 255u;
+    const int ylo = max(v - radius, y0), yhi = min(v + radius, y0 + nrows - 1);
+    uint32_t *cell = s_owner + (ylo - y0) * Wp + u + radius;
+    for (int y = ylo; y <= yhi; ++y, cell += Wp) {
+        const uint32_t k = (uint32_t)abs(y - v);
+        if (!((rowmask >> k) & 1u)) continue;
+        const int hw = (int)((hw8 >> (4u * k)) & 15u);
+        for (int d = -hw; d <= hw; ++d) atomicMax(cell + d, val);
+    }
+}
+
 // Stamps `first`, first + stride, ... < n of a band's list, four record loads in flight per thread: on bands that
 // collect tens of thousands of stamps (dense maps: every far lane converges on a few horizon rows) the loop is a chain of
 // global-load latencies, and such a band's workgroup is the kernel's straggler.  Loads are unconditional (clamped index):
@@ -175,6 +230,42 @@ __device__ __forceinline__ void patch_chunk(u32x4 &d, const uint32_t *orow, uint
         d.z = (d.z & ~m2) | (blend_bytes(d.z, v2, pal.alpha256) & m2);
         d.w = (d.w & ~m3) | (blend_bytes(d.w, v3, pal.alpha256) & m3);
     }
+}
+
+__device__ __forceinline__ u32x4 chunk_from_pixels(const uint32_t *c, uint32_t ph);
+
+// per-byte (colour * a + source * (256 - a) + 128) >> 8 with a = coverage + (coverage >> 7), four bytes of a dword
+__device__ __forceinline__ uint32_t blend_bytes_cov(uint32_t src, uint32_t col, uint32_t cov)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t cv = (cov >> (8 * k)) & 255u, a = cv + (cv >> 7);
+        const uint32_t s = (src >> (8 * k)) & 255u, c = (col >> (8 * k)) & 255u;
+        out |= (((c * a + s * (256u - a) + 128u) >> 8) & 255u) << (8 * k);
+    }
+    return out;
+}
+
+// anti-aliased variant: owner cells are ((key + 1) << 8) | coverage; every owned pixel is blended once with its own coverage
+__device__ __forceinline__ void patch_chunk_wu(u32x4 &d, const uint32_t *orow, uint32_t col, const Palette &pal)
+{
+    const uint32_t b0 = col * 16u, p0 = b0 / 3u, ph = b0 - p0 * 3u;
+    uint32_t o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = orow[p0 + k];
+    if ((o[0] | o[1] | o[2] | o[3] | o[4] | o[5]) == 0u) return;
+    uint32_t c[6], a[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        c[k] = o[k] ? ((((o[k] >> 8) - 1u) & 1u) ? pal.c[1] : pal.c[0]) : 0u;
+        a[k] = (o[k] & 255u) * 0x010101u;                       // the pixel's coverage on each of its three bytes
+    }
+    const u32x4 v = chunk_from_pixels(c, ph), cv = chunk_from_pixels(a, ph);
+    d.x = blend_bytes_cov(d.x, v.x, cv.x);
+    d.y = blend_bytes_cov(d.y, v.y, cv.y);
+    d.z = blend_bytes_cov(d.z, v.z, cv.z);
+    d.w = blend_bytes_cov(d.w, v.w, cv.w);
 }
 
 // 6 packed pixels (b | g<<8 | r<<16) that a 16-byte chunk starting `ph` bytes into the first one overlaps -> the chunk
@@ -293,7 +384,7 @@ __device__ __forceinline__ BandId decode_band(const OverlayArgs &a, const uint32
     return id;
 }
 
-template <bool VEC, bool RESAMPLE, bool ALPHA, bool SEGS = false>
+template <bool VEC, bool RESAMPLE, bool ALPHA, bool SEGS = false, bool WU = false>
 __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint32_t fl, const uint32_t f0, const uint32_t c,
                                                 const uint32_t b, uint32_t *s_owner)
 {
@@ -355,11 +446,14 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
         if (SEGS) {
             for (uint32_t sidx = threadIdx.x; sidx < n; sidx += OVERLAY_BLOCK) {
                 const uint4 r = sidx == threadIdx.x ? first4 : st4[sidx];
-                rasterise_segment_padded(s_owner, r, y0, nrows, Wp, rad);
+                if (WU) rasterise_segment_wu_padded(s_owner, r, y0, nrows, Wp, rad);
+                else rasterise_segment_padded(s_owner, r, y0, nrows, Wp, rad);
                 // (the disc of a record that is here only because its segment crosses this band may lie outside it)
                 const int v = (int)(r.x >> 16);
-                if (v + rad >= y0 && v - rad < y0 + nrows)
-                    rasterise_one_padded(s_owner, make_uint2(r.x, r.y), y0, nrows, Wp, rad, hw8, rowmask);
+                if (v + rad >= y0 && v - rad < y0 + nrows) {
+                    if (WU) rasterise_disc_wu_padded(s_owner, make_uint2(r.x, r.y), y0, nrows, Wp, rad, hw8, rowmask);
+                    else rasterise_one_padded(s_owner, make_uint2(r.x, r.y), y0, nrows, Wp, rad, hw8, rowmask);
+                }
             }
         } else {
             if (threadIdx.x < n) rasterise_one_padded(s_owner, first, y0, nrows, Wp, rad, hw8, rowmask);
@@ -419,7 +513,10 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
                     const uint32_t row = __umulhi(idx, a.cpr_magic);
                     const uint32_t col = idx - row * a.cpr;
 #ifndef ABL_NO_PATCH
-                    if (n) patch_chunk<ALPHA>(v[j], s_owner + row * Wp + rad, col, a.pal);
+                    if (n) {
+                        if (WU) patch_chunk_wu(v[j], s_owner + row * Wp + rad, col, a.pal);
+                        else patch_chunk<ALPHA>(v[j], s_owner + row * Wp + rad, col, a.pal);
+                    }
 #endif
                     u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
                     OVERLAY_STORE(v[j], drow + col);
@@ -477,12 +574,12 @@ __device__ __forceinline__ void tlb_lookahead(const OverlayArgs &a)
     asm volatile("global_load_ubyte %0, %2, off\n\tglobal_load_ubyte %1, %3, off" : "=&v"(t0), "=&v"(t1) : "v"(sp), "v"(dp) : "memory");
 }
 
-template <bool VEC, bool RESAMPLE, bool ALPHA = false, bool SEGS = false>
+template <bool VEC, bool RESAMPLE, bool ALPHA = false, bool SEGS = false, bool WU = false>
 __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x (W + 2 radius), used only by stamped bands
     const BandId id = decode_band(a, a.items, 1u, 0u);
-    if (id.valid) overlay_band_at<VEC, RESAMPLE, ALPHA, SEGS>(a, id.fl, (uint32_t)a.f0, id.c, id.b, s_owner);
+    if (id.valid) overlay_band_at<VEC, RESAMPLE, ALPHA, SEGS, WU>(a, id.fl, (uint32_t)a.f0, id.c, id.b, s_owner);
     tlb_lookahead<RESAMPLE>(a);
 }
 

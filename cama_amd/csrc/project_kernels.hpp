@@ -354,6 +354,16 @@ __device__ __forceinline__ WaveVerts load_wave_verts(const FrameArgs &a, const i
     return v;
 }
 
+// Rows a segment record can touch: its disc (vi +- radius) and its segment (vi .. vp); the anti-aliased variant (a.segments == 2,
+// Wu) writes the row above and below the exact line too, one row more at either end.
+__device__ __forceinline__ void record_bands(const FrameArgs &a, const int vi, const int vp, const bool has_prev, int &b0, int &b1)
+{
+    const int e = (a.segments == 2 && has_prev) ? 1 : 0;
+    const int r = max(a.radius, e);
+    b0 = max(min(vi - r, vp - e), 0) >> a.band_shift;
+    b1 = min(max(vi + r, vp + e), a.H - 1) >> a.band_shift;
+}
+
 // The wave's stamps of camera c (uv = packed truncated pixel or 0xffffffff): drop same-pixel predecessors, compact into the
 // wave's segment, count, add the bands to the LDS histogram.
 // Segment extension: the same with 16-byte records {uv, key, uv of the predecessor | ~0, 0}.  `uv_halo` = lane 0's
@@ -378,8 +388,8 @@ __device__ __forceinline__ void emit_wave_segments(const FrameArgs &a, const int
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         reinterpret_cast<uint4 *>(a.stamps0)[fcseg * SEG + rank] = make_uint4(uv, v.key, has_seg ? uv_prev : 0xffffffffu, 0u);
         const int vi = (int)(uv >> 16), vp = has_seg ? (int)(uv_prev >> 16) : vi;
-        const int b0 = max(min(vi - a.radius, vp), 0) >> a.band_shift;
-        const int b1 = min(max(vi + a.radius, vp), a.H - 1) >> a.band_shift;
+        int b0, b1;
+        record_bands(a, vi, vp, has_seg, b0, b1);
         for (int b = b0; b <= b1; ++b) atomicAdd(&s_cnt[c * a.NB + b], 1u);
     }
     if (lane == 0u) a.seg_cnt[fcseg] = (uint8_t)__popcll(m);
@@ -636,8 +646,7 @@ __global__ __launch_bounds__(BLOCK) void k_stamps_scatter_seg(FrameArgs a)
                 if (s_off[lo + step] <= t) lo += step;
             r = segs[(size_t)lo * SEG + (t - s_off[lo])];
             const int vi = (int)(r.x >> 16), vp = r.z != 0xffffffffu ? (int)(r.z >> 16) : vi;
-            b0 = max(min(vi - a.radius, vp), 0) >> a.band_shift;
-            b1 = min(max(vi + a.radius, vp), a.H - 1) >> a.band_shift;
+            record_bands(a, vi, vp, r.z != 0xffffffffu, b0, b1);
             for (int b = b0; b <= b1; ++b) atomicAdd(&s_cnt[b], 1u);
         }
         __syncthreads();

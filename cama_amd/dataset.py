@@ -206,6 +206,19 @@ class RenderedFrame(Mapping):
         return len(self.names)
 
 
+def _segments_mode(v):
+    """configs["segments"] / segments= argument -> False, True (one-pixel Bresenham segments) or "wu" (anti-aliased)."""
+    if isinstance(v, str):
+        if v.lower() == "wu":
+            return "wu"
+        if v.lower() in ("bresenham", "true", "1"):
+            return True
+        if v.lower() in ("", "false", "0", "none"):
+            return False
+        raise ValueError(f"segments = {v!r}: expected False, True, 'bresenham' or 'wu'")
+    return bool(v)
+
+
 class ClipManager:
     def __init__(self, configs, clip_path=None, output_size=None):
         self.configs = configs
@@ -370,8 +383,8 @@ class ClipManager:
         return {n: split_instances(vu[c], counts, classes, vis[c]) for c, n in enumerate(names)}
 
     def render_vectors(self, maps_2d_dict, image_idx):
-        segments = bool(self.configs.get("segments", False))
-        # configs["segments"] = True (EXTENSION, no reference semantics): discs + one-pixel segments between neighbouring
+        segments = _segments_mode(self.configs.get("segments", False))
+        # configs["segments"] = True | "wu" (EXTENSION, no reference semantics): discs + one-pixel segments between neighbouring
         # points; caller-supplied 2D instances go image by image through the generic path (cama_stamp_polylines)
         # (round 4: the fused path draws them too -- CAMA_BIN_SEGMENTS -- as long as the source frames are pre-resized)
         fused_ok = not segments or not (getattr(self.frame_source(), "fused", False)
@@ -386,6 +399,9 @@ class ClipManager:
         out = {}
         for cm in self.cm_list:
             image = cm.read_resized_image_by_index(image_idx)
+            if segments == "wu":
+                raise ValueError('configs["segments"] = "wu" is offered by the batched path only (lazy handles of this '
+                                 'ClipManager with pre-resized frames, or render_clip)')
             out[cm.camera_name] = cm.render_maps(image, maps_2d_dict[cm.camera_name], segments=segments) if segments \
                 else cm.render_maps(image, maps_2d_dict[cm.camera_name])
         return out
@@ -402,7 +418,7 @@ class ClipManager:
             mosaic = eng.render_frames_raw(dmap, rig, w2c, source.raw_batch(image_ids), self.cm_list, crop=self.mm.crop_box())
         else:
             mosaic = eng.render_frames(dmap, rig, w2c, source.batch(image_ids), crop=self.mm.crop_box(),
-                                       segments=bool(self.configs.get("segments", False)))
+                                       segments=_segments_mode(self.configs.get("segments", False)))
         batch = RenderBatch(eng, image_ids, mosaic)
         fmt = runtime.egress_mode()                     # a VideoGenerator is listening: start the batch's host copy now
         if fmt is not None and not batch.start_egress(fmt) and fmt == "i420":
@@ -467,7 +483,8 @@ class ClipManager:
         rig = self._rig()
         dmap = self._static(dataset).device()
         # segments: the opt-in extension (discs + one-pixel segments between polyline neighbours); None = configs["segments"]
-        segments = bool(self.configs.get("segments", False)) if segments is None else bool(segments)
+        # ("wu": the anti-aliased variant -- Wu lines blended once by coverage; batched path only)
+        segments = _segments_mode(self.configs.get("segments", False) if segments is None else segments)
         idx, w2c = poses if poses is not None else self.frame_poses(dataset)
         F = len(idx)
         shape = eng.mosaic_shape(rig, F)

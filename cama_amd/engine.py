@@ -433,7 +433,7 @@ class Engine:
             assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.uint8
             x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
             if segments:                    # extension: only through the pipeline (its sorted list is sized per launch)
-                self.render_frames_pipelined(dmap, rig, T, src, out, cols=cols, crop=crop, segments=True)
+                self.render_frames_pipelined(dmap, rig, T, src, out, cols=cols, crop=crop, segments=segments)
                 self.join()
                 return out
             if self.alpha256 == 256 and bnd is not None and (bflags & _lib.BIN_WORKLIST):
@@ -919,6 +919,8 @@ class Engine:
                 if self.alpha256 != 256:
                     raise _lib.CamaHipError("segments and translucent stamps are separate extensions")
                 bflags |= _lib.BIN_SEGMENTS
+                if segments == "wu":        # anti-aliased (Wu) segments, blended once by coverage: include/cama_hip.h
+                    bflags |= _lib.BIN_SEGMENTS_WU
             # scratch: the pipeline's own (NULL, NULL) -- sized from what the launch's cull lets through when the map is
             # site-sized (the call then waits on the host for the pre-pass: include/cama_hip.h), else for the worst case
             _lib.check(self.lib.cama_pipeline_render(

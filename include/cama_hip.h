@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 18
+#define CAMA_ABI_VERSION 19
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -58,6 +58,13 @@ extern "C" {
                                * point's draw index and colour.  Only through cama_pipeline_render with pipeline-owned scratch
                                * (a record reaches every band its segment crosses: the sorted list is sized from the scans'
                                * grand total, which costs one host wait per launch); draw_key must be NULL. */
+#define CAMA_BIN_SEGMENTS_WU 4 /* with CAMA_BIN_SEGMENTS: the segments are ANTI-ALIASED (Wu's line, the north_star's "Bresenham/Wu
+                               * line-raster + blend"): stepping the major axis pixel by pixel with the minor coordinate in 16.16
+                               * fixed point, the two pixels either side of the exact line get 8-bit coverages 255 - f and f; a
+                               * pixel shows the claim -- disc (coverage 255) or segment -- with the greatest (draw index,
+                               * coverage) and is blended ONCE over the source, (colour * a + source * (256 - a) + 128) >> 8 with
+                               * a = coverage + (coverage >> 7).  Definition: oracle/cama_oracle.c, oracle_render_frame_wu.
+                               * N < 2^22 (the owner cells carry the coverage in their low byte). */
 #define CAMA_MAX_SCENES_PER_LAUNCH 1024  /* cama_*_scenes: scenes per chain */
 
 int cama_abi_version(void);

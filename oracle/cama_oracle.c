@@ -37,6 +37,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 /* ---- 3x4 affine rows of a 4x4 row-major matrix applied to (x,y,z,1) ---- */
 static inline void xform_rows(const double *T, double x, double y, double z,
@@ -244,6 +245,85 @@ void oracle_render_frame_alpha(const uint8_t *src, uint8_t *mosaic, int C, int H
                 int owned = memcmp(l3, sentinel, 3) != 0;
                 for (int k = 0; k < 3; k++)
                     d3[k] = owned ? (uint8_t)((l3[k] * alpha256 + s3[k] * (256 - alpha256) + 128) >> 8) : s3[k];
+            }
+    }
+}
+
+/*
+ * EXTENSION restatement (no reference counterpart; the north-star's "Wu line-raster + blend"): discs plus ANTI-ALIASED
+ * one-pixel segments between polyline neighbours.  Definition (this code IS the definition the HIP kernel is checked against):
+ *   every visible point k, in draw order, claims (a) the pixels of its disc with coverage 255 and (b) -- when link[k] is set,
+ *   point k - 1 is visible in the camera too and lies on another pixel -- the pixels of the Wu line from point k - 1's pixel
+ *   to its own with a coverage in 1..255; a pixel shows the claim with the greatest (k, coverage) and is blended ONCE over the
+ *   source: (colour * a + source * (256 - a) + 128) >> 8 with a = coverage + (coverage >> 7)  (255 -> 256: opaque).
+ * Wu's line between integer pixel centres, major axis stepped pixel by pixel, minor coordinate in 16.16 fixed point:
+ *   gradient = floor((d_minor << 16) / d_major); at step j: y = (minor0 << 16) + gradient * j; row = y >> 16 (floor),
+ *   f = (y & 0xffff) >> 8; (major0 + j, row) gets 255 - f and (major0 + j, row + 1) gets f; zero coverages claim nothing.
+ * claim[] = H*W uint32 scratch, ((k + 1) << 8) | coverage; k < 2^23.
+ */
+static void wu_claim(uint32_t *claim, int H, int W, int x, int y, uint32_t v)
+{
+    if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H && (v & 255u) && claim[(int64_t)y * W + x] < v)
+        claim[(int64_t)y * W + x] = v;
+}
+
+static void wu_line_claims(uint32_t *claim, int H, int W, int x0, int y0, int x1, int y1, uint32_t key1)
+{
+    const int steep = abs(y1 - y0) > abs(x1 - x0);
+    int a0 = steep ? y0 : x0, b0 = steep ? x0 : y0, a1 = steep ? y1 : x1, b1 = steep ? x1 : y1;     /* a = major, b = minor */
+    if (a0 > a1) { int t = a0; a0 = a1; a1 = t; t = b0; b0 = b1; b1 = t; }
+    const int da = a1 - a0, db = b1 - b0;
+    if (da == 0) {
+        wu_claim(claim, H, W, x0, y0, (key1 << 8) | 255u);
+        return;
+    }
+    int32_t num = db * 65536, grad = num / da;
+    if (num % da != 0 && num < 0) grad -= 1;                                                    /* floor division (da > 0) */
+    for (int j = 0; j <= da; j++) {
+        const int32_t y = b0 * 65536 + grad * j;
+        const int row = (int)(y >> 16);                         /* arithmetic shift: floor */
+        const uint32_t f = ((uint32_t)y & 0xffffu) >> 8;
+        const int a = a0 + j;
+        if (steep) {
+            wu_claim(claim, H, W, row, a, (key1 << 8) | (255u - f));
+            wu_claim(claim, H, W, row + 1, a, (key1 << 8) | f);
+        } else {
+            wu_claim(claim, H, W, a, row, (key1 << 8) | (255u - f));
+            wu_claim(claim, H, W, a, row + 1, (key1 << 8) | f);
+        }
+    }
+}
+
+void oracle_render_frame_wu(const uint8_t *src, uint8_t *mosaic, int C, int H, int W, int cols, const double *vu,
+                            const uint8_t *vis, const uint8_t *colour_id, const uint8_t *link, int64_t N, int radius,
+                            const uint8_t *palette_bgr, uint32_t *claim /* H*W scratch */)
+{
+    const int64_t step = (int64_t)cols * W * 3;
+    int hw[64];
+    oracle_circle_halfwidths(radius, hw);
+    for (int c = 0; c < C; c++) {
+        uint8_t *cell = mosaic + (int64_t)(c / cols) * H * step + (int64_t)(c % cols) * W * 3;
+        memset(claim, 0, (size_t)H * W * 4);
+        for (int64_t i = 0; i < N; i++) {
+            if (!vis[(int64_t)c * N + i]) continue;
+            const int vi = (int32_t)vu[((int64_t)c * N + i) * 2], ui = (int32_t)vu[((int64_t)c * N + i) * 2 + 1];
+            const uint32_t key1 = (uint32_t)i + 1u;
+            if (i > 0 && link[i] && vis[(int64_t)c * N + i - 1]) {
+                const int vp = (int32_t)vu[((int64_t)c * N + i - 1) * 2], up = (int32_t)vu[((int64_t)c * N + i - 1) * 2 + 1];
+                if (vp != vi || up != ui) wu_line_claims(claim, H, W, up, vp, ui, vi, key1);
+            }
+            for (int dy = -radius; dy <= radius; dy++)          /* the disc: the footprint of oracle_circle_fill */
+                for (int dx = -hw[abs(dy)]; dx <= hw[abs(dy)]; dx++) wu_claim(claim, H, W, ui + dx, vi + dy, (key1 << 8) | 255u);
+        }
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const uint8_t *s3 = src + (((int64_t)c * H + y) * W + x) * 3;
+                uint8_t *d3 = cell + (int64_t)y * step + (int64_t)x * 3;
+                const uint32_t v = claim[(int64_t)y * W + x];
+                if (!v) { d3[0] = s3[0]; d3[1] = s3[1]; d3[2] = s3[2]; continue; }
+                const uint32_t cov = v & 255u, a = cov + (cov >> 7);
+                const uint8_t *q = palette_bgr + 3 * colour_id[(v >> 8) - 1u];
+                for (int k = 0; k < 3; k++) d3[k] = (uint8_t)((q[k] * a + s3[k] * (256u - a) + 128u) >> 8);
             }
     }
 }

@@ -63,6 +63,8 @@ def lib():
         L.oracle_render_frame.restype = None
         L.oracle_render_frame_alpha.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, i32, vp, i32, vp]
         L.oracle_render_frame_alpha.restype = None
+        L.oracle_render_frame_wu.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, i32, vp, vp]
+        L.oracle_render_frame_wu.restype = None
         L.oracle_undistort_map.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
         L.oracle_undistort_map.restype = i32
         _LIB = L
@@ -522,6 +524,24 @@ def frame_render_flat_segments(src, vu, vis, colour_id, link, radius=2, cols=3):
             L.oracle_circle_fill(base, H, W, step, int(px[k][1]), int(px[k][0]), radius, b, g, r)
         r0, q0 = divmod(c, cols)
         out[r0 * H:(r0 + 1) * H, q0 * W:(q0 + 1) * W] = img
+    return out
+
+
+def frame_render_flat_wu(src, vu, vis, colour_id, link, radius=2, cols=3):
+    """Restatement of the product's opt-in ANTI-ALIASED segment extension (oracle_render_frame_wu in cama_oracle.c holds the
+    definition: discs with coverage 255, Wu lines between linked visible neighbours with 8-bit coverages, per pixel the claim
+    with the greatest (draw index, coverage), blended once over the source).  No reference counterpart.
+    src (C,H,W,3) -> mosaic."""
+    L = lib()
+    C, H, W = src.shape[:3]
+    N = vis.shape[1]
+    rows = (C + cols - 1) // cols
+    out = np.zeros((rows * H, cols * W, 3), np.uint8)
+    pal = np.asarray([GREY_RGB[::-1], GOLD_RGB[::-1]], np.uint8)
+    claim = np.zeros((H, W), np.uint32)
+    L.oracle_render_frame_wu(_ptr(np.ascontiguousarray(src)), _ptr(out), C, H, W, cols, _ptr(np.ascontiguousarray(vu)),
+                             _ptr(np.ascontiguousarray(vis).astype(np.uint8)), _ptr(np.ascontiguousarray(colour_id).astype(np.uint8) & 1),
+                             _ptr(np.ascontiguousarray(link).astype(np.uint8)), N, radius, _ptr(pal), _ptr(claim))
     return out
 
 

@@ -144,3 +144,37 @@ def test_headline_scene_with_segments_byte_identical_to_the_restatement(scene):
     runtime.engine().join()
     torch.cuda.synchronize()
     assert torch.equal(out, mosaic)
+
+
+def test_headline_scene_with_antialiased_segments_byte_identical_to_the_restatement(scene):
+    """x1, the rest of the north-star's wording ("Bresenham/Wu line-raster + blend"): the headline scene with ANTI-ALIASED
+    segments in the batched path (render_clip(..., segments="wu"), CAMA_BIN_SEGMENTS | CAMA_BIN_SEGMENTS_WU), every frame
+    byte-equal to oracle_render_frame_wu (discs at coverage 255, Wu lines with 8-bit coverages, the greatest (draw index,
+    coverage) per pixel, blended once over the source).  No reference semantics: the reference draws discs only."""
+    import torch
+    from cama_amd import runtime
+    cm, frames, clip = scene
+    idx, mosaic = cm.render_clip("cama", segments="wu")
+    _, hard = cm.render_clip("cama", segments=True)
+    torch.cuda.synchronize()
+    att = O.read_attribute(clip)
+    cams = [O.camera_model(att, n, output_size=(900, 1600)) for n in CAMERA_NAMES]
+    ins = cm.instance_maps["cama"]
+    xyz, col, _, _ = O.flatten_instances(ins)
+    link = np.concatenate([np.arange(len(i["points"])) > 0 for i in ins])
+    _, w2c = cm.frame_poses("cama")
+    src = frames.cpu().numpy()
+    soft = 0
+    for k, i in enumerate(idx):
+        flat = O.frame_project_flat(xyz, w2c[k], cams, 1600, 900)
+        want = O.frame_render_flat_wu(src[i], flat["vu"], flat["vis"], col, link)
+        got = mosaic[k].cpu().numpy()
+        assert np.array_equal(got, want), f"frame {i}"
+        soft += int(np.count_nonzero((got != hard[k].cpu().numpy()).any(axis=2)))
+    assert soft > 0                                 # partial coverages: not the same picture as the one-pixel segments
+    out = torch.empty_like(mosaic)
+    for _ in range(3):
+        cm.render_clip("cama", out=out, pipelined=True, segments="wu")
+    runtime.engine().join()
+    torch.cuda.synchronize()
+    assert torch.equal(out, mosaic)

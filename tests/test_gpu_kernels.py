@@ -657,6 +657,38 @@ def _polyline_scene(seed, W, H, F, n_dense=24, n_sparse=10, n_single=5):
 
 
 @pytest.mark.parametrize("W,H,F", [(320, 180, 5), (1600, 900, 2)])
+def test_antialiased_segments_in_the_fused_path_equal_their_restatement(engine, W, H, F):
+    """The Wu variant of the segment extension (CAMA_BIN_SEGMENTS_WU): claims of ((key + 1) << 8 | coverage) in the overlay's
+    LDS owner table, records binned one row further at either end, every owned pixel blended once with its own coverage --
+    byte-equal to oracle_render_frame_wu on dense and sparse polylines (segments across dozens of rows and several bands, every
+    octant, end points out of view), single stream and several pipelined launches in flight."""
+    import torch
+    xyz, col, link, cams, w2c = _polyline_scene(23 + W, W, H, F)
+    rig = engine.make_rig([c["name"] for c in cams], [c["chassis2camera"] for c in cams], [c["K"] for c in cams], W, H)
+    dmap = engine.upload_map(xyz, col | (link.astype(np.uint8) << 1), spatial_sort=False)
+    src = torch.randint(0, 256, (F, 6, H, W, 3), dtype=torch.uint8, device="cuda")
+    got = engine.render_frames(dmap, rig, w2c, src, segments="wu")
+    hard = engine.render_frames(dmap, rig, w2c, src, segments=True)
+    torch.cuda.synchronize()
+    host = src.cpu().numpy()
+    for f in range(F):
+        flat = O.frame_project_flat(xyz, w2c[f], cams, W, H)
+        want = O.frame_render_flat_wu(host[f], flat["vu"], flat["vis"], col, link)
+        g = got[f].cpu().numpy()
+        if not np.array_equal(g, want):
+            bad = np.argwhere((g != want).any(axis=2))
+            raise AssertionError(f"frame {f}: {len(bad)} pixels differ from the restatement, first at {bad[:5].tolist()}")
+        assert (got[f] != hard[f]).any()
+    outs = [torch.zeros_like(got) for _ in range(3)]
+    for o in outs:
+        engine.render_frames_pipelined(dmap, rig, np.asarray(w2c, np.float32), src, o, segments="wu")
+    engine.join()
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, got)
+
+
+@pytest.mark.parametrize("W,H,F", [(320, 180, 5), (1600, 900, 2)])
 def test_segment_extension_in_the_fused_path_equals_its_restatement(engine, W, H, F):
     """the north-star's "line segments" in the BATCHED path (CAMA_BIN_SEGMENTS) -- 16-byte records binned to
     every band their segment crosses, rasterised in the overlay's LDS owner table next to the discs -- byte-equal to the

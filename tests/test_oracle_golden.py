@@ -181,3 +181,79 @@ def test_single_point_instances_measured_deviation(tmp_path, capsys):
                   f"one-point instances max dev {dev_single:.3e} px over {n_single} projections, {flips} pixel flips")
         assert dev_multi == 0.0
         assert n_single >= 30 and dev_single <= 1e-9 and flips == 0
+
+
+def _wu_python(src, vu, vis, colour_id, link, radius=2, cols=3):
+    """Pure-Python twin of oracle_render_frame_wu (oracle/cama_oracle.c): the same claims and the same blend, written with
+    Python integers and floor division -- guards the C restatement against overflow / truncation slips."""
+    C, H, W = src.shape[:3]
+    pal = np.asarray([O.GREY_RGB[::-1], O.GOLD_RGB[::-1]], np.int64)
+    hw = O.circle_halfwidths(radius)
+    rows = (C + cols - 1) // cols
+    out = np.zeros((rows * H, cols * W, 3), np.uint8)
+    for c in range(C):
+        claim = {}
+
+        def put(x, y, key1, cov):
+            if 0 <= x < W and 0 <= y < H and cov and claim.get((y, x), (0, 0)) < (key1, cov):
+                claim[(y, x)] = (key1, cov)
+        for i in range(vis.shape[1]):
+            if not vis[c, i]:
+                continue
+            vi, ui = int(vu[c, i, 0]), int(vu[c, i, 1])
+            if i > 0 and link[i] and vis[c, i - 1]:
+                vp, up = int(vu[c, i - 1, 0]), int(vu[c, i - 1, 1])
+                if (vp, up) != (vi, ui):
+                    steep = abs(vi - vp) > abs(ui - up)
+                    a0, b0, a1, b1 = (vp, up, vi, ui) if steep else (up, vp, ui, vi)
+                    if a0 > a1:
+                        a0, b0, a1, b1 = a1, b1, a0, b0
+                    grad = ((b1 - b0) * 65536) // (a1 - a0)
+                    for j in range(a1 - a0 + 1):
+                        y = b0 * 65536 + grad * j
+                        row, f = y >> 16, (y & 0xffff) >> 8
+                        for r, cov in ((row, 255 - f), (row + 1, f)):
+                            put(*((r, a0 + j) if steep else (a0 + j, r)), i + 1, cov)
+            for dy in range(-radius, radius + 1):
+                for dx in range(-hw[abs(dy)], hw[abs(dy)] + 1):
+                    put(ui + dx, vi + dy, i + 1, 255)
+        img = src[c].astype(np.int64).copy()
+        for (y, x), (key1, cov) in claim.items():
+            a = cov + (cov >> 7)
+            img[y, x] = (pal[int(colour_id[key1 - 1]) & 1] * a + img[y, x] * (256 - a) + 128) >> 8
+        r0, q0 = divmod(c, cols)
+        out[r0 * H:(r0 + 1) * H, q0 * W:(q0 + 1) * W] = img.astype(np.uint8)
+    return out
+
+
+def test_wu_restatement_in_c_equals_its_python_twin():
+    """The anti-aliased segment EXTENSION (no reference semantics): the C definition the HIP kernel is checked against,
+    against an independent Python twin, on polylines of every octant incl. points outside the image and broken links."""
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        C, H, W, N = 3, 48, 80, 40
+        src = rng.integers(0, 256, (C, H, W, 3), dtype=np.uint8)
+        vu = np.zeros((C, N, 2))
+        vu[:, :, 0] = rng.uniform(0, H, (C, N))
+        vu[:, :, 1] = rng.uniform(0, W, (C, N))
+        if trial % 2:                                   # short steps: the common case (neighbouring polyline points)
+            vu[:, 1:] = vu[:, :1] + np.cumsum(rng.uniform(-3, 3, (C, N - 1, 2)), axis=1)
+            vu[:, :, 0] = np.clip(vu[:, :, 0], 0, H - 0.01)
+            vu[:, :, 1] = np.clip(vu[:, :, 1], 0, W - 0.01)
+        vis = (rng.random((C, N)) < 0.85).astype(np.uint8)
+        col = rng.integers(0, 2, N).astype(np.uint8)
+        link = (rng.random(N) < 0.8)
+        link[0] = False
+        got = O.frame_render_flat_wu(src, vu, vis, col, link)
+        want = _wu_python(src, vu, vis, col, link)
+        assert np.array_equal(got, want), trial
+        plain = O.frame_render_flat(src, vu, vis, col)
+        assert not np.array_equal(got, plain)           # the segments show
+    # axis-aligned and 45-degree lines have exact rows: full coverage on the line, nothing beside it
+    src = np.zeros((1, 16, 16, 3), np.uint8)
+    vu = np.array([[[2.0, 2.0], [2.0, 12.0], [12.0, 12.0], [5.0, 5.0]]])
+    out = O.frame_render_flat_wu(src, vu, np.ones((1, 4), np.uint8), np.zeros(4, np.uint8), np.array([0, 1, 1, 1], bool), radius=0)
+    grey = tuple(int(v) for v in O.GREY_RGB[::-1])
+    assert all(tuple(out[2, x]) == grey for x in range(2, 13)) and not out[1, 5].any() and not out[3, 5].any()
+    assert all(tuple(out[y, 12]) == grey for y in range(2, 13)) and not out[7, 11].any()
+    assert all(tuple(out[k, k]) == grey for k in range(5, 13)) and not out[6, 5].any()
