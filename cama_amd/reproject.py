@@ -290,6 +290,9 @@ class CameraManager(BaseManager):
         asks for rasterised segments) -- neighbouring points of an instance are also joined by one-pixel Bresenham segments
         (an instance's "joined" flags when present, else every point to its predecessor); cama_stamp_polylines."""
         import torch
+        if isinstance(segments, str) and segments.lower() == "wu":
+            raise ValueError('segments="wu" (anti-aliased) is offered by the batched path only: ClipManager.render_clip / '
+                             'the lazy handles of yield_frame with pre-resized frames')
         maps_2d = list(maps_2d)
         vu, counts, classes = flatten_instances(maps_2d, width=2)
         if vu.shape[0] == 0:
