@@ -445,7 +445,8 @@ class Job:
             return torch.empty(self.eng.mosaic_shape(rig, self.F), dtype=torch.uint8, device=self.device)
         first = 1 if self.frame_range is None else 0                    # image index 0 is never rendered
         shape = self.eng.mosaic_shape(rig, self.F)
-        if int(np.prod(shape)) > (8 << 30) and len(self.scenes) == 1:   # a long clip: one placed buffer per launch
+        if int(np.prod(shape)) > (8 << 30) and len(self.scenes) == 1 and self.frame_range is not None:
+            # a long clip (frame-sharded jobs hash single frames: a ChunkedMosaic serves them): one placed buffer per launch
             per = max(1, min(self.F, self.eng.max_frames_per_call(cm._static("cama").device(), rig, pipelined=self.pipelined)))
             srcs = [frames[first + lo:first + min(self.F, lo + per)] for lo in range(0, self.F, per)]
             return self.eng.alloc_mosaics(rig, srcs, pool=None if K is None else K * len(srcs) // 4)
