@@ -550,7 +550,7 @@ class Engine:
     def alloc_mosaics(self, rig, srcs, cols=3, pool=None, reps=3, settle=True):
         """The same for a long clip rendered in several launches: `srcs` = the source view [F_k,C,H,W,3] of every launch;
         returns a ChunkedMosaic with one separately allocated buffer per launch.  A pool of `pool` allocations of the
-        largest launch's size (default CAMA_AUDITION_POOL or 4 per launch, at most 3/4 of the free memory) is timed against
+        largest launch's size (default CAMA_AUDITION_POOL or 6 per launch, at most 3/4 of the free memory) is timed against
         the first launch's source -- a destination's speed is mostly its own (3.3 GB launches: 0.99 ms into one buffer in
         four to six, 1.07-1.085 ms into the others, whichever source) -- and the fastest len(srcs) are kept, the rest freed
         to the driver.  pool = 0 / CAMA_AUDITION=0: plain allocations.  Also the way to place the mosaics of MANY scenes
@@ -563,7 +563,7 @@ class Engine:
         shape = self.mosaic_shape(rig, Fmax, cols)
         nbytes = int(np.prod(shape))
         if pool is None:
-            pool = 0 if os.environ.get("CAMA_AUDITION", "16") == "0" else int(os.environ.get("CAMA_AUDITION_POOL", str(4 * n)))
+            pool = 0 if os.environ.get("CAMA_AUDITION", "16") == "0" else int(os.environ.get("CAMA_AUDITION_POOL", str(6 * n)))
         with torch.cuda.device(self.device):
             free, _ = torch.cuda.mem_get_info(self.device)
             P = min(int(pool), int(free * 3 // 4 // nbytes))
