@@ -495,3 +495,30 @@ def test_placed_buffers_render_the_same_bytes(monkeypatch):
     torch.cuda.synchronize()
     assert torch.equal(torch.cat([c for _, _, c in chunked.spans()]), plain)
     assert isinstance(eng.alloc_mosaics(rig, srcs, pool=0), type(chunked))      # pool 0: plain allocations, same type
+
+
+@pytest.mark.gpu
+def test_fullsize_site_scenes_equal_the_oracle():
+    """configs[3] at FULL size as bench.py runs it on one GPU (12 scenes over three 10^6-vertex site maps, 40 frames at
+    1600x900): one scene of every site plus a second drive over scene 0's site,
+    rendered through the planned pipeline (cull pre-pass on its own stream, demand-sized scratch) -- whole-scene hashes against
+    the oracle-rendered golden hashes (tests/golden/gen_scene_hashes.py site-full)."""
+    import torch
+    from cama_amd import runtime
+    a = _args(map="site", verts=1000000, sites=3, scenes=12)
+    golden = shard.load_golden_hashes(GOLDEN, bench.args_key(a))
+    assert golden and len(golden) == 12
+    dev = torch.device("cuda:0")
+    eng = runtime.engine()
+    out = None
+    for sid in (0, 1, 2, 3):
+        cm, frames, _ = bench.build_scene(a, sid, dev)
+        if out is None:
+            out = torch.empty(eng.mosaic_shape(cm._rig(), a.frames), dtype=torch.uint8, device=dev)
+        out.fill_(0xA5)
+        cm.render_clip("cama", out=out, pipelined=True)
+        eng.join()
+        torch.cuda.synchronize()
+        assert shard.overlay_hash(out) == golden[sid], f"scene {sid} (site {sid % 3})"
+        del cm, frames
+    assert eng.pipeline_info()["planned_launches"] >= 4
