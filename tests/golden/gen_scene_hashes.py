@@ -5,6 +5,7 @@
     python tests/golden/gen_scene_hashes.py stress                                # BASELINE configs[4], sampled frames
     python tests/golden/gen_scene_hashes.py small                                 # reduced-size twins for -m gpu tests
     python tests/golden/gen_scene_hashes.py site-full                             # BASELINE configs[3] at full size (12 scenes)
+    python tests/golden/gen_scene_hashes.py custom --bench-args "--map random --verts 1000000"   # any other bench.py line
 
 Writes / updates tests/golden/scene_hashes.json: {workload key: {unit id: [lo hex, hi hex]}} where a unit is a scene id
 (whole-scene workloads: hash over the scene's [F, 2H, 3W, 3] mosaics) or a frame position (frame-sharded stress: hash of
@@ -104,7 +105,8 @@ def update(key, units):
 def main():
     import bench
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["sweep", "stress", "small", "site", "site-full"])
+    ap.add_argument("what", choices=["sweep", "stress", "small", "site", "site-full", "custom"])
+    ap.add_argument("--bench-args", default="", help='custom: the bench.py arguments of the workload, e.g. "--map random --verts 1000000"')
     ap.add_argument("--scenes", type=int, default=bench.SWEEP_SCENES)
     ap.add_argument("--jobs", type=int, default=min(8, os.cpu_count() or 1))
     a = ap.parse_args()
@@ -116,6 +118,13 @@ def main():
                {str(s): [lo, hi] for s, lo, hi in res})
     elif a.what == "site":
         site_twin(a.jobs)
+    elif a.what == "custom":
+        # any other whole-scene workload of bench.py (its non-BASELINE lines: big maps, other sizes): every scene's hash
+        bargs = bench.parse_args(a.bench_args.split())
+        n = max(1, bargs.scenes)
+        with mp.get_context("spawn").Pool(min(a.jobs, n)) as pool:
+            res = pool.map(scene_hash, [(bargs, s) for s in range(n)], chunksize=1)
+        update(bench.args_key(bargs), {str(s): [lo, hi] for s, lo, hi in res})
     elif a.what == "site-full":
         # BASELINE configs[3] as bench.py runs it on one GPU: 12 scenes over three 10^6-vertex site maps, 40 frames at 1600x900
         bargs = bench.parse_args(["--map", "site", "--verts", "1000000", "--sites", "3", "--scenes", "12"])

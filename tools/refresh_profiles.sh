@@ -7,7 +7,7 @@ set -u
 tag=${1:-r04}
 ulimit -c 0
 tools/profile_workload.sh $tag headline "N=10000" --steps 20 --warmup 5 > /dev/null
-tools/profile_workload.sh $tag site1e6 "N=1000000 MAP=site" --map site --verts 1000000 --steps 30 --warmup 5 --no-verify > /dev/null
+tools/profile_workload.sh $tag site1e6 "N=1000000 MAP=site" --map site --verts 1000000 --steps 30 --warmup 5 > /dev/null
 tools/profile_workload.sh $tag random1e6 "N=1000000 MAP=random" --map random --verts 1000000 --steps 30 --warmup 5 > /dev/null
 tools/profile_workload.sh $tag stress "N=1000000 MAP=random F=1000" --map random --verts 1000000 --frames 1000 --shard-frames --steps 10 --warmup 2 > /dev/null
 tools/profile_workload.sh $tag raw35 "N=10000 RAW=1 H=540 W=960" --raw-frames --height 540 --width 960 --steps 100 --warmup 5 > /dev/null
