@@ -161,7 +161,7 @@ def args_key(args, unit="scene"):
     """workload_key of an argument set (+ the site count, which changes which map a scene is rendered on)."""
     key = workload_key(args.frames, args.verts, args.width, args.height, args.map, raw=getattr(args, "raw_frames", False),
                        unit=unit)
-    return key + (f",sites={args.sites}" if getattr(args, "sites", 0) > 0 else "") + (",segments" if _segments(args) else "")
+    return key + (f",sites={args.sites}" if getattr(args, "sites", 0) > 0 else "") + ({False: "", True: ",segments", "wu": ",segments=wu"}[_segments(args)])
 
 
 def replace_map(cm, args, seed):

@@ -49,7 +49,11 @@ def scene_setup(bargs, seed):
             instance_maps = {}
         bench.replace_map(Holder, bargs, seed)
         static = Holder.instance_maps["cama"]
-    xyz, col, _, _ = O.flatten_instances(static)
+    xyz, col, counts, _ = O.flatten_instances(static)
+    if getattr(bargs, "segments", False) or getattr(bargs, "wu", False):
+        # the segment extensions: every point but the first of its instance is joined to its predecessor
+        link = np.concatenate([np.arange(n) > 0 for n in counts]) if len(counts) else np.zeros(0, bool)
+        col = (col, link)
     stamps, poses = O.pose_track(clip, att, dict(DEFAULT_CAMA_CONFIGS), "cama")
     secs = O.sensor_seconds(att, "camera_front")
     w2c = [O.frame_world2chassis(stamps, poses, secs[i]) for i in range(1, len(secs))]
@@ -65,6 +69,9 @@ def render_frame(bargs, seed, pos, xyz, col, cams, w2c):
     per_frame = 6 * H * W * 3
     src = frame_pattern_np(seed, (6, H, W, 3), first=(pos + 1) * per_frame)
     flat = O.frame_project_flat(xyz, w2c[pos], cams, W, H)
+    if isinstance(col, tuple):                          # (colour, link): bench.py --segments [--wu]
+        fn = O.frame_render_flat_wu if getattr(bargs, "wu", False) else O.frame_render_flat_segments
+        return fn(src, flat["vu"], flat["vis"], col[0], col[1])
     return O.frame_render_flat(src, flat["vu"], flat["vis"], col)
 
 
