@@ -30,6 +30,9 @@ if REPO not in sys.path:
 OUT = os.path.join(HERE, "scene_hashes.json")
 
 
+_RAW_MAPS = {}                                          # id(cams) -> per-camera (mapx, mapy): one scene's cameras at a time
+
+
 def scene_setup(bargs, seed):
     """(xyz, colour, cams, [w2c per rendered frame]) of scene `seed`, all through the oracle."""
     import bench
@@ -66,8 +69,13 @@ def render_frame(bargs, seed, pos, xyz, col, cams, w2c):
     from oracle import cama_oracle as O
     from cama_amd.synth import frame_pattern_np
     H, W = bargs.height, bargs.width
-    per_frame = 6 * H * W * 3
-    src = frame_pattern_np(seed, (6, H, W, 3), first=(pos + 1) * per_frame)
+    if getattr(bargs, "raw_frames", False):
+        # bench.py --raw-frames: 1600x900 sensor frames, undistorted + resized per camera (cama/reproject.py:232-240) before drawing
+        raw = frame_pattern_np(seed, (6, 900, 1600, 3), first=(pos + 1) * 6 * 900 * 1600 * 3)
+        maps = _RAW_MAPS.setdefault(id(cams), [O.undistort_map(c["K_origin"], c["d_origin"], c["K"], W, H) for c in cams])
+        src = np.stack([O.remap_bilinear(raw[c], maps[c][0], maps[c][1]) for c in range(6)])
+    else:
+        src = frame_pattern_np(seed, (6, H, W, 3), first=(pos + 1) * 6 * H * W * 3)
     flat = O.frame_project_flat(xyz, w2c[pos], cams, W, H)
     if isinstance(col, tuple):                          # (colour, link): bench.py --segments [--wu]
         fn = O.frame_render_flat_wu if getattr(bargs, "wu", False) else O.frame_render_flat_segments
