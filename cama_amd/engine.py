@@ -488,19 +488,20 @@ class Engine:
         if 6 * F * rig.C * rig.H * rig.W < (7 << 28) or not self._probeable(rig, src):
             return
         L = self.lib
-        need = int(L.cama_render_scratch_bytes(0, F, rig.C, rig.H, rig.W, self.radius))
-        scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
-        w2c = torch.zeros((F, 16), dtype=torch.float64, device=self.device)
-        _lib.check(L.cama_bin_frames(None, None, None, 0, None, None, None, 0, 0, w2c.data_ptr(), F, rig.c2cam.data_ptr(),
-                                     rig.K.data_ptr(), rig.C, self.crop.ctypes.data, rig.W, rig.H, self.radius,
-                                     scratch.data_ptr(), scratch.numel(), self._stream()))
-        for _ in range(4 * 3 + 1):
-            _lib.check(L.cama_overlay_frames(src.data_ptr(), out.data_ptr(), 0, F, rig.C, rig.H, rig.W, cols, self.radius,
-                                             self.halfwidth.ctypes.data, self.palette.ctypes.data, scratch.data_ptr(),
-                                             scratch.numel(), self._stream()))
-            torch.cuda.current_stream(self.device).synchronize()
-            if self.overlay_mapping()["decided"] >= 0:
-                break
+        with torch.cuda.device(self.device):
+            need = int(L.cama_render_scratch_bytes(0, F, rig.C, rig.H, rig.W, self.radius))
+            scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+            w2c = torch.zeros((F, 16), dtype=torch.float64, device=self.device)
+            _lib.check(L.cama_bin_frames(None, None, None, 0, None, None, None, 0, 0, w2c.data_ptr(), F, rig.c2cam.data_ptr(),
+                                         rig.K.data_ptr(), rig.C, self.crop.ctypes.data, rig.W, rig.H, self.radius,
+                                         scratch.data_ptr(), scratch.numel(), self._stream()))
+            for _ in range(4 * 3 + 1):
+                _lib.check(L.cama_overlay_frames(src.data_ptr(), out.data_ptr(), 0, F, rig.C, rig.H, rig.W, cols, self.radius,
+                                                 self.halfwidth.ctypes.data, self.palette.ctypes.data, scratch.data_ptr(),
+                                                 scratch.numel(), self._stream()))
+                torch.cuda.current_stream(self.device).synchronize()
+                if self.overlay_mapping()["decided"] >= 0:
+                    break
 
     def alloc_mosaic(self, rig, src, cols=3, candidates=None, reps=3):
         """A mosaic buffer [F, rows*H, cols*W, 3] for frames `src` [F,C,H,W,3] that is going to be rendered into MANY times
