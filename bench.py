@@ -776,7 +776,11 @@ def plan(args):
         # before the timed region: candidate allocations of one mosaic / frames buffer at a time (Engine.alloc_mosaic, capped by
         # the engine at half of what is free, so it cannot be what does not fit)
         one = min(F, fpl) * frame_b if ranges[r] is not None else F * frame_b
-        rec["placement_transient_bytes"] = 0 if (args.audition == 0 or args.raw_frames) else (args.audition or 16) * one
+        # (one buffer: 16 candidates; the mosaics of a multi-scene chain / the launches of a long clip: one pool of 6 per buffer,
+        # of which the kept ones are already counted above)
+        n_buf = len(mine) if (ranges[r] is None and batched) else (-(-F // fpl) if ranges[r] is not None and F * frame_b > (8 << 30) else 1)
+        cands = (args.audition or 16) if n_buf == 1 else max((args.audition or 24) // 4, 2) * n_buf - n_buf
+        rec["placement_transient_bytes"] = 0 if (args.audition == 0 or args.raw_frames) else cands * one
         if do_stress:                                               # runs after the sweep's buffers are freed
             slo, shi = shard.frame_ranges(args.stress_frames, world)[r]
             sF = shi - slo
