@@ -10,7 +10,7 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 19
+ABI_VERSION = 20
 BIN_WORKLIST = 1
 BIN_SEGMENTS = 2
 BIN_SEGMENTS_WU = 4            # EXTENSION: discs + one-pixel segments between polyline neighbours (include/cama_hip.h)
@@ -74,6 +74,7 @@ SIGNATURES = {
     "cama_set_option": (_i32, [ctypes.c_char_p, _i64]),
     "cama_get_option": (_i32, [ctypes.c_char_p, ctypes.POINTER(_i64)]),
     "cama_stamp_polylines": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "cama_stamp_polylines_wu": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_circle_halfwidths": (_i32, [_i32, _vp]),
     "cama_overlay_band_rows": (_i32, [_i32]),
     "cama_jpeg_image_bytes": (_sz, []),

@@ -2274,6 +2274,31 @@ int cama_stamp_polylines(const double *vu, const uint8_t *colour_id, const uint8
     return CAMA_OK;
 }
 
+// cama_stamp_polylines with ANTI-ALIASED segments: the one-image counterpart of CAMA_BIN_SEGMENTS_WU (same definition).
+int cama_stamp_polylines_wu(const double *vu, const uint8_t *colour_id, const uint8_t *link, int64_t n, uint8_t *image, int32_t H,
+                            int32_t W, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr, void *scratch,
+                            size_t scratch_bytes, void *stream)
+{
+    if (int rc = check_common(n, 1, 1, W, H)) return rc;
+    if (n == 0) return CAMA_OK;
+    if (!vu || !colour_id || !image || !palette_bgr || !scratch) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (n >= ((int64_t)1 << 22)) return fail(CAMA_EINVAL, "anti-aliased segments: n must be below 2^22");
+    Disc disc;
+    if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
+    const size_t need = cama_stamp_scratch_bytes(H, W);
+    if (scratch_bytes < need) return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", scratch_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)H * W * 4, s));
+    hipLaunchKernelGGL(k_stamp_global_wu, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, vu, colour_id, link, n,
+                       (uint32_t *)scratch, H, W, disc);
+    HIP_TRY(hipGetLastError());
+    const int64_t npix = (int64_t)H * W;
+    hipLaunchKernelGGL(k_apply_owner_wu, dim3((unsigned)((npix + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                       (const uint32_t *)scratch, image, npix, make_palette(palette_bgr));
+    HIP_TRY(hipGetLastError());
+    return CAMA_OK;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------ device JPEG decode

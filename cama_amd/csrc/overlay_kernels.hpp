@@ -743,6 +743,53 @@ __global__ __launch_bounds__(BLOCK) void k_segments_global(const double *__restr
     }
 }
 
+// ... the anti-aliased variant of the two kernels above for the one-image path (cama_stamp_polylines_wu): owner cells are
+// ((key + 1) << 8) | coverage, discs claim 255, segments the Wu coverages of wu_line_claims (oracle/cama_oracle.c).
+__global__ __launch_bounds__(BLOCK) void k_stamp_global_wu(const double *__restrict__ vu, const uint8_t *__restrict__ colour,
+                                                           const uint8_t *__restrict__ link, int64_t n,
+                                                           uint32_t *__restrict__ owner, int H, int W, Disc disc)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int v = (int)vu[2 * i], u = (int)vu[2 * i + 1];
+    const uint32_t key1 = (((((uint32_t)i) << 1) | (uint32_t)(colour[i] & 1)) + 1u) << 8;
+    const auto claim = [&](int x, int y, uint32_t val) {
+        if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H && (val & 255u)) atomicMax(&owner[(size_t)y * W + x], val);
+    };
+    for (int dy = -disc.radius; dy <= disc.radius; ++dy) {
+        const int hw = disc_halfwidth(disc, abs(dy));
+        for (int dx = -hw; dx <= hw; ++dx) claim(u + dx, v + dy, key1 | 255u);
+    }
+    if (i == 0 || !link || !link[i]) return;
+    const int yy0 = (int)vu[2 * (i - 1)], x0 = (int)vu[2 * (i - 1) + 1];
+    if (yy0 == v && x0 == u) return;
+    const bool steep = abs(v - yy0) > abs(u - x0);
+    int a0 = steep ? yy0 : x0, b0 = steep ? x0 : yy0, a1 = steep ? v : u, b1 = steep ? u : v;
+    if (a0 > a1) { int t = a0; a0 = a1; a1 = t; t = b0; b0 = b1; b1 = t; }
+    const int da = a1 - a0, num = (b1 - b0) * 65536;
+    int grad = num / da;
+    if (num % da != 0 && num < 0) grad -= 1;
+    for (int j = 0; j <= da; ++j) {
+        const int y = b0 * 65536 + grad * j, row = y >> 16, a = a0 + j;
+        const uint32_t f = ((uint32_t)y & 0xffffu) >> 8;
+        if (steep) { claim(row, a, key1 | (255u - f)); claim(row + 1, a, key1 | f); }
+        else { claim(a, row, key1 | (255u - f)); claim(a, row + 1, key1 | f); }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_apply_owner_wu(const uint32_t *__restrict__ owner, uint8_t *__restrict__ image,
+                                                          int64_t npix, Palette pal)
+{
+    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= npix) return;
+    const uint32_t o = owner[p];
+    if (!o) return;
+    const uint32_t col = (((o >> 8) - 1u) & 1u) ? pal.c[1] : pal.c[0], cov = o & 255u, a = cov + (cov >> 7);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        image[3 * p + k] = (uint8_t)((((col >> (8 * k)) & 255u) * a + (uint32_t)image[3 * p + k] * (256u - a) + 128u) >> 8);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_apply_owner(const uint32_t *__restrict__ owner,
                                                        uint8_t *__restrict__ image, int64_t npix, Palette pal)
 {

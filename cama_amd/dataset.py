@@ -399,9 +399,6 @@ class ClipManager:
         out = {}
         for cm in self.cm_list:
             image = cm.read_resized_image_by_index(image_idx)
-            if segments == "wu":
-                raise ValueError('configs["segments"] = "wu" is offered by the batched path only (lazy handles of this '
-                                 'ClipManager with pre-resized frames, or render_clip)')
             out[cm.camera_name] = cm.render_maps(image, maps_2d_dict[cm.camera_name], segments=segments) if segments \
                 else cm.render_maps(image, maps_2d_dict[cm.camera_name])
         return out

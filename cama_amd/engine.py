@@ -1097,10 +1097,11 @@ class Engine:
         self._scratch = None
         torch.cuda.empty_cache()
 
-    def stamp_points(self, image, vu, colour_id, link=None):
+    def stamp_points(self, image, vu, colour_id, link=None, wu=False):
         """In-place render_maps on one device image [H,W,3]: points (n,2) (v,u) float64 in draw order.  EXTENSION:
         `link` (n,) bool -- point k with link[k] is also joined to point k - 1 by a one-pixel Bresenham segment
-        (cama_stamp_polylines; no reference semantics)."""
+        (cama_stamp_polylines; no reference semantics), or -- wu=True -- by an anti-aliased Wu line whose coverages are
+        blended once per pixel (cama_stamp_polylines_wu)."""
         torch = _torch()
         with torch.cuda.device(self.device):
             assert image.is_cuda and image.dtype == torch.uint8 and image.is_contiguous() and image.shape[2] == 3
@@ -1114,8 +1115,8 @@ class Engine:
                 assert lk.shape[0] == n
             need = self.lib.cama_stamp_scratch_bytes(H, W)
             scratch = self._scratch_buf(need)
-            _lib.check(self.lib.cama_stamp_polylines(p.data_ptr(), col.data_ptr(), None if lk is None else lk.data_ptr(), n,
-                                                     image.data_ptr(), H, W, self.radius, self.halfwidth.ctypes.data,
-                                                     self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(),
-                                                     self._stream()))
+            fn = self.lib.cama_stamp_polylines_wu if wu else self.lib.cama_stamp_polylines
+            _lib.check(fn(p.data_ptr(), col.data_ptr(), None if lk is None else lk.data_ptr(), n,
+                          image.data_ptr(), H, W, self.radius, self.halfwidth.ctypes.data,
+                          self.palette.ctypes.data, scratch.data_ptr(), scratch.numel(), self._stream()))
             return image

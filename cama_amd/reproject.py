@@ -288,11 +288,10 @@ class CameraManager(BaseManager):
         `image` (H,W,3) uint8 BGR is updated in place and returned, like cv2.circle does.
         segments=True: EXTENSION without reference semantics (the reference draws discs only; BASELINE.json's north_star
         asks for rasterised segments) -- neighbouring points of an instance are also joined by one-pixel Bresenham segments
-        (an instance's "joined" flags when present, else every point to its predecessor); cama_stamp_polylines."""
+        (an instance's "joined" flags when present, else every point to its predecessor); cama_stamp_polylines.
+        segments="wu": anti-aliased Wu lines instead, blended once per pixel by coverage; cama_stamp_polylines_wu."""
         import torch
-        if isinstance(segments, str) and segments.lower() == "wu":
-            raise ValueError('segments="wu" (anti-aliased) is offered by the batched path only: ClipManager.render_clip / '
-                             'the lazy handles of yield_frame with pre-resized frames')
+        wu = isinstance(segments, str) and segments.lower() == "wu"      # anti-aliased variant: cama_stamp_polylines_wu
         maps_2d = list(maps_2d)
         vu, counts, classes = flatten_instances(maps_2d, width=2)
         if vu.shape[0] == 0:
@@ -304,6 +303,6 @@ class CameraManager(BaseManager):
                                    for ins in maps_2d if len(ins["points"])])
         eng = runtime.engine()
         dev = torch.from_numpy(np.ascontiguousarray(image)).to(eng.device)
-        eng.stamp_points(dev, vu, colour, link=link)
+        eng.stamp_points(dev, vu, colour, link=link, wu=wu)
         image[...] = dev.cpu().numpy()
         return image

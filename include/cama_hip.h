@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 19
+#define CAMA_ABI_VERSION 20
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -455,6 +455,12 @@ size_t cama_stamp_scratch_bytes(int32_t H, int32_t W);
  * index.  link == NULL is cama_stamp_points.  Checked against the oracle's own restatement, never the default.
  */
 int cama_stamp_polylines(const double *vu, const uint8_t *colour_id, const uint8_t *link, int64_t n,
+                         uint8_t *image, int32_t H, int32_t W,
+                         int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
+                         void *scratch, size_t scratch_bytes, void *stream);
+/* The same with ANTI-ALIASED segments (Wu lines, coverages blended once per pixel): the one-image counterpart of
+ * CAMA_BIN_SEGMENTS_WU, same definition (oracle/cama_oracle.c: oracle_render_frame_wu); n < 2^22.  (No reference counterpart.) */
+int cama_stamp_polylines_wu(const double *vu, const uint8_t *colour_id, const uint8_t *link, int64_t n,
                          uint8_t *image, int32_t H, int32_t W,
                          int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
                          void *scratch, size_t scratch_bytes, void *stream);

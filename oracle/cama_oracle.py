@@ -373,6 +373,18 @@ def render_instances(image, maps_2d, radius=2, segments=False):
     L = lib()
     H, W = image.shape[:2]
     assert image.dtype == np.uint8 and image.flags.c_contiguous
+    if isinstance(segments, str) and segments.lower() == "wu":
+        # the anti-aliased variant: the flat list of the image's points through oracle_render_frame_wu (one camera, all visible)
+        pts = [ins["points"].astype(np.int32) for ins in maps_2d if len(ins["points"])]
+        if not pts:
+            return image
+        link = np.concatenate([np.asarray(ins.get("joined", np.arange(len(ins["points"])) > 0), bool)
+                               for ins in maps_2d if len(ins["points"])])
+        col = np.concatenate([np.full(len(ins["points"]), 0 if ins["class"] == "lane_marking" else 1, np.uint8)
+                              for ins in maps_2d if len(ins["points"])])
+        vu = np.concatenate(pts).astype(np.float64)[None]
+        image[...] = frame_render_flat_wu(image[None], vu, np.ones((1, vu.shape[1]), np.uint8), col, link, radius=radius, cols=1)
+        return image
     base = image.ctypes.data
     step = image.strides[0]
     for ins in maps_2d:
