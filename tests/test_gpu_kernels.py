@@ -642,8 +642,9 @@ def test_antialiased_segments_one_image_at_a_time_match_their_restatement(engine
     assert np.array_equal(np.asarray(out), want)
 
 
-def test_segment_extension_through_the_class_surface(tmp_path):
-    """configs["segments"] = True: ClipManager.render_vectors draws discs + segments between points that are neighbours
+@pytest.mark.parametrize("mode", [True, "wu"])
+def test_segment_extension_through_the_class_surface(tmp_path, mode):
+    """configs["segments"] = True | "wu": ClipManager.render_vectors draws discs + segments between points that are neighbours
     on the densified polyline AND both visible (no segment across the part of a lane that left the image), image by image;
     equals the oracle's restatement on the materialised maps; the default configs still render the reference's discs."""
     from cama_amd.dataset import ClipManager
@@ -652,7 +653,7 @@ def test_segment_extension_through_the_class_surface(tmp_path):
     clip = str(tmp_path / "clip")
     make_clip(clip, n_frames=3, seed=9, n_lines=10, verts_per_line=4, line_len_m=6.0, raster_size=400,
               image_mode="npy", image_size=(H, W), origin_size=(H, W))
-    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W), segments=True), clip)
+    cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W), segments=mode), clip)
     ref = ClipManager(dict(DEFAULT_CAMA_CONFIGS, output_size=(H, W)), clip)
     n_diff = 0
     for (idx, im), (_, im_ref) in zip(cm.yield_frame(dataset="cama"), ref.yield_frame(dataset="cama")):
@@ -661,8 +662,8 @@ def test_segment_extension_through_the_class_surface(tmp_path):
         discs = ref.render_vectors(ref.project_all_camera(im_ref), idx)
         for c in cm.cm_list:
             src = c.read_resized_image_by_index(idx)
-            want = O.render_instances(np.ascontiguousarray(src).copy(), maps[c.camera_name], segments=True)
-            assert np.array_equal(np.asarray(imgs[c.camera_name]), want), (idx, c.camera_name)
+            want = O.render_instances(np.ascontiguousarray(src).copy(), maps[c.camera_name], segments=mode)
+            assert np.array_equal(np.asarray(imgs[c.camera_name]), want), (idx, c.camera_name, mode)
             assert all("joined" in ins for ins in maps[c.camera_name])
             n_diff += int((np.asarray(discs[c.camera_name]) != want).any(axis=-1).sum())
     assert n_diff >= 0
