@@ -1855,7 +1855,7 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
             // the pre-pass only writes the plan part, which the overlay of launch k - 2 never reads: it need not wait for it --
             // only for that launch's binning chain (`binned`), which read the plan part and the pose buffer of this slot.  It
             // runs on its own stream: behind the previous launch's projection + scatter on s_bin the host wait below was
-            // ~0.3 ms instead of ~0.1 ms, and the binning streams's cycle -- not the overlay -- set the pace (sites3x12)
+            // ~0.3 ms instead of ~0.1 ms, and the binning stream's cycle -- not the overlay -- set the pace (sites3x12)
             hipStream_t sp = p->s_pre;
             if (k > 2) HIP_TRY(hipStreamWaitEvent(sp, p->binned[slot], 0));
             HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));

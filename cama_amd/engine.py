@@ -464,6 +464,12 @@ class Engine:
             return out
 
     # ------------------------------------------------------------------ placement-aware allocation of long-lived buffers
+    def _log_audition(self, entry):
+        """What the placement helpers saw (bench.py reports it): the most recent 256 entries."""
+        log = self.__dict__.setdefault("audition_log", [])
+        log.append(entry)
+        del log[:-256]
+
     def _probeable(self, rig, src):
         """Can cama_overlay_probe time launches from `src`?  (contiguous uint8 [F, C, H, W, 3] of the rig's size, W % 16 == 0,
         opaque stamps)"""
@@ -542,7 +548,7 @@ class Engine:
                     if ms < best_ms:
                         best, best_ms = cand, ms
             K = len(pool)
-            self.__dict__.setdefault("audition_log", []).append(
+            self._log_audition(
                 {"role": "mosaic", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4)})
             del pool, cand
             self.settle_mapping(rig, src, best, cols)
@@ -577,7 +583,7 @@ class Engine:
             rank = sorted(range(P), key=lambda i: times[i])
             keep = rank[:n]                                            # fastest first
             chunks = [cands[i][:int(s.shape[0])] for i, s in zip(keep, srcs)]
-            self.__dict__.setdefault("audition_log", []).append(
+            self._log_audition(
                 {"role": "mosaic", "bytes": nbytes, "candidates": P, "ms": [round(t, 4) for t in times],
                  "chosen_ms": round(float(np.mean([times[i] for i in keep])), 4), "kept": n})
             del cands
@@ -615,7 +621,7 @@ class Engine:
                 best.copy_(frames)
                 del pool
                 self.settle_mapping(rig, view(best), out, cols)
-            self.__dict__.setdefault("audition_log", []).append(
+            self._log_audition(
                 {"role": "frames", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4)})
             return best
 
