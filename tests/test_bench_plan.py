@@ -35,3 +35,19 @@ def test_plan_refuses_a_job_that_cannot_fit():
     assert p.returncode == 1 and d["fits"] is False and not d["ranks"][0]["fits"]
     p, d = _plan(["--gpus", "1", "--map", "random", "--verts", "1000000", "--frames", "1000", "--shard-frames"])
     assert p.returncode == 0 and d["ranks"][0]["frame_range"] == [0, 1000] and d["ranks"][0]["frames_per_launch"] == 128
+
+
+def test_segment_modes_and_workload_keys():
+    """configs["segments"] / --segments [--wu]: False, True (Bresenham) or "wu" (anti-aliased); the three render different bytes,
+    so their golden-hash keys must differ."""
+    import pytest
+    import bench
+    from cama_amd.dataset import _segments_mode
+    assert _segments_mode(False) is False and _segments_mode(None) is False and _segments_mode(0) is False
+    assert _segments_mode(True) is True and _segments_mode(1) is True and _segments_mode("bresenham") is True
+    assert _segments_mode("wu") == "wu" and _segments_mode("WU") == "wu" and _segments_mode("false") is False
+    with pytest.raises(ValueError):
+        _segments_mode("thick")
+    keys = {bench.args_key(bench.parse_args(a)) for a in ([], ["--segments"], ["--segments", "--wu"])}
+    assert len(keys) == 3
+    assert bench._segments(bench.parse_args(["--segments", "--wu"])) == "wu" and bench._segments(bench.parse_args(["--segments"])) is True
