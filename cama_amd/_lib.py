@@ -118,9 +118,29 @@ def lib():
     return _lib
 
 
+ENOMEM = -3                    # CAMA_ENOMEM: a pipeline could not grow its own scratch
+
+
 def check(rc):
     if rc != 0:
-        raise CamaHipError(f"libcama_hip error {rc}: {lib().cama_last_error().decode()}")
+        msg = f"libcama_hip error {rc}: {lib().cama_last_error().decode()}"
+        if rc == ENOMEM:
+            # the same exception torch's allocator raises, so the callers' out-of-memory handling (ClipManager.render_clip:
+            # halve the launch) covers memory the library allocates itself
+            import torch
+            raise torch.OutOfMemoryError(msg)
+        raise CamaHipError(msg)
+
+
+def call_retrying_oom(fn, *args):
+    """fn(*args) -> check(); on CAMA_ENOMEM release what torch's caching allocator has parked (hipMalloc inside the library
+    cannot use it) and try once more before raising torch.OutOfMemoryError."""
+    rc = fn(*args)
+    if rc == ENOMEM:
+        import torch
+        torch.cuda.empty_cache()
+        rc = fn(*args)
+    check(rc)
 
 
 def circle_halfwidths(radius):

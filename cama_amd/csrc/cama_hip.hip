@@ -1794,8 +1794,13 @@ static int pipeline_grow(cama_pipeline *p, char **buf, size_t *have, size_t need
     const size_t bytes = align_up(need + need / 4, (size_t)2 << 20);
     char *raw = nullptr;
     const hipError_t e = hipMalloc((void **)&raw, bytes + 2 * g);
-    if (e != hipSuccess)
-        return fail(CAMA_EHIP, "hipMalloc of %zu bytes of pipeline scratch -> %s", bytes + 2 * g, hipGetErrorString(e));
+    if (e != hipSuccess) {
+        // out of memory is the caller's to handle (render fewer frames per launch; memory parked in the caller's own caching
+        // allocator can be released and the call repeated): a code of its own, and the sticky error is cleared
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? CAMA_ENOMEM : CAMA_EHIP, "hipMalloc of %zu bytes of pipeline scratch -> %s",
+                    bytes + 2 * g, hipGetErrorString(e));
+    }
     if (g) {
         HIP_TRY(hipMemsetAsync(raw, 0x5A, g, p->s_bin));
         HIP_TRY(hipMemsetAsync(raw + g + bytes, 0x5A, g, p->s_bin));

@@ -493,6 +493,10 @@ class ClipManager:
         crop = self.mm.crop_box()
         src_all = self.frame_source()
         fused_raw = getattr(src_all, "fused", False) and hasattr(src_all, "raw_batch")
+        if fused_raw and segments:
+            # (render_vectors falls back to the image-by-image path for this combination; a whole-clip render has no such path)
+            raise ValueError("render_clip: the segment extension needs pre-resized frames -- raw sensor frames are resampled inside "
+                             "the overlay kernel, which draws discs only (use a non-fused source or segments=False)")
         if frames_per_launch:
             step = frames_per_launch
         else:

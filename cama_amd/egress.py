@@ -52,10 +52,18 @@ class PinnedPool:
         lst = self.free.get(nbytes)
         if lst:
             return lst.pop()
+        return self.alloc(nbytes)
+
+    @staticmethod
+    def alloc(nbytes):
         return _torch().empty(nbytes, dtype=_torch().uint8, pin_memory=True)
 
     def give(self, buf, views_of=None):
-        """Hand a buffer back.  views_of: the ndarray whose slices went out to callers (or None: nothing went out)."""
+        """Hand a buffer back.  views_of: the ROOT ndarray of the views that went out to callers -- the array whose `.base`
+        is not an ndarray, i.e. what `tensor.numpy()` returned: numpy makes that the base of every derived view, however
+        many reshapes / slices lie in between -- or None: nothing went out."""
+        if views_of is not None and isinstance(getattr(views_of, "base", None), np.ndarray):
+            views_of = views_of.base                # a derived view was passed: watch its root instead
         if views_of is None:
             self._shelve(buf)
             return
@@ -100,7 +108,7 @@ class RenderBatch:
     def __init__(self, engine, image_ids, mosaic):
         self.engine, self.ids, self.mosaic = engine, [int(i) for i in image_ids], mosaic
         self._host = self._event = self._i420_dev = None
-        self._host_np = None
+        self._host_np = self._host_root = None
         self._fmt = None
 
     def start_egress(self, fmt="bgr24"):
@@ -156,7 +164,10 @@ class RenderBatch:
         if self._host_np is None:
             self._event.synchronize()
             B = int(self.mosaic.shape[0])
-            self._host_np = self._host.numpy().reshape(B, -1)
+            # numpy collapses the base chain of a view to the ROOT ndarray: every frame view handed out by bgr() has the
+            # array `.numpy()` returns as its base, not the reshaped one -- that root is what the pool has to watch
+            self._host_root = self._host.numpy()
+            self._host_np = self._host_root.reshape(B, -1)
             self._i420_dev = None
         return self._host_np
 
@@ -182,9 +193,9 @@ class RenderBatch:
             try:
                 if ev is not None:
                     ev.synchronize()            # the copy into it must be over before someone else reuses it
-                rows = self._host_np
-                self._host_np = None
-                _POOL.give(host, rows)
+                root = self._host_root
+                self._host_np = self._host_root = None
+                _POOL.give(host, root)
             except Exception:
                 pass
 

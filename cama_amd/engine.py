@@ -659,6 +659,8 @@ class Engine:
         out = np.zeros(4, np.uint64)
         with _torch().cuda.device(self.device):
             if scratch is None:             # the launch went through the pipeline's own scratch
+                if self._pipe is None:      # ... which shrink_frames_per_call() has since destroyed: nothing to read
+                    return None
                 _lib.check(self.lib.cama_pipeline_bin_stats(self._pipe["handle"], out.ctypes.data))
             else:
                 _lib.check(self.lib.cama_bin_stats(scratch.data_ptr(), scratch.numel(), N, F, C, H, W, self.radius,
@@ -815,11 +817,11 @@ class Engine:
                 P = self._pipeline()
                 staged = self._stage_poses(P, w2c)
                 T_ptr = staged[0] if staged is not None else T.data_ptr()
-                _lib.check(self.lib.cama_pipeline_render_raw35(
+                _lib.call_retrying_oom(self.lib.cama_pipeline_render_raw35,
                     P["handle"], x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T_ptr, F, rig.c2cam.data_ptr(),
                     rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, raw.data_ptr(), H0, W0, vrows[0].data_ptr(),
                     vrows[1].data_ptr(), vrows[2], out.data_ptr(), cols, self.radius, self.halfwidth.ctypes.data,
-                    self.palette.ctypes.data, None, None, 0, st))      # (scratch: the pipeline's own, demand-sized)
+                    self.palette.ctypes.data, None, None, 0, st)       # (scratch: the pipeline's own, demand-sized)
                 seq = int(self.lib.cama_pipeline_issued(P["handle"]))
                 # the overlay runs later, on the pipeline's own stream, and reads the tap tables: they belong to the
                 # launch's keep set like the frames and the map (a later call with another rig may evict the plan)
@@ -930,10 +932,10 @@ class Engine:
                     bflags |= _lib.BIN_SEGMENTS_WU
             # scratch: the pipeline's own (NULL, NULL) -- sized from what the launch's cull lets through when the map is
             # site-sized (the call then waits on the host for the pre-pass: include/cama_hip.h), else for the worst case
-            _lib.check(self.lib.cama_pipeline_render(
+            _lib.call_retrying_oom(self.lib.cama_pipeline_render,
                 P["handle"], x, y, z, dmap.is_f64, col, key, bnd, bflags, dmap.N, T_ptr, F, rig.c2cam.data_ptr(),
                 rig.K.data_ptr(), rig.C, cropa.ctypes.data, rig.W, rig.H, src.data_ptr(), out.data_ptr(), cols,
-                self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, None, None, 0, self._stream()))
+                self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, None, None, 0, self._stream())
             self._last_bin = (dmap.N, F, rig.C, rig.H, rig.W, bnd is not None, key is not None, None)
             # The internal streams are invisible to torch's caching allocator: what launch k reads / writes must stay
             # allocated until the library reports it complete (cama_pipeline_completed, a hipEventQuery over its ring
@@ -999,9 +1001,9 @@ class Engine:
             if pipelined:
                 P = self._pipeline()
                 T_ptr = self._stage_poses(P, poses)[0]
-                _lib.check(self.lib.cama_pipeline_render_scenes(
+                _lib.call_retrying_oom(self.lib.cama_pipeline_render_scenes,
                     P["handle"], host.ctypes.data, dev.data_ptr(), S, d0.is_f64, T_ptr, F, r0.C, cropa.ctypes.data, r0.W, r0.H,
-                    cols, self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, None, None, 0, self._stream()))
+                    cols, self.radius, self.halfwidth.ctypes.data, self.palette.ctypes.data, None, None, 0, self._stream())
                 seq = int(self.lib.cama_pipeline_issued(P["handle"]))
                 P["keep"].append((seq, None, dev, items[0][4], d0, r0,
                                   tuple(t for it in items for t in (it[3], it[4], it[0].soa, it[0].colour, it[0].sorted_soa,
@@ -1101,6 +1103,7 @@ class Engine:
             self.lib.cama_pipeline_destroy(self._pipe["handle"])      # (gives its own scratch back)
             self._pipe = None
         self._scratch = None
+        self._last_bin = None                   # (its statistics lived in the scratch that just went)
         torch.cuda.empty_cache()
 
     def stamp_points(self, image, vu, colour_id, link=None, wu=False):

@@ -17,7 +17,8 @@
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is
  *     enqueued asynchronously on it.
  *   - return 0 on success; <0 on error: CAMA_EINVAL (bad argument, nothing was
- *     enqueued), CAMA_EHIP (a HIP call failed).  cama_last_error() returns a
+ *     enqueued), CAMA_EHIP (a HIP call failed), CAMA_ENOMEM (pipeline-owned
+ *     scratch could not be allocated).  cama_last_error() returns a
  *     thread-local message for the most recent failure on the calling thread.
  *   - thread-safety: calls on distinct streams / buffers may run concurrently.  The library keeps three pieces of
  *     process-wide state, none of which can change a result: (i) the tuning options (cama_set_option; atomics, each
@@ -48,6 +49,8 @@ extern "C" {
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
+#define CAMA_ENOMEM (-3)      /* a cama_pipeline could not grow its own scratch (hipMalloc: out of memory); nothing was enqueued,
+                               * the pipeline stays usable: release memory (or render fewer frames per launch) and call again */
 #define CAMA_MAX_CAMERAS 16
 #define CAMA_MAX_RADIUS  15
 #define CAMA_BIN_WORKLIST 1   /* flags of the bin / render entries */

@@ -133,27 +133,66 @@ def test_concate_image_returns_a_plain_ndarray_by_default_and_the_stream_is_bgr2
 
 def test_pinned_pool_keeps_a_buffer_out_of_circulation_while_views_of_it_live():
     """bgr24 mode hands out ndarray VIEWS of a batch's pinned host copy; the pool must not give that buffer to the next
-    batch while a caller still holds one (main.py's `image` outlives the batch by one loop iteration)."""
-    class Buf:                                             # stands in for a pinned torch tensor
-        def __init__(self, n):
-            self.n = n
-
-        def numel(self):
-            return self.n
+    batch while a caller still holds one (main.py's `image` outlives the batch by one loop iteration).  The buffers are
+    torch tensors and the views NON-OWNING arrays (`tensor.numpy()`): numpy makes the root `.numpy()` array the base of
+    every derived view, so that root -- not a reshape of it -- is what the pool has to watch."""
+    import torch
     pool = egress.PinnedPool()
-    buf, rows = Buf(64), np.zeros((4, 16), np.uint8)
+    pool.alloc = lambda n: torch.empty(n, dtype=torch.uint8)       # (no GPU here: pageable stands in for pinned)
+    buf = torch.zeros(64, dtype=torch.uint8)
+    root = buf.numpy()
+    rows = root.reshape(4, 16)
     view = rows[2]
-    pool.give(buf, rows)
-    del rows
+    assert view.base is root and rows.base is root
+    pool.give(buf, root)
+    del rows, root
     pool._sweep()
     assert pool.free == {} and len(pool.limbo) == 1        # a view is out: parked
+    assert pool.take(64) is not buf                        # ... and NOT handed to the next batch
+    view[:] = 7                                            # (still the caller's bytes)
     del view
     pool._sweep()
     assert pool.free[64] == [buf] and not pool.limbo       # view gone: back in circulation
-    rows2 = np.zeros((4, 16), np.uint8)
-    pool.give(Buf(32), rows2)                              # no view handed out: back as soon as the batch lets go of it
+    # a derived (reshaped) array passed by mistake is resolved to its root
+    buf2 = torch.zeros(32, dtype=torch.uint8)
+    rows2 = buf2.numpy().reshape(2, 16)
+    held = rows2[1]
+    pool.give(buf2, rows2)
     del rows2
     pool._sweep()
+    assert 32 not in pool.free and len(pool.limbo) == 1
+    del held
+    pool._sweep()
     assert len(pool.free[32]) == 1
-    pool.give(Buf(16))                                     # nothing went out at all (I420 planes are copied into the pipe)
+    pool.give(torch.zeros(16, dtype=torch.uint8))          # nothing went out at all (I420 planes are copied into the pipe)
     assert len(pool.free[16]) == 1
+
+
+def test_render_batch_frames_survive_the_batch_and_the_next_take(monkeypatch):
+    """The sequence the advisor reproduced: a frame handed out by RenderBatch.bgr() is held, the batch dies, the pool is
+    swept and asked for a buffer of the same size -- the held frame must keep its bytes."""
+    import torch
+
+    class FakeEvent:
+        def synchronize(self):
+            pass
+    pool = egress.PinnedPool()
+    pool.alloc = lambda n: torch.empty(n, dtype=torch.uint8)
+    monkeypatch.setattr(egress, "_POOL", pool)
+    b = egress.RenderBatch.__new__(egress.RenderBatch)
+    b.engine, b.ids = None, [1, 2]
+    b.mosaic = torch.zeros((2, 2, 4, 3), dtype=torch.uint8)
+    b._host = torch.arange(48, dtype=torch.uint8)
+    b._event, b._i420_dev, b._host_np, b._host_root, b._fmt = FakeEvent(), None, None, None, "bgr24"
+    frame = b.bgr(1)
+    want = frame.copy()
+    host = b._host
+    del b
+    import gc
+    gc.collect()
+    nxt = pool.take(48)
+    assert nxt is not host                                  # the held frame's buffer is not recycled
+    nxt.fill_(255)
+    assert np.array_equal(frame, want)
+    del frame
+    assert pool.take(48) is host
