@@ -69,7 +69,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SWEEP_SCENES = 73              # BASELINE configs[2]: nuScenes v1.0-test
 STRESS = dict(verts=1000000, frames=1000)       # BASELINE configs[4]
-N_METRICS = 20
+N_METRICS = 24
 GOLDEN_SCENES = os.path.join(REPO, "tests", "golden", "scene_hashes.json")
 
 
@@ -106,7 +106,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single stream: binning and overlay of consecutive steps do not overlap")
     ap.add_argument("--audition", type=int, default=None,
-                    help="candidate allocations timed per long-lived frames / mosaic buffer (Engine.alloc_mosaic; default "
+                    help="candidate allocations timed per long-lived frames / mosaic buffer (the engine's MosaicPool; default "
                          "CAMA_AUDITION or 16; 0 = plain allocations)")
     ap.add_argument("--no-scene-batch", action="store_true",
                     help="several scenes per rank: one launch chain per scene (ClipManager.render_clip) instead of one "
@@ -409,66 +409,47 @@ class Job:
         self.lo, self.hi, self.F = lo, hi, hi - lo
         self.out = None
         self.outs = None
-        self.own_outs = None
         self.group_frames = int(os.environ.get("CAMA_SCENE_GROUP_FRAMES", "0")) or None      # A/B: frames per multi-scene launch
         self.batched = False
+        # the caller's own (unplaced) frames of scene 0, kept for the "unplaced" comparison leg; the frame source may read a
+        # placed copy from the first render on (DeviceFrameSource.place_for)
+        self.orig_frames = self.scenes[0][2] if self.scenes else None
+
+    def allocate(self):
+        """The job's output buffers (and with them the engine's placement auditions: transient candidate allocations) -- apart
+        from __init__ so that main() can let the ranks of a node do this a few at a time."""
+        args, frame_range = self.args, self.frame_range
         if self.scenes and self.F:
-            rig = self.scenes[0][1]._rig()
             # several whole scenes per rank: ONE multi-scene launch chain per step, every scene into its own mosaic
             site_like = args.map in ("site", "random") and args.verts >= 65536     # (render_clips would decline: per-scene launches)
             multi = (len(self.scenes) > 1 and frame_range is None and not getattr(args, "no_scene_batch", False)
                      and not getattr(args, "raw_frames", False) and not _segments(args) and not site_like)
-            pooled = self._alloc_outs_pooled() if multi else None
-            self.out = pooled[0] if pooled else self._alloc_out(0)        # shared by the scenes of per-scene launches
             if multi:
-                self.outs = pooled or ([self.out] + [self._alloc_out(k) for k in range(1, len(self.scenes))])
+                # the product's own buffers: views of the engine's pooled, placed mosaics (cama_amd.dataset.clip_mosaics)
+                from cama_amd.dataset import clip_mosaics
+                self.outs = clip_mosaics([cm for _, cm, _, _ in self.scenes], "cama")
+                self.out = self.outs[0]
                 self.batched = self.step_batched()
                 self.eng.join()
                 if not self.batched:
                     self.outs = None
-            elif len(self.scenes) > 1 and frame_range is None and os.environ.get("CAMA_BENCH_OWN_OUTS") == "1":
-                # A/B knob: per-scene launches, but every scene into its own mosaic like the multi-scene path
-                self.own_outs = [self.out] + [self._alloc_out(k) for k in range(1, len(self.scenes))]
+            else:
+                self.out = self._first_render(0)                          # shared by the scenes of per-scene launches
 
-    def _alloc_out(self, k):
-        """Scene k's mosaic buffer, and -- both are long-lived, rendered from / into on every step -- placed by
-        Engine.alloc_mosaic / place_frames: the fastest of a few candidate allocations for THIS source / mosaic pair
-        (profiles/r04_overlay_modes.txt section 5; CAMA_AUDITION=0 or --audition 0: plain allocations)."""
-        import torch
-        from cama_amd.frames import DeviceFrameSource
-        sid, cm, frames, clip = self.scenes[k]
-        rig = cm._rig()
-        K = getattr(self.args, "audition", None)
-        if os.environ.get("CAMA_BENCH_SHARE_GPU") == "1":               # ranks sharing one GPU (tests): no transient candidates
-            K = 0
-        if getattr(self.args, "raw_frames", False) or K == 0:
-            return torch.empty(self.eng.mosaic_shape(rig, self.F), dtype=torch.uint8, device=self.device)
-        first = 1 if self.frame_range is None else 0                    # image index 0 is never rendered
-        shape = self.eng.mosaic_shape(rig, self.F)
-        if int(np.prod(shape)) > (8 << 30) and len(self.scenes) == 1 and self.frame_range is not None:
-            # a long clip (frame-sharded jobs hash single frames: a ChunkedMosaic serves them): one placed buffer per launch
-            per = max(1, min(self.F, self.eng.max_frames_per_call(cm._static("cama").device(), rig, pipelined=self.pipelined)))
-            srcs = [frames[first + lo:first + min(self.F, lo + per)] for lo in range(0, self.F, per)]
-            return self.eng.alloc_mosaics(rig, srcs, pool=None if K is None else K * len(srcs) // 4)
-        out = self.eng.alloc_mosaic(rig, frames[first:first + self.F], candidates=K)
-        placed = self.eng.place_frames(rig, frames, out, first=first, candidates=None if K is None else max(K // 2, 0))
-        if placed is not frames:
-            src = cm.frame_source()
-            cm.set_frame_source(DeviceFrameSource(placed, index_offset=src.index_offset))
-            self.scenes[k] = (sid, cm, placed, clip)
-        return out
-
-    def _alloc_outs_pooled(self):
-        """The mosaics of all scenes of a multi-scene launch chain as the fastest len(scenes) of ONE pool of candidate
-        allocations (Engine.alloc_mosaics): timing 16 candidates per scene, one scene after the other, would mostly re-time the
-        previous scene's losers -- the allocator hands them straight back."""
-        K = getattr(self.args, "audition", None)
-        if K == 0 or os.environ.get("CAMA_BENCH_SHARE_GPU") == "1" or os.environ.get("CAMA_AUDITION") == "0":
+    def _poses(self, cm):
+        if self.frame_range is None:
             return None
-        rig = self.scenes[0][1]._rig()
-        first = 1 if self.frame_range is None else 0
-        srcs = [frames[first:first + self.F] for _, _, frames, _ in self.scenes]
-        return list(self.eng.alloc_mosaics(rig, srcs, pool=None if K is None else max(K // 4, 2) * len(srcs), settle=False).chunks)
+        idx_all, w2c_all = cm.frame_poses("cama")                       # this rank's slice of the clip's poses
+        return idx_all[self.lo:self.hi], w2c_all[self.lo:self.hi]
+
+    def _first_render(self, k):
+        """Scene k's mosaic buffer the way any caller of the public surface gets one: ClipManager.render_clip(out=None) returns
+        a view of one of the ENGINE's pooled, placed buffers (cama_amd.engine.MosaicPool: the fastest of CAMA_AUDITION candidate
+        allocations for this source, chosen once per shape per process; the resident frames are placed against it the same way,
+        DeviceFrameSource.place_for).  The bench keeps that buffer and passes it back as `out=` on every step."""
+        sid, cm, _, _ = self.scenes[k]
+        _, out = cm.render_clip("cama", pipelined=False, poses=self._poses(cm), segments=_segments(self.args))
+        return out
 
     def step_batched(self):
         from cama_amd.dataset import render_clips
@@ -482,12 +463,8 @@ class Job:
         for k, (sid, cm, _, _) in enumerate(self.scenes):
             if not self.F:
                 continue
-            poses = None
-            if self.frame_range is not None:                            # this rank's slice of the clip's poses
-                idx_all, w2c_all = cm.frame_poses("cama")
-                poses = (idx_all[self.lo:self.hi], w2c_all[self.lo:self.hi])
-            dst = self.own_outs[k] if (out is None and self.own_outs) else (self.out if out is None else out)
-            cm.render_clip("cama", out=dst, pipelined=self.pipelined, poses=poses, segments=_segments(self.args))
+            dst = self.out if out is None else out
+            cm.render_clip("cama", out=dst, pipelined=self.pipelined, poses=self._poses(cm), segments=_segments(self.args))
 
     def run(self, steps, warmup, sync_all, prof_every):
         import ctypes
@@ -560,29 +537,67 @@ class Job:
 
     def poison(self):
         import torch
-        for t in [self.out] + list(self.outs or []) + list(self.own_outs or []):
+        for t in [self.out] + list(self.outs or []):
             if t is not None:
                 t.fill_(0xA5)
         torch.cuda.synchronize(self.device)
 
-    def sustain(self, seconds, steps_hint, dt_hint):
-        """The same loop, un-profiled, for at least `seconds` of wall time: (steps, seconds).  No barrier: every rank
-        times its own loop (the ranks share nothing); the aggregate is sum(frames) / max(seconds)."""
-        import torch
+    def sustain(self, seconds, steps_hint, dt_hint, sync_all):
+        """The same loop, un-profiled, for about `seconds` of wall time: (steps, seconds).  The number of steps is fixed
+        BEFORE the region from the K timed steps' rate, and the region is bracketed like theirs (barrier + synchronize on both
+        sides), so it is a timed region of exactly that many steps -- the one `value` is taken from when the driver's K steps
+        are too short to carry a number (main(): < 50 ms)."""
+        import gc
         if seconds <= 0 or not self.scenes or not self.F:
+            sync_all()
+            sync_all()
             return 0, 0.0
         per = max(1e-6, dt_hint / max(1, steps_hint))
-        chunk = max(1, int(0.25 * seconds / per))
-        n, t0 = 0, time.perf_counter()
-        while True:
-            for _ in range(chunk):
+        n = max(1, int(seconds / per + 0.5))
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(n):
                 self.step()
-            n += chunk
             self.eng.join()
-            torch.cuda.synchronize(self.device)
-            if time.perf_counter() - t0 >= seconds:
-                break
-        return n, time.perf_counter() - t0
+            sync_all()
+            return n, time.perf_counter() - t0
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def unplaced_leg(self, steps, warmup, sync_all, prof_every):
+        """What a caller gets WITHOUT the engine's placement (the `--audition 0` figure, printed beside the default one): the
+        same scene rendered from the caller's own frames tensor into a plain torch.empty mosaic, K timed steps bracketed and
+        profiled like the main region.  Single-scene, pre-resized jobs only.  Returns a dict or None."""
+        import torch
+        from cama_amd.frames import DeviceFrameSource
+        if (len(self.scenes) != 1 or self.frame_range is not None or getattr(self.args, "raw_frames", False)
+                or self.orig_frames is None or not self.F or isinstance(self.out, (list, tuple)) or hasattr(self.out, "chunks")):
+            return None
+        sid, cm, _, _ = self.scenes[0]
+        placed_src = cm.frame_source()
+        env = os.environ.get("CAMA_AUDITION")
+        os.environ["CAMA_AUDITION"] = "0"
+        keep_out = self.out
+        keep_prof = (self.project_ms, self.project_n, self.overlay_each)
+        try:
+            cm.set_frame_source(DeviceFrameSource(self.orig_frames, index_offset=getattr(placed_src, "index_offset", 0)))
+            self.out = torch.empty(tuple(keep_out.shape), dtype=torch.uint8, device=self.device)
+            dt, ov_ms, ov_n = self.run(steps, max(warmup, 14), sync_all, prof_every)     # (14: the mapping trials of a new pair)
+            return {"seconds": dt, "steps": steps, "frames_per_s": self.F * steps / dt if dt > 0 else 0.0,
+                    "overlay_ms_mean": ov_ms / max(1, ov_n), "overlay_launches_timed": ov_n}
+        finally:
+            self.out = keep_out
+            self.project_ms, self.project_n, self.overlay_each = keep_prof
+            cm.set_frame_source(placed_src)
+            if env is None:
+                os.environ.pop("CAMA_AUDITION", None)
+            else:
+                os.environ["CAMA_AUDITION"] = env
 
     def projection_bytes(self):
         """Untimed: one plain render of the first scene, then cama_bin_stats -> (vertex bytes read, stamp bytes written)
@@ -652,7 +667,7 @@ class Job:
                 if self.lo <= f < self.hi:
                     out.append((f,) + shard.overlay_hash(self.out[f - self.lo]))
             return out
-        bufs = self.outs if self.batched else self.own_outs
+        bufs = self.outs if self.batched else None
         if bufs:
             return [(sid,) + shard.overlay_hash(bufs[k]) for k, (sid, _, _, _) in enumerate(self.scenes)]
         return [(self.scenes[-1][0],) + shard.overlay_hash(self.out)]
@@ -720,6 +735,34 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def stagger_allocate(job, rank, world, sync_all, group=4):
+    """Job.allocate() for at most `group` ranks of the node at a time: the placement auditions hold transient candidate
+    buffers (bounded per GPU by the engine: half of what is free; `--plan` counts them) and time launches into them -- eight
+    processes doing that at once share the host's driver threads and PCIe config traffic for nothing."""
+    if world <= group:
+        job.allocate()
+        return
+    for g in range(0, world, group):
+        if g <= rank < g + group:
+            job.allocate()
+        sync_all()
+
+
+def bind_this_rank(torch, local, local_world, n_dev, share):
+    """shard.bind_rank with the PCI addresses of the local ranks' GPUs (rank k drives GPU k); CAMA_BENCH_NO_AFFINITY=1 skips."""
+    from cama_amd import shard
+    if os.environ.get("CAMA_BENCH_NO_AFFINITY") == "1":
+        return {"cpus": sorted(os.sched_getaffinity(0)), "numa_node": -1, "bound": False}
+    pci = []
+    for k in range(local_world):
+        try:
+            p = torch.cuda.get_device_properties(k % n_dev if share else k)
+            pci.append("%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id))
+        except Exception:
+            pci.append(None)
+    return shard.bind_rank(local, local_world, pci)
+
+
 def plan(args):
     """`bench.py --gpus N --plan`: the memory every rank of the job needs, computed on the host (no GPU, no torch.cuda):
     which scenes it gets (the same shard.assign_scenes / frame_ranges calls main() makes), what is resident in HBM during
@@ -773,13 +816,16 @@ def plan(args):
                "mosaic_bytes": mosaics, "map_bytes": maps, "frames_per_launch": fpl,
                "scratch_worst_case_one_slot": worst, "scratch_held": held}
         total = frames_res + mosaics + maps + held
-        # before the timed region: candidate allocations of one mosaic / frames buffer at a time (Engine.alloc_mosaic, capped by
+        # before the timed region: candidate allocations of one mosaic / frames buffer at a time (cama_amd.engine.MosaicPool, capped by
         # the engine at half of what is free, so it cannot be what does not fit)
         one = min(F, fpl) * frame_b if ranges[r] is not None else F * frame_b
         # (one buffer: 16 candidates; the mosaics of a multi-scene chain / the launches of a long clip: one pool of 6 per buffer,
         # of which the kept ones are already counted above)
         n_buf = len(mine) if (ranges[r] is None and batched) else (-(-F // fpl) if ranges[r] is not None and F * frame_b > (8 << 30) else 1)
-        cands = (args.audition or 16) if n_buf == 1 else max((args.audition or 24) // 4, 2) * n_buf - n_buf
+        K_aud = 16 if args.audition is None else args.audition
+        # one mosaic: K candidates (x up to 3 rounds when they all run alike, capped at half of what is free) and then K/2
+        # candidates of the (F + 1)-frame source; several mosaics: ONE pool of max(K/4, 2) per buffer, the kept ones counted above
+        cands = (K_aud + K_aud // 2) if n_buf == 1 else max(K_aud // 4, 2) * n_buf - n_buf
         rec["placement_transient_bytes"] = 0 if (args.audition == 0 or args.raw_frames) else cands * one
         if do_stress:                                               # runs after the sweep's buffers are freed
             slo, shi = shard.frame_ranges(args.stress_frames, world)[r]
@@ -829,6 +875,14 @@ def main():
     device = torch.device(f"cuda:{local % n_dev if share else local}")
     torch.cuda.set_device(device)
     os.environ["CAMA_DEVICE"] = str(device)
+    # placement of long-lived buffers is the ENGINE's business (cama_amd.engine.MosaicPool); the bench only passes its
+    # --audition through as the engine's environment default.  Ranks sharing one GPU (tests): no transient candidates.
+    if args.audition is not None:
+        os.environ["CAMA_AUDITION"] = str(max(0, args.audition))
+    if share:
+        os.environ["CAMA_AUDITION"] = "0"
+    # one process per GPU, each on its own cores next to its GPU (the step is host-latency sensitive: ~4 us between overlays)
+    affinity = bind_this_rank(torch, local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), n_dev, share)
     use_dist = world > 1 or os.environ.get("CAMA_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: 1-rank RCCL group (debug)
     if use_dist:
         if backend == "nccl":
@@ -862,6 +916,7 @@ def main():
         mine = assignment[rank]                                          # scene ids of this rank (seed = scene id)
         frange = None
     job = Job(args, mine, device, frange)
+    stagger_allocate(job, rank, world, sync_all)
     key = args_key(args, unit="frame" if args.shard_frames else "scene")
     samples = stress_sample_frames(args.frames) if args.shard_frames else None
     # verification first (untimed): every scene rendered once on the plain single-stream path and hashed -- what the timed
@@ -877,7 +932,9 @@ def main():
             print(f"bench.py: rank {rank}: the timed path's output differs from the verified render for units {bad}",
                   file=sys.stderr, flush=True)
             sys.exit(3)
-    sus_steps, sus_dt = job.sustain(args.sustain_seconds, args.steps, dt)
+    sus_steps, sus_dt = job.sustain(args.sustain_seconds, args.steps, dt, sync_all)
+    unplaced = job.unplaced_leg(args.steps, args.warmup, sync_all, prof_every) \
+        if (world == 1 and args.steps > 0 and os.environ.get("CAMA_AUDITION", "16") != "0") else None
     vbytes, sbytes, bin_stats = job.projection_bytes()
     metrics = [float(F * args.steps * len(job.scenes)), dt, ov_ms, float(ov_n), float(N),
                float(args.steps) * len(job.scenes) * shard.scene_cost(F, N, W, H), job.frames_per_launch(), 0.0,
@@ -885,7 +942,9 @@ def main():
                float(F * sus_steps * len(job.scenes)), sus_dt,
                float(getattr(job.eng, "map_cache_stats", {}).get("uploads", 0)),
                float(getattr(job.eng, "map_cache_stats", {}).get("hits", 0)),
-               job.overlay_each["min"], job.overlay_each["max"], float(job.scratch_bytes()), 0.0]
+               job.overlay_each["min"], job.overlay_each["max"], float(job.scratch_bytes()),
+               float(len(affinity["cpus"])), float(min(affinity["cpus"] or [-1])), float(max(affinity["cpus"] or [-1])),
+               float(affinity["numa_node"]), float(bool(affinity["bound"]))]
     cm0, frames0, clip0 = (job.scenes[0][1:] if job.scenes else (None, None, None))
     slots = max(16, -(-n_scenes // world) + 1)
     report = [shard.pack_report(metrics, hashes, slots)]
@@ -901,6 +960,7 @@ def main():
         sargs.height, sargs.width, sargs.no_pipeline = H, W, args.no_pipeline
         s_range = shard.frame_ranges(sargs.frames, world)[rank]
         sjob = Job(sargs, [0], device, s_range)
+        stagger_allocate(sjob, rank, world, sync_all)
         s_steps, s_warm = max(1, args.steps // 4), max(1, args.warmup // 4)
         s_samples = stress_sample_frames(sargs.frames)
         s_hashes = [] if args.no_verify else sjob.scene_hashes(s_samples)
@@ -916,7 +976,7 @@ def main():
         s_metrics = [float(sjob.F * s_steps), sdt, sov_ms, float(sov_n), float(sjob.N),
                      float(s_steps) * shard.scene_cost(sjob.F, sjob.N, W, H), sjob.frames_per_launch(), float(s_steps),
                      sjob.project_ms, float(sjob.project_n), s_vb, s_sb, 0.0, 0.0, 0.0, 0.0,
-                     sjob.overlay_each["min"], sjob.overlay_each["max"], float(sjob.scratch_bytes()), 0.0]
+                     sjob.overlay_each["min"], sjob.overlay_each["max"], float(sjob.scratch_bytes()), 0.0, 0.0, 0.0, 0.0, 0.0]
         report.append(shard.pack_report(s_metrics, s_hashes, len(s_samples)))
         s_key = workload_key(sargs.frames, sargs.verts, W, H, "random", unit="frame")
 
@@ -1011,9 +1071,32 @@ def main():
         sus_frames, sus_secs = float(m[:, 12].sum()), float(m[:, 13].max())
         if sus_secs > 0:
             line["sustained"] = {"value": sus_frames / sus_secs, "unit": "frames/s", "seconds": sus_secs,
-                                 "frames": sus_frames,
-                                 "note": "the same step loop run for >= %.1f s after the K timed steps (per rank, no "
-                                         "barrier; sum of frames / slowest rank)" % args.sustain_seconds}
+                                 "frames": sus_frames, "steps": int(round(sus_frames / max(1.0, float(F * n_scenes)))),
+                                 "note": "the same step loop run for about %.1f s after the K timed steps, bracketed the same way "
+                                         "(barrier + synchronize on both sides; sum of frames / slowest rank)" % args.sustain_seconds}
+            if agg["seconds"] < 0.050:
+                # K steps of a few hundred microseconds each are milliseconds of work: pipeline fill and one late rank are a
+                # visible share of such a region (and a scaling curve would be built from it).  `value` is then the long region's
+                # figure; the exact-K region stays in the record.
+                line["k_steps_region"] = {"value": fps, "ms_per_step": line["ms_per_step"], "seconds": agg["seconds"],
+                                          "steps": args.steps}
+                line["value"] = line["sustained"]["value"]
+                line["ms_per_step"] = sus_secs / max(1, line["sustained"]["steps"]) * 1e3
+                line["value_source"] = ("sustained: the %d timed steps took %.1f ms (< 50 ms), so `value` and `ms_per_step` come "
+                                        "from the %d-step region of %.2f s timed right after them with the same bracketing; the "
+                                        "K-step figures are in `k_steps_region`" % (args.steps, agg["seconds"] * 1e3,
+                                                                                     line["sustained"]["steps"], sus_secs))
+                fps = line["value"]
+                if float(m[0, 13]) > 0:
+                    line["k_steps_region"]["hbm_frac_whole_step"] = line["hbm_frac_whole_step"]
+                    line["hbm_GBps_whole_step"] = bytes_per_frame * (float(m[0, 12]) / float(m[0, 13])) / 1e9
+                    line["hbm_frac_whole_step"] = line["hbm_GBps_whole_step"] / HBM_PEAK_GBS
+        line["rank_affinity"] = {"cpus_per_rank": [int(x) for x in m[:, 19]], "first_cpu": [int(x) for x in m[:, 20]],
+                                 "last_cpu": [int(x) for x in m[:, 21]], "gpu_numa_node": [int(x) for x in m[:, 22]],
+                                 "bound": [bool(x) for x in m[:, 23]],
+                                 "note": "every rank pins itself to a contiguous share of the cores of its GPU's NUMA node "
+                                         "(cama_amd.shard.bind_rank; an even split of the allowed cores when sysfs has no NUMA "
+                                         "picture); disjoint by construction"}
         if bin_stats is not None:
             line["projection_stats"] = bin_stats
         try:
@@ -1036,22 +1119,31 @@ def main():
         except Exception as e:
             line["overlay_mapping"] = {"error": repr(e)}
         log = getattr(job.eng, "audition_log", None)
+        pool = getattr(job.eng, "pool", None)
+        line["placement"] = {"source": "engine default" if os.environ.get("CAMA_AUDITION", "16") != "0" else "off (CAMA_AUDITION=0)",
+                             "pool": dict(pool.stats, bases=len(pool.bases), bytes=pool.nbytes()) if pool is not None else None,
+                             "note": "rank 0.  bench.py allocates no mosaic itself: render_clip(out=None) / clip_mosaics() hand out "
+                                     "views of the engine's pooled buffers (cama_amd.engine.MosaicPool), each the fastest of N "
+                                     "candidate allocations for its source (stamp-free overlay launches timed into each), and "
+                                     "HBM-resident frames are moved once into the fastest of M candidates for that mosaic "
+                                     "(DeviceFrameSource.place_for): the overlay's bandwidth depends on the pair's physical "
+                                     "placement (profiles/r04_overlay_modes.txt section 5).  plain_first_candidate_ms = the first "
+                                     "candidate, what an un-auditioned allocation would have been; `unplaced` = the same scene timed "
+                                     "from the caller's own frames into a plain torch.empty mosaic (the --audition 0 figure)"}
         if log:
             mos = [e for e in log if e["role"] == "mosaic"]
             frs = [e for e in log if e["role"] == "frames"]
-            line["placement"] = {
+            line["placement"].update({
                 "buffers": len(mos), "candidates_per_mosaic": mos[0]["candidates"] if mos else 0,
                 "candidates_per_frames": frs[0]["candidates"] if frs else 0,
                 "first_mosaic_candidates_ms": mos[0]["ms"] if mos else None,
                 "first_frames_candidates_ms": frs[0]["ms"] if frs else None,
                 "kept_of_pool": mos[0].get("kept") if mos else None,
                 "chosen_ms_mean": float(np.mean([e["chosen_ms"] for e in (frs or mos)])),
-                "plain_ms_mean": float(np.mean([e["ms"][0] for e in mos])) if mos else None,
-                "note": "rank 0; before the timed region, every long-lived mosaic buffer is the fastest of N candidate "
-                        "allocations for its source (stamp-free overlay launches timed into each), then the frames are moved "
-                        "into the fastest of M candidates for that mosaic: the overlay's bandwidth depends on the pair's "
-                        "physical placement (profiles/r04_overlay_modes.txt section 5); plain = the first candidate, what an "
-                        "un-auditioned allocation would have been; --audition 0 switches it off"}
+                "plain_first_candidate_ms": float(np.mean([e["ms"][0] for e in mos])) if mos else None})
+        if unplaced is not None:
+            ub = image_bytes * F / (unplaced["overlay_ms_mean"] * 1e-3) / 1e9 if unplaced["overlay_ms_mean"] > 0 else 0.0
+            line["placement"]["unplaced"] = dict(unplaced, kernel_GBps=ub, kernel_frac=ub / HBM_PEAK_GBS)
         if args.sites > 0:
             line["site_maps"] = {"sites": args.sites, "verts_per_site": N,
                                  "sites_per_rank": shard.sites_per_rank(assignment, site_of),

@@ -21,6 +21,7 @@ Extensions beyond the reference surface (used by bench.py and by batch pipelines
     set_frame_source(source)        where camera frames come from (disk by default, HBM tensors for bench)
 Reference lines: cama/dataset.py:11-126.
 """
+import os
 from collections.abc import Mapping, Sequence
 from os.path import exists, join
 
@@ -28,6 +29,7 @@ import numpy as np
 
 from . import runtime
 from .dataset_reader import DatasetReader
+from .engine import ChunkedMosaic
 from .pose_transformer import PoseTransformer
 from .reproject import CameraManager, MapManager, colour_id_of, flatten_instances, split_instances
 from .tools import load_json
@@ -468,10 +470,28 @@ class ClipManager:
         return batches[b], k - ra["bounds"][b][0]
 
     # ------------------------------------------------------------------ whole-clip fused path
+    def _pooled_mosaic(self, eng, rig, src_all, ids, step, probe):
+        """The mosaic of a whole-clip render the caller did not bring: views of the engine's pooled, placed buffers
+        (Engine.pool) -- one tensor, or, for clips beyond CAMA_MOSAIC_CHUNK_BYTES (8 GiB), a ChunkedMosaic of one buffer per
+        launch (each launch's destination is then placed on its own).  `probe`: the source is HBM-resident at output size,
+        so candidates can be timed against it."""
+        F = len(ids)
+        per = rig.C * rig.H * rig.W * 3
+        chunk_bytes = int(float(os.environ.get("CAMA_MOSAIC_CHUNK_BYTES", str(8 << 30))))
+        contiguous = ids == list(range(ids[0], ids[0] + F))
+        if F * per <= chunk_bytes or step >= F:
+            src = src_all.batch(ids) if (probe and contiguous) else None
+            return eng.pool.take(eng.mosaic_shape(rig, F), rig, src)
+        cuts = list(range(0, F, step)) + [F]
+        srcs = [src_all.batch(ids[a:b]) if (probe and contiguous) else None for a, b in zip(cuts, cuts[1:])]
+        return ChunkedMosaic(eng.pool.take_many([eng.mosaic_shape(rig, b - a) for a, b in zip(cuts, cuts[1:])], rig, srcs))
+
     def render_clip(self, dataset, out=None, frames_per_launch=None, poses=None, pipelined=False, segments=None):
         """Render every frame of `dataset` in launches of up to `frames_per_launch` frames.
 
         Returns (image indices (F,), mosaic device tensor [F, 2H, 3W, 3] uint8).  Nothing is copied to the host.
+        out=None: the mosaic is a view of one of the engine's pooled, placed buffers (Engine.pool: recycled once the caller
+        lets go of it; a ChunkedMosaic for clips beyond 8 GiB), and HBM-resident frame sources are placed against it once.
         `poses` = a previous frame_poses() result to reuse.  pipelined=True issues the binning and overlay halves on
         two side streams (Engine.render_frames_pipelined) so consecutive launches / clips overlap; the caller must
         then call runtime.engine().join() before consuming `out` on the current stream."""
@@ -485,11 +505,8 @@ class ClipManager:
         idx, w2c = poses if poses is not None else self.frame_poses(dataset)
         F = len(idx)
         shape = eng.mosaic_shape(rig, F)
-        if out is None:
-            out = torch.empty(shape, dtype=torch.uint8, device=eng.device)
-        assert tuple(out.shape) == shape
         if F == 0:
-            return idx, out
+            return idx, (out if out is not None else torch.empty(shape, dtype=torch.uint8, device=eng.device))
         crop = self.mm.crop_box()
         src_all = self.frame_source()
         fused_raw = getattr(src_all, "fused", False) and hasattr(src_all, "raw_batch")
@@ -497,20 +514,25 @@ class ClipManager:
             # (render_vectors falls back to the image-by-image path for this combination; a whole-clip render has no such path)
             raise ValueError("render_clip: the segment extension needs pre-resized frames -- raw sensor frames are resampled inside "
                              "the overlay kernel, which draws discs only (use a non-fused source or segments=False)")
+        resident = hasattr(src_all, "frames") or hasattr(src_all, "raw")
         if frames_per_launch:
             step = frames_per_launch
         else:
             # sources that decode / allocate a batch per call (files on disk) count it against the per-call budget
-            resident = hasattr(src_all, "frames") or hasattr(src_all, "raw")
             c0 = self.cm_list[0]
             raw_bytes = rig.C * int(c0.height_origin) * int(c0.width_origin) * 3 if fused_raw else None
             step = eng.max_frames_per_call(dmap, rig, resident_frames=resident, src_bytes_per_frame=raw_bytes,
                                            pipelined=pipelined)
+        ids = idx.tolist()
+        if out is None:
+            out = self._pooled_mosaic(eng, rig, src_all, ids, step, resident and not fused_raw)
+        assert tuple(out.shape) == shape
+        if resident and not fused_raw and hasattr(src_all, "place_for") and not isinstance(out, ChunkedMosaic):
+            src_all.place_for(eng, rig, out, ids)
         # pipelined launches take the host float32 poses as they are (staged by the library); the others one upload
         host_poses = pipelined and isinstance(w2c, np.ndarray) and w2c.dtype == np.float32
         T = w2c if host_poses else eng._mats(w2c)
-        ids = idx.tolist()
-        # a ChunkedMosaic (one allocation per launch, Engine.alloc_mosaics): launches end at its chunk boundaries
+        # a ChunkedMosaic (one pooled allocation per launch, _pooled_mosaic): launches end at its chunk boundaries
         cuts = sorted(set(getattr(out, "bounds", ())))
         lo = 0
         while lo < F:
@@ -535,6 +557,26 @@ class ClipManager:
                 continue
             lo = hi
         return idx, out
+
+
+def clip_mosaics(clips, dataset, poses=None):
+    """One mosaic [F, 2H, 3W, 3] per clip for render_clips(), as views of the engine's pooled, placed buffers (Engine.pool.
+    take_many: the fastest of one pool of candidate allocations when the clips' frames are HBM-resident; recycled once the
+    caller lets go of them).  What a caller of render_clips uses when it does not bring its own buffers."""
+    eng = runtime.engine()
+    clips = list(clips)
+    shapes, srcs, rig0 = [], [], None
+    for k, cm in enumerate(clips):
+        idx, _ = poses[k] if poses is not None else cm.frame_poses(dataset)
+        rig = cm._rig()
+        rig0 = rig0 or rig
+        shapes.append(eng.mosaic_shape(rig, len(idx)))
+        src_all = cm.frame_source()
+        ids = idx.tolist()
+        ok = (hasattr(src_all, "frames") and not getattr(src_all, "fused", False) and len(ids)
+              and ids == list(range(ids[0], ids[0] + len(ids))) and (rig.C, rig.H, rig.W) == (rig0.C, rig0.H, rig0.W))
+        srcs.append(src_all.batch(ids) if ok else None)
+    return eng.pool.take_many(shapes, rig0, srcs) if clips else []
 
 
 def render_clips(clips, dataset, outs, pipelined=True, poses=None, max_frames_per_launch=None):

@@ -168,7 +168,7 @@ class DeviceMap:
 
 class ChunkedMosaic:
     """F mosaic frames kept as separate device allocations of a few frames each (one per launch of a long clip), so that
-    every launch's destination can be PLACED on its own (Engine.alloc_mosaics).  Indexing: an int gives a frame, a slice
+    every launch's destination can be PLACED on its own (MosaicPool.take_many).  Indexing: an int gives a frame, a slice
     [lo:hi] a view when it stays inside one chunk (what ClipManager.render_clip asks for -- it cuts its launches at the
     chunk boundaries), anything else raises."""
 
@@ -224,6 +224,219 @@ class ChunkedMosaic:
         return self.fill_(0)
 
 
+def _storage_users(t):
+    """How many tensors / storages reference `t`'s memory besides the temporary this call creates."""
+    import torch
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata) - 1
+
+
+class MosaicPool:
+    """The engine's long-lived, PLACED mosaic buffers (placement belongs to the product).
+
+    Every mosaic the product allocates on a caller's behalf -- ClipManager.render_clip(out=None), render_clips(outs=None),
+    Engine.render_frames / render_frames_raw (out=None), the render-ahead batches behind render_vectors -- is a VIEW of a
+    base buffer this pool owns.  A base is idle when nothing but the pool references its storage (the storage use count:
+    views held by a caller, a RenderBatch or a pipelined launch's keep tuple all count), and an idle base of the right
+    frame shape is handed out again instead of allocating: across batches, passes and ClipManagers a process renders into
+    the same few buffers -- the reference's caller never manages buffers (cama/dataset.py:119-126) and need not here.
+
+    Placement: the overlay's bandwidth depends on where source and destination sit physically relative to each other
+    (profiles/r04_overlay_modes.txt section 5: 0.85 against 0.77 of 8 TB/s, the same buffers every time).  A NEW base of
+    512 MiB .. 8 GiB whose source can be probed is therefore the fastest of CAMA_AUDITION (16) candidate allocations,
+    timed with stamp-free overlay launches from that source (Engine._overlay_ms); runners-up within 3 % of the winner
+    stay in the pool as idle bases (CAMA_POOL_KEEP, default 2 per audition: a pipelined caller ping-pongs between two
+    buffers), the others go back to torch's allocator.  Paid once per shape per process.  CAMA_AUDITION=0: plain
+    allocations, still pooled.  Speed only -- no option here can change a byte."""
+
+    def __init__(self, engine):
+        self.eng = engine
+        self.bases = []                     # [{"t": tensor [F, ...frame shape], "frame": tuple, "ms": float|None, "stream": int, "lru": int}]
+        self.clock = 0
+        self.stats = {"takes": 0, "hits": 0, "allocations": 0, "auditions": 0, "trimmed": 0}
+
+    # ---- bookkeeping
+    def _on_gpu(self):
+        return _torch().device(self.eng.device).type == "cuda"
+
+    def _ctx(self):
+        import contextlib
+        return _torch().cuda.device(self.eng.device) if self._on_gpu() else contextlib.nullcontext()
+
+    def nbytes(self):
+        return sum(int(b["t"].numel()) for b in self.bases)
+
+    def idle(self, b):
+        return _storage_users(b["t"]) <= 1
+
+    def cap_bytes(self):
+        env = os.environ.get("CAMA_POOL_BYTES")
+        if env:
+            return int(float(env))
+        if not self._on_gpu():
+            return 1 << 62
+        total = _torch().cuda.get_device_properties(self.eng.device).total_memory
+        return total // 2
+
+    def trim(self, keep_bytes=0):
+        """Drop idle bases, least recently used first, until at most `keep_bytes` are pooled (0: every idle one)."""
+        n = 0
+        for b in sorted(self.bases, key=lambda b: b["lru"]):
+            if self.nbytes() <= keep_bytes:
+                break
+            if self.idle(b):
+                self.bases.remove(b)
+                n += 1
+        self.stats["trimmed"] += n
+        return n
+
+    def _lend(self, b, F):
+        torch = _torch()
+        self.clock += 1
+        b["lru"] = self.clock
+        if not self._on_gpu():
+            return b["t"][:F]
+        cur = torch.cuda.current_stream(self.eng.device)
+        if b["stream"] is not None and b["stream"].cuda_stream != cur.cuda_stream:
+            # last used under another torch stream: whatever was queued there so far comes first
+            ev = torch.cuda.Event()
+            ev.record(b["stream"])
+            cur.wait_event(ev)
+        b["stream"] = cur
+        return b["t"][:F]
+
+    def _find_idle(self, frame, F):
+        best = None
+        for b in self.bases:
+            Fb = int(b["t"].shape[0])
+            # a longer base serves a shorter request as long as not much of it lies fallow
+            if b["frame"] == frame and F <= Fb <= max(F + 8, F + F // 2) and self.idle(b):
+                if best is None or (b["ms"] or 9e9, Fb) < (best["ms"] or 9e9, int(best["t"].shape[0])):
+                    best = b
+        return best
+
+    def _alloc(self, shape):
+        torch = _torch()
+        try:
+            return torch.empty(shape, dtype=torch.uint8, device=self.eng.device)
+        except torch.OutOfMemoryError:
+            if not self.trim(0):
+                raise
+            if self._on_gpu():
+                torch.cuda.empty_cache()
+            return torch.empty(shape, dtype=torch.uint8, device=self.eng.device)
+
+    def _add(self, t, ms=None):
+        b = {"t": t, "frame": tuple(int(v) for v in t.shape[1:]), "ms": ms, "stream": None, "lru": 0}
+        self.bases.append(b)
+        over = self.nbytes() - self.cap_bytes()
+        if over > 0:
+            self.trim(self.cap_bytes())
+        return b
+
+    def audition_candidates(self):
+        return max(0, int(os.environ.get("CAMA_AUDITION", "16")))
+
+    # ---- the entry points
+    def take(self, shape, rig=None, src=None, cols=3):
+        """A mosaic tensor of `shape` = (F, rows*H, cols*W, 3): a view of an idle pooled base, else of a new one (placed
+        against `src` [F,C,H,W,3] when it is worth it: see the class comment)."""
+        shape = tuple(int(v) for v in shape)
+        F, frame = shape[0], shape[1:]
+        self.stats["takes"] += 1
+        with self._ctx():
+            b = self._find_idle(frame, F)
+            if b is not None:
+                self.stats["hits"] += 1
+                return self._lend(b, F)
+            nbytes = int(np.prod(shape))
+            K = self.audition_candidates() if self._on_gpu() else 0
+            eng = self.eng
+            if (K <= 1 or rig is None or src is None or nbytes < (1 << 29) or nbytes > (8 << 30) or F == 0
+                    or int(src.shape[0]) != F or not eng._probeable(rig, src)):
+                self.stats["allocations"] += 1
+                return self._lend(self._add(self._alloc(shape)), F)
+            free, _ = _torch().cuda.mem_get_info(eng.device)
+            K = max(1, min(K, int(free // 2 // nbytes)))
+            cands, times = [], []
+            for rnd in range(3):
+                # further rounds when all candidates so far ran alike (within 3 %): the two levels are 6-10 % apart, so a
+                # sample like that is all of one kind -- and if it is the slow kind, fresh memory may hold the other
+                if rnd and (len(cands) + K > int(free // 2 // nbytes) or max(times) > 1.03 * min(times)):
+                    break
+                for _ in range(K):
+                    try:
+                        c = _torch().empty(shape, dtype=_torch().uint8, device=eng.device)
+                    except _torch().OutOfMemoryError:
+                        break
+                    cands.append(c)                                   # alive together: distinct memory
+                    times.append(eng._overlay_ms(rig, src, c, cols, 3))
+            if not cands:
+                self.stats["allocations"] += 1
+                return self._lend(self._add(self._alloc(shape)), F)
+            rank = sorted(range(len(cands)), key=lambda i: times[i])
+            keep = [rank[0]] + [i for i in rank[1:max(1, int(os.environ.get("CAMA_POOL_KEEP", "2")))]
+                                if times[i] <= 1.03 * times[rank[0]]]
+            self.stats["auditions"] += 1
+            self.stats["allocations"] += len(keep)
+            eng._log_audition({"role": "mosaic", "bytes": nbytes, "candidates": len(cands), "ms": [round(t, 4) for t in times],
+                               "chosen_ms": round(times[rank[0]], 4), "kept": len(keep), "source": "engine pool"})
+            kept = [self._add(cands[i], times[i]) for i in keep]
+            del cands, c
+            eng.settle_mapping(rig, src, kept[0]["t"], cols)
+            return self._lend(kept[0], F)
+
+    def take_many(self, shapes, rig, srcs, cols=3):
+        """One mosaic per (shape, source) -- the scenes of a multi-scene launch chain, the launches of a long clip -- placed
+        as the fastest of ONE pool of candidates (timing candidates one buffer at a time would mostly re-time the previous
+        buffer's losers, which the allocator hands straight back).  Idle pooled bases are used first."""
+        torch = _torch()
+        shapes = [tuple(int(v) for v in sh) for sh in shapes]
+        out = [None] * len(shapes)
+        with self._ctx():
+            for k, sh in enumerate(shapes):                            # what the pool already has
+                b = self._find_idle(sh[1:], sh[0])
+                if b is not None:
+                    self.stats["takes"] += 1
+                    self.stats["hits"] += 1
+                    out[k] = self._lend(b, sh[0])                      # (lent: no longer idle for the next k)
+            todo = [k for k in range(len(shapes)) if out[k] is None]
+            if not todo:
+                return out
+            eng = self.eng
+            Fmax = max(shapes[k][0] for k in todo)
+            big = (Fmax,) + shapes[todo[0]][1:]
+            nbytes = int(np.prod(big))
+            n = len(todo)
+            K = self.audition_candidates() if self._on_gpu() else 0
+            P = 0
+            if K > 1 and nbytes >= (1 << 29) and all(shapes[k][1:] == big[1:] for k in todo) \
+                    and all(srcs[k] is not None and eng._probeable(rig, srcs[k]) for k in todo):
+                free, _ = torch.cuda.mem_get_info(eng.device)
+                P = min(int(os.environ.get("CAMA_AUDITION_POOL", str(max(K // 4, 2) * n))), int(free * 3 // 4 // nbytes))
+            if P <= n:
+                for k in todo:
+                    self.stats["takes"] += 1
+                    self.stats["allocations"] += 1
+                    out[k] = self._lend(self._add(self._alloc(shapes[k])), shapes[k][0])
+                return out
+            k0 = todo[0]
+            F0 = shapes[k0][0]
+            cands = [torch.empty(big, dtype=torch.uint8, device=eng.device) for _ in range(P)]
+            times = [eng._overlay_ms(rig, srcs[k0], c[:F0], cols, 3) for c in cands]
+            rank = sorted(range(P), key=lambda i: times[i])[:n]        # fastest first
+            self.stats["auditions"] += 1
+            eng._log_audition({"role": "mosaic", "bytes": nbytes, "candidates": P, "ms": [round(t, 4) for t in times],
+                               "chosen_ms": round(float(np.mean([times[i] for i in rank])), 4), "kept": n,
+                               "source": "engine pool"})
+            for i, k in zip(rank, todo):
+                self.stats["takes"] += 1
+                self.stats["allocations"] += 1
+                out[k] = self._lend(self._add(cands[i], times[i]), shapes[k][0])
+            del cands
+            torch.cuda.empty_cache()                                   # the losers go back to the driver, not to torch's cache
+            return out
+
+
 class Engine:
     def __init__(self, device="cuda:0", crop=CROP_BOX, radius=RADIUS, palette_bgr=PALETTE_BGR, alpha=1.0):
         torch = _torch()
@@ -241,6 +454,7 @@ class Engine:
         self.palette = np.ascontiguousarray(np.asarray(palette_bgr, np.uint8).reshape(2, 3))
         self._scratch = None
         self._pipe = None
+        self.pool = MosaicPool(self)
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -428,8 +642,8 @@ class Engine:
             assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
             assert tuple(src.shape) == (F, rig.C, rig.H, rig.W, 3), (tuple(src.shape), (F, rig.C, rig.H, rig.W, 3))
             shape = self.mosaic_shape(rig, F, cols)
-            if out is None:
-                out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+            if out is None:                 # a view of one of the engine's pooled, placed buffers (MosaicPool)
+                out = self.pool.take(shape, rig, src, cols)
             assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.uint8
             x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
             if segments:                    # extension: only through the pipeline (its sorted list is sized per launch)
@@ -463,7 +677,7 @@ class Engine:
             self._last_bin = (dmap.N, F, rig.C, rig.H, rig.W, bnd is not None, key is not None, scratch)
             return out
 
-    # ------------------------------------------------------------------ placement-aware allocation of long-lived buffers
+    # ------------------------------------------------------------------ placement of long-lived buffers (mosaics: MosaicPool above)
     def _log_audition(self, entry):
         """What the placement helpers saw (bench.py reports it): the most recent 256 entries."""
         log = self.__dict__.setdefault("audition_log", [])
@@ -509,90 +723,6 @@ class Engine:
                 if self.overlay_mapping()["decided"] >= 0:
                     break
 
-    def alloc_mosaic(self, rig, src, cols=3, candidates=None, reps=3):
-        """A mosaic buffer [F, rows*H, cols*W, 3] for frames `src` [F,C,H,W,3] that is going to be rendered into MANY times
-        (a service's output ring, bench.py's output buffer) -- chosen among `candidates` fresh allocations by timing the
-        overlay itself into each of them.
-
-        Why (round 4, profiles/r04_overlay_modes.txt section 5): the overlay's bandwidth depends on where its source and its
-        destination sit physically RELATIVE to each other -- scanning 48 one-gigabyte destinations for one source gives
-        0.312-0.326 ms for about one in six of them and 0.341-0.349 ms for the rest (0.85 against 0.77 of 8 TB/s), the same
-        ones every time -- a DRAM-side read / write interference that no order of the kernel's accesses removes.  A caller
-        who keeps the buffer can afford to look: `candidates` allocations (default CAMA_AUDITION, 16; 0 or a launch below
-        512 MiB: no audition, a plain allocation) -- and as many again, up to twice, when all of them ran within 3 % of each
-        other (a sample of one kind) -- stay alive together, each is timed with `reps` stamp-free launches
-        (cama_overlay_probe), the fastest is returned and the others go back to the allocator.  ~0.4 ms per candidate
-        launch; speed only."""
-        torch = _torch()
-        F = int(src.shape[0])
-        shape = self.mosaic_shape(rig, F, cols)
-        nbytes = int(np.prod(shape))
-        K = int(os.environ.get("CAMA_AUDITION", "16")) if candidates is None else int(candidates)
-        with torch.cuda.device(self.device):
-            if K <= 1 or nbytes < (1 << 29) or nbytes > (8 << 30) or not self._probeable(rig, src):
-                return torch.empty(shape, dtype=torch.uint8, device=self.device)
-            free, _ = torch.cuda.mem_get_info(self.device)
-            K = max(1, min(K, int(free // 2 // nbytes)))          # never more than half of what is free
-            best, best_ms, pool, times = None, float("inf"), [], []
-            budget = int(free // 2 // nbytes)
-            for rnd in range(3):
-                # a second and a third round when all candidates so far ran alike (within 3 %): the two levels are 6-10 % apart,
-                # so a sample like that is all of one kind -- and if it is the slow kind, fresh memory may hold the other
-                if rnd and (len(pool) + K > budget or max(times) > 1.03 * min(times)):
-                    break
-                for _ in range(K):
-                    cand = torch.empty(shape, dtype=torch.uint8, device=self.device)
-                    pool.append(cand)                              # alive together: distinct memory
-                    ms = self._overlay_ms(rig, src, cand, cols, reps)
-                    times.append(ms)
-                    if ms < best_ms:
-                        best, best_ms = cand, ms
-            K = len(pool)
-            self._log_audition(
-                {"role": "mosaic", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4)})
-            del pool, cand
-            self.settle_mapping(rig, src, best, cols)
-            return best
-
-    def alloc_mosaics(self, rig, srcs, cols=3, pool=None, reps=3, settle=True):
-        """The same for a long clip rendered in several launches: `srcs` = the source view [F_k,C,H,W,3] of every launch;
-        returns a ChunkedMosaic with one separately allocated buffer per launch.  A pool of `pool` allocations of the
-        largest launch's size (default CAMA_AUDITION_POOL or 6 per launch, at most 3/4 of the free memory) is timed against
-        the first launch's source -- a destination's speed is mostly its own (3.3 GB launches: 0.99 ms into one buffer in
-        four to six, 1.07-1.085 ms into the others, whichever source) -- and the fastest len(srcs) are kept, the rest freed
-        to the driver.  pool = 0 / CAMA_AUDITION=0: plain allocations.  Also the way to place the mosaics of MANY scenes
-        (srcs = one per scene; use the result's .chunks): candidates timed one buffer at a time would mostly be the previous
-        buffer's losers, handed back by the allocator.  settle=False skips the per-pair order trials (multi-scene launches
-        are keyed differently)."""
-        torch = _torch()
-        n = len(srcs)
-        Fmax = max(int(s.shape[0]) for s in srcs)
-        shape = self.mosaic_shape(rig, Fmax, cols)
-        nbytes = int(np.prod(shape))
-        if pool is None:
-            pool = 0 if os.environ.get("CAMA_AUDITION", "16") == "0" else int(os.environ.get("CAMA_AUDITION_POOL", str(6 * n)))
-        with torch.cuda.device(self.device):
-            free, _ = torch.cuda.mem_get_info(self.device)
-            P = min(int(pool), int(free * 3 // 4 // nbytes))
-            if P <= n or nbytes < (1 << 29) or not all(self._probeable(rig, s) for s in srcs):
-                return ChunkedMosaic([torch.empty(self.mosaic_shape(rig, int(s.shape[0]), cols), dtype=torch.uint8,
-                                                  device=self.device) for s in srcs])
-            F0 = int(srcs[0].shape[0])
-            cands = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(P)]
-            times = [self._overlay_ms(rig, srcs[0], c[:F0], cols, reps) for c in cands]
-            rank = sorted(range(P), key=lambda i: times[i])
-            keep = rank[:n]                                            # fastest first
-            chunks = [cands[i][:int(s.shape[0])] for i, s in zip(keep, srcs)]
-            self._log_audition(
-                {"role": "mosaic", "bytes": nbytes, "candidates": P, "ms": [round(t, 4) for t in times],
-                 "chosen_ms": round(float(np.mean([times[i] for i in keep])), 4), "kept": n})
-            del cands
-            torch.cuda.empty_cache()                                   # the losers go back to the driver, not to torch's cache
-            if settle:
-                for s, c in zip(srcs, chunks):
-                    self.settle_mapping(rig, s, c, cols)
-            return ChunkedMosaic(chunks)
-
     def place_frames(self, rig, frames, out, first=0, cols=3, candidates=None, reps=3):
         """The counterpart for the SOURCE side: `frames` [>= first + F, C,H,W,3] (already filled; the F = out.shape[0] frames
         from index `first` are what gets rendered) is copied into the one of `candidates` fresh buffers from which the overlay
@@ -622,7 +752,8 @@ class Engine:
                 del pool
                 self.settle_mapping(rig, view(best), out, cols)
             self._log_audition(
-                {"role": "frames", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4)})
+                {"role": "frames", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4),
+                 "moved": best is not frames})
             return best
 
     def xcd_map(self, n_blocks=4096):
@@ -807,8 +938,8 @@ class Engine:
             assert raw.shape[0] == F and raw.shape[1] == rig.C and raw.shape[4] == 3
             H0, W0 = int(raw.shape[2]), int(raw.shape[3])
             shape = self.mosaic_shape(rig, F, cols)
-            if out is None:
-                out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+            if out is None:                 # pooled (raw sources are not probed: a plain, recycled allocation)
+                out = self.pool.take(shape)
             assert tuple(out.shape) == shape and out.is_contiguous()
             mapx, mapy, sep, band_rows, max_rows, tiles, tiles_x, max_tile, vrows = self.rig_maps(cm_list)
             x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
@@ -1104,6 +1235,7 @@ class Engine:
             self._pipe = None
         self._scratch = None
         self._last_bin = None                   # (its statistics lived in the scratch that just went)
+        self.pool.trim(0)                       # idle pooled mosaics go as well
         torch.cuda.empty_cache()
 
     def stamp_points(self, image, vu, colour_id, link=None, wu=False):

@@ -232,3 +232,93 @@ def reduce_metrics(records):
     frames, seconds = float(r[:, 0].sum()), float(r[:, 1].max())
     return {"frames": frames, "seconds": seconds, "frames_per_s": frames / seconds if seconds > 0 else 0.0,
             "bytes": float(r[:, 5].sum()), "world": int(r.shape[0])}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# host placement of the ranks: one process per GPU, each on cores of its GPU's NUMA node
+# ---------------------------------------------------------------------------------------------------------------
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist) -> sorted list of ints."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return sorted(set(out))
+
+
+def rank_cpu_sets(allowed, world, node_of_rank=None, cpus_of_node=None):
+    """Disjoint CPU sets for the `world` ranks of one node.
+
+    allowed        the cores this job may use (the launcher's scheduler affinity)
+    node_of_rank   NUMA node of each rank's GPU (None / -1: unknown)
+    cpus_of_node   {node: cores of that node}
+    A rank gets a contiguous share of (its GPU's node's cores that are allowed), split among the ranks whose GPUs sit on
+    the same node; when any rank's node is unknown, or a node has fewer allowed cores than ranks, every rank gets an even
+    contiguous share of the allowed cores instead.  Returns a list of `world` sorted lists; empty when there is nothing sensible to pin to (fewer
+    allowed cores than ranks): the caller then leaves the affinity alone.  Pure function (tests)."""
+    allowed = sorted(set(int(c) for c in allowed))
+    if world < 1 or len(allowed) < world:
+        return [[] for _ in range(max(world, 0))]
+    even = [allowed[k * (len(allowed) // world):(k + 1) * (len(allowed) // world)] for k in range(world)]
+    node_of_rank = list(node_of_rank) if node_of_rank is not None else [None] * world
+    cpus_of_node = cpus_of_node or {}
+    if any(n is None or n < 0 or n not in cpus_of_node for n in node_of_rank):
+        return even                                     # no (complete) NUMA picture: an even split of what is allowed
+    by_node = {}
+    for r, n in enumerate(node_of_rank):
+        by_node.setdefault(n, []).append(r)
+    out = [None] * world
+    ok = set(allowed)
+    for n, ranks in sorted(by_node.items()):
+        cores = [c for c in sorted(cpus_of_node[n]) if c in ok]
+        if len(cores) < len(ranks):
+            return even                                 # (a node whose cores the job may not use)
+        per = len(cores) // len(ranks)
+        for k, r in enumerate(ranks):
+            out[r] = cores[k * per:(k + 1) * per]
+    return out
+
+
+def gpu_numa_node(pci_bus_id):
+    """NUMA node of the GPU at PCI address 'dddd:bb:dd.f' (sysfs), or -1."""
+    try:
+        return int(open(f"/sys/bus/pci/devices/{pci_bus_id.lower()}/numa_node").read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def node_cpus():
+    """{NUMA node: cores} from sysfs ({} when the host does not expose it)."""
+    import glob
+    import os
+    out = {}
+    for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+        try:
+            out[int(os.path.basename(d)[4:])] = parse_cpulist(open(os.path.join(d, "cpulist")).read())
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def bind_rank(local_rank, local_world, pci_bus_ids=None, allowed=None):
+    """Pin the calling process (one rank of `local_world` on this node) to its share of the cores next to its GPU.
+    pci_bus_ids: PCI address of every local rank's GPU (rank order), or None (no NUMA information: an even split of the
+    allowed cores).  Returns {"cpus": [...], "numa_node": n, "bound": bool}; never raises (placement is speed only)."""
+    import os
+    info = {"cpus": [], "numa_node": -1, "bound": False}
+    try:
+        allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+        nodes = [gpu_numa_node(b) if b else -1 for b in (pci_bus_ids or [None] * local_world)]
+        sets = rank_cpu_sets(allowed, local_world, nodes, node_cpus())
+        mine = sets[local_rank] if local_rank < len(sets) else []
+        info["numa_node"] = nodes[local_rank] if local_rank < len(nodes) else -1
+        if mine:
+            os.sched_setaffinity(0, mine)
+            info["cpus"], info["bound"] = mine, True
+        else:
+            info["cpus"] = allowed
+    except (OSError, AttributeError, ValueError):
+        pass
+    return info

@@ -38,7 +38,7 @@ def test_requirements_file_lists_what_the_default_path_imports():
 
 
 def test_chunked_mosaic_indexes_frames_and_refuses_slices_across_chunks():
-    """engine.ChunkedMosaic: a long clip's mosaic as one allocation per launch (Engine.alloc_mosaics).  Frames by int,
+    """engine.ChunkedMosaic: a long clip's mosaic as one allocation per launch (MosaicPool.take_many).  Frames by int,
     views by slices inside one chunk; ClipManager.render_clip cuts its launches at `bounds`."""
     import pytest
     import torch
@@ -61,7 +61,7 @@ def test_chunked_mosaic_indexes_frames_and_refuses_slices_across_chunks():
 
 
 def test_placement_helpers_only_probe_what_the_probe_kernel_can_read():
-    """Engine.alloc_mosaic / place_frames / alloc_mosaics fall back to plain allocations unless the source is a contiguous
+    """MosaicPool.take / take_many and Engine.place_frames fall back to plain allocations unless the source is a contiguous
     uint8 [F, C, H, W, 3] tensor of the rig's size with W % 16 == 0 and opaque stamps (what cama_overlay_probe takes)."""
     import types
     import torch
@@ -77,3 +77,79 @@ def test_placement_helpers_only_probe_what_the_probe_kernel_can_read():
     assert not probe(eng, types.SimpleNamespace(C=6, H=4, W=24), torch.zeros((3, 6, 4, 24, 3), dtype=torch.uint8))   # W % 16
     assert not probe(types.SimpleNamespace(alpha256=128), rig, ok)   # translucent stamps go through another kernel
     assert not probe(eng, rig, torch.zeros((3, 6, 4, 32), dtype=torch.uint8))
+
+
+def _cpu_pool():
+    """A MosaicPool over CPU tensors: the bookkeeping (who still references a base, which base serves which request) is
+    device-independent; only the audition needs a GPU."""
+    import types
+    import torch
+    eng = types.SimpleNamespace(device=torch.device("cpu"), alpha256=256, _log_audition=lambda e: None)
+    return engine.MosaicPool(eng)
+
+
+def test_mosaic_pool_recycles_a_base_only_when_no_view_of_it_is_left():
+    """the mosaics the product allocates for a caller are views of long-lived, engine-owned buffers.  A
+    base is lent again only when NOTHING but the pool references its storage -- a frame sliced out of a mosaic the caller has
+    already dropped keeps the whole base out of circulation (the reference's caller may hold a frame as long as it likes)."""
+    pool = _cpu_pool()
+    a = pool.take((4, 6, 8, 3))
+    assert tuple(a.shape) == (4, 6, 8, 3) and pool.stats["allocations"] == 1 and pool.stats["hits"] == 0
+    ptr = a.data_ptr()
+    b = pool.take((4, 6, 8, 3))                       # `a` is still out: a second base
+    assert b.data_ptr() != ptr and pool.stats["allocations"] == 2
+    frame = a[2]                                      # a view of a view ...
+    del a
+    c = pool.take((4, 6, 8, 3))                       # ... still pins the base
+    assert c.data_ptr() not in (ptr, b.data_ptr()) and pool.stats["allocations"] == 3
+    frame.fill_(9)
+    del frame
+    d = pool.take((4, 6, 8, 3))                       # now it is idle: recycled, no allocation
+    assert d.data_ptr() == ptr and pool.stats["allocations"] == 3 and pool.stats["hits"] == 1
+    assert len(pool.bases) == 3 and pool.nbytes() == 3 * 4 * 6 * 8 * 3
+
+
+def test_mosaic_pool_serves_shorter_requests_from_a_longer_idle_base_and_trims():
+    pool = _cpu_pool()
+    a = pool.take((16, 2, 4, 3))
+    ptr = a.data_ptr()
+    del a
+    b = pool.take((12, 2, 4, 3))                      # 12 <= 16 <= 12 + 8: the idle 16-frame base serves it
+    assert b.data_ptr() == ptr and tuple(b.shape) == (12, 2, 4, 3) and pool.stats["hits"] == 1
+    del b
+    c = pool.take((2, 2, 4, 3))                       # 16 > 2 + 8: too much would lie fallow -> its own base
+    assert c.data_ptr() != ptr and pool.stats["allocations"] == 2
+    d = pool.take((16, 2, 8, 3))                      # another frame shape never matches
+    assert pool.stats["allocations"] == 3
+    assert pool.trim(0) == 1 and len(pool.bases) == 2  # only the idle base goes; lent ones stay
+    del c, d
+    assert pool.trim(0) == 2 and pool.bases == [] and pool.stats["trimmed"] == 3
+
+
+def test_mosaic_pool_take_many_uses_idle_bases_first_and_never_lends_one_base_twice():
+    pool = _cpu_pool()
+    first = pool.take_many([(5, 2, 4, 3)] * 3, None, [None] * 3)
+    ptrs = sorted(t.data_ptr() for t in first)
+    assert len(set(ptrs)) == 3 and pool.stats["allocations"] == 3
+    del first
+    again = pool.take_many([(5, 2, 4, 3)] * 4, None, [None] * 4)
+    got = sorted(t.data_ptr() for t in again)
+    assert len(set(got)) == 4 and set(ptrs) <= set(got)          # the three idle bases + one new
+    assert pool.stats["hits"] == 3 and pool.stats["allocations"] == 4
+
+
+def test_rank_cpu_sets_are_disjoint_and_follow_the_gpus_numa_nodes():
+    """one process per GPU, each pinned to cores of its GPU's NUMA node."""
+    from cama_amd import shard
+    two_nodes = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    sets = shard.rank_cpu_sets(range(256), 8, [0, 0, 0, 0, 1, 1, 1, 1], two_nodes)
+    assert all(len(s) == 32 for s in sets)
+    assert len(set().union(*map(set, sets))) == 256              # disjoint and complete
+    assert all(set(s) <= set(two_nodes[0]) for s in sets[:4]) and all(set(s) <= set(two_nodes[1]) for s in sets[4:])
+    # restricted affinity (a cgroup / taskset): only allowed cores are handed out
+    sets = shard.rank_cpu_sets(range(0, 64), 2, [0, 1], two_nodes)
+    assert sets == [list(range(0, 32)), list(range(32, 64))]    # node 1 has no allowed core: even split of what is allowed
+    # no NUMA picture: even split; fewer cores than ranks: leave the affinity alone
+    assert shard.rank_cpu_sets(range(16), 4) == [list(range(k * 4, k * 4 + 4)) for k in range(4)]
+    assert shard.rank_cpu_sets([3], 2) == [[], []]
+    assert shard.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]

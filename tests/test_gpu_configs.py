@@ -439,62 +439,90 @@ def test_two_threads_two_pipelines_share_the_mapping_table(sweep_scenes):
 
 @pytest.mark.gpu
 def test_placed_buffers_render_the_same_bytes(monkeypatch):
-    """Engine.alloc_mosaic / place_frames / alloc_mosaics (round 4: long-lived buffers chosen among candidate allocations by
-    timing the overlay into them) change WHERE the bytes live, never what they are: the headline scene rendered into an
-    auditioned mosaic from auditioned frames, and into a ChunkedMosaic of placed launches, equals the plain
-    render; the audition leaves the process options as they were."""
+    """Placement lives in the PRODUCT (round 5): ClipManager.render_clip(out=None) hands out a view of one of the engine's
+    pooled buffers -- the fastest of CAMA_AUDITION candidate allocations for the clip's resident frames -- and moves the frames
+    once into the fastest of a few candidates for that mosaic (DeviceFrameSource.place_for).  That changes WHERE the bytes
+    live, never what they are; two successive ClipManagers of one shape reuse the pool (no new mosaic-sized allocation) and
+    render the oracle's bytes; a ChunkedMosaic of pooled launches equals the plain render; the audition leaves the process
+    options as they were."""
     import ctypes
+    import gc
     import torch
     from cama_amd import runtime, _lib
-    from cama_amd.frames import DeviceFrameSource
+    from cama_amd.engine import ChunkedMosaic
     a = _args()
+    golden = _golden(a)
     dev = torch.device("cuda:0")
     eng = runtime.engine()
+    eng.pool.trim(0)
+    monkeypatch.setenv("CAMA_AUDITION", "4")
     cm, frames, _ = bench.build_scene(a, 0, dev)
     rig = cm._rig()
-    _, plain = cm.render_clip("cama")
-    want = shard.overlay_hash(plain)
     before = ctypes.c_int64(-7)
     _lib.check(eng.lib.cama_get_option(b"overlay_chunk_log2", ctypes.byref(before)))
     # the probe itself: a pure mosaic copy under its own kernel name, a time, and an error for what it cannot take
-    probe_out = torch.empty_like(plain)
+    probe_out = torch.empty(eng.mosaic_shape(rig, a.frames), dtype=torch.uint8, device=dev)
     ms = ctypes.c_double(0.0)
     _lib.check(eng.lib.cama_overlay_probe(frames[1:].data_ptr(), probe_out.data_ptr(), a.frames, rig.C, rig.H, rig.W, 3, 2,
                                           ctypes.byref(ms), eng._stream()))
     assert 0.05 < ms.value < 50.0
-    want_copy = frames[1:1 + a.frames].reshape(a.frames, 2, 3, rig.H, rig.W, 3).permute(0, 1, 3, 2, 4, 5).reshape(plain.shape)
+    want_copy = frames[1:1 + a.frames].reshape(a.frames, 2, 3, rig.H, rig.W, 3).permute(0, 1, 3, 2, 4, 5).reshape(probe_out.shape)
     assert torch.equal(probe_out, want_copy)
     assert eng.lib.cama_overlay_probe(frames[1:].data_ptr(), probe_out.data_ptr(), 1, rig.C, rig.H, 1592, 3, 1,
                                       ctypes.byref(ms), eng._stream()) != 0
     del probe_out, want_copy
-    out = eng.alloc_mosaic(rig, frames[1:1 + a.frames], candidates=4)
-    log = eng.audition_log[-1]
-    # (4 candidates, and up to two more rounds of 4 when all so far ran within 3 % of each other)
-    assert log["role"] == "mosaic" and log["candidates"] in (4, 8, 12) and len(log["ms"]) == log["candidates"]
-    assert log["chosen_ms"] == min(log["ms"])
-    placed = eng.place_frames(rig, frames, out, first=1, candidates=3)
-    assert eng.audition_log[-1]["role"] == "frames" and len(eng.audition_log[-1]["ms"]) == 4
-    assert torch.equal(placed, frames)
-    cm.set_frame_source(DeviceFrameSource(placed, index_offset=0))
+    # first clip: the pool auditions 4 (.. 12) candidates for this source, the frames are placed against the winner
+    n_log = len(getattr(eng, "audition_log", []))
+    _, out = cm.render_clip("cama")
+    torch.cuda.synchronize()
+    logs = eng.audition_log[n_log:]
+    mos = [e for e in logs if e["role"] == "mosaic"]
+    frs = [e for e in logs if e["role"] == "frames"]
+    assert len(mos) == 1 and mos[0]["candidates"] in (4, 8, 12) and len(mos[0]["ms"]) == mos[0]["candidates"]
+    assert mos[0]["chosen_ms"] == min(mos[0]["ms"]) and mos[0]["source"] == "engine pool"
+    assert len(frs) == 1 and len(frs[0]["ms"]) == 3                        # the caller's tensor + 2 candidates (CAMA_AUDITION // 2)
+    assert torch.equal(cm.frame_source().frames, frames)                   # moved or not: the same bytes
+    assert shard.overlay_hash(out) == golden[0]
+    base_ptr = out.data_ptr()
+    stats0 = dict(eng.pool.stats)
+    # the pipelined path into the same pooled buffer
     out.fill_(0xA5)
     cm.render_clip("cama", out=out, pipelined=True)
     eng.join()
     torch.cuda.synchronize()
-    assert shard.overlay_hash(out) == want
+    assert shard.overlay_hash(out) == golden[0]
     after = ctypes.c_int64(-7)
     _lib.check(eng.lib.cama_get_option(b"overlay_chunk_log2", ctypes.byref(after)))
     assert after.value == before.value
-    # chunked: two launches of 24 + 16 frames, each into its own placed allocation (candidates of 622 MB)
-    srcs = [placed[1 + lo:1 + min(a.frames, lo + 24)] for lo in range(0, a.frames, 24)]
-    chunked = eng.alloc_mosaics(rig, srcs, pool=5)
-    assert chunked.shape == tuple(plain.shape) and chunked.bounds == [0, 24, 40]
-    assert eng.audition_log[-1]["candidates"] == 5 and eng.audition_log[-1]["kept"] == 2
-    chunked.fill_(0xA5)
-    cm.render_clip("cama", out=chunked, pipelined=True)
+    # second ClipManager of the same shape: the pool serves it -- no audition, no new mosaic-sized allocation
+    del out, cm
+    gc.collect()
+    mem0 = torch.cuda.memory_allocated(dev)
+    cm2, frames2, _ = bench.build_scene(a, 1, dev)
+    mem1 = torch.cuda.memory_allocated(dev)
+    _, out2 = cm2.render_clip("cama")
+    torch.cuda.synchronize()
+    assert out2.data_ptr() == base_ptr
+    assert eng.pool.stats["hits"] == stats0["hits"] + 1 and eng.pool.stats["auditions"] == stats0["auditions"]
+    assert eng.pool.stats["allocations"] == stats0["allocations"]
+    mosaic_bytes = out2.numel()
+    # (what the second clip added beyond its own frames + its placed copy of them: scratch and poses, far below one mosaic)
+    grown = torch.cuda.memory_allocated(dev) - mem1
+    assert grown < frames2.numel() + mosaic_bytes // 2, (grown, frames2.numel(), mosaic_bytes)
+    assert shard.overlay_hash(out2) == golden[1]
+    # chunked: launches of 24 + 16 frames, each into its own pooled allocation (CAMA_MOSAIC_CHUNK_BYTES below the clip's size)
+    monkeypatch.setenv("CAMA_MOSAIC_CHUNK_BYTES", str(1 << 29))
+    _, chunked = cm2.render_clip("cama", frames_per_launch=24, pipelined=True)
     eng.join()
     torch.cuda.synchronize()
-    assert torch.equal(torch.cat([c for _, _, c in chunked.spans()]), plain)
-    assert isinstance(eng.alloc_mosaics(rig, srcs, pool=0), type(chunked))      # pool 0: plain allocations, same type
+    assert isinstance(chunked, ChunkedMosaic) and chunked.shape == tuple(out2.shape) and chunked.bounds == [0, 24, 40]
+    assert torch.equal(torch.cat([c for _, _, c in chunked.spans()]), out2)
+    monkeypatch.setenv("CAMA_AUDITION", "0")                               # no audition: plain allocations, still pooled
+    del chunked
+    _, chunked = cm2.render_clip("cama", frames_per_launch=24)
+    assert isinstance(chunked, ChunkedMosaic)
+    del chunked, out2
+    eng.pool.trim(0)
 
 
 @pytest.mark.gpu
