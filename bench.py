@@ -549,22 +549,29 @@ class Job:
         are too short to carry a number (main(): < 50 ms)."""
         import gc
         if seconds <= 0 or not self.scenes or not self.F:
-            sync_all()
-            sync_all()
+            for _ in range(4):                  # (a rank without work still pairs up with the others' two regions)
+                sync_all()
             return 0, 0.0
         per = max(1e-6, dt_hint / max(1, steps_hint))
-        n = max(1, int(seconds / per + 0.5))
         gc.collect()
         gc_was_on = gc.isenabled()
         gc.disable()
-        try:
+
+        def region(n):
             sync_all()
             t0 = time.perf_counter()
             for _ in range(n):
                 self.step()
             self.eng.join()
             sync_all()
-            return n, time.perf_counter() - t0
+            return time.perf_counter() - t0
+        try:
+            # a short calibration region first (the K steps carried profiling events and pipeline fill: their rate undershoots),
+            # then THE region; every rank runs both, so the barriers pair up whatever the ranks' rates are
+            n0 = max(1, int(0.2 * seconds / per + 0.5))
+            d0 = region(n0)
+            n = max(1, int(1.05 * seconds / max(1e-6, d0 / n0) + 1.0))
+            return n, region(n)
         finally:
             if gc_was_on:
                 gc.enable()

@@ -250,10 +250,16 @@ class ClipManager:
         label_json = join(clip_path, self.configs["result_dir"], self.configs["cama_map_file"])
         if not exists(label_json):
             return None
-        bev_height = np.load(join(clip_path, self.configs["result_dir"], self.configs["height_mlp"]))
+        raster = join(clip_path, self.configs["result_dir"], self.configs["height_mlp"])
         labels = load_json(label_json)
         if self.configs.get("device_map_build", False):
-            return self._build_on_device(labels, bev_height)
+            return self._build_on_device(labels, np.load(raster))
+        # host build: the raster is only GATHERED at the densified points (cama/reproject.py:96-99) -- map the file instead
+        # of reading all of it (6000 x 6000 float32 = 144 MB per clip in the reference's data; same values either way)
+        try:
+            bev_height = np.load(raster, mmap_mode="r")
+        except ValueError:                          # (pickled / non-mappable arrays)
+            bev_height = np.load(raster)
         return self.mm.calculate_3d_instance_maps(bev_height, labels)
 
     def load_clip_nuscenes(self, clip_path):
@@ -284,7 +290,10 @@ class ClipManager:
         return StaticInstances(dmap, table["counts"], table["classes"])
 
     def prepare_camera_manager(self, clip_path):
-        return [CameraManager(clip_path, name, output_size=self.output_size) for name in self.configs["camera_list"]]
+        # one parse of attribute.json for the clip (six cameras + the pose tracks read the same dict; read-only)
+        self._reader = DatasetReader(clip_path)
+        return [CameraManager(clip_path, name, output_size=self.output_size, reader=self._reader)
+                for name in self.configs["camera_list"]]
 
     def get_pt_cama(self, dr):
         """camera_main -> world track from the label zip, right-multiplied by chassis -> camera_main:
@@ -334,7 +343,7 @@ class ClipManager:
         static maps (the reference re-reads them on every yield_frame call, cama/dataset.py:80-87)."""
         hit = self._track_cache.get(dataset)
         if hit is None:
-            dr = DatasetReader(self.clip_path)
+            dr = getattr(self, "_reader", None) or DatasetReader(self.clip_path)
             if dataset == "nuscenes":
                 pt = self.get_pt_nuscenes(dr)
             elif dataset == "cama":
@@ -431,10 +440,14 @@ class ClipManager:
         the following batch is issued right away so that it runs while this one is consumed.  Same kernels, same
         arguments per frame as a one-frame launch: only the batching differs."""
         B = max(1, int(self.configs.get("render_ahead", 16)))
+        # the FIRST batch of a pass is short (configs["render_ahead_first"], default 4): nothing can be handed to the caller
+        # before the first batch's files are read, decoded, rendered and downloaded -- with 16 frames that is ~20 ms of a
+        # 40-frame scene's pass (profiles/r05_cold_sweep.txt), with 4 a quarter of it; the pump is decoding the next ones by then
+        B0 = max(1, min(B, int(self.configs.get("render_ahead_first", os.environ.get("CAMA_RENDER_AHEAD_FIRST", 4)))))
         crop = tuple(float(v) for v in np.asarray(self.mm.crop_box()).reshape(-1))
         source = self.frame_source()                # create the (lazy) default source BEFORE it goes into the key
         ins = self.instance_maps[fr.dataset]
-        key = (fr.dataset, crop, B)
+        key = (fr.dataset, crop, B, B0)
         ra = getattr(self, "_ahead", None)
         # the state holds the objects it was built for (identity, not id(): a held reference cannot be recycled)
         if ra is None or ra["key"] != key or ra["ins"] is not ins or ra["src"] is not source:
@@ -443,7 +456,7 @@ class ClipManager:
             # that serve contiguous frame ranges only (RawDeviceFrameSource) never see a range with a hole
             bounds, of_pos = [], np.zeros(len(idx), np.int64)
             for k in range(len(idx)):
-                if not bounds or k - bounds[-1][0] >= B or idx[k] != idx[k - 1] + 1:
+                if not bounds or k - bounds[-1][0] >= (B0 if len(bounds) == 1 else B) or idx[k] != idx[k - 1] + 1:
                     bounds.append([k, k])
                 bounds[-1][1] = k + 1
                 of_pos[k] = len(bounds) - 1

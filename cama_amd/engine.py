@@ -284,7 +284,7 @@ class MosaicPool:
             if self.nbytes() <= keep_bytes:
                 break
             if self.idle(b):
-                self.bases.remove(b)
+                self.bases = [x for x in self.bases if x is not b]      # (by identity: dict equality would compare tensors)
                 n += 1
         self.stats["trimmed"] += n
         return n
@@ -455,6 +455,34 @@ class Engine:
         self._scratch = None
         self._pipe = None
         self.pool = MosaicPool(self)
+
+    # ------------------------------------------------------------------ process-wide ingest state (one Engine per GPU)
+    # A ClipManager lives for one scene (main.py:50); what its frame source needs to turn files into device frames does not
+    # have to: the JPEG decoder (its lanes = streams + pinned staging + device scratch, its pinned read arenas), the reader
+    # threads and the decode pump's stream are owned HERE and shared by every ClipFrameSource on this GPU.  Round 5,
+    # profiles/r05_cold_sweep.txt: per-clip copies of these cost ~100 ms of every scene's first frame (hipHostMalloc of the
+    # arenas, thread start-up) and 3.2 GB of new device segments per scene -- blocks allocated under a clip's own pump
+    # stream sit in that stream's pool of torch's caching allocator, where the next clip's stream cannot reuse them.
+    def jpeg_decoder(self):
+        dec = self.__dict__.get("_jpeg_decoder")
+        if dec is None:
+            from .jpeg import DeviceJpegDecoder
+            dec = self.__dict__["_jpeg_decoder"] = DeviceJpegDecoder(self.device)
+        return dec
+
+    def reader_pool(self, workers):
+        """The shared file-reader thread pool (grown, never shrunk: `workers` is the most any source asked for)."""
+        from concurrent.futures import ThreadPoolExecutor
+        pool = self.__dict__.get("_reader_pool")
+        if pool is None or pool._max_workers < workers:
+            pool = self.__dict__["_reader_pool"] = ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix="cama-read")
+        return pool
+
+    def pump_stream(self):
+        st = self.__dict__.get("_pump_stream")
+        if st is None:
+            st = self.__dict__["_pump_stream"] = _torch().cuda.Stream(device=self.device)
+        return st
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):

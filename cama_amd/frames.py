@@ -258,17 +258,48 @@ class ClipFrameSource:
         self._prefetch = prefetch
         self._pending = {}                                            # image index -> list of futures
         self._dir_sizes = {}                                          # directory -> {file name: bytes} (one scan each)
+        # decoded frames stay in HBM for the later passes over the clip (main.py renders every clip twice: the CAMA pass and
+        # the nuScenes pass read the SAME camera files, main.py:57,66): batch key -> (tensor [F,C,H0,W0,3], per-frame file
+        # signatures).  A 40-frame scene is 1 GB of 288; CAMA_FRAME_CACHE_BYTES (default 8 GiB, 0 = off) bounds it, oldest
+        # batch first.  A frame is served from the cache only while the size and mtime of its six files are what they were
+        # when it was decoded (the reference re-reads the files on every pass).
+        import collections
+        self._cache = collections.OrderedDict()
+        self._cache_of = {}                                           # image index -> (batch key, row)
+        self._cache_bytes = 0
+        self._cache_cap = int(float(os.environ.get("CAMA_FRAME_CACHE_BYTES", str(8 << 30)))) if device is not None else 0
+        self.cache_stats = {"hits": 0, "misses": 0, "stale": 0, "stored_batches": 0, "evicted_batches": 0}
+
+    def _shared(self):
+        """The process-wide Engine when it drives this source's GPU (ingest state is shared through it), else None."""
+        if self.device is None:
+            return None
+        try:
+            from . import runtime
+            eng = runtime.engine()
+        except Exception:
+            return None
+        import torch
+        return eng if torch.device(self.device) == eng.device else None
 
     def _executor(self):
         if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=self._workers, thread_name_prefix="cama-decode")
+            eng = self._shared() if self.decoder == "device" else None
+            if eng is not None:
+                self._pool, self._own_pool = eng.reader_pool(self._workers), False
+            else:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool, self._own_pool = ThreadPoolExecutor(max_workers=self._workers, thread_name_prefix="cama-decode"), True
         return self._pool
 
     def _decoder(self):
         if self._jpeg is None:
-            from .jpeg import DeviceJpegDecoder
-            self._jpeg = DeviceJpegDecoder(self.device)
+            eng = self._shared()
+            if eng is not None:
+                self._jpeg = eng.jpeg_decoder()       # one decoder per GPU: lanes, pinned arenas and scratch outlive the clip
+            else:
+                from .jpeg import DeviceJpegDecoder
+                self._jpeg = DeviceJpegDecoder(self.device)
         return self._jpeg
 
     def _submit(self, idx):
@@ -366,6 +397,8 @@ class ClipFrameSource:
         import threading
         self.cancel_plan()
         keys = [tuple(int(i) for i in b) for b in batches if len(b)]
+        # batches whose frames are all still cached from an earlier pass never reach the pump (raw_batch serves them first)
+        keys = [k for k in keys if self._cache_lookup(list(k), count=False) is None]
         if self.decoder != "device" or not keys or os.environ.get("CAMA_NO_DECODE_PUMP"):
             return
         P = {"keys": keys, "index": {k: j for j, k in enumerate(keys)}, "ready": {}, "consumed": 0,
@@ -418,7 +451,9 @@ class ClipFrameSource:
                 # its mosaics -- every decode used to start behind whatever of those was queued (round 4: the loop ran
                 # at decode + download, not at the larger of the two)
                 if getattr(self, "_pump_stream", None) is None:
-                    self._pump_stream = torch.cuda.Stream(device=self.device)
+                    eng = self._shared()
+                    # (the engine's: a stream per clip would be a pool of its own in torch's caching allocator)
+                    self._pump_stream = eng.pump_stream() if eng is not None else torch.cuda.Stream(device=self.device)
                 with torch.cuda.stream(self._pump_stream):
                     # one group per batch: the pump keeps `_pump_depth` batches in flight, that is the concurrency
                     return self._decoder().decode_async([arr for _, _, arr, _ in items], bgr=True, groups=self._pump_groups)
@@ -430,7 +465,7 @@ class ClipFrameSource:
             self.cancel_plan()
         finally:
             pool, self._pool = self._pool, None
-            if pool is not None:
+            if pool is not None and getattr(self, "_own_pool", True):        # (the engine's shared pool stays)
                 pool.shutdown(wait=False, cancel_futures=True)
 
     def __del__(self):
@@ -488,11 +523,81 @@ class ClipFrameSource:
             self._plan = None
         return pend
 
+    # ------------------------------------------------------------------ decoded frames kept for the clip's later passes
+    def _frame_signature(self, idx):
+        """(size, mtime_ns) of the C camera files of sync index `idx`, or None when one cannot be stat'ed."""
+        sig = []
+        for cm in self.cm_list:
+            try:
+                st = os.stat(cm.get_image_path(idx, True))
+            except OSError:
+                return None
+            sig.append((st.st_size, st.st_mtime_ns))
+        return tuple(sig)
+
+    def _cache_drop(self, key):
+        t, _ = self._cache.pop(key)
+        self._cache_bytes -= int(t.numel())
+        for i in key:
+            if self._cache_of.get(i, (None,))[0] == key:
+                del self._cache_of[i]
+
+    def _cache_store(self, image_indices, tensor):
+        nbytes = int(tensor.numel())
+        if self._cache_cap <= 0 or nbytes > self._cache_cap or not tensor.is_cuda:
+            return
+        key = tuple(image_indices)
+        sigs = [self._frame_signature(i) for i in key]
+        if any(s is None for s in sigs):
+            return
+        if key in self._cache:
+            self._cache_drop(key)
+        while self._cache and self._cache_bytes + nbytes > self._cache_cap:
+            self._cache_drop(next(iter(self._cache)))
+            self.cache_stats["evicted_batches"] += 1
+        self._cache[key] = (tensor, sigs)
+        self._cache_bytes += nbytes
+        for row, i in enumerate(key):
+            self._cache_of[i] = (key, row)
+        self.cache_stats["stored_batches"] += 1
+
+    def _cache_lookup(self, image_indices, count=True):
+        """The decoded frames `image_indices` from HBM when every one of them is cached and its files are unchanged: a view
+        when they are consecutive rows of one cached batch, else one gather; None otherwise."""
+        if not self._cache:
+            return None
+        where = [self._cache_of.get(i) for i in image_indices]
+        if any(w is None for w in where):
+            return None
+        for i, (key, row) in zip(image_indices, where):
+            if self._frame_signature(i) != self._cache[key][1][row]:
+                self._cache_drop(key)                                 # a file changed: that batch is decoded again
+                self.cache_stats["stale"] += 1
+                return None
+        if count:
+            self.cache_stats["hits"] += 1
+        import torch
+        k0, r0 = where[0]
+        if all(k == k0 and r == r0 + j for j, (k, r) in enumerate(where)):
+            self._cache.move_to_end(k0)
+            return self._cache[k0][0][r0:r0 + len(where)]
+        return torch.stack([self._cache[k][0][r] for k, r in where])
+
     def raw_batch(self, image_indices):
         """device uint8 BGR tensor [F,C,H0,W0,3]: every image goes to its slot as decoded (no host-side stacking or
         channel flip: both hold the GIL the decode threads need); RGB-decoded frames are flipped on the device."""
-        import torch
         image_indices = [int(i) for i in image_indices]
+        hit = self._cache_lookup(image_indices)
+        if hit is not None:
+            return hit
+        if self._cache_cap > 0:
+            self.cache_stats["misses"] += 1
+        out = self._raw_batch_decode(image_indices)
+        self._cache_store(image_indices, out)
+        return out
+
+    def _raw_batch_decode(self, image_indices):
+        import torch
         F = len(image_indices)
         planned = self._planned(tuple(image_indices))
         if planned is not None:

@@ -212,9 +212,11 @@ class MapManager(BaseManager):
 
 
 class CameraManager(BaseManager):
-    def __init__(self, clip_path, camera_name, output_size=(540, 960), undisort=True):
+    def __init__(self, clip_path, camera_name, output_size=(540, 960), undisort=True, reader=None):
         super().__init__()
-        dr = DatasetReader(clip_path)
+        # `reader` (extension): a DatasetReader of this clip that the caller already has -- ClipManager parses
+        # attribute.json ONCE for its six cameras instead of once per camera like the reference (reproject.py:166)
+        dr = reader if reader is not None else DatasetReader(clip_path)
         self.dr = dr
         self.clip_path = clip_path
         self.camera_name = camera_name

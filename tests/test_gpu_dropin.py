@@ -315,6 +315,86 @@ def test_second_pass_over_a_clip_renders_again(tmp_path):
     assert np.array_equal(second, want.cpu().numpy())
 
 
+def _main_loop(cm, dataset):
+    """main.py:57-61 with a sink-less VideoGenerator: the mosaics of one pass, copied."""
+    from cama.tools import VideoGenerator
+    vg = object.__new__(VideoGenerator)
+    out = []
+    for image_idx, instance_map in cm.yield_frame(dataset=dataset):
+        image = vg.concate_image(cm.render_vectors(cm.project_all_camera(instance_map), image_idx))
+        out.append(np.array(image, copy=True))
+    return out
+
+
+def test_sweep_reuses_the_process_wide_state_and_the_second_pass_reads_hbm(tmp_path):
+    """VERDICT r4 item 2 (the reference's real workload: a fresh ClipManager per scene, both dataset passes once,
+    main.py:32-70).  (a) The second pass of a clip takes its frames from HBM (decoded once per clip) -- unless a file changed
+    in between, which is seen and decoded again.  (b) The SECOND clip of a sweep lives on what the process-wide Engine
+    already owns -- JPEG decoder lanes and pinned arenas, reader threads, pump stream, pooled mosaics: no new device
+    segment of mosaic / frame size.  (c) Bytes: both clips, both passes, equal the one-frame-per-launch render."""
+    import gc
+    import os
+    import sys
+    import torch
+    from PIL import Image
+    from cama.dataset import ClipManager
+    from cama_amd import runtime
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import cold_sweep
+    clips = cold_sweep.write_clips(str(tmp_path), 3, 8, distinct=8)
+    eng = runtime.engine()
+
+    def sweep_one(clip, check):
+        cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)
+        got = {ds: _main_loop(cm, ds) for ds in ("cama", "nuscenes")}
+        stats = dict(cm.frame_source().cache_stats)
+        if check:
+            ref = ClipManager(dict(DEFAULT_CAMA_CONFIGS, render_ahead=1), clip)      # one frame per launch, no render-ahead
+            os.environ["CAMA_FRAME_CACHE_BYTES"] = "0"
+            try:
+                ref.set_frame_source(None)
+                for ds in ("cama", "nuscenes"):
+                    want = _main_loop(ref, ds)
+                    assert len(want) == len(got[ds]) == 8
+                    assert all(np.array_equal(a, b) for a, b in zip(got[ds], want)), ds
+                    assert any((a != got[ds][0]).any() for a in got[ds][1:])
+            finally:
+                del os.environ["CAMA_FRAME_CACHE_BYTES"]
+        return cm, stats
+
+    cm, stats = sweep_one(clips[0], check=True)
+    # (a) pass 1: 8 frames in batches of 4 + 4 (a short first batch, then up to 16): two misses; pass 2: both from HBM
+    assert stats["misses"] == 2 and stats["hits"] == 2 and stats["stored_batches"] == 2 and stats["stale"] == 0, stats
+    # a file of frame 2 changes on disk: its batch is decoded again on the next pass, the other one is still served from HBM
+    path = cm.cm_list[1].get_image_path(2, True)
+    img = np.asarray(Image.open(path)).copy()
+    os.unlink(path)                                                # (the clips hard-link their JPEGs: do not write through)
+    Image.fromarray(255 - img).save(path, quality=90)
+    before = _main_loop(cm, "cama")
+    st = cm.frame_source().cache_stats
+    assert st["stale"] == 1 and st["misses"] == 3 and st["hits"] == 3, st
+    cm2 = ClipManager(dict(DEFAULT_CAMA_CONFIGS, render_ahead=1), clips[0])
+    want = _main_loop(cm2, "cama")
+    assert all(np.array_equal(a, b) for a, b in zip(before, want))
+    del cm, cm2, before, want
+    gc.collect()
+    # (b) warm process, second and third clip
+    sweep_one(clips[1], check=True)
+    gc.collect()
+    torch.cuda.synchronize()
+    m0 = torch.cuda.memory_stats(eng.device)
+    pool0 = dict(eng.pool.stats)
+    dec = eng.jpeg_decoder()
+    lanes0, arenas0 = len(dec._lane), len(dec.__dict__.get("_arenas", []))
+    sweep_one(clips[2], check=False)
+    torch.cuda.synchronize()
+    m1 = torch.cuda.memory_stats(eng.device)
+    grown = m1["reserved_bytes.all.allocated"] - m0["reserved_bytes.all.allocated"]
+    assert grown < (32 << 20), f"the third clip of a sweep made torch reserve {grown / 1e6:.0f} MB of new device segments"
+    assert eng.pool.stats["allocations"] == pool0["allocations"] and eng.pool.stats["hits"] > pool0["hits"]
+    assert eng.jpeg_decoder() is dec and len(dec._lane) == lanes0 and len(dec.__dict__.get("_arenas", [])) == arenas0
+
+
 def test_crop_dict_override_is_honoured(tmp_path):
     from cama_amd.dataset import ClipManager
     g = load_golden("e_crop")

@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""The reference's ACTUAL workload, timed: main.py:32-70 -- for every scene a FRESH ClipManager, then the CAMA pass and the
+nuScenes pass over the clip, each exactly ONCE, through a VideoGenerator -- on K distinct on-disk clips (1600x900 JPEG
+camera frames, CAMA labels + BEV height raster, nuScenes labels, pose files, calibration).  Everything bench.py reports is
+steady state (one scene re-rendered, cached tracks, placed buffers); a real sweep never reaches it: a nuScenes scene has
+~40 frames, so the one-off part of every clip is all there is.
+
+    CAMA_VIDEO_SINK=null python tools/cold_sweep.py [--scenes 12] [--frames 40] [--warm-passes 2] [--keep DIR] [--json OUT]
+
+Per scene the wall time is split into
+    setup        ClipManager(...): attribute.json / calibration (reader), label load + static-map build (cama, nuscenes)
+    first        per pass: from entering the loop until the first frame's mosaic is in the caller's hands
+                 (poses, map upload, first decode batches, first render, first download)
+    rest         per pass: the remaining frames
+    teardown     vg.close() + dropping the ClipManager
+and, after the cold sweep, the SAME two passes are run again on the last scene's ClipManager `--warm-passes` times: the
+steady time of exactly that work, which the cold wall is compared with (cold <= 3x steady).  The device
+allocation counters around every scene (torch.cuda.memory_stats "allocation.all.allocated" above 64 MiB -- mosaic / frame
+sized blocks) show whether a scene allocated new big buffers or lived on what the process-wide Engine already owns.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("CAMA_VIDEO_SINK", "null")
+
+
+def write_clips(root, scenes, frames, distinct=8):
+    """K clips with their own labels / rasters / poses (seed = scene id); the JPEGs of a scene are `distinct` photo-like
+    frames per camera hard-linked over the clip's timestamps (the decode work per file is a real clip's; writing 3000
+    distinct 1600x900 JPEGs with Pillow would take minutes of box time for nothing)."""
+    import shutil
+    from cama_amd.synth import CAMERA_NAMES, make_clip
+    clips = []
+    for k in range(scenes):
+        clip = os.path.join(root, f"scene-{k:04d}")
+        make_clip(clip, n_frames=frames + 1, seed=k, n_lines=20, verts_per_line=11, line_len_m=5.0, raster_size=3000,
+                  image_mode="none", image_size=(900, 1600))
+        tmp = os.path.join(root, f"_imgs{k}")
+        make_clip(tmp, n_frames=distinct, seed=100 + k, n_lines=2, verts_per_line=3, line_len_m=1.0, raster_size=64,
+                  image_mode="jpg_photo", image_size=(900, 1600), with_nuscenes=False, extra_labels=False)
+        att = json.load(open(os.path.join(clip, "attribute.json")))
+        att_t = json.load(open(os.path.join(tmp, "attribute.json")))
+        for name in CAMERA_NAMES:
+            os.makedirs(os.path.join(clip, name), exist_ok=True)
+            src = [os.path.join(tmp, name, f"{ts}.jpg") for ts in att_t["sync"][name]]
+            for j, ts in enumerate(att["sync"][name]):
+                dst = os.path.join(clip, name, f"{ts}.jpg")
+                try:
+                    os.link(src[j % distinct], dst)
+                except OSError:
+                    shutil.copy(src[j % distinct], dst)
+        clips.append(clip)
+    return clips
+
+
+def big_allocs(torch, dev):
+    """(count, bytes) of device blocks torch requested from the driver so far (segments: what hipMalloc saw)."""
+    st = torch.cuda.memory_stats(dev)
+    return int(st.get("segment.all.allocated", 0)), int(st.get("reserved_bytes.all.allocated", 0))
+
+
+def one_pass(cm, vg, dataset, clock):
+    """main.py:57-61 / 66-70, verbatim, with two clock reads."""
+    n = 0
+    t0 = clock()
+    t_first = None
+    for image_idx, instance_map in cm.yield_frame(dataset=dataset):
+        maps_2d_dict = cm.project_all_camera(instance_map)
+        image_dict = cm.render_vectors(maps_2d_dict, image_idx)
+        image = vg.concate_image(image_dict)
+        vg.add_frame(image)
+        n += 1
+        if t_first is None:
+            t_first = clock()
+    t1 = clock()
+    return n, (t_first or t1) - t0, t1 - (t_first or t1)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", type=int, default=12)
+    ap.add_argument("--frames", type=int, default=40)
+    ap.add_argument("--warm-passes", type=int, default=2)
+    ap.add_argument("--keep", default=None)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--label", default="")
+    args = ap.parse_args(argv)
+    import torch
+    from cama.dataset import ClipManager
+    from cama.tools import VideoGenerator
+    from cama_amd import runtime
+    from cama_amd.synth import DEFAULT_CAMA_CONFIGS
+    root = args.keep or tempfile.mkdtemp(prefix="cama_cold_")
+    t = time.perf_counter()
+    clips = write_clips(root, args.scenes, args.frames)
+    print(f"{len(clips)} clips x {args.frames + 1} stamps x 6 JPEGs written in {time.perf_counter() - t:.1f} s -> {root}")
+    configs = {"cama_configs": dict(DEFAULT_CAMA_CONFIGS), "output_video_dir": os.path.join(root, "videos")}
+    os.makedirs(configs["output_video_dir"], exist_ok=True)
+    clock = time.perf_counter
+    dev = None
+    rows = []
+    wall0 = clock()
+    cm = None
+    for k, clip_path in enumerate(clips):
+        scene_name = os.path.basename(clip_path)
+        a0 = big_allocs(torch, dev) if dev is not None else (0, 0)
+        t0 = clock()
+        cm = None                                               # (main.py rebinds `cm`: the previous clip goes here)
+        t_drop = clock() - t0
+        t1 = clock()
+        cm = ClipManager(configs["cama_configs"], clip_path)
+        t_setup = clock() - t1
+        row = {"scene": scene_name, "setup": t_setup, "drop_previous": t_drop}
+        for dataset, suffix in (("cama", "cama"), ("nuscenes", "nuScenes")):
+            vg = VideoGenerator(os.path.join(configs["output_video_dir"], f"{scene_name}_{suffix}.mp4"))
+            n, first, rest = one_pass(cm, vg, dataset, clock)
+            t2 = clock()
+            vg.close()
+            row[dataset] = {"frames": n, "first": first, "rest": rest, "close": clock() - t2}
+        if dev is None:
+            dev = runtime.engine().device
+        torch.cuda.synchronize(dev)
+        row["wall"] = clock() - t0
+        a1 = big_allocs(torch, dev)
+        row["new_segments"], row["new_reserved_bytes"] = a1[0] - a0[0], a1[1] - a0[1]
+        pool = runtime.engine().pool
+        row["pool"] = dict(pool.stats, bases=len(pool.bases))
+        rows.append(row)
+        print(f"{scene_name}: wall {row['wall'] * 1e3:7.1f} ms | setup {t_setup * 1e3:6.1f} | "
+              + " | ".join(f"{d}: first {row[d]['first'] * 1e3:6.1f} rest {row[d]['rest'] * 1e3:6.1f} close {row[d]['close'] * 1e3:5.1f} "
+                           f"({row[d]['frames']} fr)" for d in ("cama", "nuscenes"))
+              + f" | new device segments {row['new_segments']} ({row['new_reserved_bytes'] / 1e6:.0f} MB)")
+    total = clock() - wall0
+    # the steady time of the same two passes: the last scene's ClipManager, again
+    warm = []
+    for _ in range(max(0, args.warm_passes)):
+        t0 = clock()
+        for dataset in ("cama", "nuscenes"):
+            vg = VideoGenerator(os.path.join(configs["output_video_dir"], "warm.mp4"))
+            one_pass(cm, vg, dataset, clock)
+            vg.close()
+        torch.cuda.synchronize(dev)
+        warm.append(clock() - t0)
+    frames = sum(r["cama"]["frames"] + r["nuscenes"]["frames"] for r in rows)
+    later = rows[1:] or rows
+    med = sorted(r["wall"] for r in later)[len(later) // 2]
+    steady = min(warm) if warm else None
+    summary = {"label": args.label, "scenes": len(rows), "frames_per_pass": args.frames, "frames_total": frames,
+               "sweep_wall_s": total, "frames_per_s": frames / total,
+               "first_scene_wall_s": rows[0]["wall"], "later_scene_wall_median_s": med,
+               "steady_two_passes_s": steady, "cold_over_steady": (med / steady) if steady else None,
+               "later_scenes_new_segments": sum(r["new_segments"] for r in later),
+               "later_scenes_new_reserved_MB": sum(r["new_reserved_bytes"] for r in later) / 1e6,
+               "mean_ms": {key: 1e3 * sum(r[key] for r in later) / len(later) for key in ("setup", "drop_previous")}}
+    for d in ("cama", "nuscenes"):
+        for key in ("first", "rest", "close"):
+            summary["mean_ms"][f"{d}_{key}"] = 1e3 * sum(r[d][key] for r in later) / len(later)
+    print(json.dumps(summary))
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump({"summary": summary, "scenes": rows, "warm_passes_s": warm}, f, indent=1)
+    return summary
+
+
+if __name__ == "__main__":
+    main()
