@@ -835,7 +835,7 @@ class Engine:
         """src [n,H0,W0,3] (or [H0,W0,3]) uint8 device frames of CameraManager `cm` -> [n,H,W,3] at its output size.
         `out` may be a strided view whose frames are each contiguous (e.g. mosaic-source[:, c])."""
         torch = _torch()
-        from .frames import camera_maps
+        from .frames import camera_maps_compact
         with torch.cuda.device(self.device):
             single = src.dim() == 3
             s = src[None] if single else src
@@ -845,11 +845,8 @@ class Engine:
             H, W = int(cm.height), int(cm.width)
             dev_maps = getattr(cm, "_resample_maps_dev", None)
             if dev_maps is None or dev_maps[0].device != self.device:
-                mx, my = camera_maps(cm)
-                # zero distortion gives separable maps: ship a W-vector and an H-vector instead of two H x W planes
-                sep = bool((mx == mx[0:1, :]).all() and (my == my[:, 0:1]).all())
-                if sep:
-                    mx, my = np.ascontiguousarray(mx[0, :]), np.ascontiguousarray(my[:, 0])
+                # zero distortion gives separable maps: a W-vector and an H-vector instead of two H x W planes
+                mx, my, sep = camera_maps_compact(cm)
                 dev_maps = (torch.from_numpy(mx).to(self.device), torch.from_numpy(my).to(self.device), int(sep))
                 cm._resample_maps_dev = dev_maps
             if out is None:
@@ -865,7 +862,7 @@ class Engine:
     def rig_maps(self, cm_list):
         """Per-camera undistort/resize maps of a rig, concatenated on the device: (mapx, mapy, separable)."""
         torch = _torch()
-        from .frames import camera_maps
+        from .frames import camera_maps_compact
         # keyed on CONTENT (sizes, both intrinsics, distortion), not on object identity: ids are recycled, and two clips
         # of one rig share a plan.  A small dict of plans: the tensors of a plan that queued launches still read stay
         # referenced from the launches' keep tuples (render_frames_raw) as well.
@@ -878,14 +875,16 @@ class Engine:
         plans = self.__dict__.setdefault("_rig_plans", {})
         hit = plans.get(key)
         if hit is None:
-            maps = [camera_maps(cm) for cm in cm_list]
-            sep = all(bool((mx == mx[0:1, :]).all() and (my == my[:, 0:1]).all()) for mx, my in maps)
+            maps = [camera_maps_compact(cm) for cm in cm_list]
+            sep = all(m[2] for m in maps)
             if sep:
-                mx = np.stack([m[0][0, :] for m in maps])
-                my = np.stack([m[1][:, 0] for m in maps])
-            else:
-                mx = np.stack([m[0].reshape(-1) for m in maps])
-                my = np.stack([m[1].reshape(-1) for m in maps])
+                mx = np.stack([m[0] for m in maps])
+                my = np.stack([m[1] for m in maps])
+            else:                                   # (a rig with one distorted camera: planes for all of them)
+                from .frames import camera_maps
+                full = [camera_maps(cm) for cm in cm_list]
+                mx = np.stack([m[0].reshape(-1) for m in full])
+                my = np.stack([m[1].reshape(-1) for m in full])
             band_rows, max_rows, tiles, tiles_x, max_tile = None, 0, None, 0, 0
             if sep:
                 # source rows every band of R destination rows touches (same rounding as the kernel: 1/32 px)

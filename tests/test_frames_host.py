@@ -136,3 +136,46 @@ def test_decode_pump_thread_ends_when_its_source_is_dropped():
         P2["cv"].notify_all()
     t.join(timeout=3)
     assert not t.is_alive()
+
+
+def test_separable_undistort_map_is_the_full_map_bit_for_bit():
+    """Zero distortion + an axis-aligned new camera matrix (what every nuScenes camera and the reference's CameraManager
+    give, cama/reproject.py:232-240): one row and one column of OpenCV's map carry all of it.  The O(W + H) form must equal
+    the full O(W H) restatement bit for bit -- it replaces it on every new clip's first frame -- and must decline (None)
+    whenever the map is not of that form."""
+    from cama_amd import frames as FR
+    rng = np.random.default_rng(5)
+    K0 = np.array([[1266.417203046554, 0.0, 816.2670197447984], [0.0, 1266.417203046554, 491.50706579294757], [0, 0, 1.0]])
+    for H, W in ((540, 960), (450, 800), (97, 161), (900, 1600)):
+        for _ in range(2):
+            Kn = K0.copy()
+            Kn[0, :] *= W / 1600
+            Kn[1, :] *= H / 900
+            mx, my = FR.undistort_rectify_map(K0, [], Kn, W, H)
+            for dist in ([], None, np.zeros(5), np.zeros(14)):
+                sep = FR.undistort_rectify_map_separable(K0, dist, Kn, W, H)
+                assert sep is not None and sep[0].dtype == np.float32 and sep[0].shape == (W,) and sep[1].shape == (H,)
+                assert np.array_equal(mx, np.broadcast_to(sep[0][None, :], (H, W)))
+                assert np.array_equal(my, np.broadcast_to(sep[1][:, None], (H, W)))
+            K0 = K0 + np.diag([rng.uniform(-40, 40), rng.uniform(-40, 40), 0.0])      # another calibration
+            K0[0, 2] += rng.uniform(-9, 9)
+    Kn = K0.copy()
+    Kn[0, 1] = 0.25                                                    # skew: rows differ
+    assert FR.undistort_rectify_map_separable(K0, [], Kn, 960, 540) is None
+    Kn = K0.copy()
+    Kn[2, 0] = 1e-6                                                    # projective row
+    assert FR.undistort_rectify_map_separable(K0, [], Kn, 960, 540) is None
+    assert FR.undistort_rectify_map_separable(K0, [0.0, 0.0, 1e-4, 0.0, 0.0], K0, 960, 540) is None    # any distortion
+
+    class CM:                                                          # the attributes camera_maps_compact reads
+        K_origin, d, d_origin, width, height = K0, [], np.zeros(5), 960, 540
+        K = K0 * np.array([[0.6], [0.6], [1.0]])
+    mx, my, sep = FR.camera_maps_compact(CM)
+    full = FR.undistort_rectify_map(CM.K_origin, [], CM.K, 960, 540)
+    assert sep == 1 and np.array_equal(full[0][0], mx) and np.array_equal(full[1][:, 0], my)
+
+    class CMd:                                                         # (its own class: the maps are cached on the object)
+        K_origin, d, width, height, K = CM.K_origin, [], 960, 540, CM.K
+        d_origin = np.array([-0.05, 0.01, 0.0, 0.0, 0.0])
+    mx, my, sep = FR.camera_maps_compact(CMd)
+    assert sep == 0 and mx.shape == (540, 960)

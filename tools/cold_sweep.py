@@ -102,6 +102,18 @@ def main(argv=None):
     configs = {"cama_configs": dict(DEFAULT_CAMA_CONFIGS), "output_video_dir": os.path.join(root, "videos")}
     os.makedirs(configs["output_video_dir"], exist_ok=True)
     clock = time.perf_counter
+    # the interpreter's cyclic collector runs where it pleases (a full collection over torch's and numpy's objects is ~5-10 ms):
+    # its time is reported per scene so that it is not mistaken for the stage it happened to interrupt
+    import gc
+    gc_state = {"t0": 0.0, "total": 0.0, "n": 0}
+
+    def on_gc(phase, info):
+        if phase == "start":
+            gc_state["t0"] = clock()
+        else:
+            gc_state["total"] += clock() - gc_state["t0"]
+            gc_state["n"] += 1
+    gc.callbacks.append(on_gc)
     dev = None
     rows = []
     wall0 = clock()
@@ -109,6 +121,7 @@ def main(argv=None):
     for k, clip_path in enumerate(clips):
         scene_name = os.path.basename(clip_path)
         a0 = big_allocs(torch, dev) if dev is not None else (0, 0)
+        g0 = (gc_state["total"], gc_state["n"])
         t0 = clock()
         cm = None                                               # (main.py rebinds `cm`: the previous clip goes here)
         t_drop = clock() - t0
@@ -126,6 +139,7 @@ def main(argv=None):
             dev = runtime.engine().device
         torch.cuda.synchronize(dev)
         row["wall"] = clock() - t0
+        row["gc_s"], row["gc_runs"] = gc_state["total"] - g0[0], gc_state["n"] - g0[1]
         a1 = big_allocs(torch, dev)
         row["new_segments"], row["new_reserved_bytes"] = a1[0] - a0[0], a1[1] - a0[1]
         pool = runtime.engine().pool
@@ -134,7 +148,7 @@ def main(argv=None):
         print(f"{scene_name}: wall {row['wall'] * 1e3:7.1f} ms | setup {t_setup * 1e3:6.1f} | "
               + " | ".join(f"{d}: first {row[d]['first'] * 1e3:6.1f} rest {row[d]['rest'] * 1e3:6.1f} close {row[d]['close'] * 1e3:5.1f} "
                            f"({row[d]['frames']} fr)" for d in ("cama", "nuscenes"))
-              + f" | new device segments {row['new_segments']} ({row['new_reserved_bytes'] / 1e6:.0f} MB)")
+              + f" | gc {row['gc_s'] * 1e3:.1f} ms in {row['gc_runs']} | drop prev {t_drop * 1e3:.1f} | new device segments {row['new_segments']} ({row['new_reserved_bytes'] / 1e6:.0f} MB)")
     total = clock() - wall0
     # the steady time of the same two passes: the last scene's ClipManager, again
     warm = []
@@ -156,7 +170,7 @@ def main(argv=None):
                "steady_two_passes_s": steady, "cold_over_steady": (med / steady) if steady else None,
                "later_scenes_new_segments": sum(r["new_segments"] for r in later),
                "later_scenes_new_reserved_MB": sum(r["new_reserved_bytes"] for r in later) / 1e6,
-               "mean_ms": {key: 1e3 * sum(r[key] for r in later) / len(later) for key in ("setup", "drop_previous")}}
+               "mean_ms": {key: 1e3 * sum(r[key] for r in later) / len(later) for key in ("setup", "drop_previous", "gc_s")}}
     for d in ("cama", "nuscenes"):
         for key in ("first", "rest", "close"):
             summary["mean_ms"][f"{d}_{key}"] = 1e3 * sum(r[d][key] for r in later) / len(later)
