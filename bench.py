@@ -440,7 +440,10 @@ class Job:
         if self.frame_range is None:
             return None
         idx_all, w2c_all = cm.frame_poses("cama")                       # this rank's slice of the clip's poses
-        return idx_all[self.lo:self.hi], w2c_all[self.lo:self.hi]
+        hit = self.poses.get(id(cm))
+        if hit is None or hit[0] is not w2c_all:                        # (the same slice objects while the clip's poses are the same)
+            hit = self.poses[id(cm)] = (w2c_all, (idx_all[self.lo:self.hi], w2c_all[self.lo:self.hi]))
+        return hit[1]
 
     def _first_render(self, k):
         """Scene k's mosaic buffer the way any caller of the public surface gets one: ClipManager.render_clip(out=None) returns
@@ -605,6 +608,21 @@ class Job:
                 os.environ.pop("CAMA_AUDITION", None)
             else:
                 os.environ["CAMA_AUDITION"] = env
+
+    def unmemoised_leg(self, steps, warmup, sync_all):
+        """The K steps once more with CAMA_NO_POSE_MEMO=1: every step recomputes its poses (seek + slerp + float32 inverse) and,
+        the pose arrays being new objects, goes through ClipManager.render_clip's full path instead of the memoised launch
+        list -- the round-4 step, printed beside the default one."""
+        os.environ["CAMA_NO_POSE_MEMO"] = "1"
+        keep_prof = (getattr(self, "project_ms", 0.0), getattr(self, "project_n", 0), getattr(self, "overlay_each", None))
+        try:
+            dt, _, _ = self.run(steps, warmup, sync_all, 0)
+            n = len(self.scenes)
+            return {"seconds": dt, "steps": steps, "frames_per_s": self.F * steps * n / dt if dt > 0 else 0.0,
+                    "ms_per_step": dt / max(1, steps) * 1e3}
+        finally:
+            del os.environ["CAMA_NO_POSE_MEMO"]
+            self.project_ms, self.project_n, self.overlay_each = keep_prof
 
     def projection_bytes(self):
         """Untimed: one plain render of the first scene, then cama_bin_stats -> (vertex bytes read, stamp bytes written)
@@ -940,6 +958,8 @@ def main():
                   file=sys.stderr, flush=True)
             sys.exit(3)
     sus_steps, sus_dt = job.sustain(args.sustain_seconds, args.steps, dt, sync_all)
+    unmemoised = job.unmemoised_leg(args.steps, args.warmup, sync_all) \
+        if (world == 1 and args.steps > 0 and not os.environ.get("CAMA_NO_POSE_MEMO")) else None
     unplaced = job.unplaced_leg(args.steps, args.warmup, sync_all, prof_every) \
         if (world == 1 and args.steps > 0 and os.environ.get("CAMA_AUDITION", "16") != "0") else None
     vbytes, sbytes, bin_stats = job.projection_bytes()
@@ -1098,6 +1118,14 @@ def main():
                     line["k_steps_region"]["hbm_frac_whole_step"] = line["hbm_frac_whole_step"]
                     line["hbm_GBps_whole_step"] = bytes_per_frame * (float(m[0, 12]) / float(m[0, 13])) / 1e9
                     line["hbm_frac_whole_step"] = line["hbm_GBps_whole_step"] / HBM_PEAK_GBS
+        line["config"]["step"] = ("ClipManager.render_clip(out=<the engine's pooled mosaic>, pipelined): frame poses memoised per "
+                                  "(track, stamps); the clip's launches worked out once and replayed, one library call each "
+                                  "(cama_pipeline_render_clip)" if not os.environ.get("CAMA_NO_POSE_MEMO") else
+                                  "CAMA_NO_POSE_MEMO=1: poses recomputed and launches re-derived on every step")
+        if unmemoised is not None:
+            line["without_memo"] = dict(unmemoised, note="the same K steps with CAMA_NO_POSE_MEMO=1: seek + slerp + float32 inverse "
+                                                         "recomputed and the launch arguments re-derived in Python on every step "
+                                                         "(what every step did until round 4)")
         line["rank_affinity"] = {"cpus_per_rank": [int(x) for x in m[:, 19]], "first_cpu": [int(x) for x in m[:, 20]],
                                  "last_cpu": [int(x) for x in m[:, 21]], "gpu_numa_node": [int(x) for x in m[:, 22]],
                                  "bound": [bool(x) for x in m[:, 23]],

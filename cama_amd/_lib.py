@@ -10,13 +10,25 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 20
+ABI_VERSION = 21
 BIN_WORKLIST = 1
 BIN_SEGMENTS = 2
 BIN_SEGMENTS_WU = 4            # EXTENSION: discs + one-pixel segments between polyline neighbours (include/cama_hip.h)
 
 _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _u64 = ctypes.c_uint64
+
+MAX_RADIUS = 15
+
+
+class Clip(ctypes.Structure):
+    """include/cama_hip.h: cama_clip -- what stays the same from launch to launch of one clip."""
+    _fields_ = [("x", _vp), ("y", _vp), ("z", _vp), ("colour_id", _vp), ("draw_key", _vp), ("block_bounds", _vp),
+                ("c2cam", _vp), ("K", _vp), ("vrows", _vp), ("band_rows", _vp), ("N", _i64), ("crop", ctypes.c_double * 6),
+                ("xyz_is_f64", _i32), ("flags", _i32), ("C", _i32), ("W", _i32), ("H", _i32), ("cols", _i32), ("radius", _i32),
+                ("kind", _i32), ("H0", _i32), ("W0", _i32), ("max_src_rows", _i32), ("reserved", _i32),
+                ("halfwidth", _i32 * (MAX_RADIUS + 1)), ("palette_bgr", ctypes.c_uint8 * 8)]
+
 
 # name -> (restype, argtypes); mirrors include/cama_hip.h one to one
 SIGNATURES = {
@@ -57,6 +69,7 @@ SIGNATURES = {
     "cama_pipeline_render_scenes": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
                                            _vp, _vp, _sz, _vp]),
     "cama_pipeline_stage_poses": (_i32, [_vp, _vp, _i32, _vp]),
+    "cama_pipeline_render_clip": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "cama_pipeline_join": (_i32, [_vp, _vp]),
     "cama_pipeline_issued": (_i64, [_vp]),
     "cama_pipeline_completed": (_i64, [_vp]),

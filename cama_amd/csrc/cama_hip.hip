@@ -2107,6 +2107,34 @@ int cama_pipeline_render_raw35(cama_pipeline *p, const void *x, const void *y, c
                                 });
 }
 
+int cama_pipeline_render_clip(cama_pipeline *p, const cama_clip *clip, const float *w2c_host_f32, int32_t F, const uint8_t *src,
+                              uint8_t *mosaic, void *input_stream, int64_t *issued, int64_t *completed)
+{
+    if (!p || !clip) return fail(CAMA_EINVAL, "NULL pointer argument");
+    if (clip->kind != 0 && clip->kind != 1) return fail(CAMA_EINVAL, "cama_clip.kind %d (0 = frames at output size, 1 = raw 3:5)", clip->kind);
+    if (clip->radius < 0 || clip->radius > CAMA_MAX_RADIUS) return fail(CAMA_EINVAL, "radius %d out of range", clip->radius);
+    const double *w2c = nullptr;
+    if (int rc = cama_pipeline_stage_poses(p, w2c_host_f32, F, &w2c)) return rc;
+    const cama_clip &c = *clip;
+    int rc;
+    if (c.kind == 0)
+        rc = cama_pipeline_render(p, c.x, c.y, c.z, c.xyz_is_f64, c.colour_id, c.draw_key, c.block_bounds, c.flags, c.N, w2c, F,
+                                  c.c2cam, c.K, c.C, c.crop, c.W, c.H, src, mosaic, c.cols, c.radius, c.halfwidth, c.palette_bgr,
+                                  nullptr, nullptr, 0, input_stream);
+    else
+        rc = cama_pipeline_render_raw35(p, c.x, c.y, c.z, c.xyz_is_f64, c.colour_id, c.draw_key, c.block_bounds, c.flags, c.N, w2c,
+                                        F, c.c2cam, c.K, c.C, c.crop, c.W, c.H, src, c.H0, c.W0, c.vrows, c.band_rows,
+                                        c.max_src_rows, mosaic, c.cols, c.radius, c.halfwidth, c.palette_bgr, nullptr, nullptr, 0,
+                                        input_stream);
+    if (rc) return rc;
+    if (issued) *issued = (int64_t)p->issued;
+    if (completed) {
+        if (int rp = pipeline_poll(p)) return rp;
+        *completed = (int64_t)p->completed;
+    }
+    return CAMA_OK;
+}
+
 int64_t cama_pipeline_scratch_bytes(cama_pipeline *p)
 {
     if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");

@@ -230,6 +230,8 @@ class ClipManager:
             tuple(configs.get("output_size", (540, 960)))
         self._static_cache = {}
         self._track_cache = {}
+        self._poses_memo = {}
+        self._launch_memo = {}
         self._rig_cache = None
         # configs["egress"] = "i420" | "bgr24": what a listening VideoGenerator receives (runtime.egress_format); absent =
         # the environment's choice (default bgr24, the reference's stream).  Process-wide: the newest ClipManager decides.
@@ -361,13 +363,24 @@ class ClipManager:
         chassis->world, cast to float32, float32 general inverse -- done for all frames at once.  Frames whose
         pose lookup would raise RuntimeError are left out, as the reference skips them.  Index 0 is never
         rendered (dataset.py:88 starts at 1)."""
-        pt, secs = self._track(dataset)
+        track = self._track(dataset)
+        # memoised per (track, stamps): both are parsed from the clip's files once and never change afterwards, so neither does
+        # this function of them -- the same arrays come back (read-only), bit for bit what the recomputation gives
+        # (tests/test_host_golden.py).  On launches of 0.1 ms the 0.1 ms of seek + slerp + inverse per step was what paced the
+        # host (profiles/r05_960x540_bench.json).  CAMA_NO_POSE_MEMO=1: recompute on every call (A/B).
+        memo = self._poses_memo.get(dataset)
+        if memo is not None and memo[0] is track and not os.environ.get("CAMA_NO_POSE_MEMO"):
+            return memo[1]
+        pt, secs = track
         if len(secs) <= 1:
             return np.zeros(0, np.int64), np.zeros((0, 4, 4), np.float32)
         ok, c2w = pt.seek_many(secs[1:], 0.5, interpolate=True)
         idx = np.flatnonzero(ok) + 1
         c2w32 = c2w[ok].astype(np.float32)
-        w2c = np.linalg.inv(c2w32) if len(idx) else np.zeros((0, 4, 4), np.float32)
+        w2c = np.ascontiguousarray(np.linalg.inv(c2w32)) if len(idx) else np.zeros((0, 4, 4), np.float32)
+        idx.setflags(write=False)
+        w2c.setflags(write=False)
+        self._poses_memo[dataset] = (track, (idx, w2c))
         return idx, w2c
 
     # ------------------------------------------------------------------ the reference's per-frame API
@@ -483,6 +496,52 @@ class ClipManager:
         return batches[b], k - ra["bounds"][b][0]
 
     # ------------------------------------------------------------------ whole-clip fused path
+    def _plan_launches(self, eng, dataset, dmap, rig, src_all, fused_raw, out, w2c, ids, step, cuts, crop, segments, fpl):
+        """Work out the pipelined launches of a whole-clip render ONCE: the clip's launch-invariant arguments as a cama_clip
+        (Engine.clip_desc) and per launch (host pose pointer, F, source pointer, mosaic pointer, keep tuple).  Kept in
+        `_launch_memo[dataset]` together with everything the pointers were taken from; _launches_valid() re-checks those by
+        identity before a later render_clip() replays them.  None when this clip does not fit the one-call form."""
+        F = len(ids)
+        raw = None
+        if fused_raw:
+            c0 = self.cm_list[0]
+            raw = (int(c0.height_origin), int(c0.width_origin), self.cm_list)
+        try:
+            desc = eng.clip_desc(dmap, rig, crop=crop, segments=segments, raw=raw)
+        except Exception:
+            return None
+        if desc is None:
+            return None
+        launches, lo = [], 0
+        base = w2c.ctypes.data
+        while lo < F:
+            hi = min([F, lo + step] + [c for c in cuts if c > lo][:1])
+            src = src_all.raw_batch(ids[lo:hi]) if fused_raw else src_all.batch(ids[lo:hi])
+            dst = out[lo:hi]
+            if not (src.is_cuda and src.is_contiguous() and dst.is_contiguous()):
+                return None
+            want = (hi - lo, rig.C) + ((raw[0], raw[1]) if fused_raw else (rig.H, rig.W)) + (3,)
+            assert tuple(src.shape) == want and tuple(dst.shape) == eng.mosaic_shape(rig, hi - lo), (tuple(src.shape), want)
+            launches.append((base + lo * 64, hi - lo, src.data_ptr(), dst.data_ptr(), (None, src, dst, dmap, rig, tuple(desc._keep[2:]))))
+            lo = hi
+        memo = {"desc": desc, "launches": launches, "out": out, "w2c": w2c, "source": src_all,
+                "frames": getattr(src_all, "raw", None) if fused_raw else getattr(src_all, "frames", None),
+                "ins": self.instance_maps[dataset], "dmap": dmap, "rig": rig, "segments": segments, "fpl": fpl,
+                "crop": tuple(float(v) for v in np.asarray(crop).reshape(-1)), "pipe": eng._pipeline(), "eng": eng,
+                "fused_raw": fused_raw}
+        self._launch_memo[dataset] = memo
+        return memo
+
+    def _launches_valid(self, memo, eng, dataset, out, w2c, fpl, segments):
+        """Everything a memoised launch list was derived from is still the very object it was derived from."""
+        src = self._frame_source
+        return (memo["out"] is out and memo["w2c"] is w2c and memo["source"] is src and memo["eng"] is eng
+                and memo["pipe"] is eng._pipe and memo["fpl"] == fpl and memo["segments"] == segments
+                and memo["ins"] is self.instance_maps.get(dataset) and memo["rig"] is self._rig_cache
+                and (getattr(src, "raw", None) if memo["fused_raw"] else getattr(src, "frames", None)) is memo["frames"]
+                and memo["dmap"] is self._static(dataset)._dmap
+                and memo["crop"] == tuple(float(v) for v in self.mm.crop_box()))
+
     def _pooled_mosaic(self, eng, rig, src_all, ids, step, probe):
         """The mosaic of a whole-clip render the caller did not bring: views of the engine's pooled, placed buffers
         (Engine.pool) -- one tensor, or, for clips beyond CAMA_MOSAIC_CHUNK_BYTES (8 GiB), a ChunkedMosaic of one buffer per
@@ -510,12 +569,22 @@ class ClipManager:
         then call runtime.engine().join() before consuming `out` on the current stream."""
         import torch
         eng = runtime.engine()
-        rig = self._rig()
-        dmap = self._static(dataset).device()
         # segments: the opt-in extension (discs + one-pixel segments between polyline neighbours); None = configs["segments"]
         # ("wu": the anti-aliased variant -- Wu lines blended once by coverage; batched path only)
         segments = _segments_mode(self.configs.get("segments", False) if segments is None else segments)
         idx, w2c = poses if poses is not None else self.frame_poses(dataset)
+        if pipelined and out is not None:
+            # the same clip into the same buffers again (a service re-rendering, bench.py's steps): the launches were worked
+            # out the first time -- one library call each (Engine.render_clip_launch), nothing else
+            memo = self._launch_memo.get(dataset)
+            if memo is not None and self._launches_valid(memo, eng, dataset, out, w2c, frames_per_launch, segments):
+                launch = eng.render_clip_launch
+                desc = memo["desc"]
+                for a in memo["launches"]:
+                    launch(desc, *a)
+                return idx, out
+        rig = self._rig()
+        dmap = self._static(dataset).device()
         F = len(idx)
         shape = eng.mosaic_shape(rig, F)
         if F == 0:
@@ -547,6 +616,14 @@ class ClipManager:
         T = w2c if host_poses else eng._mats(w2c)
         # a ChunkedMosaic (one pooled allocation per launch, _pooled_mosaic): launches end at its chunk boundaries
         cuts = sorted(set(getattr(out, "bounds", ())))
+        if host_poses and resident and ids == list(range(ids[0], ids[0] + F)) and eng.alpha256 == 256 \
+                and not os.environ.get("CAMA_NO_LAUNCH_MEMO"):
+            memo = self._plan_launches(eng, dataset, dmap, rig, src_all, fused_raw, out, w2c, ids, step, cuts, crop, segments,
+                                       frames_per_launch)
+            if memo is not None:
+                for a in memo["launches"]:
+                    eng.render_clip_launch(memo["desc"], *a)
+                return idx, out
         lo = 0
         while lo < F:
             hi = min([F, lo + step] + [c for c in cuts if c > lo][:1])

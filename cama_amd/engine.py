@@ -1103,6 +1103,77 @@ class Engine:
             self._release_completed(P)
             return out
 
+    # ------------------------------------------------------------------ one call per launch of a clip
+    def clip_desc(self, dmap, rig, crop=None, cols=3, segments=False, raw=None):
+        """The launch-invariant half of a clip's pipelined renders as a cama_clip (include/cama_hip.h): filled once, handed
+        to render_clip_launch() for every launch.  raw = (H0, W0, cm_list) for raw sensor frames through the 3:5 kernel
+        (returns None when the rig's maps are not of that form).  The returned object keeps what its pointers refer to."""
+        cropa = self._crop(crop)
+        x, y, z, col, key, bnd, bflags = dmap.render_ptrs(cropa)
+        if segments:
+            if key is not None or not getattr(dmap, "has_links", False):
+                raise _lib.CamaHipError("segments need a map in draw order that carries its polyline links "
+                                        "(ClipManager builds one; spatially sorted maps have no neighbours)")
+            if self.alpha256 != 256:
+                raise _lib.CamaHipError("segments and translucent stamps are separate extensions")
+            bflags |= _lib.BIN_SEGMENTS | (_lib.BIN_SEGMENTS_WU if segments == "wu" else 0)
+        d = _lib.Clip()
+        d.x, d.y, d.z, d.colour_id, d.draw_key, d.block_bounds = x, y, z, col, key, bnd
+        d.c2cam, d.K = rig.c2cam.data_ptr(), rig.K.data_ptr()
+        d.N, d.xyz_is_f64, d.flags, d.C, d.W, d.H, d.cols, d.radius = dmap.N, dmap.is_f64, bflags, rig.C, rig.W, rig.H, cols, self.radius
+        for k in range(6):
+            d.crop[k] = float(cropa[k])
+        for k, v in enumerate(self.halfwidth):
+            d.halfwidth[k] = int(v)
+        for k, v in enumerate(self.palette.reshape(-1)):
+            d.palette_bgr[k] = int(v)
+        keep = [dmap, rig]
+        if raw is not None:
+            H0, W0, cm_list = raw
+            plan = self.rig_maps(cm_list)
+            vrows = plan[8]
+            if vrows is None:
+                return None
+            d.kind, d.H0, d.W0 = 1, int(H0), int(W0)
+            d.vrows, d.band_rows, d.max_src_rows = vrows[0].data_ptr(), vrows[1].data_ptr(), int(vrows[2])
+            keep.append(tuple(t for t in (vrows[0], vrows[1], plan[0], plan[1], plan[3], plan[5]) if t is not None))
+        import ctypes
+        d._keep = keep
+        d._ref = ctypes.byref(d)
+        return d
+
+    def render_clip_launch(self, desc, w2c_ptr, F, src_ptr, out_ptr, keep):
+        """One pipelined launch of a clip in ONE library call (cama_pipeline_render_clip): w2c_ptr = HOST float32 [F,16].
+        `keep` = the 6-tuple (None, src, out, dmap, rig, extra) of what the launch reads / writes (held until it completes)."""
+        P = self._pipe or self._pipeline()
+        torch = _torch()
+        box = self.__dict__.get("_seq_box")
+        if box is None:
+            import ctypes
+            box = self.__dict__["_seq_box"] = (ctypes.c_int64(0), ctypes.c_int64(0))
+            box = box + (ctypes.byref(box[0]), ctypes.byref(box[1]))
+            self.__dict__["_seq_box"] = box
+        fn = self.lib.cama_pipeline_render_clip
+        args = (P["handle"], desc._ref, w2c_ptr, F, src_ptr, out_ptr)
+        if torch.cuda.current_device() == self.device.index:
+            rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream, box[2], box[3])
+            if rc == _lib.ENOMEM:
+                torch.cuda.empty_cache()
+                rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream, box[2], box[3])
+        else:
+            with torch.cuda.device(self.device):
+                rc = fn(*args, self._stream(), box[2], box[3])
+        if rc:
+            _lib.check(rc)
+        kp = P["keep"]
+        kp.append((box[0].value,) + keep)
+        done = box[1].value
+        n = 0
+        while n < len(kp) and kp[n][0] <= done:
+            n += 1
+        if n:
+            del kp[:n]
+
     # ------------------------------------------------------------------ many scenes per launch
     def scene_batchable(self, items):
         """True when `items` = [(dmap, rig, w2c, src, out), ...] can go out as ONE multi-scene launch (cama_*_scenes):

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 20
+#define CAMA_ABI_VERSION 21
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -252,6 +252,35 @@ int cama_pipeline_render_raw35(cama_pipeline *p, const void *x, const void *y, c
                                const uint32_t *vrows, const int32_t *band_rows, int32_t max_src_rows, uint8_t *mosaic,
                                int32_t cols, int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
                                void *scratch0, void *scratch1, size_t scratch_bytes, void *input_stream);
+/*
+ * One call per launch of a clip (round 5): everything about a clip that does NOT change from launch to launch -- its static
+ * map, calibration, crop box, output geometry, disc, palette, and for raw sensor frames the 3:5 tap tables -- lives in a
+ * `cama_clip` the caller fills once (HOST struct of device pointers and scalars; read during the call only).  A launch is then
+ *     cama_pipeline_stage_poses + cama_pipeline_render (kind 0) | cama_pipeline_render_raw35 (kind 1) + the two counters
+ * in ONE crossing of the boundary: the host float32 world->chassis matrices of the launch's F frames (the np.linalg.inv result,
+ * cama/dataset.py:99), the frames to read and the mosaic to write.  Pipeline-owned scratch.  *issued = this launch's number,
+ * *completed = launches known to be over (as cama_pipeline_issued / cama_pipeline_completed; either may be NULL).  Replaces, per
+ * step of ClipManager.render_clip, four calls with ~30 marshalled arguments each -- on launches of 0.1 ms (960x540) the host, not
+ * the GPU, set the pace.  Same kernels, same results.  Mirrors the per-frame body of cama/dataset.py:78-126 like the entries above.
+ */
+typedef struct cama_clip {
+    const void *x, *y, *z;             /* static map, SoA [N] each (float32, or float64 when xyz_is_f64) */
+    const uint8_t *colour_id;          /* [N] */
+    const uint32_t *draw_key;          /* [N] or NULL */
+    const double *block_bounds;        /* per-64-vertex AABBs (cama_map_bounds) or NULL */
+    const double *c2cam, *K;           /* [C,16], [C,9] */
+    const uint32_t *vrows;             /* kind 1: cama_raw35_plan's tables */
+    const int32_t *band_rows;
+    int64_t N;
+    double crop[6];
+    int32_t xyz_is_f64, flags, C, W, H, cols, radius;
+    int32_t kind;                      /* 0: `src` holds frames at output size [F,C,H,W,3]; 1: raw sensor frames [F,C,H0,W0,3] */
+    int32_t H0, W0, max_src_rows, reserved;
+    int32_t halfwidth[CAMA_MAX_RADIUS + 1];
+    uint8_t palette_bgr[8];            /* 2 x BGR, 2 bytes of padding */
+} cama_clip;
+int cama_pipeline_render_clip(cama_pipeline *p, const cama_clip *clip, const float *w2c_host_f32, int32_t F,
+                              const uint8_t *src, uint8_t *mosaic, void *input_stream, int64_t *issued, int64_t *completed);
 int cama_pipeline_join(cama_pipeline *p, void *stream);
 int64_t cama_pipeline_issued(cama_pipeline *p);
 int64_t cama_pipeline_completed(cama_pipeline *p);

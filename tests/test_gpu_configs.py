@@ -526,6 +526,76 @@ def test_placed_buffers_render_the_same_bytes(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_memoised_launch_list_replays_the_same_bytes_and_notices_every_change():
+    """Round 5: a pipelined render_clip into the same buffers works out its launches once (Engine.clip_desc + one
+    cama_pipeline_render_clip call per launch) and replays them while everything they were derived from is still the very
+    same object.  The replay writes the bytes the un-memoised path writes (= the oracle's, golden hashes); a new mosaic, a new
+    frame tensor, a changed crop box, a re-parsed pose track or CAMA_NO_LAUNCH_MEMO each send the next call down the full path."""
+    import torch
+    from cama_amd import runtime
+    from cama_amd.frames import DeviceFrameSource
+    a = _args(frames=12, height=270, width=480)
+    dev = torch.device("cuda:0")
+    eng = runtime.engine()
+    cm, frames, _ = bench.build_scene(a, 3, dev)
+    _, plain = cm.render_clip("cama")                                  # single stream, no memo
+    want = plain.clone()
+    out = torch.empty_like(want)
+    calls = []
+    real = eng.render_clip_launch
+    eng.render_clip_launch = lambda *args: (calls.append(args[2]), real(*args))[1]
+    try:
+        def step(o=out, **kw):
+            o.fill_(0xA5)
+            cm.render_clip("cama", out=o, pipelined=True, **kw)
+            eng.join()
+            torch.cuda.synchronize()
+            assert torch.equal(o, want)
+        step()
+        memo = cm._launch_memo["cama"]
+        assert len(memo["launches"]) == 1 and calls == [12]
+        step()
+        assert cm._launch_memo["cama"] is memo and calls == [12, 12]          # replayed
+        step(frames_per_launch=5)                                             # another launch size: planned again (5 + 5 + 2)
+        assert cm._launch_memo["cama"] is not memo and calls[2:] == [5, 5, 2]
+        memo = cm._launch_memo["cama"]
+        step(frames_per_launch=5)
+        assert cm._launch_memo["cama"] is memo
+        other = torch.empty_like(want)
+        step(other, frames_per_launch=5)                                      # another mosaic
+        assert cm._launch_memo["cama"]["out"] is other
+        memo = cm._launch_memo["cama"]
+        cm.set_frame_source(DeviceFrameSource(frames.clone()))                # another source object
+        step(other, frames_per_launch=5)
+        assert cm._launch_memo["cama"] is not memo
+        memo = cm._launch_memo["cama"]
+        cm._track_cache.pop("cama")                                           # re-parsed track: new pose arrays
+        step(other, frames_per_launch=5)
+        assert cm._launch_memo["cama"] is not memo
+        # a changed crop box changes the picture: the memo must not replay the old one
+        cm.mm.crop_dict["x_max"] = 5.0
+        _, cropped = cm.render_clip("cama")
+        assert not torch.equal(cropped, want)
+        other.fill_(0xA5)
+        cm.render_clip("cama", out=other, pipelined=True, frames_per_launch=5)
+        eng.join()
+        torch.cuda.synchronize()
+        assert torch.equal(other, cropped)
+    finally:
+        eng.render_clip_launch = real
+    # raw sensor frames through the 3:5 kernel: the same one-call form (kind 1)
+    b = _args(frames=6, height=540, width=960, raw_frames=True)
+    cm2, raw, _ = bench.build_scene(b, 4, dev)
+    _, plain2 = cm2.render_clip("cama")
+    o2 = torch.full_like(plain2, 0xA5)
+    for _ in range(2):
+        cm2.render_clip("cama", out=o2, pipelined=True)
+    eng.join()
+    torch.cuda.synchronize()
+    assert torch.equal(o2, plain2) and cm2._launch_memo["cama"]["desc"].kind == 1
+
+
+@pytest.mark.gpu
 def test_fullsize_site_scenes_equal_the_oracle():
     """configs[3] at FULL size as bench.py runs it on one GPU (12 scenes over three 10^6-vertex site maps, 40 frames at
     1600x900): one scene of every site plus a second drive over scene 0's site,
