@@ -573,7 +573,7 @@ class Job:
             # then THE region; every rank runs both, so the barriers pair up whatever the ranks' rates are
             n0 = max(1, int(0.2 * seconds / per + 0.5))
             d0 = region(n0)
-            n = max(1, int(1.05 * seconds / max(1e-6, d0 / n0) + 1.0))
+            n = max(1, int(1.15 * seconds / max(1e-6, d0 / n0) + 1.0))
             return n, region(n)
         finally:
             if gc_was_on:
@@ -643,7 +643,7 @@ class Job:
                                segments=_segments(self.args))
                 break
             except torch.OutOfMemoryError:                      # (ranks sharing one GPU: the single-stream scratch on top of
-                if per == 1:                                    # the pipeline's two slots may not fit; fewer frames do)
+                if per == 1:                                    # the pipeline's slots may not fit; fewer frames do)
                     raise
                 self.eng.shrink_frames_per_call()
                 per = max(1, per // 2)
@@ -793,6 +793,7 @@ def plan(args):
     which scenes it gets (the same shard.assign_scenes / frame_ranges calls main() makes), what is resident in HBM during
     the timed region, and the stamp scratch.  An 8-GPU node's first run must not die on memory."""
     from cama_amd import _lib, shard
+    from cama_amd.engine import PIPELINE_DEPTH as DEPTH
     L = _lib.lib()                                    # host-side size functions of the library (no device call)
     world = args.gpus
     H, W, C = args.height, args.width, 6
@@ -801,11 +802,11 @@ def plan(args):
     cap = int(args.hbm_gb * 1e9)
 
     def scratch(N, F, planned_demand=None):
-        """(worst-case bytes of ONE slot, what the pipeline will hold for its two slots)."""
+        """(worst-case bytes of ONE slot, what the pipeline will hold for its slots: three, cama_amd.engine.PIPELINE_DEPTH)."""
         worst = int(L.cama_render_scratch_bytes(int(N), int(F), C, H, W, 2))
         if planned_demand is not None:
-            return worst, int(2 * planned_demand * F)
-        return worst, 2 * worst
+            return worst, int(DEPTH * planned_demand * F)
+        return worst, DEPTH * worst
 
     ranks = []
     if args.shard_frames:
@@ -855,7 +856,7 @@ def plan(args):
         if do_stress:                                               # runs after the sweep's buffers are freed
             slo, shi = shard.frame_ranges(args.stress_frames, world)[r]
             sF = shi - slo
-            sw, sh = int(L.cama_render_scratch_bytes(args.stress_verts, min(sF, 128), C, H, W, 2)), int(2 * 8e6 * (args.stress_verts / 1e6) * min(sF, 128))
+            sw, sh = int(L.cama_render_scratch_bytes(args.stress_verts, min(sF, 128), C, H, W, 2)), int(DEPTH * 8e6 * (args.stress_verts / 1e6) * min(sF, 128))
             stress_total = 2 * sF * frame_b + args.stress_verts * 30 + sh
             rec["stress"] = {"frame_range": [slo, shi], "resident_frames_bytes": sF * frame_b, "mosaic_bytes": sF * frame_b,
                              "scratch_worst_case_one_slot": sw, "scratch_held_planned": sh, "total_bytes": stress_total}
@@ -866,7 +867,7 @@ def plan(args):
     out = {"plan": True, "gpus": world, "hbm_bytes_per_gpu": cap, "workload": args_key(args), "scenes": n_scenes,
            "ranks": ranks, "fits": all(r["fits"] for r in ranks),
            "note": "host arithmetic only: frames / mosaics / maps resident during the timed region + the stamp scratch the "
-                   "two pipeline slots hold (site-sized maps: demand-sized by the pipeline, ~8 MB per frame and 10^6 "
+                   "pipeline's slots hold (site-sized maps: demand-sized by the pipeline, ~8 MB per frame and 10^6 "
                    "vertices measured; others: the worst case of cama_render_scratch_bytes)"}
     print(json.dumps(out))
     return 0 if out["fits"] else 1
@@ -1095,6 +1096,16 @@ def main():
             "roofline_project": r_project,
             "scratch_bytes": int(m[0, 18]),
         }
+        if args.raw_frames:
+            line["config"]["workload"] += "; raw 1600x900 frames resampled on device each step"
+            # this mode's kernel reads the raw frames and writes the resized mosaic: 3*C*(H0*W0 + H*W) bytes per frame
+            raw_image = 3 * 6 * (900 * 1600 + H * W)
+            r_overlay, r_project, raw_bytes = rooflines(m, raw_image, "k_overlay_raw*")
+            r_overlay["bytes_per_frame"] = "3*C*(H0*W0 + H*W): raw frame read once, resized mosaic written once"
+            line["roofline"], line["roofline_project"] = r_overlay, r_project
+            bytes_per_frame = raw_bytes
+            line["hbm_GBps_whole_step"] = raw_bytes * (float(m[0, 0]) / float(m[0, 1])) / 1e9
+            line["hbm_frac_whole_step"] = line["hbm_GBps_whole_step"] / HBM_PEAK_GBS
         sus_frames, sus_secs = float(m[:, 12].sum()), float(m[:, 13].max())
         if sus_secs > 0:
             line["sustained"] = {"value": sus_frames / sus_secs, "unit": "frames/s", "seconds": sus_secs,
@@ -1195,15 +1206,6 @@ def main():
             line["config"]["extension"] = ("segments: no reference semantics (the reference draws a disc per point, "
                                            "cama/reproject.py:255-256); bytes checked against the oracle's own restatement "
                                            "in tests/test_gpu_kernels.py and tests/test_gpu_fullsize.py")
-        if args.raw_frames:
-            line["config"]["workload"] += "; raw 1600x900 frames resampled on device each step"
-            # this mode's kernel reads the raw frames and writes the resized mosaic: 3*C*(H0*W0 + H*W) bytes per frame
-            raw_image = 3 * 6 * (900 * 1600 + H * W)
-            r_overlay, r_project, raw_bytes = rooflines(m, raw_image, "k_overlay_raw*")
-            r_overlay["bytes_per_frame"] = "3*C*(H0*W0 + H*W): raw frame read once, resized mosaic written once"
-            line["roofline"], line["roofline_project"] = r_overlay, r_project
-            line["hbm_GBps_whole_step"] = raw_bytes * (float(m[0, 0]) / float(m[0, 1])) / 1e9
-            line["hbm_frac_whole_step"] = line["hbm_GBps_whole_step"] / HBM_PEAK_GBS
         if do_stress:
             sm, sagg, sfound, scheck = finish(allrep[:, sizes[0]:], N_METRICS, s_key, s_samples, "frame positions")
             s_rov, s_rpj, s_bpf = rooflines(sm, 36 * W * H, "k_overlay")

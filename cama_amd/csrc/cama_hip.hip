@@ -337,13 +337,14 @@ Option g_options[] = {
     {"raw35_subrows", "CAMA_RAW35_SUBROWS", 0, {0}, {false}},              // 3:5 raw overlay: 1 = half bands per workgroup
     {"cull_list_min", "CAMA_CULL_LIST_MIN", 16384, {0}, {false}},          // (block, frame) items from which a site-sized
                                                                             // map's cull goes through work lists
+    {"pipeline_depth", "CAMA_PIPELINE_DEPTH", 3, {0}, {false}},            // scratch slots of a cama_pipeline created from now on (2 | 3)
     {"pipeline_host_wait", "CAMA_PIPELINE_HOST_WAIT", -1, {0}, {false}},   // 1: cama_pipeline_* wait for a launch's binning on the
                                                                             // HOST before queueing its overlay (no barrier packet
                                                                             // between consecutive overlays; the call blocks ~0.1 ms);
                                                                             // 0: stream-side wait; -1: host wait for launches that
                                                                             // move >= 1 GiB (the host has the time to spare; at 960x540 it has not)
 };
-enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_RAW35_WS, OPT_RAW35_LOADERS, OPT_RAW35_SUBROWS, OPT_CULL_LIST_MIN, OPT_HOST_WAIT, OPT_COUNT };
+enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_RAW35_WS, OPT_RAW35_LOADERS, OPT_RAW35_SUBROWS, OPT_CULL_LIST_MIN, OPT_PIPELINE_DEPTH, OPT_HOST_WAIT, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
 int64_t option(int k)
 {
@@ -1625,17 +1626,26 @@ int cama_build_static_map(const float *verts, const int32_t *seg_v0, const int32
 // ------------------------------------------------------------------------------------------
 // two-stream pipeline context: binning of batch k+1 overlaps the overlay of batch k
 // ------------------------------------------------------------------------------------------
-// Launch k (1-based) uses scratch slot (k - 1) % 2 and records done[k % RING] on s_ov after its overlay.  The ring
-// serves three purposes: (i) launch k's binning waits for done[(k - 2) % RING], the overlay that last read its slot;
+// Launch k (1-based) uses scratch slot (k - 1) % depth and records done[k % RING] on s_ov after its overlay.  The ring
+// serves three purposes: (i) launch k's binning waits for done[(k - depth) % RING], the overlay that last read its slot;
 // (ii) cama_pipeline_completed() polls it, so the caller knows which launches' inputs (poses, frames) and outputs may
 // be released -- the internal streams are invisible to the caller's allocator; (iii) it bounds the run-ahead: issuing
 // launch k blocks until launch k - (RING - 2) has completed.
+//
+// depth (round 5): THREE slots by default.  With two, launch k+1's binning chain runs beside overlay k and overlay k+1 needs
+// its result the moment overlay k ends -- but beside an HBM-saturating overlay the chain's projection kernel (10 us alone) takes
+// as long as the overlay itself (its loads queue behind the overlay's: profiles/r05_960x540_timeline.txt), so the scans and the
+// scatter (~30 us) landed in the gap BETWEEN two overlays: 144 us per step for a 118 us overlay at 960x540.  With three, the
+// chain of launch k+2 has overlay k AND overlay k+1 to hide under.  Costs one more slot of stamp scratch (pipeline-owned:
+// allocated on first use of the slot); CAMA_PIPELINE_DEPTH=2 restores the old behaviour.
 struct cama_pipeline {
     static constexpr int RING = 64;
+    static constexpr int MAX_DEPTH = 3;
+    int depth = 3;
     // s_pre: the cull pre-pass of PLANNED launches (site-sized maps) and their pose upload -- the call waits for it on the
     // host, and on its own stream it runs beside the previous launch's projection / scatter instead of queueing behind them
     hipStream_t s_bin = nullptr, s_ov = nullptr, s_pre = nullptr;
-    hipEvent_t ready = nullptr, staged = nullptr, binned[2] = {nullptr, nullptr};
+    hipEvent_t ready = nullptr, staged = nullptr, binned[MAX_DEPTH] = {};
     bool prev_planned = false;                  // the previous launch was planned: the next poses go up on s_pre
     uint64_t poses_for = 0;                     // the launch the staged poses belong to, and the stream they went up on
     bool poses_on_pre = false;
@@ -1643,17 +1653,17 @@ struct cama_pipeline {
     uint64_t issued = 0, completed = 0;
     // staged poses (cama_pipeline_stage_poses): a pinned host ring (one slot per in-flight launch) and one device pose
     // buffer per scratch slot: no per-call pose tensor on the caller's side, the upload rides on the binning stream
-    double *pose_host = nullptr, *pose_dev[2] = {nullptr, nullptr};
+    double *pose_host = nullptr, *pose_dev[MAX_DEPTH] = {};
     size_t pose_cap = 0;                        // doubles per slot
     // scratch the pipeline owns (cama_pipeline_render* with scratch0 == NULL): per slot a plan part and a stamp part, grown
     // on demand and never shrunk; the stamp part carries `guard` pattern bytes on either side (cama_pipeline_guard_check)
-    char *own_plan[2] = {nullptr, nullptr}, *own_stamp[2] = {nullptr, nullptr}, *own_sorted[2] = {nullptr, nullptr};
-    size_t own_plan_bytes[2] = {0, 0}, own_stamp_bytes[2] = {0, 0}, own_sorted_bytes[2] = {0, 0};
+    char *own_plan[MAX_DEPTH] = {}, *own_stamp[MAX_DEPTH] = {}, *own_sorted[MAX_DEPTH] = {};
+    size_t own_plan_bytes[MAX_DEPTH] = {}, own_stamp_bytes[MAX_DEPTH] = {}, own_sorted_bytes[MAX_DEPTH] = {};
     static constexpr size_t GUARD = (size_t)1 << 20;
     uint64_t *demand_host = nullptr;            // pinned: [0] (wave, camera) chains, [1..] surviving blocks per frame
     size_t demand_cap = 0;                      // uint64 words
     // what the last launch of each slot looked like (cama_pipeline_bin_stats)
-    struct Last { ScratchRef sc; int64_t N = 0; int32_t F = 0, C = 0, H = 0, W = 0, radius = 0; bool bounds = false; } last[2];
+    struct Last { ScratchRef sc; int64_t N = 0; int32_t F = 0, C = 0, H = 0, W = 0, radius = 0; bool bounds = false; } last[MAX_DEPTH];
     int last_slot = -1;
     uint64_t planned_launches = 0, grows = 0;
 };
@@ -1665,18 +1675,19 @@ int cama_pipeline_create(cama_pipeline **out)
     // device-scope release, no timing: a default event makes the recording stream do a system-scope release after
     // an overlay that wrote ~1 GB, which showed up as ~20 us between consecutive overlays
     const unsigned flags = hipEventDisableTiming | hipEventReleaseToDevice;
-    // A/B knob: CAMA_BIN_PRIORITY=high|low gives the binning stream another priority than the overlay stream
+    const int64_t depth = option(OPT_PIPELINE_DEPTH);
+    p->depth = depth == 2 ? 2 : cama_pipeline::MAX_DEPTH;
+    // The binning stream is the most urgent one: its kernels are small and latency-bound, the overlay beside them fills every
+    // wave slot of the chip, and whatever the chain does not finish under the overlay shows up between two overlays
+    // (960x540, two slots: whole step 0.655 -> 0.680 of 8 TB/s; 10^5 vertices 0.72 -> 0.74; headline unchanged).
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least urgent (numerically greatest)
-    const char *pe = getenv("CAMA_BIN_PRIORITY");
-    const int bin_prio = pe && !strcmp(pe, "high") ? hi : pe && !strcmp(pe, "low") ? lo : (lo + hi) / 2;
-    hipError_t e = pe ? hipStreamCreateWithPriority(&p->s_bin, hipStreamNonBlocking, bin_prio)
-                      : hipStreamCreateWithFlags(&p->s_bin, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithPriority(&p->s_bin, hipStreamNonBlocking, hi);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_ov, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_pre, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready, flags);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->staged, flags);
-    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->binned[k], flags);
+    for (int k = 0; k < cama_pipeline::MAX_DEPTH && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->binned[k], flags);
     for (int k = 0; k < cama_pipeline::RING && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->done[k], flags);
     if (e != hipSuccess) {
         cama_pipeline_destroy(p);
@@ -1694,13 +1705,13 @@ int cama_pipeline_destroy(cama_pipeline *p)
     if (p->s_pre) { (void)hipStreamSynchronize(p->s_pre); (void)hipStreamDestroy(p->s_pre); }
     if (p->ready) (void)hipEventDestroy(p->ready);
     if (p->staged) (void)hipEventDestroy(p->staged);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < cama_pipeline::MAX_DEPTH; ++k)
         if (p->binned[k]) (void)hipEventDestroy(p->binned[k]);
     for (int k = 0; k < cama_pipeline::RING; ++k)
         if (p->done[k]) (void)hipEventDestroy(p->done[k]);
     if (p->pose_host) (void)hipHostFree(p->pose_host);
     if (p->demand_host) (void)hipHostFree(p->demand_host);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < cama_pipeline::MAX_DEPTH; ++k) {
         if (p->pose_dev[k]) (void)hipFree(p->pose_dev[k]);
         if (p->own_plan[k]) (void)hipFree(p->own_plan[k]);
         if (p->own_sorted[k]) (void)hipFree(p->own_sorted[k]);
@@ -1713,7 +1724,7 @@ int cama_pipeline_destroy(cama_pipeline *p)
 // Copy the next launch's world->chassis matrices (HOST, float32 [F,16]: the np.linalg.inv result of
 // cama/dataset.py:99, promoted to double here, exactly) into the pipeline's pinned ring and enqueue their upload on the
 // binning stream, into the device pose buffer of the next launch's scratch slot.  Returns that device pointer: pass it
-// as `w2c` to the next cama_pipeline_render*.  In order behind the previous user of the slot (launch k - 2): on s_bin, or --
+// as `w2c` to the next cama_pipeline_render*.  In order behind the previous user of the slot (launch k - depth): on s_bin, or --
 // after a planned launch -- on the pre-pass stream s_pre.
 int cama_pipeline_stage_poses(cama_pipeline *p, const float *w2c_host_f32, int32_t F, const double **w2c_dev)
 {
@@ -1728,13 +1739,14 @@ int cama_pipeline_stage_poses(cama_pipeline *p, const float *w2c_host_f32, int32
         HIP_TRY(hipStreamSynchronize(p->s_pre));
         const size_t cap = std::max(need, (size_t)64 * 16);
         if (p->pose_host) (void)hipHostFree(p->pose_host);
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < cama_pipeline::MAX_DEPTH; ++k) {
             if (p->pose_dev[k]) (void)hipFree(p->pose_dev[k]);
+            p->pose_dev[k] = nullptr;
+        }
         p->pose_host = nullptr;
-        p->pose_dev[0] = p->pose_dev[1] = nullptr;
         p->pose_cap = 0;
         HIP_TRY(hipHostMalloc((void **)&p->pose_host, RING * cap * sizeof(double), hipHostMallocDefault));
-        for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void **)&p->pose_dev[k], cap * sizeof(double)));
+        for (int k = 0; k < cama_pipeline::MAX_DEPTH; ++k) HIP_TRY(hipMalloc((void **)&p->pose_dev[k], cap * sizeof(double)));
         p->pose_cap = cap;
     }
     const uint64_t k = p->issued + 1;           // the launch these poses belong to
@@ -1743,14 +1755,14 @@ int cama_pipeline_stage_poses(cama_pipeline *p, const float *w2c_host_f32, int32
     }
     double *h = p->pose_host + (size_t)(k % RING) * p->pose_cap;
     for (size_t i = 0; i < (size_t)F * 16; ++i) h[i] = (double)w2c_host_f32[i];
-    const int slot = (int)((k - 1) & 1u);
+    const int slot = (int)((k - 1) % (uint64_t)p->depth);
     double *d = p->pose_dev[slot];
     // after a planned launch the next one is expected to be planned too: its poses go up on the pre-pass stream, behind the
-    // chain that last read this slot's pose buffer (launch k - 2); cama_pipeline_render* orders whichever stream it did
+    // chain that last read this slot's pose buffer (launch k - depth); cama_pipeline_render* orders whichever stream it did
     // not go up on behind the copy
     p->poses_on_pre = p->prev_planned;
     p->poses_for = k;
-    if (p->poses_on_pre && k > 2) HIP_TRY(hipStreamWaitEvent(p->s_pre, p->binned[slot], 0));
+    if (p->poses_on_pre && k > (uint64_t)p->depth) HIP_TRY(hipStreamWaitEvent(p->s_pre, p->binned[slot], 0));
     if (F) HIP_TRY(hipMemcpyAsync(d, h, (size_t)F * 16 * sizeof(double), hipMemcpyHostToDevice, p->poses_on_pre ? p->s_pre : p->s_bin));
     *w2c_dev = d;
     return CAMA_OK;
@@ -1784,7 +1796,7 @@ static int pipeline_grow(cama_pipeline *p, char **buf, size_t *have, size_t need
 {
     if (*have >= need) return CAMA_OK;
     constexpr uint64_t RING = cama_pipeline::RING;
-    if (k > 2) HIP_TRY(hipEventSynchronize(p->done[(k - 2) % RING]));     // the previous user of this slot is over
+    if (k > (uint64_t)p->depth) HIP_TRY(hipEventSynchronize(p->done[(k - p->depth) % RING]));     // the previous user of this slot is over
     HIP_TRY(hipStreamSynchronize(p->s_bin));
     const size_t g = guarded ? cama_pipeline::GUARD : 0;
     if (*buf) HIP_TRY(hipFree(*buf - g));
@@ -1829,7 +1841,9 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
     if (segments && !managed) return fail(CAMA_EINVAL, "CAMA_BIN_SEGMENTS needs pipeline-owned scratch (scratch0 == scratch1 == NULL)");
     constexpr uint64_t RING = cama_pipeline::RING;
     const uint64_t k = p->issued + 1;                     // this launch
-    const int slot = (int)((k - 1) & 1u);
+    // (caller-supplied scratch comes as TWO buffers: such launches alternate between them whatever the context's depth is)
+    const uint64_t D = managed ? (uint64_t)p->depth : 2u;
+    const int slot = (int)((k - 1) % D);
     // bound the run-ahead (and keep done[k % RING], last used by launch k - RING, free): launch k - (RING - 2) must be over
     if (k > RING - 2) {
         HIP_TRY(hipEventSynchronize(p->done[(k - (RING - 2)) % RING]));
@@ -1857,12 +1871,12 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
         sc.plan = p->own_plan[slot];
         sc.plan_bytes = p->own_plan_bytes[slot];
         if (plannable) {
-            // the pre-pass only writes the plan part, which the overlay of launch k - 2 never reads: it need not wait for it --
+            // the pre-pass only writes the plan part, which the overlay of launch k - depth never reads: it need not wait for it --
             // only for that launch's binning chain (`binned`), which read the plan part and the pose buffer of this slot.  It
             // runs on its own stream: behind the previous launch's projection + scatter on s_bin the host wait below was
             // ~0.3 ms instead of ~0.1 ms, and the binning stream's cycle -- not the overlay -- set the pace (sites3x12)
             hipStream_t sp = p->s_pre;
-            if (k > 2) HIP_TRY(hipStreamWaitEvent(sp, p->binned[slot], 0));
+            if (k > D) HIP_TRY(hipStreamWaitEvent(sp, p->binned[slot], 0));
             HIP_TRY(hipEventRecord(p->ready, (hipStream_t)input_stream));
             HIP_TRY(hipStreamWaitEvent(sp, p->ready, 0));
             if (p->poses_for == k && !p->poses_on_pre) {           // the poses went up on s_bin
@@ -1912,7 +1926,7 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
         }
     }
     p->prev_planned = prepass_done;
-    if (k > 2) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->done[(k - 2) % RING], 0));   // the overlay that read this slot
+    if (k > D) HIP_TRY(hipStreamWaitEvent(p->s_bin, p->done[(k - D) % RING], 0));   // the overlay that read this slot
     if (F > 0) {
         if (!prepass_done)
             if (int rc = bin_prepass(call, L, sc.plan, p->s_bin)) return rc;
@@ -2139,7 +2153,8 @@ int64_t cama_pipeline_scratch_bytes(cama_pipeline *p)
 {
     if (!p) return fail(CAMA_EINVAL, "pipeline is NULL");
     int64_t n = 0;
-    for (int k = 0; k < 2; ++k) n += (int64_t)p->own_plan_bytes[k] + (int64_t)p->own_stamp_bytes[k] + (int64_t)p->own_sorted_bytes[k];
+    for (int k = 0; k < cama_pipeline::MAX_DEPTH; ++k)
+        n += (int64_t)p->own_plan_bytes[k] + (int64_t)p->own_stamp_bytes[k] + (int64_t)p->own_sorted_bytes[k];
     return n;
 }
 
@@ -2171,7 +2186,7 @@ int cama_pipeline_guard_check(cama_pipeline *p, int64_t *bad_bytes)
     constexpr size_t G = cama_pipeline::GUARD;
     std::vector<uint8_t> h(G);
     int64_t bad = 0;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < cama_pipeline::MAX_DEPTH; ++k) {
         if (!p->own_stamp[k]) continue;
         for (int side = 0; side < 2; ++side) {
             const char *g = side ? p->own_stamp[k] + p->own_stamp_bytes[k] : p->own_stamp[k] - G;

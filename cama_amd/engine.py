@@ -18,6 +18,7 @@ RADIUS = 2                                                    # cama/reproject.p
 # maps with at least this many vertices hand their block index (per-block AABBs) to the render: below, the
 # one-thread-per-block pre-pass costs a launch for nothing.  CAMA_BOUNDS_MIN_VERTS=1 forces it (tests).
 BOUNDS_MIN_VERTS = int(os.environ.get("CAMA_BOUNDS_MIN_VERTS", "65536"))
+PIPELINE_DEPTH = 2 if os.environ.get("CAMA_PIPELINE_DEPTH") == "2" else 3      # scratch slots of a cama_pipeline (cama_hip.hip)
 MAX_SCENES_PER_LAUNCH = 1024                                  # include/cama_hip.h CAMA_MAX_SCENES_PER_LAUNCH
 
 
@@ -1139,7 +1140,9 @@ class Engine:
             keep.append(tuple(t for t in (vrows[0], vrows[1], plan[0], plan[1], plan[3], plan[5]) if t is not None))
         import ctypes
         d._keep = keep
-        d._ref = ctypes.byref(d)
+        # (the address, not ctypes.byref(d): a byref object stored on the struct it points to is a reference cycle the
+        # collector cannot see through -- CArgObject has no tp_traverse -- and would pin the map and the rig for ever)
+        d._addr = ctypes.addressof(d)
         return d
 
     def render_clip_launch(self, desc, w2c_ptr, F, src_ptr, out_ptr, keep):
@@ -1154,7 +1157,7 @@ class Engine:
             box = box + (ctypes.byref(box[0]), ctypes.byref(box[1]))
             self.__dict__["_seq_box"] = box
         fn = self.lib.cama_pipeline_render_clip
-        args = (P["handle"], desc._ref, w2c_ptr, F, src_ptr, out_ptr)
+        args = (P["handle"], desc._addr, w2c_ptr, F, src_ptr, out_ptr)
         if torch.cuda.current_device() == self.device.index:
             rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream, box[2], box[3])
             if rc == _lib.ENOMEM:
@@ -1288,7 +1291,7 @@ class Engine:
     def max_frames_per_call(self, dmap, rig, budget_bytes=None, resident_frames=True, src_bytes_per_frame=None,
                             pipelined=False):
         """Largest F whose per-call memory fits `budget_bytes` (and 32-bit stamp offsets).  Per frame: the worst-case
-        stamp scratch (every vertex visible in every camera; two slots when pipelined) and -- unless the source frames
+        stamp scratch (every vertex visible in every camera; the pipeline's three slots when pipelined) and -- unless the source frames
         and the mosaic are already resident (`resident_frames`, the bench / streaming case) -- the decoded source batch
         and its mosaic slice, which a disk-backed source allocates per call.  Default budget: a quarter of the free HBM,
         at most 64 GB -- sized for 288 GB parts, so that 4*10^6-vertex site maps still render 40 frames per launch."""
@@ -1311,7 +1314,7 @@ class Engine:
             budget_bytes = min(64 << 30, max(1 << 30, free // 4))
         per = max(1, self.lib.cama_render_scratch_bytes(dmap.N, 1, rig.C, rig.H, rig.W, self.radius))
         if pipelined:
-            per *= 2
+            per *= PIPELINE_DEPTH
         if not resident_frames:
             src = src_bytes_per_frame if src_bytes_per_frame is not None else rig.C * rig.H * rig.W * 3
             per += int(src) + rig.C * rig.H * rig.W * 3

@@ -284,7 +284,7 @@ int cama_pipeline_render_clip(cama_pipeline *p, const cama_clip *clip, const flo
 int cama_pipeline_join(cama_pipeline *p, void *stream);
 int64_t cama_pipeline_issued(cama_pipeline *p);
 int64_t cama_pipeline_completed(cama_pipeline *p);
-/* Device bytes of scratch the pipeline owns right now (both slots, plan + stamp parts). */
+/* Device bytes of scratch the pipeline owns right now (all slots, plan + stamp parts). */
 int64_t cama_pipeline_scratch_bytes(cama_pipeline *p);
 /* out[6] (host): launches issued, launches that were planned, buffer (re)allocations so far, scratch bytes owned, and the
  * last launch's plan: segments per (frame, camera), band-entry capacity (0, 0 when it was not planned). */

@@ -67,7 +67,7 @@ def test_bench_line_site_map_roofline_is_attributed_per_kernel():
     assert 0.0 < rp["vertex_read_fraction"] < 0.5              # most of the site is outside the crop box: never fetched
     assert line["hbm_frac_whole_step"] <= max(ro["frac"], rp["frac"]) + 1e-9
     assert line["projection_stats"]["block_cull"] is True
-    assert line["sustained"]["seconds"] >= 0.3 and line["sustained"]["value"] > 0
+    assert line["sustained"]["seconds"] >= 0.27 and line["sustained"]["value"] > 0        # (about 0.3 s: sized from a calibration region)
 
 
 def test_bench_default_line_has_every_contract_field():
@@ -80,7 +80,7 @@ def test_bench_default_line_has_every_contract_field():
     assert line["hash_check"]["verified"] == 1
     assert line["roofline"]["bytes_per_launch"] == 36 * 1600 * 900 * 40
     assert 0.5 < line["roofline"]["frac"] <= 1.0
-    assert line["sustained"]["seconds"] >= 1.0
+    assert line["sustained"]["seconds"] >= 0.9
     cb = line["cpu_baseline"]
     assert cb["cores"] == 1 and cb["value"] > 0
     assert cb["all_cores"]["cores"] == 4 and cb["all_cores"]["value"] > 0

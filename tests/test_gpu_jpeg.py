@@ -239,10 +239,13 @@ def test_clip_frame_source_device_decode_equals_host_decode(tmp_path):
     cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)
     dev = FR.ClipFrameSource(cm.cm_list, torch.device("cuda:0"), decoder="device")
     host = FR.ClipFrameSource(cm.cm_list, torch.device("cuda:0"), decoder="host")
+    before = dict(dev._decoder().stats)              # (the decoder is the process-wide one, Engine.jpeg_decoder: deltas)
     a = dev.raw_batch([1, 2, 3]).cpu().numpy()
     b = host.raw_batch([1, 2, 3]).cpu().numpy()
     assert a.shape == b.shape == (3, 6, 180, 320, 3) and np.array_equal(a, b)
-    assert dev._jpeg.stats["device"] == 18 and dev._jpeg.stats["host_flagged"] == 0
+    from cama_amd import runtime
+    assert dev._jpeg is runtime.engine().jpeg_decoder()
+    assert dev._jpeg.stats["device"] - before["device"] == 18 and dev._jpeg.stats["host_flagged"] == before["host_flagged"]
     # the device path read the files straight into a pinned arena (no packing copy on the submitting thread)
     from cama_amd.jpeg import ArenaBlob
     blobs = [f.result()[0] for f in dev._submit(2)]
