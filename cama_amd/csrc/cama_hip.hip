@@ -1683,6 +1683,8 @@ int cama_pipeline_create(cama_pipeline **out)
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least urgent (numerically greatest)
     hipError_t e = hipStreamCreateWithPriority(&p->s_bin, hipStreamNonBlocking, hi);
+    // (a CU-masked overlay stream that leaves 8 / 16 / 32 compute units to the chain was tried and is gone: masked queues
+    // dispatch far slower -- whole step 0.72 -> 0.44 at 960x540, profiles/r05_960x540_timeline.txt)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_ov, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_pre, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready, flags);
