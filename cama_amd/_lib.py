@@ -10,7 +10,7 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 21
+ABI_VERSION = 22
 BIN_WORKLIST = 1
 BIN_SEGMENTS = 2
 BIN_SEGMENTS_WU = 4            # EXTENSION: discs + one-pixel segments between polyline neighbours (include/cama_hip.h)
@@ -80,8 +80,6 @@ SIGNATURES = {
     "cama_stamp_scratch_bytes": (_sz, [_i32, _i32]),
     "cama_stamp_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "cama_probe_xcd_map": (_i32, [_vp, _i32, _vp]),
-    "cama_stream_create_masked": (_i32, [_i32, _vp]),
-    "cama_stream_destroy": (_i32, [_vp]),
     "cama_overlay_mapping_info": (_i32, [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(ctypes.c_double)]),
     "cama_overlay_probe": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, ctypes.POINTER(ctypes.c_double), _vp]),
     "cama_set_option": (_i32, [ctypes.c_char_p, _i64]),
@@ -102,6 +100,11 @@ SIGNATURES = {
     "cama_profile_collect_project": (_i32, [_vp, _vp]),
     "cama_bin_stats": (_i32, [_vp, _sz, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
 }
+
+# the entries include/cama_hip_diag.h declares (diagnostics, live timing, options, test hooks): not part of the contract
+DIAG = ("cama_pipeline_info", "cama_pipeline_bin_stats", "cama_pipeline_guard_check", "cama_probe_xcd_map",
+        "cama_overlay_mapping_info", "cama_set_option", "cama_get_option", "cama_profile_enable", "cama_profile_collect",
+        "cama_profile_collect_each", "cama_profile_collect_project", "cama_bin_stats")
 
 _lib = None
 

@@ -35,7 +35,7 @@
 #include <atomic>
 #include <algorithm>
 
-#include "cama_hip.h"
+#include "cama_hip_diag.h"      // (includes cama_hip.h: the contract)
 
 namespace {
 
@@ -146,8 +146,6 @@ Palette make_palette(const uint8_t *bgr, uint32_t alpha256 = 256u)
 
 int band_rows_for(int W)
 {
-    static const int forced = getenv("CAMA_BAND_ROWS") ? atoi(getenv("CAMA_BAND_ROWS")) : 0;      // (A/B; read once)
-    if (forced == 4 || forced == 8 || forced == 16 || forced == 32) return forced;
     // Measured on MI355X (profiles/): ~20 KB of image per workgroup streams best (more, smaller
     // workgroups balance stamped bands and keep the LDS owner table R*W*4 <= 26 KB -> 6 workgroups per CU).
     // R must stay >= 2*radius so a disc touches at most two bands.
@@ -284,17 +282,13 @@ uint64_t cull_list_threshold();
 // ~16 k workgroups (64 per CU), at most 8.  CAMA_PROJECT_VB overrides (A/B).
 int project_blocks_per_workgroup(uint64_t items)
 {
-    static const int forced = getenv("CAMA_PROJECT_VB") ? atoi(getenv("CAMA_PROJECT_VB")) : 0;
+    static const int forced = getenv("CAMA_PROJECT_VB") ? atoi(getenv("CAMA_PROJECT_VB")) : 0;      // TEST HOOK (fuzz: 3 / 8)
     if (forced > 0) return forced;
     const uint64_t vb = items / 16384ull;
     return vb < 1 ? 1 : (vb > 8 ? 8 : (int)vb);
 }
 
-unsigned persistent_workgroups()
-{
-    static const unsigned v = getenv("CAMA_PERSISTENT_WGS") ? (unsigned)atoi(getenv("CAMA_PERSISTENT_WGS")) : 2048u;
-    return v ? (v + 7u) & ~7u : 2048u;
-}
+constexpr unsigned persistent_workgroups() { return 2048u; }      // 256 CUs x 8 resident
 
 // Workgroup -> band mapping of the overlay kernels (overlay_kernels.hpp: xcd_item_of): 0 = workgroup L renders
 // band L (every XCD owns every eighth band of one stream), 31 = every XCD renders one contiguous eighth of the launch.
@@ -325,16 +319,6 @@ struct Option { const char *name, *env; int64_t fallback; std::atomic<int64_t> v
 Option g_options[] = {
     {"overlay_chunk_log2", "CAMA_OVERLAY_CHUNK_LOG2", -1, {0}, {false}},   // -1 = library's choice, 0..31 = forced order
     {"overlay_tune", "CAMA_OVERLAY_TUNE", 1, {0}, {false}},                // 0 = big launches keep the contiguous order
-    {"overlay_rot", "CAMA_OVERLAY_ROT", 0, {0}, {false}},                  // contiguous order: XCD x starts rot * x bands in
-    {"overlay_prefetch", "CAMA_OVERLAY_PREFETCH", -1, {0}, {false}},       // translation look-ahead in workgroups per XCD:
-                                                                            // 0 = off, -1 = library's choice
-    {"overlay_item_order", "CAMA_OVERLAY_ITEM_ORDER", 0, {0}, {false}},    // 0 = camera column innermost, 1 = band innermost
-    {"overlay_groups_log2", "CAMA_OVERLAY_GROUPS_LOG2", 0, {0}, {false}},  // 1 / 2: 2 / 4 XCD groups, chunked inside (with a
-                                                                            // forced overlay_chunk_log2 < 31)
-    {"raw35_ws", "CAMA_RAW35_WS", 0, {0}, {false}},                        // 3:5 raw overlay: wave-specialised persistent
-                                                                            // kernel, value = workgroups per CU (0 = classic)
-    {"raw35_loaders", "CAMA_RAW35_LOADERS", 2, {0}, {false}},              // ... and its loader waves per workgroup
-    {"raw35_subrows", "CAMA_RAW35_SUBROWS", 0, {0}, {false}},              // 3:5 raw overlay: 1 = half bands per workgroup
     {"cull_list_min", "CAMA_CULL_LIST_MIN", 16384, {0}, {false}},          // (block, frame) items from which a site-sized
                                                                             // map's cull goes through work lists
     {"pipeline_depth", "CAMA_PIPELINE_DEPTH", 3, {0}, {false}},            // scratch slots of a cama_pipeline created from now on (2 | 3)
@@ -344,7 +328,7 @@ Option g_options[] = {
                                                                             // 0: stream-side wait; -1: host wait for launches that
                                                                             // move >= 1 GiB (the host has the time to spare; at 960x540 it has not)
 };
-enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_ROT, OPT_PREFETCH, OPT_ITEM_ORDER, OPT_GROUPS, OPT_RAW35_WS, OPT_RAW35_LOADERS, OPT_RAW35_SUBROWS, OPT_CULL_LIST_MIN, OPT_PIPELINE_DEPTH, OPT_HOST_WAIT, OPT_COUNT };
+enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_CULL_LIST_MIN, OPT_PIPELINE_DEPTH, OPT_HOST_WAIT, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
 int64_t option(int k)
 {
@@ -479,30 +463,8 @@ struct MapTuner {
 };
 MapTuner g_map_tuner;
 
-// stagger + translation look-ahead of a launch of `items` bands (OverlayArgs::rot / per_magic / pf_slots)
-void set_walk_options(OverlayArgs &o, uint32_t items)
-{
-    const uint32_t per = (items + 7u) >> 3;
-    o.rot = 0; o.per_magic = 0; o.pf_slots = 0;
-    if (o.chunk_log2 >= 31u && per > 1u) {
-        o.rot = (uint32_t)((uint64_t)std::max<int64_t>(option(OPT_ROT), 0) % per);
-        o.per_magic = (uint32_t)(((1ull << 32) + per - 1) / per);
-    }
-    const int64_t pf = option(OPT_PREFETCH);
-    o.pf_slots = pf < 0 ? 0u : (uint32_t)std::min<int64_t>(pf, 1 << 20);
-    o.item_order = option(OPT_ITEM_ORDER) == 1 ? 1u : 0u;
-    const int64_t gl2 = option(OPT_GROUPS);
-    o.groups_log2 = (o.chunk_log2 < 31u && (gl2 == 1 || gl2 == 2)) ? (uint32_t)gl2 : 0u;
-}
-
 dim3 overlay_grid(size_t items, uint32_t chunk_log2)
 {
-    const int64_t gl2 = option(OPT_GROUPS);
-    if (chunk_log2 < 31u && (gl2 == 1 || gl2 == 2)) {        // grouped order: 8 * K * ceil(ceil(T / G) / (M K))
-        const size_t G = (size_t)1 << gl2, M = 8 / G, K = (size_t)1 << chunk_log2;
-        const size_t per_g = (items + G - 1) / G;
-        return dim3((unsigned)(8 * K * ((per_g + M * K - 1) / (M * K))));
-    }
     if (chunk_log2 >= 31u) return dim3((unsigned)((items + 7) / 8 * 8));
     const size_t per = (size_t)8 << chunk_log2;
     return dim3((unsigned)((items + per - 1) / per * per));
@@ -733,15 +695,11 @@ int cama_map_bounds(const void *x, const void *y, const void *z, int32_t xyz_is_
 // Completion events attached to the NEXT overlay / scatter launch itself (hipExtLaunchKernelGGL stop event) instead of a
 // separate hipEventRecord marker packet behind it: one packet less between consecutive overlays on the pipeline's
 // stream.  Set by cama_pipeline_render, consumed (and cleared) by the launch.
-thread_local bool g_skip_bin_memset = false;   // (hipGraph experiment only: the clear is issued outside the captured chain)
 thread_local hipEvent_t g_overlay_stop_event = nullptr;
 thread_local bool g_overlay_probe = false;     // the next plain overlay launch is cama_overlay_probe's: k_overlay_probe, contiguous order
 thread_local hipEvent_t g_scatter_stop_event = nullptr;
-static bool ext_events()
-{
-    static const bool v = !getenv("CAMA_NO_EXT_EVENTS");
-    return v;
-}   // consumed by the next overlay launch (cama_overlay_frames_alpha)
+// the pipeline's completion events ride on the launches themselves (hipExtLaunchKernelGGL stop events)
+static constexpr bool ext_events() { return true; }
 
 }  // extern "C"
 
@@ -757,13 +715,13 @@ struct BinCall {
     int32_t W, H, radius;
 };
 
-// A/B switches of the binning chain, read from the environment once (a getenv per launch is a scan of the whole environment,
-// and the 960x540 pipeline is bound by the host issuing its launches)
-struct BinEnv { bool no_cam_mask, no_candidates, no_plan, no_xcd_pad; };
+// TEST HOOKS of the binning chain (tests/test_gpu_fuzz.py forces each of the production code paths on inputs that would not
+// select it by themselves): read from the environment once per process.  None can change a result.
+struct BinEnv { bool no_cam_mask, no_candidates, no_plan; };
 static const BinEnv &bin_env()
 {
     static const BinEnv e{getenv("CAMA_NO_CAM_MASK") != nullptr, getenv("CAMA_NO_CANDIDATES") != nullptr,
-                          getenv("CAMA_NO_PLAN") != nullptr, getenv("CAMA_NO_XCD_PAD") != nullptr};
+                          getenv("CAMA_NO_PLAN") != nullptr};
     return e;
 }
 
@@ -826,24 +784,6 @@ static int bin_prepass(const BinCall &b, const ScratchLayout &L, char *pbase, hi
         hipLaunchKernelGGL(k_block_cameras<false>, cgrid, dim3(BLOCK), 0, s, b.block_bounds, b.w2c, cam_fn, C, cr, vblocks, nsub,
                            cam_mask, (uint32_t)L.list_cap, work_count, work);
     HIP_TRY(hipGetLastError());
-#ifdef ABL_MASK_STATS
-    if (use_cand) {
-        uint32_t wc[32];
-        hipStreamSynchronize(s);
-        hipMemcpy(wc, work_count, sizeof(wc), hipMemcpyDeviceToHost);
-        uint32_t listed = 0, cands = 0;
-        for (int l = 0; l < 8; ++l) listed += wc[l], cands += wc[CAND_COUNT_WORD + l];
-        fprintf(stderr, "[cand stats] %u (block, frame) items: %u candidates, %u listed\n", vblocks * F, cands, listed);
-    } else {
-        std::vector<uint64_t> hm((size_t)vblocks * F);
-        hipStreamSynchronize(s);
-        hipMemcpy(hm.data(), (const void *)cam_mask, hm.size() * 8, hipMemcpyDeviceToHost);
-        uint64_t bits = 0, zero = 0;
-        for (uint64_t m : hm) { bits += __builtin_popcountll(m); zero += m == 0; }
-        fprintf(stderr, "[mask stats] %zu (block, frame) items: %.3f cameras per wave, %.3f of the blocks empty\n", hm.size(),
-                (double)bits / hm.size() / 4, (double)zero / hm.size());
-    }
-#endif
     return CAMA_OK;
 }
 
@@ -862,7 +802,7 @@ static int bin_main(const BinCall &b, const ScratchLayout &L, const ScratchRef &
     const int nfc = F * C;
 
     // counts, cursor and the segment count table are adjacent: one memset
-    if ((phases & BIN_PHASE_A) && !g_skip_bin_memset) HIP_TRY(hipMemsetAsync(counts, 0, L.zero_bytes, s));
+    if (phases & BIN_PHASE_A) HIP_TRY(hipMemsetAsync(counts, 0, L.zero_bytes, s));
 
     FrameArgs a{};
     a.scenes = b.scenes_dev; a.frames_per_scene = b.frames_per_scene;
@@ -887,7 +827,7 @@ static int bin_main(const BinCall &b, const ScratchLayout &L, const ScratchRef &
     // chip anyway (launch + histogram clear / flush per 256 vertices made big maps dispatch-bound)
     const int vb_per_wg = project_blocks_per_workgroup((uint64_t)vblocks * (uint64_t)F);
     const unsigned vchunks = (vblocks + vb_per_wg - 1) / vb_per_wg;
-    const dim3 fgrid(bin_env().no_xcd_pad ? vchunks : ((vchunks + 7u) & ~7u), (unsigned)F);
+    const dim3 fgrid((vchunks + 7u) & ~7u, (unsigned)F);
     const size_t hist_lds = align_up((size_t)C * L.NB * 4, 16);
     // With the map's spatial index (block AABBs) a one-thread-per-(block, frame) pre-pass decided which cameras can see
     // each block at all (bin_prepass); the projection skips the others.  Site-sized maps (CAMA_BIN_WORKLIST: most
@@ -1067,16 +1007,14 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     if ((!scenes_dev && (!src || !mosaic)) || !palette_bgr) return fail(CAMA_EINVAL, "NULL pointer argument");
     Disc disc;
     if (make_disc(radius, halfwidth, disc)) return fail(CAMA_EINVAL, "bad radius/halfwidth table");
-    // (A/B knob: CAMA_OVERLAY_LDS_PAD=bytes inflates the allocation, i.e. lowers the overlay's workgroups per CU)
     // The binning chain of the NEXT launch runs beside every overlay; an overlay that fills the CU's LDS (6 workgroups of
     // 25.6 KB at W = 1600) leaves that chain one workgroup per CU.  So the overlay asks for a little more LDS than it needs --
     // just enough that ONE workgroup fewer fits a CU.  Alternating A/B runs on one box, 3 each, frames/s (sustained):
     // site map of 4e6 vertices 74.0 (76.1) -> 80.3 (84.4) k, site 1e6 106.6 (110.3) -> 107.1 (111.0) k, headline 108.3 (111.7)
     // -> 109.9 (113.2) k; 73-scene sweep, 960x540, random 1e6 within noise.  It pays where the chain is long (hundreds of
-    // microseconds) and costs nothing elsewhere.  CAMA_OVERLAY_LDS_PAD=bytes overrides (0 = never), for A/B.
-    static const long lds_pad_env = getenv("CAMA_OVERLAY_LDS_PAD") ? atol(getenv("CAMA_OVERLAY_LDS_PAD")) : -1;
-    size_t lds_pad = lds_pad_env >= 0 ? (size_t)lds_pad_env : 0;
-    if (lds_pad_env < 0) {
+    // microseconds) and costs nothing elsewhere.
+    size_t lds_pad = 0;
+    {
         const size_t lds0 = align_up((size_t)L.R * (W + 2 * radius) * 4, 16), cu_lds = 160 * 1024;
         const size_t fit = cu_lds / lds0;
         if (fit >= 4 && fit <= 16) lds_pad = align_up(cu_lds / fit + 16 - lds0, 16);   // smallest size of which fit - 1 fit a CU
@@ -1144,7 +1082,6 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     const uint32_t chunk_log2 = o.chunk_log2;
     const auto grid8 = [chunk_log2](size_t items) { return overlay_grid(items, chunk_log2); };
     o.items = nblocks;
-    set_walk_options(o, scenes_dev ? (uint32_t)((size_t)frames_per_scene * items_per_frame) : nblocks);
     const dim3 ogrid = grid8(nblocks);
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1444,22 +1381,13 @@ static int raw35_impl(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t
     if (L.segments) return fail(CAMA_EINVAL, "segments: plain overlay only");
     o.disc = disc; o.pal = make_palette(palette_bgr);
     o.H0 = H0; o.W0 = W0;
-    // column tiles per band (CAMA_RAW35_TILES=2: 960-wide tiles, 160 threads, 17 KB of LDS -> 8 workgroups per CU instead of
-    // 4; A/B only)
-    static const int forced_tx = getenv("CAMA_RAW35_TILES") ? atoi(getenv("CAMA_RAW35_TILES")) : 0;
-    int TX = 1;       // (measured at 960x540: two tiles 0.66-0.70 of 8 TB/s, one tile 0.70-0.74 -- half rows are short bursts)
-    if (forced_tx == 1 || (forced_tx == 2 && upr % 8 == 0)) TX = forced_tx;
+    // one column tile per band (two 480-wide tiles measured 0.66-0.70 of 8 TB/s against 0.70-0.74: half rows are short bursts;
+    // half bands of R / 2 rows per workgroup measured no gain either -- both variants are gone, profiles/r04_raw35_account.txt)
+    constexpr int TX = 1;
     const int upr_t = upr / TX, Wt = W / TX;
-    // Half bands (round 4, option raw35_subrows = 1; A/B only): a band's R rows go to two workgroups of R / 2 rows -- 4 source
-    // rows = 19.2 KB of staging instead of 7 = 33.6 KB at 960 wide, 8 workgroups per CU instead of 4, a half band's rows still
-    // one contiguous range (unlike round 3's column tiles).  Built on the theory that the kernel is bound by the source bytes
-    // it keeps in flight (counters: 16 KB per CU on average, profiles/r04_raw35_account.txt); measured: no gain (0.692-0.704
-    // against 0.704-0.710 of 8 TB/s, alternating inside single processes), byte-identical.
-    const int64_t sub_opt = option(OPT_RAW35_SUBROWS);
-    const bool halves = sub_opt != 0 && TX == 1 && max_half_rows > 0 && L.R % 2 == 0 && L.R / 2 >= 1 &&
-                        (size_t)max_half_rows * upr_t * 15 >= (size_t)(L.R / 2) * upr_t * 9 + (size_t)(L.R / 2) * Wt;
-    const uint32_t sub = halves ? 2u : 1u, subrows = halves ? (uint32_t)L.R / 2u : (uint32_t)L.R;
-    const int stage_rows = halves ? max_half_rows : max_src_rows;
+    const uint32_t subrows = (uint32_t)L.R;
+    const int stage_rows = max_src_rows;
+    (void)max_half_rows;
     const unsigned block = (subrows * (unsigned)upr_t + 63u) & ~63u;
     // the owner table of a stamped band goes INTO the staging area, behind the tile's output rows (raw35_kernels.hpp)
     const size_t staging_dw = (size_t)stage_rows * upr_t * 15, owner_off = (size_t)subrows * upr_t * 9, owner_dw = (size_t)subrows * Wt;
@@ -1472,10 +1400,9 @@ static int raw35_impl(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    // bands per workgroup: 2 = the second band's source loads fly during the first band's blend (CAMA_RAW35_PAIR=0|1, A/B)
-    static const int pair_env = getenv("CAMA_RAW35_PAIR") ? atoi(getenv("CAMA_RAW35_PAIR")) : RAW35_PAIR_DEFAULT;
-    const int bands_per_wg = (pair_env && !halves) ? 2 : 1;
-    const uint32_t NBx = bands_per_wg == 2 ? (uint32_t)(L.NB + 1) / 2 : (uint32_t)L.NB * sub;
+    // bands per workgroup: 2 = the second band's source loads fly during the first band's blend
+    constexpr int bands_per_wg = RAW35_PAIR_DEFAULT ? 2 : 1;
+    const uint32_t NBx = bands_per_wg == 2 ? (uint32_t)(L.NB + 1) / 2 : (uint32_t)L.NB;
     const uint32_t nbx_magic = (uint32_t)(((1ull << 32) + NBx - 1) / NBx);
     o.items = (uint32_t)((size_t)F * rows * cols * NBx * TX);
     // (the 3:5 raw overlay always takes the chunked order unless one is forced: measured inside single processes at 1.41 GB per
@@ -1499,25 +1426,12 @@ static int raw35_impl(const uint8_t *raw, int32_t H0, int32_t W0, const uint32_t
     hipEvent_t e1 = e0 ? ev1 : g_overlay_stop_event;
     const uint2 *vr2 = reinterpret_cast<const uint2 *>(vrows);
     const int2 *br2 = reinterpret_cast<const int2 *>(band_rows);
-    // wave-specialised persistent variant (raw35_kernels.hpp: k_overlay_raw35_ws; option raw35_ws): one band per workgroup
-    // round, a loader wave, a double staging buffer -- needs contiguous staged rows (row pitch == staged row) and whole bands
-    const int64_t ws = option(OPT_RAW35_WS);
-    const uint32_t src_pitch16 = (uint32_t)W0 * 3u / 16u;
-    const unsigned nloaders = (unsigned)std::min<int64_t>(std::max<int64_t>(option(OPT_RAW35_LOADERS), 1), 8);
-    if (ws > 0 && !halves && TX == 1 && bands_per_wg == 1 && src_pitch16 == cpt && block + 64u * nloaders <= 1024u && 2 * lds + 64 <= 160 * 1024) {
-        const size_t lds2 = 2 * lds;
-        if (lds2 > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void *)k_overlay_raw35_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ws, (160 * 1024) / lds2));
-        const unsigned G = std::min<unsigned>(256u * per_cu, (rgrid.x + 7u) & ~7u) & ~7u;
-        hipExtLaunchKernelGGL(k_overlay_raw35_ws, dim3(std::max(G, 8u)), dim3(block + 64u * nloaders), (uint32_t)lds2, s, e0, e1, 0u, o,
-                              vr2, br2, upr, max_src_rows, (int)owner_off, nbx_magic, rgrid.x, (uint32_t)staging_dw, nloaders);
-    } else if (bands_per_wg == 2)
+    if (bands_per_wg == 2)
         hipExtLaunchKernelGGL(k_overlay_raw35<2>, rgrid, dim3(block), (uint32_t)lds, s, e0, e1, 0u, o, vr2, br2, upr, max_src_rows,
-                              (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic, 1u, (uint32_t)L.R);
+                              (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic);
     else
         hipExtLaunchKernelGGL(k_overlay_raw35<1>, rgrid, dim3(block), (uint32_t)lds, s, e0, e1, 0u, o, vr2, br2, upr, stage_rows,
-                              (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic, sub, subrows);
+                              (int)owner_off, TX, tx_magic, cpt_magic, nbx_magic);
     if (!e0) g_overlay_stop_event = nullptr;
     HIP_TRY(hipGetLastError());
     if (ev0 && ev1) g_prof.pending.emplace_back(ev0, ev1);
@@ -2241,36 +2155,6 @@ int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per
         if (samples) samples[k] = e ? e->done[k] : 0;
         if (ns_per_mb) ns_per_mb[k] = (e && e->done[k]) ? MapTuner::median(e->t[k], e->done[k]) * 1e15 : 0.0;
     }
-    return CAMA_OK;
-}
-
-// A stream whose kernels may only run on `n_cus` of the device's compute units, spread evenly over the chip (every
-// (total / n_cus)-th CU).  For the egress side of the main.py loop: the runtime performs device -> pinned-host copies with
-// blit kernels whose waves sit on PCIe write latency; confined to a few CUs they stop competing with the JPEG decoder for
-// wave slots.  The caller owns the stream (cama_stream_destroy).  (No reference counterpart.)
-int cama_stream_create_masked(int32_t n_cus, void **stream)
-{
-    if (!stream || n_cus < 1) return fail(CAMA_EINVAL, "bad arguments");
-    int dev = 0, total = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev));
-    if (total < 1) return fail(CAMA_EHIP, "no compute units reported");
-    const int n = std::min(n_cus, total), words = (total + 31) / 32;
-    std::vector<uint32_t> mask((size_t)words, 0u);
-    for (int k = 0; k < n; ++k) {
-        const int cu = (int)((int64_t)k * total / n);
-        mask[cu >> 5] |= 1u << (cu & 31);
-    }
-    hipStream_t s = nullptr;
-    HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask.data()));
-    *stream = (void *)s;
-    return CAMA_OK;
-}
-
-int cama_stream_destroy(void *stream)
-{
-    if (!stream) return CAMA_OK;
-    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return CAMA_OK;
 }
 

@@ -10,13 +10,6 @@ struct OverlayArgs {
     int f0;                           // multi-scene chains: launch-wide number of this launch's first frame (the scratch is
                                       // indexed by the launch-wide frame, src / mosaic by the frame inside the scene)
     uint32_t chunk_log2;              // items per XCD chunk = 2^chunk_log2 (>= 31: one contiguous range per XCD)
-    uint32_t rot, per_magic;          // contiguous order: XCD x starts rot * x items into its own range (wraps); ceil(2^32 / per)
-    uint32_t groups_log2;             // 0 = the two-order scheme above; 1 / 2: 2 / 4 groups of XCDs, each group one contiguous
-                                      // range, chunks of 2^chunk_log2 items round-robin inside (xcd_item_grouped)
-    uint32_t item_order;              // 0: items run (frame, camera row, band, camera column); 1: (frame, camera row, camera
-                                      // column, band) -- one source stream per XCD at a time instead of `cols`
-    uint32_t pf_slots;                // translation look-ahead: 0 = off, else every 16th workgroup of an XCD touches the pages
-                                      // of the band that XCD renders pf_slots workgroups later (tlb_lookahead)
     uint32_t items;                   // bands of this launch = F * camera rows * cols * NB (x column tiles); grid = 8 * ceil(items / 8)
     uint32_t cols_magic, nb_magic, cr_magic;     // ceil(2^32 / d) for d = cols, NB, camera rows (divmod_magic)
     const uint8_t *src;
@@ -306,38 +299,17 @@ __device__ __forceinline__ void lds_barrier()
 //                against the chunked order on its own first launches.
 // Either mapping is a bijection whatever the hardware's placement is: a different dispatch rule costs speed, never pixels.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t divmod_magic(const uint32_t n, const uint32_t d, const uint32_t magic, uint32_t &r);
-
-// workgroup number L -> item; `rot` (contiguous order only): XCD x walks its range starting rot * x items in
-__device__ __forceinline__ bool xcd_item_of(const uint32_t L, const uint32_t T, const uint32_t chunk_log2, const uint32_t rot,
-                                            const uint32_t per_magic, uint32_t &item)
+// workgroup number L -> item
+__device__ __forceinline__ bool xcd_item_of(const uint32_t L, const uint32_t T, const uint32_t chunk_log2, uint32_t &item)
 {
     const uint32_t x = L & 7u, slot = L >> 3;
     if (chunk_log2 >= 31u) {                                 // one contiguous range per XCD; grid = 8 * ceil(T / 8)
-        const uint32_t per = (T + 7u) >> 3;
-        uint32_t s = slot;
-        if (rot) (void)divmod_magic(slot + rot * x, per, per_magic, s);     // (rot < per, slot < per: no overflow)
-        item = x * per + s;
+        item = x * ((T + 7u) >> 3) + slot;
     } else {                                                 // chunks of K = 2^chunk_log2 items dealt round-robin to the XCDs;
         const uint32_t K = 1u << chunk_log2;                 // grid = 8 * K * ceil(T / (8 K))
         item = (((slot >> chunk_log2) << 3) + x) * K + (slot & (K - 1u));
     }
     return item < T;
-}
-
-// The general form (round 4 experiment): the launch is cut into G = 2^groups_log2 contiguous ranges, one per group of
-// M = 8 / G neighbouring XCDs, and inside a range chunks of K = 2^chunk_log2 items go round-robin to the group's members.
-// G = 1 is the chunked order above, G = 8 the contiguous one; G = 4 makes the two XCDs of a pair share a stream.
-// grid = 8 * K * ceil(ceil(T / G) / (M K)).
-__device__ __forceinline__ bool xcd_item_grouped(const uint32_t L, const uint32_t T, const uint32_t chunk_log2,
-                                                 const uint32_t groups_log2, uint32_t &item)
-{
-    const uint32_t x = L & 7u, slot = L >> 3, ml2 = 3u - groups_log2, M = 1u << ml2, G = 1u << groups_log2;
-    const uint32_t per_g = (T + G - 1u) >> groups_log2, K = 1u << chunk_log2;
-    const uint32_t g = x >> ml2, m = x & (M - 1u);
-    const uint32_t local = ((((slot >> chunk_log2) << ml2) + m) << chunk_log2) + (slot & (K - 1u));
-    item = g * per_g + local;
-    return local < per_g && item < T;
 }
 
 // Diagnostic: which XCD does block L of a 1-D grid run on?  out[L] = HW_REG_XCC_ID (0..7).  The contiguous mapping above
@@ -365,19 +337,12 @@ __device__ __forceinline__ BandId decode_band(const OverlayArgs &a, const uint32
 {
     BandId id{0u, 0u, 0u, 0u, false};
     uint32_t item;
-    if (a.groups_log2 ? !xcd_item_grouped(L, T, a.chunk_log2, a.groups_log2, item)
-                      : !xcd_item_of(L, T, a.chunk_log2, a.rot, a.per_magic, item)) return id;
+    if (!xcd_item_of(L, T, a.chunk_log2, item)) return id;
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C, camrows = (C + cols - 1u) / cols;
     uint32_t cc, cr;
     const uint32_t q0 = TX == 1u ? item : divmod_magic(item, TX, tx_magic, id.tx);
-    uint32_t q2;
-    if (a.item_order == 0u) {
-        const uint32_t q1 = divmod_magic(q0, cols, a.cols_magic, cc);
-        q2 = divmod_magic(q1, NB, a.nb_magic, id.b);
-    } else {
-        const uint32_t q1 = divmod_magic(q0, NB, a.nb_magic, id.b);
-        q2 = divmod_magic(q1, cols, a.cols_magic, cc);
-    }
+    const uint32_t q1 = divmod_magic(q0, cols, a.cols_magic, cc);
+    const uint32_t q2 = divmod_magic(q1, NB, a.nb_magic, id.b);
     id.fl = divmod_magic(q2, camrows, a.cr_magic, cr);
     id.c = cr * cols + cc;
     id.valid = id.c < C;                                  // ragged last camera row
@@ -396,11 +361,7 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
     const int y0 = (int)b * a.R;
     const int nrows = min(a.R, a.H - y0);
     const int W = a.W;
-#ifdef ABL_NO_STAMPS
-    const uint32_t n = 0u * a.counts[bin];
-#else
     const uint32_t n = a.counts[bin];
-#endif
 
     // A stamped band fetches this thread's first stamp record and THEN issues its (first, normally only) batch of
     // 16-byte source loads, all before clearing / rasterising: the source chunks do not depend on the owner table, so
@@ -441,7 +402,6 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
         const int n4 = (nrows * Wp + 3) >> 2;
         for (int j = threadIdx.x; j < n4; j += OVERLAY_BLOCK) o4[j] = make_uint4(0, 0, 0, 0);
         lds_barrier();
-#ifndef ABL_NO_RASTER
         const uint32_t hw8 = (uint32_t)a.disc.hw4, rowmask = a.disc.rows;      // radius <= 7 (host-checked for this kernel)
         if (SEGS) {
             for (uint32_t sidx = threadIdx.x; sidx < n; sidx += OVERLAY_BLOCK) {
@@ -459,7 +419,6 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
             if (threadIdx.x < n) rasterise_one_padded(s_owner, first, y0, nrows, Wp, rad, hw8, rowmask);
             rasterise_rest_padded(s_owner, st, threadIdx.x + OVERLAY_BLOCK, OVERLAY_BLOCK, n, y0, nrows, Wp, rad, hw8, rowmask);
         }
-#endif
         lds_barrier();
     }
 
@@ -512,12 +471,10 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
                 if (idx < nchunks) {
                     const uint32_t row = __umulhi(idx, a.cpr_magic);
                     const uint32_t col = idx - row * a.cpr;
-#ifndef ABL_NO_PATCH
                     if (n) {
                         if (WU) patch_chunk_wu(v[j], s_owner + row * Wp + rad, col, a.pal);
                         else patch_chunk<ALPHA>(v[j], s_owner + row * Wp + rad, col, a.pal);
                     }
-#endif
                     u32x4 *drow = reinterpret_cast<u32x4 *>(dcell + (size_t)row * a.mosaic_row_bytes);
                     OVERLAY_STORE(v[j], drow + col);
                 }
@@ -545,42 +502,12 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
     }
 }
 
-// Translation look-ahead (round 4).  A launch over buffers it has not touched before (a long clip, the 73-scene sweep: frames
-// are never re-read, main.py:57-61) meets a cold address translation at every 2 MB of every stream it walks: 8.6 GB per
-// launch = 4 300 page walks, and in the XCD-contiguous order all ~180 workgroups an XCD has in flight sit on the same two or
-// three pages, so they meet a walk together.  Every 16th workgroup of an XCD therefore ends by touching -- one byte, result
-// unused -- the source and the mosaic address of the band that SAME XCD renders `pf_slots` workgroups later (the page then
-// sits in that XCD's UTCL2 when the band's own loads arrive).  The load is the wave's last instruction: nothing in the
-// workgroup waits for it except its own end.  Addresses are those of a real later band of this launch, so they are inside
-// the caller's buffers by construction.  Speed only.
-template <bool RESAMPLE>
-__device__ __forceinline__ void tlb_lookahead(const OverlayArgs &a)
-{
-    if (!a.pf_slots) return;
-    const uint32_t slot = blockIdx.x >> 3;
-    if ((slot & 15u) != 0u) return;                                     // wave-uniform
-    const uint32_t L2 = blockIdx.x + (a.pf_slots << 3);                 // same XCD, pf_slots workgroups on
-    if (L2 >= gridDim.x || threadIdx.x != 0) return;
-    const BandId id = decode_band(a, a.items, 1u, 0u, L2);
-    if (!id.valid) return;
-    const int y0 = (int)id.b * a.R;
-    const uint32_t fcl = id.fl * (uint32_t)a.C + id.c;
-    const uint8_t *sp = RESAMPLE ? a.src + (size_t)fcl * ((size_t)a.H0 * a.W0 * 3)
-                                 : a.src + ((size_t)fcl * a.H + y0) * (size_t)a.W * 3;
-    const uint8_t *dp = a.mosaic + (size_t)id.fl * a.mosaic_frame_bytes +
-                        ((size_t)(id.c / (uint32_t)a.cols) * a.H + y0) * a.mosaic_row_bytes +
-                        (size_t)(id.c % (uint32_t)a.cols) * a.W * 3;
-    uint32_t t0, t1;
-    asm volatile("global_load_ubyte %0, %2, off\n\tglobal_load_ubyte %1, %3, off" : "=&v"(t0), "=&v"(t1) : "v"(sp), "v"(dp) : "memory");
-}
-
 template <bool VEC, bool RESAMPLE, bool ALPHA = false, bool SEGS = false, bool WU = false>
 __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay(OverlayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];  // R x (W + 2 radius), used only by stamped bands
     const BandId id = decode_band(a, a.items, 1u, 0u);
     if (id.valid) overlay_band_at<VEC, RESAMPLE, ALPHA, SEGS, WU>(a, id.fl, (uint32_t)a.f0, id.c, id.b, s_owner);
-    tlb_lookahead<RESAMPLE>(a);
 }
 
 
@@ -591,7 +518,6 @@ __global__ __launch_bounds__(OVERLAY_BLOCK) void k_overlay_probe(OverlayArgs a)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_owner[];
     const BandId id = decode_band(a, a.items, 1u, 0u);
     if (id.valid) overlay_band_at<true, false, false, false>(a, id.fl, (uint32_t)a.f0, id.c, id.b, s_owner);
-    tlb_lookahead<false>(a);
 }
 
 // Raw-frame overlay, LDS-staged (separable maps = zero lens distortion, the nuScenes / CAMA calibration):

@@ -434,11 +434,6 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
     const WaveVerts v = load_wave_verts<T>(a, vblock, f, cams4, seg_base);
     if (!v.cams) return;
     const double Wd = (double)a.W, Hd = (double)a.H;
-    // -DABL_PROJ_NO_CAMS / -DABL_PROJ_NO_OUT: ablation builds behind profiles/r02_project_ablation.txt
-#ifdef ABL_PROJ_NO_OUT
-    uint32_t sink = 0;
-#endif
-#ifndef ABL_PROJ_NO_CAMS
     // only the cameras the wave's mask lets through (wave-uniform scalar loop: the kernel issues as many SALU as VALU
     // instructions, PMC: profiles/r02_project_dense1e6_pmc_sq.csv)
     for (uint32_t todo = v.cams & ((1u << a.C) - 1u); todo; todo &= todo - 1u) {
@@ -452,9 +447,6 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
                                          v.cy, v.cz, Wd, Hd, packed))
                 uv = packed;
         }
-#ifdef ABL_PROJ_NO_OUT
-        sink ^= uv;                     // (ablation: the chains run, nothing is emitted)
-#else
         if (a.segments) {               // (wave-uniform; the halo chain runs for lane 0 only -- an opt-in extension pays it)
             uint32_t uv_halo = 0xffffffffu;
             if (v.link && v.hin && (threadIdx.x & 63u) == 0u) {
@@ -466,12 +458,7 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
             emit_wave_segments(a, f, c, v, uv, uv_halo, s_cnt);
         } else
             emit_wave_stamps(a, f, c, v, uv, s_cnt);
-#endif
     }
-#endif
-#ifdef ABL_PROJ_NO_OUT
-    if (sink == 0x12345678u) a.seg_cnt[0] = 1;
-#endif
 }
 
 // workgroup-level frame of project_block: zero the histogram, run `body`, add the non-empty bins to the frame's counts

@@ -25,47 +25,12 @@
 #define RAW35_STAGE_UNROLL 7      // 16-byte source chunks in flight per thread (7 rows x 300 chunks over 320 threads)
 #endif
 
-// channel `ch` of destination pixel k of a unit, horizontal part: t = wl * s[e] + wr * s[e + 3], e = 3 * q + ch
-template <int K, int CH>
-__device__ __forceinline__ uint32_t raw35_tap(const uint32_t (&d)[15])
-{
-    constexpr int g = K / 3, p = K % 3;
-    constexpr int q = 5 * g + (p == 0 ? 0 : p == 1 ? 1 : 3);
-    constexpr uint32_t wl = p == 0 ? 32u : p == 1 ? 11u : 21u, wr = 32u - wl;
-    constexpr int e = 3 * q + CH, el = e >> 2, er = (e + 3) >> 2;
-    constexpr uint32_t ml = wl << (8 * (e & 3)), mr = wr << (8 * ((e + 3) & 3));
-    if constexpr (wr == 0u) {
-        return __builtin_amdgcn_udot4(d[el], ml, 0u, false);
-    } else if constexpr (el == er) {
-        return __builtin_amdgcn_udot4(d[el], ml | mr, 0u, false);
-    } else {
-        return __builtin_amdgcn_udot4(d[er < 15 ? er : 14], mr, __builtin_amdgcn_udot4(d[el], ml, 0u, false), false);
-    }
-}
-
-template <int K>
-__device__ __forceinline__ uint32_t raw35_pixel(const uint32_t (&d0)[15], const uint32_t (&d1)[15], uint32_t wt, uint32_t wb)
-{
-    // weights <= 32, t <= 32*255: 24-bit multiply-adds; the rounding constant rides in the first mad
-    const uint32_t vB = (__umul24(wb, raw35_tap<K, 0>(d1)) + (__umul24(wt, raw35_tap<K, 0>(d0)) + 512u)) >> 10;
-    const uint32_t vG = (__umul24(wb, raw35_tap<K, 1>(d1)) + (__umul24(wt, raw35_tap<K, 1>(d0)) + 512u)) >> 10;
-    const uint32_t vR = (__umul24(wb, raw35_tap<K, 2>(d1)) + (__umul24(wt, raw35_tap<K, 2>(d0)) + 512u)) >> 10;
-    return vB | (vG << 8) | (vR << 16);
-}
-
 // four packed pixels (b | g<<8 | r<<16) -> the 12 bytes they occupy, as three dwords
 __device__ __forceinline__ void raw35_pack4(const uint32_t *c, uint32_t *o)
 {
     o[0] = c[0] | (c[1] << 24);
     o[1] = (c[1] >> 8) | (c[2] << 16);
     o[2] = (c[2] >> 16) | (c[3] << 8);
-}
-
-template <int... K>
-__device__ __forceinline__ void raw35_unit(const uint32_t (&d0)[15], const uint32_t (&d1)[15], uint32_t wt, uint32_t wb,
-                                           uint32_t (&px)[12], std::integer_sequence<int, K...>)
-{
-    ((px[K] = raw35_pixel<K>(d0, d1, wt, wb)), ...);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -225,37 +190,26 @@ struct Raw35Band {
 struct Raw35Tile {
     int upr, Wt, x_first, W0, owner_off;
     uint32_t row_dwords, src_row_dwords, src_pitch16, cpt, cpt_magic, tx;
-    uint32_t sub = 1, subrows = 0;   // round 4: a band of R rows is rendered by `sub` workgroups of `subrows` rows each
 };
 
 // phase 1: scalar loads (count, list offset, source rows), the band's first stamp record, then the source loads
 template <int U, bool LOAD = true>
 __device__ __forceinline__ void raw35_issue(const OverlayArgs &a, const int2 *__restrict__ band_rows, const Raw35Tile &t,
-                                            const uint32_t f, const uint32_t c, const uint32_t bsub, Raw35Band &k, u32x4 (&v)[U],
-                                            const uint2 *__restrict__ vrows = nullptr)
+                                            const uint32_t f, const uint32_t c, const uint32_t b, Raw35Band &k, u32x4 (&v)[U])
 {
     const uint32_t NB = (uint32_t)a.NB, C = (uint32_t)a.C;
-    // sub-bands (t.sub > 1): workgroup `bsub` = rows [h * subrows, (h + 1) * subrows) of band bsub / sub -- the band's stamp
-    // list is shared, each part rasterises its own rows
-    const uint32_t b = t.sub > 1u ? bsub / t.sub : bsub, h = t.sub > 1u ? bsub - b * t.sub : 0u;
     k.b = b;
     k.fc = f * C + c;
     const uint32_t bin = k.fc * NB + b;
-    k.y0 = (int)b * a.R + (int)(h * t.subrows);
-    k.nrows = t.sub > 1u ? min((int)t.subrows, min(a.R, a.H - (int)b * a.R) - (int)(h * t.subrows)) : min(a.R, a.H - k.y0);
+    k.y0 = (int)b * a.R;
+    k.nrows = min(a.R, a.H - k.y0);
     k.n = a.counts[bin];
     const uint32_t list0 = a.fc_base[k.fc] + a.bin_off[bin];          // (unconditional: three parallel scalar loads)
     k.st = a.stamps + (k.n ? (size_t)list0 : (size_t)0);
     // the band's first stamp record before the source loads (VMEM returns in order; see k_overlay)
     k.first = k.st[k.n ? min(threadIdx.x, k.n - 1u) : 0u];
     __builtin_amdgcn_sched_barrier(0);
-    if (t.sub > 1u) {
-        if (k.nrows <= 0) { k.nrows = 0; k.nsrc = 0; k.br = make_int2(0, 0); k.g = nullptr; return; }   // ragged last band
-        // the part's source rows from its first and last row's vertical taps (the per-band table covers whole bands)
-        const uint2 va = vrows[(size_t)c * a.H + k.y0], vb = vrows[(size_t)c * a.H + k.y0 + k.nrows - 1];
-        k.br = make_int2((int)(va.x & 0xffffu), (int)(vb.x >> 16) - (int)(va.x & 0xffffu) + 1);
-    } else
-        k.br = band_rows[c * NB + b];
+    k.br = band_rows[c * NB + b];
     k.g = reinterpret_cast<const u32x4 *>(a.src + ((size_t)k.fc * a.H0 + k.br.x) * (size_t)a.W0 * 3) + t.tx * t.cpt;
     k.nsrc = (uint32_t)k.br.y * t.cpt;
     // chunk idx of the tile = (source row idx / cpt, chunk idx % cpt) (cpt_magic = ceil(2^32 / cpt) from the host: exact for
@@ -325,22 +279,11 @@ __device__ __forceinline__ void raw35_finish(const OverlayArgs &a, const uint2 *
         lds_barrier();
     }
     uint32_t o[9];
-#if defined(RAW35_ABL_NOMATH)                                          // ablation: taps read, nothing computed
-#pragma unroll
-    for (int j = 0; j < 9; ++j) o[j] = d0[j] ^ d1[j + 6] ^ wt ^ wb;
-#elif defined(RAW35_OLD_MATH)
-    uint32_t px[12];
-    raw35_unit(d0, d1, wt, wb, px, std::make_integer_sequence<int, 12>{});
-    raw35_pack4(px, o);
-    raw35_pack4(px + 4, o + 3);
-    raw35_pack4(px + 8, o + 6);
-#else
     {
         uint32_t r[30];
         raw35_values(d0, d1, wt, wb, r, std::make_integer_sequence<int, 30>{});
         raw35_gather_out(r, o, std::make_integer_sequence<int, 9>{});
     }
-#endif
     if (n) {
         // stamped band: owned pixels take the palette colour -- colour and mask streams of the unit's 12 pixels, packed
         // like the output, then one select per dword
@@ -363,14 +306,12 @@ __device__ __forceinline__ void raw35_finish(const OverlayArgs &a, const uint2 *
         for (int j = 0; j < 9; ++j) o[j] = (o[j] & ~M[j]) | V[j];
     }
     lds_barrier();                                                     // every unit has read its taps: staging is dead
-#ifndef RAW35_ABL_COPYONLY                                             // (ablation: the staged bytes go out as they are)
     if (active) {
         uint32_t *dst = s_stage + row * t.row_dwords + u * 9u;         // R * row_dwords <= staging size (host-checked)
 #pragma unroll
         for (int j = 0; j < 9; ++j) dst[j] = o[j];
     }
     lds_barrier();
-#endif
     uint8_t *dcell = a.mosaic + (size_t)f * a.mosaic_frame_bytes +
                      ((size_t)(c / cols) * a.H + y0) * a.mosaic_row_bytes + (size_t)(c % cols) * W * 3 + (size_t)x_first * 3;
     const uint32_t cpr = t.row_dwords >> 2;                             // 16-byte chunks per destination tile row
@@ -395,16 +336,15 @@ template <int bands_per_wg>
 __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a, const uint2 *__restrict__ vrows,
                                                                    const int2 *__restrict__ band_rows, int upr,
                                                                    int max_src_rows, int owner_off, int TX,
-                                                                   uint32_t tx_magic, uint32_t cpt_magic, uint32_t nbx_magic,
-                                                                   uint32_t sub, uint32_t subrows)
+                                                                   uint32_t tx_magic, uint32_t cpt_magic, uint32_t nbx_magic)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     // same item order as k_overlay -- (frame, mosaic row of cameras, band [pair], camera column), column tile innermost -- and
     // the same workgroup -> item mapping (overlay_kernels.hpp: xcd_item_of)
     const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C, camrows = (C + cols - 1u) / cols;
-    const uint32_t NBx = bands_per_wg == 2 ? (NB + 1u) >> 1 : NB * sub;
+    const uint32_t NBx = bands_per_wg == 2 ? (NB + 1u) >> 1 : NB;
     uint32_t item;
-    if (!xcd_item_of(blockIdx.x, a.items, a.chunk_log2, a.rot, a.per_magic, item)) return;
+    if (!xcd_item_of(blockIdx.x, a.items, a.chunk_log2, item)) return;
     uint32_t tx = 0, cc, bx, cr;
     const uint32_t q0 = TX == 1 ? item : divmod_magic(item, (uint32_t)TX, tx_magic, tx);
     const uint32_t q1 = divmod_magic(q0, cols, a.cols_magic, cc);
@@ -419,16 +359,11 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     t.src_row_dwords = (uint32_t)upr * 15u;                             // source dwords per tile row (multiple of 4)
     t.src_pitch16 = (uint32_t)a.W0 * 3u / 16u;                          // 16-byte chunks per raw row (W0*3 % 16 == 0)
     t.cpt = t.src_row_dwords >> 2; t.cpt_magic = cpt_magic; t.tx = tx;
-    t.sub = bands_per_wg == 2 ? 1u : sub; t.subrows = subrows;
     uint32_t *s_stage = s_dyn;                                          // [max_src_rows * src_row_dwords], later the output
     constexpr int U = RAW35_STAGE_UNROLL;
     if constexpr (bands_per_wg != 2) {
         Raw35Band k;
-#ifndef RAW35_NO_LDS_DIRECT
         constexpr bool lds_direct = true;
-#else
-        constexpr bool lds_direct = false;
-#endif
         // (only when the staged rows are contiguous in memory, i.e. the raw row pitch equals the staged row: W0 * 3 == 5 * W
         // bytes; a wider sensor row -- 5 * W / 3 < W0, which the plan accepts -- takes the register-staged path with its
         // src_pitch16 stride)
@@ -438,8 +373,7 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
             // keep their layout.  Measured at 960x540 against the register-staged version (-DRAW35_NO_LDS_DIRECT),
             // alternating, three each on one box: 141.5 -> 143.7 k frames/s with the non-temporal hint, 140.5 k without.
             u32x4 none[1];
-            raw35_issue<1, false>(a, band_rows, t, f, c, bx, k, none, vrows);
-            if (!k.nrows) return;                                       // (ragged last band of a sub-band launch; uniform)
+            raw35_issue<1, false>(a, band_rows, t, f, c, bx, k, none);
             for (uint32_t base = threadIdx.x & ~63u; base < k.nsrc; base += blockDim.x) {
                 const uint32_t idx = base + (threadIdx.x & 63u);
                 if (idx < k.nsrc)
@@ -451,7 +385,7 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
             lds_barrier();
         } else {
             u32x4 v[U];
-            raw35_issue<U>(a, band_rows, t, f, c, bx, k, v, vrows);
+            raw35_issue<U>(a, band_rows, t, f, c, bx, k, v);
             if (!k.nrows) return;
             raw35_stage<U>(t, k, v, s_stage);
         }
@@ -472,120 +406,3 @@ __global__ __launch_bounds__(RAW35_MAX_BLOCK) void k_overlay_raw35(OverlayArgs a
     }
 }
 
-
-// ------------------------------------------------------------------------------------------
-// Round 4: wave-specialised, persistent variant (k_overlay_raw35_ws).
-// What bounds k_overlay_raw35<1> is bytes in flight: a band's 33.6 KB of source rows are requested when its workgroup starts
-// and nothing else is in flight for that workgroup for the remaining ~5 us of its ~7.6 us life (blend, transpose, stores):
-// four workgroups per CU -- all the LDS holds -- average about ONE band's worth of loads in flight per CU.  The two persistent
-// variants of round 3 that tried to keep a second band in flight (every wave loading the next band's rows before blending
-// this one) were slower: on gfx9 loads and stores share vmcnt, so a wave that waits for its next rows also waits for the
-// stores it has just issued.  Here the roles are split instead: a workgroup = 5 blend waves + ONE loader wave that does
-// nothing but issue the next band's rows straight into the other half of a double staging buffer (global_load_lds) and wait
-// for them -- its vmcnt sees loads only -- while the blend waves work on the current half and never wait for memory at all
-// (their stores are fire-and-forget).  2 workgroups per CU x 2 x 33.6 KB: a full band per workgroup is in flight all the time.
-// Persistent: workgroup g renders the bands of virtual blocks g, g + G, g + 2 G, ... under the launch's usual workgroup ->
-// band order (G a multiple of 8: every workgroup stays on its XCD's share).  Same taps, same arithmetic, same stamp
-// resolution as k_overlay_raw35<1> (raw35_finish): byte-identical.
-// ------------------------------------------------------------------------------------------
-struct Raw35Item { uint32_t f, c, b; bool valid; };
-
-__device__ __forceinline__ Raw35Item raw35_item_of(const OverlayArgs &a, const uint32_t L, const uint32_t nbx_magic)
-{
-    Raw35Item it{0u, 0u, 0u, false};
-    const uint32_t cols = (uint32_t)a.cols, NB = (uint32_t)a.NB, C = (uint32_t)a.C, camrows = (C + cols - 1u) / cols;
-    uint32_t item;
-    if (!xcd_item_of(L, a.items, a.chunk_log2, a.rot, a.per_magic, item)) return it;
-    uint32_t cc, cr;
-    const uint32_t q1 = divmod_magic(item, cols, a.cols_magic, cc);
-    const uint32_t q2 = divmod_magic(q1, NB, nbx_magic, it.b);
-    it.f = divmod_magic(q2, camrows, a.cr_magic, cr);
-    it.c = cr * cols + cc;
-    it.valid = it.c < C;
-    return it;
-}
-
-// header of a band (scalar loads), its first stamp record, and -- loader only -- its source rows into `stage`
-template <bool LOADER>
-__device__ __forceinline__ void raw35_ws_begin(const OverlayArgs &a, const int2 *__restrict__ band_rows, const Raw35Tile &t,
-                                               const Raw35Item &it, Raw35Band &k, uint32_t *stage, const uint32_t lane,
-                                               const uint32_t lwave, const uint32_t nloaders)
-{
-    u32x4 none[1];
-    raw35_issue<1, false>(a, band_rows, t, it.f, it.c, it.b, k, none);
-    if (LOADER) {
-        // (one wave issuing all ~33 KB of a band took ~3.3 us per band: the loader waves share the chunks round-robin)
-        for (uint32_t base = lwave * 64u; base < k.nsrc; base += 64u * nloaders) {
-            const uint32_t idx = base + lane;
-            if (idx < k.nsrc)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(k.g + idx),
-                                                 (__attribute__((address_space(3))) void *)(stage + base * 4u), 16, 0, 2 /* nt */);
-        }
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_overlay_raw35_ws(OverlayArgs a, const uint2 *__restrict__ vrows,
-                                                           const int2 *__restrict__ band_rows, int upr, int max_src_rows,
-                                                           int owner_off, uint32_t nbx_magic, uint32_t virtual_blocks,
-                                                           uint32_t stage_dwords, uint32_t nloaders)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    Raw35Tile t;
-    t.upr = upr; t.Wt = upr * 12; t.x_first = 0; t.W0 = a.W0; t.owner_off = owner_off;
-    t.row_dwords = (uint32_t)upr * 9u;
-    t.src_row_dwords = (uint32_t)upr * 15u;
-    t.src_pitch16 = (uint32_t)a.W0 * 3u / 16u;
-    t.cpt = t.src_row_dwords >> 2; t.cpt_magic = 0u; t.tx = 0u;
-    (void)max_src_rows;
-    const uint32_t nblend = blockDim.x - 64u * nloaders;               // blend threads (a multiple of 64); the last waves load
-    const bool loader = threadIdx.x >= nblend;
-    const uint32_t lane = threadIdx.x & 63u, lwave = loader ? (threadIdx.x - nblend) >> 6 : 0u;
-    uint32_t L = blockIdx.x;
-    // first band of this workgroup
-    Raw35Item it = raw35_item_of(a, L, nbx_magic);
-    while (!it.valid && L < virtual_blocks) {                           // (ragged camera rows / padding of the order: skip)
-        L += gridDim.x;
-        if (L >= virtual_blocks) break;
-        it = raw35_item_of(a, L, nbx_magic);
-    }
-    if (!it.valid) return;                                               // workgroup-uniform
-    uint32_t cur = 0;
-    Raw35Band k;
-    if (loader) {
-        raw35_ws_begin<true>(a, band_rows, t, it, k, s_dyn, lane, lwave, nloaders);
-        __builtin_amdgcn_s_waitcnt(0x0f70);                              // vmcnt(0): the first band has landed
-    } else
-        raw35_ws_begin<false>(a, band_rows, t, it, k, s_dyn, lane, 0u, nloaders);
-    lds_barrier();
-    for (;;) {
-        // the next band of this workgroup (workgroup-uniform)
-        uint32_t Ln = L + gridDim.x;
-        Raw35Item nx{0u, 0u, 0u, false};
-        while (Ln < virtual_blocks) {
-            nx = raw35_item_of(a, Ln, nbx_magic);
-            if (nx.valid) break;
-            Ln += gridDim.x;
-        }
-        const bool more = nx.valid;
-        uint32_t *stage = s_dyn + cur * stage_dwords, *stage_next = s_dyn + (cur ^ 1u) * stage_dwords;
-        Raw35Band kn;
-        if (loader) {
-            // the other half is free: whoever read it last did so before the barrier that ended the previous round
-            if (more) raw35_ws_begin<true>(a, band_rows, t, nx, kn, stage_next, lane, lwave, nloaders);
-            // the same barriers as raw35_finish executes for this band (n is workgroup-uniform)
-            if (k.n) { lds_barrier(); lds_barrier(); lds_barrier(); }
-            lds_barrier();
-            lds_barrier();
-            __builtin_amdgcn_s_waitcnt(0x0f70);                          // the next band's rows are in LDS
-            lds_barrier();
-        } else {
-            if (more) raw35_ws_begin<false>(a, band_rows, t, nx, kn, stage_next, lane, 0u, nloaders);
-            raw35_finish(a, vrows, t, it.f, it.c, k, stage, true, nblend);
-        }
-        if (!more) break;
-        k = kn;
-        it = nx;
-        L = Ln;
-        cur ^= 1u;
-    }
-}

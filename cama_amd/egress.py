@@ -74,32 +74,6 @@ class PinnedPool:
 
 
 _POOL = PinnedPool()
-_EGRESS_STREAMS = {}
-
-
-def egress_stream(engine):
-    """A/B knob (CAMA_EGRESS_CUS=n > 0): run the batches' downloads on a stream whose kernels are confined to n compute
-    units spread over the chip (cama_stream_create_masked).  Built when a trace showed the downloads as blit kernels
-    (__amd_rocclr_copyBuffer, 41 ms per 240-frame bgr24 pass) next to the JPEG decoder; measured SLOWER (bgr24 3.07 k ->
-    2.39-2.48 k frames/s) -- and the premise was an artefact: torch's bundled HIP runtime copies device -> pinned memory with
-    blit kernels only while rocprofv3 is attached, by SDMA otherwise (profiles/r04_demo_loop_timeline.txt, CORRECTION).
-    Default 0 = the render stream."""
-    import ctypes
-    import os
-    n = int(os.environ.get("CAMA_EGRESS_CUS", "0"))
-    if n <= 0:
-        return None
-    key = (str(engine.device), n)
-    st = _EGRESS_STREAMS.get(key)
-    if st is None:
-        torch = _torch()
-        handle = ctypes.c_void_p()
-        with torch.cuda.device(engine.device):
-            rc = engine.lib.cama_stream_create_masked(n, ctypes.byref(handle))
-        st = _EGRESS_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=engine.device) if rc == 0 else False
-    return st or None
-
-
 class RenderBatch:
     """B consecutive frames rendered in one launch: `mosaic` [B, rows*H, cols*W, 3] uint8 in HBM (complete on the
     stream it was rendered on), plus -- after start_egress() -- their host copy on its way to pinned memory: the BGR
@@ -141,24 +115,13 @@ class RenderBatch:
         return True
 
     def _download(self, host_view, dev_view, keep):
-        """Asynchronous device -> pinned copy behind the work queued on the current stream, on the CU-masked egress stream
-        when there is one; records self._event."""
+        """Asynchronous device -> pinned copy behind the work queued on the current stream; records self._event.  (A CU-masked
+        side stream for the copies was tried in round 4 and measured slower: profiles/r04_demo_loop_timeline.txt.)"""
         torch = _torch()
-        eng = self.engine
-        cur = torch.cuda.current_stream(eng.device)
-        side = egress_stream(eng)
+        cur = torch.cuda.current_stream(self.engine.device)
         self._event = torch.cuda.Event()
-        if side is None:
-            host_view.copy_(dev_view, non_blocking=True)
-            self._event.record(cur)
-            return
-        ready = torch.cuda.Event()
-        ready.record(cur)
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            host_view.copy_(dev_view, non_blocking=True)
-            self._event.record(side)
-        keep.record_stream(side)
+        host_view.copy_(dev_view, non_blocking=True)
+        self._event.record(cur)
 
     def _host_rows(self):
         if self._host_np is None:

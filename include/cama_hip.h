@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 21
+#define CAMA_ABI_VERSION 22
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)
@@ -286,14 +286,6 @@ int64_t cama_pipeline_issued(cama_pipeline *p);
 int64_t cama_pipeline_completed(cama_pipeline *p);
 /* Device bytes of scratch the pipeline owns right now (all slots, plan + stamp parts). */
 int64_t cama_pipeline_scratch_bytes(cama_pipeline *p);
-/* out[6] (host): launches issued, launches that were planned, buffer (re)allocations so far, scratch bytes owned, and the
- * last launch's plan: segments per (frame, camera), band-entry capacity (0, 0 when it was not planned). */
-int cama_pipeline_info(cama_pipeline *p, uint64_t *out);
-/* cama_bin_stats (below) of the pipeline's LAST launch out of its own scratch; blocks until that launch is over. */
-int cama_pipeline_bin_stats(cama_pipeline *p, uint64_t *out /* host, 4 */);
-/* Test hook: the pipeline-owned stamp buffers sit between two 1 MiB zones filled with 0x5A; *bad_bytes = how many of
- * those bytes no longer hold the pattern (0 = no launch wrote outside its demand-sized buffers).  Blocks. */
-int cama_pipeline_guard_check(cama_pipeline *p, int64_t *bad_bytes /* host */);
 
 /*
  * Many scenes per chain.  main.py:32 renders scene after scene; a scene of ~1e4 vertices x 40 frames is ~0.35 ms of GPU
@@ -411,31 +403,8 @@ int cama_overlay_frames_raw(const uint8_t *raw, int32_t H0, int32_t W0, const fl
                             int32_t radius, const int32_t *halfwidth, const uint8_t *palette_bgr,
                             const void *scratch, size_t scratch_bytes, void *stream);
 
-/*
- * Diagnostic: xcd_of_block[L] (device, n_blocks uint32) = the XCD (HW_REG_XCC_ID, 0..7) that block L of a 1-D grid of
- * n_blocks 64-thread blocks ran on.  The overlay kernels' XCD-contiguous workgroup -> band mapping assumes L % 8 -- for
- * speed only, the output never depends on it -- and bench.py prints what the box does.
- */
-int cama_probe_xcd_map(uint32_t *xcd_of_block, int32_t n_blocks, void *stream);
 
-/* A HIP stream (returned as void*) whose kernels are confined to n_cus compute units spread evenly over the chip
- * (hipExtStreamCreateWithCUMask).  An A/B knob of the host side's egress (CAMA_EGRESS_CUS, default off): it was built to
- * confine the blit kernels a trace showed the runtime copying device -> pinned host memory with -- which it only does while
- * a profiler is attached (SDMA otherwise), and confined they were slower anyway.  The caller owns the stream.  (No reference
- * counterpart.) */
-int cama_stream_create_masked(int32_t n_cus, void **stream /* host */);
-int cama_stream_destroy(void *stream);
 
-/* Which workgroup -> band order do big overlay launches (>= 1.75 GiB touched) use?  The speed of the XCD-contiguous order (31)
- * depends on the buffers a launch walks (their physical placement: 0.75 .. 0.835 of 8 TB/s at 40 frames of 1600x900, the same
- * for a given pair of buffers every time), that of round-robin chunks of 32 bands (5) does not (0.775 .. 0.79).  So the
- * library times both on the first launches over each (frames, mosaic) pair -- three timings each, the launch's own start /
- * stop events, no host synchronisation -- and keeps the faster median for that pair (cama_hip.hip: MapTuner; the 64 most
- * recently used pairs per process; speed only, the pixels never depend on it).  This call reports the pair of the most
- * recent big launch: decided: -1 while measuring, else 31 or 5 (or the value overlay_chunk_log2 forces); samples[2],
- * ns_per_mb[2]: timings taken so far and their median time per 10^6 bytes, [0] = contiguous, [1] = chunked.  Any pointer
- * may be NULL.  (No reference counterpart.) */
-int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per_mb);
 
 /* How fast does the overlay run from `src` [F,C,H,W,3] into `mosaic` [F, rows*H, cols*W, 3] -- as a pure copy (no stamps), in
  * the XCD-contiguous order?  One untimed launch, then `reps` timed ones on `stream`; *ms_mean = their mean duration; blocks
@@ -443,33 +412,12 @@ int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per
  * bandwidth depends on where its source and destination sit physically relative to each other (about one destination
  * allocation in six runs at 0.83 of 8 TB/s, the others at 0.77, the same every time: profiles/r04_overlay_modes.txt section 5),
  * so a caller that keeps a mosaic (or frame) buffer for many launches allocates a few candidates, probes each and keeps the
- * fastest (cama_amd/engine.py: Engine.alloc_mosaic / alloc_mosaics / place_frames).  The launches run under their own kernel
+ * fastest (cama_amd/engine.py: MosaicPool / Engine.place_frames).  The launches run under their own kernel
  * name (k_overlay_probe: the same code) so that a workload's kernel statistics keep them apart, and do not go through the
  * mapping table above.  W % 16 == 0 and 16-byte aligned buffers (CAMA_EINVAL otherwise).  (No reference counterpart.) */
 int cama_overlay_probe(const uint8_t *src /* device */, uint8_t *mosaic /* device */, int32_t F, int32_t C, int32_t H, int32_t W,
                        int32_t cols, int32_t reps, double *ms_mean /* host */, void *stream);
 
-/* Process-wide tuning options: performance only -- no option can change a result (every one of them selects among orders /
- * schedules that are bijections over the same work; the parity suite runs with each forced).  An option starts from its
- * environment variable, read once, and may be changed at run time; launches already enqueued keep what they were given.
- *   name                  env                      meaning
- *   overlay_chunk_log2    CAMA_OVERLAY_CHUNK_LOG2  -1 = library's choice; 0 = workgroup L renders band L; 1..30 = round-robin
- *                                                  chunks of 2^k bands over the 8 XCDs; 31 = one contiguous range per XCD
- *   overlay_tune          CAMA_OVERLAY_TUNE        0 = big launches keep the contiguous order (no self-timing)
- *   overlay_rot           CAMA_OVERLAY_ROT         contiguous order: XCD x starts rot * x bands into its own range
- *   overlay_prefetch      CAMA_OVERLAY_PREFETCH    translation look-ahead, in workgroups per XCD (0 = off, -1 = library's choice)
- *   overlay_item_order    CAMA_OVERLAY_ITEM_ORDER  0 = bands run (frame, camera row, band, camera column); 1 = band innermost
- *   overlay_groups_log2   CAMA_OVERLAY_GROUPS_LOG2 with a forced overlay_chunk_log2 < 31: 2^g groups of XCDs, each one contiguous
- *                                                  range of the launch, chunks round-robin inside a group (1, 2; 0 = off)
- *   cull_list_min         CAMA_CULL_LIST_MIN       (vertex block, frame) items from which the cull of a site-sized map goes
- *                                                  through work lists + persistent workgroups (default 16384)
- *   pipeline_host_wait    CAMA_PIPELINE_HOST_WAIT  1 = cama_pipeline_render* waits on the HOST for a launch's binning before it
- *                                                  queues the overlay (the call blocks ~0.1 ms; no barrier packet between
- *                                                  consecutive overlays on the GPU: +1.5 % on the headline); 0 = stream-side
- *                                                  wait; -1 (default) = host wait for launches that move >= 1 GiB (smaller ones are host-bound)
- * Unknown names: CAMA_EINVAL.  (No reference counterpart: the reference has no native code.) */
-int cama_set_option(const char *name, int64_t value);
-int cama_get_option(const char *name, int64_t *value);
 
 /*
  * Stamp-only overlay for caller-supplied 2D points (the generic CameraManager.render_maps,
@@ -538,30 +486,6 @@ int cama_circle_halfwidths(int32_t radius, int32_t *hw /* host */);
 /* Rows per band the overlay kernel uses for images of width W (its LDS owner table is rows*W*4 bytes). */
 int cama_overlay_band_rows(int32_t W);
 
-/*
- * Live timing of the dominant kernel (the overlay) for roofline reporting.  While enabled on the calling
- * thread, every cama_render_frames call records a hipEvent pair around its overlay launch, on the stream
- * the kernel is launched on.  cama_profile_collect waits for the recorded events (host-blocking), returns
- * the summed elapsed milliseconds and the number of launches since the last collect, and recycles the events.
- */
-int cama_profile_enable(int32_t on);
-int cama_profile_collect(double *total_ms /* host */, int32_t *launches /* host */);
-/* The same, launch by launch: the durations (ms) of the timed overlay launches since the last collect, in issue order, up to
- * `capacity` of them into ms[]; *launches = how many there were (all are drained).  bench.py reports min / mean / max. */
-int cama_profile_collect_each(double *ms /* host */, int32_t capacity, int32_t *launches /* host */);
-/* The same for the projection kernel (k_frames_project / k_frames_project_list) of every cama_bin_frames call made
- * while profiling was enabled: the kernel's own start / stop events. */
-int cama_profile_collect_project(double *total_ms /* host */, int32_t *launches /* host */);
-/*
- * Diagnostic read-back of a finished cama_bin_frames (same N, F, C, H, W, radius, scratch; had_block_bounds = whether
- * block_bounds was passed).  Blocks the host until `stream` is idle, then copies the small tables back.  out (host, 4):
- *   out[0] (wave, frame) items the projection read = 64-vertex runs whose camera mask was not 0 (all of them without
- *          block_bounds): the vertex buffer bytes the kernel really fetched are 13 B (16 B with draw_key) x 64 x out[0]
- *   out[1] camera bits set over those items (fp64 chains run = out[1] x 64 lanes)
- *   out[2] stamps written (8 B each)          out[3] band entries (what the overlay reads, 8 B each)
- */
-int cama_bin_stats(const void *scratch, size_t scratch_bytes, int64_t N, int32_t F, int32_t C, int32_t H, int32_t W,
-                   int32_t radius, int32_t had_block_bounds, uint64_t *out /* host, 4 */, void *stream);
 
 /*
  * Device baseline-JPEG decode of a batch of camera frames: what CameraManager.read_resized_image /

@@ -598,25 +598,6 @@ def test_raw_overlay_reference_default_size(tmp_path):
     assert _raw_pipeline_vs_oracle(tmp_path, (900, 1600), (540, 960), seed=34, n_frames=3, check_frames=(1,)) == "raw35"
 
 
-@pytest.mark.parametrize("options", [{"raw35_ws": 2, "raw35_loaders": 3}, {"raw35_ws": 1, "raw35_loaders": 1},
-                                     {"raw35_subrows": 1}])
-def test_raw35_kernel_variants_render_the_same_bytes(tmp_path, options):
-    """Round 4 built two more structures around the 3:5 raw overlay's arithmetic -- a wave-specialised persistent kernel
-    (loader waves + a double staging buffer) and half bands per workgroup; neither beat the classic kernel (profiles/
-    r04_raw35_account.txt), both stay selectable options and must render the oracle's bytes: the reference's default
-    pipeline at full size and a small stamped one."""
-    from cama_amd import _lib
-    L = _lib.lib()
-    try:
-        for k, v in options.items():
-            assert L.cama_set_option(k.encode(), v) == 0
-        assert _raw_pipeline_vs_oracle(tmp_path / "full", (900, 1600), (540, 960), seed=35, n_frames=3, check_frames=(0, 1)) == "raw35"
-        assert _raw_pipeline_vs_oracle(tmp_path / "small", (90, 160), (54, 96), seed=36, n_frames=4, check_frames=(0, 1, 2)) == "raw35"
-    finally:
-        for k, v in (("raw35_ws", 0), ("raw35_loaders", 2), ("raw35_subrows", 0)):
-            L.cama_set_option(k.encode(), v)
-
-
 def test_integration_md_binding_example_runs(repo_root):
     """The ctypes stub shown in INTEGRATION.md (what a maintainer of the reference would add) is real code: extract
     it, point it at the built library, render with it and compare with the engine."""

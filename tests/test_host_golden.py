@@ -145,15 +145,31 @@ def test_mosaic_layout_plain_dict():
 
 
 def test_library_exports_every_declared_symbol(repo_root):
-    """The C-ABI library loads (no GPU needed) and exports exactly what include/cama_hip.h declares."""
+    """The C-ABI library loads (no GPU needed) and exports exactly what the two headers declare: include/cama_hip.h = the
+    contract (every entry listed in INTEGRATION.md), include/cama_hip_diag.h = diagnostics / live timing / options."""
     import re
+    import subprocess
     from cama_amd import _lib
     L = _lib.lib()
     header = open(join(repo_root, "include", "cama_hip.h")).read()
-    declared = set(re.findall(r"\b(cama_[a-z_0-9]+)\s*\(", header))
+    diag = open(join(repo_root, "include", "cama_hip_diag.h")).read()
+    fn = r"^(?:int|int64_t|size_t|const char \*)\s*\*?(cama_[a-z_0-9]+)\s*\("
+    contract = set(re.findall(fn, header, flags=re.M))
+    diagnostic = set(re.findall(fn, diag, flags=re.M))
+    assert not contract & diagnostic
+    assert diagnostic == set(_lib.DIAG), diagnostic ^ set(_lib.DIAG)
+    declared = contract | diagnostic
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert getattr(L, name) is not None
+    # ... and nothing else: every cama_* symbol the shared object exports is declared
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("cama_")}
+    assert exported == declared, exported ^ declared
+    # the contract is documented entry by entry
+    integ = open(join(repo_root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in contract if n not in integ)
+    assert not missing, f"INTEGRATION.md does not mention {missing}"
     assert L.cama_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define CAMA_ABI_VERSION (\d+)", header).group(1))
     assert _lib.circle_halfwidths(2).tolist() == [2, 1, 0]
     assert L.cama_render_scratch_bytes(10000, 40, 6, 900, 1600, 2) > 0
