@@ -332,6 +332,50 @@ def test_dense_polyline_duplicate_pixels(engine):
         assert np.array_equal(out[f], O.frame_render_flat(src[f], flat["vu"], flat["vis"], col))
 
 
+@pytest.mark.parametrize("spatial_sort", [False, True])
+def test_interleaved_pixel_runs_keep_the_last_writer(engine, spatial_sort):
+    """Round 5: a stamp is dropped in the projection when one of the next 8 lanes of its wave carries a greater draw key on
+    the SAME pixel (not just the next lane).  Far-range polylines alternate between two or three pixels (A B A B ..., A B C A
+    B C ...); the colours below change with a period that is coprime to those patterns, so dropping the wrong one of two
+    stamps on a pixel changes the rendered colour.  Also with a Morton-sorted buffer, where a later lane may carry a SMALLER
+    draw key (then nothing may be dropped on its account).  Byte-exact against the oracle."""
+    import torch
+    W, H = 320, 180
+    _, _, cams, _ = _random_scene(5, 10, 1, W, H)
+    cam = cams[1]
+    Kinv, c2cam_inv = np.linalg.inv(cam["K"]), np.linalg.inv(cam["chassis2camera"])
+    rng = np.random.default_rng(11)
+    pts = []
+    for run in range(60):                                        # runs of 40 .. 200 points hopping between 2 .. 4 pixels
+        period = int(rng.integers(2, 5))
+        centres = [(float(rng.integers(20, W - 20)) + 0.5, float(rng.integers(20, H - 20)) + 0.5) for _ in range(period)]
+        depth = float(rng.uniform(20.0, 60.0))
+        for j in range(int(rng.integers(40, 200))):
+            u, v = centres[j % period]
+            u += float(rng.uniform(-0.3, 0.3))                   # stays inside the pixel
+            v += float(rng.uniform(-0.3, 0.3))
+            pc = Kinv @ np.array([u * depth, v * depth, depth])
+            pts.append((c2cam_inv @ np.r_[pc, 1.0])[:3])
+    xyz = np.ascontiguousarray(np.asarray(pts, np.float64))
+    N = len(xyz)
+    col = ((np.arange(N) // 5) % 2).astype(np.uint8)             # period 10 against hop periods 2, 3, 4
+    w2c = np.eye(4, dtype=np.float32)[None]
+    crop = [-1e9, 1e9, -1e9, 1e9, -1e9, 1e9]
+    rig = _rig(engine, cams)
+    dmap = engine.upload_map(xyz, col, spatial_sort=spatial_sort)
+    assert (dmap.sorted_key is not None) == spatial_sort
+    src = np.random.default_rng(4).integers(0, 256, (1, 6, H, W, 3), dtype=np.uint8)
+    out = engine.render_frames(dmap, rig, w2c, torch.from_numpy(src).cuda(), crop=crop).cpu().numpy()
+    flat = O.frame_project_flat(xyz, w2c[0], cams, W, H, crop=crop)
+    vis = flat["vis"][1].astype(bool)
+    px = flat["vu"][1][vis].astype(np.int32)
+    assert vis.sum() > 4000 and len(np.unique(px[:, 0] * W + px[:, 1])) < 400       # thousands of stamps on a few hundred pixels
+    assert np.array_equal(out[0], O.frame_render_flat(src[0], flat["vu"], flat["vis"], col))
+    st = engine.bin_stats()
+    if not spatial_sort:                                         # most of them never leave the projection kernel
+        assert st["stamps"] < 0.6 * sum(int(flat["vis"][c].sum()) for c in range(6)), st
+
+
 def test_early_outs_do_not_change_visibility_on_knife_edges(engine):
     """Points placed exactly on / within an ulp of the image borders and of the z = 0 plane of the front camera:
     the bin kernel's depth and frustum early-outs must agree with the full chain (oracle) bit for bit."""
