@@ -398,36 +398,39 @@ __device__ __forceinline__ void emit_wave_segments(const FrameArgs &a, const int
 // How far ahead in its wave a stamp looks for a later point on the same pixel (see emit_wave_stamps)
 constexpr int DEDUP_WINDOW = 8;
 
-// bit d - 1: lane + d is in this wave and carries a GREATER draw key than this lane (camera-independent: once per wave)
-__device__ __forceinline__ uint32_t later_key_mask(const uint32_t key)
-{
-    const uint32_t lane = __lane_id();
-    uint32_t later = 0u;
-#pragma unroll
-    for (int d = 1; d <= DEDUP_WINDOW; ++d) {
-        const uint32_t key_d = __shfl_down(key, d, 64);
-        later |= ((lane + (uint32_t)d < 64u) && key_d > key) ? (1u << (d - 1)) : 0u;
-    }
-    return later;
-}
-
 __device__ __forceinline__ void emit_wave_stamps(const FrameArgs &a, const int f, const int c, const WaveVerts &v,
-                                                 const uint32_t uv, const uint32_t later, uint32_t *s_cnt)
+                                                 const uint32_t uv, uint32_t *s_cnt)
 {
     const uint32_t lane = __lane_id();
+    const bool valid = uv != 0xffffffffu;
+    const uint64_t mv = __ballot(valid);
+    if (!mv) return;                    // wave-uniform
     // A disc is invisible if a LATER point (higher draw index) stamps the very same pixel (same footprint).  The
     // following lanes are the following vertices of the polyline, so on dense maps (1 cm spacing) most far-range stamps
-    // collapse here, exactly, before they cost HBM or LDS traffic.  Round 5: not just the next lane but the next
-    // DEDUP_WINDOW -- far from the camera a polyline's points alternate between two or three pixels (A B A B ...), which the
-    // next-lane test cannot see: on the 10^6-vertex site maps 36 % of the stamps that survived it were still duplicates of a
-    // later stamp, a window of 8 leaves 10 % (the whole wave: 8 %).  (executed by every lane: shuffles)
-    bool covered = false;
+    // collapse here, exactly, before they cost HBM or LDS traffic.
+    // Round 5: not just the next lane but the next DEDUP_WINDOW -- where a polyline crosses the image at a shallow angle far
+    // from the camera its points hop back and forth between two or three pixels (A B A B ..., A A B A B B ...), which the
+    // next-lane test cannot see: on the 10^6-vertex site maps 36 % of the stamps that survived it were still duplicates of
+    // a later stamp; a window of 8 leaves 10 % (the whole wave: 8 %).  The window costs ~40 instructions per (wave, camera)
+    // -- +23 % on the dense lane map's projection when every wave paid it, for 0.8 % fewer stamps: lanes that run towards
+    // the vanishing point step monotonically, A A A B B B, and the next-lane test gets them all -- so a wave runs it only
+    // when it shows the pattern: some lane's pixel comes back two lanes on with another pixel in between (A B A).  The test
+    // is wave-uniform; which stamps are dropped is a matter of speed, never of pixels.
+    const uint32_t uv_1 = __shfl_down(uv, 1, 64), uv_2 = __shfl_down(uv, 2, 64);
+    const bool monotone_keys = a.key == nullptr;                     // draw order = buffer order: later lanes carry greater keys
+    const uint32_t key_1 = monotone_keys ? 0xffffffffu : __shfl_down(v.key, 1, 64);
+    bool covered = valid && (lane < 63u) && (uv_1 == uv) && (key_1 > v.key);
+    if (__ballot(valid && (lane < 62u) && (uv_2 == uv) && (uv_1 != uv))) {       // wave-uniform
+        const uint32_t key_2 = monotone_keys ? 0xffffffffu : __shfl_down(v.key, 2, 64);
+        covered |= valid && (lane < 62u) && (uv_2 == uv) && (key_2 > v.key);
 #pragma unroll
-    for (int d = 1; d <= DEDUP_WINDOW; ++d) {
-        const uint32_t uv_d = __shfl_down(uv, d, 64);
-        covered |= ((later >> (d - 1)) & 1u) && (uv_d == uv);
+        for (int d = 3; d <= DEDUP_WINDOW; ++d) {
+            const uint32_t uv_d = __shfl_down(uv, d, 64);
+            const uint32_t key_d = monotone_keys ? 0xffffffffu : __shfl_down(v.key, d, 64);
+            covered |= valid && (lane + (uint32_t)d < 64u) && (uv_d == uv) && (key_d > v.key);
+        }
     }
-    const bool keep = (uv != 0xffffffffu) && !covered;
+    const bool keep = valid && !covered;
     const uint64_t m = __ballot(keep);
     if (!m) return;                     // wave-uniform
     const size_t fcseg = ((size_t)f * a.C + c) * a.nseg + v.seg;
@@ -456,7 +459,6 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
     const WaveVerts v = load_wave_verts<T>(a, vblock, f, cams4, seg_base);
     if (!v.cams) return;
     const double Wd = (double)a.W, Hd = (double)a.H;
-    const uint32_t later = a.segments ? 0u : later_key_mask(v.key);
     // only the cameras the wave's mask lets through (wave-uniform scalar loop: the kernel issues as many SALU as VALU
     // instructions, PMC: profiles/r02_project_dense1e6_pmc_sq.csv)
     for (uint32_t todo = v.cams & ((1u << a.C) - 1u); todo; todo &= todo - 1u) {
@@ -480,7 +482,7 @@ __device__ __forceinline__ void project_block(const FrameArgs &a, const int64_t 
             }
             emit_wave_segments(a, f, c, v, uv, uv_halo, s_cnt);
         } else
-            emit_wave_stamps(a, f, c, v, uv, later, s_cnt);
+            emit_wave_stamps(a, f, c, v, uv, s_cnt);
     }
 }
 

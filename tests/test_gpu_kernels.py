@@ -372,8 +372,8 @@ def test_interleaved_pixel_runs_keep_the_last_writer(engine, spatial_sort):
     assert vis.sum() > 4000 and len(np.unique(px[:, 0] * W + px[:, 1])) < 400       # thousands of stamps on a few hundred pixels
     assert np.array_equal(out[0], O.frame_render_flat(src[0], flat["vu"], flat["vis"], col))
     st = engine.bin_stats()
-    if not spatial_sort:                                         # most of them never leave the projection kernel
-        assert st["stamps"] < 0.6 * sum(int(flat["vis"][c].sum()) for c in range(6)), st
+    if not spatial_sort:                 # the waves that show an A B A pattern (period-2 runs) drop theirs in the projection
+        assert st["stamps"] < 0.9 * sum(int(flat["vis"][c].sum()) for c in range(6)), st
 
 
 def test_early_outs_do_not_change_visibility_on_knife_edges(engine):
