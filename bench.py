@@ -853,6 +853,10 @@ def plan(args):
         # candidates of the (F + 1)-frame source; several mosaics: ONE pool of max(K/4, 2) per buffer, the kept ones counted above
         cands = (K_aud + K_aud // 2) if n_buf == 1 else max(K_aud // 4, 2) * n_buf - n_buf
         rec["placement_transient_bytes"] = 0 if (args.audition == 0 or args.raw_frames) else cands * one
+        # while the engine auditions (Job.allocate, at most 4 ranks of the node at a time): the resident frames and maps + the
+        # candidates; the engine itself never takes more than half (one mosaic) / three quarters (a pool) of what is free
+        rec["peak_bytes_during_placement"] = frames_res + maps + rec["placement_transient_bytes"]
+        total = max(total, rec["peak_bytes_during_placement"])
         if do_stress:                                               # runs after the sweep's buffers are freed
             slo, shi = shard.frame_ranges(args.stress_frames, world)[r]
             sF = shi - slo

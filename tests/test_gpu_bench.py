@@ -42,6 +42,13 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert st["hash_check"]["verified"] == 16 and not st["hash_check"]["mismatched"]
     for r in (line["roofline"], line["roofline_project"], st["roofline"], st["roofline_project"]):
         assert 0.0 < r["frac"] <= 1.0, r
+    # every rank pinned itself to its own cores (disjoint contiguous shares of the allowed / NUMA-local ones)
+    aff = line["rank_affinity"]
+    assert aff["bound"] == [True, True] and min(aff["cpus_per_rank"]) >= 1
+    spans = sorted(zip(aff["first_cpu"], aff["last_cpu"]))
+    assert spans[0][1] < spans[1][0], aff
+    # ranks sharing one GPU run without placement auditions; the line says where placement lives
+    assert line["placement"]["source"].startswith("off") and line["placement"]["pool"]["auditions"] == 0
 
 
 def test_bench_gpus_beyond_the_node_is_refused_not_asserted():
