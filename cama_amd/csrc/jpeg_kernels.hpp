@@ -297,6 +297,79 @@ __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegSta
     return nb;
 }
 
+// ---- the synchronisation phases' own decoder (round 5) --------------------------------------------------------------
+// k_jpeg_sync<1|2> never need a coefficient's VALUE: only how many bits a symbol takes and where it leaves the zigzag index.
+// Their workgroups therefore rewrite the LUT copy in LDS into TRANSITION entries (jpeg_sync_entry):
+//     bits 0..5  used = code length + magnitude bits          bits 8..14  kinc: the zigzag index after the symbol is k + kinc
+//                                                                          (DC: 1; AC with a value: run + 1; ZRL: 16; EOB: 64)
+// -- the same state transitions as jpeg_decode_span (T.81 F.2.2), with "k + kinc >= 64" as the one end-of-block test.  The
+// loop is ~30 instructions per symbol with two rare branches (codes longer than 10 bits, the window refill) where
+// jpeg_decode_span<false> compiled to ~58 with five divergent regions; the phases are latency-bound chains of exactly this
+// loop (profiles/r04_demo_loop_timeline.txt: 62.7 of a 79 ms decode pass).
+__device__ __forceinline__ uint32_t jpeg_sync_entry(uint32_t tab, uint32_t e)       // e = (length << 8) | symbol, != 0
+{
+    const uint32_t len = e >> 8, size = e & 15u, run = (e >> 4) & 15u;
+    const uint32_t kinc = (tab & 1u) ? (size ? run + 1u : (run == 15u ? 16u : 64u)) : 1u;
+    return (len + size) | (kinc << 8);
+}
+
+__device__ __forceinline__ void jpeg_sync_tables(JpegHuffSet &H)                     // in place, whole workgroup; barrier after
+{
+    uint16_t *lut = &H.lut[0][0];
+    for (uint32_t i = threadIdx.x; i < 4u << JPEG_LUT_BITS; i += JPEG_WG) {
+        const uint32_t e = lut[i];
+        if (e) lut[i] = (uint16_t)jpeg_sync_entry(i >> JPEG_LUT_BITS, e);
+    }
+}
+
+// every symbol that STARTS in [s.pos, end), state only; H's LUT holds transition entries (jpeg_sync_tables)
+__device__ __forceinline__ uint32_t jpeg_sync_span(const JpegWgCtx &c, JpegState &s, uint32_t end)
+{
+    if (s.pos >= end) return 0;
+    uint32_t nb = 0, pos = s.pos, blk = s.blk, k = s.k;
+    uint32_t w = (pos >> 5) - c.word0;
+    uint32_t hi, lo;
+    int32_t cnt;                                                    // valid bits in lo (all of hi is valid)
+    {
+        const uint32_t w0 = jpeg_word(c, w), w1 = jpeg_word(c, w + 1), sh = pos & 31u;
+        hi = sh ? __builtin_amdgcn_alignbit(w0, w1, 32u - sh) : w0;
+        lo = sh ? w1 << sh : w1;
+        cnt = 32 - (int32_t)sh;
+        w += 2;
+    }
+    const uint16_t *lut = &c.H->lut[0][0];
+    const uint32_t bpm = c.bpm;
+    while (pos < end) {
+        const uint32_t isac = k ? 1u : 0u;
+        const uint32_t tab = (((isac ? c.ac_mask : c.dc_mask) >> blk) & 1u) * 2u + isac;
+        uint32_t e = lut[(tab << JPEG_LUT_BITS) + (hi >> (32 - JPEG_LUT_BITS))];
+        const uint32_t next = jpeg_word(c, w);                      // refill word (used when lo runs dry)
+        if (e == 0u) e = jpeg_sync_entry(tab, jpeg_symbol_long(*c.H, tab, hi));
+        const uint32_t used = e & 63u;                              // 1..31
+        k += e >> 8;
+        pos += used;
+        hi = __builtin_amdgcn_alignbit(hi, lo, 32u - used);
+        lo <<= used;
+        cnt -= (int32_t)used;
+        if (cnt < 0) {                                              // hi is short of -cnt bits at its bottom: the top bits of `next`
+            const uint32_t miss = (uint32_t)(-cnt);
+            hi |= next >> (32u - miss);
+            lo = next << miss;
+            cnt = 32 - (int32_t)miss;
+            ++w;
+        }
+        const bool done = k >= 64u;
+        const uint32_t blk1 = blk + 1u == bpm ? 0u : blk + 1u;
+        k = done ? 0u : k;
+        blk = done ? blk1 : blk;
+        nb += done ? 1u : 0u;
+    }
+    s.pos = pos;
+    s.blk = blk;
+    s.k = k;
+    return nb;
+}
+
 // The same decode executed by a whole WAVE for ONE subsequence: lane i looks up, under all four tables, the symbol
 // that would start at bit pos + i; the wave then walks the actual symbol chain with scalar state and v_readlane
 // (no memory access per symbol).  A lone lane needs ~700 cycles per symbol (dependent LDS lookup + ~75 instructions
@@ -317,10 +390,11 @@ __device__ __forceinline__ uint32_t jpeg_decode_span_wave(const JpegWgCtx &c, Jp
         uint32_t e1 = lut[(1u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
         uint32_t e2 = lut[(2u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
         uint32_t e3 = lut[(3u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
-        if (e0 == 0u) e0 = jpeg_symbol_long(*c.H, 0u, win);
-        if (e1 == 0u) e1 = jpeg_symbol_long(*c.H, 1u, win);
-        if (e2 == 0u) e2 = jpeg_symbol_long(*c.H, 2u, win);
-        if (e3 == 0u) e3 = jpeg_symbol_long(*c.H, 3u, win);
+        // (the LUT holds transition entries: jpeg_sync_tables)
+        if (e0 == 0u) e0 = jpeg_sync_entry(0u, jpeg_symbol_long(*c.H, 0u, win));
+        if (e1 == 0u) e1 = jpeg_sync_entry(1u, jpeg_symbol_long(*c.H, 1u, win));
+        if (e2 == 0u) e2 = jpeg_sync_entry(2u, jpeg_symbol_long(*c.H, 2u, win));
+        if (e3 == 0u) e3 = jpeg_sync_entry(3u, jpeg_symbol_long(*c.H, 3u, win));
         const uint32_t e01 = e0 | (e1 << 16), e23 = e2 | (e3 << 16);
         uint32_t off = 0;
         while (off < 64u && pos + off < end) {
@@ -328,9 +402,8 @@ __device__ __forceinline__ uint32_t jpeg_decode_span_wave(const JpegWgCtx &c, Jp
             const uint32_t sel = ((isac ? c.ac_mask : c.dc_mask) >> blk) & 1u;       // table = sel * 2 + isac
             const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)(sel ? e23 : e01), (int)off);
             const uint32_t e = isac ? pair >> 16 : pair & 0xffffu;
-            const uint32_t len = e >> 8, size = e & 15u, run = (e >> 4) & 15u;
-            const uint32_t knext = isac ? (size ? k + run + 1u : (run == 15u ? k + 16u : 64u)) : 1u;
-            off += len + size;
+            const uint32_t knext = k + (e >> 8);
+            off += e & 63u;
             const bool done = knext >= 64u;
             k = done ? 0u : knext;
             blk = done ? (blk + 1u == c.bpm ? 0u : blk + 1u) : blk;
@@ -415,6 +488,8 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
     if (PHASE == 2 && lw == 0) return;                                  // its entry state was exact in phase 1
     JpegWgCtx c;
     jpeg_wg_setup(a, D, lw, S, c);
+    __syncthreads();
+    jpeg_sync_tables(S.H);                                              // LUT -> transition entries (state only)
     const uint32_t nsub_img = (nbits + JPEG_SUB_BITS - 1) / JPEG_SUB_BITS;
     const uint32_t last = min((uint32_t)JPEG_WG - 1u, nsub_img - 1u - sub0);   // last subsequence with bits
     const uint32_t t = sub0 + threadIdx.x;
@@ -426,7 +501,7 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
     if (PHASE == 1) {
         JpegState s{lo, 0u, 0u};
         uint32_t nb = 0;
-        if (active) nb = jpeg_decode_span<false>(c, s, hi, nullptr, 0, 0);
+        if (active) nb = jpeg_sync_span(c, s, hi);
         S.E[threadIdx.x] = jpeg_pack(s);
         S.nb[threadIdx.x] = nb;
         S.flag[0][threadIdx.x] = 1;
@@ -473,7 +548,7 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
         if (m > JPEG_WAVE_MAX) {
             if (redo) {
                 JpegState st = jpeg_unpack(start);
-                const uint32_t nb = jpeg_decode_span<false>(c, st, hi, nullptr, 0, 0);
+                const uint32_t nb = jpeg_sync_span(c, st, hi);
                 const uint64_t e = jpeg_pack(st);
                 S.flag[cur ^ 1][threadIdx.x] = (uint8_t)(e != S.E[threadIdx.x]);
                 S.E[threadIdx.x] = e;
