@@ -1,10 +1,10 @@
 #!/bin/bash
 # Everything under profiles/<tag>_* that comes from bench.py, in one gpurun call (from the repo root, on the GPU box):
 #   gpurun --timeout 3000 -- 'tools/refresh_profiles.sh r03'
-# then, in the build container:  for n in headline site1e6 random1e6 stress raw35 scenes73 sites3x12; do python tools/collect_profiles.py r04 $n; done
+# then, in the build container:  for n in headline site1e6 random1e6 stress raw35 scenes73 sites3x12; do python tools/collect_profiles.py r05 $n; done
 # and copy gpurun_out/<tag>_*_bench.json of the plain lines into profiles/.
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 ulimit -c 0
 tools/profile_workload.sh $tag headline "N=10000" --steps 20 --warmup 5 > /dev/null
 tools/profile_workload.sh $tag site1e6 "N=1000000 MAP=site" --map site --verts 1000000 --steps 30 --warmup 5 > /dev/null
@@ -20,3 +20,9 @@ plain 960x540 --height 540 --width 960 --steps 60 --warmup 5
 plain n1e5 --verts 100000 --steps 30 --warmup 5
 plain dense1e6 --verts 1000000 --steps 20 --warmup 3
 plain site4e6 --map site --verts 4000000 --steps 20 --warmup 3
+# N > 1 code path end to end on this one GPU (eight ranks share it, gloo for the one collective): functional, not a measurement
+CAMA_BENCH_SHARE_GPU=1 timeout 1500 python bench.py --gpus 8 --steps 2 --warmup 1 > gpurun_out/${tag}_8ranks_on_one_gpu_bench.json 2> gpurun_out/${tag}_8ranks_on_one_gpu_bench.err; tail -c 300 gpurun_out/${tag}_8ranks_on_one_gpu_bench.json; echo
+# the reference's real workload: a fresh ClipManager per scene, both passes once (tools/cold_sweep.py)
+timeout 600 python tools/cold_sweep.py --scenes 12 --frames 40 --label final --json gpurun_out/${tag}_cold_final.json > gpurun_out/${tag}_cold_final.txt 2>&1
+CAMA_FRAME_CACHE_BYTES=0 timeout 600 python tools/cold_sweep.py --scenes 12 --frames 40 --label final_nocache --json gpurun_out/${tag}_cold_final_nocache.json > gpurun_out/${tag}_cold_final_nocache.txt 2>&1
+grep -h "^{" gpurun_out/${tag}_cold_final.txt gpurun_out/${tag}_cold_final_nocache.txt | cut -c1-400
