@@ -849,7 +849,7 @@ def plan(args):
         # of which the kept ones are already counted above)
         n_buf = len(mine) if (ranges[r] is None and batched) else (-(-F // fpl) if ranges[r] is not None and F * frame_b > (8 << 30) else 1)
         K_aud = 16 if args.audition is None else args.audition
-        # one mosaic: K candidates (x up to 3 rounds when they all run alike, capped at half of what is free) and then K/2
+        # one mosaic: K candidates (x up to 4 rounds until a fast one is seen, capped at half of what is free) and then K/2
         # candidates of the (F + 1)-frame source; several mosaics: ONE pool of max(K/4, 2) per buffer, the kept ones counted above
         cands = (K_aud + K_aud // 2) if n_buf == 1 else max(K_aud // 4, 2) * n_buf - n_buf
         rec["placement_transient_bytes"] = 0 if (args.audition == 0 or args.raw_frames) else cands * one

@@ -201,7 +201,13 @@ struct JpegWgCtx {
                                // JPEG_WORDS_GLOBAL, the image's unstuffed segment in global memory, little-endian dwords)
     uint32_t word0;            // image-relative index of words[0] (0 with JPEG_WORDS_GLOBAL)
     uint32_t nwords;           // JPEG_WORDS_GLOBAL: readable dwords of the segment (zero beyond)
-    const JpegHuffSet *H;      // LDS
+    const JpegHuffSet *H;      // LDS (k_jpeg_write)
+    // k_jpeg_sync only (JpegSyncShared): transition tables instead of H
+    const uint16_t *sync_dc;   // [2][1024]: used | kinc << 6
+    const uint32_t *sync_ac;   // [2][1024]: used1 | kinc1 << 6 | used12 << 13 | kinc12 << 19 (0: code longer than 10 bits)
+    const uint32_t (*lim)[8];
+    const int32_t (*valoff)[17];
+    const uint8_t (*vals)[256];
     uint32_t dc_mask, ac_mask; // bit b: Huffman table selector (0/1) of block b of the MCU
     uint32_t bpm;
     const uint8_t *zigzag;     // LDS copy of the zigzag -> natural order table
@@ -218,14 +224,19 @@ __device__ __forceinline__ uint32_t jpeg_word(const JpegWgCtx &c, uint32_t w)
 
 // codes longer than 10 bits: canonical codes grow with their length, so the length is 11 + the number of per-length
 // limits (left-aligned to 16 bits, monotone) that the 16-bit prefix has reached -- no dependent loop
-__device__ __forceinline__ uint32_t jpeg_symbol_long(const JpegHuffSet &H, uint32_t tab, uint32_t window)
+__device__ __forceinline__ uint32_t jpeg_symbol_long_t(const uint32_t (*lim)[8], const int32_t (*valoff)[17],
+                                                       const uint8_t (*vals)[256], uint32_t tab, uint32_t window)
 {
     const uint32_t w16 = window >> 16;
-    const uint4 lim0 = *reinterpret_cast<const uint4 *>(&H.lim[tab][0]);
-    const uint2 lim1 = *reinterpret_cast<const uint2 *>(&H.lim[tab][4]);
+    const uint4 lim0 = *reinterpret_cast<const uint4 *>(&lim[tab][0]);
+    const uint2 lim1 = *reinterpret_cast<const uint2 *>(&lim[tab][4]);
     const uint32_t l = 11u + (w16 >= lim0.x) + (w16 >= lim0.y) + (w16 >= lim0.z) + (w16 >= lim0.w) + (w16 >= lim1.x);
     if (w16 >= lim1.y) return 16u << 8;        // no such code (only on speculative paths): skip 16 bits, symbol 0
-    return (l << 8) | H.vals[tab][((w16 >> (16u - l)) + (uint32_t)H.valoff[tab][l]) & 255u];
+    return (l << 8) | vals[tab][((w16 >> (16u - l)) + (uint32_t)valoff[tab][l]) & 255u];
+}
+__device__ __forceinline__ uint32_t jpeg_symbol_long(const JpegHuffSet &H, uint32_t tab, uint32_t window)
+{
+    return jpeg_symbol_long_t(H.lim, H.valoff, H.vals, tab, window);
 }
 
 __constant__ uint8_t c_jpeg_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
@@ -299,30 +310,53 @@ __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegSta
 
 // ---- the synchronisation phases' own decoder (round 5) --------------------------------------------------------------
 // k_jpeg_sync<1|2> never need a coefficient's VALUE: only how many bits a symbol takes and where it leaves the zigzag index.
-// Their workgroups therefore rewrite the LUT copy in LDS into TRANSITION entries (jpeg_sync_entry):
-//     bits 0..5  used = code length + magnitude bits          bits 8..14  kinc: the zigzag index after the symbol is k + kinc
-//                                                                          (DC: 1; AC with a value: run + 1; ZRL: 16; EOB: 64)
-// -- the same state transitions as jpeg_decode_span (T.81 F.2.2), with "k + kinc >= 64" as the one end-of-block test.  The
-// loop is ~30 instructions per symbol with two rare branches (codes longer than 10 bits, the window refill) where
-// jpeg_decode_span<false> compiled to ~58 with five divergent regions; the phases are latency-bound chains of exactly this
-// loop (profiles/r04_demo_loop_timeline.txt: 62.7 of a 79 ms decode pass).
+// Their workgroups therefore build TRANSITION tables in LDS instead of copying the symbol LUT (jpeg_sync_tables):
+//     used = code length + magnitude bits (6 bits)       kinc: the zigzag index after the symbol is k + kinc (7 bits;
+//                                                               DC: 1; AC with a value: run + 1; ZRL: 16; EOB: 64)
+// -- the same state transitions as jpeg_decode_span (T.81 F.2.2), with "k + kinc >= 64" as the one end-of-block test: ~30
+// instructions per symbol with two rare branches where jpeg_decode_span<false> compiled to ~58 with five divergent regions.
+// The chain is latency-bound, though (one dependent LDS lookup per symbol at 3 waves per SIMD: the leaner loop alone gave
+// +5 %), so an AC entry also carries the symbol AFTER it when that one's code lies inside the 10 known bits too:
+//     used1 | kinc1 << 6 | used12 << 13 | kinc12 << 19          (used12 = used1, kinc12 = kinc1: no second symbol)
+// and one lookup advances two symbols whenever the first does not end the block and the second still starts inside the
+// subsequence -- exactly what two single steps would have done (same table: the block, hence the selector, is unchanged;
+// same code: its bits are all known).  The phases are 62.7 of a 79 ms decode pass (profiles/r04_demo_loop_timeline.txt).
 __device__ __forceinline__ uint32_t jpeg_sync_entry(uint32_t tab, uint32_t e)       // e = (length << 8) | symbol, != 0
 {
     const uint32_t len = e >> 8, size = e & 15u, run = (e >> 4) & 15u;
     const uint32_t kinc = (tab & 1u) ? (size ? run + 1u : (run == 15u ? 16u : 64u)) : 1u;
-    return (len + size) | (kinc << 8);
+    return (len + size) | (kinc << 6);
 }
 
-__device__ __forceinline__ void jpeg_sync_tables(JpegHuffSet &H)                     // in place, whole workgroup; barrier after
+// the workgroup's transition tables from the image's table set in global memory; barrier after
+__device__ __forceinline__ void jpeg_sync_tables(const JpegHuffSet &G, uint16_t (*dc)[1 << JPEG_LUT_BITS],
+                                                 uint32_t (*ac)[1 << JPEG_LUT_BITS])
 {
-    uint16_t *lut = &H.lut[0][0];
-    for (uint32_t i = threadIdx.x; i < 4u << JPEG_LUT_BITS; i += JPEG_WG) {
-        const uint32_t e = lut[i];
-        if (e) lut[i] = (uint16_t)jpeg_sync_entry(i >> JPEG_LUT_BITS, e);
+    constexpr uint32_t NLUT = 1u << JPEG_LUT_BITS;
+    for (uint32_t i = threadIdx.x; i < 2u * NLUT; i += JPEG_WG) {
+        const uint32_t t = i >> JPEG_LUT_BITS, x = i & (NLUT - 1u);
+        const uint32_t e = G.lut[2u * t][x];
+        dc[t][x] = e ? (uint16_t)jpeg_sync_entry(0u, e) : (uint16_t)0u;
+        const uint32_t e1 = G.lut[2u * t + 1u][x];
+        uint32_t out = 0u;
+        if (e1) {
+            const uint32_t s1 = jpeg_sync_entry(1u, e1), u1 = s1 & 63u, k1 = s1 >> 6;
+            uint32_t s12 = s1;
+            if (k1 != 64u && u1 < (uint32_t)JPEG_LUT_BITS) {
+                const uint32_t e2 = G.lut[2u * t + 1u][(x << u1) & (NLUT - 1u)];      // the bits behind symbol 1, zero-padded
+                if (e2 && (e2 >> 8) <= (uint32_t)JPEG_LUT_BITS - u1) {                 // its code lies inside the known bits
+                    const uint32_t s2 = jpeg_sync_entry(1u, e2);
+                    const uint32_t u12 = u1 + (s2 & 63u), k12 = k1 + (s2 >> 6);
+                    if (u12 <= 31u) s12 = u12 | (k12 << 6);                          // (the bit window advances <= 31 bits a step)
+                }
+            }
+            out = s1 | (s12 << 13);
+        }
+        ac[t][x] = out;
     }
 }
 
-// every symbol that STARTS in [s.pos, end), state only; H's LUT holds transition entries (jpeg_sync_tables)
+// every symbol that STARTS in [s.pos, end), state only; c.sync_dc / c.sync_ac hold the transition tables
 __device__ __forceinline__ uint32_t jpeg_sync_span(const JpegWgCtx &c, JpegState &s, uint32_t end)
 {
     if (s.pos >= end) return 0;
@@ -337,16 +371,31 @@ __device__ __forceinline__ uint32_t jpeg_sync_span(const JpegWgCtx &c, JpegState
         cnt = 32 - (int32_t)sh;
         w += 2;
     }
-    const uint16_t *lut = &c.H->lut[0][0];
     const uint32_t bpm = c.bpm;
     while (pos < end) {
-        const uint32_t isac = k ? 1u : 0u;
-        const uint32_t tab = (((isac ? c.ac_mask : c.dc_mask) >> blk) & 1u) * 2u + isac;
-        uint32_t e = lut[(tab << JPEG_LUT_BITS) + (hi >> (32 - JPEG_LUT_BITS))];
+        const uint32_t peek = hi >> (32 - JPEG_LUT_BITS);
         const uint32_t next = jpeg_word(c, w);                      // refill word (used when lo runs dry)
-        if (e == 0u) e = jpeg_sync_entry(tab, jpeg_symbol_long(*c.H, tab, hi));
-        const uint32_t used = e & 63u;                              // 1..31
-        k += e >> 8;
+        uint32_t used, kinc;
+        if (k == 0u) {                                              // DC symbol
+            const uint32_t sel = (c.dc_mask >> blk) & 1u;
+            uint32_t e = c.sync_dc[(sel << JPEG_LUT_BITS) + peek];
+            if (e == 0u) e = jpeg_sync_entry(0u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 2u * sel, hi));
+            used = e & 63u;
+            kinc = e >> 6;
+        } else {
+            const uint32_t sel = (c.ac_mask >> blk) & 1u;
+            uint32_t e = c.sync_ac[(sel << JPEG_LUT_BITS) + peek];
+            if (e == 0u) {
+                e = jpeg_sync_entry(1u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 2u * sel + 1u, hi));
+                e |= e << 13;
+            }
+            const uint32_t u1 = e & 63u, k1 = (e >> 6) & 127u;
+            // both symbols, unless the first ends the block (the next is then a DC symbol) or the second starts past `end`
+            const bool both = (k + k1 < 64u) && (pos + u1 < end);
+            used = both ? (e >> 13) & 63u : u1;
+            kinc = both ? e >> 19 : k1;
+        }
+        k += kinc;
         pos += used;
         hi = __builtin_amdgcn_alignbit(hi, lo, 32u - used);
         lo <<= used;
@@ -380,21 +429,19 @@ __device__ __forceinline__ uint32_t jpeg_decode_span_wave(const JpegWgCtx &c, Jp
 {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t pos = s.pos, blk = s.blk, k = s.k, nb = 0;            // wave-uniform
-    const uint16_t *lut = &c.H->lut[0][0];
     while (pos < end) {
         const uint32_t bp = pos + lane;
         const uint32_t w = (bp >> 5) - c.word0, sh = bp & 31u;
         const uint32_t hi = jpeg_word(c, w), lo = jpeg_word(c, w + 1);
         const uint32_t win = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
-        uint32_t e0 = lut[(0u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
-        uint32_t e1 = lut[(1u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
-        uint32_t e2 = lut[(2u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
-        uint32_t e3 = lut[(3u << JPEG_LUT_BITS) + (win >> (32 - JPEG_LUT_BITS))];
-        // (the LUT holds transition entries: jpeg_sync_tables)
-        if (e0 == 0u) e0 = jpeg_sync_entry(0u, jpeg_symbol_long(*c.H, 0u, win));
-        if (e1 == 0u) e1 = jpeg_sync_entry(1u, jpeg_symbol_long(*c.H, 1u, win));
-        if (e2 == 0u) e2 = jpeg_sync_entry(2u, jpeg_symbol_long(*c.H, 2u, win));
-        if (e3 == 0u) e3 = jpeg_sync_entry(3u, jpeg_symbol_long(*c.H, 3u, win));
+        // single-symbol transition entries (used | kinc << 6) under all four tables: 0 = DC0, 1 = AC0, 2 = DC1, 3 = AC1
+        const uint32_t peek = win >> (32 - JPEG_LUT_BITS);
+        uint32_t e0 = c.sync_dc[peek], e2 = c.sync_dc[(1u << JPEG_LUT_BITS) + peek];
+        uint32_t e1 = c.sync_ac[peek] & 0x1fffu, e3 = c.sync_ac[(1u << JPEG_LUT_BITS) + peek] & 0x1fffu;
+        if (e0 == 0u) e0 = jpeg_sync_entry(0u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 0u, win));
+        if (e1 == 0u) e1 = jpeg_sync_entry(1u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 1u, win));
+        if (e2 == 0u) e2 = jpeg_sync_entry(0u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 2u, win));
+        if (e3 == 0u) e3 = jpeg_sync_entry(1u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 3u, win));
         const uint32_t e01 = e0 | (e1 << 16), e23 = e2 | (e3 << 16);
         uint32_t off = 0;
         while (off < 64u && pos + off < end) {
@@ -402,7 +449,7 @@ __device__ __forceinline__ uint32_t jpeg_decode_span_wave(const JpegWgCtx &c, Jp
             const uint32_t sel = ((isac ? c.ac_mask : c.dc_mask) >> blk) & 1u;       // table = sel * 2 + isac
             const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)(sel ? e23 : e01), (int)off);
             const uint32_t e = isac ? pair >> 16 : pair & 0xffffu;
-            const uint32_t knext = k + (e >> 8);
+            const uint32_t knext = k + (e >> 6);
             off += e & 63u;
             const bool done = knext >= 64u;
             k = done ? 0u : knext;
@@ -429,19 +476,17 @@ struct JpegWgShared {
     uint8_t zigzag[64];
 };
 
-__device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg_image &D, uint32_t lw, JpegWgShared &S,
-                                              JpegWgCtx &c)
+// the workgroup's share of the unstuffed stream into LDS + the per-image decoder constants
+__device__ __forceinline__ void jpeg_wg_stream(const JpegArgs &a, const cama_jpeg_image &D, uint32_t lw, uint32_t *words,
+                                               JpegWgCtx &c)
 {
-    // tables
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.huff + D.huff_set);
-    uint4 *dst = reinterpret_cast<uint4 *>(&S.H);
-    for (uint32_t i = threadIdx.x; i < sizeof(JpegHuffSet) / 16; i += JPEG_WG) dst[i] = src[i];
     // stream: dwords [lw*256*32, +256*32 + 2) of the unstuffed segment (clean_off is 16-byte aligned; the region
     // past the segment is zero: the clean buffer is cleared per batch)
     const uint32_t *g = reinterpret_cast<const uint32_t *>(a.clean + D.clean_off);
     const uint32_t nwords_img = (D.stream_len + 3u) / 4u + 8u;          // slack words exist (plan pads every segment)
 #ifdef JPEG_WORDS_GLOBAL
     (void)lw;
+    (void)words;
     c.words = g;
     c.word0 = 0;
     c.nwords = nwords_img;
@@ -449,15 +494,12 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
     const uint32_t w0 = lw * JPEG_WG * JPEG_SUB_WORDS;
     for (uint32_t i = threadIdx.x; i < JPEG_WG * JPEG_SUB_WORDS + 8; i += JPEG_WG) {
         const uint32_t w = w0 + i;
-        S.words[i + (i >> JPEG_SUB_SHIFT)] = w < nwords_img ? __builtin_bswap32(g[w]) : 0u;
+        words[i + (i >> JPEG_SUB_SHIFT)] = w < nwords_img ? __builtin_bswap32(g[w]) : 0u;
     }
-    c.words = S.words;
+    c.words = words;
     c.word0 = w0;
     c.nwords = 0;
 #endif
-    if (threadIdx.x < 64) S.zigzag[threadIdx.x] = c_jpeg_zigzag[threadIdx.x];
-    c.zigzag = S.zigzag;
-    c.H = &S.H;
     c.bpm = D.bpm;
     uint32_t b = 0;
     c.dc_mask = c.ac_mask = 0;
@@ -471,11 +513,67 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
     }
 }
 
+__device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg_image &D, uint32_t lw, JpegWgShared &S,
+                                              JpegWgCtx &c)
+{
+    // tables
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.huff + D.huff_set);
+    uint4 *dst = reinterpret_cast<uint4 *>(&S.H);
+    for (uint32_t i = threadIdx.x; i < sizeof(JpegHuffSet) / 16; i += JPEG_WG) dst[i] = src[i];
+#ifndef JPEG_WORDS_GLOBAL
+    jpeg_wg_stream(a, D, lw, S.words, c);
+#else
+    jpeg_wg_stream(a, D, lw, nullptr, c);
+#endif
+    if (threadIdx.x < 64) S.zigzag[threadIdx.x] = c_jpeg_zigzag[threadIdx.x];
+    c.zigzag = S.zigzag;
+    c.H = &S.H;
+    c.sync_dc = nullptr; c.sync_ac = nullptr; c.lim = nullptr; c.valoff = nullptr; c.vals = nullptr;
+}
+
+// k_jpeg_sync's LDS: transition tables (jpeg_sync_tables) instead of the symbol LUT -- 51.2 KB, three workgroups per CU
+struct JpegSyncShared {
+    uint16_t dc[2][1 << JPEG_LUT_BITS];
+    uint32_t ac[2][1 << JPEG_LUT_BITS];
+    uint32_t lim[4][8];
+    int32_t valoff[4][17];
+    uint8_t vals[4][256];
+#ifndef JPEG_WORDS_GLOBAL
+    uint32_t words[JPEG_WG * JPEG_SUB_WORDS + JPEG_WG + 40];   // one pad word per subsequence: lane stride odd
+#endif
+    uint64_t E[JPEG_WG];
+    uint32_t nb[JPEG_WG];
+    uint8_t flag[2][JPEG_WG];
+};
+static_assert(sizeof(JpegSyncShared) <= 52 * 1024, "three k_jpeg_sync workgroups per CU");
+
+__device__ __forceinline__ void jpeg_sync_setup(const JpegArgs &a, const cama_jpeg_image &D, uint32_t lw, JpegSyncShared &S,
+                                                JpegWgCtx &c)
+{
+    const JpegHuffSet &G = a.huff[D.huff_set];
+    jpeg_sync_tables(G, S.dc, S.ac);
+    for (uint32_t i = threadIdx.x; i < 4u * 8u; i += JPEG_WG) S.lim[i >> 3][i & 7u] = G.lim[i >> 3][i & 7u];
+    for (uint32_t i = threadIdx.x; i < 4u * 17u; i += JPEG_WG) S.valoff[i / 17u][i % 17u] = G.valoff[i / 17u][i % 17u];
+    for (uint32_t i = threadIdx.x; i < 4u * 256u; i += JPEG_WG) S.vals[i >> 8][i & 255u] = G.vals[i >> 8][i & 255u];
+#ifndef JPEG_WORDS_GLOBAL
+    jpeg_wg_stream(a, D, lw, S.words, c);
+#else
+    jpeg_wg_stream(a, D, lw, nullptr, c);
+#endif
+    c.H = nullptr;
+    c.zigzag = nullptr;
+    c.sync_dc = &S.dc[0][0];
+    c.sync_ac = &S.ac[0][0];
+    c.lim = S.lim;
+    c.valoff = S.valoff;
+    c.vals = S.vals;
+}
+
 // PHASE 1: speculative decode + fixpoint inside the workgroup.  PHASE 2: fixpoint seeded with the true entry state.
 template <int PHASE>
 __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
 {
-    __shared__ JpegWgShared S;
+    __shared__ JpegSyncShared S;
     const int img = jpeg_find_image(a.imgs, a.n, blockIdx.x, false);
     const cama_jpeg_image &D = a.imgs[img];
     const uint32_t lw = blockIdx.x - D.wg0;
@@ -487,9 +585,7 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
     }
     if (PHASE == 2 && lw == 0) return;                                  // its entry state was exact in phase 1
     JpegWgCtx c;
-    jpeg_wg_setup(a, D, lw, S, c);
-    __syncthreads();
-    jpeg_sync_tables(S.H);                                              // LUT -> transition entries (state only)
+    jpeg_sync_setup(a, D, lw, S, c);                                    // transition tables (state only) + stream words
     const uint32_t nsub_img = (nbits + JPEG_SUB_BITS - 1) / JPEG_SUB_BITS;
     const uint32_t last = min((uint32_t)JPEG_WG - 1u, nsub_img - 1u - sub0);   // last subsequence with bits
     const uint32_t t = sub0 + threadIdx.x;

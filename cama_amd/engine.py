@@ -359,10 +359,14 @@ class MosaicPool:
             free, _ = _torch().cuda.mem_get_info(eng.device)
             K = max(1, min(K, int(free // 2 // nbytes)))
             cands, times = [], []
-            for rnd in range(3):
-                # further rounds when all candidates so far ran alike (within 3 %): the two levels are 6-10 % apart, so a
-                # sample like that is all of one kind -- and if it is the slow kind, fresh memory may hold the other
-                if rnd and (len(cands) + K > int(free // 2 // nbytes) or max(times) > 1.03 * min(times)):
+            # The fast kind runs the stamp-free overlay at >= 0.82 of 8 TB/s, the slow kind at <= 0.78 (2 x nbytes moved per
+            # launch).  Rounds of K candidates until one of the fast kind has been seen -- 16 candidates that are all of the slow
+            # kind happen (r05 profile box: 0.3298 .. 0.3434 ms, nothing below 0.78), neighbouring allocations are correlated --
+            # or CAMA_AUDITION_ROUNDS (4) rounds / half of the free memory are used up.
+            good_ms = 2.0 * nbytes / (0.805 * 8.0e12) * 1e3
+            rounds = max(1, int(os.environ.get("CAMA_AUDITION_ROUNDS", "4")))
+            for rnd in range(rounds):
+                if rnd and (len(cands) + K > int(free // 2 // nbytes) or min(times) <= good_ms):
                     break
                 for _ in range(K):
                     try:

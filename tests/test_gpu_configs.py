@@ -471,14 +471,14 @@ def test_placed_buffers_render_the_same_bytes(monkeypatch):
     assert eng.lib.cama_overlay_probe(frames[1:].data_ptr(), probe_out.data_ptr(), 1, rig.C, rig.H, 1592, 3, 1,
                                       ctypes.byref(ms), eng._stream()) != 0
     del probe_out, want_copy
-    # first clip: the pool auditions 4 (.. 12) candidates for this source, the frames are placed against the winner
+    # first clip: the pool auditions 4 (.. 16) candidates for this source, the frames are placed against the winner
     n_log = len(getattr(eng, "audition_log", []))
     _, out = cm.render_clip("cama")
     torch.cuda.synchronize()
     logs = eng.audition_log[n_log:]
     mos = [e for e in logs if e["role"] == "mosaic"]
     frs = [e for e in logs if e["role"] == "frames"]
-    assert len(mos) == 1 and mos[0]["candidates"] in (4, 8, 12) and len(mos[0]["ms"]) == mos[0]["candidates"]
+    assert len(mos) == 1 and mos[0]["candidates"] in (4, 8, 12, 16) and len(mos[0]["ms"]) == mos[0]["candidates"]     # (rounds of 4 until a fast one)
     assert mos[0]["chosen_ms"] == min(mos[0]["ms"]) and mos[0]["source"] == "engine pool"
     assert len(frs) == 1 and len(frs[0]["ms"]) == 3                        # the caller's tensor + 2 candidates (CAMA_AUDITION // 2)
     assert torch.equal(cm.frame_source().frames, frames)                   # moved or not: the same bytes
