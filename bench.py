@@ -851,7 +851,7 @@ def plan(args):
         K_aud = 16 if args.audition is None else args.audition
         # one mosaic: K candidates (x up to 4 rounds until a fast one is seen, capped at half of what is free) and then K/2
         # candidates of the (F + 1)-frame source; several mosaics: ONE pool of max(K/4, 2) per buffer, the kept ones counted above
-        cands = (K_aud + K_aud // 2) if n_buf == 1 else max(K_aud // 4, 2) * n_buf - n_buf
+        cands = (4 * K_aud + K_aud // 2) if n_buf == 1 else max(K_aud // 4, 2) * n_buf - n_buf
         rec["placement_transient_bytes"] = 0 if (args.audition == 0 or args.raw_frames) else cands * one
         # while the engine auditions (Job.allocate, at most 4 ranks of the node at a time): the resident frames and maps + the
         # candidates; the engine itself never takes more than half (one mosaic) / three quarters (a pool) of what is free
