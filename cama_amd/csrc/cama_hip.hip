@@ -321,6 +321,7 @@ Option g_options[] = {
     {"overlay_tune", "CAMA_OVERLAY_TUNE", 1, {0}, {false}},                // 0 = big launches keep the contiguous order
     {"cull_list_min", "CAMA_CULL_LIST_MIN", 16384, {0}, {false}},          // (block, frame) items from which a site-sized
                                                                             // map's cull goes through work lists
+    {"bin_priority", "CAMA_BIN_PRIORITY", 2, {0}, {false}},                // priority of a new cama_pipeline's binning stream: 2 high, 1 normal, 0 low
     {"pipeline_depth", "CAMA_PIPELINE_DEPTH", 3, {0}, {false}},            // scratch slots of a cama_pipeline created from now on (2 | 3)
     {"pipeline_host_wait", "CAMA_PIPELINE_HOST_WAIT", -1, {0}, {false}},   // 1: cama_pipeline_* wait for a launch's binning on the
                                                                             // HOST before queueing its overlay (no barrier packet
@@ -328,7 +329,7 @@ Option g_options[] = {
                                                                             // 0: stream-side wait; -1: host wait for launches that
                                                                             // move >= 1 GiB (the host has the time to spare; at 960x540 it has not)
 };
-enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_CULL_LIST_MIN, OPT_PIPELINE_DEPTH, OPT_HOST_WAIT, OPT_COUNT };
+enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_CULL_LIST_MIN, OPT_BIN_PRIORITY, OPT_PIPELINE_DEPTH, OPT_HOST_WAIT, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
 int64_t option(int k)
 {
@@ -1596,7 +1597,8 @@ int cama_pipeline_create(cama_pipeline **out)
     // (960x540, two slots: whole step 0.655 -> 0.680 of 8 TB/s; 10^5 vertices 0.72 -> 0.74; headline unchanged).
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least urgent (numerically greatest)
-    hipError_t e = hipStreamCreateWithPriority(&p->s_bin, hipStreamNonBlocking, hi);
+    const int64_t prio = option(OPT_BIN_PRIORITY);           // 2 = highest (default), 1 = the overlay's, 0 = lowest
+    hipError_t e = hipStreamCreateWithPriority(&p->s_bin, hipStreamNonBlocking, prio >= 2 ? hi : prio == 1 ? (lo + hi) / 2 : lo);
     // (a CU-masked overlay stream that leaves 8 / 16 / 32 compute units to the chain was tried and is gone: masked queues
     // dispatch far slower -- whole step 0.72 -> 0.44 at 960x540, profiles/r05_960x540_timeline.txt)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_ov, hipStreamNonBlocking);

@@ -57,6 +57,8 @@ int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per
  *   overlay_tune          CAMA_OVERLAY_TUNE        0 = big launches keep the contiguous order (no self-timing)
  *   cull_list_min         CAMA_CULL_LIST_MIN       (vertex block, frame) items from which the cull of a site-sized map goes
  *                                                  through work lists + persistent workgroups (default 16384)
+ *   bin_priority          CAMA_BIN_PRIORITY        priority of the binning stream of a cama_pipeline created from now on: 2 = highest
+ *                                                  (default: its small kernels get wave slots beside the overlay), 1 = the overlay's, 0 = lowest
  *   pipeline_depth        CAMA_PIPELINE_DEPTH      scratch slots of a cama_pipeline created from now on: 3 (default: the binning chain of
  *                                                  launch k+2 hides under the overlays of launches k and k+1) or 2
  *   pipeline_host_wait    CAMA_PIPELINE_HOST_WAIT  1 = cama_pipeline_render* waits on the HOST for a launch's binning before it

@@ -83,7 +83,7 @@ L.cama_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(i64)]
 L.cama_overlay_mapping_info.argtypes = [ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double)]
 assert L.cama_set_option(b"no_such_option", 1) == -1 and b"unknown option" in L.cama_last_error()
 assert L.cama_set_option(None, 1) == -1
-names = [b"overlay_chunk_log2", b"overlay_tune", b"cull_list_min", b"pipeline_depth", b"pipeline_host_wait"]
+names = [b"overlay_chunk_log2", b"overlay_tune", b"cull_list_min", b"bin_priority", b"pipeline_depth", b"pipeline_host_wait"]
 errors = []
 def hammer(seed):
     try:
