@@ -500,21 +500,23 @@ class Job:
         step = self.step
         if os.environ.get("CAMA_BENCH_FAULT") == "skip_overlay":       # fault injection (tests): the timed steps render nothing
             step = lambda: None
-        trace = [] if os.environ.get("CAMA_BENCH_STEP_TRACE") == "1" else None     # diagnostic: host time of every step's issue
+        verbose = os.environ.get("CAMA_BENCH_STEP_TRACE") == "1"                   # diagnostic: host time of every step's issue
+        trace = []
         sync_all()
         t0 = time.perf_counter()
         for k in range(steps):
             if prof_every > 0:                                          # live hipEvent timing of every n-th overlay
                 L.cama_profile_enable(1 if k % prof_every == 0 else 0)
             step()
-            if trace is not None:
-                trace.append(time.perf_counter())
+            trace.append(time.perf_counter())                           # (~0.1 us: how long the HOST took to issue the step)
         self.eng.join()
-        if trace is not None:
-            trace.append(time.perf_counter())
+        trace.append(time.perf_counter())
         sync_all()
         dt = time.perf_counter() - t0
-        if trace is not None:
+        issue = np.diff(np.asarray([t0] + trace[:-1])) * 1e6 if steps else np.zeros(0)
+        self.host_issue_us = {"mean": float(issue.mean()) if issue.size else 0.0, "max": float(issue.max()) if issue.size else 0.0,
+                              "median": float(np.median(issue)) if issue.size else 0.0}
+        if verbose:
             ts = [t0] + trace + [t0 + dt]
             print("step trace (us): issue of each step, join, final sync: " +
                   " ".join("%.0f" % ((b - a) * 1e6) for a, b in zip(ts, ts[1:])), file=sys.stderr, flush=True)
@@ -593,7 +595,7 @@ class Job:
         env = os.environ.get("CAMA_AUDITION")
         os.environ["CAMA_AUDITION"] = "0"
         keep_out = self.out
-        keep_prof = (self.project_ms, self.project_n, self.overlay_each)
+        keep_prof = (self.project_ms, self.project_n, self.overlay_each, self.host_issue_us)
         try:
             cm.set_frame_source(DeviceFrameSource(self.orig_frames, index_offset=getattr(placed_src, "index_offset", 0)))
             self.out = torch.empty(tuple(keep_out.shape), dtype=torch.uint8, device=self.device)
@@ -602,7 +604,7 @@ class Job:
                     "overlay_ms_mean": ov_ms / max(1, ov_n), "overlay_launches_timed": ov_n}
         finally:
             self.out = keep_out
-            self.project_ms, self.project_n, self.overlay_each = keep_prof
+            self.project_ms, self.project_n, self.overlay_each, self.host_issue_us = keep_prof
             cm.set_frame_source(placed_src)
             if env is None:
                 os.environ.pop("CAMA_AUDITION", None)
@@ -614,15 +616,16 @@ class Job:
         the pose arrays being new objects, goes through ClipManager.render_clip's full path instead of the memoised launch
         list -- the round-4 step, printed beside the default one."""
         os.environ["CAMA_NO_POSE_MEMO"] = "1"
-        keep_prof = (getattr(self, "project_ms", 0.0), getattr(self, "project_n", 0), getattr(self, "overlay_each", None))
+        keep_prof = (getattr(self, "project_ms", 0.0), getattr(self, "project_n", 0), getattr(self, "overlay_each", None),
+                     getattr(self, "host_issue_us", None))
         try:
             dt, _, _ = self.run(steps, warmup, sync_all, 0)
             n = len(self.scenes)
             return {"seconds": dt, "steps": steps, "frames_per_s": self.F * steps * n / dt if dt > 0 else 0.0,
-                    "ms_per_step": dt / max(1, steps) * 1e3}
+                    "ms_per_step": dt / max(1, steps) * 1e3, "host_issue_us": self.host_issue_us}
         finally:
             del os.environ["CAMA_NO_POSE_MEMO"]
-            self.project_ms, self.project_n, self.overlay_each = keep_prof
+            self.project_ms, self.project_n, self.overlay_each, self.host_issue_us = keep_prof
 
     def projection_bytes(self):
         """Untimed: one plain render of the first scene, then cama_bin_stats -> (vertex bytes read, stamp bytes written)
@@ -1141,6 +1144,8 @@ def main():
             line["without_memo"] = dict(unmemoised, note="the same K steps with CAMA_NO_POSE_MEMO=1: seek + slerp + float32 inverse "
                                                          "recomputed and the launch arguments re-derived in Python on every step "
                                                          "(what every step did until round 4)")
+        line["host_issue_us"] = dict(job.host_issue_us, note="rank 0: wall time of one step()'s issue on the host inside the K timed "
+                                     "steps (the GPU is paced by the host whenever this approaches the step time)")
         line["rank_affinity"] = {"cpus_per_rank": [int(x) for x in m[:, 19]], "first_cpu": [int(x) for x in m[:, 20]],
                                  "last_cpu": [int(x) for x in m[:, 21]], "gpu_numa_node": [int(x) for x in m[:, 22]],
                                  "bound": [bool(x) for x in m[:, 23]],

@@ -697,6 +697,7 @@ int cama_map_bounds(const void *x, const void *y, const void *z, int32_t xyz_is_
 // separate hipEventRecord marker packet behind it: one packet less between consecutive overlays on the pipeline's
 // stream.  Set by cama_pipeline_render, consumed (and cleared) by the launch.
 thread_local hipEvent_t g_overlay_stop_event = nullptr;
+thread_local int g_overlay_leave = 1;           // workgroups per CU the next overlay launch leaves to its neighbours (overlay_impl)
 thread_local bool g_overlay_probe = false;     // the next plain overlay launch is cama_overlay_probe's: k_overlay_probe, contiguous order
 thread_local hipEvent_t g_scatter_stop_event = nullptr;
 // the pipeline's completion events ride on the launches themselves (hipExtLaunchKernelGGL stop events)
@@ -1014,11 +1015,28 @@ static int overlay_impl(const uint8_t *src, const RawSource *raw, uint8_t *mosai
     // site map of 4e6 vertices 74.0 (76.1) -> 80.3 (84.4) k, site 1e6 106.6 (110.3) -> 107.1 (111.0) k, headline 108.3 (111.7)
     // -> 109.9 (113.2) k; 73-scene sweep, 960x540, random 1e6 within noise.  It pays where the chain is long (hundreds of
     // microseconds) and costs nothing elsewhere.
+    // Round 5: "fits" has two limits -- LDS and the CU's 32 wave slots (8 workgroups of 4 waves).  At W = 960 ten workgroups
+    // fit the LDS, the rule above made it nine, and the wave slots held the overlay at eight per CU = EVERY slot: the next
+    // launch's binning chain got its waves only as overlay workgroups retired, its 10 us projection kernel ran 104-108 us
+    // and the chain (145 us per step) -- not the 118 us overlay -- set the pace (profiles/r05_960x540_timeline.txt section 6).
+    // So: fewer workgroups than what BOTH limits allow -- by `leave`, which the pipeline sets per launch from what runs beside
+    // the overlay (g_overlay_leave; same-box A/Bs of 1 / 2 / 3, whole step / 8 TB/s): a stamp-heavy overlay beside a culled
+    // chain (site maps, work lists) wants its occupancy: 0.760 / 0.746 / 0.733 -> 1; a long chain beside a light overlay
+    // (dense 10^6-lane map) wants the room: 0.468 / 0.478 / 0.492 -> 3; everything between: 10^5 vertices 0.799 / 0.821 /
+    // 0.810, headline 0.822 / 0.829, 960x540 0.728 / 0.732 / 0.739, stress 0.798 / 0.798 / 0.780 -> 2.  Launches outside a
+    // pipeline (nothing runs beside them) keep 1.
+    const size_t leave = (size_t)std::max(1, std::min(3, g_overlay_leave));
+    g_overlay_leave = 1;
     size_t lds_pad = 0;
     {
         const size_t lds0 = align_up((size_t)L.R * (W + 2 * radius) * 4, 16), cu_lds = 160 * 1024;
-        const size_t fit = cu_lds / lds0;
-        if (fit >= 4 && fit <= 16) lds_pad = align_up(cu_lds / fit + 16 - lds0, 16);   // smallest size of which fit - 1 fit a CU
+        const size_t by_lds = cu_lds / lds0, by_waves = 32 / (OVERLAY_BLOCK / 64);
+        const size_t fit = std::min(by_lds, by_waves);                        // workgroups per CU without padding
+        if (by_lds >= 4 && by_lds <= 16 && fit > leave) {
+            const size_t want = fit - leave;                                   // ... and with it
+            lds_pad = align_up(cu_lds / (want + 1) + 16, 16);                 // smallest size of which `want` + 1 do not fit
+            lds_pad = lds_pad > lds0 ? lds_pad - lds0 : 0;
+        }
     }
     // k_overlay's owner table carries `radius` spare cells on either side of every row (rasterise_one_padded: 4-bit half
     // widths of 8 rows in one register => radius <= 7 on this path; the generic cama_stamp_points has no such limit)
@@ -1895,6 +1913,8 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
         HIP_TRY(hipEventSynchronize(p->binned[slot]));
     HIP_TRY(hipStreamWaitEvent(so, p->binned[slot], 0));
     g_overlay_stop_event = (overlay_takes_stop_event && ext_events()) ? p->done[k % RING] : nullptr;
+    // how much of every CU the overlay leaves to the NEXT launch's binning chain (overlay_impl: lds_pad)
+    g_overlay_leave = (F > 0 && bin_uses_list(call)) ? 1 : (N >= 500000 ? 3 : 2);
     if (int rc = overlay(sc, (void *)so)) {
         g_overlay_stop_event = nullptr;
         return rc;
