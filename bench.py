@@ -805,7 +805,7 @@ def plan(args):
     cap = int(args.hbm_gb * 1e9)
 
     def scratch(N, F, planned_demand=None):
-        """(worst-case bytes of ONE slot, what the pipeline will hold for its slots: three, cama_amd.engine.PIPELINE_DEPTH)."""
+        """(worst-case bytes of ONE slot, what the pipeline will hold for its slots: cama_amd.engine.PIPELINE_DEPTH)."""
         worst = int(L.cama_render_scratch_bytes(int(N), int(F), C, H, W, 2))
         if planned_demand is not None:
             return worst, int(DEPTH * planned_demand * F)

@@ -322,7 +322,7 @@ Option g_options[] = {
     {"cull_list_min", "CAMA_CULL_LIST_MIN", 16384, {0}, {false}},          // (block, frame) items from which a site-sized
                                                                             // map's cull goes through work lists
     {"bin_priority", "CAMA_BIN_PRIORITY", 2, {0}, {false}},                // priority of a new cama_pipeline's binning stream: 2 high, 1 normal, 0 low
-    {"pipeline_depth", "CAMA_PIPELINE_DEPTH", 3, {0}, {false}},            // scratch slots of a cama_pipeline created from now on (2 | 3)
+    {"pipeline_depth", "CAMA_PIPELINE_DEPTH", 2, {0}, {false}},            // scratch slots of a cama_pipeline created from now on (2 | 3)
     {"pipeline_host_wait", "CAMA_PIPELINE_HOST_WAIT", -1, {0}, {false}},   // 1: cama_pipeline_* wait for a launch's binning on the
                                                                             // HOST before queueing its overlay (no barrier packet
                                                                             // between consecutive overlays; the call blocks ~0.1 ms);
@@ -1565,16 +1565,16 @@ int cama_build_static_map(const float *verts, const int32_t *seg_v0, const int32
 // be released -- the internal streams are invisible to the caller's allocator; (iii) it bounds the run-ahead: issuing
 // launch k blocks until launch k - (RING - 2) has completed.
 //
-// depth (round 5): THREE slots by default.  With two, launch k+1's binning chain runs beside overlay k and overlay k+1 needs
-// its result the moment overlay k ends -- but beside an HBM-saturating overlay the chain's projection kernel (10 us alone) takes
-// as long as the overlay itself (its loads queue behind the overlay's: profiles/r05_960x540_timeline.txt), so the scans and the
-// scatter (~30 us) landed in the gap BETWEEN two overlays: 144 us per step for a 118 us overlay at 960x540.  With three, the
-// chain of launch k+2 has overlay k AND overlay k+1 to hide under.  Costs one more slot of stamp scratch (pipeline-owned:
-// allocated on first use of the slot); CAMA_PIPELINE_DEPTH=2 restores the old behaviour.
+// depth (round 5): two slots by default, three on request (option pipeline_depth / CAMA_PIPELINE_DEPTH=3: the chain of launch
+// k+2 then has overlay k AND overlay k+1 to hide under, for one more slot of stamp scratch).  Three slots were built when a
+// 960x540 step took 144 us around a 118 us overlay and helped on some boxes (0.148 -> 0.127-0.136 ms) -- a symptom: the
+// overlay held every wave slot of every CU and the chain's 10 us projection kernel ran 105 us beside it.  Since the overlay
+// leaves wave slots free (overlay_impl: g_overlay_leave) two and three slots measure the same everywhere
+// (profiles/r05_960x540_timeline.txt section 6), so the default is the one that holds less memory.
 struct cama_pipeline {
     static constexpr int RING = 64;
     static constexpr int MAX_DEPTH = 3;
-    int depth = 3;
+    int depth = 2;
     // s_pre: the cull pre-pass of PLANNED launches (site-sized maps) and their pose upload -- the call waits for it on the
     // host, and on its own stream it runs beside the previous launch's projection / scatter instead of queueing behind them
     hipStream_t s_bin = nullptr, s_ov = nullptr, s_pre = nullptr;
@@ -1609,7 +1609,7 @@ int cama_pipeline_create(cama_pipeline **out)
     // an overlay that wrote ~1 GB, which showed up as ~20 us between consecutive overlays
     const unsigned flags = hipEventDisableTiming | hipEventReleaseToDevice;
     const int64_t depth = option(OPT_PIPELINE_DEPTH);
-    p->depth = depth == 2 ? 2 : cama_pipeline::MAX_DEPTH;
+    p->depth = depth == 3 ? 3 : 2;
     // The binning stream is the most urgent one: its kernels are small and latency-bound, the overlay beside them fills every
     // wave slot of the chip, and whatever the chain does not finish under the overlay shows up between two overlays
     // (960x540, two slots: whole step 0.655 -> 0.680 of 8 TB/s; 10^5 vertices 0.72 -> 0.74; headline unchanged).

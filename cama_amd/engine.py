@@ -18,7 +18,7 @@ RADIUS = 2                                                    # cama/reproject.p
 # maps with at least this many vertices hand their block index (per-block AABBs) to the render: below, the
 # one-thread-per-block pre-pass costs a launch for nothing.  CAMA_BOUNDS_MIN_VERTS=1 forces it (tests).
 BOUNDS_MIN_VERTS = int(os.environ.get("CAMA_BOUNDS_MIN_VERTS", "65536"))
-PIPELINE_DEPTH = 2 if os.environ.get("CAMA_PIPELINE_DEPTH") == "2" else 3      # scratch slots of a cama_pipeline (cama_hip.hip)
+PIPELINE_DEPTH = 3 if os.environ.get("CAMA_PIPELINE_DEPTH") == "3" else 2      # scratch slots of a cama_pipeline (cama_hip.hip)
 MAX_SCENES_PER_LAUNCH = 1024                                  # include/cama_hip.h CAMA_MAX_SCENES_PER_LAUNCH
 
 
@@ -1295,7 +1295,7 @@ class Engine:
     def max_frames_per_call(self, dmap, rig, budget_bytes=None, resident_frames=True, src_bytes_per_frame=None,
                             pipelined=False):
         """Largest F whose per-call memory fits `budget_bytes` (and 32-bit stamp offsets).  Per frame: the worst-case
-        stamp scratch (every vertex visible in every camera; the pipeline's three slots when pipelined) and -- unless the source frames
+        stamp scratch (every vertex visible in every camera; the pipeline's slots when pipelined) and -- unless the source frames
         and the mosaic are already resident (`resident_frames`, the bench / streaming case) -- the decoded source batch
         and its mosaic slice, which a disk-backed source allocates per call.  Default budget: a quarter of the free HBM,
         at most 64 GB -- sized for 288 GB parts, so that 4*10^6-vertex site maps still render 40 frames per launch."""

@@ -59,8 +59,8 @@ int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per
  *                                                  through work lists + persistent workgroups (default 16384)
  *   bin_priority          CAMA_BIN_PRIORITY        priority of the binning stream of a cama_pipeline created from now on: 2 = highest
  *                                                  (default: its small kernels get wave slots beside the overlay), 1 = the overlay's, 0 = lowest
- *   pipeline_depth        CAMA_PIPELINE_DEPTH      scratch slots of a cama_pipeline created from now on: 3 (default: the binning chain of
- *                                                  launch k+2 hides under the overlays of launches k and k+1) or 2
+ *   pipeline_depth        CAMA_PIPELINE_DEPTH      scratch slots of a cama_pipeline created from now on: 2 (default) or 3 (the binning
+ *                                                  chain of launch k+2 hides under the overlays of launches k and k+1)
  *   pipeline_host_wait    CAMA_PIPELINE_HOST_WAIT  1 = cama_pipeline_render* waits on the HOST for a launch's binning before it
  *                                                  queues the overlay (the call blocks ~0.1 ms; no barrier packet between
  *                                                  consecutive overlays on the GPU: +1.5 % on the headline); 0 = stream-side
