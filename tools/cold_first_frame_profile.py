@@ -32,7 +32,7 @@ def main():
             pstats.Stats(pr).sort_stats("cumulative").print_stats(20)
         cm = ClipManager(dict(DEFAULT_CAMA_CONFIGS), clip)
         vg = VideoGenerator(os.path.join(root, "x.mp4"))
-        pr = cProfile.Profile() if k >= 2 else None
+        pr = cProfile.Profile() if k != 1 else None          # clip 0: the process's one-off start-up; clips 2, 3: a warm process
         it = cm.yield_frame(dataset="cama")
         t0 = time.perf_counter()
         if pr:
