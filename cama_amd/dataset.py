@@ -487,7 +487,11 @@ class ClipManager:
             # every batch of the pass from here on is known: let the source read and decode ahead of the renders
             source.plan([[int(i) for i in ra["idx"][lo:hi]] for lo, hi in ra["bounds"][b:]])
         ra["last"] = k
-        for nb in (b, b + 1):                       # this batch now, the next one a batch early
+        # this batch now; the next one a batch early -- but not while the caller still waits for the FIRST frame of this one:
+        # issuing a batch means waiting for its frames' decode, and the first frame of a pass used to pay for the second
+        # batch's 96 JPEGs as well (profiles/r05_cold_sweep.txt: 12 ms to the first mosaic of a new clip)
+        first_of_batch = k == ra["bounds"][b][0]
+        for nb in ((b,) if (first_of_batch and b not in batches) else (b, b + 1)):
             if nb not in batches and nb < len(ra["bounds"]):
                 lo, hi = ra["bounds"][nb]
                 batches[nb] = self._render_batch(fr.dataset, [int(i) for i in ra["idx"][lo:hi]], ra["w2c"][lo:hi])

@@ -890,8 +890,30 @@ class Engine:
                 full = [camera_maps(cm) for cm in cm_list]
                 mx = np.stack([m[0].reshape(-1) for m in full])
                 my = np.stack([m[1].reshape(-1) for m in full])
+            # rational 3:5 scale (the reference default 1600x900 -> 960x540): the library verifies the tap pattern and
+            # builds the per-row vertical taps for its gather-free kernel (cama_raw35_plan)
+            vrows = None
+            if sep and not os.environ.get("CAMA_NO_RAW35"):
+                Cn, Hd, Wd = len(cm_list), int(cm_list[0].height), int(cm_list[0].width)
+                mxh = np.ascontiguousarray(mx, np.float32)
+                myh = np.ascontiguousarray(my, np.float32)
+                table = np.zeros((Cn, Hd, 2), np.uint32)
+                R35 = self.lib.cama_overlay_band_rows(Wd)
+                brows = np.zeros((Cn, (Hd + R35 - 1) // R35, 2), np.int32)
+                import ctypes
+                most = ctypes.c_int32(0)
+                rc = self.lib.cama_raw35_plan(mxh.ctypes.data, myh.ctypes.data, Cn, Hd, Wd,
+                                              int(cm_list[0].height_origin), int(cm_list[0].width_origin), table.ctypes.data,
+                                              brows.ctypes.data, ctypes.byref(most))
+                if rc < 0:
+                    _lib.check(rc)
+                if rc == 1:
+                    vrows = (torch.from_numpy(table.view(np.int32)).to(self.device), torch.from_numpy(brows).to(self.device),
+                             int(most.value))
+            # (only for maps the 3:5 kernel does not take: its plan carries its own band table -- and building these for
+            # every new calibration was 2-3 ms of a new clip's first frame)
             band_rows, max_rows, tiles, tiles_x, max_tile = None, 0, None, 0, 0
-            if sep:
+            if sep and vrows is None:
                 # source rows every band of R destination rows touches (same rounding as the kernel: 1/32 px)
                 H, H0 = int(cm_list[0].height), int(cm_list[0].height_origin)
                 R = self.lib.cama_overlay_band_rows(int(cm_list[0].width))
@@ -923,26 +945,6 @@ class Engine:
                     tb[:, :, 1] = max_tile                      # one LDS row stride for every tile (clamped below)
                     tb[:, :, 0] = np.minimum(tb[:, :, 0], W0 * 3 - max_tile)
                     tiles = torch.from_numpy(tb).to(self.device)
-            # rational 3:5 scale (the reference default 1600x900 -> 960x540): the library verifies the tap pattern and
-            # builds the per-row vertical taps for its gather-free kernel (cama_raw35_plan)
-            vrows = None
-            if sep and not os.environ.get("CAMA_NO_RAW35"):
-                Cn, Hd, Wd = len(cm_list), int(cm_list[0].height), int(cm_list[0].width)
-                mxh = np.ascontiguousarray(mx, np.float32)
-                myh = np.ascontiguousarray(my, np.float32)
-                table = np.zeros((Cn, Hd, 2), np.uint32)
-                R35 = self.lib.cama_overlay_band_rows(Wd)
-                brows = np.zeros((Cn, (Hd + R35 - 1) // R35, 2), np.int32)
-                import ctypes
-                most = ctypes.c_int32(0)
-                rc = self.lib.cama_raw35_plan(mxh.ctypes.data, myh.ctypes.data, Cn, Hd, Wd,
-                                              int(cm_list[0].height_origin), int(cm_list[0].width_origin), table.ctypes.data,
-                                              brows.ctypes.data, ctypes.byref(most))
-                if rc < 0:
-                    _lib.check(rc)
-                if rc == 1:
-                    vrows = (torch.from_numpy(table.view(np.int32)).to(self.device), torch.from_numpy(brows).to(self.device),
-                             int(most.value))
             hit = (key, torch.from_numpy(np.ascontiguousarray(mx)).to(self.device),
                    torch.from_numpy(np.ascontiguousarray(my)).to(self.device), int(sep), band_rows, max_rows,
                    tiles, tiles_x, max_tile, vrows)
