@@ -452,7 +452,7 @@ class ClipManager:
         (configs["render_ahead"], default 16; 1 = one launch per frame) the first time one of a batch is asked for, and
         the following batch is issued right away so that it runs while this one is consumed.  Same kernels, same
         arguments per frame as a one-frame launch: only the batching differs."""
-        B = max(1, int(self.configs.get("render_ahead", 16)))
+        B = max(1, int(self.configs.get("render_ahead", os.environ.get("CAMA_RENDER_AHEAD", 16))))
         # the FIRST batch of a pass is short (configs["render_ahead_first"], default 4): nothing can be handed to the caller
         # before the first batch's files are read, decoded, rendered and downloaded -- with 16 frames that is ~20 ms of a
         # 40-frame scene's pass (profiles/r05_cold_sweep.txt), with 4 a quarter of it; the pump is decoding the next ones by then
@@ -468,8 +468,13 @@ class ClipManager:
             # batches = runs of up to B CONSECUTIVE image indices: a pose gap (skipped frames) ends a batch, so sources
             # that serve contiguous frame ranges only (RawDeviceFrameSource) never see a range with a hole
             bounds, of_pos = [], np.zeros(len(idx), np.int64)
+            # batch sizes ramp up: B0, then B / 2 twice, then B -- a pass is a pipeline of decode -> render -> download stages and
+            # a nuScenes scene has ~40 frames: with 4 + 16 + 16 + 4 it never fills (cold scene 33.9 ms; with 8s 27.9 ms, same
+            # box), while long passes reach the full batch after 4 + 8 + 8 frames
+            def cap(n):                                             # size of the n-th batch of the pass (0-based)
+                return B0 if n == 0 else (max(B0, B // 2) if n <= 2 else B)
             for k in range(len(idx)):
-                if not bounds or k - bounds[-1][0] >= (B0 if len(bounds) == 1 else B) or idx[k] != idx[k - 1] + 1:
+                if not bounds or k - bounds[-1][0] >= cap(len(bounds) - 1) or idx[k] != idx[k - 1] + 1:
                     bounds.append([k, k])
                 bounds[-1][1] = k + 1
                 of_pos[k] = len(bounds) - 1
