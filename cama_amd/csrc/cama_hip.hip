@@ -697,6 +697,7 @@ int cama_map_bounds(const void *x, const void *y, const void *z, int32_t xyz_is_
 // separate hipEventRecord marker packet behind it: one packet less between consecutive overlays on the pipeline's
 // stream.  Set by cama_pipeline_render, consumed (and cleared) by the launch.
 thread_local hipEvent_t g_overlay_stop_event = nullptr;
+thread_local bool g_pipeline_raw_overlay = false;   // the pipelined launch being issued uses the raw 3:5 overlay (pipeline_impl's host-wait rule)
 thread_local int g_overlay_leave = 1;           // workgroups per CU the next overlay launch leaves to its neighbours (overlay_impl)
 thread_local bool g_overlay_probe = false;     // the next plain overlay launch is cama_overlay_probe's: k_overlay_probe, contiguous order
 thread_local hipEvent_t g_scatter_stop_event = nullptr;
@@ -1909,7 +1910,14 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
     const int64_t host_wait = option(OPT_HOST_WAIT);
     // (not for a planned launch: its call already waited for the cull on the host, and waiting for the rest of the chain as
     // well would start the NEXT launch's cull ~0.3 ms later than the GPU could -- sites3x12: 94 k -> 89 k frames/s)
-    if (host_wait > 0 || (host_wait < 0 && !prepass_done && !segments && (size_t)F * C * H * W * 6 >= ((size_t)1 << 30)))
+    // Round 5: from 512 MiB (was 1 GiB) for the plain overlay -- since the overlay leaves wave slots to the chain, the chain is
+    // over long before the overlay it runs beside, the wait costs the host nothing it needs (960x540 x 40 frames: host 45 ->
+    // 125 us per 124 us step) and the barrier packet's ~8 us go: 0.1277 -> 0.1236 ms, twice on one box.  The raw 3:5 overlay
+    // stays on the stream-side wait (0.2359 -> 0.2339 / 0.2410: no clear gain).
+    const bool raw_overlay = g_pipeline_raw_overlay;
+    g_pipeline_raw_overlay = false;
+    if (host_wait > 0 || (host_wait < 0 && !prepass_done && !segments && !raw_overlay &&
+                          (size_t)F * C * H * W * 6 >= ((size_t)1 << 29)))
         HIP_TRY(hipEventSynchronize(p->binned[slot]));
     HIP_TRY(hipStreamWaitEvent(so, p->binned[slot], 0));
     g_overlay_stop_event = (overlay_takes_stop_event && ext_events()) ? p->done[k % RING] : nullptr;
@@ -2051,6 +2059,7 @@ int cama_pipeline_render_raw35(cama_pipeline *p, const void *x, const void *y, c
 {
     if (F > 0 && (!raw || !vrows || !band_rows || !mosaic || !palette_bgr || !halfwidth || cols < 1))
         return fail(CAMA_EINVAL, "NULL pointer argument");
+    g_pipeline_raw_overlay = true;
     return pipeline_render_impl(p, x, y, z, xyz_is_f64, colour_id, draw_key, block_bounds, flags, N, w2c, F, c2cam, K, C, crop, W, H,
                                 radius, scratch0, scratch1, scratch_bytes, input_stream, true,
                                 [&](const ScratchRef &sc, void *so) {

@@ -64,7 +64,7 @@ int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per
  *   pipeline_host_wait    CAMA_PIPELINE_HOST_WAIT  1 = cama_pipeline_render* waits on the HOST for a launch's binning before it
  *                                                  queues the overlay (the call blocks ~0.1 ms; no barrier packet between
  *                                                  consecutive overlays on the GPU: +1.5 % on the headline); 0 = stream-side
- *                                                  wait; -1 (default) = host wait for launches that move >= 1 GiB (smaller ones are host-bound)
+ *                                                  wait; -1 (default) = host wait for plain-overlay launches that move >= 512 MiB
  * Unknown names: CAMA_EINVAL.  (No reference counterpart: the reference has no native code.) */
 int cama_set_option(const char *name, int64_t value);
 int cama_get_option(const char *name, int64_t *value);
