@@ -594,7 +594,7 @@ class ClipFrameSource:
 
     def _cache_store(self, image_indices, tensor):
         nbytes = int(tensor.numel())
-        if self._cache_cap <= 0 or nbytes > self._cache_cap or not tensor.is_cuda:
+        if self._cache_cap <= 0 or nbytes > self._cache_cap:
             return
         key = tuple(image_indices)
         sigs = [self._frame_signature(i) for i in key]

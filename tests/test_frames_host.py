@@ -179,3 +179,57 @@ def test_separable_undistort_map_is_the_full_map_bit_for_bit():
         d_origin = np.array([-0.05, 0.01, 0.0, 0.0, 0.0])
     mx, my, sep = FR.camera_maps_compact(CMd)
     assert sep == 0 and mx.shape == (540, 960)
+
+
+def test_decoded_frame_cache_serves_views_notices_changed_files_and_evicts_oldest_first(tmp_path):
+    """ClipFrameSource keeps a clip's decoded frames for its later passes (main.py renders every clip twice from the same
+    camera files): whole cached batches come back as views, frames spread over batches as one gather, a file whose size /
+    mtime changed drops its batch, and the byte cap evicts the oldest batch first.  (Bookkeeping only: CPU tensors.)"""
+    import os
+    import torch
+    from cama_amd import frames as FR
+
+    class Cam:
+        def __init__(self, name):
+            self.name = name
+
+        def get_image_path(self, idx, sync):
+            return str(tmp_path / f"{self.name}_{idx}.jpg")
+
+        def needs_resample(self):
+            return False
+    cams = [Cam("a"), Cam("b")]
+    for c in cams:
+        for i in range(1, 9):
+            (tmp_path / f"{c.name}_{i}.jpg").write_bytes(bytes([i]) * (10 + i))
+    src = FR.ClipFrameSource(cams, None, decoder="host")
+    assert src._cache_cap == 0 and src._cache_lookup([1, 2]) is None            # no device: off
+    per_batch = 4 * 2 * 3 * 5 * 3
+    src._cache_cap = 2 * per_batch + 1                                           # room for two batches
+    b1 = torch.arange(per_batch, dtype=torch.uint8).reshape(4, 2, 3, 5, 3)
+    b2 = (b1 + 100)
+    src._cache_store([1, 2, 3, 4], b1)
+    src._cache_store([5, 6, 7, 8], b2)
+    assert src._cache_bytes == 2 * per_batch and src.cache_stats["stored_batches"] == 2
+    v = src._cache_lookup([2, 3])
+    assert v.data_ptr() == b1[1:3].data_ptr() and torch.equal(v, b1[1:3])       # consecutive rows of one batch: a view
+    g = src._cache_lookup([4, 5])                                                # across batches: one gather
+    assert torch.equal(g, torch.stack([b1[3], b2[0]])) and src.cache_stats["hits"] == 2
+    assert src._cache_lookup([8, 9]) is None                                     # frame 9 was never decoded
+    # a camera file of frame 6 changes: its whole batch goes, the other batch is still served
+    p = tmp_path / "b_6.jpg"
+    p.write_bytes(b"x" * 99)
+    assert src._cache_lookup([5, 6]) is None and src.cache_stats["stale"] == 1
+    assert src._cache_lookup([7]) is None and src._cache_bytes == per_batch
+    assert src._cache_lookup([1, 2, 3, 4]).data_ptr() == b1.data_ptr()
+    # the cap: a third batch evicts the OLDEST one
+    src._cache_store([5, 6, 7, 8], b2)
+    src._cache_lookup([1])                                                       # touch batch 1: batch (5..8) is now the older one
+    b3 = b1 + 7
+    os.utime(tmp_path / "a_1.jpg")                                               # (same size, new mtime: also a change)
+    for c in cams:
+        for i in range(9, 13):
+            (tmp_path / f"{c.name}_{i}.jpg").write_bytes(b"z" * i)
+    src._cache_store([9, 10, 11, 12], b3)
+    assert src.cache_stats["evicted_batches"] == 1 and (5, 6, 7, 8) not in src._cache and (9, 10, 11, 12) in src._cache
+    assert src._cache_lookup([1, 2]) is None and src.cache_stats["stale"] == 2   # the touched mtime is noticed too
