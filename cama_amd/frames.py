@@ -257,12 +257,12 @@ class DeviceFrameSource:
         tensor is left alone -- the source simply reads the placed copy from now on."""
         if self._placed:
             return
-        self._placed = True
         import os
         K = int(os.environ.get("CAMA_AUDITION", "16")) // 2
         idx = [int(i) - self.index_offset for i in image_indices]
         if K <= 1 or not idx or idx != list(range(idx[0], idx[0] + len(idx))) or len(idx) != int(out.shape[0]):
-            return
+            return                                  # (not this time: a later whole-run render may still place the frames)
+        self._placed = True
         self.frames = eng.place_frames(rig, self.frames, out, first=idx[0], candidates=K)
 
     def batch(self, image_indices):
