@@ -20,6 +20,8 @@ plain 960x540 --height 540 --width 960 --steps 60 --warmup 5
 plain n1e5 --verts 100000 --steps 30 --warmup 5
 plain dense1e6 --verts 1000000 --steps 20 --warmup 3
 plain site4e6 --map site --verts 4000000 --steps 20 --warmup 3
+plain segments --segments --steps 20 --warmup 5 --cpu-seconds 0
+plain wu --segments --wu --steps 20 --warmup 5 --cpu-seconds 0
 # N > 1 code path end to end on this one GPU (eight ranks share it, gloo for the one collective): functional, not a measurement
 CAMA_BENCH_SHARE_GPU=1 timeout 1500 python bench.py --gpus 8 --steps 2 --warmup 1 > gpurun_out/${tag}_8ranks_on_one_gpu_bench.json 2> gpurun_out/${tag}_8ranks_on_one_gpu_bench.err; tail -c 300 gpurun_out/${tag}_8ranks_on_one_gpu_bench.json; echo
 # the reference's real workload: a fresh ClipManager per scene, both passes once (tools/cold_sweep.py)
