@@ -71,6 +71,39 @@ __device__ __forceinline__ void rasterise_one_padded(uint32_t *s_owner, const ui
     }
 }
 
+// The reference's disc (cv2.circle radius 2, cama/reproject.py:256: rows of half width 0 / 1 / 2 / 1 / 0, 13 pixels) with
+// nothing left to loop over: five row tests, thirteen ds_max at immediate offsets from five row addresses.  The generic
+// loops above compile to ~120 instructions per stamp (per row: |dy|, mask test, half-width extract, exec juggling; per pixel
+// pair: two address adds, a loop counter, a branch); this is ~40 -- and the rasteriser is instruction-bound on stamp-heavy
+// bands (site maps: 7 k stamps per image, most of them in a few horizon bands).  Same cells, same values: max is order-free.
+__device__ __forceinline__ void rasterise_r2_padded(uint32_t *s_owner, const uint2 r, int y0, int nrows, int Wp)
+{
+    const int rel = (int)(r.x >> 16) - y0;                              // centre row relative to the band: -2 .. nrows + 1
+    const int c = rel * Wp + (int)(r.x & 0xffffu) + 2;                  // centre cell (pixel x at cell x + radius)
+    const uint32_t val = r.y + 1u;
+    const unsigned n = (unsigned)nrows;
+    if ((unsigned)rel < n) {
+        atomicMax(&s_owner[c - 2], val); atomicMax(&s_owner[c - 1], val); atomicMax(&s_owner[c], val);
+        atomicMax(&s_owner[c + 1], val); atomicMax(&s_owner[c + 2], val);
+    }
+    if ((unsigned)(rel - 1) < n) {
+        const int p = c - Wp;
+        atomicMax(&s_owner[p - 1], val); atomicMax(&s_owner[p], val); atomicMax(&s_owner[p + 1], val);
+    }
+    if ((unsigned)(rel + 1) < n) {
+        const int p = c + Wp;
+        atomicMax(&s_owner[p - 1], val); atomicMax(&s_owner[p], val); atomicMax(&s_owner[p + 1], val);
+    }
+    if ((unsigned)(rel - 2) < n) atomicMax(&s_owner[c - 2 * Wp], val);
+    if ((unsigned)(rel + 2) < n) atomicMax(&s_owner[c + 2 * Wp], val);
+}
+
+// is this the reference's radius-2 disc?  (wave-uniform: kernel arguments)
+__device__ __forceinline__ bool disc_is_r2(int radius, uint32_t hw8, uint32_t rowmask)
+{
+    return radius == 2 && (hw8 & 0xfffu) == 0x012u && (rowmask & 7u) == 7u;
+}
+
 // EXTENSION (segment records, 16 bytes): the one-pixel 8-connected Bresenham segment from the predecessor's pixel (r.z) to the
 // point's own (r.x), both ends included, under the point's key -- the integer recurrence of oracle_line_bresenham, restated;
 // only the rows of this band are written (the other bands the segment crosses hold a copy of the record and do theirs).
@@ -156,6 +189,17 @@ __device__ __forceinline__ void rasterise_rest_padded(uint32_t *s_owner, const u
                                                       uint32_t n, int y0, int nrows, int Wp, int radius, uint32_t hw8,
                                                       uint32_t rowmask)
 {
+    if (disc_is_r2(radius, hw8, rowmask)) {                              // the reference's disc: the unrolled diamond
+        for (uint32_t s = first; s < n; s += 4u * stride) {
+            const uint2 r0 = st[s], r1 = st[min(s + stride, n - 1u)], r2 = st[min(s + 2u * stride, n - 1u)],
+                        r3 = st[min(s + 3u * stride, n - 1u)];
+            rasterise_r2_padded(s_owner, r0, y0, nrows, Wp);
+            if (s + stride < n) rasterise_r2_padded(s_owner, r1, y0, nrows, Wp);
+            if (s + 2u * stride < n) rasterise_r2_padded(s_owner, r2, y0, nrows, Wp);
+            if (s + 3u * stride < n) rasterise_r2_padded(s_owner, r3, y0, nrows, Wp);
+        }
+        return;
+    }
     for (uint32_t s = first; s < n; s += 4u * stride) {
         const uint2 r0 = st[s], r1 = st[min(s + stride, n - 1u)], r2 = st[min(s + 2u * stride, n - 1u)],
                     r3 = st[min(s + 3u * stride, n - 1u)];
@@ -412,11 +456,15 @@ __device__ __forceinline__ void overlay_band_at(const OverlayArgs &a, const uint
                 const int v = (int)(r.x >> 16);
                 if (v + rad >= y0 && v - rad < y0 + nrows) {
                     if (WU) rasterise_disc_wu_padded(s_owner, make_uint2(r.x, r.y), y0, nrows, Wp, rad, hw8, rowmask);
+                    else if (disc_is_r2(rad, hw8, rowmask)) rasterise_r2_padded(s_owner, make_uint2(r.x, r.y), y0, nrows, Wp);
                     else rasterise_one_padded(s_owner, make_uint2(r.x, r.y), y0, nrows, Wp, rad, hw8, rowmask);
                 }
             }
         } else {
-            if (threadIdx.x < n) rasterise_one_padded(s_owner, first, y0, nrows, Wp, rad, hw8, rowmask);
+            if (threadIdx.x < n) {
+                if (disc_is_r2(rad, hw8, rowmask)) rasterise_r2_padded(s_owner, first, y0, nrows, Wp);
+                else rasterise_one_padded(s_owner, first, y0, nrows, Wp, rad, hw8, rowmask);
+            }
             rasterise_rest_padded(s_owner, st, threadIdx.x + OVERLAY_BLOCK, OVERLAY_BLOCK, n, y0, nrows, Wp, rad, hw8, rowmask);
         }
         lds_barrier();
