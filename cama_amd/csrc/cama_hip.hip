@@ -2392,6 +2392,15 @@ extern "C" int cama_jpeg_find_restarts(const uint8_t *stream, uint64_t stream_by
     return CAMA_OK;
 }
 
+#ifdef JPEG_TRACE
+extern "C" int cama_diag_jpeg_trace(uint64_t *clocks, uint32_t *redone)
+{
+    if (hipMemcpyFromSymbol(clocks, HIP_SYMBOL(g_jpeg_trace), sizeof(uint64_t) * 4096 * 16) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(redone, HIP_SYMBOL(g_jpeg_trace_m), sizeof(uint32_t) * 4096 * 16) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, const cama_jpeg_image *imgs,
                                 const cama_jpeg_image *imgs_dev, int32_t n, const void *huff_sets, int32_t n_huff_sets,
                                 const uint16_t *quant_sets, int32_t n_quant_sets, uint8_t *out, uint64_t out_stride,

@@ -31,6 +31,8 @@ constexpr int JPEG_SUB_BITS = JPEG_SUB_WORDS * 32;
 constexpr int JPEG_WG = JPEG_WG_N;                 // subsequences (threads) per workgroup
 constexpr int JPEG_TILE = 1024;                    // unstuff tile, bytes (4 per thread)
 constexpr int JPEG_LUT_BITS = 10;
+constexpr int JPEG_L2_MAX = 1024;                  // second-level entries per table set (the standard tables need 674)
+constexpr uint32_t JPEG_L2_NONE = 0xffffu;
 
 // Huffman table set as uploaded by the host (cama_amd/jpeg.py: build_huff_set) and copied verbatim to LDS.
 // Tables: 0 = DC0, 1 = AC0, 2 = DC1, 3 = AC1.
@@ -40,9 +42,16 @@ struct JpegHuffSet {
                                            // of length <= 11+i; a longer code's length is 11 + #limits <= its prefix
     int32_t valoff[4][17];                 // index of a length's first symbol minus its first code
     uint8_t vals[4][256];
-    uint8_t pad[16];                       // sizeof == 9632, a multiple of 16
+    // second level for the codes of 11..16 bits (round 5): canonical codes grow with their length, so they occupy the 16-bit
+    // prefixes from l2_first[t] << 6 up to the end of the table's code space, top = min(lim[t][5], 0xffff).
+    // l2[l2_off[t] + min(prefix16, top) - (l2_first[t] << 6)] = (length << 8) | symbol, the entry at `top` = 16 << 8 (no
+    // code) -- exactly what jpeg_symbol_long_t computes, one lookup instead of a compare chain and two dependent reads.
+    // l2_off[t] == JPEG_L2_NONE: the set's long codes did not fit (slow path).
+    uint16_t l2_first[4];                  // 10-bit prefix of the first lut entry that is 0 (1024: none)
+    uint16_t l2_off[4];
+    uint16_t l2[JPEG_L2_MAX];
 };
-static_assert(sizeof(JpegHuffSet) == 9632, "JpegHuffSet layout");
+static_assert(sizeof(JpegHuffSet) == 9632 + 2 * JPEG_L2_MAX && sizeof(JpegHuffSet) % 16 == 0, "JpegHuffSet layout");
 
 struct JpegArgs {
     const uint8_t *stream;            // stuffed entropy segments
@@ -205,9 +214,9 @@ struct JpegWgCtx {
     // k_jpeg_sync only (JpegSyncShared): transition tables instead of H
     const uint16_t *sync_dc;   // [2][1024]: used | kinc << 6
     const uint32_t *sync_ac;   // [2][1024]: used1 | kinc1 << 6 | used12 << 13 | kinc12 << 19 (0: code longer than 10 bits)
-    const uint32_t (*lim)[8];
-    const int32_t (*valoff)[17];
-    const uint8_t (*vals)[256];
+    const JpegHuffSet *G;      // global: the table set (slow path of a set whose long codes have no second level)
+    const uint16_t *l2;        // LDS: second level, k_jpeg_write: (length << 8) | symbol, k_jpeg_sync: used | kinc << 6
+    uint32_t l2_adj[4];        // top << 16 | adj: table t's entry for 16-bit prefix p is l2[min(p, top) - adj]; JPEG_L2_ABSENT: slow path
     uint32_t dc_mask, ac_mask; // bit b: Huffman table selector (0/1) of block b of the MCU
     uint32_t bpm;
     const uint8_t *zigzag;     // LDS copy of the zigzag -> natural order table
@@ -237,6 +246,36 @@ __device__ __forceinline__ uint32_t jpeg_symbol_long_t(const uint32_t (*lim)[8],
 __device__ __forceinline__ uint32_t jpeg_symbol_long(const JpegHuffSet &H, uint32_t tab, uint32_t window)
 {
     return jpeg_symbol_long_t(H.lim, H.valoff, H.vals, tab, window);
+}
+constexpr uint32_t JPEG_L2_ABSENT = 0xffffffffu;
+// per-table clamp and rebasing of the second level (wave-uniform), top << 16 | adj: l2[min(prefix16, top) - adj]
+__device__ __forceinline__ void jpeg_l2_adjust(const JpegHuffSet &G, uint32_t (&adj)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t top = min(G.lim[t][5], 0xffffu);
+        adj[t] = G.l2_off[t] == JPEG_L2_NONE ? JPEG_L2_ABSENT
+                                             : (top << 16) | (((uint32_t)G.l2_first[t] << 6) - (uint32_t)G.l2_off[t]);
+    }
+}
+__device__ __forceinline__ uint32_t jpeg_l2_index(uint32_t adj, uint32_t window)
+{
+    return min(window >> 16, adj >> 16) - (adj & 0xffffu);
+}
+// a code longer than 10 bits, in k_jpeg_write's form (length << 8 | symbol)
+__device__ __forceinline__ uint32_t jpeg_long_symbol(const JpegWgCtx &c, uint32_t tab, uint32_t window)
+{
+    const uint32_t adj = (tab & 2u) ? ((tab & 1u) ? c.l2_adj[3] : c.l2_adj[2]) : ((tab & 1u) ? c.l2_adj[1] : c.l2_adj[0]);
+    if (adj != JPEG_L2_ABSENT) return c.l2[jpeg_l2_index(adj, window)];
+    return jpeg_symbol_long(*c.G, tab, window);
+}
+// the same in k_jpeg_sync's form (used | kinc << 6): its second level holds transition entries
+__device__ __forceinline__ uint32_t jpeg_sync_entry(uint32_t tab, uint32_t e);
+__device__ __forceinline__ uint32_t jpeg_long_entry(const JpegWgCtx &c, uint32_t tab, uint32_t window)
+{
+    const uint32_t adj = (tab & 2u) ? ((tab & 1u) ? c.l2_adj[3] : c.l2_adj[2]) : ((tab & 1u) ? c.l2_adj[1] : c.l2_adj[0]);
+    if (adj != JPEG_L2_ABSENT) return c.l2[jpeg_l2_index(adj, window)];
+    return jpeg_sync_entry(tab & 1u, jpeg_symbol_long(*c.G, tab, window));
 }
 
 __constant__ uint8_t c_jpeg_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
@@ -271,7 +310,7 @@ __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegSta
         const uint32_t tab = (((isac ? c.ac_mask : c.dc_mask) >> blk) & 1u) * 2u + isac;
         uint32_t e = lut[(tab << JPEG_LUT_BITS) + (hi >> (32 - JPEG_LUT_BITS))];
         const uint32_t next = jpeg_word(c, w);                     // refill word (used when lo runs dry)
-        if (e == 0u) e = jpeg_symbol_long(*c.H, tab, hi);
+        if (e == 0u) e = jpeg_long_symbol(c, tab, hi);
         const uint32_t len = e >> 8, size = e & 15u, run = (e >> 4) & 15u;
         // zigzag index of the coded coefficient (DC: 0) and the index after this symbol
         const uint32_t at = isac ? k + run : 0u;
@@ -379,14 +418,14 @@ __device__ __forceinline__ uint32_t jpeg_sync_span(const JpegWgCtx &c, JpegState
         if (k == 0u) {                                              // DC symbol
             const uint32_t sel = (c.dc_mask >> blk) & 1u;
             uint32_t e = c.sync_dc[(sel << JPEG_LUT_BITS) + peek];
-            if (e == 0u) e = jpeg_sync_entry(0u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 2u * sel, hi));
+            if (e == 0u) e = jpeg_long_entry(c, 2u * sel, hi);
             used = e & 63u;
             kinc = e >> 6;
         } else {
             const uint32_t sel = (c.ac_mask >> blk) & 1u;
             uint32_t e = c.sync_ac[(sel << JPEG_LUT_BITS) + peek];
             if (e == 0u) {
-                e = jpeg_sync_entry(1u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 2u * sel + 1u, hi));
+                e = jpeg_long_entry(c, 2u * sel + 1u, hi);
                 e |= e << 13;
             }
             const uint32_t u1 = e & 63u, k1 = (e >> 6) & 127u;
@@ -428,7 +467,9 @@ __device__ __forceinline__ uint32_t jpeg_sync_span(const JpegWgCtx &c, JpegState
 __device__ __forceinline__ uint32_t jpeg_decode_span_wave(const JpegWgCtx &c, JpegState &s, uint32_t end)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t pos = s.pos, blk = s.blk, k = s.k, nb = 0;            // wave-uniform
+    end = (uint32_t)__builtin_amdgcn_readfirstlane((int)end);
+    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.pos), blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.blk),
+             k = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.k), nb = 0;            // wave-uniform
     while (pos < end) {
         const uint32_t bp = pos + lane;
         const uint32_t w = (bp >> 5) - c.word0, sh = bp & 31u;
@@ -438,23 +479,40 @@ __device__ __forceinline__ uint32_t jpeg_decode_span_wave(const JpegWgCtx &c, Jp
         const uint32_t peek = win >> (32 - JPEG_LUT_BITS);
         uint32_t e0 = c.sync_dc[peek], e2 = c.sync_dc[(1u << JPEG_LUT_BITS) + peek];
         uint32_t e1 = c.sync_ac[peek] & 0x1fffu, e3 = c.sync_ac[(1u << JPEG_LUT_BITS) + peek] & 0x1fffu;
-        if (e0 == 0u) e0 = jpeg_sync_entry(0u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 0u, win));
-        if (e1 == 0u) e1 = jpeg_sync_entry(1u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 1u, win));
-        if (e2 == 0u) e2 = jpeg_sync_entry(0u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 2u, win));
-        if (e3 == 0u) e3 = jpeg_sync_entry(1u, jpeg_symbol_long_t(c.lim, c.valoff, c.vals, 3u, win));
-        const uint32_t e01 = e0 | (e1 << 16), e23 = e2 | (e3 << 16);
+        if (e0 == 0u) e0 = jpeg_long_entry(c, 0u, win);
+        if (e1 == 0u) e1 = jpeg_long_entry(c, 1u, win);
+        if (e2 == 0u) e2 = jpeg_long_entry(c, 2u, win);
+        if (e3 == 0u) e3 = jpeg_long_entry(c, 3u, win);
+        // The walk, in scalar registers: a block's DC symbol, then its AC symbols under ONE table vector (chosen once per block
+        // and window).  Bit offset and zigzag index advance in one add -- t = (off + 0x8000 - lim) | (k + 0x8000 - 64) << 16,
+        // an AC entry re-packed as used | kinc << 16 -- and "window ran out or block ended" is one mask test (no field can
+        // carry: off < 128, k < 128).  Six scalar instructions per AC symbol; a generic per-symbol table choice cost 33, at one
+        // instruction per ~10 cycles: 27 us per 1024-bit subsequence.
+        const uint32_t lim = min(64u, end - pos);
+        const uint32_t a1 = (e1 & 63u) | ((e1 >> 6) << 16), a3 = (e3 & 63u) | ((e3 >> 6) << 16);
+        const uint32_t boff = 0x8000u - lim, bk = 0x8000u - 64u;
         uint32_t off = 0;
-        while (off < 64u && pos + off < end) {
-            const uint32_t isac = k ? 1u : 0u;
-            const uint32_t sel = ((isac ? c.ac_mask : c.dc_mask) >> blk) & 1u;       // table = sel * 2 + isac
-            const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)(sel ? e23 : e01), (int)off);
-            const uint32_t e = isac ? pair >> 16 : pair & 0xffffu;
-            const uint32_t knext = k + (e >> 6);
-            off += e & 63u;
-            const bool done = knext >= 64u;
-            k = done ? 0u : knext;
-            blk = done ? (blk + 1u == c.bpm ? 0u : blk + 1u) : blk;
-            nb += done ? 1u : 0u;
+        for (;;) {
+            if (k == 0u) {
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)e0, (int)off);
+                const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)e2, (int)off);
+                const uint32_t e = ((c.dc_mask >> blk) & 1u) ? d2 : d0;
+                off += e & 63u;
+                k = e >> 6;                                              // (1: a DC symbol)
+                if (off >= lim) break;
+            }
+            const uint32_t vac = ((c.ac_mask >> blk) & 1u) ? a3 : a1;    // wave-uniform choice
+            uint32_t t = (off + boff) | ((k + bk) << 16);                // here off < lim and k < 64
+            do {
+                t += (uint32_t)__builtin_amdgcn_readlane((int)vac, (int)((t - boff) & 63u));
+            } while ((t & 0x80008000u) == 0u);
+            off = (t & 0xffffu) - boff;
+            k = (t >> 16) - bk;
+            if (k < 64u) break;                                          // the window (or the subsequence) ran out
+            k = 0u;
+            blk = blk + 1u == c.bpm ? 0u : blk + 1u;
+            ++nb;
+            if (off >= lim) break;
         }
         pos += off;
     }
@@ -528,16 +586,17 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
     if (threadIdx.x < 64) S.zigzag[threadIdx.x] = c_jpeg_zigzag[threadIdx.x];
     c.zigzag = S.zigzag;
     c.H = &S.H;
-    c.sync_dc = nullptr; c.sync_ac = nullptr; c.lim = nullptr; c.valoff = nullptr; c.vals = nullptr;
+    c.G = a.huff + D.huff_set;
+    c.l2 = S.H.l2;
+    jpeg_l2_adjust(*c.G, c.l2_adj);
+    c.sync_dc = nullptr; c.sync_ac = nullptr;
 }
 
-// k_jpeg_sync's LDS: transition tables (jpeg_sync_tables) instead of the symbol LUT -- 51.2 KB, three workgroups per CU
+// k_jpeg_sync's LDS: transition tables (jpeg_sync_tables) instead of the symbol LUT -- 51.9 KB, three workgroups per CU
 struct JpegSyncShared {
     uint16_t dc[2][1 << JPEG_LUT_BITS];
     uint32_t ac[2][1 << JPEG_LUT_BITS];
-    uint32_t lim[4][8];
-    int32_t valoff[4][17];
-    uint8_t vals[4][256];
+    uint16_t l2[JPEG_L2_MAX];              // transition entries of the codes of 11..16 bits (JpegHuffSet::l2)
 #ifndef JPEG_WORDS_GLOBAL
     uint32_t words[JPEG_WG * JPEG_SUB_WORDS + JPEG_WG + 40];   // one pad word per subsequence: lane stride odd
 #endif
@@ -552,9 +611,20 @@ __device__ __forceinline__ void jpeg_sync_setup(const JpegArgs &a, const cama_jp
 {
     const JpegHuffSet &G = a.huff[D.huff_set];
     jpeg_sync_tables(G, S.dc, S.ac);
-    for (uint32_t i = threadIdx.x; i < 4u * 8u; i += JPEG_WG) S.lim[i >> 3][i & 7u] = G.lim[i >> 3][i & 7u];
-    for (uint32_t i = threadIdx.x; i < 4u * 17u; i += JPEG_WG) S.valoff[i / 17u][i % 17u] = G.valoff[i / 17u][i % 17u];
-    for (uint32_t i = threadIdx.x; i < 4u * 256u; i += JPEG_WG) S.vals[i >> 8][i & 255u] = G.vals[i >> 8][i & 255u];
+    {   // second level: table t's entries are l2[l2_off[t], l2_off[t+1]) (tables without one are skipped by the host's layout)
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            lo[t] = G.l2_off[t];
+            hi[t] = (lo[t] == JPEG_L2_NONE || G.l2_first[t] == 1024u)
+                        ? 0u : lo[t] + min(G.lim[t][5], 0xffffu) - ((uint32_t)G.l2_first[t] << 6) + 1u;
+        }
+        for (uint32_t i = threadIdx.x; i < (uint32_t)JPEG_L2_MAX; i += JPEG_WG) {
+            const uint32_t ac = ((i >= lo[1] && i < hi[1]) || (i >= lo[3] && i < hi[3])) ? 1u : 0u;
+            const uint32_t e = G.l2[i];
+            S.l2[i] = e ? (uint16_t)jpeg_sync_entry(ac, e) : (uint16_t)0u;
+        }
+    }
 #ifndef JPEG_WORDS_GLOBAL
     jpeg_wg_stream(a, D, lw, S.words, c);
 #else
@@ -564,10 +634,22 @@ __device__ __forceinline__ void jpeg_sync_setup(const JpegArgs &a, const cama_jp
     c.zigzag = nullptr;
     c.sync_dc = &S.dc[0][0];
     c.sync_ac = &S.ac[0][0];
-    c.lim = S.lim;
-    c.valoff = S.valoff;
-    c.vals = S.vals;
+    c.G = &G;
+    c.l2 = S.l2;
+    jpeg_l2_adjust(G, c.l2_adj);
 }
+
+#ifdef JPEG_TRACE
+// diagnostic build only (tools/jpeg_phase_clock.sh): per workgroup of k_jpeg_sync<1>, the constant 100 MHz clock at entry, after
+// the setup, after the first decode and after each fixpoint round, and how many subsequences each round re-decoded
+__device__ uint64_t g_jpeg_trace[4096][16];
+__device__ uint32_t g_jpeg_trace_m[4096][16];
+#define JPEG_T(i) do { if (PHASE == 1 && threadIdx.x == 0 && blockIdx.x < 4096 && (i) < 16) g_jpeg_trace[blockIdx.x][(i)] = wall_clock64(); } while (0)
+#define JPEG_M(i, m) do { if (PHASE == 1 && threadIdx.x == 0 && blockIdx.x < 4096 && (i) < 16) g_jpeg_trace_m[blockIdx.x][(i)] = (m); } while (0)
+#else
+#define JPEG_T(i) do { } while (0)
+#define JPEG_M(i, m) do { } while (0)
+#endif
 
 // PHASE 1: speculative decode + fixpoint inside the workgroup.  PHASE 2: fixpoint seeded with the true entry state.
 template <int PHASE>
@@ -584,6 +666,7 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
         return;
     }
     if (PHASE == 2 && lw == 0) return;                                  // its entry state was exact in phase 1
+    JPEG_T(0);
     JpegWgCtx c;
     jpeg_sync_setup(a, D, lw, S, c);                                    // transition tables (state only) + stream words
     const uint32_t nsub_img = (nbits + JPEG_SUB_BITS - 1) / JPEG_SUB_BITS;
@@ -594,6 +677,7 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
     const size_t gsub = (size_t)D.wg0 * JPEG_WG + (size_t)lw * JPEG_WG + threadIdx.x;   // global subsequence slot
     int cur = 0;
     __syncthreads();
+    JPEG_T(1);
     if (PHASE == 1) {
         JpegState s{lo, 0u, 0u};
         uint32_t nb = 0;
@@ -627,6 +711,7 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
     __shared__ uint32_t s_wcount[JPEG_WG / 64];
     for (int round = 0; round < JPEG_WG; ++round) {
         __syncthreads();
+        JPEG_T(2 + round);
         const bool redo = active && threadIdx.x > 0 && S.flag[cur][threadIdx.x - 1];
         const uint64_t start = threadIdx.x > 0 ? S.E[threadIdx.x - 1] : 0ull;
         const uint64_t mask = __ballot(redo);
@@ -640,6 +725,7 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
             before += wv < (int)(threadIdx.x >> 6) ? cnt : 0u;
             m += cnt;
         }
+        JPEG_M(2 + round, m);
         if (m == 0u) break;                                              // uniform
         if (m > JPEG_WAVE_MAX) {
             if (redo) {

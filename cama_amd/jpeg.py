@@ -28,8 +28,10 @@ IMAGE_DTYPE = np.dtype([
 KIND_WHOLE, KIND_SEGMENT, KIND_PIXELS = 0, 1, 2
 
 LUT_BITS = 10
+L2_MAX, L2_NONE = 1024, 0xFFFF
 HUFF_DTYPE = np.dtype([("lut", "<u2", (4, 1 << LUT_BITS)), ("lim", "<u4", (4, 8)), ("valoff", "<i4", (4, 17)),
-                       ("vals", "u1", (4, 256)), ("pad", "u1", (16,))])                       # == JpegHuffSet
+                       ("vals", "u1", (4, 256)), ("l2_first", "<u2", (4,)), ("l2_off", "<u2", (4,)),
+                       ("l2", "<u2", (L2_MAX,))])                                             # == JpegHuffSet
 
 _ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20,
                     13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52,
@@ -272,7 +274,46 @@ def build_huff_set(huff):
                 # exclusive upper limit of all codes of length <= l, left-aligned to 16 bits (monotone in l)
                 rec["lim"][t, l - LUT_BITS - 1] = code << (16 - l)
             code <<= 1
+    _second_level(rec)
     return rec
+
+
+def long_symbol(rec, t, w16):
+    """(length << 8) | symbol of the code of 11..16 bits that starts the 16-bit prefixes `w16` (array) under table t; 16 << 8
+    where no code starts there -- jpeg_kernels.hpp: jpeg_symbol_long_t, vectorised."""
+    w16 = np.asarray(w16, np.int64)
+    lim = rec["lim"][t].astype(np.int64)
+    l = 11 + sum((w16 >= lim[i]).astype(np.int64) for i in range(5))
+    idx = ((w16 >> (16 - l)) + rec["valoff"][t].astype(np.int64)[l]) & 255
+    sym = (l << 8) | rec["vals"][t].astype(np.int64)[idx]
+    return np.where(w16 >= lim[5], 16 << 8, sym).astype(np.uint16)
+
+
+def _second_level(rec):
+    """Second-level lookup of the codes longer than LUT_BITS: canonical codes grow with their length, so they start at the
+    first 10-bit prefix whose lut entry is 0 (l2_first) and end where the code space of the table ends (lim[5], the exclusive
+    limit of all its codes as a 16-bit prefix); one entry per 16-bit prefix in between plus ONE for everything above (no
+    code: 16 << 8) -- the kernels clamp the prefix to that last entry.  A set whose long codes do not fit L2_MAX entries keeps
+    l2_off = L2_NONE for the tables left out (the kernels then walk the per-length limits instead)."""
+    at = 0
+    for t in range(4):
+        zero = np.flatnonzero(rec["lut"][t] == 0)
+        first = int(zero[0]) if len(zero) else 1 << LUT_BITS
+        assert not len(zero) or len(zero) == (1 << LUT_BITS) - first, "long codes are a suffix of the prefix space"
+        rec["l2_first"][t] = first
+        if not len(zero):
+            rec["l2_off"][t] = at                                    # (never looked up)
+            continue
+        base, top = first << (16 - LUT_BITS), min(int(rec["lim"][t, 5]), 0xFFFF)
+        n = top - base + 1
+        assert n >= 1
+        if at + n > L2_MAX:
+            rec["l2_off"][t] = L2_NONE
+            continue
+        rec["l2_off"][t] = at
+        rec["l2"][at:at + n] = long_symbol(rec, t, base + np.arange(n))
+        rec["l2"][at + n - 1] = 16 << 8                              # the clamp target: no code from here on
+        at += n
 
 
 _RST = [bytes((0xFF, 0xD0 + k)) for k in range(8)]

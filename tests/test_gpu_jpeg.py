@@ -46,6 +46,28 @@ def test_grey_optimised_tables_and_mixed_batch(dec):
         assert np.array_equal(got[k], pillow_rgb(b)), k
 
 
+def test_table_sets_without_a_second_level_decode_the_same(monkeypatch):
+    """The codes of 11..16 bits come from a second-level table per set; a set whose long codes do not fit it is marked
+    (l2_off = L2_NONE) and walks the per-length limits instead.  Forced here for every table: same bytes, nothing flagged.
+    Noise at quality 100 uses the 16-bit codes all the time."""
+    from cama_amd import jpeg as PJ
+
+    def no_second_level(rec):
+        rec["l2_first"][:] = 0
+        rec["l2_off"][:] = PJ.L2_NONE
+
+    monkeypatch.setattr(PJ, "_second_level", no_second_level)
+    dec = PJ.DeviceJpegDecoder("cuda:0")
+    img = synth_image(203, 317, "noise", seed=9)
+    img[:, :150] = synth_image(203, 150, "smooth")
+    blobs = [encode(img, quality=q, subsampling=sub, **kw) for q in (35, 90, 100) for sub in (0, 2)
+             for kw in ((dict(), dict(optimize=True)) if sub else (dict(),))]  # (Pillow cannot optimise 4:4:4 noise this size)
+    got = dec.decode(blobs, bgr=False).cpu().numpy()
+    assert dec.stats["device"] == len(blobs) and not dec.stats["host_flagged"], dec.stats
+    for k, b in enumerate(blobs):
+        assert np.array_equal(got[k], pillow_rgb(b)), k
+
+
 def test_restart_intervals_decode_on_the_device(dec):
     """DRI files: every restart interval is its own entropy segment (exact start state, DC predictors reset)."""
     rng = np.random.default_rng(4)

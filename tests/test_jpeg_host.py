@@ -10,12 +10,17 @@ from oracle import jpeg_oracle as J
 from tests.test_oracle_jpeg import encode, synth_image
 
 
-def _lookup(rec, t, window32):
-    """numpy mirror of jpeg_symbol() in jpeg_kernels.hpp: (length, symbol) for a 32-bit window."""
+def _lookup(rec, t, window32, second_level=False):
+    """numpy mirror of jpeg_symbol() in jpeg_kernels.hpp: (length, symbol) for a 32-bit window; `second_level`: through the
+    set's second-level table (jpeg_long_symbol) instead of the per-length limits."""
     e = int(rec["lut"][t, window32 >> 22])
     if e:
         return e >> 8, e & 255
     w16 = window32 >> 16
+    if second_level:
+        assert int(rec["l2_off"][t]) != PJ.L2_NONE
+        e = int(rec["l2"][int(rec["l2_off"][t]) + min(w16, min(int(rec["lim"][t, 5]), 0xFFFF)) - (int(rec["l2_first"][t]) << 6)])
+        return (16, None) if e == 16 << 8 else (e >> 8, e & 255)
     lim = rec["lim"][t]
     if w16 >= lim[5]:
         return 16, None
@@ -45,10 +50,35 @@ def test_header_and_tables_agree_with_the_oracle(kw):
             for _ in range(int(bits[l - 1])):
                 for tail in (0, (1 << (32 - l)) - 1):                # the code followed by all zeros / all ones
                     assert _lookup(rec, t, (code << (32 - l)) | tail) == (l, int(vals[k])), (cls, tid, l, code)
+                    assert _lookup(rec, t, (code << (32 - l)) | tail, True) == (l, int(vals[k])), (cls, tid, l, code)
                 code += 1
                 k += 1
             code <<= 1
         assert _lookup(rec, t, 0xFFFFFFFF) == (16, None)             # the all-ones prefix is never a code (T.81 C)
+        assert _lookup(rec, t, 0xFFFFFFFF, True) == (16, None)
+    # the second level covers exactly the 16-bit prefixes above the last 10-bit code, back to back, inside its budget
+    at = 0
+    for t in range(4):
+        first = int(rec["l2_first"][t])
+        assert (rec["lut"][t, :first] != 0).all() and (rec["lut"][t, first:] == 0).all()
+        assert int(rec["l2_off"][t]) == at
+        at += (min(int(rec["lim"][t, 5]), 0xFFFF) - (first << 6) + 1) if first < 1024 else 0
+    assert at <= PJ.L2_MAX and (rec["l2"][:at] != 0).all() and (rec["l2"][at:] == 0).all()
+
+
+def test_table_set_whose_long_codes_do_not_fit_the_second_level_says_so():
+    """A DHT with 200 codes of 16 bits below a short prefix: its second level would need > L2_MAX entries -> that table is
+    left to the per-length limits (l2_off = L2_NONE), the others keep theirs."""
+    bits = np.zeros(16, np.uint8)
+    bits[1], bits[10], bits[15] = 2, 40, 120                          # 2 codes of 2 bits, 40 of 11, 120 of 16
+    payload = bytes(bits) + bytes(range(162))
+    std = PJ.build_huff_set({(0, 0): bytes([0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]) + bytes(range(12)),
+                             (1, 0): payload})
+    assert int(std["l2_off"][0]) == 0 and int(std["l2_off"][1]) == PJ.L2_NONE
+    assert int(std["lim"][1, 5]) - (int(std["l2_first"][1]) << 6) + 1 > PJ.L2_MAX
+    # the tables after it still get theirs (DC1 / AC1 absent here: no codes at all -> the one "no code" entry each)
+    n0 = int(std["lim"][0, 5]) - (int(std["l2_first"][0]) << 6) + 1
+    assert [int(v) for v in std["l2_off"][2:]] == [n0, n0 + 1]
 
 
 def test_scope_checks():
