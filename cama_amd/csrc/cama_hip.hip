@@ -2268,7 +2268,7 @@ int cama_stamp_polylines_wu(const double *vu, const uint8_t *colour_id, const ui
 
 // ------------------------------------------------------------------------------------------ device JPEG decode
 struct JpegLayout {
-    size_t clean, tile_count, tile_base, nbits, E, nb, wg_total, coef, planes, total;
+    size_t clean, tile_count, tile_base, nbits, E, nb, wg_total, coef, dcd, planes, total;
     size_t coef_elems, plane_bytes, clean_bytes;
     uint32_t total_wgs, total_tiles, max_blocks;
 };
@@ -2355,6 +2355,7 @@ static int jpeg_layout(cama_jpeg_image *imgs, const cama_jpeg_image *cimgs, int3
     L.nb = off;         off = align_up(off + (size_t)wg * JPEG_WG * 4, 256);
     L.wg_total = off;   off = align_up(off + (size_t)wg * 4, 256);
     L.coef = off;       off = align_up(off + coef * 2, 256);
+    L.dcd = off;        off = align_up(off + coef / 64 * 2 + 64, 256);
     L.planes = off;     off = align_up(off + planes, 256);
     L.total = off;
     return CAMA_OK;
@@ -2439,11 +2440,12 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
     a.huff = (const JpegHuffSet *)huff_sets; a.quant = quant_sets;
     a.tile_count = (uint32_t *)(base + L.tile_count); a.tile_base = (uint32_t *)(base + L.tile_base);
     a.nbits = (uint32_t *)(base + L.nbits); a.E = (uint64_t *)(base + L.E); a.nb = (uint32_t *)(base + L.nb);
-    a.wg_total = (uint32_t *)(base + L.wg_total); a.coef = (int16_t *)(base + L.coef);
+    a.wg_total = (uint32_t *)(base + L.wg_total); a.coef = (int16_t *)(base + L.coef); a.dcd = (int16_t *)(base + L.dcd);
     a.planes = (uint8_t *)(base + L.planes); a.out = out; a.out_stride = (size_t)out_stride; a.bgr = bgr;
     a.status = status;
     HIP_TRY(hipMemsetAsync(a.clean, 0, L.clean_bytes, s));
     HIP_TRY(hipMemsetAsync(a.coef, 0, L.coef_elems * 2, s));
+    if (L.coef_elems) HIP_TRY(hipMemsetAsync(a.dcd, 0, L.coef_elems / 64 * 2, s));
     HIP_TRY(hipMemsetAsync(status, 0, (size_t)n * 4, s));
     if (L.total_tiles) hipLaunchKernelGGL(k_jpeg_count, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
     hipLaunchKernelGGL(k_jpeg_tilescan, dim3((unsigned)n), dim3(256), 0, s, a);

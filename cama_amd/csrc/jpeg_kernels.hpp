@@ -66,6 +66,7 @@ struct JpegArgs {
     uint32_t *nb;                     // per subsequence: blocks completed
     uint32_t *wg_total;               // per decode workgroup: blocks completed
     int16_t *coef;
+    int16_t *dcd;                     // per block (scan order, coef_off / 64): the DC difference, after k_jpeg_dc the DC term itself
     uint8_t *planes;
     uint8_t *out;                     // [n, height, width, 3]
     size_t out_stride;                // bytes between images
@@ -291,7 +292,7 @@ __constant__ uint8_t c_jpeg_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24
 // `block` onwards (DC as the raw difference).
 template <bool WRITE>
 __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegState &s, uint32_t end, int16_t *coef,
-                                                     uint32_t block, uint32_t total_blocks)
+                                                     int16_t *dcd, uint32_t block, uint32_t total_blocks)
 {
     if (s.pos >= end) return 0;
     uint32_t nb = 0, pos = s.pos, blk = s.blk, k = s.k;
@@ -318,7 +319,10 @@ __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegSta
         if (WRITE && size && at < 64u && block + nb < total_blocks) {
             const uint32_t v = (hi << len) >> (32u - size);
             const int32_t val = (v < (1u << (size - 1u))) ? (int32_t)v - (int32_t)((1u << size) - 1u) : (int32_t)v;
-            coef[(size_t)(block + nb) * 64 + c.zigzag[at]] = (int16_t)val;
+            // the DC difference goes to its own compact array: the prefix sum over a component's blocks (k_jpeg_dc) walked the
+            // coefficient buffer with a 128-byte stride otherwise, every cache line of it once more (640 of a 4 500 us batch)
+            if (isac) coef[(size_t)(block + nb) * 64 + c.zigzag[at]] = (int16_t)val;
+            else dcd[block + nb] = (int16_t)val;
         }
         const uint32_t used = len + size;                            // 1..31
         pos += used;
@@ -412,28 +416,33 @@ __device__ __forceinline__ uint32_t jpeg_sync_span(const JpegWgCtx &c, JpegState
     }
     const uint32_t bpm = c.bpm;
     while (pos < end) {
+        // One round of FOUR independent LDS reads per step -- the DC entry, the AC entry, the second-level entry (as if the
+        // code were longer than 10 bits) and the refill word -- then selects: the lanes of a wave are at different places of
+        // their blocks, so a branch per case (DC / AC / long code / refill) was taken by SOME lane nearly every step and the
+        // wave paid every body plus three dependent LDS latencies (62 -> 46 us per subsequence with the second level alone).
         const uint32_t peek = hi >> (32 - JPEG_LUT_BITS);
         const uint32_t next = jpeg_word(c, w);                      // refill word (used when lo runs dry)
-        uint32_t used, kinc;
-        if (k == 0u) {                                              // DC symbol
-            const uint32_t sel = (c.dc_mask >> blk) & 1u;
-            uint32_t e = c.sync_dc[(sel << JPEG_LUT_BITS) + peek];
-            if (e == 0u) e = jpeg_long_entry(c, 2u * sel, hi);
-            used = e & 63u;
-            kinc = e >> 6;
-        } else {
-            const uint32_t sel = (c.ac_mask >> blk) & 1u;
-            uint32_t e = c.sync_ac[(sel << JPEG_LUT_BITS) + peek];
-            if (e == 0u) {
-                e = jpeg_long_entry(c, 2u * sel + 1u, hi);
+        const bool isdc = k == 0u;
+        const uint32_t sel = ((isdc ? c.dc_mask : c.ac_mask) >> blk) & 1u;
+        const uint32_t at = (sel << JPEG_LUT_BITS) + peek;
+        const uint32_t edc = c.sync_dc[at], eac = c.sync_ac[at];
+        const uint32_t adj = sel ? (isdc ? c.l2_adj[2] : c.l2_adj[3]) : (isdc ? c.l2_adj[0] : c.l2_adj[1]);
+        const int32_t i2 = (int32_t)min(hi >> 16, adj >> 16) - (int32_t)(adj & 0xffffu);   // (< 0: not a long code; absent: <= 0)
+        const uint32_t e2 = c.l2[max(i2, 0)];
+        uint32_t e = isdc ? edc | (edc << 13) : eac;
+        if (e == 0u) {
+            e = e2 | (e2 << 13);
+            if (adj == JPEG_L2_ABSENT) {                                // (a table set without a second level: never the usual files)
+                e = jpeg_long_entry(c, 2u * sel + (isdc ? 0u : 1u), hi);
                 e |= e << 13;
             }
-            const uint32_t u1 = e & 63u, k1 = (e >> 6) & 127u;
-            // both symbols, unless the first ends the block (the next is then a DC symbol) or the second starts past `end`
-            const bool both = (k + k1 < 64u) && (pos + u1 < end);
-            used = both ? (e >> 13) & 63u : u1;
-            kinc = both ? e >> 19 : k1;
         }
+        const uint32_t u1 = e & 63u, k1 = (e >> 6) & 127u;
+        // both symbols, unless the first ends the block (the next is then a DC symbol) or the second starts past `end`
+        // (a DC entry carries itself twice)
+        const bool both = (k + k1 < 64u) && (pos + u1 < end);
+        const uint32_t used = both ? (e >> 13) & 63u : u1;
+        const uint32_t kinc = both ? e >> 19 : k1;
         k += kinc;
         pos += used;
         hi = __builtin_amdgcn_alignbit(hi, lo, 32u - used);
@@ -819,15 +828,15 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_write(JpegArgs a)
     }
     if (!active) return;
     JpegState s = (t == 0) ? JpegState{0u, 0u, 0u} : jpeg_unpack(a.E[gsub - 1]);
-    const uint32_t nb = jpeg_decode_span<true>(c, s, hi, a.coef + D.coef_off, first_block, D.total_blocks);
+    const uint32_t nb = jpeg_decode_span<true>(c, s, hi, a.coef + D.coef_off, a.dcd + D.coef_off / 64, first_block, D.total_blocks);
     int bad = (jpeg_pack(s) != a.E[gsub]) || (nb != mine);
     if (t == nsub_img - 1u && first_block + nb != D.total_blocks) bad |= 2;
     if (bad) atomicOr(&a.status[img], bad);
 }
 
 // per (image, component): DC[i] = sum of the differences up to block i of that component (T.81 F.2.1.3.1).
-// One workgroup per component; the DC terms sit 128 bytes apart (one per block), so each thread gathers its
-// consecutive blocks in batches of independent loads (one memory latency per batch, not per block).
+// One workgroup per component over the compact array of DC differences (k_jpeg_write: dcd, one int16 per block in scan
+// order); each thread gathers its consecutive blocks in batches of independent loads.
 constexpr int JPEG_DC_THREADS = 1024;
 constexpr int JPEG_DC_BATCH = 8;
 __global__ __launch_bounds__(JPEG_DC_THREADS) void k_jpeg_dc(JpegArgs a)
@@ -838,7 +847,7 @@ __global__ __launch_bounds__(JPEG_DC_THREADS) void k_jpeg_dc(JpegArgs a)
     const uint32_t hv = ci == 0 ? D.hs * D.vs : 1u;
     const uint32_t first = ci == 0 ? 0u : D.hs * D.vs + (ci - 1u);
     const uint32_t n = D.mx * D.my * hv;
-    int16_t *coef = a.coef + D.coef_off;
+    int16_t *dcd = a.dcd + D.coef_off / 64;
     const uint32_t per = (n + JPEG_DC_THREADS - 1u) / JPEG_DC_THREADS;
     const uint32_t i0 = min(threadIdx.x * per, n), i1 = min(i0 + per, n);
     // scan-order block of this component's i-th block: (i / hv) * bpm + first + i % hv, advanced incrementally
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(JPEG_DC_THREADS) void k_jpeg_dc(JpegArgs a)
             int32_t v[JPEG_DC_BATCH];
 #pragma unroll
             for (int q = 0; q < JPEG_DC_BATCH; ++q) {
-                v[q] = (i + q < i1) ? (int32_t)coef[(size_t)(mcu * D.bpm + first + sub) * 64] : 0;
+                v[q] = (i + q < i1) ? (int32_t)dcd[mcu * D.bpm + first + sub] : 0;
                 if (++sub == hv) { sub = 0; ++mcu; }
             }
 #pragma unroll
@@ -875,7 +884,7 @@ __global__ __launch_bounds__(JPEG_DC_THREADS) void k_jpeg_dc(JpegArgs a)
         int16_t *ptr[JPEG_DC_BATCH];
 #pragma unroll
         for (int q = 0; q < JPEG_DC_BATCH; ++q) {
-            ptr[q] = coef + (size_t)(mcu * D.bpm + first + sub) * 64;
+            ptr[q] = dcd + (mcu * D.bpm + first + sub);
             v[q] = (i + q < i1) ? (int32_t)*ptr[q] : 0;
             if (++sub == hv) { sub = 0; ++mcu; }
         }
@@ -945,6 +954,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(JpegArgs a)
         int32_t d[8], o[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) d[r] = (int32_t)cf[r * 8 + lane] * (int32_t)q[r * 8 + lane];
+        if (lane == 0u) d[0] = (int32_t)a.dcd[D.coef_off / 64 + j] * (int32_t)q[0];      // the DC term lives in the compact array
         jpeg_idct8(d, o, 13 - 2);
 #pragma unroll
         for (int r = 0; r < 8; ++r) s_ws[lb][r][lane] = o[r];

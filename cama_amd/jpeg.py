@@ -405,6 +405,7 @@ class DeviceJpegDecoder:
         self.group_wgs = int(os.environ.get("CAMA_JPEG_GROUP_WGS", 0)) or \
             self.WGS_PER_CU * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
         self.max_lanes = 16
+        self._copy_stream = None
         import threading
         self._lock = threading.Lock()      # lanes + stats: decode_async may run on a pump thread, result() on the consumer's
         self._lane = []
@@ -496,12 +497,11 @@ class DeviceJpegDecoder:
         import torch
         n = len(blobs)
         assert n >= 1
-        headers = []
-        for b in blobs:
-            try:
-                headers.append(parse_header_blob(b) if isinstance(b, ArenaBlob) else parse_header(b))
-            except Unsupported:
-                headers.append(None)
+        arena = blobs[0].arena if isinstance(blobs[0], ArenaBlob) else None
+        if arena is not None and n >= 2 and all(isinstance(b, ArenaBlob) and b.arena is arena for b in blobs) and \
+                all(blobs[k].off + blobs[k].n <= blobs[k + 1].off for k in range(n - 1)):
+            return self._decode_arena(blobs, arena, bgr, out, groups)
+        headers = [self._header_of(b) for b in blobs]
         size = None
         for h in headers:
             if h is not None:
@@ -519,23 +519,82 @@ class DeviceJpegDecoder:
             if ok:
                 # decode workgroups per image (from the stuffed length: a slight over-estimate), groups of ~group_wgs
                 wgs = np.array([-(-(headers[i].scan_end - headers[i].scan_start) // self.WG_BYTES) for i in ok])
-                cum = np.concatenate([[0], np.cumsum(wgs)])
-                if groups is not None:
-                    groups = max(1, min(int(groups), max(1, len(ok) // self.min_group)))
-                elif self.lanes is not None:
-                    groups = max(1, min(self.lanes, len(ok) // self.min_group))
-                else:
-                    groups = max(1, min(self.max_lanes, len(ok) // self.min_group, -(-int(cum[-1]) // self.group_wgs)))
-                # equal shares of the workgroups, not of the images (filling every group to group_wgs and leaving a small
-                # last one measures the same)
-                bounds = [0] + [int(np.searchsorted(cum, cum[-1] * g / groups, "left")) for g in range(1, groups)] + [len(ok)]
-                bounds = sorted(set(bounds))
-                groups = len(bounds) - 1
+                bounds = self._group_bounds(wgs, groups)
                 cur = torch.cuda.current_stream(self.device)
-                tickets = [self._submit([blobs[i] for i in ok[bounds[g]:bounds[g + 1]]],
-                                        [headers[i] for i in ok[bounds[g]:bounds[g + 1]]], ok[bounds[g]:bounds[g + 1]],
-                                        out, bgr, cur) for g in range(groups)]
+                tickets = [self._submit([blobs[i] for i in ok[lo:hi]], [headers[i] for i in ok[lo:hi]], ok[lo:hi], out, bgr, cur)
+                           for lo, hi in zip(bounds[:-1], bounds[1:])]
         return PendingDecode(self, blobs, ok, tickets, out, bgr)
+
+    @staticmethod
+    def _header_of(b):
+        try:
+            return parse_header_blob(b) if isinstance(b, ArenaBlob) else parse_header(b)
+        except Unsupported:
+            return None
+
+    def _group_bounds(self, wgs, groups):
+        """Split images with `wgs` decode workgroups each into groups: equal shares of the workgroups, not of the images
+        (filling every group to group_wgs and leaving a small last one measures the same)."""
+        cum = np.concatenate([[0], np.cumsum(wgs)])
+        n = len(wgs)
+        if groups is not None:
+            groups = max(1, min(int(groups), max(1, n // self.min_group)))
+        elif self.lanes is not None:
+            groups = max(1, min(self.lanes, n // self.min_group))
+        else:
+            groups = max(1, min(self.max_lanes, n // self.min_group, -(-int(cum[-1]) // self.group_wgs)))
+        bounds = [0] + [int(np.searchsorted(cum, cum[-1] * g / groups, "left")) for g in range(1, groups)] + [n]
+        return sorted(set(bounds))
+
+    def _decode_arena(self, blobs, arena, bgr, out, groups):
+        """decode_async for files that sit in ONE pinned arena in order (the pipeline's path).  Nothing about a file has to be
+        known to start moving it: the groups are cut by FILE size, every group's span goes to the device at once on the
+        decoder's copy stream (back to back, an event each), and the headers are parsed group by group while the bytes
+        travel -- the first kernels start after one group's parse instead of after the whole batch's (0.5 ms of a 5 ms batch
+        of 240), and a group's upload no longer queues behind the kernels of the group that used its stream before."""
+        import torch
+        n = len(blobs)
+        bounds = self._group_bounds(np.array([-(-b.n // self.WG_BYTES) for b in blobs]), groups)
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            cs = self._copy_stream
+            span0 = blobs[0].off
+            uploads = []
+            with torch.cuda.stream(cs):
+                dev = torch.empty(blobs[-1].off + blobs[-1].n - span0 + 16, dtype=torch.uint8, device=self.device)
+                for lo, hi in zip(bounds[:-1], bounds[1:]):
+                    a, b = blobs[lo].off, blobs[hi - 1].off + blobs[hi - 1].n
+                    dev[a - span0:b - span0].copy_(arena.buf[a:b], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(cs)
+                    a16 = (a - span0) & ~15                           # (cama_jpeg_find_restarts wants a 16-byte aligned start;
+                    uploads.append((dev[a16:b - span0], span0 + a16, ev))   # the bytes before `a` are nobody's scan)
+            tickets, ok, size, pending = [], [], None, []
+            for g, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+                headers = [self._header_of(b) for b in blobs[lo:hi]]
+                if size is None:
+                    for h in headers:
+                        if h is not None:
+                            size = (h.height, h.width)
+                            break
+                    if size is None:
+                        continue                                     # (nothing for the device in this group so far)
+                    if out is None:
+                        out = torch.empty((n,) + size + (3,), dtype=torch.uint8, device=self.device)
+                    assert tuple(out.shape) == (n,) + size + (3,) and out.is_contiguous() and out.dtype == torch.uint8
+                sel = [k for k, h in enumerate(headers) if h is not None and (h.height, h.width) == size]
+                if sel:
+                    slots = [lo + k for k in sel]
+                    ok += slots
+                    tickets.append(self._submit([blobs[i] for i in slots], [headers[k] for k in sel], slots, out, bgr, cur,
+                                                uploaded=uploads[g]))
+            if size is None:                                         # nothing for the device: all on the host
+                size = _host_decode(as_bytes(blobs[0]), bgr).shape[:2]
+                if out is None:
+                    out = torch.empty((n,) + tuple(size) + (3,), dtype=torch.uint8, device=self.device)
+        return PendingDecode(self, blobs, ok, tickets, out, bgr, keep=(dev, arena))
 
     def _lane_acquire(self):
         import torch
@@ -545,7 +604,7 @@ class DeviceJpegDecoder:
                     L["busy"] = True
                     return L
             L = {"stream": torch.cuda.Stream(device=self.device), "pinned": None, "scratch": None, "status": None,
-                 "busy": True}
+                 "desc": None, "busy": True}
             self._lane = [x for x in self._lane if x is not None] + [L]
             return L
 
@@ -610,7 +669,7 @@ class DeviceJpegDecoder:
         dri = np.asarray(dri)
         return parents, segs, dri[g][rg], [int(i) for i in dri[~good]]
 
-    def _submit(self, blobs, headers, slots, out, bgr, cur):
+    def _submit(self, blobs, headers, slots, out, bgr, cur, uploaded=None):
         """Pack, upload and launch the decode of one group on a free lane's stream; returns a ticket for _finish."""
         import torch
         L = self._lane_acquire()
@@ -623,7 +682,13 @@ class DeviceJpegDecoder:
         # library lays out its own aligned unstuffed copies)
         lens = np.array([h.scan_end - h.scan_start for h in headers], dtype=np.int64)
         arena = blobs[0].arena if isinstance(blobs[0], ArenaBlob) else None
-        if arena is not None and all(isinstance(b, ArenaBlob) and b.arena is arena for b in blobs) and \
+        if uploaded is not None:
+            # the group's span is already on its way (decode_async's copy stream): descriptors point into it
+            stream_dev, span_lo, upload_done = uploaded
+            span_hi = span_lo + stream_dev.numel()
+            base = np.array([b.off - span_lo + h.scan_start for b, h in zip(blobs, headers)], dtype=np.int64)
+            stream_bytes = int(span_hi - span_lo)
+        elif arena is not None and all(isinstance(b, ArenaBlob) and b.arena is arena for b in blobs) and \
                 all(blobs[k].off < blobs[k + 1].off for k in range(n - 1)):
             # the files already sit in pinned memory, in order: upload the span they occupy as it is (headers included,
             # ~0.2 % of the bytes) and point the descriptors into it -- no packing copy
@@ -645,8 +710,11 @@ class DeviceJpegDecoder:
         host_bytes = arena.np[span_lo:span_hi] if arena is not None else host[:stream_bytes]
         st = L["stream"]
         st.wait_stream(cur)                                # `out`, the tables and earlier work of the caller
-        with torch.cuda.stream(st):
-            stream_dev = pinned_src.to(self.device, non_blocking=True)
+        if uploaded is not None:
+            st.wait_event(upload_done)
+        else:
+            with torch.cuda.stream(st):
+                stream_dev = pinned_src.to(self.device, non_blocking=True)
         # descriptors: images without restart intervals first, as one vectorised block
         whole = [i for i, h in enumerate(headers) if not h.restart_interval]
         if whole:
@@ -684,7 +752,12 @@ class DeviceJpegDecoder:
             if L["scratch"] is None or L["scratch"].numel() < scratch_bytes:
                 L["scratch"] = None
                 L["scratch"] = torch.empty(scratch_bytes * 5 // 4, dtype=torch.uint8, device=self.device)
-            imgs_dev = torch.from_numpy(imgs.view(np.uint8).reshape(nd, -1)).to(self.device, non_blocking=True)
+            # (descriptors through a pinned buffer of the lane: a copy from pageable memory is staged synchronously)
+            raw = imgs.view(np.uint8).reshape(-1)
+            if L["desc"] is None or L["desc"].numel() < raw.size:
+                L["desc"] = torch.empty(max(raw.size * 2, 1 << 14), dtype=torch.uint8).pin_memory()
+            L["desc"][:raw.size].numpy()[:] = raw
+            imgs_dev = L["desc"][:raw.size].to(self.device, non_blocking=True).view(nd, -1)
             status = torch.empty(nd, dtype=torch.int32, device=self.device)
             target = out[slots[0]:slots[0] + n] if contiguous else \
                 torch.empty((n,) + tuple(out.shape[1:]), dtype=torch.uint8, device=self.device)
@@ -714,8 +787,9 @@ class DeviceJpegDecoder:
 
 
 class PendingDecode:
-    def __init__(self, dec, blobs, ok, tickets, out, bgr):
+    def __init__(self, dec, blobs, ok, tickets, out, bgr, keep=None):
         self.dec, self.blobs, self.ok, self.tickets, self.out, self.bgr = dec, blobs, ok, tickets, out, bgr
+        self._keep = keep                                  # (the batch's device copy of the arena span, until result())
         self._done = False
 
     def result(self):
@@ -743,5 +817,5 @@ class PendingDecode:
             # must not hand the block out again while the consumer's stream still reads it
             out.record_stream(cur)
         self._done = True
-        self.blobs = self.tickets = None
+        self.blobs = self.tickets = self._keep = None
         return out

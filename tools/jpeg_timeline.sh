@@ -1,8 +1,9 @@
-# kernel timeline of ONE decoded batch (240 photo-like images): tools/jpeg_timeline.sh
+# kernel timeline of ONE decoded batch (240 photo-like images): tools/jpeg_timeline.sh [tag] [jpeg_probe.py arguments]
 export TMPDIR=/tmp
 R=$PWD
-o=$R/gpurun_out/jpeg_tl
-(cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace --memory-copy-trace -d $o -o j -- python $R/tools/jpeg_probe.py --batch 240 --reps 3 > $o.log 2>&1)
+tag=${1:-default}; shift
+o=$R/gpurun_out/jpeg_tl_$tag
+(cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace --memory-copy-trace -d $o -o j -- python $R/tools/jpeg_probe.py --batch 240 --reps 3 "$@" > $o.log 2>&1)
 python - $o <<'PY'
 import csv, glob, sys, collections
 d = sys.argv[1]
@@ -16,7 +17,14 @@ for r in csv.DictReader(open(mc[0])) if mc else []:
 rows.sort()
 # the last batch = everything after the last k_jpeg_count that follows a gap: take the last 7 groups' kernels
 cnt = [i for i, r in enumerate(rows) if r[2].startswith("k_jpeg_count")]
-first = cnt[-7] if len(cnt) >= 7 else cnt[0]
+# a batch starts at a count kernel before which every earlier group has finished (as many colour kernels ended as count
+# kernels started): decode() returns only when all its groups are done
+col_end = sorted(r[1] for r in rows if r[2].startswith("k_jpeg_colour"))
+import bisect
+first = cnt[0]
+for rank, i in enumerate(cnt):
+    if bisect.bisect_right(col_end, rows[i][0]) == rank:
+        first = i
 # walk back over copies just before
 t0 = rows[first][0]
 sel = [r for r in rows[first:] ]
