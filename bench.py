@@ -65,6 +65,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+import cama_amd                # (first: the package's GPU_MAX_HW_QUEUES default must precede the first HIP call, cama_amd/__init__.py)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SWEEP_SCENES = 73              # BASELINE configs[2]: nuScenes v1.0-test
@@ -1146,6 +1147,7 @@ def main():
                                                          "(what every step did until round 4)")
         line["host_issue_us"] = dict(job.host_issue_us, note="rank 0: wall time of one step()'s issue on the host inside the K timed "
                                      "steps (the GPU is paced by the host whenever this approaches the step time)")
+        line["hw_queues"] = cama_amd.hw_queue_default()
         line["rank_affinity"] = {"cpus_per_rank": [int(x) for x in m[:, 19]], "first_cpu": [int(x) for x in m[:, 20]],
                                  "last_cpu": [int(x) for x in m[:, 21]], "gpu_numa_node": [int(x) for x in m[:, 22]],
                                  "bound": [bool(x) for x in m[:, 23]],

@@ -2443,10 +2443,9 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
     a.wg_total = (uint32_t *)(base + L.wg_total); a.coef = (int16_t *)(base + L.coef); a.dcd = (int16_t *)(base + L.dcd);
     a.planes = (uint8_t *)(base + L.planes); a.out = out; a.out_stride = (size_t)out_stride; a.bgr = bgr;
     a.status = status;
-    HIP_TRY(hipMemsetAsync(a.clean, 0, L.clean_bytes, s));
+    // one fill in front of the chain: the coefficients (only non-zero ones are stored).  The unstuffed copy's slack is cleared
+    // by k_jpeg_unstuff, the status words by k_jpeg_tilescan, and every block's DC difference is stored by k_jpeg_write.
     HIP_TRY(hipMemsetAsync(a.coef, 0, L.coef_elems * 2, s));
-    if (L.coef_elems) HIP_TRY(hipMemsetAsync(a.dcd, 0, L.coef_elems / 64 * 2, s));
-    HIP_TRY(hipMemsetAsync(status, 0, (size_t)n * 4, s));
     if (L.total_tiles) hipLaunchKernelGGL(k_jpeg_count, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
     hipLaunchKernelGGL(k_jpeg_tilescan, dim3((unsigned)n), dim3(256), 0, s, a);
     if (L.total_tiles) hipLaunchKernelGGL(k_jpeg_unstuff, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);

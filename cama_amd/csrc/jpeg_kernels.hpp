@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void k_jpeg_tilescan(JpegArgs a)
             run += v;
         }
         a.nbits[blockIdx.x] = (D.stream_len - run) * 8u;
+        a.status[blockIdx.x] = 0;                 // (k_jpeg_write raises it; no separate fill on the chain)
     }
     __syncthreads();
     uint32_t run = s_part[threadIdx.x];
@@ -188,6 +189,13 @@ __global__ __launch_bounds__(JPEG_TILE / 4) void k_jpeg_unstuff(JpegArgs a)
             if (m & (1u << k)) ++before;
             else dst[i - before] = (uint8_t)(bytes >> (8 * k));
         }
+    }
+    // The decoders read up to 35 bytes past a segment and expect zeros behind its last unstuffed byte: the image's last tile
+    // clears [unstuffed length, end of the segment's slot) -- as many bytes as were dropped + the slack, instead of a fill of
+    // the whole buffer in front of every group's chain (no other tile writes at or past the unstuffed length).
+    if (blockIdx.x - D.tile0 == D.ntile - 1u) {
+        const uint32_t from = a.nbits[img] >> 3, to = (D.stream_len + 64u + 15u) & ~15u;
+        for (uint32_t i = from + threadIdx.x; i < to; i += JPEG_TILE / 4) dst[i] = 0;
     }
 }
 
@@ -316,9 +324,12 @@ __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegSta
         // zigzag index of the coded coefficient (DC: 0) and the index after this symbol
         const uint32_t at = isac ? k + run : 0u;
         const uint32_t knext = isac ? (size ? at + 1u : (run == 15u ? k + 16u : 64u)) : 1u;
-        if (WRITE && size && at < 64u && block + nb < total_blocks) {
-            const uint32_t v = (hi << len) >> (32u - size);
-            const int32_t val = (v < (1u << (size - 1u))) ? (int32_t)v - (int32_t)((1u << size) - 1u) : (int32_t)v;
+        if (WRITE && (size | (isac ^ 1u)) && at < 64u && block + nb < total_blocks) {
+            // (a DC symbol stores its difference even when that is zero: the compact array needs no fill in front of the chain)
+            const uint32_t sz = size ? size : 1u;
+            const uint32_t v = (hi << len) >> (32u - sz);
+            int32_t val = (v < (1u << (sz - 1u))) ? (int32_t)v - (int32_t)((1u << sz) - 1u) : (int32_t)v;
+            val = size ? val : 0;
             // the DC difference goes to its own compact array: the prefix sum over a component's blocks (k_jpeg_dc) walked the
             // coefficient buffer with a 128-byte stride otherwise, every cache line of it once more (640 of a 4 500 us batch)
             if (isac) coef[(size_t)(block + nb) * 64 + c.zigzag[at]] = (int16_t)val;
@@ -714,7 +725,9 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
     }
     // Fixpoint rounds.  While many subsequences changed, every thread re-decodes its own; once at most
     // JPEG_WAVE_MAX are left (the serial chains), each is re-decoded by a whole wave (jpeg_decode_span_wave).
-    constexpr uint32_t JPEG_WAVE_MAX = 4;
+    // (a thread-mode round costs a whole subsequence's latency, 31-37 us, however few lanes take part; a wave walks one in 12.5:
+    // with four waves, eight left = two walks each = 25 us.  4 -> 8: +3 % decoder rate, profiles/r05_jpeg_decoder.txt)
+    constexpr uint32_t JPEG_WAVE_MAX = 8;
     __shared__ uint16_t s_list[JPEG_WG];
     __shared__ uint64_t s_start[JPEG_WAVE_MAX];
     __shared__ uint32_t s_wcount[JPEG_WG / 64];
