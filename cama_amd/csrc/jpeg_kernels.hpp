@@ -225,7 +225,11 @@ struct JpegWgCtx {
     const uint32_t *sync_ac;   // [2][1024]: used1 | kinc1 << 6 | used12 << 13 | kinc12 << 19 (0: code longer than 10 bits)
     const JpegHuffSet *G;      // global: the table set (slow path of a set whose long codes have no second level)
     const uint16_t *l2;        // LDS: second level, k_jpeg_write: (length << 8) | symbol, k_jpeg_sync: used | kinc << 6
-    uint32_t l2_adj[4];        // top << 16 | adj: table t's entry for 16-bit prefix p is l2[min(p, top) - adj]; JPEG_L2_ABSENT: slow path
+    // top << 16 | adj per table (0 = DC0, 1 = AC0, 2 = DC1, 3 = AC1): table t's entry for 16-bit prefix p is l2[min(p, top) - adj];
+    // JPEG_L2_ABSENT: slow path.  Four SCALARS, not an array: picked by lane-varying selectors, an array was placed in scratch
+    // memory and every code longer than 10 bits -- some lane of a wave has one nearly every step -- paid a scratch load
+    // (s_waitcnt vmcnt(0)) in front of its second-level lookup.
+    uint32_t adj0, adj1, adj2, adj3;
     uint32_t dc_mask, ac_mask; // bit b: Huffman table selector (0/1) of block b of the MCU
     uint32_t bpm;
     const uint8_t *zigzag;     // LDS copy of the zigzag -> natural order table
@@ -257,32 +261,43 @@ __device__ __forceinline__ uint32_t jpeg_symbol_long(const JpegHuffSet &H, uint3
     return jpeg_symbol_long_t(H.lim, H.valoff, H.vals, tab, window);
 }
 constexpr uint32_t JPEG_L2_ABSENT = 0xffffffffu;
-// per-table clamp and rebasing of the second level (wave-uniform), top << 16 | adj: l2[min(prefix16, top) - adj]
-__device__ __forceinline__ void jpeg_l2_adjust(const JpegHuffSet &G, uint32_t (&adj)[4])
+// per-table clamp and rebasing of the second level (wave-uniform: a scalar register each), top << 16 | adj: l2[min(prefix16, top) - adj]
+__device__ __forceinline__ uint32_t jpeg_l2_adjust1(const JpegHuffSet &G, int t)
 {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const uint32_t top = min(G.lim[t][5], 0xffffu);
-        adj[t] = G.l2_off[t] == JPEG_L2_NONE ? JPEG_L2_ABSENT
-                                             : (top << 16) | (((uint32_t)G.l2_first[t] << 6) - (uint32_t)G.l2_off[t]);
-    }
+    const uint32_t top = min(G.lim[t][5], 0xffffu);
+    const uint32_t v = G.l2_off[t] == JPEG_L2_NONE ? JPEG_L2_ABSENT
+                                                   : (top << 16) | (((uint32_t)G.l2_first[t] << 6) - (uint32_t)G.l2_off[t]);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+// The four values as scalar-register VALUES (read once per function, outside its loop): a lane-varying choice between struct
+// fields is turned into an indexed load by the compiler, which then keeps the whole context in scratch memory.
+struct JpegAdj { uint32_t a0, a1, a2, a3; };
+__device__ __forceinline__ JpegAdj jpeg_adj(const JpegWgCtx &c)
+{
+    return JpegAdj{(uint32_t)__builtin_amdgcn_readfirstlane((int)c.adj0), (uint32_t)__builtin_amdgcn_readfirstlane((int)c.adj1),
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)c.adj2), (uint32_t)__builtin_amdgcn_readfirstlane((int)c.adj3)};
+}
+__device__ __forceinline__ uint32_t jpeg_adj_of(const JpegAdj &A, uint32_t tab)      // tab: 0 = DC0, 1 = AC0, 2 = DC1, 3 = AC1
+{
+    const uint32_t lo = (tab & 1u) ? A.a1 : A.a0, hi = (tab & 1u) ? A.a3 : A.a2;
+    return (tab & 2u) ? hi : lo;
 }
 __device__ __forceinline__ uint32_t jpeg_l2_index(uint32_t adj, uint32_t window)
 {
     return min(window >> 16, adj >> 16) - (adj & 0xffffu);
 }
 // a code longer than 10 bits, in k_jpeg_write's form (length << 8 | symbol)
-__device__ __forceinline__ uint32_t jpeg_long_symbol(const JpegWgCtx &c, uint32_t tab, uint32_t window)
+__device__ __forceinline__ uint32_t jpeg_long_symbol(const JpegWgCtx &c, const JpegAdj &A, uint32_t tab, uint32_t window)
 {
-    const uint32_t adj = (tab & 2u) ? ((tab & 1u) ? c.l2_adj[3] : c.l2_adj[2]) : ((tab & 1u) ? c.l2_adj[1] : c.l2_adj[0]);
+    const uint32_t adj = jpeg_adj_of(A, tab);
     if (adj != JPEG_L2_ABSENT) return c.l2[jpeg_l2_index(adj, window)];
     return jpeg_symbol_long(*c.G, tab, window);
 }
 // the same in k_jpeg_sync's form (used | kinc << 6): its second level holds transition entries
 __device__ __forceinline__ uint32_t jpeg_sync_entry(uint32_t tab, uint32_t e);
-__device__ __forceinline__ uint32_t jpeg_long_entry(const JpegWgCtx &c, uint32_t tab, uint32_t window)
+__device__ __forceinline__ uint32_t jpeg_long_entry(const JpegWgCtx &c, const JpegAdj &A, uint32_t tab, uint32_t window)
 {
-    const uint32_t adj = (tab & 2u) ? ((tab & 1u) ? c.l2_adj[3] : c.l2_adj[2]) : ((tab & 1u) ? c.l2_adj[1] : c.l2_adj[0]);
+    const uint32_t adj = jpeg_adj_of(A, tab);
     if (adj != JPEG_L2_ABSENT) return c.l2[jpeg_l2_index(adj, window)];
     return jpeg_sync_entry(tab & 1u, jpeg_symbol_long(*c.G, tab, window));
 }
@@ -314,12 +329,23 @@ __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegSta
         w += 2;
     }
     const uint16_t *lut = &c.H->lut[0][0];
+    const JpegAdj A = jpeg_adj(c);
     while (pos < end) {
         const uint32_t isac = k ? 1u : 0u;
         const uint32_t tab = (((isac ? c.ac_mask : c.dc_mask) >> blk) & 1u) * 2u + isac;
         uint32_t e = lut[(tab << JPEG_LUT_BITS) + (hi >> (32 - JPEG_LUT_BITS))];
         const uint32_t next = jpeg_word(c, w);                     // refill word (used when lo runs dry)
-        if (e == 0u) e = jpeg_long_symbol(c, tab, hi);
+#ifdef JPEG_WRITE_PIN
+        {   // the second-level entry read beside the other two (as in jpeg_sync_span): some lane has a long code nearly every step
+            const uint32_t adj = jpeg_adj_of(A, tab);
+            const int32_t i2 = (int32_t)min(hi >> 16, adj >> 16) - (int32_t)(adj & 0xffffu);
+            uint32_t e2 = c.l2[max(i2, 0)];
+            asm volatile("" : "+v"(e2));
+            if (e == 0u) e = adj != JPEG_L2_ABSENT ? e2 : jpeg_symbol_long(*c.G, tab, hi);
+        }
+#else
+        if (e == 0u) e = jpeg_long_symbol(c, A, tab, hi);
+#endif
         const uint32_t len = e >> 8, size = e & 15u, run = (e >> 4) & 15u;
         // zigzag index of the coded coefficient (DC: 0) and the index after this symbol
         const uint32_t at = isac ? k + run : 0u;
@@ -426,6 +452,7 @@ __device__ __forceinline__ uint32_t jpeg_sync_span(const JpegWgCtx &c, JpegState
         w += 2;
     }
     const uint32_t bpm = c.bpm;
+    const JpegAdj A = jpeg_adj(c);
     while (pos < end) {
         // One round of FOUR independent LDS reads per step -- the DC entry, the AC entry, the second-level entry (as if the
         // code were longer than 10 bits) and the refill word -- then selects: the lanes of a wave are at different places of
@@ -437,14 +464,18 @@ __device__ __forceinline__ uint32_t jpeg_sync_span(const JpegWgCtx &c, JpegState
         const uint32_t sel = ((isdc ? c.dc_mask : c.ac_mask) >> blk) & 1u;
         const uint32_t at = (sel << JPEG_LUT_BITS) + peek;
         const uint32_t edc = c.sync_dc[at], eac = c.sync_ac[at];
-        const uint32_t adj = sel ? (isdc ? c.l2_adj[2] : c.l2_adj[3]) : (isdc ? c.l2_adj[0] : c.l2_adj[1]);
+        const uint32_t adj = sel ? (isdc ? A.a2 : A.a3) : (isdc ? A.a0 : A.a1);
         const int32_t i2 = (int32_t)min(hi >> 16, adj >> 16) - (int32_t)(adj & 0xffffu);   // (< 0: not a long code; absent: <= 0)
-        const uint32_t e2 = c.l2[max(i2, 0)];
+        uint32_t e2 = c.l2[max(i2, 0)];
+#ifndef JPEG_NO_PIN
+        asm volatile("" : "+v"(e2));                                 // (keeps the read HERE, beside the other three: the compiler
+                                                                    //  sank it into the long-code branch, a dependent LDS latency)
+#endif
         uint32_t e = isdc ? edc | (edc << 13) : eac;
         if (e == 0u) {
             e = e2 | (e2 << 13);
             if (adj == JPEG_L2_ABSENT) {                                // (a table set without a second level: never the usual files)
-                e = jpeg_long_entry(c, 2u * sel + (isdc ? 0u : 1u), hi);
+                e = jpeg_long_entry(c, A, 2u * sel + (isdc ? 0u : 1u), hi);
                 e |= e << 13;
             }
         }
@@ -490,6 +521,7 @@ __device__ __forceinline__ uint32_t jpeg_decode_span_wave(const JpegWgCtx &c, Jp
     end = (uint32_t)__builtin_amdgcn_readfirstlane((int)end);
     uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.pos), blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.blk),
              k = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.k), nb = 0;            // wave-uniform
+    const JpegAdj A = jpeg_adj(c);
     while (pos < end) {
         const uint32_t bp = pos + lane;
         const uint32_t w = (bp >> 5) - c.word0, sh = bp & 31u;
@@ -499,10 +531,10 @@ __device__ __forceinline__ uint32_t jpeg_decode_span_wave(const JpegWgCtx &c, Jp
         const uint32_t peek = win >> (32 - JPEG_LUT_BITS);
         uint32_t e0 = c.sync_dc[peek], e2 = c.sync_dc[(1u << JPEG_LUT_BITS) + peek];
         uint32_t e1 = c.sync_ac[peek] & 0x1fffu, e3 = c.sync_ac[(1u << JPEG_LUT_BITS) + peek] & 0x1fffu;
-        if (e0 == 0u) e0 = jpeg_long_entry(c, 0u, win);
-        if (e1 == 0u) e1 = jpeg_long_entry(c, 1u, win);
-        if (e2 == 0u) e2 = jpeg_long_entry(c, 2u, win);
-        if (e3 == 0u) e3 = jpeg_long_entry(c, 3u, win);
+        if (e0 == 0u) e0 = jpeg_long_entry(c, A, 0u, win);
+        if (e1 == 0u) e1 = jpeg_long_entry(c, A, 1u, win);
+        if (e2 == 0u) e2 = jpeg_long_entry(c, A, 2u, win);
+        if (e3 == 0u) e3 = jpeg_long_entry(c, A, 3u, win);
         // The walk, in scalar registers: a block's DC symbol, then its AC symbols under ONE table vector (chosen once per block
         // and window).  Bit offset and zigzag index advance in one add -- t = (off + 0x8000 - lim) | (k + 0x8000 - 64) << 16,
         // an AC entry re-packed as used | kinc << 16 -- and "window ran out or block ended" is one mask test (no field can
@@ -608,7 +640,7 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
     c.H = &S.H;
     c.G = a.huff + D.huff_set;
     c.l2 = S.H.l2;
-    jpeg_l2_adjust(*c.G, c.l2_adj);
+    c.adj0 = jpeg_l2_adjust1(*c.G, 0); c.adj1 = jpeg_l2_adjust1(*c.G, 1); c.adj2 = jpeg_l2_adjust1(*c.G, 2); c.adj3 = jpeg_l2_adjust1(*c.G, 3);
     c.sync_dc = nullptr; c.sync_ac = nullptr;
 }
 
@@ -656,7 +688,7 @@ __device__ __forceinline__ void jpeg_sync_setup(const JpegArgs &a, const cama_jp
     c.sync_ac = &S.ac[0][0];
     c.G = &G;
     c.l2 = S.l2;
-    jpeg_l2_adjust(G, c.l2_adj);
+    c.adj0 = jpeg_l2_adjust1(G, 0); c.adj1 = jpeg_l2_adjust1(G, 1); c.adj2 = jpeg_l2_adjust1(G, 2); c.adj3 = jpeg_l2_adjust1(G, 3);
 }
 
 #ifdef JPEG_TRACE

@@ -213,7 +213,10 @@ int cama_overlay_frames(const uint8_t *src, uint8_t *mosaic, int64_t N, int32_t 
  * third stream, beside the previous launch's projection and scatter (queued behind them it made the wait ~0.3 ms and the
  * binning stream, not the overlay, set the pace: 94 k -> 105 k frames/s on 12 scenes over three 10^6-vertex site maps); the
  * wait is ~0.1 ms, hidden by the overlays already queued; it makes such a call synchronous with the pre-pass, not with the
- * overlays.  An unplanned plain-overlay launch that moves >= 512 MiB waits on the host for its whole binning chain instead of queueing a
+ * overlays -- AND with whatever the caller had queued on `input_stream` before the call: the pre-pass reads the map, which is
+ * only known to be complete in that stream's order, so it waits for an event recorded there (a caller that queues long work
+ * on its input stream -- a download, a decode -- before a planned launch blocks for it; issue planned launches from a stream
+ * that carries only their inputs).  An unplanned plain-overlay launch that moves >= 512 MiB waits on the host for its whole binning chain instead of queueing a
  * stream-side wait in front of its overlay (option pipeline_host_wait, below).  cama_pipeline_info / cama_pipeline_bin_stats /
  * cama_pipeline_guard_check below report on it.
  *
