@@ -2362,7 +2362,7 @@ static int jpeg_layout(cama_jpeg_image *imgs, const cama_jpeg_image *cimgs, int3
 }
 
 extern "C" size_t cama_jpeg_image_bytes(void) { return sizeof(cama_jpeg_image); }
-extern "C" size_t cama_jpeg_huff_set_bytes(void) { return sizeof(JpegHuffSet); }
+extern "C" size_t cama_jpeg_huff_set_bytes(void) { return sizeof(JpegHuffRec); }
 
 extern "C" int cama_jpeg_plan(cama_jpeg_image *imgs, int32_t n, uint64_t stream_bytes, cama_jpeg_plan_info *info)
 {
@@ -2437,7 +2437,7 @@ extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, co
     char *base = (char *)scratch;
     JpegArgs a{};
     a.stream = stream; a.clean = (uint8_t *)(base + L.clean); a.imgs = imgs_dev; a.n = n;
-    a.huff = (const JpegHuffSet *)huff_sets; a.quant = quant_sets;
+    a.huff = (const JpegHuffRec *)huff_sets; a.quant = quant_sets;
     a.tile_count = (uint32_t *)(base + L.tile_count); a.tile_base = (uint32_t *)(base + L.tile_base);
     a.nbits = (uint32_t *)(base + L.nbits); a.E = (uint64_t *)(base + L.E); a.nb = (uint32_t *)(base + L.nb);
     a.wg_total = (uint32_t *)(base + L.wg_total); a.coef = (int16_t *)(base + L.coef); a.dcd = (int16_t *)(base + L.dcd);

@@ -53,12 +53,28 @@ struct JpegHuffSet {
 };
 static_assert(sizeof(JpegHuffSet) == 9632 + 2 * JPEG_L2_MAX && sizeof(JpegHuffSet) % 16 == 0, "JpegHuffSet layout");
 
+// What the host uploads per table set (cama_jpeg_huff_set_bytes()): the symbol tables, then the TRANSITION tables of the
+// synchronisation phases (jpeg_sync_span) in the order k_jpeg_sync keeps them in LDS -- one 14 KB block copy per workgroup.
+// Until round 5 every workgroup of k_jpeg_sync<1|2> derived them from the symbol tables itself (two dependent global reads per
+// entry, 19 us of a 230 us workgroup and of the 75-130 us ones of phase 2); they depend on the table set alone.
+struct JpegSyncSet {
+    uint16_t dc[2][1 << JPEG_LUT_BITS];    // used | kinc << 6
+    uint32_t ac[2][1 << JPEG_LUT_BITS];    // used1 | kinc1 << 6 | used12 << 13 | kinc12 << 19 (0: code longer than 10 bits)
+    uint16_t l2[JPEG_L2_MAX];              // transition entries of the codes of 11..16 bits (JpegHuffSet::l2)
+};
+struct JpegHuffRec {
+    JpegHuffSet set;
+    JpegSyncSet sync;
+};
+static_assert(sizeof(JpegSyncSet) == 14336 && sizeof(JpegHuffRec) == sizeof(JpegHuffSet) + sizeof(JpegSyncSet) &&
+              offsetof(JpegHuffRec, sync) % 16 == 0, "JpegHuffRec layout");
+
 struct JpegArgs {
     const uint8_t *stream;            // stuffed entropy segments
     uint8_t *clean;                   // unstuffed copy (same offsets)
     const cama_jpeg_image *imgs;      // device copy of the planned descriptors
     int n;
-    const JpegHuffSet *huff;
+    const JpegHuffRec *huff;
     const uint16_t *quant;            // [sets][3][64] natural order
     uint32_t *tile_count, *tile_base; // per unstuff tile
     uint32_t *nbits;                  // per image: bits in the unstuffed stream
@@ -335,17 +351,7 @@ __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegSta
         const uint32_t tab = (((isac ? c.ac_mask : c.dc_mask) >> blk) & 1u) * 2u + isac;
         uint32_t e = lut[(tab << JPEG_LUT_BITS) + (hi >> (32 - JPEG_LUT_BITS))];
         const uint32_t next = jpeg_word(c, w);                     // refill word (used when lo runs dry)
-#ifdef JPEG_WRITE_PIN
-        {   // the second-level entry read beside the other two (as in jpeg_sync_span): some lane has a long code nearly every step
-            const uint32_t adj = jpeg_adj_of(A, tab);
-            const int32_t i2 = (int32_t)min(hi >> 16, adj >> 16) - (int32_t)(adj & 0xffffu);
-            uint32_t e2 = c.l2[max(i2, 0)];
-            asm volatile("" : "+v"(e2));
-            if (e == 0u) e = adj != JPEG_L2_ABSENT ? e2 : jpeg_symbol_long(*c.G, tab, hi);
-        }
-#else
-        if (e == 0u) e = jpeg_long_symbol(c, A, tab, hi);
-#endif
+        if (e == 0u) e = jpeg_long_symbol(c, A, tab, hi);   // (read beside the others as in jpeg_sync_span: measured, no gain here)
         const uint32_t len = e >> 8, size = e & 15u, run = (e >> 4) & 15u;
         // zigzag index of the coded coefficient (DC: 0) and the index after this symbol
         const uint32_t at = isac ? k + run : 0u;
@@ -390,7 +396,7 @@ __device__ __forceinline__ uint32_t jpeg_decode_span(const JpegWgCtx &c, JpegSta
 
 // ---- the synchronisation phases' own decoder (round 5) --------------------------------------------------------------
 // k_jpeg_sync<1|2> never need a coefficient's VALUE: only how many bits a symbol takes and where it leaves the zigzag index.
-// Their workgroups therefore build TRANSITION tables in LDS instead of copying the symbol LUT (jpeg_sync_tables):
+// Their workgroups therefore keep TRANSITION tables in LDS instead of the symbol LUT (JpegSyncSet, built by the host):
 //     used = code length + magnitude bits (6 bits)       kinc: the zigzag index after the symbol is k + kinc (7 bits;
 //                                                               DC: 1; AC with a value: run + 1; ZRL: 16; EOB: 64)
 // -- the same state transitions as jpeg_decode_span (T.81 F.2.2), with "k + kinc >= 64" as the one end-of-block test: ~30
@@ -406,34 +412,6 @@ __device__ __forceinline__ uint32_t jpeg_sync_entry(uint32_t tab, uint32_t e)   
     const uint32_t len = e >> 8, size = e & 15u, run = (e >> 4) & 15u;
     const uint32_t kinc = (tab & 1u) ? (size ? run + 1u : (run == 15u ? 16u : 64u)) : 1u;
     return (len + size) | (kinc << 6);
-}
-
-// the workgroup's transition tables from the image's table set in global memory; barrier after
-__device__ __forceinline__ void jpeg_sync_tables(const JpegHuffSet &G, uint16_t (*dc)[1 << JPEG_LUT_BITS],
-                                                 uint32_t (*ac)[1 << JPEG_LUT_BITS])
-{
-    constexpr uint32_t NLUT = 1u << JPEG_LUT_BITS;
-    for (uint32_t i = threadIdx.x; i < 2u * NLUT; i += JPEG_WG) {
-        const uint32_t t = i >> JPEG_LUT_BITS, x = i & (NLUT - 1u);
-        const uint32_t e = G.lut[2u * t][x];
-        dc[t][x] = e ? (uint16_t)jpeg_sync_entry(0u, e) : (uint16_t)0u;
-        const uint32_t e1 = G.lut[2u * t + 1u][x];
-        uint32_t out = 0u;
-        if (e1) {
-            const uint32_t s1 = jpeg_sync_entry(1u, e1), u1 = s1 & 63u, k1 = s1 >> 6;
-            uint32_t s12 = s1;
-            if (k1 != 64u && u1 < (uint32_t)JPEG_LUT_BITS) {
-                const uint32_t e2 = G.lut[2u * t + 1u][(x << u1) & (NLUT - 1u)];      // the bits behind symbol 1, zero-padded
-                if (e2 && (e2 >> 8) <= (uint32_t)JPEG_LUT_BITS - u1) {                 // its code lies inside the known bits
-                    const uint32_t s2 = jpeg_sync_entry(1u, e2);
-                    const uint32_t u12 = u1 + (s2 & 63u), k12 = k1 + (s2 >> 6);
-                    if (u12 <= 31u) s12 = u12 | (k12 << 6);                          // (the bit window advances <= 31 bits a step)
-                }
-            }
-            out = s1 | (s12 << 13);
-        }
-        ac[t][x] = out;
-    }
 }
 
 // every symbol that STARTS in [s.pos, end), state only; c.sync_dc / c.sync_ac hold the transition tables
@@ -602,9 +580,18 @@ __device__ __forceinline__ void jpeg_wg_stream(const JpegArgs &a, const cama_jpe
     c.nwords = nwords_img;
 #else
     const uint32_t w0 = lw * JPEG_WG * JPEG_SUB_WORDS;
-    for (uint32_t i = threadIdx.x; i < JPEG_WG * JPEG_SUB_WORDS + 8; i += JPEG_WG) {
+    // four words per load (clean_off and w0 are multiples of four words; the slot of a segment is readable 64 bytes past its
+    // end, nwords_img ends 35 past it at most): 9 loads per thread instead of 33
+    const uint4 *g4 = reinterpret_cast<const uint4 *>(g + w0);
+    for (uint32_t i = threadIdx.x * 4u; i < JPEG_WG * JPEG_SUB_WORDS + 8; i += JPEG_WG * 4u) {
         const uint32_t w = w0 + i;
-        words[i + (i >> JPEG_SUB_SHIFT)] = w < nwords_img ? __builtin_bswap32(g[w]) : 0u;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (w < nwords_img) v = g4[i >> 2];
+        uint32_t *d = &words[i + (i >> JPEG_SUB_SHIFT)];               // (i % 4 == 0: the four words share one pad offset)
+        d[0] = w < nwords_img ? __builtin_bswap32(v.x) : 0u;
+        d[1] = w + 1u < nwords_img ? __builtin_bswap32(v.y) : 0u;
+        d[2] = w + 2u < nwords_img ? __builtin_bswap32(v.z) : 0u;
+        d[3] = w + 3u < nwords_img ? __builtin_bswap32(v.w) : 0u;
     }
     c.words = words;
     c.word0 = w0;
@@ -627,7 +614,7 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
                                               JpegWgCtx &c)
 {
     // tables
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.huff + D.huff_set);
+    const uint4 *src = reinterpret_cast<const uint4 *>(&a.huff[D.huff_set].set);
     uint4 *dst = reinterpret_cast<uint4 *>(&S.H);
     for (uint32_t i = threadIdx.x; i < sizeof(JpegHuffSet) / 16; i += JPEG_WG) dst[i] = src[i];
 #ifndef JPEG_WORDS_GLOBAL
@@ -638,17 +625,16 @@ __device__ __forceinline__ void jpeg_wg_setup(const JpegArgs &a, const cama_jpeg
     if (threadIdx.x < 64) S.zigzag[threadIdx.x] = c_jpeg_zigzag[threadIdx.x];
     c.zigzag = S.zigzag;
     c.H = &S.H;
-    c.G = a.huff + D.huff_set;
+    c.G = &a.huff[D.huff_set].set;
     c.l2 = S.H.l2;
     c.adj0 = jpeg_l2_adjust1(*c.G, 0); c.adj1 = jpeg_l2_adjust1(*c.G, 1); c.adj2 = jpeg_l2_adjust1(*c.G, 2); c.adj3 = jpeg_l2_adjust1(*c.G, 3);
     c.sync_dc = nullptr; c.sync_ac = nullptr;
 }
 
-// k_jpeg_sync's LDS: transition tables (jpeg_sync_tables) instead of the symbol LUT -- 51.9 KB, three workgroups per CU
+// k_jpeg_sync's LDS: transition tables (JpegSyncSet, copied from the table set's record) instead of the symbol LUT -- 51.9 KB,
+// three workgroups per CU
 struct JpegSyncShared {
-    uint16_t dc[2][1 << JPEG_LUT_BITS];
-    uint32_t ac[2][1 << JPEG_LUT_BITS];
-    uint16_t l2[JPEG_L2_MAX];              // transition entries of the codes of 11..16 bits (JpegHuffSet::l2)
+    JpegSyncSet T;
 #ifndef JPEG_WORDS_GLOBAL
     uint32_t words[JPEG_WG * JPEG_SUB_WORDS + JPEG_WG + 40];   // one pad word per subsequence: lane stride odd
 #endif
@@ -661,21 +647,12 @@ static_assert(sizeof(JpegSyncShared) <= 52 * 1024, "three k_jpeg_sync workgroups
 __device__ __forceinline__ void jpeg_sync_setup(const JpegArgs &a, const cama_jpeg_image &D, uint32_t lw, JpegSyncShared &S,
                                                 JpegWgCtx &c)
 {
-    const JpegHuffSet &G = a.huff[D.huff_set];
-    jpeg_sync_tables(G, S.dc, S.ac);
-    {   // second level: table t's entries are l2[l2_off[t], l2_off[t+1]) (tables without one are skipped by the host's layout)
-        uint32_t lo[4], hi[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            lo[t] = G.l2_off[t];
-            hi[t] = (lo[t] == JPEG_L2_NONE || G.l2_first[t] == 1024u)
-                        ? 0u : lo[t] + min(G.lim[t][5], 0xffffu) - ((uint32_t)G.l2_first[t] << 6) + 1u;
-        }
-        for (uint32_t i = threadIdx.x; i < (uint32_t)JPEG_L2_MAX; i += JPEG_WG) {
-            const uint32_t ac = ((i >= lo[1] && i < hi[1]) || (i >= lo[3] && i < hi[3])) ? 1u : 0u;
-            const uint32_t e = G.l2[i];
-            S.l2[i] = e ? (uint16_t)jpeg_sync_entry(ac, e) : (uint16_t)0u;
-        }
+    const JpegHuffRec &R = a.huff[D.huff_set];
+    const JpegHuffSet &G = R.set;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(&R.sync);
+        uint4 *dst = reinterpret_cast<uint4 *>(&S.T);
+        for (uint32_t i = threadIdx.x; i < sizeof(JpegSyncSet) / 16; i += JPEG_WG) dst[i] = src[i];
     }
 #ifndef JPEG_WORDS_GLOBAL
     jpeg_wg_stream(a, D, lw, S.words, c);
@@ -684,10 +661,10 @@ __device__ __forceinline__ void jpeg_sync_setup(const JpegArgs &a, const cama_jp
 #endif
     c.H = nullptr;
     c.zigzag = nullptr;
-    c.sync_dc = &S.dc[0][0];
-    c.sync_ac = &S.ac[0][0];
+    c.sync_dc = &S.T.dc[0][0];
+    c.sync_ac = &S.T.ac[0][0];
     c.G = &G;
-    c.l2 = S.l2;
+    c.l2 = S.T.l2;
     c.adj0 = jpeg_l2_adjust1(G, 0); c.adj1 = jpeg_l2_adjust1(G, 1); c.adj2 = jpeg_l2_adjust1(G, 2); c.adj3 = jpeg_l2_adjust1(G, 3);
 }
 

@@ -31,7 +31,9 @@ LUT_BITS = 10
 L2_MAX, L2_NONE = 1024, 0xFFFF
 HUFF_DTYPE = np.dtype([("lut", "<u2", (4, 1 << LUT_BITS)), ("lim", "<u4", (4, 8)), ("valoff", "<i4", (4, 17)),
                        ("vals", "u1", (4, 256)), ("l2_first", "<u2", (4,)), ("l2_off", "<u2", (4,)),
-                       ("l2", "<u2", (L2_MAX,))])                                             # == JpegHuffSet
+                       ("l2", "<u2", (L2_MAX,)),                                              # == JpegHuffSet, then
+                       ("sync_dc", "<u2", (2, 1 << LUT_BITS)), ("sync_ac", "<u4", (2, 1 << LUT_BITS)),
+                       ("sync_l2", "<u2", (L2_MAX,))])                                        # JpegSyncSet (== JpegHuffRec)
 
 _ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20,
                     13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52,
@@ -275,7 +277,52 @@ def build_huff_set(huff):
                 rec["lim"][t, l - LUT_BITS - 1] = code << (16 - l)
             code <<= 1
     _second_level(rec)
+    _sync_tables(rec)
     return rec
+
+
+def _sync_entry(is_ac, e):
+    """Transition entry of a symbol entry e = (length << 8) | symbol, e != 0 (array): bits consumed | zigzag advance << 6 -- DC: 1;
+    AC with a value: run + 1; ZRL: 16; EOB: 64 (T.81 F.2.2; jpeg_kernels.hpp: jpeg_sync_entry)."""
+    e = np.asarray(e, np.int64)
+    ln, size, run = e >> 8, e & 15, (e >> 4) & 15
+    kinc = np.where(size != 0, run + 1, np.where(run == 15, 16, 64)) if is_ac else np.ones_like(e)
+    return (ln + size) | (kinc << 6)
+
+
+def _sync_tables(rec):
+    """The synchronisation phases' tables (jpeg_kernels.hpp: JpegSyncSet, jpeg_sync_span): they only need a symbol's bit count
+    and where it leaves the zigzag index.  An AC entry also carries the symbol AFTER it when that one's code lies inside the
+    10 known bits too and the first does not end the block: used1 | kinc1 << 6 | used12 << 13 | kinc12 << 19 (used12 = used1,
+    kinc12 = kinc1: no second symbol).  They depend on the table set alone, so they are built here, once per set, and every
+    workgroup copies them (until round 5 every workgroup derived them on the device)."""
+    n = 1 << LUT_BITS
+    x = np.arange(n, dtype=np.int64)
+    for t in range(2):
+        e = rec["lut"][2 * t].astype(np.int64)
+        rec["sync_dc"][t] = np.where(e != 0, _sync_entry(False, np.maximum(e, 1)), 0)
+        lut = rec["lut"][2 * t + 1].astype(np.int64)
+        e1 = lut
+        s1 = _sync_entry(True, np.maximum(e1, 1))
+        u1, k1 = s1 & 63, s1 >> 6
+        first = (e1 != 0) & (k1 != 64) & (u1 < LUT_BITS)
+        e2 = lut[(x << np.where(first, u1, 0)) & (n - 1)]                  # the bits behind symbol 1, zero-padded
+        second = first & (e2 != 0) & ((e2 >> 8) <= LUT_BITS - u1)           # its code lies inside the known bits
+        s2 = _sync_entry(True, np.maximum(e2, 1))
+        u12, k12 = u1 + (s2 & 63), k1 + (s2 >> 6)
+        second &= u12 <= 31                                                # (the bit window advances <= 31 bits a step)
+        s12 = np.where(second, u12 | (k12 << 6), s1)
+        rec["sync_ac"][t] = np.where(e1 != 0, s1 | (s12 << 13), 0)
+    # second level: table t's entries are l2[l2_off[t], +its span); AC tables are 1 and 3
+    l2 = rec["l2"].astype(np.int64)
+    is_ac = np.zeros(L2_MAX, bool)
+    for t in (1, 3):
+        if int(rec["l2_off"][t]) != L2_NONE and int(rec["l2_first"][t]) != n:
+            lo = int(rec["l2_off"][t])
+            hi = lo + min(int(rec["lim"][t, 5]), 0xFFFF) - (int(rec["l2_first"][t]) << 6) + 1
+            is_ac[lo:hi] = True
+    safe = np.maximum(l2, 1)
+    rec["sync_l2"] = np.where(l2 != 0, np.where(is_ac, _sync_entry(True, safe), _sync_entry(False, safe)), 0)
 
 
 def long_symbol(rec, t, w16):

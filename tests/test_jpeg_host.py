@@ -66,6 +66,50 @@ def test_header_and_tables_agree_with_the_oracle(kw):
     assert at <= PJ.L2_MAX and (rec["l2"][:at] != 0).all() and (rec["l2"][at:] == 0).all()
 
 
+def _sync_entry_scalar(is_ac, e):
+    """T.81 F.2.2 state transition of one symbol entry (length << 8 | symbol): bits consumed | zigzag advance << 6."""
+    ln, size, run = e >> 8, e & 15, (e >> 4) & 15
+    kinc = ((run + 1) if size else (16 if run == 15 else 64)) if is_ac else 1
+    return (ln + size) | (kinc << 6)
+
+
+@pytest.mark.parametrize("kw", [dict(quality=90, subsampling=2), dict(quality=40, subsampling=0, optimize=True),
+                                dict(quality=100, subsampling=1, optimize=True)])
+def test_transition_tables_of_the_sync_phases_follow_the_symbol_tables(kw):
+    """JpegSyncSet (built on the host since round 5, vectorised) against an entry-by-entry walk of its definition: a DC entry is
+    its symbol's transition; an AC entry carries the symbol after it when that code lies inside the 10 known bits, the first
+    does not end the block and both together consume at most 31 bits; the second level holds single transitions."""
+    rec = PJ.build_huff_set(PJ.parse_header(encode(synth_image(67, 131, "noise", seed=4), **kw)).huff)
+    n, two = 1 << PJ.LUT_BITS, 0
+    for t in range(2):
+        for x in range(n):
+            e = int(rec["lut"][2 * t, x])
+            assert int(rec["sync_dc"][t, x]) == (_sync_entry_scalar(False, e) if e else 0)
+            e1 = int(rec["lut"][2 * t + 1, x])
+            if not e1:
+                assert int(rec["sync_ac"][t, x]) == 0
+                continue
+            s1 = _sync_entry_scalar(True, e1)
+            s12, u1, k1 = s1, s1 & 63, s1 >> 6
+            if k1 != 64 and u1 < PJ.LUT_BITS:
+                e2 = int(rec["lut"][2 * t + 1, (x << u1) & (n - 1)])
+                if e2 and (e2 >> 8) <= PJ.LUT_BITS - u1:
+                    s2 = _sync_entry_scalar(True, e2)
+                    if u1 + (s2 & 63) <= 31:
+                        s12 = (u1 + (s2 & 63)) | ((k1 + (s2 >> 6)) << 6)
+                        two += 1
+            assert int(rec["sync_ac"][t, x]) == s1 | (s12 << 13), (t, x)
+    assert two > 100                                                     # (the short codes do pair up)
+    for t in range(4):
+        if int(rec["l2_first"][t]) == n:
+            continue
+        lo = int(rec["l2_off"][t])
+        hi = lo + min(int(rec["lim"][t, 5]), 0xFFFF) - (int(rec["l2_first"][t]) << 6) + 1
+        for i in range(lo, hi):
+            assert int(rec["sync_l2"][i]) == _sync_entry_scalar(t & 1, int(rec["l2"][i])), (t, i)
+    assert (rec["sync_l2"][(rec["l2"] == 0)] == 0).all()
+
+
 def test_table_set_whose_long_codes_do_not_fit_the_second_level_says_so():
     """A DHT with 200 codes of 16 bits below a short prefix: its second level would need > L2_MAX entries -> that table is
     left to the per-length limits (l2_off = L2_NONE), the others keep theirs."""
