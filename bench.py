@@ -757,6 +757,10 @@ def self_launch(args, argv):
     env = dict(os.environ)
     if share and have < args.gpus:
         env.setdefault("CAMA_BENCH_BACKEND", "gloo")       # RCCL refuses two ranks on one device
+        # ranks that share a GPU also share its hardware queue slots (32; beyond them the firmware time-slices queues and
+        # everything crawls): the package's default of 8 per process is for one process per GPU
+        if "set by cama_amd" in (cama_amd.hw_queue_default() or ""):
+            env["GPU_MAX_HW_QUEUES"] = str(max(2, min(cama_amd.HW_QUEUES, 24 * max(have, 1) // args.gpus)))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",

@@ -28,3 +28,11 @@ CAMA_BENCH_SHARE_GPU=1 timeout 1500 python bench.py --gpus 8 --steps 2 --warmup 
 timeout 600 python tools/cold_sweep.py --scenes 12 --frames 40 --label final --json gpurun_out/${tag}_cold_final.json > gpurun_out/${tag}_cold_final.txt 2>&1
 CAMA_FRAME_CACHE_BYTES=0 timeout 600 python tools/cold_sweep.py --scenes 12 --frames 40 --label final_nocache --json gpurun_out/${tag}_cold_final_nocache.json > gpurun_out/${tag}_cold_final_nocache.txt 2>&1
 grep -h "^{" gpurun_out/${tag}_cold_final.txt gpurun_out/${tag}_cold_final_nocache.txt | cut -c1-400
+# the device JPEG decoder: per-kernel time of a 240-image batch, the decoder-alone rate with the package's eight hardware queues and
+# with the HIP runtime's four, and the verbatim main.py loop (bgr24 sink) with and without the decoded-frame cache
+bash tools/jpeg_kernel_stats.sh > gpurun_out/${tag}_jpeg_kernel_stats.txt 2>&1
+python tools/jpeg_probe.py --batch 240 --reps 5 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_jpeg_probe.txt
+GPU_MAX_HW_QUEUES=4 python tools/jpeg_probe.py --batch 240 --reps 5 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_jpeg_probe_4queues.txt
+CAMA_VIDEO_SINK=null timeout 300 python tools/demo_loop_probe.py --frames 240 --passes 6 2>&1 | grep "main.py loop\|steady state over" > gpurun_out/${tag}_demo_loop.txt
+CAMA_FRAME_CACHE_BYTES=0 CAMA_VIDEO_SINK=null timeout 300 python tools/demo_loop_probe.py --frames 240 --passes 6 2>&1 | grep "main.py loop\|steady state over" > gpurun_out/${tag}_demo_loop_nocache.txt
+grep -h "images/s =\|steady state over" gpurun_out/${tag}_jpeg_probe.txt gpurun_out/${tag}_jpeg_probe_4queues.txt gpurun_out/${tag}_demo_loop.txt gpurun_out/${tag}_demo_loop_nocache.txt
