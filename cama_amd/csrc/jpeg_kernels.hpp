@@ -5,7 +5,9 @@
 // upsampling, 16-bit fixed-point YCbCr->RGB), pinned by oracle/jpeg_oracle.py == Pillow's libjpeg-turbo.
 //
 // Stages, all images of a batch per launch:
-//   k_jpeg_count / k_jpeg_tilescan / k_jpeg_unstuff   remove 0xFF00 byte stuffing (count, per-image scan, compact)
+//   k_jpeg_count / k_jpeg_tilescan / k_jpeg_unstuff   remove 0xFF00 byte stuffing (count, per-image scan, compact); the scan
+//                    also clears the image's status word and the compaction the slack behind the unstuffed bytes -- the chain
+//                    has ONE fill in front of it (the coefficients: only non-zero ones are stored)
 //   k_jpeg_sync<1>   Huffman decode of every 1024-bit subsequence from a SPECULATIVE start (its first bit, block 0,
 //                    DC expected), then a fixpoint inside each 256-subsequence workgroup: a subsequence is re-decoded
 //                    from its predecessor's end state until no end state changes.  Huffman streams self-synchronise,
