@@ -248,6 +248,28 @@ def test_full_size_rig(dec):
         assert np.array_equal(got[k][:, :, ::-1], pillow_rgb(b)), k
 
 
+def test_decode_does_not_depend_on_what_the_scratch_held(dec):
+    """The chain has one fill in front of it (the coefficients); the slack behind the unstuffed bytes, the status words and the
+    DC differences are written by the kernels themselves.  Poisoned lane scratch (every byte 0xA5 / 0xFF) must give the same
+    pixels and no flagged image -- for streams that end anywhere inside a dword, with and without stuffed bytes."""
+    import torch
+    sets = [[encode(synth_image(h, w, kind, seed=h + w), quality=q, subsampling=sub)
+             for kind in ("noise", "edges") for q, sub in ((100, 0), (75, 2))] for (h, w) in ((203, 317), (90, 160), (17, 23))]
+    for poison in (0xA5, 0xFF, 0x00):
+        for blobs in sets:                                               # (one size per batch)
+            dec.decode(blobs[:2], bgr=False)                             # (make sure a lane with scratch exists)
+            torch.cuda.synchronize()
+            for lane in dec._lane:
+                if lane is not None and lane["scratch"] is not None:
+                    lane["scratch"].fill_(poison)
+            torch.cuda.synchronize()
+            before = dict(dec.stats)
+            got = dec.decode(blobs, bgr=False).cpu().numpy()
+            assert dec.stats["device"] - before["device"] == len(blobs), (poison, dec.stats)
+            for k, b in enumerate(blobs):
+                assert np.array_equal(got[k], pillow_rgb(b)), (poison, k)
+
+
 def test_clip_frame_source_device_decode_equals_host_decode(tmp_path):
     """ClipFrameSource (the demo's ingest): JPEG bytes -> device decoder gives the same BGR frames as the host
     decoder threads, for a synthetic clip with 6 cameras."""
