@@ -125,6 +125,11 @@ class DeviceMap:
         self.bounds, self.extent_xy = None, (0.0, 0.0)
         if not self.N or os.environ.get("CAMA_NO_BOUNDS"):
             return
+        if self.N < BOUNDS_MIN_VERTS:
+            # every reader of the index asks for N >= BOUNDS_MIN_VERTS first: a clip-sized map (the usual 10^4 vertices) skips
+            # the launch, the two reductions and -- what costs -- the blocking read-back of the extent (~1 ms of a new clip's
+            # first frame, twice per scene: tools/cold_first_frame_profile.py)
+            return
         L = _lib.lib()
         blk = L.cama_map_bounds_block()
         device = self.soa.device
