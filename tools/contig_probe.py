@@ -36,7 +36,7 @@ def probe(src, dst, reps):
     return ms.value
 
 
-for contig in (False, True, False, True):
+for contig in ([False] if os.environ.get("PROBE_PLAIN_ONLY") else [False, True, False, True]):
     try:
         pairs = [(alloc(contig), alloc(contig)) for _ in range(K)]
     except RuntimeError as e:
