@@ -118,17 +118,42 @@ class DeviceMap:
             self.sorted_key = torch.from_numpy(np.ascontiguousarray(key)).to(device)
         self._index()
 
-    def _index(self):
+    # `bounds` / `extent_xy`: plain attributes once the index exists; a clip-sized map computes it on first access
+    _index_pending = False
+
+    @property
+    def bounds(self):
+        if self._index_pending:
+            self._index(force=True)
+        return self._bounds
+
+    @bounds.setter
+    def bounds(self, value):
+        self._bounds = value
+        self._index_pending = False
+
+    @property
+    def extent_xy(self):
+        if self._index_pending:
+            self._index(force=True)
+        return self._extent_xy
+
+    @extent_xy.setter
+    def extent_xy(self, value):
+        self._extent_xy = value
+
+    def _index(self, force=False):
         """Spatial index for the fused render's crop step: per-block AABBs of the buffer it reads (cama_map_bounds,
         include/cama_hip.h) + the map's overall XY extent (host), which decides whether the index is worth using."""
         torch = _torch()
         self.bounds, self.extent_xy = None, (0.0, 0.0)
         if not self.N or os.environ.get("CAMA_NO_BOUNDS"):
             return
-        if self.N < BOUNDS_MIN_VERTS:
-            # every reader of the index asks for N >= BOUNDS_MIN_VERTS first: a clip-sized map (the usual 10^4 vertices) skips
-            # the launch, the two reductions and -- what costs -- the blocking read-back of the extent (~1 ms of a new clip's
-            # first frame, twice per scene: tools/cold_first_frame_profile.py)
+        if self.N < BOUNDS_MIN_VERTS and not force:
+            # the render path asks for N >= BOUNDS_MIN_VERTS before it looks at the index: a clip-sized map (the usual 10^4
+            # vertices) leaves the launch, the two reductions and -- what costs -- the blocking read-back of the extent (~1 ms
+            # of a new clip's first frame, twice per scene: tools/cold_first_frame_profile.py) to whoever asks first (`bounds`)
+            self._index_pending = True
             return
         L = _lib.lib()
         blk = L.cama_map_bounds_block()
@@ -160,7 +185,7 @@ class DeviceMap:
         block bounds (per-camera / crop culling of whole vertex blocks) whenever the map has an index and is big enough
         for the one-thread-per-block pre-pass to pay; the work-list flag only for maps that are site-sized against `crop`."""
         bounds, flags = None, 0
-        if crop is not None and getattr(self, "bounds", None) is not None and self.N >= BOUNDS_MIN_VERTS:
+        if crop is not None and self.N >= BOUNDS_MIN_VERTS and getattr(self, "bounds", None) is not None:
             bounds = self.bounds.data_ptr()
             if self.site_sized(crop):
                 flags = _lib.BIN_WORKLIST
@@ -1310,7 +1335,7 @@ class Engine:
         memo = self.__dict__.setdefault("_fpc_memo", {})
         if memo_key in memo:                    # (the free-memory probe is a driver call: once per shape is enough)
             return memo[memo_key]
-        planned = (self.alpha256 == 256 and getattr(dmap, "bounds", None) is not None and dmap.N >= BOUNDS_MIN_VERTS
+        planned = (self.alpha256 == 256 and dmap.N >= BOUNDS_MIN_VERTS and getattr(dmap, "bounds", None) is not None
                    and dmap.site_sized(self.crop) and not os.environ.get("CAMA_NO_PLAN"))
         if planned and resident_frames:
             # site-sized maps are PLANNED (the pipeline sizes its own stamp scratch from what survives the launch's cull:
