@@ -447,10 +447,8 @@ __device__ __forceinline__ uint32_t jpeg_sync_span(const JpegWgCtx &c, JpegState
         const uint32_t adj = sel ? (isdc ? A.a2 : A.a3) : (isdc ? A.a0 : A.a1);
         const int32_t i2 = (int32_t)min(hi >> 16, adj >> 16) - (int32_t)(adj & 0xffffu);   // (< 0: not a long code; absent: <= 0)
         uint32_t e2 = c.l2[max(i2, 0)];
-#ifndef JPEG_NO_PIN
         asm volatile("" : "+v"(e2));                                 // (keeps the read HERE, beside the other three: the compiler
                                                                     //  sank it into the long-code branch, a dependent LDS latency)
-#endif
         uint32_t e = isdc ? edc | (edc << 13) : eac;
         if (e == 0u) {
             e = e2 | (e2 << 13);
