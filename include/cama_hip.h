@@ -499,7 +499,10 @@ int cama_overlay_band_rows(int32_t W);
  * The host parses the markers (cama_amd/jpeg.py) and uploads: the bytes that hold the entropy-coded segments (whole
  * files are fine: a descriptor points at its segment, byte stuffing still in place, any alignment), one descriptor
  * per image, the Huffman table sets (device layout: cama_jpeg_huff_set_bytes() each, built by the host from the DHT
- * segments) and the quantisation tables ([set][component 0..2][64] uint16, natural order).
+ * segments -- cama_amd/jpeg.py: build_huff_set is the reference builder, csrc/jpeg_kernels.hpp: JpegHuffRec the layout: 10-bit
+ * symbol tables + per-length limits + a second level for the codes of 11..16 bits, then, since ABI 23, the state-transition
+ * tables of the synchronisation phases, which depend on the table set alone and used to be derived by every workgroup)
+ * and the quantisation tables ([set][component 0..2][64] uint16, natural order).
  * Scope: SOF0, 8 bit, 1 or 3 components in one interleaved scan, luma sampling 1x1 / 2x1 / 2x2 with 1x1 chroma,
  * restart intervals through per-interval descriptors.  Everything else is the caller's host fallback.
  *   cama_jpeg_plan    fills the derived descriptor fields and reports grid sizes and scratch bytes (host only)
