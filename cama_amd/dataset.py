@@ -541,6 +541,22 @@ class ClipManager:
         self._launch_memo[dataset] = memo
         return memo
 
+    def _replay_launches(self, eng, dataset, memo):
+        """Issue a memoised launch list.  -> None when all of it went out; on out-of-memory (the library could not grow its
+        stamp scratch: CAMA_ENOMEM -> torch.OutOfMemoryError) the memo is dropped, the engine's frames-per-call budget is
+        shrunk and the number of FRAMES already issued is returned -- render_clip's halving loop renders the rest."""
+        import torch
+        launch, desc, issued = eng.render_clip_launch, memo["desc"], 0
+        for a in memo["launches"]:
+            try:
+                launch(desc, *a)
+            except torch.OutOfMemoryError:
+                self._launch_memo.pop(dataset, None)
+                eng.shrink_frames_per_call()
+                return issued
+            issued += a[1]
+        return None
+
     def _launches_valid(self, memo, eng, dataset, out, w2c, fpl, segments):
         """Everything a memoised launch list was derived from is still the very object it was derived from."""
         src = self._frame_source
@@ -582,16 +598,16 @@ class ClipManager:
         # ("wu": the anti-aliased variant -- Wu lines blended once by coverage; batched path only)
         segments = _segments_mode(self.configs.get("segments", False) if segments is None else segments)
         idx, w2c = poses if poses is not None else self.frame_poses(dataset)
+        resume = 0
         if pipelined and out is not None:
             # the same clip into the same buffers again (a service re-rendering, bench.py's steps): the launches were worked
             # out the first time -- one library call each (Engine.render_clip_launch), nothing else
             memo = self._launch_memo.get(dataset)
             if memo is not None and self._launches_valid(memo, eng, dataset, out, w2c, frames_per_launch, segments):
-                launch = eng.render_clip_launch
-                desc = memo["desc"]
-                for a in memo["launches"]:
-                    launch(desc, *a)
-                return idx, out
+                done = self._replay_launches(eng, dataset, memo)
+                if done is None:
+                    return idx, out
+                resume = done                                   # out of memory part-way: the loop below takes over from there
         rig = self._rig()
         dmap = self._static(dataset).device()
         F = len(idx)
@@ -629,11 +645,13 @@ class ClipManager:
                 and not os.environ.get("CAMA_NO_LAUNCH_MEMO"):
             memo = self._plan_launches(eng, dataset, dmap, rig, src_all, fused_raw, out, w2c, ids, step, cuts, crop, segments,
                                        frames_per_launch)
-            if memo is not None:
-                for a in memo["launches"]:
-                    eng.render_clip_launch(memo["desc"], *a)
-                return idx, out
-        lo = 0
+            if memo is not None and not resume:
+                done = self._replay_launches(eng, dataset, memo)
+                if done is None:
+                    return idx, out
+                resume = done
+                step = max(1, step // 2) if not frames_per_launch else step
+        lo = resume
         while lo < F:
             hi = min([F, lo + step] + [c for c in cuts if c > lo][:1])
             try:

@@ -283,7 +283,9 @@ class MosaicPool:
         self.eng = engine
         self.bases = []                     # [{"t": tensor [F, ...frame shape], "frame": tuple, "ms": float|None, "stream": int, "lru": int}]
         self.clock = 0
-        self.stats = {"takes": 0, "hits": 0, "allocations": 0, "auditions": 0, "trimmed": 0}
+        self.stats = {"takes": 0, "hits": 0, "allocations": 0, "auditions": 0, "trimmed": 0, "audition_seconds": 0.0,
+                      "audition_peak_bytes": 0}
+        self.flat_box = False               # an audition found every candidate alike: no further auditions in this process
 
     # ---- bookkeeping
     def _on_gpu(self):
@@ -306,7 +308,7 @@ class MosaicPool:
         if not self._on_gpu():
             return 1 << 62
         total = _torch().cuda.get_device_properties(self.eng.device).total_memory
-        return total // 2
+        return total // 8                   # idle bases beyond this are dropped least recently used first (live ones never)
 
     def trim(self, keep_bytes=0):
         """Drop idle bases, least recently used first, until at most `keep_bytes` are pooled (0: every idle one)."""
@@ -367,6 +369,47 @@ class MosaicPool:
     def audition_candidates(self):
         return max(0, int(os.environ.get("CAMA_AUDITION", "16")))
 
+    # A box either has a fast kind of (source, destination) placement -- the stamp-free overlay at >= 0.82 of 8 TB/s against <= 0.78
+    # for the usual kind -- or it does not (round 5, the driver's box: 72 candidates within 2.1 % of each other, none fast; the
+    # audition cost 133 GB of transient allocations and bought nothing).  So candidates are timed FOUR at a time and the audition
+    # stops as soon as it knows: a fast one has been seen (keep it), or FLAT_AFTER candidates lie within FLAT_RATIO of each other
+    # (keep candidate 0 -- exactly what a plain allocation would have been -- and never audition on this box again), or
+    # CAMA_AUDITION (16) candidates / half of the free memory are used up (keep the fastest).
+    FLAT_AFTER = 8
+    FLAT_RATIO = 1.03
+    GOOD_FRAC = 0.805
+
+    def _audition(self, shape, n_keep, time_one, K):
+        """Time candidate allocations of `shape` (time_one(tensor) -> ms) under the rules above.
+        -> (candidates, times, verdict, seconds, peak transient bytes)."""
+        import time as _time
+        torch = _torch()
+        nbytes = int(np.prod(shape))
+        good_ms = 2.0 * nbytes / (self.GOOD_FRAC * 8.0e12) * 1e3
+        t0 = _time.perf_counter()
+        cands, times, verdict = [], [], "budget"
+        while len(cands) < K:
+            for _ in range(min(4, K - len(cands))):
+                try:
+                    c = torch.empty(shape, dtype=torch.uint8, device=self.eng.device)
+                except torch.OutOfMemoryError:
+                    K = len(cands)
+                    break
+                cands.append(c)                                       # alive together: distinct memory
+                times.append(time_one(c))
+            if not times:
+                break
+            fast = sum(1 for t in times if t <= good_ms)
+            if fast >= n_keep:
+                verdict = "fast placement found"
+                break
+            if len(times) >= max(self.FLAT_AFTER, n_keep) and not fast and max(times) < self.FLAT_RATIO * min(times):
+                verdict = "no fast mode on this box"
+                break
+        if verdict == "no fast mode on this box":
+            self.flat_box = True
+        return cands, times, verdict, _time.perf_counter() - t0, len(cands) * nbytes
+
     # ---- the entry points
     def take(self, shape, rig=None, src=None, cols=3):
         """A mosaic tensor of `shape` = (F, rows*H, cols*W, 3): a view of an idle pooled base, else of a new one (placed
@@ -382,41 +425,32 @@ class MosaicPool:
             nbytes = int(np.prod(shape))
             K = self.audition_candidates() if self._on_gpu() else 0
             eng = self.eng
-            if (K <= 1 or rig is None or src is None or nbytes < (1 << 29) or nbytes > (8 << 30) or F == 0
+            if (K <= 1 or self.flat_box or rig is None or src is None or nbytes < (1 << 29) or nbytes > (8 << 30) or F == 0
                     or int(src.shape[0]) != F or not eng._probeable(rig, src)):
                 self.stats["allocations"] += 1
                 return self._lend(self._add(self._alloc(shape)), F)
             free, _ = _torch().cuda.mem_get_info(eng.device)
             K = max(1, min(K, int(free // 2 // nbytes)))
-            cands, times = [], []
-            # The fast kind runs the stamp-free overlay at >= 0.82 of 8 TB/s, the slow kind at <= 0.78 (2 x nbytes moved per
-            # launch).  Rounds of K candidates until one of the fast kind has been seen -- 16 candidates that are all of the slow
-            # kind happen (r05 profile box: 0.3298 .. 0.3434 ms, nothing below 0.78), neighbouring allocations are correlated --
-            # or CAMA_AUDITION_ROUNDS (4) rounds / half of the free memory are used up.
-            good_ms = 2.0 * nbytes / (0.805 * 8.0e12) * 1e3
-            rounds = max(1, int(os.environ.get("CAMA_AUDITION_ROUNDS", "4")))
-            for rnd in range(rounds):
-                if rnd and (len(cands) + K > int(free // 2 // nbytes) or min(times) <= good_ms):
-                    break
-                for _ in range(K):
-                    try:
-                        c = _torch().empty(shape, dtype=_torch().uint8, device=eng.device)
-                    except _torch().OutOfMemoryError:
-                        break
-                    cands.append(c)                                   # alive together: distinct memory
-                    times.append(eng._overlay_ms(rig, src, c, cols, 3))
+            cands, times, verdict, secs, peak = self._audition(shape, 1, lambda c: eng._overlay_ms(rig, src, c, cols, 3), K)
             if not cands:
                 self.stats["allocations"] += 1
                 return self._lend(self._add(self._alloc(shape)), F)
-            rank = sorted(range(len(cands)), key=lambda i: times[i])
-            keep = [rank[0]] + [i for i in rank[1:max(1, int(os.environ.get("CAMA_POOL_KEEP", "2")))]
-                                if times[i] <= 1.03 * times[rank[0]]]
+            if self.flat_box:
+                keep = [0]                                            # what a plain allocation would have been
+            else:
+                rank = sorted(range(len(cands)), key=lambda i: times[i])
+                keep = [rank[0]] + [i for i in rank[1:max(1, int(os.environ.get("CAMA_POOL_KEEP", "2")))]
+                                    if times[i] <= 1.03 * times[rank[0]]]
             self.stats["auditions"] += 1
             self.stats["allocations"] += len(keep)
+            self.stats["audition_seconds"] += secs
+            self.stats["audition_peak_bytes"] = max(self.stats["audition_peak_bytes"], peak)
             eng._log_audition({"role": "mosaic", "bytes": nbytes, "candidates": len(cands), "ms": [round(t, 4) for t in times],
-                               "chosen_ms": round(times[rank[0]], 4), "kept": len(keep), "source": "engine pool"})
+                               "chosen_ms": round(times[keep[0]], 4), "kept": len(keep), "source": "engine pool",
+                               "verdict": verdict, "seconds": round(secs, 4), "peak_bytes": peak})
             kept = [self._add(cands[i], times[i]) for i in keep]
-            del cands, c
+            del cands
+            _torch().cuda.empty_cache()                               # the losers go back to the driver, not to torch's cache
             eng.settle_mapping(rig, src, kept[0]["t"], cols)
             return self._lend(kept[0], F)
 
@@ -444,31 +478,37 @@ class MosaicPool:
             n = len(todo)
             K = self.audition_candidates() if self._on_gpu() else 0
             P = 0
-            if K > 1 and nbytes >= (1 << 29) and all(shapes[k][1:] == big[1:] for k in todo) \
+            if K > 1 and not self.flat_box and nbytes >= (1 << 29) and all(shapes[k][1:] == big[1:] for k in todo) \
                     and all(srcs[k] is not None and eng._probeable(rig, srcs[k]) for k in todo):
                 free, _ = torch.cuda.mem_get_info(eng.device)
                 P = min(int(os.environ.get("CAMA_AUDITION_POOL", str(max(K // 4, 2) * n))), int(free * 3 // 4 // nbytes))
-            if P <= n:
-                for k in todo:
+            cands, times = [], []
+            if P > n:
+                k0 = todo[0]
+                F0 = shapes[k0][0]
+                cands, times, verdict, secs, peak = self._audition(
+                    big, n, lambda c: eng._overlay_ms(rig, srcs[k0], c[:F0], cols, 3), P)
+                self.stats["auditions"] += 1
+                self.stats["audition_seconds"] += secs
+                self.stats["audition_peak_bytes"] = max(self.stats["audition_peak_bytes"], peak)
+                # flat box: the candidates in the order they came (= plain allocations); else fastest first
+                rank = list(range(len(cands))) if self.flat_box else sorted(range(len(cands)), key=lambda i: times[i])
+                rank = rank[:n]
+                eng._log_audition({"role": "mosaic", "bytes": nbytes, "candidates": len(cands), "ms": [round(t, 4) for t in times],
+                                   "chosen_ms": round(float(np.mean([times[i] for i in rank])), 4) if rank else None,
+                                   "kept": len(rank), "source": "engine pool", "verdict": verdict, "seconds": round(secs, 4),
+                                   "peak_bytes": peak})
+                for i, k in zip(rank, todo):
+                    self.stats["takes"] += 1
+                    self.stats["allocations"] += 1
+                    out[k] = self._lend(self._add(cands[i], times[i]), shapes[k][0])
+                del cands
+                torch.cuda.empty_cache()                               # the losers go back to the driver, not to torch's cache
+            for k in todo:                                             # no audition, or fewer candidates than buffers
+                if out[k] is None:
                     self.stats["takes"] += 1
                     self.stats["allocations"] += 1
                     out[k] = self._lend(self._add(self._alloc(shapes[k])), shapes[k][0])
-                return out
-            k0 = todo[0]
-            F0 = shapes[k0][0]
-            cands = [torch.empty(big, dtype=torch.uint8, device=eng.device) for _ in range(P)]
-            times = [eng._overlay_ms(rig, srcs[k0], c[:F0], cols, 3) for c in cands]
-            rank = sorted(range(P), key=lambda i: times[i])[:n]        # fastest first
-            self.stats["auditions"] += 1
-            eng._log_audition({"role": "mosaic", "bytes": nbytes, "candidates": P, "ms": [round(t, 4) for t in times],
-                               "chosen_ms": round(float(np.mean([times[i] for i in rank])), 4), "kept": n,
-                               "source": "engine pool"})
-            for i, k in zip(rank, todo):
-                self.stats["takes"] += 1
-                self.stats["allocations"] += 1
-                out[k] = self._lend(self._add(cands[i], times[i]), shapes[k][0])
-            del cands
-            torch.cuda.empty_cache()                                   # the losers go back to the driver, not to torch's cache
             return out
 
 
@@ -797,10 +837,13 @@ class Engine:
         nbytes = int(frames.numel())
         K = int(os.environ.get("CAMA_AUDITION", "16")) // 2 if candidates is None else int(candidates)
         with torch.cuda.device(self.device):
-            if K <= 1 or nbytes < (1 << 29) or nbytes > (8 << 30) or not self._probeable(rig, view(frames)):
-                return frames
+            if (K <= 1 or self.pool.flat_box or nbytes < (1 << 29) or nbytes > (8 << 30)
+                    or not self._probeable(rig, view(frames))):
+                return frames                                      # (a box without a fast placement has none for the source either)
             free, _ = torch.cuda.mem_get_info(self.device)
             K = max(1, min(K, int(free // 2 // nbytes)))
+            import time as _time
+            t0 = _time.perf_counter()
             best, best_ms = frames, self._overlay_ms(rig, view(frames), out, cols, reps)
             times, pool = [best_ms], []
             for _ in range(K):
@@ -814,9 +857,12 @@ class Engine:
                 best.copy_(frames)
                 del pool
                 self.settle_mapping(rig, view(best), out, cols)
+            secs = _time.perf_counter() - t0
+            self.pool.stats["audition_seconds"] += secs
+            self.pool.stats["audition_peak_bytes"] = max(self.pool.stats["audition_peak_bytes"], K * nbytes)
             self._log_audition(
                 {"role": "frames", "bytes": nbytes, "candidates": K, "ms": [round(t, 4) for t in times], "chosen_ms": round(best_ms, 4),
-                 "moved": best is not frames})
+                 "moved": best is not frames, "seconds": round(secs, 4), "peak_bytes": K * nbytes})
             return best
 
     def xcd_map(self, n_blocks=4096):
@@ -1197,11 +1243,16 @@ class Engine:
         if torch.cuda.current_device() == self.device.index:
             rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream, box[2], box[3])
             if rc == _lib.ENOMEM:
+                self.pool.trim(0)                                   # idle pooled mosaics first: they are outside torch's cache
                 torch.cuda.empty_cache()
                 rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream, box[2], box[3])
         else:
             with torch.cuda.device(self.device):
                 rc = fn(*args, self._stream(), box[2], box[3])
+                if rc == _lib.ENOMEM:
+                    self.pool.trim(0)
+                    torch.cuda.empty_cache()
+                    rc = fn(*args, self._stream(), box[2], box[3])
         if rc:
             _lib.check(rc)
         kp = P["keep"]
@@ -1310,7 +1361,7 @@ class Engine:
             cur = torch.cuda.current_stream(self.device)
             for _, T, src, out, dmap, rig, extra in self._pipe["keep"]:
                 for t in (T, src, out, dmap.soa, dmap.colour, dmap.sorted_soa, dmap.sorted_key,
-                          getattr(dmap, "bounds", None), rig.c2cam, rig.K) + tuple(extra):
+                          dmap.__dict__.get("_bounds"), rig.c2cam, rig.K) + tuple(extra):        # (never the lazy property)
                     if t is not None and hasattr(t, "record_stream"):
                         t.record_stream(cur)
             self._pipe["keep"].clear()

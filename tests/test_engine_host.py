@@ -138,6 +138,42 @@ def test_mosaic_pool_take_many_uses_idle_bases_first_and_never_lends_one_base_tw
     assert pool.stats["hits"] == 3 and pool.stats["allocations"] == 4
 
 
+def test_audition_stops_as_soon_as_it_knows():
+    """on a box without a fast placement (round 5, the driver's box: 72 candidates within 2.1 %) the audition
+    must cost eight candidates, not 72; a fast candidate ends it at once; otherwise CAMA_AUDITION bounds it."""
+    shape = (2, 4, 8, 3)
+    nbytes = 2 * 4 * 8 * 3
+    good = 2.0 * nbytes / (engine.MosaicPool.GOOD_FRAC * 8.0e12) * 1e3
+
+    def run(seq, K=16, n_keep=1):
+        pool = _cpu_pool()
+        it = iter(seq)
+        cands, times, verdict, secs, peak = pool._audition(shape, n_keep, lambda c: next(it), K)
+        assert len(cands) == len(times) and peak == len(cands) * nbytes and secs >= 0
+        assert len({c.data_ptr() for c in cands}) == len(cands)              # alive together: distinct memory
+        return pool, times, verdict
+
+    flat = [good * 1.06 * (1 + 0.002 * (k % 5)) for k in range(64)]           # all slow, within 1 %
+    pool, times, verdict = run(flat)
+    assert len(times) == 8 and verdict == "no fast mode on this box" and pool.flat_box
+    fast_third = [good * 1.06, good * 1.07, good * 0.99, good * 1.05] + flat
+    pool, times, verdict = run(fast_third)
+    assert len(times) == 4 and verdict == "fast placement found" and not pool.flat_box
+    spread = [good * (1.03 + 0.006 * (k % 9)) for k in range(64)]               # none fast, but 4 % apart: not flat either
+    pool, times, verdict = run(spread)
+    assert len(times) == 16 and verdict == "budget" and not pool.flat_box
+    pool, times, verdict = run(spread, K=6)
+    assert len(times) == 6 and verdict == "budget"
+    # several buffers at once (take_many): it goes on until n_keep fast ones are in hand
+    two_fast = [good * 1.06] * 3 + [good * 0.99] + [good * 1.06] * 3 + [good * 0.98] + flat
+    pool, times, verdict = run(two_fast, K=32, n_keep=2)
+    assert len(times) == 8 and verdict == "fast placement found"
+    # a flat box is remembered: the next take() does not audition (no rig / source needed to see that it allocates plainly)
+    pool, _, _ = run(flat)
+    t = pool.take(shape)
+    assert pool.stats["auditions"] == 0 and pool.stats["allocations"] == 1 and tuple(t.shape) == shape
+
+
 def test_rank_cpu_sets_are_disjoint_and_follow_the_gpus_numa_nodes():
     """one process per GPU, each pinned to cores of its GPU's NUMA node."""
     from cama_amd import shard

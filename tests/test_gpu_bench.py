@@ -49,6 +49,9 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert spans[0][1] < spans[1][0], aff
     # ranks sharing one GPU run without placement auditions; the line says where placement lives
     assert line["placement"]["source"].startswith("off") and line["placement"]["pool"]["auditions"] == 0
+    # ... and that a rank's transient placement memory is bounded: none at all when ranks share a GPU
+    assert line["placement"]["audition_peak_bytes"] == 0 and line["placement"]["audition_ms"] == 0.0
+    assert "reference_default" not in line and "ingest" not in line            # nested N = 1 measurements only
 
 
 def test_bench_gpus_beyond_the_node_is_refused_not_asserted():
@@ -95,12 +98,31 @@ def test_bench_default_line_has_every_contract_field():
     # this process's own launches and settled on one of them
     om = line["overlay_mapping"]
     assert om["decided"] in (5, 31) and min(om["samples"]) >= 2 and min(om["ns_per_mb"]) > 0, om
+    # `value` is the exactly-K-steps region (the sustained region is printed beside it, never instead of it)
+    assert abs(line["value"] - 20 * 40 / (line["ms_per_step"] * 20e-3)) < 1e-6 * line["value"]
+    assert abs(line["per_rank_seconds"][0] - line["ms_per_step"] * 20e-3) < 1e-9
+    # placement: at most 16 mosaic candidates, its cost is in the line, and on a flat box it keeps the plain allocation
+    pl = line["placement"]
+    assert pl["candidates_per_mosaic"] <= 16 and pl["audition_ms"] > 0
+    assert pl["audition_peak_bytes"] <= 16 * 36 * 1600 * 900 * 41
+    assert pl["verdict"] in ("fast placement found", "no fast mode on this box", "budget")
+    if pl["flat_box"]:
+        assert pl["candidates_per_mosaic"] == 8 and pl["candidates_per_frames"] == 0 and pl["kept_of_pool"] == 1
+    # the reference's default pipeline (raw 1600x900 -> 960x540) and the ingest stage, nested in the driver-run line
+    rd = line["reference_default"]
+    assert rd["hash_check"]["verified"] == 1 and rd["hash_check"]["timed_output_equals_verified_render"]
+    assert rd["roofline"]["kernel"] == "k_overlay_raw35" and rd["roofline"]["bytes_per_launch"] == 18 * (1600 * 900 + 960 * 540) * 40
+    assert 0.3 < rd["roofline"]["frac"] <= 1.0 and rd["value"] > 0 and rd["hbm_frac_whole_step"] <= rd["roofline"]["frac"] + 0.02
+    ing = line["ingest"]
+    assert ing["byte_equal_to_host_decoder"] is True and ing["value"] > 1000 and ing["bytes_out_per_image"] == 1600 * 900 * 3
+    assert ing["decoder_stats"]["host_unsupported"] == 0 and ing["decoder_stats"]["host_flagged"] == 0
+    assert rd["leg_seconds"] + ing["leg_seconds"] < 12.0
 
 
 def test_bench_timed_path_that_renders_nothing_is_caught():
     """the output buffers are poisoned between the warm-up and the timed region, so the hash check after
     it can only pass on bytes the timed steps wrote.  Fault injection: the timed steps render nothing -> exit 3, no line."""
-    args = ["--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--sustain-seconds", "0"]
+    args = ["--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--sustain-seconds", "0", "--no-extras"]
     p, line = _run(args, {"CAMA_BENCH_FAULT": "skip_overlay"}, timeout=600)
     assert p.returncode == 3 and line is None, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
     assert "timed path's output differs" in p.stderr
@@ -127,7 +149,7 @@ def test_bench_one_rank_rccl_group():
     (init with device_id, barrier, the int64 all_gather_into_tensor of the report) on the box's one GPU."""
     env = {"CAMA_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29517", "RANK": "0", "WORLD_SIZE": "1",
            "LOCAL_RANK": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
-    p, line = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--sustain-seconds", "0"], env,
+    p, line = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--sustain-seconds", "0", "--no-extras"], env,
                    timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     assert line["rccl_world"] == 1 and "RCCL" in line["collective"], line["collective"]
