@@ -1058,6 +1058,9 @@ def main():
         assignment = shard.assign_scenes([cost] * n_scenes, world, site_of=site_of, site_cost=40.0 * args.verts)
         mine = assignment[rank]                                          # scene ids of this rank (seed = scene id)
         frange = None
+    if os.environ.get("CAMA_BENCH_BAND_ROWS"):                    # A/B: force the overlay's band height (0 = the pipeline's choice)
+        from cama_amd import _lib
+        _lib.check(_lib.lib().cama_set_option(b"band_rows", int(os.environ["CAMA_BENCH_BAND_ROWS"])))
     job = Job(args, mine, device, frange)
     stagger_allocate(job, rank, world, sync_all)
     key = args_key(args, unit="frame" if args.shard_frames else "scene")
@@ -1254,6 +1257,12 @@ def main():
                                          "picture); disjoint by construction"}
         if bin_stats is not None:
             line["projection_stats"] = bin_stats
+        pinfo = job.eng.pipeline_info() if hasattr(job, "eng") else None
+        if pinfo:
+            line["band_rows"] = {"last_launch": pinfo["last_band_rows"], "tall_band_launches": pinfo["tall_band_launches"],
+                                 "launches": pinfo["launches"],
+                                 "note": "rows per band of the overlay, chosen per launch by the pipeline: 8 instead of 4 once the same map's "
+                                         "earlier launches have shown >= 0.045 band entries per destination pixel (dense maps)"}
         try:
             periodic, first8, per_xcd = job.eng.xcd_map()
             line["xcd_dispatch"] = {"round_robin_over_8_xcds": periodic, "xcd_of_blocks_0_to_7": first8,

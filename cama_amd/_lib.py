@@ -10,7 +10,7 @@ from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
 LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
-ABI_VERSION = 23
+ABI_VERSION = 24
 BIN_WORKLIST = 1
 BIN_SEGMENTS = 2
 BIN_SEGMENTS_WU = 4            # EXTENSION: discs + one-pixel segments between polyline neighbours (include/cama_hip.h)

@@ -182,6 +182,9 @@ struct BinPlan {
     bool wu = false;                // ... anti-aliased (CAMA_BIN_SEGMENTS_WU)
     bool have_sorted_capacity = false;
     uint64_t sorted_capacity = 0;
+    // rows per band of THIS launch (0: band_rows_for(W)).  A pipeline picks 8 instead of 4 for launches whose map stamps the
+    // image densely (cama_pipeline: BandMemo); both halves of a launch and cama_pipeline_bin_stats read it from here.
+    int band_rows = 0;
 };
 struct ScratchLayout {
     // plan part (offsets from its base)
@@ -200,7 +203,7 @@ struct ScratchLayout {
 
 int layout_scratch(int64_t N, int F, int C, int H, int W, int radius, ScratchLayout &L, const BinPlan *plan = nullptr)
 {
-    L.R = band_rows_for(W);
+    L.R = plan && plan->band_rows > 0 ? plan->band_rows : band_rows_for(W);
     L.NB = (H + L.R - 1) / L.R;
     L.bands_per_stamp = radius > 0 ? 2 : 1;  // 2r+1 rows touch <= 2 bands when 2r <= R (checked by the caller)
     const size_t nbins = (size_t)F * C * L.NB, nfc = (size_t)F * C;
@@ -328,14 +331,16 @@ Option g_options[] = {
                                                                             // between consecutive overlays; the call blocks ~0.1 ms);
                                                                             // 0: stream-side wait; -1: host wait for launches that
                                                                             // move >= 1 GiB (the host has the time to spare; at 960x540 it has not)
+    {"band_rows", nullptr, 0, {0}, {false}},                               // rows per band of a pipeline's plain launches: 0 = per launch
+                                                                            // from the map's measured stamp density, 4 | 8 = forced (tests)
 };
-enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_CULL_LIST_MIN, OPT_BIN_PRIORITY, OPT_PIPELINE_DEPTH, OPT_HOST_WAIT, OPT_COUNT };
+enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_CULL_LIST_MIN, OPT_BIN_PRIORITY, OPT_PIPELINE_DEPTH, OPT_HOST_WAIT, OPT_BAND_ROWS, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
 int64_t option(int k)
 {
     Option &o = g_options[k];
     if (!o.loaded.load(std::memory_order_acquire)) {
-        const char *e = getenv(o.env);
+        const char *e = o.env ? getenv(o.env) : nullptr;
         o.value.store(e && *e ? strtoll(e, nullptr, 10) : o.fallback, std::memory_order_relaxed);
         o.loaded.store(true, std::memory_order_release);
     }
@@ -1600,7 +1605,69 @@ struct cama_pipeline {
     struct Last { ScratchRef sc; int64_t N = 0; int32_t F = 0, C = 0, H = 0, W = 0, radius = 0; bool bounds = false; } last[MAX_DEPTH];
     int last_slot = -1;
     uint64_t planned_launches = 0, grows = 0;
+    // Band height per launch (round 6).  Every radius-2 stamp lies in TWO 4-row bands but in 1.25 8-row bands on average: on a
+    // map that stamps the image densely (10^6 lanes inside the crop box: 630 k band entries per 6-camera frame, one stamped
+    // pixel per pixel) the overlay is bound by its rasteriser's LDS atomics, and 8-row bands cut the entries by a quarter
+    // (whole step 0.51 -> 0.55 of 8 TB/s); everywhere else the owner table of an 8-row band (51 KB: three workgroups per CU
+    // instead of six) costs 2-4 % (profiles/r05_dense1e6_bench.json).  So the choice is made per launch from what
+    // the SAME map produced last time: behind the binning chain of a launch with >= BAND_MEMO_MIN_N vertices two words (the
+    // grand total of band entries) are copied to pinned memory on the binning stream; a later launch over the same vertex
+    // buffer finds the total once its event has fired -- nothing ever waits for it -- and picks 8 rows when the density,
+    // normalised to 4-row bands, is >= BAND_DENSE entries per destination pixel.  First launch over a map: 4.
+    static constexpr int64_t BAND_MEMO_MIN_N = 200000;
+    static constexpr double BAND_DENSE = 0.045;     // dense 10^6 lanes: 0.073; 4*10^6-vertex site: 0.021; stress: 0.012
+    struct BandMemo { const void *x = nullptr; int64_t N = 0; int32_t W = 0, H = 0; double density = -1.0; uint64_t age = 0; };
+    static constexpr int BAND_MEMOS = 16;
+    BandMemo band_memo[BAND_MEMOS];
+    struct BandPending { bool on = false; const void *x = nullptr; int64_t N = 0; int32_t W = 0, H = 0, R = 0; double pixels = 0; };
+    BandPending band_pending[MAX_DEPTH];
+    hipEvent_t band_ev[MAX_DEPTH] = {};
+    uint32_t *band_host = nullptr;              // pinned: [slot][2] = fc_base[last], fc_total[last]
+    uint64_t band_clock = 0, band8_launches = 0;
 };
+
+// fold the finished read-backs into the memo (never blocks)
+static void band_memo_harvest(cama_pipeline *p)
+{
+    for (int sl = 0; sl < cama_pipeline::MAX_DEPTH; ++sl) {
+        cama_pipeline::BandPending &q = p->band_pending[sl];
+        if (!q.on || hipEventQuery(p->band_ev[sl]) != hipSuccess) continue;
+        q.on = false;
+        const double entries = (double)p->band_host[2 * sl] + (double)p->band_host[2 * sl + 1];
+        // in 4-row terms: a radius-2 stamp (5 rows) reaches 2 bands of 4 rows and 1.5 of 8
+        const double density = entries * (q.R >= 8 ? 2.0 / 1.5 : 1.0) / std::max(q.pixels, 1.0);
+        cama_pipeline::BandMemo *slot = nullptr;
+        for (auto &m : p->band_memo)
+            if (m.x == q.x && m.N == q.N && m.W == q.W && m.H == q.H) { slot = &m; break; }
+        if (!slot) {
+            slot = &p->band_memo[0];
+            for (auto &m : p->band_memo)
+                if (m.age < slot->age) slot = &m;                          // least recently used (unused ones have age 0)
+            slot->x = q.x; slot->N = q.N; slot->W = q.W; slot->H = q.H;
+        }
+        slot->density = density;
+        slot->age = ++p->band_clock;
+    }
+}
+
+static int band_rows_choice(cama_pipeline *p, const BinCall &call, int radius, bool eligible)
+{
+    const int64_t forced = option(OPT_BAND_ROWS);
+    const int base = band_rows_for(call.W);
+    const auto fits = [&](int R) {
+        return R >= base && 2 * radius <= R && align_up((size_t)R * (call.W + 2 * radius) * 4, 16) * 2 <= 160 * 1024;
+    };
+    if (!eligible) return 0;
+    if (forced > 0) return (forced == 4 || forced == 8 || forced == 16) && fits((int)forced) ? (int)forced : 0;
+    if (call.N < cama_pipeline::BAND_MEMO_MIN_N || base != 4 || !fits(8)) return 0;
+    band_memo_harvest(p);
+    for (auto &m : p->band_memo)
+        if (m.x == call.x && m.N == call.N && m.W == call.W && m.H == call.H && m.density >= 0.0) {
+            m.age = ++p->band_clock;
+            return m.density >= cama_pipeline::BAND_DENSE ? 8 : 0;
+        }
+    return 0;
+}
 
 int cama_pipeline_create(cama_pipeline **out)
 {
@@ -1626,6 +1693,8 @@ int cama_pipeline_create(cama_pipeline **out)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->staged, flags);
     for (int k = 0; k < cama_pipeline::MAX_DEPTH && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->binned[k], flags);
     for (int k = 0; k < cama_pipeline::RING && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->done[k], flags);
+    for (int k = 0; k < cama_pipeline::MAX_DEPTH && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->band_ev[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&p->band_host, cama_pipeline::MAX_DEPTH * 2 * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         cama_pipeline_destroy(p);
         return fail(CAMA_EHIP, "cama_pipeline_create -> %s", hipGetErrorString(e));
@@ -1646,6 +1715,9 @@ int cama_pipeline_destroy(cama_pipeline *p)
         if (p->binned[k]) (void)hipEventDestroy(p->binned[k]);
     for (int k = 0; k < cama_pipeline::RING; ++k)
         if (p->done[k]) (void)hipEventDestroy(p->done[k]);
+    for (int k = 0; k < cama_pipeline::MAX_DEPTH; ++k)
+        if (p->band_ev[k]) (void)hipEventDestroy(p->band_ev[k]);
+    if (p->band_host) (void)hipHostFree(p->band_host);
     if (p->pose_host) (void)hipHostFree(p->pose_host);
     if (p->demand_host) (void)hipHostFree(p->demand_host);
     for (int k = 0; k < cama_pipeline::MAX_DEPTH; ++k) {
@@ -1793,6 +1865,7 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
     ScratchRef sc;
     ScratchLayout L;
     bool prepass_done = false;
+    const bool raw_overlay_launch = g_pipeline_raw_overlay;
     sc.bin_plan.segments = segments;
     sc.bin_plan.wu = segments && (call.flags & CAMA_BIN_SEGMENTS_WU) != 0;
     if ((call.flags & CAMA_BIN_SEGMENTS_WU) && !segments) return fail(CAMA_EINVAL, "CAMA_BIN_SEGMENTS_WU goes with CAMA_BIN_SEGMENTS");
@@ -1802,6 +1875,10 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
         if (int rc = check_render(N, F, C, W, H, radius, scratch, scratch_bytes, L)) return rc;
         sc = legacy_scratch(scratch, scratch_bytes, N, F, C, H, W, radius);
     } else {
+        // plain single-scene launches only: the raw 3:5 overlay's source-row tables are built for band_rows_for(W), segment
+        // records reach every band they cross, multi-scene chains are clip-sized maps
+        const bool band_eligible = F > 0 && !segments && !g_pipeline_raw_overlay && !call.scenes_dev && call.x;
+        sc.bin_plan.band_rows = band_rows_choice(p, call, radius, band_eligible);
         layout_scratch(N, F, C, H, W, radius, L, &sc.bin_plan);
         const bool plannable = F > 0 && bin_plannable(call) && !bin_env().no_plan;
         if (int rc = pipeline_grow(p, &p->own_plan[slot], &p->own_plan_bytes[slot], L.plan_total, false, k)) return rc;
@@ -1899,6 +1976,17 @@ static int pipeline_impl(cama_pipeline *p, const BinCall &call, void *scratch0, 
         }
         if (!ext || g_scatter_stop_event) HIP_TRY(hipEventRecord(p->binned[slot], p->s_bin));
         g_scatter_stop_event = nullptr;
+        if (managed && !segments && !raw_overlay_launch && !call.scenes_dev && call.x && N >= cama_pipeline::BAND_MEMO_MIN_N &&
+            band_rows_for(W) == 4 && !p->band_pending[slot].on) {
+            // behind `binned` (the overlay does not wait for it): the grand total of band entries, for the NEXT launches over this map
+            const size_t nfc = (size_t)F * C;
+            HIP_TRY(hipMemcpyAsync(&p->band_host[2 * slot], sc.stamp + L.fc_base + (nfc - 1) * 4, 4, hipMemcpyDeviceToHost, p->s_bin));
+            HIP_TRY(hipMemcpyAsync(&p->band_host[2 * slot + 1], sc.stamp + L.fc_total + (nfc - 1) * 4, 4, hipMemcpyDeviceToHost, p->s_bin));
+            HIP_TRY(hipEventRecord(p->band_ev[slot], p->s_bin));
+            cama_pipeline::BandPending &q = p->band_pending[slot];
+            q.on = true; q.x = call.x; q.N = N; q.W = W; q.H = H; q.R = L.R; q.pixels = (double)F * C * H * W;
+        }
+        if (L.R != band_rows_for(W)) ++p->band8_launches;
     } else
         HIP_TRY(hipEventRecord(p->binned[slot], p->s_bin));
     // (overlays stay on ONE stream: two overlays in flight at once interleave their streams in DRAM -- measured
@@ -2113,6 +2201,8 @@ int cama_pipeline_info(cama_pipeline *p, uint64_t *out)
     const int sl = p->last_slot;
     out[4] = sl >= 0 ? p->last[sl].sc.bin_plan.nseg : 0;
     out[5] = sl >= 0 ? p->last[sl].sc.bin_plan.capacity : 0;
+    out[6] = p->band8_launches;                                  // launches that ran with other than band_rows_for(W) rows per band
+    out[7] = sl >= 0 ? (uint64_t)(p->last[sl].sc.bin_plan.band_rows > 0 ? p->last[sl].sc.bin_plan.band_rows : band_rows_for(p->last[sl].W)) : 0;
     return CAMA_OK;
 }
 

@@ -282,9 +282,16 @@ constexpr uint32_t JPEG_L2_ABSENT = 0xffffffffu;
 // per-table clamp and rebasing of the second level (wave-uniform: a scalar register each), top << 16 | adj: l2[min(prefix16, top) - adj]
 __device__ __forceinline__ uint32_t jpeg_l2_adjust1(const JpegHuffSet &G, int t)
 {
-    const uint32_t top = min(G.lim[t][5], 0xffffu);
-    const uint32_t v = G.l2_off[t] == JPEG_L2_NONE ? JPEG_L2_ABSENT
-                                                   : (top << 16) | (((uint32_t)G.l2_first[t] << 6) - (uint32_t)G.l2_off[t]);
+    const uint32_t top = min(G.lim[t][5], 0xffffu), base = (uint32_t)G.l2_first[t] << 6, off = G.l2_off[t];
+    uint32_t v;
+    if (G.lim[t][5] == 0u || G.l2_first[t] >= (1u << JPEG_LUT_BITS))
+        v = 0u;                        // a table the file does not define (grayscale: tables 2 and 3), or one without long codes:
+                                       // its second level is never USED, but every lane of a wave-mode walk evaluates all four
+                                       // tables -- top = 0, adj = 0 makes that the in-bounds read l2[0]
+    else if (off == JPEG_L2_NONE || base < off || base - off > 0xffffu)
+        v = JPEG_L2_ABSENT;            // no second level, or one the 16-bit rebasing cannot express (a table of long codes only)
+    else
+        v = (top << 16) | (base - off);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 // The four values as scalar-register VALUES (read once per function, outside its loop): a lane-varying choice between struct
@@ -302,7 +309,8 @@ __device__ __forceinline__ uint32_t jpeg_adj_of(const JpegAdj &A, uint32_t tab) 
 }
 __device__ __forceinline__ uint32_t jpeg_l2_index(uint32_t adj, uint32_t window)
 {
-    return min(window >> 16, adj >> 16) - (adj & 0xffffu);
+    // (a prefix below the table's first long code -- a lane that evaluates a table its symbol does not use -- clamps to entry 0)
+    return (uint32_t)max((int32_t)min(window >> 16, adj >> 16) - (int32_t)(adj & 0xffffu), 0);
 }
 // a code longer than 10 bits, in k_jpeg_write's form (length << 8 | symbol)
 __device__ __forceinline__ uint32_t jpeg_long_symbol(const JpegWgCtx &c, const JpegAdj &A, uint32_t tab, uint32_t window)

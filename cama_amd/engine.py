@@ -1103,13 +1103,14 @@ class Engine:
 
     def pipeline_info(self):
         """What the pipeline's own scratch looks like (cama_pipeline_info): dict with launches, planned_launches, grows,
-        scratch_bytes, last_plan_segments, last_plan_capacity; None before the first pipelined launch."""
+        scratch_bytes, last_plan_segments, last_plan_capacity, tall_band_launches (launches that ran with 8-row bands: chosen per
+        launch from the map's measured stamp density), last_band_rows; None before the first pipelined launch."""
         if self._pipe is None:
             return None
-        out = np.zeros(6, np.uint64)
+        out = np.zeros(8, np.uint64)
         _lib.check(self.lib.cama_pipeline_info(self._pipe["handle"], out.ctypes.data))
         return dict(zip(("launches", "planned_launches", "grows", "scratch_bytes", "last_plan_segments",
-                         "last_plan_capacity"), (int(v) for v in out)))
+                         "last_plan_capacity", "tall_band_launches", "last_band_rows"), (int(v) for v in out)))
 
     def scratch_bytes(self):
         """Device bytes of stamp scratch this engine holds: the pipeline's own (demand-sized) + the single-stream buffer."""

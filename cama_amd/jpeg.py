@@ -359,7 +359,8 @@ def _second_level(rec):
             continue
         rec["l2_off"][t] = at
         rec["l2"][at:at + n] = long_symbol(rec, t, base + np.arange(n))
-        rec["l2"][at + n - 1] = 16 << 8                              # the clamp target: no code from here on
+        if int(rec["lim"][t, 5]) <= 0xFFFF:                          # (a fully subscribed table has a code at prefix 0xFFFF too)
+            rec["l2"][at + n - 1] = 16 << 8                          # the clamp target: no code from here on
         at += n
 
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define CAMA_ABI_VERSION 23
+#define CAMA_ABI_VERSION 24
 #define CAMA_OK      0
 #define CAMA_EINVAL (-1)
 #define CAMA_EHIP   (-2)

@@ -21,8 +21,9 @@
 extern "C" {
 #endif
 
-/* out[6] (host): launches issued, launches that were planned, buffer (re)allocations so far, scratch bytes owned, and the
- * last launch's plan: segments per (frame, camera), band-entry capacity (0, 0 when it was not planned). */
+/* out[8] (host): launches issued, launches that were planned, buffer (re)allocations so far, scratch bytes owned, the last
+ * launch's plan: segments per (frame, camera), band-entry capacity (0, 0 when it was not planned); launches so far that ran with
+ * 8-row instead of 4-row bands (chosen per launch from the map's measured stamp density), rows per band of the last launch. */
 int cama_pipeline_info(cama_pipeline *p, uint64_t *out);
 /* cama_bin_stats (below) of the pipeline's LAST launch out of its own scratch; blocks until that launch is over. */
 int cama_pipeline_bin_stats(cama_pipeline *p, uint64_t *out /* host, 4 */);
@@ -65,6 +66,10 @@ int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per
  *                                                  queues the overlay (the call blocks ~0.1 ms; no barrier packet between
  *                                                  consecutive overlays on the GPU: +1.5 % on the headline); 0 = stream-side
  *                                                  wait; -1 (default) = host wait for plain-overlay launches that move >= 512 MiB
+ *   band_rows             (none)                   rows per band of a pipeline's plain single-scene launches: 0 (default) = per launch
+ *                                                  -- 8 instead of 4 when the same map's previous launches stamped >= 0.045 band
+ *                                                  entries per destination pixel (dense maps: the rasteriser's LDS atomics, not HBM,
+ *                                                  bound the overlay there) --, 4 | 8 = forced (the parity suite forces each)
  * Unknown names: CAMA_EINVAL.  (No reference counterpart: the reference has no native code.) */
 int cama_set_option(const char *name, int64_t value);
 int cama_get_option(const char *name, int64_t *value);

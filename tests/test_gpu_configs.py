@@ -599,6 +599,65 @@ def test_memoised_launch_list_replays_the_same_bytes_and_notices_every_change():
 
 
 @pytest.mark.gpu
+def test_band_height_is_chosen_per_launch_and_never_changes_a_byte():
+    """8-row bands pay on maps that stamp the image densely and cost 2-4 % elsewhere, so a pipeline picks the
+    height per launch from what the same map produced before (cama_pipeline BandMemo; first launch over a map: 4 rows).  Here:
+    both heights FORCED on one dense scene give the plain path's bytes; left to itself the pipeline moves a dense map to 8 rows
+    after its first launches and leaves a 10^4-vertex map at 4 -- same bytes throughout."""
+    import ctypes
+    import torch
+    from cama_amd import runtime, _lib
+    dev = torch.device("cuda:0")
+    eng = runtime.engine()
+    L = eng.lib
+
+    def info():
+        return eng.pipeline_info() or {"tall_band_launches": 0, "last_band_rows": 0}
+
+    def set_rows(v):
+        _lib.check(L.cama_set_option(b"band_rows", v))
+
+    a = _args(verts=1000000, frames=6)
+    cm, frames, _ = bench.build_scene(a, 0, dev)
+    _, plain = cm.render_clip("cama")                                  # single stream: band_rows_for(W) = 4
+    want = plain.clone()
+    out = torch.empty_like(want)
+
+    def step(cmx=cm, o=out, w=want):
+        o.fill_(0xA5)
+        cmx.render_clip("cama", out=o, pipelined=True)
+        eng.join()
+        torch.cuda.synchronize()
+        assert torch.equal(o, w)
+    try:
+        for rows in (8, 4, 8):
+            set_rows(rows)
+            n0 = info()["tall_band_launches"]
+            step()
+            assert info()["last_band_rows"] == rows and info()["tall_band_launches"] - n0 == (1 if rows == 8 else 0)
+        set_rows(0)                                                    # the pipeline's own choice
+        n0 = info()["tall_band_launches"]
+        for _ in range(6):                                             # the read-back of launch k is in hand two launches later at most
+            step()
+        assert info()["tall_band_launches"] > n0 and info()["last_band_rows"] == 8
+        # a clip-sized map never moves (and never pays for the read-back: N < 200 000)
+        b = _args(frames=6)
+        cm2, frames2, _ = bench.build_scene(b, 1, dev)
+        _, plain2 = cm2.render_clip("cama")
+        want2, out2 = plain2.clone(), torch.empty_like(plain2)
+        n0 = info()["tall_band_launches"]
+        for _ in range(4):
+            step(cm2, out2, want2)
+        assert info()["tall_band_launches"] == n0 and info()["last_band_rows"] == 4
+        # a height the launch cannot take (owner table beyond half the LDS, or below 2 x radius) falls back to the default
+        set_rows(16)
+        step(cm2, out2, want2)
+        assert info()["last_band_rows"] in (4, 16)
+    finally:
+        set_rows(0)
+
+
+@pytest.mark.gpu
 def test_fullsize_site_scenes_equal_the_oracle():
     """configs[3] at FULL size as bench.py runs it on one GPU (12 scenes over three 10^6-vertex site maps, 40 frames at
     1600x900): one scene of every site plus a second drive over scene 0's site,

@@ -125,6 +125,57 @@ def test_table_set_whose_long_codes_do_not_fit_the_second_level_says_so():
     assert [int(v) for v in std["l2_off"][2:]] == [n0, n0 + 1]
 
 
+def _kernel_l2_adjust(rec, t):
+    """Python twin of jpeg_l2_adjust1 (jpeg_kernels.hpp): top << 16 | adj, 0 for a table whose second level is never used,
+    None = JPEG_L2_ABSENT (slow path)."""
+    lim5, first, off = int(rec["lim"][t, 5]), int(rec["l2_first"][t]), int(rec["l2_off"][t])
+    top, base = min(lim5, 0xFFFF), first << 6
+    if lim5 == 0 or first >= (1 << PJ.LUT_BITS):
+        return 0
+    if off == PJ.L2_NONE or base < off or base - off > 0xFFFF:
+        return None
+    return (top << 16) | (base - off)
+
+
+def _kernel_l2_index(adj, w16):
+    return max(min(w16, adj >> 16) - (adj & 0xFFFF), 0)
+
+
+def test_second_level_index_stays_inside_the_table_for_every_table_of_any_set():
+    """a grayscale file (or one that defines only the DC0 / AC0 pair) leaves tables 2 and 3 without codes; the
+    kernels' wave-mode walk evaluates all four tables on every lane, so the rebased index must be in bounds for ANY 16-bit
+    prefix under ANY table -- and agree with the per-length limits wherever a long code exists."""
+    gray = encode(synth_image(40, 56, "noise", seed=2).mean(axis=2).astype(np.uint8), quality=85)
+    colour = encode(synth_image(40, 56, "noise", seed=3), quality=92, subsampling=2, optimize=True)
+    bits = np.zeros(16, np.uint8)
+    bits[15] = 3                                                      # a table of three 16-bit codes and nothing else
+    only_long = {(0, 0): bytes(bits) + bytes([1, 2, 3]), (1, 0): bytes(bits) + bytes([0x11, 0x12, 0x00])}
+    full = np.zeros(16, np.uint8)
+    full[0:15] = 1
+    full[15] = 2                                                      # Kraft sum 1: the prefix 0xFFFF is a code
+    sets = [PJ.build_huff_set(PJ.parse_header(gray).huff), PJ.build_huff_set(PJ.parse_header(colour).huff),
+            PJ.build_huff_set(only_long), PJ.build_huff_set({(0, 0): bytes(full) + bytes(range(17))})]
+    probes = np.unique(np.concatenate([np.arange(0, 0x10000, 97), np.arange(0xFF00, 0x10000), [0, 1, 63, 64]]))
+    seen_absent = seen_unused = 0
+    for rec in sets:
+        for t in range(4):
+            adj = _kernel_l2_adjust(rec, t)
+            if adj is None:
+                seen_absent += 1
+                continue
+            seen_unused += adj == 0
+            for w16 in probes:
+                i = _kernel_l2_index(adj, int(w16))
+                assert 0 <= i < PJ.L2_MAX, (t, w16, i)
+                if adj and int(rec["lut"][t, int(w16) >> 6]) == 0:      # a long code (or none) starts here: same answer as the limits
+                    assert int(rec["l2"][i]) == int(PJ.long_symbol(rec, t, [int(w16)])[0]), (t, hex(int(w16)))
+    assert seen_unused >= 2 and seen_absent >= 1                      # grayscale's tables 2/3; the long-codes-only table
+    # the fully subscribed table keeps its last code: no "no code" sentinel over prefix 0xFFFF
+    rec = sets[3]
+    assert int(rec["lim"][0, 5]) == 0x10000
+    assert int(rec["l2"][_kernel_l2_index(_kernel_l2_adjust(rec, 0), 0xFFFF)]) == int(PJ.long_symbol(rec, 0, [0xFFFF])[0]) != 16 << 8
+
+
 def test_scope_checks():
     img = synth_image(32, 48, "smooth")
     for bad in (encode(img, progressive=True), b"not a jpeg"):

@@ -12,6 +12,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--restart-rows", type=int, default=0, help="encode with a restart interval of this many MCU rows")
 ap.add_argument("--lanes", type=int, default=0, help="fixed number of groups (0 = the decoder's own sizing)")
 ap.add_argument("--min-group", type=int, default=8)
+ap.add_argument("--sets", default="noise,photo", help="which image sets to run")
 a = ap.parse_args()
 rng = np.random.default_rng(0)
 y, x = np.mgrid[0:900, 0:1600]
@@ -23,8 +24,9 @@ def enc(im, q=90):
     b = io.BytesIO(); Image.fromarray(im).save(b, format="JPEG", quality=q, **kw); return b.getvalue()
 
 
-sets = {"noise": [enc(rng.integers(0, 256, (900, 1600, 3), dtype=np.uint8)) for _ in range(a.batch)],
-        "photo": [enc(np.clip(base + rng.normal(0, 6, base.shape), 0, 255).astype(np.uint8)) for _ in range(a.batch)]}
+make = {"noise": lambda: enc(rng.integers(0, 256, (900, 1600, 3), dtype=np.uint8)),
+        "photo": lambda: enc(np.clip(base + rng.normal(0, 6, base.shape), 0, 255).astype(np.uint8))}
+sets = {k: [make[k]() for _ in range(a.batch)] for k in make if k in a.sets.split(",")}
 dec = DeviceJpegDecoder("cuda:0", lanes=a.lanes or None, min_group=a.min_group)
 for name, blobs in sets.items():
     out = dec.decode(blobs)
