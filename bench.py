@@ -419,7 +419,7 @@ class Job:
         self.lo, self.hi, self.F = lo, hi, hi - lo
         self.out = None
         self.outs = None
-        self.group_frames = int(os.environ.get("CAMA_SCENE_GROUP_FRAMES", "0")) or None      # A/B: frames per multi-scene launch
+        self.group_frames = None                                        # (frames per multi-scene launch: the library's 16 384)
         self.batched = False
         # the caller's own (unplaced) frames of scene 0, kept for the "unplaced" comparison leg; the frame source may read a
         # placed copy from the first render on (DeviceFrameSource.place_for)
@@ -622,10 +622,11 @@ class Job:
                 os.environ["CAMA_AUDITION"] = env
 
     def unmemoised_leg(self, steps, warmup, sync_all):
-        """The K steps once more with CAMA_NO_POSE_MEMO=1: every step recomputes its poses (seek + slerp + float32 inverse) and,
+        """The K steps once more with cama_amd.dataset.POSE_MEMO = False: every step recomputes its poses (seek + slerp + float32 inverse) and,
         the pose arrays being new objects, goes through ClipManager.render_clip's full path instead of the memoised launch
         list -- the round-4 step, printed beside the default one."""
-        os.environ["CAMA_NO_POSE_MEMO"] = "1"
+        from cama_amd import dataset as cama_dataset
+        cama_dataset.POSE_MEMO = False
         keep_prof = (getattr(self, "project_ms", 0.0), getattr(self, "project_n", 0), getattr(self, "overlay_each", None),
                      getattr(self, "host_issue_us", None))
         try:
@@ -634,7 +635,7 @@ class Job:
             return {"seconds": dt, "steps": steps, "frames_per_s": self.F * steps * n / dt if dt > 0 else 0.0,
                     "ms_per_step": dt / max(1, steps) * 1e3, "host_issue_us": self.host_issue_us}
         finally:
-            del os.environ["CAMA_NO_POSE_MEMO"]
+            cama_dataset.POSE_MEMO = True
             self.project_ms, self.project_n, self.overlay_each, self.host_issue_us = keep_prof
 
     def projection_bytes(self):
@@ -1079,8 +1080,7 @@ def main():
                   file=sys.stderr, flush=True)
             sys.exit(3)
     sus_steps, sus_dt = job.sustain(args.sustain_seconds, args.steps, dt, sync_all)
-    unmemoised = job.unmemoised_leg(args.steps, args.warmup, sync_all) \
-        if (world == 1 and args.steps > 0 and not os.environ.get("CAMA_NO_POSE_MEMO")) else None
+    unmemoised = job.unmemoised_leg(args.steps, args.warmup, sync_all) if (world == 1 and args.steps > 0) else None
     unplaced = job.unplaced_leg(args.steps, args.warmup, sync_all, prof_every) \
         if (world == 1 and args.steps > 0 and os.environ.get("CAMA_AUDITION", "16") != "0") else None
     vbytes, sbytes, bin_stats = job.projection_bytes()
@@ -1240,10 +1240,9 @@ def main():
             line["value_source"] = "the %d timed steps (%.1f ms)" % (args.steps, agg["seconds"] * 1e3)
         line["config"]["step"] = ("ClipManager.render_clip(out=<the engine's pooled mosaic>, pipelined): frame poses memoised per "
                                   "(track, stamps); the clip's launches worked out once and replayed, one library call each "
-                                  "(cama_pipeline_render_clip)" if not os.environ.get("CAMA_NO_POSE_MEMO") else
-                                  "CAMA_NO_POSE_MEMO=1: poses recomputed and launches re-derived on every step")
+                                  "(cama_pipeline_render_clip)")
         if unmemoised is not None:
-            line["without_memo"] = dict(unmemoised, note="the same K steps with CAMA_NO_POSE_MEMO=1: seek + slerp + float32 inverse "
+            line["without_memo"] = dict(unmemoised, note="the same K steps with cama_amd.dataset.POSE_MEMO = False: seek + slerp + float32 inverse "
                                                          "recomputed and the launch arguments re-derived in Python on every step "
                                                          "(what every step did until round 4)")
         line["host_issue_us"] = dict(job.host_issue_us, note="rank 0: wall time of one step()'s issue on the host inside the K timed "

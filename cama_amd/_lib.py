@@ -9,7 +9,20 @@ import os
 from os.path import dirname, join, abspath, exists
 
 _HERE = dirname(abspath(__file__))
-LIB_PATH = os.environ.get("CAMA_HIP_LIB", join(_HERE, "libcama_hip.so"))   # override only for kernel A/B experiments
+LIB_PATH = join(_HERE, "libcama_hip.so")
+if os.environ.get("CAMA_HIP_LIB") and os.environ.get("CAMA_ALLOW_LIB_OVERRIDE") == "1":
+    LIB_PATH = os.environ["CAMA_HIP_LIB"]          # another build of the library: kernel A/B experiments (tools/) only
+
+
+def test_hooks():
+    """CAMA_TEST_HOOKS = "name[=value],..." as a dict (the parity suite's child processes force production code paths with it:
+    the library reads the same variable, cama_hip.hip: test_hook).  Python-side names: bounds_min_verts=n, no_bounds."""
+    out = {}
+    for item in os.environ.get("CAMA_TEST_HOOKS", "").split(","):
+        if item:
+            k, _, v = item.partition("=")
+            out[k] = int(v) if v else 1
+    return out
 ABI_VERSION = 24
 BIN_WORKLIST = 1
 BIN_SEGMENTS = 2
@@ -144,7 +157,7 @@ def check(rc):
             # the same exception torch's allocator raises, so the callers' out-of-memory handling (ClipManager.render_clip:
             # halve the launch) covers memory the library allocates itself
             import torch
-            raise torch.OutOfMemoryError(msg)
+            raise getattr(torch, "OutOfMemoryError", torch.cuda.OutOfMemoryError)(msg)
         raise CamaHipError(msg)
 
 

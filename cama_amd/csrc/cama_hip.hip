@@ -33,15 +33,13 @@
 #include <vector>
 #include <mutex>
 #include <atomic>
-#include <algorithm>
+#include <string>
 
-#include "cama_hip_diag.h"      // (includes cama_hip.h: the contract)
+#include "cama_common.hpp"       // cama_hip_diag.h (which includes cama_hip.h: the contract), fail(), HIP_TRY, align_up
 
-namespace {
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, ...)
+// thread-local message of the most recent failure (cama_last_error); shared by the library's translation units (cama_common.hpp)
+thread_local char cama_impl::g_err[512] = "";
+int cama_impl::fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -50,11 +48,9 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                      \
-    do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess) return fail(CAMA_EHIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
+namespace {
+using cama_impl::fail;
+using cama_impl::g_err;
 
 // Opt-in timing of the dominant kernel (k_overlay) with HIP events recorded on the launch stream.
 struct ProfileState {
@@ -115,7 +111,6 @@ struct Palette { uint32_t c[2]; uint32_t alpha256; };  // colours b | g<<8 | r<<
 #include "resample_kernels.hpp"
 #include "map_kernels.hpp"
 #include "egress_kernels.hpp"
-#include "jpeg_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host helpers
@@ -161,7 +156,7 @@ int log2i(int v)
     return s;
 }
 
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+using cama_impl::align_up;
 
 // Scratch of one launch = two parts (round 4):
 //   plan part   what the cull pre-pass writes and the chain reads: work-list / candidate counters, the camera masks, the work
@@ -280,12 +275,13 @@ constexpr int CAND_COUNT_WORD = 8;     // work_count[0..7] = the 8 work lists' l
 // (block, frame) items from which the crop cull goes through a work list + persistent workgroups; and how many of those
 // workgroups (256 CUs x 8 resident).  Env overrides are for A/B measurements only.
 int64_t option(int k);
+bool test_hook(const char *name, int64_t *value);
 uint64_t cull_list_threshold();
 // vertex blocks one projection workgroup runs: 1 until the launch has >= 16 k (block, frame) items, then as many as keep
-// ~16 k workgroups (64 per CU), at most 8.  CAMA_PROJECT_VB overrides (A/B).
+// ~16 k workgroups (64 per CU), at most 8.  (test hook project_vb=n overrides)
 int project_blocks_per_workgroup(uint64_t items)
 {
-    static const int forced = getenv("CAMA_PROJECT_VB") ? atoi(getenv("CAMA_PROJECT_VB")) : 0;      // TEST HOOK (fuzz: 3 / 8)
+    static const int forced = [] { int64_t v = 0; (void)test_hook("project_vb", &v); return (int)v; }();   // TEST HOOK (fuzz: 3 / 8)
     if (forced > 0) return forced;
     const uint64_t vb = items / 16384ull;
     return vb < 1 ? 1 : (vb > 8 ? 8 : (int)vb);
@@ -312,36 +308,63 @@ constexpr unsigned persistent_workgroups() { return 2048u; }      // 256 CUs x 8
 //     launches alternate between the two with their own start / stop events, and once each has two timings the faster
 //     one (per byte) is kept for the life of the process (MapTuner below; cama_overlay_mapping_info() reports it).
 // The mapping is a bijection either way: pixels never depend on it.
-// CAMA_OVERLAY_CHUNK_LOG2 = 0 .. 31 forces one mapping (no tuning), CAMA_OVERLAY_TUNE=0 keeps "contiguous" for big launches.
+// Option overlay_chunk_log2 = 0 .. 31 forces one mapping (no tuning).
 constexpr uint32_t MAP_CHUNKED = 5u, MAP_CONTIGUOUS = 31u;
 constexpr size_t MAP_BIG_LAUNCH = (size_t)7 << 28;               // 1.75 GiB
 
-// Process-wide tuning options (cama_set_option / cama_get_option, include/cama_hip.h): performance knobs only -- none of
-// them can change a result.  Each starts from its environment variable (read once) and may be changed at run time.
-struct Option { const char *name, *env; int64_t fallback; std::atomic<int64_t> value; std::atomic<bool> loaded; };
+// TEST HOOKS: ONE environment variable, CAMA_TEST_HOOKS = "name[=value],name[=value],..." (read once per process), lets the
+// parity suite force every production code path in child processes -- the options below by name, and the binning chain's
+// switches (no_cam_mask, no_candidates, no_plan, project_vb=n).  None can change a result.  (Until round 5 each was its own
+// environment variable, and the options had one each as well: thirteen in all.)
+bool test_hook(const char *name, int64_t *value)
+{
+    static const std::vector<std::pair<std::string, int64_t>> hooks = [] {
+        std::vector<std::pair<std::string, int64_t>> h;
+        const char *e = getenv("CAMA_TEST_HOOKS");
+        if (!e) return h;
+        std::string s(e);
+        size_t at = 0;
+        while (at <= s.size()) {
+            const size_t end = std::min(s.find(',', at), s.size());
+            const std::string item = s.substr(at, end - at);
+            const size_t eq = item.find('=');
+            if (!item.empty())
+                h.emplace_back(item.substr(0, eq), eq == std::string::npos ? 1 : strtoll(item.c_str() + eq + 1, nullptr, 10));
+            at = end + 1;
+        }
+        return h;
+    }();
+    for (const auto &kv : hooks)
+        if (kv.first == name) {
+            if (value) *value = kv.second;
+            return true;
+        }
+    return false;
+}
+
+// Process-wide options (cama_set_option / cama_get_option, include/cama_hip_diag.h): schedules and orders only -- none of them
+// can change a result.  Changed at run time through the API (the parity suite forces each); no environment variables.
+// Retired in round 6, their A/Bs settled: overlay_tune (the per-pair order trial stays on), bin_priority (highest: 0 / 1 / 2
+// measure the same, profiles/r06_raw35_knobs.txt), pipeline_depth (two slots: three measured the same everywhere).
+struct Option { const char *name; int64_t fallback; std::atomic<int64_t> value; std::atomic<bool> loaded; };
 Option g_options[] = {
-    {"overlay_chunk_log2", "CAMA_OVERLAY_CHUNK_LOG2", -1, {0}, {false}},   // -1 = library's choice, 0..31 = forced order
-    {"overlay_tune", "CAMA_OVERLAY_TUNE", 1, {0}, {false}},                // 0 = big launches keep the contiguous order
-    {"cull_list_min", "CAMA_CULL_LIST_MIN", 16384, {0}, {false}},          // (block, frame) items from which a site-sized
-                                                                            // map's cull goes through work lists
-    {"bin_priority", "CAMA_BIN_PRIORITY", 2, {0}, {false}},                // priority of a new cama_pipeline's binning stream: 2 high, 1 normal, 0 low
-    {"pipeline_depth", "CAMA_PIPELINE_DEPTH", 2, {0}, {false}},            // scratch slots of a cama_pipeline created from now on (2 | 3)
-    {"pipeline_host_wait", "CAMA_PIPELINE_HOST_WAIT", -1, {0}, {false}},   // 1: cama_pipeline_* wait for a launch's binning on the
-                                                                            // HOST before queueing its overlay (no barrier packet
-                                                                            // between consecutive overlays; the call blocks ~0.1 ms);
-                                                                            // 0: stream-side wait; -1: host wait for launches that
-                                                                            // move >= 1 GiB (the host has the time to spare; at 960x540 it has not)
-    {"band_rows", nullptr, 0, {0}, {false}},                               // rows per band of a pipeline's plain launches: 0 = per launch
-                                                                            // from the map's measured stamp density, 4 | 8 = forced (tests)
+    {"overlay_chunk_log2", -1, {0}, {false}},   // -1 = library's choice, 0..31 = forced workgroup -> band order
+    {"cull_list_min", 16384, {0}, {false}},     // (block, frame) items from which a site-sized map's cull goes through work lists
+    {"pipeline_host_wait", -1, {0}, {false}},   // 1: cama_pipeline_* wait for a launch's binning on the HOST before queueing its
+                                                // overlay (no barrier packet between consecutive overlays; the call blocks
+                                                // ~0.1 ms); 0: stream-side wait; -1: host wait for plain launches that move >= 512 MiB
+    {"band_rows", 0, {0}, {false}},             // rows per band of a pipeline's plain launches: 0 = per launch from the map's
+                                                // measured stamp density, 4 | 8 = forced
 };
-enum { OPT_CHUNK_LOG2 = 0, OPT_TUNE, OPT_CULL_LIST_MIN, OPT_BIN_PRIORITY, OPT_PIPELINE_DEPTH, OPT_HOST_WAIT, OPT_BAND_ROWS, OPT_COUNT };
+enum { OPT_CHUNK_LOG2 = 0, OPT_CULL_LIST_MIN, OPT_HOST_WAIT, OPT_BAND_ROWS, OPT_COUNT };
 static_assert(sizeof(g_options) / sizeof(g_options[0]) == OPT_COUNT, "option table");
 int64_t option(int k)
 {
     Option &o = g_options[k];
     if (!o.loaded.load(std::memory_order_acquire)) {
-        const char *e = o.env ? getenv(o.env) : nullptr;
-        o.value.store(e && *e ? strtoll(e, nullptr, 10) : o.fallback, std::memory_order_relaxed);
+        int64_t v = o.fallback;
+        (void)test_hook(o.name, &v);
+        o.value.store(v, std::memory_order_relaxed);
         o.loaded.store(true, std::memory_order_release);
     }
     return o.value.load(std::memory_order_relaxed);
@@ -419,8 +442,6 @@ struct MapTuner {
     // the mapping for a big launch over (src, dst); a trial if the caller can give the launch its own start / stop events
     MapTrial pick(const void *src, const void *dst, size_t bytes, bool can_trial)
     {
-        const bool tune = option(OPT_TUNE) != 0;
-        if (!tune) return MapTrial{MAP_CONTIGUOUS, nullptr, nullptr, 0, 0};
         int device = 0;
         (void)hipGetDevice(&device);
         std::lock_guard<std::mutex> lock(mu);
@@ -724,12 +745,11 @@ struct BinCall {
 };
 
 // TEST HOOKS of the binning chain (tests/test_gpu_fuzz.py forces each of the production code paths on inputs that would not
-// select it by themselves): read from the environment once per process.  None can change a result.
+// select it by themselves): CAMA_TEST_HOOKS, read once per process.  None can change a result.
 struct BinEnv { bool no_cam_mask, no_candidates, no_plan; };
 static const BinEnv &bin_env()
 {
-    static const BinEnv e{getenv("CAMA_NO_CAM_MASK") != nullptr, getenv("CAMA_NO_CANDIDATES") != nullptr,
-                          getenv("CAMA_NO_PLAN") != nullptr};
+    static const BinEnv e{test_hook("no_cam_mask", nullptr), test_hook("no_candidates", nullptr), test_hook("no_plan", nullptr)};
     return e;
 }
 
@@ -1571,15 +1591,11 @@ int cama_build_static_map(const float *verts, const int32_t *seg_v0, const int32
 // be released -- the internal streams are invisible to the caller's allocator; (iii) it bounds the run-ahead: issuing
 // launch k blocks until launch k - (RING - 2) has completed.
 //
-// depth (round 5): two slots by default, three on request (option pipeline_depth / CAMA_PIPELINE_DEPTH=3: the chain of launch
-// k+2 then has overlay k AND overlay k+1 to hide under, for one more slot of stamp scratch).  Three slots were built when a
-// 960x540 step took 144 us around a 118 us overlay and helped on some boxes (0.148 -> 0.127-0.136 ms) -- a symptom: the
-// overlay held every wave slot of every CU and the chain's 10 us projection kernel ran 105 us beside it.  Since the overlay
-// leaves wave slots free (overlay_impl: g_overlay_leave) two and three slots measure the same everywhere
-// (profiles/r05_960x540_timeline.txt section 6), so the default is the one that holds less memory.
+// Two scratch slots.  (A third -- the chain of launch k+2 hiding under overlays k and k+1 -- was an option in round 5 and measured
+// the same everywhere once the overlay left wave slots to the chain, profiles/r05_960x540_timeline.txt section 6; retired.)
 struct cama_pipeline {
     static constexpr int RING = 64;
-    static constexpr int MAX_DEPTH = 3;
+    static constexpr int MAX_DEPTH = 2;
     int depth = 2;
     // s_pre: the cull pre-pass of PLANNED launches (site-sized maps) and their pose upload -- the call waits for it on the
     // host, and on its own stream it runs beside the previous launch's projection / scatter instead of queueing behind them
@@ -1676,15 +1692,13 @@ int cama_pipeline_create(cama_pipeline **out)
     // device-scope release, no timing: a default event makes the recording stream do a system-scope release after
     // an overlay that wrote ~1 GB, which showed up as ~20 us between consecutive overlays
     const unsigned flags = hipEventDisableTiming | hipEventReleaseToDevice;
-    const int64_t depth = option(OPT_PIPELINE_DEPTH);
-    p->depth = depth == 3 ? 3 : 2;
+    p->depth = 2;
     // The binning stream is the most urgent one: its kernels are small and latency-bound, the overlay beside them fills every
     // wave slot of the chip, and whatever the chain does not finish under the overlay shows up between two overlays
     // (960x540, two slots: whole step 0.655 -> 0.680 of 8 TB/s; 10^5 vertices 0.72 -> 0.74; headline unchanged).
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least urgent (numerically greatest)
-    const int64_t prio = option(OPT_BIN_PRIORITY);           // 2 = highest (default), 1 = the overlay's, 0 = lowest
-    hipError_t e = hipStreamCreateWithPriority(&p->s_bin, hipStreamNonBlocking, prio >= 2 ? hi : prio == 1 ? (lo + hi) / 2 : lo);
+    hipError_t e = hipStreamCreateWithPriority(&p->s_bin, hipStreamNonBlocking, hi);
     // (a CU-masked overlay stream that leaves 8 / 16 / 32 compute units to the chain was tried and is gone: masked queues
     // dispatch far slower -- whole step 0.72 -> 0.44 at 960x540, profiles/r05_960x540_timeline.txt)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_ov, hipStreamNonBlocking);
@@ -2351,254 +2365,6 @@ int cama_stamp_polylines_wu(const double *vu, const uint8_t *colour_id, const ui
     hipLaunchKernelGGL(k_apply_owner_wu, dim3((unsigned)((npix + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
                        (const uint32_t *)scratch, image, npix, make_palette(palette_bgr));
     HIP_TRY(hipGetLastError());
-    return CAMA_OK;
-}
-
-}  // extern "C"
-
-// ------------------------------------------------------------------------------------------ device JPEG decode
-struct JpegLayout {
-    size_t clean, tile_count, tile_base, nbits, E, nb, wg_total, coef, dcd, planes, total;
-    size_t coef_elems, plane_bytes, clean_bytes;
-    uint32_t total_wgs, total_tiles, max_blocks;
-};
-
-// derived descriptor fields + scratch layout; `write` = fill the [plan] fields (cama_jpeg_plan) or check them
-static int jpeg_layout(cama_jpeg_image *imgs, const cama_jpeg_image *cimgs, int32_t n, uint64_t stream_bytes, bool write,
-                       JpegLayout &L)
-{
-    if (n < 1 || n > 65535) return fail(CAMA_EINVAL, "n=%d images out of range [1, 65535]", n);
-    uint32_t wg = 0, tile = 0, max_blocks = 0;
-    size_t coef = 0, planes = 0, clean = 0;
-    std::vector<cama_jpeg_image> planned((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const cama_jpeg_image &D = cimgs[i];
-        if (D.width < 1 || D.width > 65535 || D.height < 1 || D.height > 65535)
-            return fail(CAMA_EINVAL, "image %d: %ux%u out of range", i, D.width, D.height);
-        if (!(D.ncomp == 1 || D.ncomp == 3)) return fail(CAMA_EINVAL, "image %d: %u components", i, D.ncomp);
-        const bool samp_ok = (D.hs == 1 && D.vs == 1) || (D.ncomp == 3 && D.hs == 2 && (D.vs == 1 || D.vs == 2));
-        if (!samp_ok) return fail(CAMA_EINVAL, "image %d: sampling %ux%u not supported", i, D.hs, D.vs);
-        if (D.kind > CAMA_JPEG_PIXELS) return fail(CAMA_EINVAL, "image %d: kind %u", i, D.kind);
-        for (uint32_t c = 0; c < D.ncomp; ++c)
-            if (D.comp_dc[c] > 1 || D.comp_ac[c] > 1) return fail(CAMA_EINVAL, "image %d: Huffman selector > 1", i);
-        const bool has_stream = D.kind != CAMA_JPEG_PIXELS, has_pixels = D.kind != CAMA_JPEG_SEGMENT;
-        if (has_stream) {
-            if (D.stream_len < 1 || D.stream_len > (1u << 29) || D.stream_off + D.stream_len > stream_bytes)
-                return fail(CAMA_EINVAL, "image %d: segment [%llu, +%u) outside the %llu stream bytes", i,
-                            (unsigned long long)D.stream_off, D.stream_len, (unsigned long long)stream_bytes);
-        } else if (D.stream_len != 0) {
-            return fail(CAMA_EINVAL, "image %d: a pixels-only descriptor carries no stream", i);
-        }
-        cama_jpeg_image W = D;
-        W.clean_off = has_stream ? clean : 0;
-        if (has_stream) clean += align_up((size_t)D.stream_len + 64, 16);   // zero slack after every unstuffed segment
-        W.mx = (D.width + 8 * D.hs - 1) / (8 * D.hs);
-        W.my = (D.height + 8 * D.vs - 1) / (8 * D.vs);
-        W.bpm = D.ncomp == 1 ? 1u : D.hs * D.vs + 2u;
-        const uint64_t blocks = (uint64_t)W.mx * W.my * W.bpm;
-        if (blocks > (1u << 28)) return fail(CAMA_EINVAL, "image %d: too many blocks", i);
-        W.total_blocks = (uint32_t)blocks;
-        const uint32_t nsub = (uint32_t)(((uint64_t)D.stream_len * 8 + JPEG_SUB_BITS - 1) / JPEG_SUB_BITS);
-        W.wg0 = wg;
-        W.nwg = (nsub + JPEG_WG - 1) / JPEG_WG;
-        W.tile0 = tile;
-        W.ntile = (D.stream_len + JPEG_TILE - 1) / JPEG_TILE;
-        if (D.kind == CAMA_JPEG_SEGMENT) {
-            if (D.parent >= (uint32_t)i) return fail(CAMA_EINVAL, "image %d: parent %u must come earlier", i, D.parent);
-            const cama_jpeg_image &P = planned[D.parent];
-            if (P.kind != CAMA_JPEG_PIXELS || P.ncomp != D.ncomp || P.hs != D.hs || P.vs != D.vs || W.my != 1 ||
-                (uint64_t)D.first_block + blocks > P.total_blocks || D.first_block % W.bpm)
-                return fail(CAMA_EINVAL, "image %d: restart segment does not fit its parent %u", i, D.parent);
-            W.coef_off = P.coef_off + (uint64_t)D.first_block * 64;
-            W.out_slot = 0;
-        } else {
-            W.coef_off = coef;
-            coef += (size_t)blocks * 64;
-            W.parent = 0; W.first_block = 0;
-            if (D.out_slot >= (uint32_t)n) return fail(CAMA_EINVAL, "image %d: out_slot %u out of range", i, D.out_slot);
-        }
-        for (uint32_t c = 0; c < 3; ++c) {
-            W.plane_off[c] = 0; W.plane_w[c] = 0; W.plane_h[c] = 0;
-            if (c < D.ncomp && has_pixels) {
-                W.plane_w[c] = W.mx * (c == 0 ? D.hs : 1u) * 8u;
-                W.plane_h[c] = W.my * (c == 0 ? D.vs : 1u) * 8u;
-                W.plane_off[c] = planes;
-                planes += align_up((size_t)W.plane_w[c] * W.plane_h[c], 16);
-            }
-        }
-        wg += W.nwg;
-        tile += W.ntile;
-        if (has_pixels) max_blocks = std::max(max_blocks, W.total_blocks);
-        planned[i] = W;
-        if (write) imgs[i] = W;
-        else if (memcmp(&W, &D, sizeof(W)) != 0)
-            return fail(CAMA_EINVAL, "image %d: descriptor was not produced by cama_jpeg_plan()", i);
-    }
-    L.total_wgs = wg; L.total_tiles = tile; L.max_blocks = max_blocks;
-    L.coef_elems = coef; L.plane_bytes = planes; L.clean_bytes = clean + 64;
-    size_t off = 0;
-    L.clean = off;      off = align_up(off + clean + 64, 256);
-    L.tile_count = off; off = align_up(off + (size_t)tile * 4, 256);
-    L.tile_base = off;  off = align_up(off + (size_t)tile * 4, 256);
-    L.nbits = off;      off = align_up(off + (size_t)n * 4, 256);
-    L.E = off;          off = align_up(off + (size_t)wg * JPEG_WG * 8, 256);
-    L.nb = off;         off = align_up(off + (size_t)wg * JPEG_WG * 4, 256);
-    L.wg_total = off;   off = align_up(off + (size_t)wg * 4, 256);
-    L.coef = off;       off = align_up(off + coef * 2, 256);
-    L.dcd = off;        off = align_up(off + coef / 64 * 2 + 64, 256);
-    L.planes = off;     off = align_up(off + planes, 256);
-    L.total = off;
-    return CAMA_OK;
-}
-
-extern "C" size_t cama_jpeg_image_bytes(void) { return sizeof(cama_jpeg_image); }
-extern "C" size_t cama_jpeg_huff_set_bytes(void) { return sizeof(JpegHuffRec); }
-
-extern "C" int cama_jpeg_plan(cama_jpeg_image *imgs, int32_t n, uint64_t stream_bytes, cama_jpeg_plan_info *info)
-{
-    if (!imgs || !info) return fail(CAMA_EINVAL, "NULL pointer argument");
-    JpegLayout L;
-    if (int rc = jpeg_layout(imgs, imgs, n, stream_bytes, true, L)) return rc;
-    info->scratch_bytes = L.total;
-    info->total_wgs = L.total_wgs;
-    info->total_tiles = L.total_tiles;
-    info->max_blocks = L.max_blocks;
-    info->reserved = 0;
-    return CAMA_OK;
-}
-
-extern "C" int cama_jpeg_find_restarts(const uint8_t *stream, uint64_t stream_bytes, uint32_t *positions,
-                                       uint32_t capacity, uint32_t *count, void *stream_handle)
-{
-    if (!stream || !positions || !count) return fail(CAMA_EINVAL, "NULL pointer argument");
-    if (stream_bytes < 1 || stream_bytes > 0xffffffffull)
-        return fail(CAMA_EINVAL, "stream_bytes=%llu out of range [1, 2^32)", (unsigned long long)stream_bytes);
-    if ((uintptr_t)stream % 16) return fail(CAMA_EINVAL, "stream must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream_handle;
-    HIP_TRY(hipMemsetAsync(count, 0, 4, s));
-    const uint64_t threads = (stream_bytes + 15) / 16;
-    hipLaunchKernelGGL(k_jpeg_find_restarts, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, stream, stream_bytes,
-                       positions, capacity, count);
-    HIP_TRY(hipGetLastError());
-    return CAMA_OK;
-}
-
-#ifdef JPEG_TRACE
-extern "C" int cama_diag_jpeg_trace(uint64_t *clocks, uint32_t *redone)
-{
-    if (hipMemcpyFromSymbol(clocks, HIP_SYMBOL(g_jpeg_trace), sizeof(uint64_t) * 4096 * 16) != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(redone, HIP_SYMBOL(g_jpeg_trace_m), sizeof(uint32_t) * 4096 * 16) != hipSuccess) return -1;
-    return 0;
-}
-#endif
-
-extern "C" int cama_jpeg_decode(const uint8_t *stream, uint64_t stream_bytes, const cama_jpeg_image *imgs,
-                                const cama_jpeg_image *imgs_dev, int32_t n, const void *huff_sets, int32_t n_huff_sets,
-                                const uint16_t *quant_sets, int32_t n_quant_sets, uint8_t *out, uint64_t out_stride,
-                                int32_t bgr, void *scratch, size_t scratch_bytes, int32_t *status, void *stream_handle)
-{
-    if (!stream || !imgs || !imgs_dev || !huff_sets || !quant_sets || !out || !scratch || !status)
-        return fail(CAMA_EINVAL, "NULL pointer argument");
-    JpegLayout L;
-    if (int rc = jpeg_layout(nullptr, imgs, n, stream_bytes, false, L)) return rc;
-    if (scratch_bytes < L.total) return fail(CAMA_EINVAL, "scratch too small: %zu < %zu", scratch_bytes, L.total);
-    uint32_t maxw = 0, maxh = 0;
-    // the pixel stages (IDCT, colour) run over the descriptors that own pixels; restart-interval segments do not, and
-    // there are ~60 of them per image: when they all come after the pixel owners (as cama_amd/jpeg.py lays them out)
-    // the grids stop at the first one instead of launching a million workgroups that return at once
-    int npix = 0;
-    while (npix < n && imgs[npix].kind != CAMA_JPEG_SEGMENT) ++npix;
-    for (int i = npix; i < n; ++i)
-        if (imgs[i].kind != CAMA_JPEG_SEGMENT) { npix = n; break; }
-    for (int i = 0; i < n; ++i) {
-        if ((int32_t)imgs[i].huff_set >= n_huff_sets || (int32_t)imgs[i].quant_set >= n_quant_sets)
-            return fail(CAMA_EINVAL, "image %d: table set index out of range", i);
-        if (imgs[i].kind != CAMA_JPEG_SEGMENT && (uint64_t)imgs[i].width * imgs[i].height * 3 > out_stride)
-            return fail(CAMA_EINVAL, "image %d: %ux%ux3 bytes exceed out_stride %llu", i, imgs[i].width, imgs[i].height,
-                        (unsigned long long)out_stride);
-        if (imgs[i].kind != CAMA_JPEG_SEGMENT) {
-            maxw = std::max(maxw, imgs[i].width);
-            maxh = std::max(maxh, imgs[i].height);
-        }
-    }
-    if ((uintptr_t)scratch % 256 || (uintptr_t)huff_sets % 16)
-        return fail(CAMA_EINVAL, "huff_sets must be 16-byte and scratch 256-byte aligned");
-    hipStream_t s = (hipStream_t)stream_handle;
-    char *base = (char *)scratch;
-    JpegArgs a{};
-    a.stream = stream; a.clean = (uint8_t *)(base + L.clean); a.imgs = imgs_dev; a.n = n;
-    a.huff = (const JpegHuffRec *)huff_sets; a.quant = quant_sets;
-    a.tile_count = (uint32_t *)(base + L.tile_count); a.tile_base = (uint32_t *)(base + L.tile_base);
-    a.nbits = (uint32_t *)(base + L.nbits); a.E = (uint64_t *)(base + L.E); a.nb = (uint32_t *)(base + L.nb);
-    a.wg_total = (uint32_t *)(base + L.wg_total); a.coef = (int16_t *)(base + L.coef); a.dcd = (int16_t *)(base + L.dcd);
-    a.planes = (uint8_t *)(base + L.planes); a.out = out; a.out_stride = (size_t)out_stride; a.bgr = bgr;
-    a.status = status;
-    // one fill in front of the chain: the coefficients (only non-zero ones are stored).  The unstuffed copy's slack is cleared
-    // by k_jpeg_unstuff, the status words by k_jpeg_tilescan, and every block's DC difference is stored by k_jpeg_write.
-    HIP_TRY(hipMemsetAsync(a.coef, 0, L.coef_elems * 2, s));
-    if (L.total_tiles) hipLaunchKernelGGL(k_jpeg_count, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
-    hipLaunchKernelGGL(k_jpeg_tilescan, dim3((unsigned)n), dim3(256), 0, s, a);
-    if (L.total_tiles) hipLaunchKernelGGL(k_jpeg_unstuff, dim3(L.total_tiles), dim3(JPEG_TILE / 4), 0, s, a);
-    if (L.total_wgs) {
-        hipLaunchKernelGGL(k_jpeg_sync<1>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
-        hipLaunchKernelGGL(k_jpeg_sync<2>, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
-        hipLaunchKernelGGL(k_jpeg_write, dim3(L.total_wgs), dim3(JPEG_WG), 0, s, a);
-    }
-    hipLaunchKernelGGL(k_jpeg_dc, dim3((unsigned)n, 3), dim3(JPEG_DC_THREADS), 0, s, a);
-    if (npix) {
-        hipLaunchKernelGGL(k_jpeg_idct, dim3((L.max_blocks + 31) / 32, (unsigned)npix), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_jpeg_colour,
-                           dim3((maxw + 2047) / 2048, (maxh + JPEG_COLOUR_ROWS - 1) / JPEG_COLOUR_ROWS, (unsigned)npix),
-                           dim3(256), 0, s, a);
-    }
-    HIP_TRY(hipGetLastError());
-    return CAMA_OK;
-}
-
-
-// ------------------------------------------------------------------------------------------
-// host-side ingest helper: many files -> caller-provided (pinned) buffers, without the interpreter
-// ------------------------------------------------------------------------------------------
-
-#include <atomic>
-#include <thread>
-#include <fcntl.h>
-#include <unistd.h>
-
-extern "C" {
-
-int cama_read_files(const char *const *paths, void *const *dst, const uint64_t *sizes, int32_t n, int32_t threads,
-                    int32_t *status)
-{
-    if (n < 0 || (n && (!paths || !dst || !sizes || !status))) return fail(CAMA_EINVAL, "NULL pointer argument");
-    if (n == 0) return CAMA_OK;
-    const int workers = std::max(1, std::min<int>(threads, std::min(n, 64)));
-    std::atomic<int> next{0};
-    const auto work = [&]() {
-        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-            status[i] = 1;
-            if (!paths[i] || !dst[i]) continue;
-            const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
-            if (fd < 0) continue;
-            uint64_t got = 0;
-            bool ok = true;
-            while (got < sizes[i]) {
-                const ssize_t k = read(fd, (char *)dst[i] + got, (size_t)(sizes[i] - got));
-                if (k <= 0) { ok = false; break; }
-                got += (uint64_t)k;
-            }
-            if (ok) {                                   // the size came from a directory scan: the file must end here
-                char extra;
-                ok = read(fd, &extra, 1) == 0;
-            }
-            close(fd);
-            status[i] = ok ? 0 : 1;
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < workers; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
     return CAMA_OK;
 }
 

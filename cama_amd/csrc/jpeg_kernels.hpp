@@ -1,5 +1,5 @@
 // Device baseline-JPEG decoder (frame ingest; the reference decodes every frame with cv2.imread =
-// libjpeg(-turbo) on one host core, cama/reproject.py:224,243).  Included by cama_hip.hip inside its anonymous namespace.
+// libjpeg(-turbo) on one host core, cama/reproject.py:224,243).  Included by cama_jpeg.hip inside its anonymous namespace.
 //
 // Bit-exact restatement of libjpeg-turbo's default decode path (JDCT_ISLOW integer IDCT, "fancy" triangle chroma
 // upsampling, 16-bit fixed-point YCbCr->RGB), pinned by oracle/jpeg_oracle.py == Pillow's libjpeg-turbo.
@@ -676,17 +676,6 @@ __device__ __forceinline__ void jpeg_sync_setup(const JpegArgs &a, const cama_jp
     c.adj0 = jpeg_l2_adjust1(G, 0); c.adj1 = jpeg_l2_adjust1(G, 1); c.adj2 = jpeg_l2_adjust1(G, 2); c.adj3 = jpeg_l2_adjust1(G, 3);
 }
 
-#ifdef JPEG_TRACE
-// diagnostic build only (tools/jpeg_phase_clock.sh): per workgroup of k_jpeg_sync<1>, the constant 100 MHz clock at entry, after
-// the setup, after the first decode and after each fixpoint round, and how many subsequences each round re-decoded
-__device__ uint64_t g_jpeg_trace[4096][16];
-__device__ uint32_t g_jpeg_trace_m[4096][16];
-#define JPEG_T(i) do { if (PHASE == 1 && threadIdx.x == 0 && blockIdx.x < 4096 && (i) < 16) g_jpeg_trace[blockIdx.x][(i)] = wall_clock64(); } while (0)
-#define JPEG_M(i, m) do { if (PHASE == 1 && threadIdx.x == 0 && blockIdx.x < 4096 && (i) < 16) g_jpeg_trace_m[blockIdx.x][(i)] = (m); } while (0)
-#else
-#define JPEG_T(i) do { } while (0)
-#define JPEG_M(i, m) do { } while (0)
-#endif
 
 // PHASE 1: speculative decode + fixpoint inside the workgroup.  PHASE 2: fixpoint seeded with the true entry state.
 template <int PHASE>
@@ -703,7 +692,6 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
         return;
     }
     if (PHASE == 2 && lw == 0) return;                                  // its entry state was exact in phase 1
-    JPEG_T(0);
     JpegWgCtx c;
     jpeg_sync_setup(a, D, lw, S, c);                                    // transition tables (state only) + stream words
     const uint32_t nsub_img = (nbits + JPEG_SUB_BITS - 1) / JPEG_SUB_BITS;
@@ -714,7 +702,6 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
     const size_t gsub = (size_t)D.wg0 * JPEG_WG + (size_t)lw * JPEG_WG + threadIdx.x;   // global subsequence slot
     int cur = 0;
     __syncthreads();
-    JPEG_T(1);
     if (PHASE == 1) {
         JpegState s{lo, 0u, 0u};
         uint32_t nb = 0;
@@ -750,7 +737,6 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
     __shared__ uint32_t s_wcount[JPEG_WG / 64];
     for (int round = 0; round < JPEG_WG; ++round) {
         __syncthreads();
-        JPEG_T(2 + round);
         const bool redo = active && threadIdx.x > 0 && S.flag[cur][threadIdx.x - 1];
         const uint64_t start = threadIdx.x > 0 ? S.E[threadIdx.x - 1] : 0ull;
         const uint64_t mask = __ballot(redo);
@@ -764,7 +750,6 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
             before += wv < (int)(threadIdx.x >> 6) ? cnt : 0u;
             m += cnt;
         }
-        JPEG_M(2 + round, m);
         if (m == 0u) break;                                              // uniform
         if (m > JPEG_WAVE_MAX) {
             if (redo) {

@@ -34,6 +34,11 @@ from .pose_transformer import PoseTransformer
 from .reproject import CameraManager, MapManager, colour_id_of, flatten_instances, split_instances
 from .tools import load_json
 
+# Module switches (A/B and test hooks; speed only -- none can change a byte).  They were environment variables until round 5.
+POSE_MEMO = True                     # frame_poses() memoised per (track, stamps); False: seek + slerp + inverse on every call
+LAUNCH_MEMO = True                   # a pipelined render_clip into the same buffers replays its launch list (one library call each)
+MOSAIC_CHUNK_BYTES = 8 << 30         # clips beyond this get a ChunkedMosaic (one pooled buffer per launch) from render_clip(out=None)
+
 try:                                    # progress bar exactly like the reference when tqdm is there
     from tqdm import tqdm as _tqdm
 except ImportError:                     # pragma: no cover
@@ -369,7 +374,7 @@ class ClipManager:
         # (tests/test_host_golden.py).  On launches of 0.1 ms the 0.1 ms of seek + slerp + inverse per step was what paced the
         # host (profiles/r05_960x540_bench.json).  CAMA_NO_POSE_MEMO=1: recompute on every call (A/B).
         memo = self._poses_memo.get(dataset)
-        if memo is not None and memo[0] is track and not os.environ.get("CAMA_NO_POSE_MEMO"):
+        if memo is not None and memo[0] is track and POSE_MEMO:
             return memo[1]
         pt, secs = track
         if len(secs) <= 1:
@@ -452,11 +457,11 @@ class ClipManager:
         (configs["render_ahead"], default 16; 1 = one launch per frame) the first time one of a batch is asked for, and
         the following batch is issued right away so that it runs while this one is consumed.  Same kernels, same
         arguments per frame as a one-frame launch: only the batching differs."""
-        B = max(1, int(self.configs.get("render_ahead", os.environ.get("CAMA_RENDER_AHEAD", 16))))
+        B = max(1, int(self.configs.get("render_ahead", 16)))
         # the FIRST batch of a pass is short (configs["render_ahead_first"], default 4): nothing can be handed to the caller
         # before the first batch's files are read, decoded, rendered and downloaded -- with 16 frames that is ~20 ms of a
         # 40-frame scene's pass (profiles/r05_cold_sweep.txt), with 4 a quarter of it; the pump is decoding the next ones by then
-        B0 = max(1, min(B, int(self.configs.get("render_ahead_first", os.environ.get("CAMA_RENDER_AHEAD_FIRST", 4)))))
+        B0 = max(1, min(B, int(self.configs.get("render_ahead_first", 4))))
         crop = tuple(float(v) for v in np.asarray(self.mm.crop_box()).reshape(-1))
         source = self.frame_source()                # create the (lazy) default source BEFORE it goes into the key
         ins = self.instance_maps[fr.dataset]
@@ -574,7 +579,7 @@ class ClipManager:
         so candidates can be timed against it."""
         F = len(ids)
         per = rig.C * rig.H * rig.W * 3
-        chunk_bytes = int(float(os.environ.get("CAMA_MOSAIC_CHUNK_BYTES", str(8 << 30))))
+        chunk_bytes = int(MOSAIC_CHUNK_BYTES)
         contiguous = ids == list(range(ids[0], ids[0] + F))
         if F * per <= chunk_bytes or step >= F:
             src = src_all.batch(ids) if (probe and contiguous) else None
@@ -642,7 +647,7 @@ class ClipManager:
         # a ChunkedMosaic (one pooled allocation per launch, _pooled_mosaic): launches end at its chunk boundaries
         cuts = sorted(set(getattr(out, "bounds", ())))
         if host_poses and resident and ids == list(range(ids[0], ids[0] + F)) and eng.alpha256 == 256 \
-                and not os.environ.get("CAMA_NO_LAUNCH_MEMO"):
+                and LAUNCH_MEMO:
             memo = self._plan_launches(eng, dataset, dmap, rig, src_all, fused_raw, out, w2c, ids, step, cuts, crop, segments,
                                        frames_per_launch)
             if memo is not None and not resume:

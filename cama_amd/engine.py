@@ -17,8 +17,13 @@ PALETTE_BGR = ((211, 211, 211), (0, 215, 255))                # grey lane_markin
 RADIUS = 2                                                    # cama/reproject.py:256
 # maps with at least this many vertices hand their block index (per-block AABBs) to the render: below, the
 # one-thread-per-block pre-pass costs a launch for nothing.  CAMA_BOUNDS_MIN_VERTS=1 forces it (tests).
-BOUNDS_MIN_VERTS = int(os.environ.get("CAMA_BOUNDS_MIN_VERTS", "65536"))
-PIPELINE_DEPTH = 3 if os.environ.get("CAMA_PIPELINE_DEPTH") == "3" else 2      # scratch slots of a cama_pipeline (cama_hip.hip)
+_HOOKS = _lib.test_hooks()          # CAMA_TEST_HOOKS (the fuzz tests' child processes)
+BOUNDS_MIN_VERTS = int(_HOOKS.get("bounds_min_verts", 65536))   # maps from this size get the per-block spatial index
+PIPELINE_DEPTH = 2                  # scratch slots of a cama_pipeline (cama_hip.hip; three measured the same everywhere, round 5)
+USE_BOUNDS = not _HOOKS.get("no_bounds")    # test hook: no spatial index
+USE_RAW35 = True                    # test hook: False = the general raw-frame kernels instead of the 3:5 one
+PLAN_SITE_MAPS = True               # test hook: False = worst-case scratch for site-sized maps
+SITE_FRAMES_PER_LAUNCH = 128        # frames per launch of site-sized (planned) maps
 MAX_SCENES_PER_LAUNCH = 1024                                  # include/cama_hip.h CAMA_MAX_SCENES_PER_LAUNCH
 
 
@@ -147,7 +152,7 @@ class DeviceMap:
         include/cama_hip.h) + the map's overall XY extent (host), which decides whether the index is worth using."""
         torch = _torch()
         self.bounds, self.extent_xy = None, (0.0, 0.0)
-        if not self.N or os.environ.get("CAMA_NO_BOUNDS"):
+        if not self.N or not USE_BOUNDS:
             return
         if self.N < BOUNDS_MIN_VERTS and not force:
             # the render path asks for N >= BOUNDS_MIN_VERTS before it looks at the index: a clip-sized map (the usual 10^4
@@ -378,6 +383,7 @@ class MosaicPool:
     FLAT_AFTER = 8
     FLAT_RATIO = 1.03
     GOOD_FRAC = 0.805
+    KEEP = 2                            # bases kept per audition (the winner + runners-up within 3 %: a pipelined caller ping-pongs)
 
     def _audition(self, shape, n_keep, time_one, K):
         """Time candidate allocations of `shape` (time_one(tensor) -> ms) under the rules above.
@@ -439,8 +445,7 @@ class MosaicPool:
                 keep = [0]                                            # what a plain allocation would have been
             else:
                 rank = sorted(range(len(cands)), key=lambda i: times[i])
-                keep = [rank[0]] + [i for i in rank[1:max(1, int(os.environ.get("CAMA_POOL_KEEP", "2")))]
-                                    if times[i] <= 1.03 * times[rank[0]]]
+                keep = [rank[0]] + [i for i in rank[1:self.KEEP] if times[i] <= 1.03 * times[rank[0]]]
             self.stats["auditions"] += 1
             self.stats["allocations"] += len(keep)
             self.stats["audition_seconds"] += secs
@@ -481,7 +486,7 @@ class MosaicPool:
             if K > 1 and not self.flat_box and nbytes >= (1 << 29) and all(shapes[k][1:] == big[1:] for k in todo) \
                     and all(srcs[k] is not None and eng._probeable(rig, srcs[k]) for k in todo):
                 free, _ = torch.cuda.mem_get_info(eng.device)
-                P = min(int(os.environ.get("CAMA_AUDITION_POOL", str(max(K // 4, 2) * n))), int(free * 3 // 4 // nbytes))
+                P = min(max(K // 4, 2) * n, int(free * 3 // 4 // nbytes))
             cands, times = [], []
             if P > n:
                 k0 = todo[0]
@@ -969,7 +974,7 @@ class Engine:
             # rational 3:5 scale (the reference default 1600x900 -> 960x540): the library verifies the tap pattern and
             # builds the per-row vertical taps for its gather-free kernel (cama_raw35_plan)
             vrows = None
-            if sep and not os.environ.get("CAMA_NO_RAW35"):
+            if sep and USE_RAW35:
                 Cn, Hd, Wd = len(cm_list), int(cm_list[0].height), int(cm_list[0].width)
                 mxh = np.ascontiguousarray(mx, np.float32)
                 myh = np.ascontiguousarray(my, np.float32)
@@ -1388,14 +1393,14 @@ class Engine:
         if memo_key in memo:                    # (the free-memory probe is a driver call: once per shape is enough)
             return memo[memo_key]
         planned = (self.alpha256 == 256 and dmap.N >= BOUNDS_MIN_VERTS and getattr(dmap, "bounds", None) is not None
-                   and dmap.site_sized(self.crop) and not os.environ.get("CAMA_NO_PLAN"))
+                   and dmap.site_sized(self.crop) and PLAN_SITE_MAPS)
         if planned and resident_frames:
             # site-sized maps are PLANNED (the pipeline sizes its own stamp scratch from what survives the launch's cull:
             # ~1 GB per 167 frames of the 10^6-vertex stress instead of 24 GB), so memory no longer bounds the launch;
             # what does is the overlay's bandwidth, which falls slowly with the bytes a launch walks (40 / 80 / 167 frames
             # of 1600x900: 0.784 / 0.779 / 0.767 of 8 TB/s on never-touched buffers) against one ~12 us kernel boundary per
             # launch.  CAMA_FRAMES_PER_LAUNCH overrides.
-            memo[memo_key] = max(1, int(os.environ.get("CAMA_FRAMES_PER_LAUNCH", "128")))
+            memo[memo_key] = max(1, int(SITE_FRAMES_PER_LAUNCH))
             return memo[memo_key]
         if budget_bytes is None:
             free, _ = _torch().cuda.mem_get_info(self.device)

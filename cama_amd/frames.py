@@ -296,15 +296,15 @@ class ClipFrameSource:
         self._pool = None
         # host decode: 12 threads peak (~500 images/s; the GIL beyond that).  Device decode: the workers only read
         # files, a few are enough (more just burn the container's CPU quota)
-        self._workers = workers or int(os.environ.get("CAMA_READ_WORKERS", 0)) or \
-            (4 if self.decoder == "device" else min(12, (os.cpu_count() or 4)))
+        self._workers = workers or (4 if self.decoder == "device" else min(12, (os.cpu_count() or 4)))
         # planned passes (plan()): a pump thread reads, parses and submits the device decode of the next batches while the
         # consumer renders / encodes the current one
         self._plan = None
-        self._pump_depth = int(os.environ.get("CAMA_DECODE_AHEAD", 3))   # decoded or decoding batches ahead of the consumer
-        self._pump_groups = int(os.environ.get("CAMA_PUMP_GROUPS", 1)) or None   # decode groups per pumped batch (0: the decoder's own rule)
+        self._pump_depth = 3                                             # decoded or decoding batches ahead of the consumer
+        self._pump_groups = 1                                            # decode groups per pumped batch (None: the decoder's own rule)
+        self.use_pump = True                                             # (False: every batch on the unplanned path)
         self._batch_reads = {}                                           # batch key -> future of its file reads
-        self._native_threads = int(os.environ.get("CAMA_READ_THREADS", 8))   # native reader threads per batch
+        self._native_threads = 8                                         # native reader threads per batch
         self._prefetch = prefetch
         self._pending = {}                                            # image index -> list of futures
         self._dir_sizes = {}                                          # directory -> {file name: bytes} (one scan each)
@@ -449,7 +449,7 @@ class ClipFrameSource:
         keys = [tuple(int(i) for i in b) for b in batches if len(b)]
         # batches whose frames are all still cached from an earlier pass never reach the pump (raw_batch serves them first)
         keys = [k for k in keys if self._cache_lookup(list(k), count=False) is None]
-        if self.decoder != "device" or not keys or os.environ.get("CAMA_NO_DECODE_PUMP"):
+        if self.decoder != "device" or not keys or not self.use_pump:
             return
         P = {"keys": keys, "index": {k: j for j, k in enumerate(keys)}, "ready": {}, "consumed": 0,
              "cv": threading.Condition(), "stop": False, "error": None}

@@ -450,8 +450,7 @@ class DeviceJpegDecoder:
         # 37 k, 1 group 33 k (profiles/r02_jpeg_lanes.txt).  `lanes` fixes the number of groups instead (A/B).
         self.lanes = None if lanes is None else int(lanes)
         self.min_group = int(min_group)
-        self.group_wgs = int(os.environ.get("CAMA_JPEG_GROUP_WGS", 0)) or \
-            self.WGS_PER_CU * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
+        self.group_wgs = self.WGS_PER_CU * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
         self.max_lanes = 16
         self._copy_stream = None
         import threading

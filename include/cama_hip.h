@@ -21,8 +21,8 @@
  *     scratch could not be allocated).  cama_last_error() returns a
  *     thread-local message for the most recent failure on the calling thread.
  *   - thread-safety: calls on distinct streams / buffers may run concurrently.  The library keeps three pieces of
- *     process-wide state, none of which can change a result: (i) the tuning options (cama_set_option; atomics, each
- *     initialised once from its environment variable), (ii) the overlay's per-buffer-pair choice between two workgroup
+ *     process-wide state, none of which can change a result: (i) the options (cama_set_option; atomics; no
+ *     environment variables), (ii) the overlay's per-buffer-pair choice between two workgroup
  *     orders (cama_overlay_mapping_info; a table behind a mutex, entries keyed by device and buffer addresses, its
  *     pending timing events are destroyed whether or not their launch succeeded), (iii) per-THREAD profiling state
  *     (cama_profile_*) and the per-thread last-error string.  A cama_pipeline is owned by one thread at a time.

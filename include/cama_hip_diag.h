@@ -5,12 +5,13 @@
  * selects among schedules that are bijections over the same work -- none of it can change a result.  bench.py, tools/ and the
  * test-suite use it; a drop-in user does not have to.
  *
- * Test hooks that are environment variables, read once per process by the library (tests/test_gpu_fuzz.py forces each
- * production code path on inputs that would not select it by themselves):
- *   CAMA_PROJECT_VB=n      vertex blocks per projection workgroup (otherwise 1..8, from the launch's size)
- *   CAMA_NO_CAM_MASK=1     no per-wave camera masks (every camera's chain runs for every wave inside the crop box)
- *   CAMA_NO_CANDIDATES=1   site-sized maps: the one-kernel cull instead of the candidate pre-pass
- *   CAMA_NO_PLAN=1         pipeline-owned scratch sized for the worst case instead of from the cull's demand
+ * Test hooks: ONE environment variable, CAMA_TEST_HOOKS = "name[=value],...", read once per process by the library
+ * (tests/test_gpu_fuzz.py forces each production code path on inputs that would not select it by themselves):
+ *   project_vb=n      vertex blocks per projection workgroup (otherwise 1..8, from the launch's size)
+ *   no_cam_mask       no per-wave camera masks (every camera's chain runs for every wave inside the crop box)
+ *   no_candidates     site-sized maps: the one-kernel cull instead of the candidate pre-pass
+ *   no_plan           pipeline-owned scratch sized for the worst case instead of from the cull's demand
+ *   <option>=v        the start value of an option of cama_set_option (below)
  */
 #ifndef CAMA_HIP_DIAG_H
 #define CAMA_HIP_DIAG_H
@@ -49,27 +50,24 @@ int cama_probe_xcd_map(uint32_t *xcd_of_block, int32_t n_blocks, void *stream);
  * may be NULL.  (No reference counterpart.) */
 int cama_overlay_mapping_info(int32_t *decided, int32_t *samples, double *ns_per_mb);
 
-/* Process-wide tuning options: performance only -- no option can change a result (every one of them selects among orders /
- * schedules that are bijections over the same work; the parity suite runs with each forced).  An option starts from its
- * environment variable, read once, and may be changed at run time; launches already enqueued keep what they were given.
- *   name                  env                      meaning
- *   overlay_chunk_log2    CAMA_OVERLAY_CHUNK_LOG2  -1 = library's choice; 0 = workgroup L renders band L; 1..30 = round-robin
- *                                                  chunks of 2^k bands over the 8 XCDs; 31 = one contiguous range per XCD
- *   overlay_tune          CAMA_OVERLAY_TUNE        0 = big launches keep the contiguous order (no self-timing)
- *   cull_list_min         CAMA_CULL_LIST_MIN       (vertex block, frame) items from which the cull of a site-sized map goes
- *                                                  through work lists + persistent workgroups (default 16384)
- *   bin_priority          CAMA_BIN_PRIORITY        priority of the binning stream of a cama_pipeline created from now on: 2 = highest
- *                                                  (default: its small kernels get wave slots beside the overlay), 1 = the overlay's, 0 = lowest
- *   pipeline_depth        CAMA_PIPELINE_DEPTH      scratch slots of a cama_pipeline created from now on: 2 (default) or 3 (the binning
- *                                                  chain of launch k+2 hides under the overlays of launches k and k+1)
- *   pipeline_host_wait    CAMA_PIPELINE_HOST_WAIT  1 = cama_pipeline_render* waits on the HOST for a launch's binning before it
- *                                                  queues the overlay (the call blocks ~0.1 ms; no barrier packet between
- *                                                  consecutive overlays on the GPU: +1.5 % on the headline); 0 = stream-side
- *                                                  wait; -1 (default) = host wait for plain-overlay launches that move >= 512 MiB
- *   band_rows             (none)                   rows per band of a pipeline's plain single-scene launches: 0 (default) = per launch
- *                                                  -- 8 instead of 4 when the same map's previous launches stamped >= 0.045 band
- *                                                  entries per destination pixel (dense maps: the rasteriser's LDS atomics, not HBM,
- *                                                  bound the overlay there) --, 4 | 8 = forced (the parity suite forces each)
+/* Process-wide options: schedules and orders only -- no option can change a result (every one of them selects among orders /
+ * schedules that are bijections over the same work; the parity suite runs with each forced).  Changed at run time through
+ * this API; launches already enqueued keep what they were given.  No environment variables (round 6: the per-option variables
+ * and the options overlay_tune, bin_priority and pipeline_depth are retired, their A/Bs settled under profiles/).
+ *   name                  meaning
+ *   overlay_chunk_log2    -1 = library's choice (chunks of 32 bands; launches >= 1.75 GiB: whichever of contiguous / chunks the
+ *                         process's own first launches over the buffer pair time faster); 0 = workgroup L renders band L;
+ *                         1..30 = round-robin chunks of 2^k bands over the 8 XCDs; 31 = one contiguous range per XCD
+ *   cull_list_min         (vertex block, frame) items from which the cull of a site-sized map goes through work lists +
+ *                         persistent workgroups (default 16384)
+ *   pipeline_host_wait    1 = cama_pipeline_render* waits on the HOST for a launch's binning before it queues the overlay (the
+ *                         call blocks ~0.1 ms; no barrier packet between consecutive overlays: +1.5 % on the headline);
+ *                         0 = stream-side wait; -1 (default) = host wait for plain-overlay launches that move >= 512 MiB
+ *   band_rows             rows per band of a pipeline's plain single-scene launches: 0 (default) = per launch -- 8 instead of 4
+ *                         when the same map's previous launches stamped >= 0.045 band entries per destination pixel (dense
+ *                         maps: the rasteriser's LDS atomics, not HBM, bound the overlay there) --, 4 | 8 = forced
+ * Test hooks (the parity suite's child processes): CAMA_TEST_HOOKS = "name[=value],..." -- any option above, and no_cam_mask,
+ * no_candidates, no_plan, project_vb=n for the binning chain.
  * Unknown names: CAMA_EINVAL.  (No reference counterpart: the reference has no native code.) */
 int cama_set_option(const char *name, int64_t value);
 int cama_get_option(const char *name, int64_t *value);

@@ -513,8 +513,9 @@ def test_placed_buffers_render_the_same_bytes(monkeypatch):
     grown = torch.cuda.memory_allocated(dev) - mem1
     assert grown < frames2.numel() + mosaic_bytes // 2, (grown, frames2.numel(), mosaic_bytes)
     assert shard.overlay_hash(out2) == golden[1]
-    # chunked: launches of 24 + 16 frames, each into its own pooled allocation (CAMA_MOSAIC_CHUNK_BYTES below the clip's size)
-    monkeypatch.setenv("CAMA_MOSAIC_CHUNK_BYTES", str(1 << 29))
+    # chunked: launches of 24 + 16 frames, each into its own pooled allocation (dataset.MOSAIC_CHUNK_BYTES below the clip's size)
+    from cama_amd import dataset as cama_dataset
+    monkeypatch.setattr(cama_dataset, "MOSAIC_CHUNK_BYTES", 1 << 29)
     _, chunked = cm2.render_clip("cama", frames_per_launch=24, pipelined=True)
     eng.join()
     torch.cuda.synchronize()
@@ -533,7 +534,7 @@ def test_memoised_launch_list_replays_the_same_bytes_and_notices_every_change():
     """Round 5: a pipelined render_clip into the same buffers works out its launches once (Engine.clip_desc + one
     cama_pipeline_render_clip call per launch) and replays them while everything they were derived from is still the very
     same object.  The replay writes the bytes the un-memoised path writes (= the oracle's, golden hashes); a new mosaic, a new
-    frame tensor, a changed crop box, a re-parsed pose track or CAMA_NO_LAUNCH_MEMO each send the next call down the full path."""
+    frame tensor, a changed crop box, a re-parsed pose track or dataset.LAUNCH_MEMO = False each send the next call down the full path."""
     import torch
     from cama_amd import runtime
     from cama_amd.frames import DeviceFrameSource

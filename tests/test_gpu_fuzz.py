@@ -99,16 +99,16 @@ def _fuzz_child(extra_env):
 
 
 def test_fuzz_block_index_and_camera_masks():
-    """Same fuzz in a child process with CAMA_BOUNDS_MIN_VERTS=1: every map hands its block AABBs to the render, so
+    """Same fuzz in a child process with CAMA_TEST_HOOKS bounds_min_verts=1: every map hands its block AABBs to the render, so
     k_block_cameras runs for all of these rigs -- skewed K, projective last rows, flipped depth signs, odd crop boxes --
     and the projection skips cameras / blocks by its masks; the output must not change by a byte."""
-    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_FUZZ_SEED": "4242"})
+    _fuzz_child({"CAMA_TEST_HOOKS": "bounds_min_verts=1", "CAMA_FUZZ_SEED": "4242"})
 
 
 def test_fuzz_work_list_path():
-    """... and with CAMA_CULL_LIST_MIN=1 on top: every site-sized map additionally goes through the work lists and the
+    """... and with cull_list_min=1 on top: every site-sized map additionally goes through the work lists and the
     persistent k_frames_project_list instead of the grid launch."""
-    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "77"})
+    _fuzz_child({"CAMA_TEST_HOOKS": "bounds_min_verts=1,cull_list_min=1", "CAMA_FUZZ_SEED": "77"})
 
 
 def test_fuzz_candidate_prepass_odd_poses():
@@ -116,21 +116,21 @@ def test_fuzz_candidate_prepass_odd_poses():
     world->chassis matrices that stress the inverse it relies on -- full rotations with tilt, survey-grid translations of
     5e6 m, scale + shear, a rank-2 matrix, NaN / inf entries -- and a crop box open to infinity.  Bit-exact against the
     oracle, i.e. the pre-pass never drops a vertex the per-vertex test keeps."""
-    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "505", "CAMA_FUZZ_POSES": "odd",
+    _fuzz_child({"CAMA_TEST_HOOKS": "bounds_min_verts=1,cull_list_min=1", "CAMA_FUZZ_SEED": "505", "CAMA_FUZZ_POSES": "odd",
                  "CAMA_FUZZ_ITERS": "60"})
     # launches of 130 frames: the candidate search runs over three frame chunks (64 + 64 + 2) per box
-    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "506", "CAMA_FUZZ_FRAMES": "130",
+    _fuzz_child({"CAMA_TEST_HOOKS": "bounds_min_verts=1,cull_list_min=1", "CAMA_FUZZ_SEED": "506", "CAMA_FUZZ_FRAMES": "130",
                  "CAMA_FUZZ_ITERS": "8"})
     # and the same cases through the one-kernel pre-pass it replaced (A/B switch): the oracle agrees with both
-    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_CULL_LIST_MIN": "1", "CAMA_FUZZ_SEED": "505", "CAMA_FUZZ_POSES": "odd",
-                 "CAMA_FUZZ_ITERS": "20", "CAMA_NO_CANDIDATES": "1"})
+    _fuzz_child({"CAMA_TEST_HOOKS": "bounds_min_verts=1,cull_list_min=1,no_candidates", "CAMA_FUZZ_SEED": "505", "CAMA_FUZZ_POSES": "odd",
+                 "CAMA_FUZZ_ITERS": "20"})
 
 
 def test_fuzz_several_vertex_blocks_per_workgroup():
-    """... and with CAMA_PROJECT_VB forced: the projection runs 3 (ragged last chunk) / 8 vertex blocks per workgroup as it
+    """... and with project_vb forced: the projection runs 3 (ragged last chunk) / 8 vertex blocks per workgroup as it
     does on launches with >= 16 k (block, frame) items, with the per-wave camera masks and without any."""
-    _fuzz_child({"CAMA_BOUNDS_MIN_VERTS": "1", "CAMA_PROJECT_VB": "3", "CAMA_FUZZ_SEED": "31"})
-    _fuzz_child({"CAMA_NO_BOUNDS": "1", "CAMA_PROJECT_VB": "8", "CAMA_FUZZ_SEED": "32"})
+    _fuzz_child({"CAMA_TEST_HOOKS": "bounds_min_verts=1,project_vb=3", "CAMA_FUZZ_SEED": "31"})
+    _fuzz_child({"CAMA_TEST_HOOKS": "no_bounds,project_vb=8", "CAMA_FUZZ_SEED": "32"})
 
 
 def test_fuzz_against_oracle():

@@ -584,7 +584,7 @@ def test_every_workgroup_to_band_mapping_renders_the_same_bytes(chunk_log2, repo
     import sys
     # (round 4's further orders -- stagger, translation look-ahead, XCD groups, band-innermost items -- measured never better and
     # were removed in round 5)
-    env = dict(os.environ, CAMA_OVERLAY_CHUNK_LOG2=chunk_log2)
+    env = dict(os.environ, CAMA_TEST_HOOKS="overlay_chunk_log2=%s" % chunk_log2)
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "tests/test_gpu_kernels.py", "tests/test_gpu_dropin.py",
                         "-k", "byte_identical_to_oracle or radius_variants or other_camera_counts or last_writer or "

@@ -318,7 +318,8 @@ def test_video_generator_sink_and_i420_stream(tmp_path):
 
 def test_frame_poses_are_memoised_per_track_bit_identically(tmp_path, monkeypatch):
     """ClipManager.frame_poses(dataset) is a pure function of the clip's pose track and frame stamps, both parsed once: the
-    second call returns the SAME (read-only) arrays, and they equal the recomputation (CAMA_NO_POSE_MEMO=1) bit for bit."""
+    second call returns the SAME (read-only) arrays, and they equal the recomputation (dataset.POSE_MEMO = False) bit for bit."""
+    from cama_amd import dataset as cama_dataset
     from cama_amd.dataset import ClipManager
     g = load_golden("c_gaps")
     clip = rebuild_clip(g, tmp_path)
@@ -327,9 +328,9 @@ def test_frame_poses_are_memoised_per_track_bit_identically(tmp_path, monkeypatc
         a = cm.frame_poses(ds)
         b = cm.frame_poses(ds)
         assert a[0] is b[0] and a[1] is b[1] and not a[1].flags.writeable and a[1].dtype == np.float32
-        monkeypatch.setenv("CAMA_NO_POSE_MEMO", "1")
+        monkeypatch.setattr(cama_dataset, "POSE_MEMO", False)
         c = cm.frame_poses(ds)
-        monkeypatch.delenv("CAMA_NO_POSE_MEMO")
+        monkeypatch.setattr(cama_dataset, "POSE_MEMO", True)
         assert c[1] is not a[1] and np.array_equal(c[0], a[0]) and c[1].tobytes() == a[1].tobytes()
         assert a[0].tolist() == g[f"{ds}_frame_ids"].tolist()
         # a re-parsed track (new objects) invalidates the memo

@@ -83,7 +83,7 @@ L.cama_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(i64)]
 L.cama_overlay_mapping_info.argtypes = [ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double)]
 assert L.cama_set_option(b"no_such_option", 1) == -1 and b"unknown option" in L.cama_last_error()
 assert L.cama_set_option(None, 1) == -1
-names = [b"overlay_chunk_log2", b"overlay_tune", b"cull_list_min", b"bin_priority", b"pipeline_depth", b"pipeline_host_wait"]
+names = [b"overlay_chunk_log2", b"cull_list_min", b"pipeline_host_wait", b"band_rows"]
 errors = []
 def hammer(seed):
     try:
@@ -101,7 +101,7 @@ ths = [threading.Thread(target=hammer, args=(s,)) for s in range(4)]
 [t.start() for t in ths]
 [t.join() for t in ths]
 assert not errors, errors
-for name, dflt in zip(names, (-1, 1, 0, -1, 0, 0, 16384)):
+for name, dflt in zip(names, (-1, 16384, -1, 0)):
     assert L.cama_set_option(name, dflt) == 0
 print("sanitizer driver ok")
 '''
@@ -116,7 +116,8 @@ def test_host_code_under_asan_ubsan(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                            "-I" + os.path.join(REPO, "include"), "-fsanitize=address,undefined", "-fno-gpu-sanitize",
                            "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
-                           os.path.join(REPO, "cama_amd", "csrc", "cama_hip.hip"), "-o", so], stderr=subprocess.DEVNULL)
+                           os.path.join(REPO, "cama_amd", "csrc", "cama_hip.hip"),
+                           os.path.join(REPO, "cama_amd", "csrc", "cama_jpeg.hip"), "-o", so], stderr=subprocess.DEVNULL)
     env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     p = subprocess.run([sys.executable, "-c", DRIVER, so], env=env, capture_output=True, text=True, timeout=600)

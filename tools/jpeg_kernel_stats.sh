@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 R=$PWD
 o=$R/gpurun_out/jpeg_stats
-[ -n "${1:-}" ] && export CAMA_HIP_LIB=$R/$1
+[ -n "${1:-}" ] && export CAMA_ALLOW_LIB_OVERRIDE=1 CAMA_HIP_LIB=$R/$1
 (cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $o -o j -- python $R/tools/jpeg_probe.py --batch 240 --reps 5 > $o.log 2>&1)
 python - $o <<'PY'
 import csv, glob, sys
