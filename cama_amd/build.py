@@ -5,9 +5,9 @@ from os.path import abspath, dirname, exists, getmtime, join
 
 _HERE = dirname(abspath(__file__))
 REPO = dirname(_HERE)
-SOURCES = [join(_HERE, "csrc", "cama_hip.hip"), join(_HERE, "csrc", "cama_jpeg.hip")]
+SOURCES = [join(_HERE, "csrc", n) for n in ("cama_hip.hip", "cama_pipeline.hip", "cama_jpeg.hip")]
 DEVICE_HEADERS = [join(_HERE, "csrc", n) for n in ("project_kernels.hpp", "remap_device.hpp", "overlay_kernels.hpp",
-                                                    "resample_kernels.hpp", "map_kernels.hpp", "jpeg_kernels.hpp", "raw35_kernels.hpp", "egress_kernels.hpp", "cama_common.hpp")]
+                                                    "resample_kernels.hpp", "map_kernels.hpp", "jpeg_kernels.hpp", "raw35_kernels.hpp", "egress_kernels.hpp", "cama_common.hpp", "cama_internal.hpp")]
 HEADER = join(REPO, "include", "cama_hip.h")
 OUT = join(_HERE, "libcama_hip.so")
 # -ffp-contract=off: the fp64 FMA chains are written explicitly; nothing else may be fused

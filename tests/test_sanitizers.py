@@ -117,6 +117,7 @@ def test_host_code_under_asan_ubsan(tmp_path):
                            "-I" + os.path.join(REPO, "include"), "-fsanitize=address,undefined", "-fno-gpu-sanitize",
                            "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
                            os.path.join(REPO, "cama_amd", "csrc", "cama_hip.hip"),
+                           os.path.join(REPO, "cama_amd", "csrc", "cama_pipeline.hip"),
                            os.path.join(REPO, "cama_amd", "csrc", "cama_jpeg.hip"), "-o", so], stderr=subprocess.DEVNULL)
     env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")

@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 R=$PWD
 o=$R/gpurun_out/jpeg_stats
 [ -n "${1:-}" ] && export CAMA_ALLOW_LIB_OVERRIDE=1 CAMA_HIP_LIB=$R/$1
-(cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $o -o j -- python $R/tools/jpeg_probe.py --batch 240 --reps 5 > $o.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $o -o j -- python $R/tools/jpeg_probe.py --batch 240 --reps 5 --sets ${JPEG_SETS:-noise,photo} > $o.log 2>&1)
 python - $o <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]

@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VA
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS"; do
   i=$((i+1))
-  (cd /tmp && timeout 300 rocprofv3 --output-format csv --kernel-trace --pmc $set -d $o/p$i -o c -- python $R/tools/jpeg_probe.py --batch 240 --reps 1 > $o/p$i.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --output-format csv --kernel-trace --pmc $set -d $o/p$i -o c -- python $R/tools/jpeg_probe.py --batch 240 --reps 1 --sets ${JPEG_SETS:-photo} > $o/p$i.log 2>&1)
 done
 python - $o <<'PY'
 import csv, glob, sys, collections
