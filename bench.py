@@ -958,14 +958,14 @@ def plan(args):
         # before the timed region: candidate allocations of one mosaic / frames buffer at a time (cama_amd.engine.MosaicPool, capped by
         # the engine at half of what is free, so it cannot be what does not fit)
         one = min(F, fpl) * frame_b if ranges[r] is not None else F * frame_b
-        # (one buffer: 16 candidates; the mosaics of a multi-scene chain / the launches of a long clip: one pool of 6 per buffer,
-        # of which the kept ones are already counted above)
+        # (one buffer: <= 16 candidates; the mosaics of a multi-scene chain / the launches of a long clip: the buffers themselves,
+        # counted above, + <= 16 spare candidates)
         n_buf = len(mine) if (ranges[r] is None and batched) else (-(-F // fpl) if ranges[r] is not None and F * frame_b > (8 << 30) else 1)
         K_aud = 16 if args.audition is None else args.audition
         # one mosaic: at most K candidates (capped at half of what is free) and then K/2 candidates of the (F + 1)-frame source; several mosaics: ONE pool of max(K/4, 2) per buffer, the kept ones counted above
         # (round 6: candidates are timed four at a time and the audition stops at the first fast one / after eight alike: these are
         # upper bounds)
-        cands = (K_aud + K_aud // 2) if n_buf == 1 else max(K_aud // 4, 2) * n_buf - n_buf
+        cands = (K_aud + K_aud // 2) if n_buf == 1 else K_aud
         rec["placement_transient_bytes"] = 0 if (args.audition == 0 or args.raw_frames) else cands * one
         # while the engine auditions (Job.allocate, at most 4 ranks of the node at a time): the resident frames and maps + the
         # candidates; the engine itself never takes more than half (one mosaic) / three quarters (a pool) of what is free

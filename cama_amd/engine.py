@@ -486,7 +486,9 @@ class MosaicPool:
             if K > 1 and not self.flat_box and nbytes >= (1 << 29) and all(shapes[k][1:] == big[1:] for k in todo) \
                     and all(srcs[k] is not None and eng._probeable(rig, srcs[k]) for k in todo):
                 free, _ = torch.cuda.mem_get_info(eng.device)
-                P = min(max(K // 4, 2) * n, int(free * 3 // 4 // nbytes))
+                # n buffers are needed anyway; beyond them at most K spare candidates (round 6: a pool of 4 per buffer timed 164
+                # candidates = 170 GB of transient allocations for the 73-scene sweep on one GPU)
+                P = min(n + K, int(free * 3 // 4 // nbytes))
             cands, times = [], []
             if P > n:
                 k0 = todo[0]

@@ -25,7 +25,8 @@ def test_plan_of_the_8_gpu_job_fits_and_covers_every_scene():
         assert r["fits"] and r["total_bytes"] < 0.92 * d["hbm_bytes_per_gpu"]
         assert r["resident_frames_bytes"] == len(r["scenes"]) * 41 * 6 * 900 * 1600 * 3
         # the placement auditions' transient candidates are part of the plan and fit beside the frames
-        assert r["placement_transient_bytes"] == (16 // 4) * len(r["scenes"]) * 40 * 6 * 900 * 1600 * 3 - len(r["scenes"]) * 40 * 6 * 900 * 1600 * 3
+        # (round 6: the buffers themselves + at most 16 spare candidates, whatever the number of scenes)
+        assert r["placement_transient_bytes"] == 16 * 40 * 6 * 900 * 1600 * 3
         assert r["peak_bytes_during_placement"] <= r["total_bytes"] < 0.92 * d["hbm_bytes_per_gpu"]
         st = r["stress"]                                                   # the nested configs[4] measurement
         assert st["frame_range"][1] - st["frame_range"][0] == 125

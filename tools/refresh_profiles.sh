@@ -1,10 +1,10 @@
 #!/bin/bash
 # Everything under profiles/<tag>_* that comes from bench.py, in one gpurun call (from the repo root, on the GPU box):
 #   gpurun --timeout 3000 -- 'tools/refresh_profiles.sh r03'
-# then, in the build container:  for n in headline site1e6 random1e6 stress raw35 scenes73 sites3x12; do python tools/collect_profiles.py r05 $n; done
+# then, in the build container:  for n in headline site1e6 random1e6 stress raw35 scenes73 sites3x12; do python tools/collect_profiles.py r06 $n; done
 # and copy gpurun_out/<tag>_*_bench.json of the plain lines into profiles/.
 set -u
-tag=${1:-r05}
+tag=${1:-r06}
 ulimit -c 0
 tools/profile_workload.sh $tag headline "N=10000" --steps 20 --warmup 5 > /dev/null
 tools/profile_workload.sh $tag site1e6 "N=1000000 MAP=site" --map site --verts 1000000 --steps 30 --warmup 5 > /dev/null
@@ -31,6 +31,8 @@ grep -h "^{" gpurun_out/${tag}_cold_final.txt gpurun_out/${tag}_cold_final_nocac
 # the device JPEG decoder: per-kernel time of a 240-image batch, the decoder-alone rate with the package's eight hardware queues and
 # with the HIP runtime's four, and the verbatim main.py loop (bgr24 sink) with and without the decoded-frame cache
 bash tools/jpeg_kernel_stats.sh > gpurun_out/${tag}_jpeg_kernel_stats.txt 2>&1
+JPEG_SETS=photo bash tools/jpeg_kernel_stats.sh > gpurun_out/${tag}_jpeg_kernel_stats_photo.txt 2>&1
+JPEG_SETS=photo bash tools/jpeg_pmc.sh ${tag}_jpmc_photo > gpurun_out/${tag}_jpeg_pmc_photo.txt 2>&1
 python tools/jpeg_probe.py --batch 240 --reps 5 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_jpeg_probe.txt
 GPU_MAX_HW_QUEUES=4 python tools/jpeg_probe.py --batch 240 --reps 5 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_jpeg_probe_4queues.txt
 CAMA_VIDEO_SINK=null timeout 300 python tools/demo_loop_probe.py --frames 240 --passes 6 2>&1 | grep "main.py loop\|steady state over" > gpurun_out/${tag}_demo_loop.txt
