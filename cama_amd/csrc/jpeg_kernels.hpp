@@ -32,6 +32,9 @@ constexpr int JPEG_SUB_BITS = JPEG_SUB_WORDS * 32;
 #endif
 constexpr int JPEG_WG = JPEG_WG_N;                 // subsequences (threads) per workgroup
 constexpr int JPEG_TILE = 1024;                    // unstuff tile, bytes (4 per thread)
+#ifndef JPEG_SPEC_SKIP
+#define JPEG_SPEC_SKIP 0
+#endif
 constexpr int JPEG_LUT_BITS = 10;
 constexpr int JPEG_L2_MAX = 1024;                  // second-level entries per table set (the standard tables need 674)
 constexpr uint32_t JPEG_L2_NONE = 0xffffu;
@@ -703,7 +706,8 @@ __global__ __launch_bounds__(JPEG_WG) void k_jpeg_sync(JpegArgs a)
     int cur = 0;
     __syncthreads();
     if (PHASE == 1) {
-        JpegState s{lo, 0u, 0u};
+        // (thread 0's decode is never repeated in this phase -- for the image's first workgroup it IS the true start)
+        JpegState s{threadIdx.x ? min(lo + (uint32_t)JPEG_SPEC_SKIP, hi) : lo, 0u, 0u};
         uint32_t nb = 0;
         if (active) nb = jpeg_sync_span(c, s, hi);
         S.E[threadIdx.x] = jpeg_pack(s);

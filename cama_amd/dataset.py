@@ -372,7 +372,7 @@ class ClipManager:
         # memoised per (track, stamps): both are parsed from the clip's files once and never change afterwards, so neither does
         # this function of them -- the same arrays come back (read-only), bit for bit what the recomputation gives
         # (tests/test_host_golden.py).  On launches of 0.1 ms the 0.1 ms of seek + slerp + inverse per step was what paced the
-        # host (profiles/r05_960x540_bench.json).  CAMA_NO_POSE_MEMO=1: recompute on every call (A/B).
+        # host (profiles/r05_960x540_bench.json).  POSE_MEMO = False (module switch): recompute on every call (A/B).
         memo = self._poses_memo.get(dataset)
         if memo is not None and memo[0] is track and POSE_MEMO:
             return memo[1]
@@ -574,7 +574,7 @@ class ClipManager:
 
     def _pooled_mosaic(self, eng, rig, src_all, ids, step, probe):
         """The mosaic of a whole-clip render the caller did not bring: views of the engine's pooled, placed buffers
-        (Engine.pool) -- one tensor, or, for clips beyond CAMA_MOSAIC_CHUNK_BYTES (8 GiB), a ChunkedMosaic of one buffer per
+        (Engine.pool) -- one tensor, or, for clips beyond MOSAIC_CHUNK_BYTES (8 GiB), a ChunkedMosaic of one buffer per
         launch (each launch's destination is then placed on its own).  `probe`: the source is HBM-resident at output size,
         so candidates can be timed against it."""
         F = len(ids)

@@ -16,7 +16,7 @@ CROP_BOX = (-50.0, 50.0, -100.0, 100.0, -200.0, 200.0)        # cama/reproject.p
 PALETTE_BGR = ((211, 211, 211), (0, 215, 255))                # grey lane_marking, gold everything else
 RADIUS = 2                                                    # cama/reproject.py:256
 # maps with at least this many vertices hand their block index (per-block AABBs) to the render: below, the
-# one-thread-per-block pre-pass costs a launch for nothing.  CAMA_BOUNDS_MIN_VERTS=1 forces it (tests).
+# one-thread-per-block pre-pass costs a launch for nothing.  CAMA_TEST_HOOKS=bounds_min_verts=1 forces it (tests).
 _HOOKS = _lib.test_hooks()          # CAMA_TEST_HOOKS (the fuzz tests' child processes)
 BOUNDS_MIN_VERTS = int(_HOOKS.get("bounds_min_verts", 65536))   # maps from this size get the per-block spatial index
 PIPELINE_DEPTH = 2                  # scratch slots of a cama_pipeline (cama_hip.hip; three measured the same everywhere, round 5)
@@ -263,7 +263,10 @@ class ChunkedMosaic:
 def _storage_users(t):
     """How many tensors / storages reference `t`'s memory besides the temporary this call creates."""
     import torch
-    return torch._C._storage_Use_Count(t.untyped_storage()._cdata) - 1
+    fn = getattr(torch._C, "_storage_Use_Count", None)
+    if fn is None:
+        return 1 << 30          # (a torch without the private counter: no base ever looks idle -- plain allocations, no recycling)
+    return fn(t.untyped_storage()._cdata) - 1
 
 
 class MosaicPool:
@@ -280,7 +283,7 @@ class MosaicPool:
     (profiles/r04_overlay_modes.txt section 5: 0.85 against 0.77 of 8 TB/s, the same buffers every time).  A NEW base of
     512 MiB .. 8 GiB whose source can be probed is therefore the fastest of CAMA_AUDITION (16) candidate allocations,
     timed with stamp-free overlay launches from that source (Engine._overlay_ms); runners-up within 3 % of the winner
-    stay in the pool as idle bases (CAMA_POOL_KEEP, default 2 per audition: a pipelined caller ping-pongs between two
+    stay in the pool as idle bases (KEEP = 2 per audition: a pipelined caller ping-pongs between two
     buffers), the others go back to torch's allocator.  Paid once per shape per process.  CAMA_AUDITION=0: plain
     allocations, still pooled.  Speed only -- no option here can change a byte."""
 
@@ -1367,6 +1370,11 @@ class Engine:
             _lib.check(self.lib.cama_pipeline_join(self._pipe["handle"], self._stream()))
             self._release_completed(self._pipe)
             cur = torch.cuda.current_stream(self.device)
+            # the consumer reads its mosaics on THIS stream from here on: a base that is re-lent later under another stream must
+            # be ordered behind it (MosaicPool._lend waits for an event of the stream noted here)
+            for b in self.pool.bases:
+                if b["stream"] is not None and not self.pool.idle(b):
+                    b["stream"] = cur
             for _, T, src, out, dmap, rig, extra in self._pipe["keep"]:
                 for t in (T, src, out, dmap.soa, dmap.colour, dmap.sorted_soa, dmap.sorted_key,
                           dmap.__dict__.get("_bounds"), rig.c2cam, rig.K) + tuple(extra):        # (never the lazy property)
@@ -1401,7 +1409,7 @@ class Engine:
             # ~1 GB per 167 frames of the 10^6-vertex stress instead of 24 GB), so memory no longer bounds the launch;
             # what does is the overlay's bandwidth, which falls slowly with the bytes a launch walks (40 / 80 / 167 frames
             # of 1600x900: 0.784 / 0.779 / 0.767 of 8 TB/s on never-touched buffers) against one ~12 us kernel boundary per
-            # launch.  CAMA_FRAMES_PER_LAUNCH overrides.
+            # launch.  engine.SITE_FRAMES_PER_LAUNCH overrides.
             memo[memo_key] = max(1, int(SITE_FRAMES_PER_LAUNCH))
             return memo[memo_key]
         if budget_bytes is None:
