@@ -122,22 +122,20 @@ class PoseEvaluator():
 
     def umeyama_alignment(self, x, y, with_scale=False):
         """Least-squares Sim(m) fit y ~ c r x + t (Umeyama 1991; pose_evaluator.py:106-154).  x, y: (m,n)."""
-        if x.shape != y.shape:
-            assert False, "x.shape not equal to y.shape"
-        m, n = x.shape
-        mean_x = x.mean(axis=1)
-        mean_y = y.mean(axis=1)
-        xc = x - mean_x[:, np.newaxis]
-        sigma_x = 1.0 / n * (np.linalg.norm(xc)**2)
-        cov_xy = np.multiply(1.0 / n, (y - mean_y[:, np.newaxis]) @ xc.T)
-        u, d, v = np.linalg.svd(cov_xy)
-        s = np.eye(m)
-        if np.linalg.det(u) * np.linalg.det(v) < 0.0:
-            s[m - 1, m - 1] = -1            # keep a right-handed frame
-        r = u.dot(s).dot(v)
-        c = 1 / sigma_x * np.trace(np.diag(d).dot(s)) if with_scale else 1.0
-        t = mean_y - np.multiply(c, r.dot(mean_x))
-        return r, t, c
+        assert x.shape == y.shape, "x.shape not equal to y.shape"
+        dim, count = x.shape
+        centre_x, centre_y = x.mean(axis=1), y.mean(axis=1)
+        dx = x - centre_x[:, np.newaxis]
+        var_x = 1.0 / count * (np.linalg.norm(dx)**2)
+        cross = np.multiply(1.0 / count, (y - centre_y[:, np.newaxis]) @ dx.T)
+        left, singular, right_t = np.linalg.svd(cross)
+        handed = np.eye(dim)
+        if np.linalg.det(left) * np.linalg.det(right_t) < 0.0:
+            handed[dim - 1, dim - 1] = -1        # a reflection would fit better: keep a right-handed frame
+        rotation = left.dot(handed).dot(right_t)
+        scale = 1 / var_x * np.trace(np.diag(singular).dot(handed)) if with_scale else 1.0
+        shift = centre_y - np.multiply(scale, rotation.dot(centre_x))
+        return rotation, shift, scale
 
     def array2dict(self, array):
         return {line[0]: line[1:] for line in array}

@@ -116,6 +116,8 @@ def test_bench_default_line_has_every_contract_field():
     ing = line["ingest"]
     assert ing["byte_equal_to_host_decoder"] is True and ing["value"] > 1000 and ing["bytes_out_per_image"] == 1600 * 900 * 3
     assert ing["decoder_stats"]["host_unsupported"] == 0 and ing["decoder_stats"]["host_flagged"] == 0
+    fl = ing["images_per_s_by_batches_in_flight"]                      # one, two, three batches at once (the pump's steady state)
+    assert set(fl) == {"1", "2", "3"} and min(fl.values()) > 1000
     assert rd["leg_seconds"] + ing["leg_seconds"] < 12.0
 
 
