@@ -174,6 +174,30 @@ def test_audition_stops_as_soon_as_it_knows():
     assert pool.stats["auditions"] == 0 and pool.stats["allocations"] == 1 and tuple(t.shape) == shape
 
 
+def test_replaying_a_memoised_launch_list_survives_out_of_memory():
+    """a CAMA_ENOMEM from the library inside the memoised replay (torch.OutOfMemoryError) must not escape
+    render_clip: the memo is dropped, the engine's frames-per-call budget shrunk, and the number of frames already issued
+    comes back so that the halving loop carries on from there."""
+    import types
+    import torch
+    from cama_amd.dataset import ClipManager
+    calls, shrunk = [], []
+
+    def launch(desc, w2c_ptr, F, src_ptr, out_ptr, keep):
+        if len(calls) == 2:
+            raise torch.OutOfMemoryError("libcama_hip error -3: hipMalloc of pipeline scratch")
+        calls.append(F)
+    eng = types.SimpleNamespace(render_clip_launch=launch, shrink_frames_per_call=lambda: shrunk.append(1))
+    cm = ClipManager.__new__(ClipManager)
+    memo = {"desc": object(), "launches": [(0, 16, 0, 0, ()), (64 * 16, 16, 0, 0, ()), (64 * 32, 8, 0, 0, ())]}
+    cm._launch_memo = {"cama": memo}
+    assert cm._replay_launches(eng, "cama", memo) == 32 and calls == [16, 16] and shrunk == [1] and "cama" not in cm._launch_memo
+    calls.clear()
+    eng.render_clip_launch = lambda desc, w, F, s, o, k: calls.append(F)
+    cm._launch_memo = {"cama": memo}
+    assert cm._replay_launches(eng, "cama", memo) is None and calls == [16, 16, 8] and "cama" in cm._launch_memo
+
+
 def test_rank_cpu_sets_are_disjoint_and_follow_the_gpus_numa_nodes():
     """one process per GPU, each pinned to cores of its GPU's NUMA node."""
     from cama_amd import shard
