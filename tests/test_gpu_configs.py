@@ -565,6 +565,22 @@ def test_memoised_launch_list_replays_the_same_bytes_and_notices_every_change():
         memo = cm._launch_memo["cama"]
         step(frames_per_launch=5)
         assert cm._launch_memo["cama"] is memo
+        # out of memory inside the replay (the library could not grow its scratch): the launches already issued stay, the rest
+        # goes through the general path, the bytes are the same and the memo is gone
+        n_before = len(calls)
+        ok_launch = eng.render_clip_launch
+
+        def failing(*args):
+            if len(calls) - n_before == 1:
+                eng.render_clip_launch = ok_launch
+                raise torch.OutOfMemoryError("simulated CAMA_ENOMEM")
+            return ok_launch(*args)
+        eng.render_clip_launch = failing
+        step(frames_per_launch=5)
+        eng.render_clip_launch = ok_launch
+        assert calls[n_before:n_before + 1] == [5]
+        step(frames_per_launch=5)                                             # planned again, replayable again
+        memo = cm._launch_memo["cama"]
         other = torch.empty_like(want)
         step(other, frames_per_launch=5)                                      # another mosaic
         assert cm._launch_memo["cama"]["out"] is other
