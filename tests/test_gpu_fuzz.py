@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def _case(rng):
     from scipy.spatial.transform import Rotation
-    W = int(rng.choice([16, 48, 64, 100, 160, 272, 333, 640]))
+    W = int(rng.choice([640, 960, 640, 160, 333] if os.environ.get("CAMA_FUZZ_WIDE") else [16, 48, 64, 100, 160, 272, 333, 640]))
     H = int(rng.integers(9, 150))
     C = int(rng.integers(1, 10))
     F = int(os.environ.get("CAMA_FUZZ_FRAMES", 0)) or int(rng.integers(1, 4))
@@ -133,6 +133,15 @@ def test_fuzz_several_vertex_blocks_per_workgroup():
     _fuzz_child({"CAMA_TEST_HOOKS": "no_bounds,project_vb=8", "CAMA_FUZZ_SEED": "32"})
 
 
+def test_fuzz_through_the_pipeline_with_both_band_heights():
+    """The same fuzz through cama_pipeline_render (pipeline-owned scratch, planned launches for the site-sized maps) -- what the
+    product runs -- once with the pipeline's own band height and once with 8-row bands forced (they apply from W >= 600: the
+    W = 640 / 960 cases)."""
+    _fuzz_child({"CAMA_FUZZ_PIPELINED": "1", "CAMA_FUZZ_WIDE": "1", "CAMA_TEST_HOOKS": "bounds_min_verts=1", "CAMA_FUZZ_SEED": "611"})
+    _fuzz_child({"CAMA_FUZZ_PIPELINED": "1", "CAMA_FUZZ_WIDE": "1", "CAMA_TEST_HOOKS": "bounds_min_verts=1,band_rows=8,cull_list_min=1",
+                 "CAMA_FUZZ_SEED": "612"})
+
+
 def test_fuzz_against_oracle():
     import torch
     from cama_amd.engine import Engine
@@ -149,7 +158,15 @@ def test_fuzz_against_oracle():
         band = e.lib.cama_overlay_band_rows(c["W"])
         if 2 * c["radius"] > band:
             continue
-        out = e.render_frames(dmap, rig, c["w2c"], torch.from_numpy(src).cuda(), crop=c["crop"]).cpu().numpy()
+        if os.environ.get("CAMA_FUZZ_PIPELINED"):
+            # the product's path: the pipeline (its own demand-sized scratch, planned launches, band height per launch)
+            dev_out = torch.full(e.mosaic_shape(rig, c["F"]), 0xA5, dtype=torch.uint8, device="cuda:0")
+            e.render_frames_pipelined(dmap, rig, c["w2c"], torch.from_numpy(src).cuda(), dev_out, crop=c["crop"])
+            e.join()
+            torch.cuda.synchronize()
+            out = dev_out.cpu().numpy()
+        else:
+            out = e.render_frames(dmap, rig, c["w2c"], torch.from_numpy(src).cuda(), crop=c["crop"]).cpu().numpy()
         vu, vis, _ = (t.cpu().numpy() for t in e.project_frames(dmap, rig, c["w2c"], crop=c["crop"]))
         tag = {k: c[k] for k in ("W", "H", "C", "F", "N", "radius", "sort", "kind")}
         for f in range(c["F"]):
